@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""Headline benchmark: 512-res try-on images/s through the SynthesisNetwork forward
+(BASELINE.json config 2: SynthesisNetworkFull_v18, 512^2, N=8 per GPU, fp32, eval,
+random latents + style maps, noise_mode='const', argmax parsing path as test.py runs it).
+
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 is launched by the driver through torch.distributed.run, one rank per GPU; every rank
+runs the same workload on its own batch (independent images, no data-path collective:
+"weak" scaling); RCCL is used only for the barrier and the max-over-ranks
+of the timed region.  Rank 0 prints ONE JSON line.
+
+Extra objects on that line:
+  roofline     -- dominant kernel = conv2d_mfma<3,3,1> (the 3x3 implicit-GEMM conv, 96 % of the
+                  FLOPs): sum of algorithmic FLOPs of its launches in the timed region / sum of
+                  their durations measured with HIP events on the launch stream, vs 157.3 TFLOP/s.
+  cpu_baseline -- the CPU oracle (oracle/network_ref.py, a port) timed on this host at N=1 on a
+                  bounded sample (rank 0, --gpus 1 only).
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, 'pasta-gan-plusplus_amd'))
+sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+CFG2 = dict(w_dim=512, img_resolution=512, img_channels=3, channel_base=32768, channel_max=512, conv_clamp=256)
+BATCH_PER_GPU = 8
+GFLOP_PER_IMAGE = 962.2          # SURVEY.md section 8d (conv FLOPs of one 512^2 image)
+F32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+
+
+def make_inputs(n, device, seed):
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    r = lambda *s: torch.randn(*s, generator=g)
+    inp = dict(
+        ws=r(n, 14, 512), pose_feat=r(n, 512, 8, 8),
+        cat_feat={str(k): r(n, 64, k, k) for k in (512, 256, 128, 64)},
+        du=torch.rand(n, 3, 512, 512, generator=g) * 2 - 1, dl=torch.rand(n, 3, 512, 512, generator=g) * 2 - 1,
+        mu=(torch.rand(n, 1, 512, 512, generator=g) > 0.5).float(), ml=(torch.rand(n, 1, 512, 512, generator=g) > 0.5).float(),
+    )
+    mv = lambda t: t.to(device)
+    return dict(ws=mv(inp['ws']), pose_feat=mv(inp['pose_feat']), cat_feat={k: mv(v) for k, v in inp['cat_feat'].items()},
+                du=mv(inp['du']), dl=mv(inp['dl']), mu=mv(inp['mu']), ml=mv(inp['ml']))
+
+
+def run_net(net, inp):
+    return net(inp['ws'], inp['pose_feat'], inp['cat_feat'], inp['du'], inp['dl'], inp['mu'], inp['ml'], None, noise_mode='const')
+
+
+def init_weights(net):
+    from detgen import fill_module_
+    return fill_module_(net, 'cfg2.')      # name-keyed N(0,1) weights, noise_strength 0.1
+
+
+def cpu_baseline(max_seconds=45.0):
+    """Oracle network on the host cores, N=1, fp32: 1 warm-up + up to 2 timed images (bounded)."""
+    from oracle import network_ref as NR
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    net = init_weights(NR.SynthesisNetworkFull_v18(**CFG2)).eval()
+    inp = make_inputs(1, 'cpu', seed=0)
+    times = []
+    t_start = time.perf_counter()
+    with torch.no_grad():
+        run_net(net, inp)                                   # warm-up (oneDNN primitive creation)
+        while len(times) < 2 and time.perf_counter() - t_start < max_seconds:
+            t0 = time.perf_counter()
+            run_net(net, inp)
+            times.append(time.perf_counter() - t0)
+    if not times:
+        times = [time.perf_counter() - t_start]
+    times.sort()
+    med = times[len(times) // 2]
+    return dict(value=1.0 / med, unit='images/s', cores=threads, kind='port',
+                sample=f'oracle/network_ref.py SynthesisNetworkFull_v18 fwd, N=1, 512^2, fp32, 1 warm-up + {len(times)} timed image(s), median')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=BATCH_PER_GPU, help='images per GPU per step (config 2: 8)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if not torch.cuda.is_available():
+        sys.exit('bench.py needs an MI355X: the product has no CPU path')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=dev)      # RCCL over xGMI
+
+    from torch_utils import custom_ops
+    custom_ops.verbosity = 'none'
+    from torch_utils.ops import conv2d_mfma
+    from training import networks
+
+    net = init_weights(networks.SynthesisNetworkFull_v18(**CFG2)).to(dev).eval()
+    inp = make_inputs(args.batch, dev, seed=rank)           # inputs resident in HBM before the timed region
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            run_net(net, inp)
+        barrier()
+        timeline = conv2d_mfma.start_timeline()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = run_net(net, inp)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        conv2d_mfma.stop_timeline()
+    assert all(torch.isfinite(o).all() for o in out)
+
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        images = args.batch * args.steps * world
+        value = images / elapsed
+        k3 = [(fl, e0.elapsed_time(e1) * 1e-3) for geo, fl, e0, e1 in timeline if geo == (3, 3, 1)]
+        allk = [(fl, e0.elapsed_time(e1) * 1e-3) for geo, fl, e0, e1 in timeline]
+        k3_flops, k3_time = sum(f for f, _ in k3), sum(t for _, t in k3)
+        achieved = k3_flops / k3_time / 1e12 if k3_time > 0 else 0.0
+        roofline = dict(bound='mfma', kernel='conv2d_mfma<3,3,1,BM,8> (3x3 stride-1 implicit GEMM, v_mfma_f32_32x32x2_f32)',
+                        achieved=round(achieved, 2), peak=F32_MFMA_PEAK_TFLOPS, unit='TFLOP/s', frac=round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
+                        traffic=None, launches_per_step=len(k3) // max(args.steps, 1), avg_launch_ms=round(1e3 * k3_time / max(len(k3), 1), 4),
+                        all_conv_tflops=round(sum(f for f, _ in allk) / max(sum(t for _, t in allk), 1e-12) / 1e12, 2),
+                        conv_time_frac_of_step=round(sum(t for _, t in allk) / elapsed, 4),
+                        end_to_end_frac=round(value / world * GFLOP_PER_IMAGE / 1e3 / F32_MFMA_PEAK_TFLOPS, 4))
+        line = dict(metric='512-res try-on images/sec (SynthesisNetwork fwd)', value=round(value, 3), unit='images/s', n_gpus=world,
+                    steps=args.steps, warmup=args.warmup, ms_per_step=round(1e3 * elapsed / args.steps, 3), higher_is_better=True,
+                    scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
+                    config=dict(workload='BASELINE config 2: SynthesisNetworkFull_v18 forward, 512x512, channel_base 32768, fp32, eval, '
+                                         'noise_mode=const, argmax parsing, random-init weights', images_per_gpu_per_step=args.batch,
+                                global_batch=args.batch * world, parallelism=f'replicas x{world}'),
+                    roofline=roofline)
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

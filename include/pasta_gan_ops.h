@@ -1,0 +1,150 @@
+/*
+ * pasta_gan_ops.h -- C ABI of the MI355X (gfx950) kernels behind PASTA-GAN++'s
+ * generator-synthesis operator API.
+ *
+ * Three shared libraries export these symbols (one per reference "plugin"):
+ *   bias_act_plugin.so   pg_bias_act
+ *   upfirdn2d_plugin.so  pg_upfirdn2d
+ *   conv2d_plugin.so     pg_conv2d_pack_weight, pg_conv2d_forward,
+ *                        pg_modconv_prepare, pg_instance_norm_stats, pg_spade_norm
+ * plus pg_<plugin>_abi_version() in each.  They are what the reference's L1
+ * Python ops bind in place of its pybind plugins (see INTEGRATION.md for the
+ * ctypes stub a maintainer adds to the reference tree).
+ *
+ * Conventions (all entry points)
+ *   - plain pointers to DEVICE memory + sizes; no torch types; never throws.
+ *   - asynchronous: work is enqueued on `stream` (a hipStream_t passed as void*;
+ *     NULL = the null stream); no allocation, no synchronisation inside.
+ *   - return 0 on success; a negative PG_ERR_* for rejected arguments (nothing
+ *     was launched); a positive hipError_t if the launch itself failed.
+ *   - strides are in ELEMENTS, not bytes.
+ */
+#ifndef PASTA_GAN_OPS_H
+#define PASTA_GAN_OPS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PG_ABI_VERSION 1
+
+enum pg_dtype { PG_F32 = 0, PG_F16 = 1, PG_BF16 = 2, PG_F64 = 3 };
+
+enum pg_error {
+    PG_OK = 0,
+    PG_ERR_INVALID_ARG = -1,   /* NULL pointer, non-positive size, bad enum     */
+    PG_ERR_UNSUPPORTED = -2,   /* valid request the kernels do not cover         */
+    PG_ERR_TOO_LARGE = -3      /* index range exceeds the kernel's 32-bit maths  */
+};
+
+/* Activation indices: identical to the reference's cuda_idx (bias_act.py:23-33). */
+enum pg_act {
+    PG_ACT_LINEAR = 1, PG_ACT_RELU = 2, PG_ACT_LRELU = 3, PG_ACT_TANH = 4, PG_ACT_SIGMOID = 5,
+    PG_ACT_ELU = 6, PG_ACT_SELU = 7, PG_ACT_SOFTPLUS = 8, PG_ACT_SWISH = 9
+};
+
+/* ------------------------------------------------------------------------
+ * bias_act  -- replaces bias_act_plugin.bias_act (torch_utils/ops/bias_act.cpp:32-90,
+ * kernel bias_act.cu:23-147).
+ *
+ *   grad == 0:  y = clamp(act(x + b[(i / stepB) % sizeB]) * gain)
+ *   grad == 1:  x holds dy;          y = dy * act'(.) * gain, zeroed where |yref| >= clamp
+ *   grad == 2:  x holds d_dx, `dy` the first-order upstream gradient; second derivative
+ *   xref / yref: forward input / output as the activation's backward needs them
+ *   (bias_act.py:23-33 column `ref`); NULL where the reference passes an empty tensor.
+ *   All tensors share x's dense layout; `b` has sizeB contiguous elements of x's dtype.
+ *   clamp < 0 disables clamping.
+ */
+int pg_bias_act(const void* x, const void* b, const void* xref, const void* yref, const void* dy, void* y,
+                int dtype, int64_t sizeX, int sizeB, int64_t stepB,
+                int grad, int act, float alpha, float gain, float clamp, void* stream);
+int pg_bias_act_abi_version(void);
+
+/* ------------------------------------------------------------------------
+ * upfirdn2d -- replaces upfirdn2d_plugin.upfirdn2d (torch_utils/ops/upfirdn2d.cpp:16-94,
+ * kernels upfirdn2d.cu:29-200).
+ *
+ *   y[n,c,oy,ox] = gain * sum_{ky,kx} g[ky,kx] * xs[oy*downy + ky - pady0, ox*downx + kx - padx0]
+ *   xs = x zero-stuffed by (upx, upy), zero outside; g = f flipped in both axes unless `flip`.
+ *   outW = (inW*upx + padx0 + padx1 - fw + downx) / downx is computed by the CALLER
+ *   (upfirdn2d.cpp:32-33) and passed in; x/y strides are (n, c, h, w) in elements, any layout;
+ *   f is float32 [fh, fw] with its own strides.
+ */
+int pg_upfirdn2d(const void* x, const float* f, void* y, int dtype,
+                 int N, int C, int inH, int inW, const int64_t xstride[4],
+                 int fh, int fw, const int64_t fstride[2],
+                 int outH, int outW, const int64_t ystride[4],
+                 int upx, int upy, int downx, int downy, int padx0, int pady0,
+                 int flip, float gain, void* stream);
+int pg_upfirdn2d_abi_version(void);
+
+/* ------------------------------------------------------------------------
+ * conv2d (new: the reference has no native conv; its arithmetic is cuDNN's behind
+ * conv2d_gradfix.py:35-43 / conv2d_resample.py:29-54).  fp32 NCHW implicit GEMM on
+ * v_mfma_f32_32x32x2_f32 with fused prologue/epilogue.
+ *
+ * Weight packing: OIHW [Cout, Cin, KH, KW] -> the kernel's [CinP][KH*KW][CoutP] layout
+ * (CinP = Cin rounded up to 8, CoutP = Cout rounded up to 32, zero filled), scaled by
+ * `scale` (the layers' runtime weight_gain, networks.py:171) and optionally flipped in
+ * both spatial axes (flip_weight=False in conv2d_resample.py:34-35) or transposed
+ * O<->I (the conv_transpose2d weight view, conv2d_resample.py:127).
+ * pg_conv2d_packed_size returns the number of floats the packed buffer needs.
+ */
+int64_t pg_conv2d_packed_size(int Cout, int Cin, int KH, int KW);
+int pg_conv2d_pack_weight(const float* w, float* packed, int Cout, int Cin, int KH, int KW,
+                          float scale, int flip_hw, int transpose_oi, void* stream);
+
+/* Optional fused stages of pg_conv2d_forward; every pointer may be NULL (= stage off). */
+typedef struct pg_conv2d_fusion {
+    /* prologue, applied to each in-image input element before the contraction
+       (zero padding stays zero):  x' = in_act(x * in_scale[n,ci] + in_bias[ci]) * in_gain   */
+    const float* in_scale;      /* [N, Cin]  style modulation (networks.py:74)                  */
+    const float* in_bias;       /* [Cin]     Spade_Conv2dLayer pre-activation (networks.py:1627) */
+    int          in_act;        /* pg_act; 0 or PG_ACT_LINEAR = none                             */
+    float        in_alpha;
+    float        in_gain;       /* used only when in_act/in_bias/in_gain stage is on (0 => 1)    */
+    float        in_clamp;      /* < 0 = off                                                     */
+    /* epilogue:  v = acc * out_scale[n,co] + noise[...] * noise_gain + bias[co];
+                  v = clamp(act(v) * gain);  y = v + residual * residual_gain                    */
+    const float* out_scale;     /* [N, Cout] demodulation coefficients (networks.py:68,77)       */
+    const float* noise;         /* [OH, OW] (noise_batch_stride = 0) or [N, OH, OW]              */
+    int64_t      noise_batch_stride;
+    float        noise_gain;
+    const float* bias;          /* [Cout]                                                        */
+    int          act;           /* pg_act                                                        */
+    float        alpha;
+    float        gain;          /* 0 => 1 */
+    float        clamp;         /* < 0 = off */
+    const float* residual;      /* same shape/strides as y: y += residual (ResBlock add, img.add_) */
+} pg_conv2d_fusion;
+
+/*
+ * y[n, co, oy*osy + ooy, ox*osx + oox] (+)= sum_{ci,ky,kx} wp[ci][ky*KW+kx][co] * x'[n, ci, oy*stride + ky - pad_y, ox*stride + kx - pad_x]
+ * for oy in [0, OH), ox in [0, OW).  (osy, osx, ooy, oox) = (1,1,0,0) for ordinary convs; a stride-2
+ * transposed conv is issued as up to four such calls, one per output phase (see conv2d_gradfix.py of
+ * this package).  x: [N, Cin, H, W] contiguous; y: strides given in elements.
+ */
+int pg_conv2d_forward(const float* x, const float* packed_w, float* y,
+                      int N, int Cin, int H, int W, int Cout, int KH, int KW,
+                      int stride, int pad_y, int pad_x, int OH, int OW,
+                      const int64_t ystride[4], int out_step_y, int out_step_x, int out_off_y, int out_off_x,
+                      const pg_conv2d_fusion* fusion, void* stream);
+
+/* Demodulation coefficients of modulated_conv2d (networks.py:64-68):
+ *   dcoefs[n,o] = rsqrt(sum_{i,k} (w[o,i,k] * scale * styles[n,i])^2 + 1e-8);  w is OIHW. */
+int pg_modconv_dcoefs(const float* w, const float* styles, float* dcoefs,
+                      int N, int Cout, int Cin, int KHW, float scale, void* stream);
+
+/* Per-(n,c) mean and rsqrt(var + eps) over H*W (nn.InstanceNorm2d(affine=False), networks.py:1713),
+ * and the SPADE combine out = (x - mean) * rstd * (1 + gamma) + beta (networks.py:1722). */
+int pg_instance_norm_stats(const float* x, float* mean, float* rstd, int NC, int64_t HW, float eps, void* stream);
+int pg_spade_norm(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                  float* y, int NC, int64_t HW, void* stream);
+int pg_conv2d_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PASTA_GAN_OPS_H */

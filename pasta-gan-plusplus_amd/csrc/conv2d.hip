@@ -1,0 +1,212 @@
+// C ABI of the conv2d plugin + its small support kernels (weight packing, demodulation
+// coefficients, instance-norm statistics, SPADE combine).  The MFMA implicit-GEMM kernel itself
+// lives in conv2d_kernel.h and is instantiated per geometry in conv2d_inst_*.hip.
+#include "conv2d_kernel.h"
+
+namespace {
+
+using namespace pg;
+using pgconv::ConvParams;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------ weight packing
+__global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin, int KH, int KW,
+                                                          int CinP, int CoutP, float scale, int flip, int transpose_oi) {
+    const int T = KH * KW;
+    const int64_t total = (int64_t)CinP * T * CoutP;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int co = (int)(i % CoutP);
+        const int tap = (int)((i / CoutP) % T);
+        const int ci = (int)(i / ((int64_t)CoutP * T));
+        float v = 0.f;
+        if (co < Cout && ci < Cin) {
+            int ky = tap / KW, kx = tap % KW;
+            if (flip) { ky = KH - 1 - ky; kx = KW - 1 - kx; }
+            const int64_t src = transpose_oi ? (((int64_t)ci * Cout + co) * KH + ky) * KW + kx
+                                             : (((int64_t)co * Cin + ci) * KH + ky) * KW + kx;
+            v = w[src] * scale;
+        }
+        wp[i] = v;
+    }
+}
+
+// ------------------------------------------------------------------ demodulation coefficients
+// one workgroup per (n, o): rsqrt(sum_{i,k} (w[o,i,k] * scale * s[n,i])^2 + 1e-8)
+__global__ __launch_bounds__(256) void dcoefs_kernel(const float* __restrict__ w, const float* __restrict__ styles, float* __restrict__ d,
+                                                     int Cout, int Cin, int KHW, float scale) {
+    const int o = blockIdx.x % Cout, n = blockIdx.x / Cout;
+    const float* wo = w + (int64_t)o * Cin * KHW;
+    const float* sn = styles + (int64_t)n * Cin;
+    float acc = 0.f;
+    for (int e = threadIdx.x; e < Cin * KHW; e += 256) {
+        const float v = wo[e] * scale * sn[e / KHW];
+        acc += v * v;
+    }
+    __shared__ float red[4];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) d[blockIdx.x] = rsqrtf(red[0] + red[1] + red[2] + red[3] + 1e-8f);
+}
+
+// ------------------------------------------------------------------ instance-norm statistics (two passes over one plane)
+constexpr int IN_THREADS = 1024;
+__device__ __forceinline__ float block_sum_1024(float v, float* red) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float s = 0.f;
+    if (threadIdx.x < 64) {
+        s = threadIdx.x < IN_THREADS / 64 ? red[threadIdx.x] : 0.f;
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) red[0] = s;
+    __syncthreads();
+    return red[0];
+}
+
+__global__ __launch_bounds__(IN_THREADS) void instance_norm_stats_kernel(const float* __restrict__ x, float* __restrict__ mean, float* __restrict__ rstd, int64_t HW, float eps) {
+    __shared__ float red[IN_THREADS / 64];
+    const float* xp = x + (int64_t)blockIdx.x * HW;
+    float s = 0.f;
+    const bool vec = (HW % 4 == 0) && aligned16(xp);
+    if (vec) {
+        for (int64_t i = threadIdx.x; i < HW / 4; i += IN_THREADS) { const f32x4 v = ((const f32x4*)xp)[i]; s += (v[0] + v[1]) + (v[2] + v[3]); }
+    } else {
+        for (int64_t i = threadIdx.x; i < HW; i += IN_THREADS) s += xp[i];
+    }
+    const float m = block_sum_1024(s, red) / (float)HW;
+    float q = 0.f;
+    if (vec) {
+        for (int64_t i = threadIdx.x; i < HW / 4; i += IN_THREADS) {
+            const f32x4 v = ((const f32x4*)xp)[i];
+            const float a = v[0] - m, b = v[1] - m, c = v[2] - m, d = v[3] - m;
+            q += (a * a + b * b) + (c * c + d * d);
+        }
+    } else {
+        for (int64_t i = threadIdx.x; i < HW; i += IN_THREADS) { const float a = xp[i] - m; q += a * a; }
+    }
+    const float var = block_sum_1024(q, red) / (float)HW;
+    if (threadIdx.x == 0) { mean[blockIdx.x] = m; rstd[blockIdx.x] = 1.0f / sqrtf(var + eps); }
+}
+
+// out = (x - mean) * rstd * (1 + gamma) + beta
+__global__ __launch_bounds__(256) void spade_norm_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ y,
+                                                         int64_t HW4, int64_t total4) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+        const int64_t plane = i / HW4;
+        const float m = mean[plane], r = rstd[plane];
+        const f32x4 xv = ((const f32x4*)x)[i], g = ((const f32x4*)gamma)[i], b = ((const f32x4*)beta)[i];
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; k++) o[k] = (xv[k] - m) * r * (1.f + g[k]) + b[k];
+        ((f32x4*)y)[i] = o;
+    }
+}
+__global__ __launch_bounds__(256) void spade_norm_scalar_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ y,
+                                                                int64_t HW, int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t plane = i / HW;
+        y[i] = (x[i] - mean[plane]) * rstd[plane] * (1.f + gamma[i]) + beta[i];
+    }
+}
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+}  // namespace
+
+PG_EXPORT int pg_conv2d_abi_version(void) { return PG_ABI_VERSION; }
+
+PG_EXPORT int64_t pg_conv2d_packed_size(int Cout, int Cin, int KH, int KW) {
+    if (Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0) return 0;
+    return (int64_t)round_up(Cin, 16) * KH * KW * round_up(Cout, 32);
+}
+
+PG_EXPORT int pg_conv2d_pack_weight(const float* w, float* packed, int Cout, int Cin, int KH, int KW,
+                                    float scale, int flip_hw, int transpose_oi, void* stream) {
+    if (!w || !packed || Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0) return PG_ERR_INVALID_ARG;
+    const int CinP = round_up(Cin, 16), CoutP = round_up(Cout, 32);
+    const int64_t total = (int64_t)CinP * KH * KW * CoutP;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > pg::kMaxStreamBlocks) blocks = pg::kMaxStreamBlocks;
+    hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, packed, Cout, Cin, KH, KW, CinP, CoutP, scale, flip_hw, transpose_oi);
+    return pg::launch_status();
+}
+
+PG_EXPORT int pg_conv2d_forward(const float* x, const float* packed_w, float* y,
+                                int N, int Cin, int H, int W, int Cout, int KH, int KW,
+                                int stride, int pad_y, int pad_x, int OH, int OW,
+                                const int64_t ystride[4], int out_step_y, int out_step_x, int out_off_y, int out_off_x,
+                                const pg_conv2d_fusion* fusion, void* stream) {
+    if (!x || !packed_w || !y || !ystride) return PG_ERR_INVALID_ARG;
+    if (N <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0 || OH <= 0 || OW <= 0) return PG_ERR_INVALID_ARG;
+    if (out_step_y < 1 || out_step_x < 1) return PG_ERR_INVALID_ARG;
+    if ((int64_t)Cin * H * W > 0x7fffffffLL || (int64_t)16 * H * W > 0x7fffffffLL) return PG_ERR_TOO_LARGE;
+    ConvParams p;
+    p.x = x; p.wp = packed_w; p.y = y;
+    p.N = N; p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout; p.CoutP = round_up(Cout, 32); p.OH = OH; p.OW = OW;
+    p.pad_y = pad_y; p.pad_x = pad_x;
+    for (int i = 0; i < 4; i++) p.ys[i] = ystride[i];
+    p.osy = out_step_y; p.osx = out_step_x; p.ooy = out_off_y; p.oox = out_off_x;
+    if (fusion) {
+        p.f = *fusion;
+    } else {
+        pg_conv2d_fusion z = {};
+        z.in_clamp = -1.f; z.clamp = -1.f;
+        p.f = z;
+    }
+    if (p.f.in_gain == 0.f) p.f.in_gain = 1.f;
+    if (p.f.gain == 0.f) p.f.gain = 1.f;
+    if (p.f.in_act == 0) p.f.in_act = PG_ACT_LINEAR;
+    if (p.f.act == 0) p.f.act = PG_ACT_LINEAR;
+    if (p.f.in_act < PG_ACT_LINEAR || p.f.in_act > PG_ACT_SWISH || p.f.act < PG_ACT_LINEAR || p.f.act > PG_ACT_SWISH) return PG_ERR_INVALID_ARG;
+    p.in_xform = (p.f.in_bias || p.f.in_act != PG_ACT_LINEAR || p.f.in_gain != 1.f || p.f.in_clamp >= 0.f) ? 1 : 0;
+    hipStream_t s = (hipStream_t)stream;
+
+    if (stride == 1) {
+        if (KH == 3 && KW == 3) return pgconv::launch_k3s1(p, s);
+        if (KH == 1 && KW == 1) return pgconv::launch_k1s1(p, s);
+        if (KH == 2 && KW == 2) return pgconv::launch_k2x2(p, s);     // polyphase pieces of a stride-2 transposed 3x3
+        if (KH == 2 && KW == 1) return pgconv::launch_k2x1(p, s);
+        if (KH == 1 && KW == 2) return pgconv::launch_k1x2(p, s);
+        if (KH == 7 && KW == 7) return pgconv::launch_k7s1(p, s);
+    } else if (stride == 2) {
+        if (KH == 3 && KW == 3) return pgconv::launch_k3s2(p, s);
+        if (KH == 1 && KW == 1) return pgconv::launch_k1s2(p, s);
+    }
+    return PG_ERR_UNSUPPORTED;
+}
+
+PG_EXPORT int pg_modconv_dcoefs(const float* w, const float* styles, float* dcoefs,
+                                int N, int Cout, int Cin, int KHW, float scale, void* stream) {
+    if (!w || !styles || !dcoefs || N <= 0 || Cout <= 0 || Cin <= 0 || KHW <= 0) return PG_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(dcoefs_kernel, dim3((unsigned)(N * Cout)), dim3(256), 0, (hipStream_t)stream, w, styles, dcoefs, Cout, Cin, KHW, scale);
+    return pg::launch_status();
+}
+
+PG_EXPORT int pg_instance_norm_stats(const float* x, float* mean, float* rstd, int NC, int64_t HW, float eps, void* stream) {
+    if (!x || !mean || !rstd || NC <= 0 || HW <= 0) return PG_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(instance_norm_stats_kernel, dim3((unsigned)NC), dim3(IN_THREADS), 0, (hipStream_t)stream, x, mean, rstd, HW, eps);
+    return pg::launch_status();
+}
+
+PG_EXPORT int pg_spade_norm(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                            float* y, int NC, int64_t HW, void* stream) {
+    if (!x || !mean || !rstd || !gamma || !beta || !y || NC <= 0 || HW <= 0) return PG_ERR_INVALID_ARG;
+    const int64_t total = (int64_t)NC * HW;
+    const bool vec = HW % 4 == 0 && pg::aligned16(x) && pg::aligned16(gamma) && pg::aligned16(beta) && pg::aligned16(y);
+    int64_t blocks = ((vec ? total / 4 : total) + 255) / 256;
+    if (blocks > pg::kMaxStreamBlocks) blocks = pg::kMaxStreamBlocks;
+    if (vec)
+        hipLaunchKernelGGL(spade_norm_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, mean, rstd, gamma, beta, y, HW / 4, total / 4);
+    else
+        hipLaunchKernelGGL(spade_norm_scalar_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, mean, rstd, gamma, beta, y, HW, total);
+    return pg::launch_status();
+}

@@ -1,0 +1,224 @@
+// upfirdn2d for gfx950: pad -> zero-stuff -> 2-D FIR -> decimate in one pass.
+// Drop-in for the reference's upfirdn2d plugin (torch_utils/ops/upfirdn2d.cpp:16-94,
+// upfirdn2d.cu:29-200).
+//
+// Two kernels:
+//   * upfirdn2d_tiled  -- NCHW-dense tensors, small filters.  A 256-thread workgroup owns a
+//     64 x 16 output tile of one (n, c) plane: the input footprint is staged once into LDS
+//     with coalesced row loads (zero filled outside the image), the flipped, zero-padded
+//     taps sit in LDS too, and each lane produces a 1 x 4 column strip so vertically
+//     adjacent outputs reuse LDS reads.  Polyphase for up > 1: only the taps that hit
+//     non-zero samples are visited (FW/up x FH/up per output).  Wave lanes run along x, so
+//     LDS reads are conflict-free (consecutive dwords) and stores are 256-byte row segments.
+//   * upfirdn2d_generic -- any strides / dtype / factors / filter size: one output per
+//     thread straight from global memory, visiting valid taps only.
+//
+// Roofline: HBM streaming; algorithmic bytes per call = sizeof(T) * (numel(x) + numel(y))
+// (SURVEY.md section 8d).
+#include "pg_common.h"
+
+namespace {
+
+using namespace pg;
+
+struct Params {
+    const void* x; const float* f; void* y;
+    int N, C, inH, inW, outH, outW, fh, fw;
+    int64_t xs[4], ys[4], fs[2];
+    int upx, upy, dnx, dny, padx0, pady0, flip;
+    float gain;
+};
+
+__device__ __forceinline__ int floor_div(int a, int b) {   // b > 0
+    int q = a / b;
+    return (a % b != 0 && a < 0) ? q - 1 : q;
+}
+__device__ __forceinline__ int pos_mod(int a, int b) {     // b > 0, result in [0, b)
+    int r = a % b;
+    return r < 0 ? r + b : r;
+}
+
+// ---------------------------------------------------------------- generic
+template <typename T>
+__global__ __launch_bounds__(256) void upfirdn2d_generic(Params p) {
+    typedef typename acc_of<T>::type S;
+    const T* __restrict__ x = (const T*)p.x;
+    T* __restrict__ y = (T*)p.y;
+    const int64_t total = (int64_t)p.N * p.C * p.outH * p.outW;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+        int ox = (int)(idx % p.outW);
+        int64_t r = idx / p.outW;
+        int oy = (int)(r % p.outH); r /= p.outH;
+        int c = (int)(r % p.C);
+        int n = (int)(r / p.C);
+        const int uy0 = oy * p.dny - p.pady0;      // upsampled-grid coordinate of tap ky = 0
+        const int ux0 = ox * p.dnx - p.padx0;
+        const int ky0 = pos_mod(-uy0, p.upy);      // first tap that lands on a real sample
+        const int kx0 = pos_mod(-ux0, p.upx);
+        const T* xb = x + n * p.xs[0] + c * p.xs[1];
+        S acc = (S)0;
+        for (int ky = ky0; ky < p.fh; ky += p.upy) {
+            const int iy = (uy0 + ky) / p.upy;     // exact
+            if (iy < 0 || iy >= p.inH) continue;
+            const int fy = p.flip ? ky : p.fh - 1 - ky;
+            for (int kx = kx0; kx < p.fw; kx += p.upx) {
+                const int ix = (ux0 + kx) / p.upx;
+                if (ix < 0 || ix >= p.inW) continue;
+                const int fx = p.flip ? kx : p.fw - 1 - kx;
+                acc += (S)xb[iy * p.xs[2] + ix * p.xs[3]] * (S)p.f[fy * p.fs[0] + fx * p.fs[1]];
+            }
+        }
+        y[n * p.ys[0] + c * p.ys[1] + oy * p.ys[2] + ox * p.ys[3]] = (T)(acc * (S)p.gain);
+    }
+}
+
+// ---------------------------------------------------------------- tiled
+template <int UPX, int UPY, int DNX, int DNY, int FW, int FH>
+struct Tile {
+    static constexpr int TOW = 64, TOH = 16, RPT = 4;                       // outputs per workgroup, rows per lane
+    static constexpr int TIW = ((TOW - 1) * DNX + FW - 1) / UPX + 2;        // staged input footprint
+    static constexpr int TIH = ((TOH - 1) * DNY + FH - 1) / UPY + 2;
+    static constexpr int TIWP = TIW | 1;                                    // odd row pitch: decimated (stride-2) reads stay conflict-free
+};
+
+template <typename T, int UPX, int UPY, int DNX, int DNY, int FW, int FH>
+__global__ __launch_bounds__(256) void upfirdn2d_tiled(Params p, int tilesX, int tilesY) {
+    typedef Tile<UPX, UPY, DNX, DNY, FW, FH> G;
+    static_assert(FW % UPX == 0 && FH % UPY == 0, "padded filter must be a multiple of the up factor");
+    __shared__ float sf[FH][FW];
+    __shared__ float sx[G::TIH][G::TIWP];
+
+    int bid = blockIdx.x;
+    const int tx = bid % tilesX; bid /= tilesX;
+    const int ty = bid % tilesY;
+    const int64_t plane = bid / tilesY;
+    const int t = threadIdx.x;
+
+    // taps: flipped (true convolution) unless p.flip, zero padded up to FH x FW
+    for (int i = t; i < FH * FW; i += 256) {
+        const int ky = i / FW, kx = i % FW;
+        float v = 0.f;
+        if (ky < p.fh && kx < p.fw) {
+            const int fy = p.flip ? ky : p.fh - 1 - ky;
+            const int fx = p.flip ? kx : p.fw - 1 - kx;
+            v = p.f[fy * p.fs[0] + fx * p.fs[1]];
+        }
+        sf[ky][kx] = v;
+    }
+
+    const int ox0 = tx * G::TOW, oy0 = ty * G::TOH;
+    const int ix0 = floor_div(ox0 * DNX - p.padx0, UPX);
+    const int iy0 = floor_div(oy0 * DNY - p.pady0, UPY);
+    const T* __restrict__ xp = (const T*)p.x + plane * (int64_t)p.inH * p.inW;
+    for (int i = t; i < G::TIH * G::TIW; i += 256) {
+        const int r = i / G::TIW, c = i % G::TIW;
+        const int gy = iy0 + r, gx = ix0 + c;
+        float v = 0.f;
+        if (gy >= 0 && gy < p.inH && gx >= 0 && gx < p.inW) v = (float)xp[(int64_t)gy * p.inW + gx];
+        sx[r][c] = v;
+    }
+    __syncthreads();
+
+    const int lx = t & 63;                    // lanes of a wave run along x
+    const int ly0 = (t >> 6) * G::RPT;        // each wave owns RPT adjacent rows
+    const int ox = ox0 + lx;
+    const int ux0 = ox * DNX - p.padx0;
+    const int kx0 = UPX == 1 ? 0 : pos_mod(-ux0, UPX);
+    const int cx = floor_div(ux0 + kx0, UPX) - ix0;   // LDS column of the first contributing sample
+    T* __restrict__ yp = (T*)p.y + plane * (int64_t)p.outH * p.outW;
+
+#pragma unroll
+    for (int r = 0; r < G::RPT; r++) {
+        const int oy = oy0 + ly0 + r;
+        const int uy0 = oy * DNY - p.pady0;
+        const int ky0 = UPY == 1 ? 0 : pos_mod(-uy0, UPY);
+        const int cy = floor_div(uy0 + ky0, UPY) - iy0;
+        float acc = 0.f;
+#pragma unroll
+        for (int jy = 0; jy < FH / UPY; jy++) {
+#pragma unroll
+            for (int jx = 0; jx < FW / UPX; jx++) {
+                acc += sx[cy + jy][cx + jx] * sf[ky0 + jy * UPY][kx0 + jx * UPX];
+            }
+        }
+        if (ox < p.outW && oy < p.outH) yp[(int64_t)oy * p.outW + ox] = (T)(acc * p.gain);
+    }
+}
+
+template <typename T, int UPX, int UPY, int DNX, int DNY, int FW, int FH>
+int launch_tiled(const Params& p, hipStream_t s) {
+    typedef Tile<UPX, UPY, DNX, DNY, FW, FH> G;
+    const int tilesX = (p.outW + G::TOW - 1) / G::TOW, tilesY = (p.outH + G::TOH - 1) / G::TOH;
+    const int64_t blocks = (int64_t)tilesX * tilesY * p.N * p.C;
+    if (blocks > 0x7fffffffLL) return PG_ERR_TOO_LARGE;
+    hipLaunchKernelGGL((upfirdn2d_tiled<T, UPX, UPY, DNX, DNY, FW, FH>), dim3((unsigned)blocks), dim3(256), 0, s, p, tilesX, tilesY);
+    return launch_status();
+}
+
+// Returns 1 if a tiled specialisation took the call (status in *st).
+template <typename T>
+bool try_tiled(const Params& p, hipStream_t s, int* st) {
+#define PG_SPEC(UX, UY, DX, DY, W, H)                                                               \
+    if (p.upx == UX && p.upy == UY && p.dnx == DX && p.dny == DY && p.fw <= W && p.fh <= H) {        \
+        *st = launch_tiled<T, UX, UY, DX, DY, W, H>(p, s);                                           \
+        return true;                                                                                 \
+    }
+    // 2-D filters (the generator's [1,3,3,1] x [1,3,3,1] and anything up to 8 x 8)
+    PG_SPEC(1, 1, 1, 1, 4, 4) PG_SPEC(2, 2, 1, 1, 4, 4) PG_SPEC(1, 1, 2, 2, 4, 4)
+    PG_SPEC(1, 1, 1, 1, 8, 8) PG_SPEC(2, 2, 1, 1, 8, 8) PG_SPEC(1, 1, 2, 2, 8, 8)
+    // separable passes (one axis at a time; upfirdn2d.py:239-240), up to 16 taps
+    PG_SPEC(1, 1, 1, 1, 16, 1) PG_SPEC(1, 1, 1, 1, 1, 16)
+    PG_SPEC(2, 1, 1, 1, 16, 1) PG_SPEC(1, 2, 1, 1, 1, 16)
+    PG_SPEC(1, 1, 2, 1, 16, 1) PG_SPEC(1, 1, 1, 2, 1, 16)
+#undef PG_SPEC
+    return false;
+}
+
+template <typename T>
+int run(const Params& p, hipStream_t s, bool allow_tiled) {
+    const bool dense_nchw = p.xs[3] == 1 && p.xs[2] == p.inW && p.xs[1] == (int64_t)p.inH * p.inW &&
+                            p.xs[0] == (int64_t)p.C * p.inH * p.inW && p.ys[3] == 1 && p.ys[2] == p.outW &&
+                            p.ys[1] == (int64_t)p.outH * p.outW && p.ys[0] == (int64_t)p.C * p.outH * p.outW;
+    int st = PG_OK;
+    if (allow_tiled && dense_nchw && try_tiled<T>(p, s, &st)) return st;
+    const int64_t total = (int64_t)p.N * p.C * p.outH * p.outW;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > kMaxStreamBlocks * 4) blocks = kMaxStreamBlocks * 4;
+    hipLaunchKernelGGL((upfirdn2d_generic<T>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+    return launch_status();
+}
+
+}  // namespace
+
+PG_EXPORT int pg_upfirdn2d_abi_version(void) { return PG_ABI_VERSION; }
+
+PG_EXPORT int pg_upfirdn2d(const void* x, const float* f, void* y, int dtype,
+                           int N, int C, int inH, int inW, const int64_t xstride[4],
+                           int fh, int fw, const int64_t fstride[2],
+                           int outH, int outW, const int64_t ystride[4],
+                           int upx, int upy, int downx, int downy, int padx0, int pady0,
+                           int flip, float gain, void* stream) {
+    if (!x || !f || !y || !xstride || !fstride || !ystride) return PG_ERR_INVALID_ARG;
+    if (N <= 0 || C <= 0 || inH <= 0 || inW <= 0 || outH <= 0 || outW <= 0 || fh <= 0 || fw <= 0) return PG_ERR_INVALID_ARG;
+    if (upx < 1 || upy < 1 || downx < 1 || downy < 1) return PG_ERR_INVALID_ARG;
+    // 32-bit coordinate maths inside the kernels (the reference has the same INT_MAX limits, upfirdn2d.cpp:22-23,36)
+    if ((int64_t)inW * upx + 2LL * (fw + 1) + (padx0 < 0 ? -(int64_t)padx0 : padx0) > 0x7fffffffLL ||
+        (int64_t)inH * upy + 2LL * (fh + 1) + (pady0 < 0 ? -(int64_t)pady0 : pady0) > 0x7fffffffLL)
+        return PG_ERR_TOO_LARGE;
+    Params p;
+    p.x = x; p.f = f; p.y = y;
+    p.N = N; p.C = C; p.inH = inH; p.inW = inW; p.outH = outH; p.outW = outW; p.fh = fh; p.fw = fw;
+    for (int i = 0; i < 4; i++) { p.xs[i] = xstride[i]; p.ys[i] = ystride[i]; }
+    p.fs[0] = fstride[0]; p.fs[1] = fstride[1];
+    p.upx = upx; p.upy = upy; p.dnx = downx; p.dny = downy; p.padx0 = padx0; p.pady0 = pady0;
+    p.flip = flip ? 1 : 0; p.gain = gain;
+    hipStream_t s = (hipStream_t)stream;
+    switch (dtype) {
+        case PG_F32: return run<float>(p, s, true);
+        case PG_F16: return run<pg::f16_t>(p, s, true);
+        case PG_BF16: return run<pg::bf16_t>(p, s, true);
+        case PG_F64: return run<double>(p, s, false);
+    }
+    return PG_ERR_INVALID_ARG;
+}

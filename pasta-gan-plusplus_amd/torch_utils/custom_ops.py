@@ -1,0 +1,176 @@
+"""Loader for the gfx950 native plugins (C-ABI shared libraries built from ``csrc/*.hip``).
+
+Same role and entry point as the reference's ``torch_utils/custom_ops.py`` --
+``get_plugin(module_name, sources, **build_kwargs)`` (reference custom_ops.py:46-124),
+module global ``verbosity`` (:23), one cached instance per process (:44-51), a
+file lock so concurrent ranks build once (:95-105) -- but MI355X-native: the sources
+are hand-written HIP compiled by ``hipcc --offload-arch=gfx950`` into an in-tree
+``csrc/<module_name>.so`` that is bound with ``ctypes`` (no pybind, no torch
+extension, no hipify).  A content digest next to the .so makes the build
+incremental; the prebuilt library travels with the tree, so a machine without
+``hipcc`` (or with an up-to-date .so) just loads it.
+
+There is no fallback: if the library can neither be found nor built this raises,
+and the ops built on it raise too.
+"""
+
+import concurrent.futures
+import ctypes
+import fcntl
+import glob
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+
+verbosity = 'brief'  # Verbosity level: 'none', 'brief', 'full' (reference custom_ops.py:23)
+
+CSRC_DIR = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'csrc'))
+INCLUDE_DIR = os.path.normpath(os.path.join(CSRC_DIR, '..', '..', 'include'))
+OFFLOAD_ARCH = 'gfx950'
+HIPCC_FLAGS = ['-O3', '-std=c++17', '-fPIC', '-fvisibility=hidden', f'--offload-arch={OFFLOAD_ARCH}']
+
+# Default source lists of the three plugins (callers may pass their own `sources`).
+PLUGIN_SOURCES = {
+    'bias_act_plugin': ['bias_act.hip'],
+    'upfirdn2d_plugin': ['upfirdn2d.hip'],
+    'conv2d_plugin': ['conv2d.hip', 'conv2d_inst_k3s1.hip', 'conv2d_inst_k1s1.hip', 'conv2d_inst_k2x2.hip', 'conv2d_inst_k2x1.hip',
+                      'conv2d_inst_k1x2.hip', 'conv2d_inst_k7s1.hip', 'conv2d_inst_k3s2.hip', 'conv2d_inst_k1s2.hip'],
+}
+
+_cached_plugins = dict()
+
+
+class NativePlugin:
+    """A loaded C-ABI library: ``plugin.lib`` is the ``ctypes.CDLL``; ``plugin.path`` its file."""
+
+    def __init__(self, name, path):
+        self.name = name
+        self.path = path
+        self.lib = ctypes.CDLL(path)
+
+    def __repr__(self):
+        return f'<NativePlugin {self.name} at {self.path}>'
+
+
+def _find_hipcc():
+    for cand in (os.environ.get('HIPCC'), shutil.which('hipcc'), '/opt/rocm/bin/hipcc'):
+        if cand and os.path.isfile(cand):
+            return cand
+    return None
+
+
+def _digest(sources, extra_flags):
+    h = hashlib.md5()
+    deps = sorted(set(list(sources) + glob.glob(os.path.join(CSRC_DIR, '*.h')) + glob.glob(os.path.join(INCLUDE_DIR, '*.h'))))
+    for path in deps:
+        h.update(os.path.basename(path).encode())
+        with open(path, 'rb') as f:
+            h.update(f.read())
+    h.update(' '.join(HIPCC_FLAGS + list(extra_flags)).encode())
+    return h.hexdigest()
+
+
+def _log(msg, end='\n'):
+    if verbosity != 'none':
+        print(msg, end=end, flush=True)
+
+
+def _compile_one(hipcc, src, obj, extra_flags):
+    cmd = [hipcc] + HIPCC_FLAGS + list(extra_flags) + ['-I', INCLUDE_DIR, '-I', CSRC_DIR, '-c', src, '-o', obj]
+    if verbosity == 'full':
+        print(' '.join(cmd), flush=True)
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if proc.returncode != 0:
+        raise RuntimeError(f'hipcc failed on {src}:\n{proc.stdout}')
+    return obj
+
+
+def _build(module_name, sources, so_path, digest, extra_flags):
+    hipcc = _find_hipcc()
+    if hipcc is None:
+        raise RuntimeError(f'cannot build "{module_name}": hipcc not found and no up-to-date {so_path}')
+    obj_dir = os.path.join(CSRC_DIR, 'build', module_name)
+    os.makedirs(obj_dir, exist_ok=True)
+    jobs = max(1, min(len(sources), int(os.environ.get('PG_BUILD_JOBS', os.cpu_count() or 1))))
+    objs = [os.path.join(obj_dir, os.path.splitext(os.path.basename(s))[0] + '.o') for s in sources]
+    with concurrent.futures.ThreadPoolExecutor(max_workers=jobs) as pool:
+        list(pool.map(lambda so: _compile_one(hipcc, so[0], so[1], extra_flags), zip(sources, objs)))
+    tmp = so_path + f'.tmp{os.getpid()}'
+    cmd = [hipcc, '-shared', '-fPIC', f'--offload-arch={OFFLOAD_ARCH}', '-o', tmp] + objs
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if proc.returncode != 0:
+        raise RuntimeError(f'link of {module_name} failed:\n{proc.stdout}')
+    os.replace(tmp, so_path)
+    with open(so_path + '.digest', 'w') as f:
+        f.write(digest)
+
+
+def plugin_path(module_name):
+    return os.path.join(CSRC_DIR, module_name + '.so')
+
+
+def is_up_to_date(module_name, sources=None, extra_flags=()):
+    sources = _resolve_sources(module_name, sources)
+    so_path = plugin_path(module_name)
+    try:
+        with open(so_path + '.digest') as f:
+            return os.path.isfile(so_path) and f.read().strip() == _digest(sources, extra_flags)
+    except OSError:
+        return False
+
+
+def _resolve_sources(module_name, sources):
+    if sources is None:
+        sources = PLUGIN_SOURCES[module_name]
+    return [s if os.path.isabs(s) else os.path.join(CSRC_DIR, s) for s in sources]
+
+
+def get_plugin(module_name, sources=None, extra_hipcc_flags=(), build_only=False, **_ignored_build_kwargs):
+    """Build (if stale) and load the native plugin `module_name`; returns a `NativePlugin`.
+
+    Extra keyword arguments of the reference signature (``extra_cuda_cflags=...``) are accepted
+    and ignored -- there is no nvcc here.
+    """
+    assert verbosity in ['none', 'brief', 'full']
+    if module_name in _cached_plugins and not build_only:
+        return _cached_plugins[module_name]
+
+    sources = _resolve_sources(module_name, sources)
+    so_path = plugin_path(module_name)
+    digest = _digest(sources, extra_hipcc_flags)
+    os.makedirs(os.path.join(CSRC_DIR, 'build'), exist_ok=True)
+    lock_path = os.path.join(CSRC_DIR, 'build', module_name + '.lock')
+    with open(lock_path, 'w') as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)          # concurrent ranks: first one builds, the rest wait
+        try:
+            if not is_up_to_date(module_name, sources, extra_hipcc_flags):
+                if os.path.isfile(so_path) and _find_hipcc() is None:
+                    _log(f'Warning: "{module_name}" is older than its sources and hipcc is missing; loading the stale library.')
+                else:
+                    _log(f'Building native plugin "{module_name}" for {OFFLOAD_ARCH}... ', end='' if verbosity == 'brief' else '\n')
+                    try:
+                        _build(module_name, sources, so_path, digest, extra_hipcc_flags)
+                    except Exception:
+                        _log('Failed!')
+                        raise
+                    _log('Done.')
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+    if build_only:
+        return so_path
+    plugin = NativePlugin(module_name, so_path)
+    _cached_plugins[module_name] = plugin
+    return plugin
+
+
+def build_all(names=None):
+    """Compile every plugin (used by __graft_entry__.build())."""
+    return [get_plugin(n, build_only=True) for n in (names or PLUGIN_SOURCES)]
+
+
+if __name__ == '__main__':
+    verbosity = 'full' if '-v' in sys.argv else 'brief'
+    for p in build_all([a for a in sys.argv[1:] if not a.startswith('-')] or None):
+        print(p)

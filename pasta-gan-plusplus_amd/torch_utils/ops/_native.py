@@ -1,0 +1,45 @@
+"""Small shared helpers for the ctypes bindings of the native plugins."""
+
+import ctypes
+
+import torch
+
+PG_DTYPE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2, torch.float64: 3}
+
+PG_ERRORS = {-1: 'invalid argument', -2: 'unsupported configuration', -3: 'tensor too large for 32-bit kernel indexing'}
+
+
+class NativeOpError(RuntimeError):
+    pass
+
+
+def check(status, what):
+    """Turn a C-ABI status into a RuntimeError (TORCH_CHECK analogue of the reference plugins)."""
+    if status != 0:
+        msg = PG_ERRORS.get(status, f'hipError_t {status}' if status > 0 else f'error {status}')
+        raise NativeOpError(f'{what}: {msg}')
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None and t.numel() > 0 else ctypes.c_void_p(0)
+
+
+def stream_of(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def i64arr(vals):
+    return (ctypes.c_int64 * len(vals))(*[int(v) for v in vals])
+
+
+def require_gpu(x, opname):
+    if x.device.type != 'cuda':
+        raise NativeOpError(
+            f'{opname}: this package is MI355X/HIP-only; got a {x.device.type} tensor. '
+            'There is no CPU fallback in the product (the CPU restatement lives in oracle/ and is test-only).')
+
+
+def no_ref(opname):
+    raise NotImplementedError(
+        f"{opname}(impl='ref'): the product ships no reference implementation; "
+        "use oracle/ops_ref.py (test infrastructure) for the CPU restatement.")

@@ -1,0 +1,265 @@
+"""ctypes binding of ``conv2d_plugin`` (csrc/conv2d*.hip): the fp32 MFMA implicit-GEMM
+convolution with fused prologue/epilogue and its support kernels.
+
+This module has no counterpart in the reference -- there the contraction is cuDNN's,
+reached through ``conv2d_gradfix`` (torch_utils/ops/conv2d_gradfix.py:35-43).  It is the
+native layer under this package's ``conv2d_gradfix`` / ``conv2d_resample`` /
+``training.networks``; forward only (gradients are attached in ``conv2d_gradfix``).
+"""
+
+import ctypes
+
+import torch
+
+from .. import custom_ops
+from . import _native as nat
+
+ACT_INDEX = {'linear': 1, 'relu': 2, 'lrelu': 3, 'tanh': 4, 'sigmoid': 5, 'elu': 6, 'selu': 7, 'softplus': 8, 'swish': 9}
+
+# (KH, KW, stride) geometries instantiated in csrc/conv2d_inst_*.hip
+SUPPORTED = {(3, 3, 1), (1, 1, 1), (2, 2, 1), (2, 1, 1), (1, 2, 1), (7, 7, 1), (3, 3, 2), (1, 1, 2)}
+
+
+class Fusion(ctypes.Structure):
+    """Mirror of ``pg_conv2d_fusion`` (include/pasta_gan_ops.h)."""
+    _fields_ = [
+        ('in_scale', ctypes.c_void_p), ('in_bias', ctypes.c_void_p), ('in_act', ctypes.c_int), ('in_alpha', ctypes.c_float),
+        ('in_gain', ctypes.c_float), ('in_clamp', ctypes.c_float),
+        ('out_scale', ctypes.c_void_p), ('noise', ctypes.c_void_p), ('noise_batch_stride', ctypes.c_int64), ('noise_gain', ctypes.c_float),
+        ('bias', ctypes.c_void_p), ('act', ctypes.c_int), ('alpha', ctypes.c_float), ('gain', ctypes.c_float), ('clamp', ctypes.c_float),
+        ('residual', ctypes.c_void_p),
+    ]
+
+
+_plugin = None
+
+# Optional launch timeline for bench.py's roofline: when a list, every pg_conv2d_forward launch appends
+# (geometry, algorithmic FLOPs, start event, end event) recorded on the launch stream.
+_timeline = None
+
+
+def start_timeline():
+    global _timeline
+    _timeline = []
+    return _timeline
+
+
+def stop_timeline():
+    global _timeline
+    tl, _timeline = _timeline, None
+    return tl
+
+
+def _init():
+    global _plugin
+    if _plugin is None:
+        plugin = custom_ops.get_plugin('conv2d_plugin')
+        lib = plugin.lib
+        i, f, vp, i64 = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_int64
+        lib.pg_conv2d_packed_size.restype = i64
+        lib.pg_conv2d_packed_size.argtypes = [i, i, i, i]
+        lib.pg_conv2d_pack_weight.restype = i
+        lib.pg_conv2d_pack_weight.argtypes = [vp, vp, i, i, i, i, f, i, i, vp]
+        lib.pg_conv2d_forward.restype = i
+        lib.pg_conv2d_forward.argtypes = [vp, vp, vp, i, i, i, i, i, i, i, i, i, i, i, i, ctypes.POINTER(i64), i, i, i, i, ctypes.POINTER(Fusion), vp]
+        lib.pg_modconv_dcoefs.restype = i
+        lib.pg_modconv_dcoefs.argtypes = [vp, vp, vp, i, i, i, i, f, vp]
+        lib.pg_instance_norm_stats.restype = i
+        lib.pg_instance_norm_stats.argtypes = [vp, vp, vp, i, i64, f, vp]
+        lib.pg_spade_norm.restype = i
+        lib.pg_spade_norm.argtypes = [vp, vp, vp, vp, vp, vp, i, i64, vp]
+        _plugin = plugin
+    return _plugin
+
+
+def supported(kh, kw, stride):
+    return (int(kh), int(kw), int(stride)) in SUPPORTED
+
+
+def _f32c(t, name):
+    if t is None:
+        return None
+    if t.dtype != torch.float32 or not t.is_cuda:
+        raise nat.NativeOpError(f'conv2d_mfma: {name} must be a float32 GPU tensor')
+    return t.contiguous()
+
+
+def pack_weight(w, scale=1.0, flip=False, transpose_oi=False):
+    """OIHW (or IOHW when `transpose_oi`) float32 weights -> the kernel's [CinP][taps][CoutP] layout."""
+    lib = _init().lib
+    w = _f32c(w.detach(), 'weight')
+    if transpose_oi:
+        cin, cout, kh, kw = w.shape
+    else:
+        cout, cin, kh, kw = w.shape
+    packed = torch.empty([lib.pg_conv2d_packed_size(cout, cin, kh, kw)], dtype=torch.float32, device=w.device)
+    with torch.cuda.device(w.device):
+        st = lib.pg_conv2d_pack_weight(nat.ptr(w), nat.ptr(packed), cout, cin, kh, kw, float(scale), int(bool(flip)), int(bool(transpose_oi)), nat.stream_of(w))
+    nat.check(st, 'pg_conv2d_pack_weight')
+    return packed
+
+
+def conv2d_forward(x, packed, cout, kh, kw, stride=1, pad=(0, 0), out_hw=None, y=None, out_step=(1, 1), out_off=(0, 0),
+                   in_scale=None, in_bias=None, in_act='linear', in_alpha=0.0, in_gain=1.0, in_clamp=None,
+                   out_scale=None, noise=None, noise_gain=1.0, bias=None, act='linear', alpha=0.0, gain=1.0, clamp=None,
+                   residual=None):
+    """One launch of the MFMA convolution.  `x` [N,Cin,H,W] float32 contiguous; `packed` from
+    `pack_weight`.  Writes y[n, co, oy*step+off, ox*step+off] for oy < out_hw[0], ox < out_hw[1]
+    (allocating a dense [N,Cout,OH,OW] `y` when none is given) and returns `y`."""
+    lib = _init().lib
+    x = _f32c(x, 'x')
+    n, cin, h, w = x.shape
+    pad_y, pad_x = pad
+    if out_hw is None:
+        out_hw = ((h + 2 * pad_y - kh) // stride + 1, (w + 2 * pad_x - kw) // stride + 1)
+    oh, ow = out_hw
+    if y is None:
+        assert tuple(out_step) == (1, 1) and tuple(out_off) == (0, 0)
+        y = torch.empty([n, cout, oh, ow], dtype=torch.float32, device=x.device)
+    else:
+        assert y.dtype == torch.float32 and y.device == x.device and y.shape[0] == n and y.shape[1] == cout
+    fz = Fusion()
+    keep = []
+
+    def dev(t, name, numel=None):
+        t = _f32c(t, name)
+        if t is None:
+            return None
+        if numel is not None and t.numel() != numel:
+            raise nat.NativeOpError(f'conv2d_mfma: {name} has {t.numel()} elements, expected {numel}')
+        keep.append(t)
+        return t.data_ptr()
+
+    fz.in_scale = dev(in_scale, 'in_scale', n * cin)
+    fz.in_bias = dev(in_bias, 'in_bias', cin)
+    fz.in_act, fz.in_alpha, fz.in_gain = ACT_INDEX[in_act], float(in_alpha), float(in_gain)
+    fz.in_clamp = -1.0 if in_clamp is None else float(in_clamp)
+    fz.out_scale = dev(out_scale, 'out_scale', n * cout)
+    if noise is not None:
+        noise = _f32c(noise, 'noise')
+        if noise.numel() == oh * ow:
+            fz.noise_batch_stride = 0
+        elif noise.numel() == n * oh * ow:
+            fz.noise_batch_stride = oh * ow
+        else:
+            raise nat.NativeOpError('conv2d_mfma: noise must have OH*OW or N*OH*OW elements')
+        keep.append(noise)
+        fz.noise = noise.data_ptr()
+    fz.noise_gain = float(noise_gain)
+    fz.bias = dev(bias, 'bias', cout)
+    fz.act, fz.alpha, fz.gain = ACT_INDEX[act], float(alpha), float(gain)
+    fz.clamp = -1.0 if clamp is None else float(clamp)
+    if residual is not None:
+        if residual.dtype != torch.float32 or residual.shape != y.shape or residual.stride() != y.stride():
+            raise nat.NativeOpError('conv2d_mfma: residual must match y in dtype, shape and strides')
+        keep.append(residual)
+        fz.residual = residual.data_ptr()
+    with torch.cuda.device(x.device):
+        if _timeline is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+        st = lib.pg_conv2d_forward(nat.ptr(x), nat.ptr(packed), nat.ptr(y), n, cin, h, w, cout, kh, kw, int(stride), int(pad_y), int(pad_x),
+                                   int(oh), int(ow), nat.i64arr(y.stride()), int(out_step[0]), int(out_step[1]), int(out_off[0]), int(out_off[1]),
+                                   ctypes.byref(fz), nat.stream_of(x))
+        if _timeline is not None:
+            ev1.record()
+            _timeline.append(((kh, kw, int(stride)), 2.0 * n * cout * oh * ow * cin * kh * kw, ev0, ev1))
+    nat.check(st, 'pg_conv2d_forward')
+    return y
+
+
+def transposed_phases(kh, kw, stride, pad_y, pad_x, in_hw, out_hw):
+    """Decompose a stride-`s` transposed convolution into gather-form sub-convolutions, one per
+    output phase.  For output row o, phase a = (o + pad) mod s, m = (o + pad - a) / s:
+        out[o] = sum_j x[m - j] * w[a + s*j],  j < J_a = ceil((K - a) / s)
+    which as a correlation over taps t = J_a-1-j reads x[m - (J_a-1) + t] * w[a + s*(J_a-1-t)].
+    Returns a list of dicts: tap index lists (ky, kx), conv pads, output offsets and counts."""
+    s = stride
+
+    def axis(k, pad, n_out):
+        res = []
+        for a in range(s):
+            j = -(-(k - a) // s)            # ceil
+            if j <= 0:
+                return None                 # a phase with no tap (K < s): outputs there are zero
+            o_first = (a - pad) % s
+            if o_first >= n_out:
+                res.append(None)
+                continue
+            m_first = (o_first + pad - a) // s
+            count = (n_out - 1 - o_first) // s + 1
+            taps = [a + s * (j - 1 - t) for t in range(j)]
+            res.append(dict(taps=taps, conv_pad=(j - 1) - m_first, off=o_first, count=count))
+        return res
+
+    ys, xs = axis(kh, pad_y, out_hw[0]), axis(kw, pad_x, out_hw[1])
+    if ys is None or xs is None:
+        return None
+    return [dict(ky=py['taps'], kx=px['taps'], pad=(py['conv_pad'], px['conv_pad']), off=(py['off'], px['off']), out_hw=(py['count'], px['count']))
+            for py in ys if py is not None for px in xs if px is not None]
+
+
+def pack_transposed(w_iohw, stride, pad, in_hw, out_hw, scale=1.0):
+    """Packed per-phase weights of conv_transpose2d(x, w_iohw, stride, padding=pad) -> list of (phase, packed)."""
+    kh, kw = int(w_iohw.shape[2]), int(w_iohw.shape[3])
+    phases = transposed_phases(kh, kw, stride, pad[0], pad[1], in_hw, out_hw)
+    if phases is None:
+        return None
+    out = []
+    for ph in phases:
+        if not supported(len(ph['ky']), len(ph['kx']), 1):
+            return None
+        sel = w_iohw.detach()[:, :, ph['ky'], :][:, :, :, ph['kx']]
+        out.append((ph, pack_weight(sel, scale=scale, transpose_oi=True)))
+    return out
+
+
+def conv_transpose2d_forward(x, packed_phases, cout, out_hw, **fusion):
+    """Run the phases of `pack_transposed` into one dense [N, Cout, OH, OW] output."""
+    n = x.shape[0]
+    y = torch.empty([n, cout, out_hw[0], out_hw[1]], dtype=torch.float32, device=x.device)
+    stride = fusion.pop('stride', 2)
+    for ph, packed in packed_phases:
+        conv2d_forward(x, packed, cout, len(ph['ky']), len(ph['kx']), stride=1, pad=ph['pad'], out_hw=ph['out_hw'], y=y,
+                       out_step=(stride, stride), out_off=ph['off'], **fusion)
+    return y
+
+
+def modconv_dcoefs(weight, styles, scale=1.0):
+    """rsqrt(sum_{i,k} (w[o,i,k] * scale * s[n,i])^2 + 1e-8) -> [N, Cout] (networks.py:64-68)."""
+    lib = _init().lib
+    weight, styles = _f32c(weight.detach(), 'weight'), _f32c(styles.detach(), 'styles')
+    cout, cin, kh, kw = weight.shape
+    n = styles.shape[0]
+    assert styles.shape[1] == cin
+    d = torch.empty([n, cout], dtype=torch.float32, device=weight.device)
+    with torch.cuda.device(weight.device):
+        st = lib.pg_modconv_dcoefs(nat.ptr(weight), nat.ptr(styles), nat.ptr(d), n, cout, cin, kh * kw, float(scale), nat.stream_of(weight))
+    nat.check(st, 'pg_modconv_dcoefs')
+    return d
+
+
+def instance_norm_stats(x, eps=1e-5):
+    """Per-(n,c) mean and 1/sqrt(var+eps) (biased variance) of a contiguous float32 [N,C,H,W]."""
+    lib = _init().lib
+    x = _f32c(x, 'x')
+    n, c, h, w = x.shape
+    mean = torch.empty([n * c], dtype=torch.float32, device=x.device)
+    rstd = torch.empty_like(mean)
+    with torch.cuda.device(x.device):
+        st = lib.pg_instance_norm_stats(nat.ptr(x), nat.ptr(mean), nat.ptr(rstd), n * c, h * w, float(eps), nat.stream_of(x))
+    nat.check(st, 'pg_instance_norm_stats')
+    return mean, rstd
+
+
+def spade_norm(x, mean, rstd, gamma, beta):
+    """(x - mean) * rstd * (1 + gamma) + beta (networks.py:1715-1722)."""
+    lib = _init().lib
+    x, gamma, beta = _f32c(x, 'x'), _f32c(gamma, 'gamma'), _f32c(beta, 'beta')
+    assert gamma.shape == x.shape and beta.shape == x.shape
+    n, c, h, w = x.shape
+    y = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        st = lib.pg_spade_norm(nat.ptr(x), nat.ptr(mean), nat.ptr(rstd), nat.ptr(gamma), nat.ptr(beta), nat.ptr(y), n * c, h * w, nat.stream_of(x))
+    nat.check(st, 'pg_spade_norm')
+    return y

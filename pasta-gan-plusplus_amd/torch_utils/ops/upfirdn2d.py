@@ -1,0 +1,200 @@
+"""Pad / zero-stuff / FIR / decimate for batches of 2-D images on MI355X.
+
+Public surface of the reference's ``torch_utils/ops/upfirdn2d.py``: ``setup_filter``
+(:72-116), ``upfirdn2d`` (:120-164), ``filter2d`` (:272-304), ``upsample2d``
+(:308-343), ``downsample2d`` (:347-382) and the private helpers its siblings import
+(``_parse_scaling``, ``_parse_padding``, ``_get_filter_size``, :37-68).  Every
+evaluation runs ``csrc/upfirdn2d.hip`` through the C ABI ``pg_upfirdn2d``; the
+gradient is another upfirdn2d with the factors swapped (:245-264), so arbitrary
+order derivatives work.  No CPU / pure-torch path exists in the product.
+"""
+
+import ctypes
+
+import numpy as np
+import torch
+
+from .. import custom_ops
+from .. import misc
+from . import _native as nat
+
+_plugin = None
+
+
+def _init():
+    global _plugin
+    if _plugin is None:
+        plugin = custom_ops.get_plugin('upfirdn2d_plugin')
+        fn = plugin.lib.pg_upfirdn2d
+        fn.restype = ctypes.c_int
+        i, p64 = ctypes.c_int, ctypes.POINTER(ctypes.c_int64)
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, i, i, i, i, i, p64, i, i, p64, i, i, p64,
+                       i, i, i, i, i, i, i, ctypes.c_float, ctypes.c_void_p]
+        _plugin = plugin
+    return True
+
+
+# ---------------------------------------------------------------------------- argument algebra
+
+def _parse_scaling(scaling):
+    if isinstance(scaling, int):
+        scaling = [scaling, scaling]
+    assert isinstance(scaling, (list, tuple)) and len(scaling) == 2
+    assert all(isinstance(v, int) for v in scaling)
+    sx, sy = scaling
+    assert sx >= 1 and sy >= 1
+    return sx, sy
+
+
+def _parse_padding(padding):
+    if isinstance(padding, int):
+        padding = [padding, padding]
+    assert isinstance(padding, (list, tuple))
+    assert all(isinstance(v, int) for v in padding)
+    if len(padding) == 2:
+        px, py = padding
+        padding = [px, px, py, py]
+    px0, px1, py0, py1 = padding
+    return px0, px1, py0, py1
+
+
+def _get_filter_size(f):
+    if f is None:
+        return 1, 1
+    assert isinstance(f, torch.Tensor) and f.ndim in [1, 2]
+    fw, fh = int(f.shape[-1]), int(f.shape[0])
+    misc.assert_shape(f, [fh, fw][:f.ndim])
+    assert fw >= 1 and fh >= 1
+    return fw, fh
+
+
+def setup_filter(f, device=torch.device('cpu'), normalize=True, flip_filter=False, gain=1, separable=None):
+    r"""FIR taps for `upfirdn2d()`: `[fh, fw]`, `[taps]` (separable), `[]` (impulse) or None (identity).
+    1-D tap lists shorter than 8 become their outer product unless `separable` says otherwise."""
+    if f is None:
+        f = 1
+    f = torch.as_tensor(f, dtype=torch.float32)
+    assert f.ndim in [0, 1, 2] and f.numel() > 0
+    if f.ndim == 0:
+        f = f[np.newaxis]
+    if separable is None:
+        separable = (f.ndim == 1 and f.numel() >= 8)
+    if f.ndim == 1 and not separable:
+        f = torch.outer(f, f)
+    assert f.ndim == (1 if separable else 2)
+    if normalize:
+        f = f / f.sum()
+    if flip_filter:
+        f = f.flip(list(range(f.ndim)))
+    f = f * (gain ** (f.ndim / 2))
+    return f.to(device=device)
+
+
+# ---------------------------------------------------------------------------- native call
+
+def _native_upfirdn2d(x, f, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, gain):
+    """Tensor-level twin of the reference plugin entry ``upfirdn2d(...)`` (upfirdn2d.cpp:16-94)."""
+    _init()
+    if x.dtype not in nat.PG_DTYPE:
+        raise nat.NativeOpError(f'upfirdn2d: unsupported dtype {x.dtype}')
+    if f.device != x.device:
+        raise nat.NativeOpError('upfirdn2d: f must reside on the same device as x')
+    if f.dtype != torch.float32:
+        raise nat.NativeOpError('upfirdn2d: f must be float32')
+    if x.ndim != 4 or f.ndim != 2:
+        raise nat.NativeOpError('upfirdn2d: x must be rank 4 and f rank 2')
+    if upx < 1 or upy < 1 or downx < 1 or downy < 1:
+        raise nat.NativeOpError('upfirdn2d: up/down factors must be at least 1')
+    n, c, ih, iw = x.shape
+    fh, fw = f.shape
+    ow = (iw * upx + padx0 + padx1 - fw + downx) // downx
+    oh = (ih * upy + pady0 + pady1 - fh + downy) // downy
+    if ow < 1 or oh < 1:
+        raise nat.NativeOpError('upfirdn2d: output must be at least 1x1')
+    channels_last = x.stride(1) == 1 and c > 1 and x.is_contiguous(memory_format=torch.channels_last)
+    y = torch.empty([n, c, oh, ow], dtype=x.dtype, device=x.device,
+                    memory_format=torch.channels_last if channels_last else torch.contiguous_format)
+    if n == 0 or c == 0:
+        return y
+    with torch.cuda.device(x.device):
+        st = _plugin.lib.pg_upfirdn2d(nat.ptr(x), nat.ptr(f), nat.ptr(y), nat.PG_DTYPE[x.dtype], n, c, ih, iw, nat.i64arr(x.stride()),
+                                      fh, fw, nat.i64arr(f.stride()), oh, ow, nat.i64arr(y.stride()),
+                                      upx, upy, downx, downy, padx0, pady0, int(bool(flip)), float(gain), nat.stream_of(x))
+    nat.check(st, 'pg_upfirdn2d')
+    return y
+
+
+class _Upfirdn2d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, f, up, down, padding, flip_filter, gain):
+        assert isinstance(x, torch.Tensor) and x.ndim == 4
+        upx, upy = up
+        downx, downy = down
+        padx0, padx1, pady0, pady1 = padding
+        if f is None:
+            f = torch.ones([1, 1], dtype=torch.float32, device=x.device)
+        assert isinstance(f, torch.Tensor) and f.ndim in [1, 2]
+        if f.ndim == 2:
+            y = _native_upfirdn2d(x, f, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip_filter, gain)
+        else:   # separable: one pass per axis, sqrt(gain) each (upfirdn2d.py:239-240)
+            y = _native_upfirdn2d(x, f.unsqueeze(0), upx, 1, downx, 1, padx0, padx1, 0, 0, flip_filter, np.sqrt(gain))
+            y = _native_upfirdn2d(y, f.unsqueeze(1), 1, upy, 1, downy, 0, 0, pady0, pady1, flip_filter, np.sqrt(gain))
+        ctx.save_for_backward(f)
+        ctx.cfg = (x.shape, up, down, padding, flip_filter, gain)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        f, = ctx.saved_tensors
+        x_shape, (upx, upy), (downx, downy), (padx0, _, pady0, _), flip_filter, gain = ctx.cfg
+        _, _, ih, iw = x_shape
+        _, _, oh, ow = dy.shape
+        fw, fh = _get_filter_size(f)
+        p = (fw - padx0 - 1, iw * upx - ow * downx + padx0 - upx + 1,
+             fh - pady0 - 1, ih * upy - oh * downy + pady0 - upy + 1)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = _Upfirdn2d.apply(dy, f, (downx, downy), (upx, upy), p, not flip_filter, gain)
+        assert not ctx.needs_input_grad[1]
+        return dx, None, None, None, None, None, None
+
+
+# ---------------------------------------------------------------------------- public ops
+
+def upfirdn2d(x, f, up=1, down=1, padding=0, flip_filter=False, gain=1, impl='cuda'):
+    r"""Upsample by zero insertion (`up`), pad/crop (`padding`, negative = crop), convolve with `f`
+    (true convolution unless `flip_filter`), keep every `down`-th sample, scale by `gain`.
+    Arguments as in the reference (upfirdn2d.py:120-159).  `impl='ref'` raises: HIP only."""
+    assert isinstance(x, torch.Tensor)
+    assert impl in ['ref', 'cuda']
+    if impl == 'ref':
+        nat.no_ref('upfirdn2d')
+    nat.require_gpu(x, 'upfirdn2d')
+    assert f is None or (isinstance(f, torch.Tensor) and f.dtype == torch.float32 and not f.requires_grad)
+    return _Upfirdn2d.apply(x, f, _parse_scaling(up), _parse_scaling(down), _parse_padding(padding), bool(flip_filter), gain)
+
+
+def filter2d(x, f, padding=0, flip_filter=False, gain=1, impl='cuda'):
+    r"""FIR filtering that keeps the image size (plus user padding); upfirdn2d.py:272-304."""
+    padx0, padx1, pady0, pady1 = _parse_padding(padding)
+    fw, fh = _get_filter_size(f)
+    p = [padx0 + fw // 2, padx1 + (fw - 1) // 2, pady0 + fh // 2, pady1 + (fh - 1) // 2]
+    return upfirdn2d(x, f, padding=p, flip_filter=flip_filter, gain=gain, impl=impl)
+
+
+def upsample2d(x, f, up=2, padding=0, flip_filter=False, gain=1, impl='cuda'):
+    r"""FIR upsampling to `up` times the size (plus user padding); upfirdn2d.py:308-343."""
+    upx, upy = _parse_scaling(up)
+    padx0, padx1, pady0, pady1 = _parse_padding(padding)
+    fw, fh = _get_filter_size(f)
+    p = [padx0 + (fw + upx - 1) // 2, padx1 + (fw - upx) // 2, pady0 + (fh + upy - 1) // 2, pady1 + (fh - upy) // 2]
+    return upfirdn2d(x, f, up=up, padding=p, flip_filter=flip_filter, gain=gain * upx * upy, impl=impl)
+
+
+def downsample2d(x, f, down=2, padding=0, flip_filter=False, gain=1, impl='cuda'):
+    r"""FIR downsampling to 1/`down` of the size (plus user padding); upfirdn2d.py:347-382."""
+    downx, downy = _parse_scaling(down)
+    padx0, padx1, pady0, pady1 = _parse_padding(padding)
+    fw, fh = _get_filter_size(f)
+    p = [padx0 + (fw - downx + 1) // 2, padx1 + (fw - downx) // 2, pady0 + (fh - downy + 1) // 2, pady1 + (fh - downy) // 2]
+    return upfirdn2d(x, f, down=down, padding=p, flip_filter=flip_filter, gain=gain, impl=impl)

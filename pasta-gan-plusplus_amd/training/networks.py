@@ -1,0 +1,615 @@
+"""PASTA-GAN++ generator-synthesis stack on the MI355X-native ops.
+
+``modulated_conv2d`` keeps the reference's exact signature (training/networks.py:37-94) and
+the classes keep the reference's names, constructor arguments, parameter names and forward
+signatures (FullyConnectedLayer :99-128, Conv2dLayer :133-179, ResBlock :287-316,
+Spade_Conv2dLayer :1586-1635, Spade_Norm_Block :1702-1723, Spade_ResBlockV4_512 :1859-1904,
+ToRGBLayerFull_v1_v4/_v5 :1910-1967, SynthesisBlockFull_v1_v4/_v6 :1971-2194,
+SynthesisNetworkFull_v18 :2198-2327), so a reference ``state_dict`` loads unchanged.
+``SynthesisLayer`` -- used but never defined in the reference tree --
+is defined here from its call-site contract.
+
+Two execution routes, chosen per call:
+  * inference route (no autograd graph needed, float32): every layer is ONE launch of the MFMA
+    implicit-GEMM conv with its neighbours folded in -- style scaling and SPADE pre-activation
+    in the prologue; demodulation, noise, bias, activation, gain, clamp and the residual /
+    skip-image add in the epilogue (csrc/conv2d_kernel.h);
+  * differentiable route: the same maths composed from this package's ops
+    (conv2d_resample / upfirdn2d / bias_act / fma), each of which carries its own gradient.
+Both run only on the GPU; there is no CPU path.
+"""
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from torch_utils import misc
+from torch_utils.ops import bias_act
+from torch_utils.ops import conv2d_mfma
+from torch_utils.ops import conv2d_resample
+from torch_utils.ops import fma
+from torch_utils.ops import upfirdn2d
+
+SQRT_HALF = float(np.sqrt(0.5))
+
+
+def _needs_graph(*tensors):
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+
+
+def _fast_ok(x, *others):
+    return x.is_cuda and x.dtype == torch.float32 and not _needs_graph(x, *others)
+
+
+class _PackCache:
+    """Packed-weight cache of one layer: re-packs when the parameter is updated in place or replaced."""
+
+    def __init__(self):
+        self._store = {}
+
+    def get(self, tag, params, build):
+        key = tuple((p.data_ptr(), p._version, p.device) for p in params)
+        hit = self._store.get(tag)
+        if hit is None or hit[0] != key:
+            hit = (key, build())
+            self._store[tag] = hit
+        return hit[1]
+
+
+# ----------------------------------------------------------------------------
+
+@misc.profiled_function
+def normalize_2nd_moment(x, dim=1, eps=1e-8):
+    return x * (x.square().mean(dim=dim, keepdim=True) + eps).rsqrt()
+
+
+def _up2_geometry(kh, kw, fw, fh, padding, up=2):
+    """Paddings of the transposed-conv + FIR route of conv2d_resample (conv2d_resample.py:92-142)."""
+    px0 = px1 = py0 = py1 = padding
+    px0 += (fw + up - 1) // 2 - (kw - 1)
+    px1 += (fw - up) // 2 - (kw - up)
+    py0 += (fh + up - 1) // 2 - (kh - 1)
+    py1 += (fh - up) // 2 - (kh - up)
+    pxt = max(min(-px0, -px1), 0)
+    pyt = max(min(-py0, -py1), 0)
+    return (pyt, pxt), [px0 + pxt, px1 + pxt, py0 + pyt, py1 + pyt]
+
+
+@misc.profiled_function
+def modulated_conv2d(
+    x,                          # Input tensor of shape [batch_size, in_channels, in_height, in_width].
+    weight,                     # Weight tensor of shape [out_channels, in_channels, kernel_height, kernel_width].
+    styles,                     # Modulation coefficients of shape [batch_size, in_channels].
+    noise           = None,     # Optional noise tensor to add to the output activations.
+    up              = 1,        # Integer upsampling factor.
+    down            = 1,        # Integer downsampling factor.
+    padding         = 0,        # Padding with respect to the upsampled image.
+    resample_filter = None,     # Low-pass filter to apply when resampling activations (upfirdn2d.setup_filter()).
+    demodulate      = True,     # Apply weight demodulation?
+    flip_weight     = True,     # False = convolution, True = correlation (matches torch.nn.functional.conv2d).
+    fused_modconv   = True,     # Reference: grouped-conv form vs scale-activations form; both are one kernel here.
+    _cache          = None,     # (private) packed-weight cache of the calling layer
+    _epilogue       = None,     # (private) dict(bias, act, alpha, gain, clamp, residual) folded into the same launch
+):
+    batch_size = x.shape[0]
+    out_channels, in_channels, kh, kw = weight.shape
+    misc.assert_shape(weight, [out_channels, in_channels, kh, kw])
+    misc.assert_shape(x, [batch_size, in_channels, None, None])
+    misc.assert_shape(styles, [batch_size, in_channels])
+
+    if _fast_ok(x, weight, styles, noise) and down == 1 and up in (1, 2) and isinstance(padding, int):
+        out = _modconv_fast(x, weight, styles, noise, up, padding, resample_filter, demodulate, flip_weight, _cache, _epilogue)
+        if out is not None:
+            return out
+    assert _epilogue is None
+    return _modconv_graph(x, weight, styles, noise, up, down, padding, resample_filter, demodulate, flip_weight, fused_modconv)
+
+
+def _modconv_fast(x, weight, styles, noise, up, padding, resample_filter, demodulate, flip_weight, cache, epilogue):
+    cout, cin, kh, kw = (int(s) for s in weight.shape)
+    n, _, h, w = x.shape
+    cache = cache if cache is not None else _PackCache()
+    ep = dict(epilogue) if epilogue else {}
+    dcoefs = conv2d_mfma.modconv_dcoefs(weight, styles) if demodulate else None
+    if up == 1:
+        if not conv2d_mfma.supported(kh, kw, 1):
+            return None
+        packed = cache.get(('plain', flip_weight), [weight], lambda: conv2d_mfma.pack_weight(weight, flip=not flip_weight))
+        return conv2d_mfma.conv2d_forward(x, packed, cout, kh, kw, stride=1, pad=(padding, padding), in_scale=styles,
+                                          out_scale=dcoefs, noise=noise, **ep)
+    # up == 2: stride-2 transposed conv (one gather-form launch per output phase), then the FIR.
+    fw, fh = upfirdn2d._get_filter_size(resample_filter)
+    tpad, fir_pad = _up2_geometry(kh, kw, fw, fh, padding)
+    out_hw = ((h - 1) * 2 - 2 * tpad[0] + kh, (w - 1) * 2 - 2 * tpad[1] + kw)
+
+    def build():
+        # conv2d_resample hands conv_transpose2d the O<->I transposed weight, flipped iff flip_weight (its `not flip_weight` twist)
+        wt = weight.detach().transpose(0, 1)
+        if flip_weight:
+            wt = wt.flip([2, 3])
+        return conv2d_mfma.pack_transposed(wt.contiguous(), 2, tpad, (h, w), out_hw)
+    phases = cache.get(('up2', flip_weight, h, w), [weight], build)
+    if phases is None:
+        return None
+    y = conv2d_mfma.conv_transpose2d_forward(x, phases, cout, out_hw, stride=2, in_scale=styles, out_scale=dcoefs)
+    y = upfirdn2d.upfirdn2d(y, resample_filter, padding=fir_pad, gain=4)
+    if noise is not None:
+        y = y.add_(noise)
+    if ep:
+        res = ep.pop('residual', None)
+        y = bias_act.bias_act(y, ep.get('bias'), act=ep.get('act', 'linear'), alpha=ep.get('alpha'), gain=ep.get('gain', 1.0), clamp=ep.get('clamp'))
+        if res is not None:
+            y = y.add_(res)
+    return y
+
+
+def _modconv_graph(x, weight, styles, noise, up, down, padding, resample_filter, demodulate, flip_weight, fused_modconv):
+    """Differentiable composition (the two forms of networks.py:61-94)."""
+    n = x.shape[0]
+    cout, cin, kh, kw = weight.shape
+    if x.dtype == torch.float16 and demodulate:      # keep fp16 in range (networks.py:57-59)
+        weight = weight * (1 / np.sqrt(cin * kh * kw) / weight.norm(float('inf'), dim=[1, 2, 3], keepdim=True))
+        styles = styles / styles.norm(float('inf'), dim=1, keepdim=True)
+    per_sample = dcoefs = None
+    if demodulate or fused_modconv:
+        per_sample = weight.unsqueeze(0) * styles.reshape(n, 1, -1, 1, 1)
+    if demodulate:
+        dcoefs = (per_sample.square().sum(dim=[2, 3, 4]) + 1e-8).rsqrt()
+    if not fused_modconv:
+        y = x * styles.to(x.dtype).reshape(n, -1, 1, 1)
+        y = conv2d_resample.conv2d_resample(x=y, w=weight.to(x.dtype), f=resample_filter, up=up, down=down, padding=padding, flip_weight=flip_weight)
+        if demodulate and noise is not None:
+            return fma.fma(y, dcoefs.to(x.dtype).reshape(n, -1, 1, 1), noise.to(x.dtype))
+        if demodulate:
+            return y * dcoefs.to(x.dtype).reshape(n, -1, 1, 1)
+        if noise is not None:
+            return y.add_(noise.to(x.dtype))
+        return y
+    if demodulate:
+        per_sample = per_sample * dcoefs.reshape(n, -1, 1, 1, 1)
+    y = conv2d_resample.conv2d_resample(x=x.reshape(1, -1, *x.shape[2:]), w=per_sample.reshape(-1, cin, kh, kw).to(x.dtype), f=resample_filter,
+                                        up=up, down=down, padding=padding, groups=n, flip_weight=flip_weight)
+    y = y.reshape(n, -1, *y.shape[2:])
+    if noise is not None:
+        y = y.add_(noise)
+    return y
+
+
+# ----------------------------------------------------------------------------
+
+class FullyConnectedLayer(nn.Module):
+    def __init__(self, in_features, out_features, bias=True, activation='linear', lr_multiplier=1, bias_init=0):
+        super().__init__()
+        self.activation = activation
+        self.weight = nn.Parameter(torch.randn([out_features, in_features]) / lr_multiplier)
+        self.bias = nn.Parameter(torch.full([out_features], np.float32(bias_init))) if bias else None
+        self.weight_gain = lr_multiplier / np.sqrt(in_features)
+        self.bias_gain = lr_multiplier
+
+    def forward(self, x):
+        w = self.weight.to(x.dtype) * self.weight_gain
+        b = self.bias
+        if b is not None:
+            b = b.to(x.dtype)
+            if self.bias_gain != 1:
+                b = b * self.bias_gain
+        if self.activation == 'linear' and b is not None:
+            return torch.addmm(b.unsqueeze(0), x, w.t())
+        return bias_act.bias_act(x.matmul(w.t()), b, act=self.activation)
+
+
+class _ConvBase(nn.Module):
+    """Shared constructor of Conv2dLayer / Spade_Conv2dLayer (identical in the reference, :133-168 / :1586-1621)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, bias=True, activation='linear', up=1, down=1,
+                 resample_filter=[1, 3, 3, 1], conv_clamp=None, channels_last=False, trainable=True):
+        super().__init__()
+        self.activation, self.up, self.down, self.conv_clamp = activation, up, down, conv_clamp
+        self.register_buffer('resample_filter', upfirdn2d.setup_filter(resample_filter))
+        self.padding = kernel_size // 2
+        self.weight_gain = 1 / np.sqrt(in_channels * (kernel_size ** 2))
+        self.act_gain = bias_act.activation_funcs[activation].def_gain
+        memory_format = torch.channels_last if channels_last else torch.contiguous_format
+        weight = torch.randn([out_channels, in_channels, kernel_size, kernel_size]).to(memory_format=memory_format)
+        bias = torch.zeros([out_channels]) if bias else None
+        if trainable:
+            self.weight = nn.Parameter(weight)
+            self.bias = nn.Parameter(bias) if bias is not None else None
+        else:
+            self.register_buffer('weight', weight)
+            if bias is not None:
+                self.register_buffer('bias', bias)
+            else:
+                self.bias = None
+        self._cache = _PackCache()
+
+    def _packed(self, flip):
+        return self._cache.get(('plain', flip), [self.weight], lambda: conv2d_mfma.pack_weight(self.weight, scale=self.weight_gain, flip=flip))
+
+    def _fast_geometry(self):
+        k = int(self.weight.shape[2])
+        return self.up == 1 and conv2d_mfma.supported(k, k, self.down)
+
+
+class Conv2dLayer(_ConvBase):
+    """conv2d_resample -> bias_act (networks.py:170-179); `residual` (private) is added to the result."""
+
+    def forward(self, x, gain=1, residual=None):
+        act_gain = self.act_gain * gain
+        act_clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
+        cout, _, k, _ = self.weight.shape
+        if _fast_ok(x, self.weight, self.bias, residual) and self._fast_geometry():
+            ep = dict(bias=self.bias, act=self.activation, alpha=bias_act.activation_funcs[self.activation].def_alpha, gain=act_gain,
+                      clamp=act_clamp, residual=residual)
+            if self.down == 1:
+                return conv2d_mfma.conv2d_forward(x, self._packed(False), cout, k, k, pad=(self.padding, self.padding), **ep)
+            # down == 2: FIR first (conv2d_resample.py:107-110, 119-122), then the (strided) conv with the fused epilogue
+            fw, fh = upfirdn2d._get_filter_size(self.resample_filter)
+            p = self.padding
+            pads = [p + (fw - self.down + 1) // 2, p + (fw - self.down) // 2, p + (fh - self.down + 1) // 2, p + (fh - self.down) // 2]
+            if k == 1:
+                x = upfirdn2d.upfirdn2d(x, self.resample_filter, down=self.down, padding=pads)
+                return conv2d_mfma.conv2d_forward(x, self._packed(False), cout, 1, 1, **ep)
+            x = upfirdn2d.upfirdn2d(x, self.resample_filter, padding=pads)
+            return conv2d_mfma.conv2d_forward(x, self._packed(False), cout, k, k, stride=self.down, **ep)
+        w = self.weight * self.weight_gain
+        b = self.bias.to(x.dtype) if self.bias is not None else None
+        x = conv2d_resample.conv2d_resample(x=x, w=w.to(x.dtype), f=self.resample_filter, up=self.up, down=self.down,
+                                            padding=self.padding, flip_weight=(self.up == 1))
+        x = bias_act.bias_act(x, b, act=self.activation, gain=act_gain, clamp=act_clamp)
+        return x if residual is None else residual.add_(x) if not _needs_graph(residual, x) else residual + x
+
+
+class ResBlock(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size, bias=True, activation='linear', up=1, down=1,
+                 resample_filter=[1, 3, 3, 1], conv_clamp=None, channels_last=False, trainable=True):
+        super().__init__()
+        self.register_buffer('resample_filter', upfirdn2d.setup_filter(resample_filter))
+        kw = dict(resample_filter=resample_filter, conv_clamp=conv_clamp, channels_last=channels_last)
+        self.conv0 = Conv2dLayer(in_channels, out_channels, kernel_size=3, activation=activation, up=up, down=down, bias=bias, **kw)
+        self.conv1 = Conv2dLayer(out_channels, out_channels, kernel_size=3, activation=activation, bias=bias, **kw)
+        self.skip = Conv2dLayer(in_channels, out_channels, kernel_size=1, bias=False, up=up, down=down, **kw)
+
+    def forward(self, x):
+        y = self.skip(x, gain=SQRT_HALF)
+        x = self.conv0(x)
+        return self.conv1(x, gain=SQRT_HALF, residual=y)      # y + conv1(x), the add folded into conv1's epilogue
+
+
+class Spade_Conv2dLayer(_ConvBase):
+    """bias_act first (unless no_act), then the conv (networks.py:1623-1635).  On the inference route the
+    pre-activation is the conv's prologue; `post_act` / `residual` (private) fold a following ReLU or add."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, bias=True, activation='relu', **kw):
+        super().__init__(in_channels, out_channels, kernel_size, bias=bias, activation=activation, **kw)
+
+    def forward(self, x, gain=1, no_act=False, post_act='linear', residual=None):
+        act_gain = self.act_gain * gain
+        act_clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
+        cout, _, k, _ = self.weight.shape
+        if _fast_ok(x, self.weight, self.bias, residual) and self._fast_geometry() and self.down == 1:
+            pro = {} if no_act else dict(in_bias=self.bias, in_act=self.activation, in_gain=act_gain, in_clamp=act_clamp,
+                                         in_alpha=bias_act.activation_funcs[self.activation].def_alpha)
+            return conv2d_mfma.conv2d_forward(x, self._packed(False), cout, k, k, pad=(self.padding, self.padding), act=post_act, residual=residual, **pro)
+        w = self.weight * self.weight_gain
+        b = self.bias.to(x.dtype) if self.bias is not None else None
+        if not no_act:
+            x = bias_act.bias_act(x, b, act=self.activation, gain=act_gain, clamp=act_clamp)
+        x = conv2d_resample.conv2d_resample(x=x, w=w.to(x.dtype), f=self.resample_filter, up=self.up, down=self.down,
+                                            padding=self.padding, flip_weight=(self.up == 1))
+        if post_act != 'linear':
+            x = bias_act.bias_act(x, act=post_act, gain=1)
+        return x if residual is None else residual + x
+
+
+class Spade_Norm_Block(nn.Module):
+    def __init__(self, in_channels, norm_channels):
+        super().__init__()
+        self.conv_mlp = Spade_Conv2dLayer(in_channels, norm_channels, kernel_size=3, bias=False)
+        self.conv_mlp_act = nn.ReLU()
+        self.conv_gamma = Spade_Conv2dLayer(norm_channels, norm_channels, kernel_size=3, bias=False)
+        self.conv_beta = Spade_Conv2dLayer(norm_channels, norm_channels, kernel_size=3, bias=False)
+        self.param_free_norm = nn.InstanceNorm2d(norm_channels, affine=False)
+
+    def forward(self, x, denorm_feats):
+        if _fast_ok(x, denorm_feats, self.conv_mlp.weight):
+            mean, rstd = conv2d_mfma.instance_norm_stats(x, eps=self.param_free_norm.eps)
+            actv = self.conv_mlp(denorm_feats, no_act=True, post_act='relu')     # conv + ReLU in one launch
+            gamma = self.conv_gamma(actv, no_act=True)
+            beta = self.conv_beta(actv, no_act=True)
+            return conv2d_mfma.spade_norm(x, mean, rstd, gamma, beta)
+        normalized = self.param_free_norm(x)
+        actv = self.conv_mlp_act(self.conv_mlp(denorm_feats, no_act=True))
+        gamma = self.conv_gamma(actv, no_act=True)
+        beta = self.conv_beta(actv, no_act=True)
+        return normalized * (1 + gamma) + beta
+
+
+class Spade_ResBlockV4_512(nn.Module):
+    def __init__(self, in_channels, out_channels, spade_channels, kernel_size=3, bias=True, activation='linear', up=1, down=1,
+                 resample_filter=[1, 3, 3, 1], conv_clamp=None, channels_last=False, trainable=True, resolution=256):
+        super().__init__()
+        self.register_buffer('resample_filter', upfirdn2d.setup_filter(resample_filter))
+        kw = dict(bias=False, resample_filter=resample_filter, conv_clamp=conv_clamp, channels_last=channels_last)
+        self.conv = Spade_Conv2dLayer(in_channels, in_channels, kernel_size=3, **kw)
+        self.conv0 = Spade_Conv2dLayer(in_channels, out_channels, kernel_size=3, **kw)
+        self.conv1 = Spade_Conv2dLayer(out_channels, out_channels, kernel_size=3, **kw)
+        self.skip = Spade_Conv2dLayer(in_channels, out_channels, kernel_size=1, **kw)
+        self.spade_skip = Spade_Norm_Block(spade_channels, in_channels)
+        self.spade0 = Spade_Norm_Block(spade_channels, in_channels)
+        self.spade1 = Spade_Norm_Block(spade_channels, out_channels)
+
+    def forward(self, x, denorm_feat):
+        x = self.conv(x, no_act=True)
+        y = self.skip(self.spade_skip(x, denorm_feat), gain=SQRT_HALF)
+        x = self.conv0(self.spade0(x, denorm_feat))
+        return self.conv1(self.spade1(x, denorm_feat), gain=SQRT_HALF, residual=y)
+
+
+class SynthesisLayer(nn.Module):
+    """affine -> modulated_conv2d (+noise) -> bias_act.  Absent from the reference tree; contract from its call
+    sites: ctor kwargs networks.py:2006-2011, forward kwargs :2054-2062, parameter names legacy.py:178-195."""
+
+    def __init__(self, in_channels, out_channels, w_dim, resolution, kernel_size=3, up=1, use_noise=True, activation='lrelu',
+                 resample_filter=[1, 3, 3, 1], conv_clamp=None, channels_last=False):
+        super().__init__()
+        self.resolution, self.up, self.use_noise, self.activation, self.conv_clamp = resolution, up, use_noise, activation, conv_clamp
+        self.register_buffer('resample_filter', upfirdn2d.setup_filter(resample_filter))
+        self.padding = kernel_size // 2
+        self.act_gain = bias_act.activation_funcs[activation].def_gain
+        self.affine = FullyConnectedLayer(w_dim, in_channels, bias_init=1)
+        memory_format = torch.channels_last if channels_last else torch.contiguous_format
+        self.weight = nn.Parameter(torch.randn([out_channels, in_channels, kernel_size, kernel_size]).to(memory_format=memory_format))
+        if use_noise:
+            self.register_buffer('noise_const', torch.randn([resolution, resolution]))
+            self.noise_strength = nn.Parameter(torch.zeros([]))
+        self.bias = nn.Parameter(torch.zeros([out_channels]))
+        self._cache = _PackCache()
+
+    def forward(self, x, w, noise_mode='random', fused_modconv=True, gain=1):
+        assert noise_mode in ['random', 'const', 'none']
+        in_res = self.resolution // self.up
+        misc.assert_shape(x, [None, self.weight.shape[1], in_res, in_res])
+        styles = self.affine(w)
+        noise = None
+        if self.use_noise and noise_mode == 'random':
+            noise = torch.randn([x.shape[0], 1, self.resolution, self.resolution], device=x.device) * self.noise_strength
+        if self.use_noise and noise_mode == 'const':
+            noise = self.noise_const * self.noise_strength
+        act_gain = self.act_gain * gain
+        act_clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
+        if _fast_ok(x, self.weight, self.bias, styles, noise):
+            ep = dict(bias=self.bias, act=self.activation, alpha=bias_act.activation_funcs[self.activation].def_alpha, gain=act_gain, clamp=act_clamp)
+            return modulated_conv2d(x=x, weight=self.weight, styles=styles, noise=noise, up=self.up, padding=self.padding,
+                                    resample_filter=self.resample_filter, flip_weight=(self.up == 1), fused_modconv=fused_modconv,
+                                    _cache=self._cache, _epilogue=ep)
+        x = modulated_conv2d(x=x, weight=self.weight, styles=styles, noise=noise, up=self.up, padding=self.padding,
+                             resample_filter=self.resample_filter, flip_weight=(self.up == 1), fused_modconv=fused_modconv)
+        return bias_act.bias_act(x, self.bias.to(x.dtype), act=self.activation, gain=act_gain, clamp=act_clamp)
+
+
+class _ToRGBBase(nn.Module):
+    PARSING_CHANNELS = 7
+
+    def __init__(self, in_channels, out_channels, w_dim, kernel_size=1, conv_clamp=None, channels_last=False, is_last=False, is_style=False):
+        super().__init__()
+        self.conv_clamp = conv_clamp
+        self.affine = FullyConnectedLayer(w_dim, in_channels, bias_init=1)
+        memory_format = torch.channels_last if channels_last else torch.contiguous_format
+        self.weight = nn.Parameter(torch.randn([out_channels, in_channels, kernel_size, kernel_size]).to(memory_format=memory_format))
+        self.bias = nn.Parameter(torch.zeros([out_channels]))
+        self.weight_gain = 1 / np.sqrt(in_channels * (kernel_size ** 2))
+        self.is_last, self.is_style = is_last, is_style
+        if self.is_last and self.is_style:
+            self.m_weight1 = nn.Parameter(torch.randn([self.PARSING_CHANNELS, in_channels, kernel_size, kernel_size]).to(memory_format=memory_format))
+            self.m_bias1 = nn.Parameter(torch.zeros([self.PARSING_CHANNELS]))
+        self._cache, self._cache_p = _PackCache(), _PackCache()
+
+    def forward(self, x, w, fused_modconv=True, skip_img=None):
+        """Returns (rgb, pred_parsing); `skip_img` (private) is added to rgb inside the same launch."""
+        styles = self.affine(w) * self.weight_gain
+        fast = _fast_ok(x, self.weight, self.bias, styles, skip_img)
+        pred_parsing = None
+        if self.is_last and self.is_style:
+            if fast:
+                pred_parsing = modulated_conv2d(x=x, weight=self.m_weight1, styles=styles, demodulate=False, fused_modconv=fused_modconv,
+                                                _cache=self._cache_p, _epilogue=dict(bias=self.m_bias1, clamp=self.conv_clamp))
+            else:
+                pred_parsing = modulated_conv2d(x=x, weight=self.m_weight1, styles=styles, demodulate=False, fused_modconv=fused_modconv)
+                pred_parsing = bias_act.bias_act(pred_parsing, self.m_bias1.to(x.dtype), clamp=self.conv_clamp)
+        if fast:
+            y = modulated_conv2d(x=x, weight=self.weight, styles=styles, demodulate=False, fused_modconv=fused_modconv,
+                                 _cache=self._cache, _epilogue=dict(bias=self.bias, clamp=self.conv_clamp, residual=skip_img))
+            return y, pred_parsing
+        y = modulated_conv2d(x=x, weight=self.weight, styles=styles, demodulate=False, fused_modconv=fused_modconv)
+        y = bias_act.bias_act(y, self.bias.to(x.dtype), clamp=self.conv_clamp)
+        if skip_img is not None:
+            y = skip_img + y
+        return y, pred_parsing
+
+
+class ToRGBLayerFull_v1_v5(_ToRGBBase):
+    PARSING_CHANNELS = 7
+
+
+class ToRGBLayerFull_v1_v4(_ToRGBBase):
+    PARSING_CHANNELS = 6
+
+
+class _SynthesisBlockBase(nn.Module):
+    TORGB = ToRGBLayerFull_v1_v5
+    TEXTURE = False
+
+    def __init__(self, in_channels, out_channels, w_dim, resolution, img_channels, is_last, is_style=False, architecture='skip',
+                 resample_filter=[1, 3, 3, 1], conv_clamp=None, use_fp16=False, fp16_channels_last=False, **layer_kwargs):
+        assert architecture in ['orig', 'skip', 'resnet']
+        super().__init__()
+        self.in_channels, self.w_dim, self.resolution, self.img_channels = in_channels, w_dim, resolution, img_channels
+        self.is_last, self.architecture, self.use_fp16 = is_last, architecture, use_fp16
+        self.channels_last = (use_fp16 and fp16_channels_last)
+        self.register_buffer('resample_filter', upfirdn2d.setup_filter(resample_filter))
+        self.num_conv = 0
+        self.num_torgb = 0
+        if in_channels == 0:
+            self.const = nn.Parameter(torch.randn([out_channels, resolution, resolution]))   # kept for checkpoint parity; bypassed (networks.py:2157-2161)
+        if in_channels != 0:
+            self.conv0 = SynthesisLayer(in_channels, out_channels, w_dim=w_dim, resolution=resolution, up=2,
+                                        resample_filter=resample_filter, conv_clamp=conv_clamp, channels_last=self.channels_last, **layer_kwargs)
+            self.num_conv += 1
+        self.conv1 = SynthesisLayer(out_channels, out_channels, w_dim=w_dim, resolution=resolution,
+                                    conv_clamp=conv_clamp, channels_last=self.channels_last, **layer_kwargs)
+        self.num_conv += 1
+        if is_last or architecture == 'skip':
+            self.torgb = self.TORGB(out_channels, img_channels, w_dim=w_dim, conv_clamp=conv_clamp, channels_last=self.channels_last,
+                                    is_last=is_last, is_style=is_style)
+            self.num_torgb += 1
+        if in_channels != 0 and architecture == 'resnet':
+            self.skip = Conv2dLayer(in_channels, out_channels, kernel_size=1, bias=False, up=2, resample_filter=resample_filter, channels_last=self.channels_last)
+        if self.resolution > 32:
+            self.merge_conv = Conv2dLayer(out_channels + 64, out_channels, kernel_size=1, resample_filter=resample_filter, channels_last=self.channels_last)
+        if self.TEXTURE:
+            self.spade_b512 = Spade_ResBlockV4_512(out_channels, out_channels, spade_channels=1)
+
+    def _forward(self, x, img, ws, pose_feature, cat_feat, parsing, force_fp32, fused_modconv, **layer_kwargs):
+        misc.assert_shape(ws, [None, self.num_conv + self.num_torgb, self.w_dim])
+        w_iter = iter(ws.unbind(dim=1))
+        dtype = torch.float16 if self.use_fp16 and not force_fp32 else torch.float32
+        memory_format = torch.channels_last if self.channels_last and not force_fp32 else torch.contiguous_format
+        if fused_modconv is None:
+            fused_modconv = (not self.training) and (dtype == torch.float32 or int(ws.shape[0]) == 1)
+
+        if self.in_channels == 0:
+            x = pose_feature.to(dtype=dtype, memory_format=memory_format)
+        else:
+            misc.assert_shape(x, [None, self.in_channels, self.resolution // 2, self.resolution // 2])
+            x = x.to(dtype=dtype, memory_format=memory_format)
+
+        if self.in_channels == 0:
+            x = self.conv1(x, next(w_iter), fused_modconv=fused_modconv, **layer_kwargs)
+        elif self.architecture == 'resnet':
+            y = self.skip(x, gain=SQRT_HALF)
+            x = self.conv0(x, next(w_iter), fused_modconv=fused_modconv, **layer_kwargs)
+            x = self.conv1(x, next(w_iter), fused_modconv=fused_modconv, gain=SQRT_HALF, **layer_kwargs)
+            x = y.add_(x)
+        else:
+            x = self.conv0(x, next(w_iter), fused_modconv=fused_modconv, **layer_kwargs)
+            x = self.conv1(x, next(w_iter), fused_modconv=fused_modconv, **layer_kwargs)
+            if x.shape[2] > 32:      # concatenate the warped-garment feature map and mix it in (networks.py:2179-2181)
+                x = torch.cat([x, cat_feat[str(x.shape[2])].to(dtype=dtype, memory_format=memory_format)], dim=1)
+                x = self.merge_conv(x)
+            if self.TEXTURE:
+                x = self.spade_b512(x, parsing)
+
+        pred_parsing = None
+        if img is not None:
+            misc.assert_shape(img, [None, self.img_channels, self.resolution // 2, self.resolution // 2])
+            img = upfirdn2d.upsample2d(img, self.resample_filter)
+        if self.is_last or self.architecture == 'skip':
+            y, pred_parsing = self.torgb(x, next(w_iter), fused_modconv=fused_modconv, skip_img=img)   # img + torgb(x) in one launch
+            img = y.to(dtype=torch.float32, memory_format=torch.contiguous_format)
+        return x, img, pred_parsing
+
+
+class SynthesisBlockFull_v1_v6(_SynthesisBlockBase):
+    """Style-branch block (networks.py:2086-2194)."""
+    TORGB = ToRGBLayerFull_v1_v5
+
+    def forward(self, x, img, ws, pose_feature, cat_feat, force_fp32=False, fused_modconv=None, **layer_kwargs):
+        return self._forward(x, img, ws, pose_feature, cat_feat, None, force_fp32, fused_modconv, **layer_kwargs)
+
+
+class SynthesisBlockFull_v1_v4(_SynthesisBlockBase):
+    """Texture-branch block with the parsing-conditioned SPADE residual block (networks.py:1971-2082)."""
+    TORGB = ToRGBLayerFull_v1_v4
+    TEXTURE = True
+
+    def forward(self, x, img, ws, pose_feature, cat_feat, parsing, force_fp32=False, fused_modconv=None, **layer_kwargs):
+        return self._forward(x, img, ws, pose_feature, cat_feat, parsing, force_fp32, fused_modconv, **layer_kwargs)
+
+
+def _half_nearest(t):
+    """F.interpolate(t, scale_factor=0.5), default 'nearest' (networks.py:2255-2256, 2311-2312): every other pixel."""
+    return t[:, :, ::2, ::2]
+
+
+class SynthesisNetworkFull_v18(nn.Module):
+    def __init__(self, w_dim, img_resolution, img_channels, channel_base=32768, channel_max=512, num_fp16_res=0, **block_kwargs):
+        assert img_resolution >= 8 and img_resolution & (img_resolution - 1) == 0
+        super().__init__()
+        self.w_dim, self.img_resolution, self.img_channels = w_dim, img_resolution, img_channels
+        self.img_resolution_log2 = int(np.log2(img_resolution))
+        self.block_resolutions = [2 ** i for i in range(3, self.img_resolution_log2 + 1)]
+        channels_dict = {res: min(channel_base // res, channel_max) for res in self.block_resolutions}
+        self.num_ws = 0
+        for res in self.block_resolutions:
+            in_channels = channels_dict[res // 2] if res > 8 else 0
+            is_last = (res == self.img_resolution)
+            block = SynthesisBlockFull_v1_v6(in_channels, channels_dict[res], w_dim=w_dim, resolution=res, img_channels=img_channels,
+                                             is_last=is_last, is_style=True, use_fp16=False, **block_kwargs)   # fp32 everywhere (networks.py:2223)
+            self.num_ws += block.num_conv
+            if is_last:
+                self.num_ws += block.num_torgb
+            setattr(self, f'b{res}', block)
+        res = self.block_resolutions[-2]
+        self.spade_b256_1 = Spade_ResBlockV4_512(channels_dict[res], channels_dict[res], spade_channels=128)
+        self.spade_b256_2 = Spade_ResBlockV4_512(channels_dict[res], channels_dict[res], spade_channels=128)
+        res = self.block_resolutions[-1]
+        self.texture_b512 = SynthesisBlockFull_v1_v4(channels_dict[res // 2], channels_dict[res], w_dim=w_dim, resolution=res,
+                                                     img_channels=img_channels, is_last=True, is_style=False, use_fp16=False, **block_kwargs)
+        ngf = 64
+        self.spade_encoder = nn.Sequential(
+            Conv2dLayer(3, ngf, kernel_size=7, activation='relu'),
+            ResBlock(ngf, ngf, kernel_size=4, activation='relu'),                 # 512
+            ResBlock(ngf, ngf * 2, kernel_size=4, activation='relu', down=2),     # 256
+        )
+
+    def get_spade_feat(self, mask_512, denorm_mask, denorm_input):
+        dt = mask_512.dtype
+        mask_512 = (mask_512 > 0.9).to(dt)
+        mask_256 = (_half_nearest(mask_512) > 0.9).to(dt)
+        denorm_mask_256 = (_half_nearest(denorm_mask) > 0.9).to(dt)
+        valid_mask = ((mask_256 + denorm_mask_256) == 2.0).to(dt)
+        res_mask = mask_256 - valid_mask
+        feat = self.spade_encoder(denorm_input * mask_512 - (1 - mask_512))
+        valid_feat_sum = torch.sum(feat * valid_mask, dim=(2, 3), keepdim=True)
+        valid_mask_sum = torch.sum(valid_mask, dim=(2, 3), keepdim=True)
+        valid_index = (valid_mask_sum > 10).to(dt)
+        valid_mask_sum = valid_mask_sum * valid_index + (256 * 256) * (1 - valid_index)
+        return feat * (1 - res_mask) + (valid_feat_sum / valid_mask_sum) * res_mask
+
+    def forward(self, ws, pose_feat, cat_feat, denorm_upper_input, denorm_lower_input, denorm_upper_mask,
+                denorm_lower_mask, gt_parsing, **block_kwargs):
+        block_ws = []
+        with torch.autograd.profiler.record_function('split_ws'):
+            misc.assert_shape(ws, [None, self.num_ws, self.w_dim])
+            ws = ws.to(torch.float32)
+            w_idx = 0
+            for res in self.block_resolutions:
+                block = getattr(self, f'b{res}')
+                block_ws.append(ws.narrow(1, w_idx, block.num_conv + block.num_torgb))
+                w_idx += block.num_conv
+
+        x = img = None
+        for res, cur_ws in zip(self.block_resolutions, block_ws):
+            x, img, pred_parsing = getattr(self, f'b{res}')(x, img, cur_ws, pose_feat, cat_feat, force_fp32=True, **block_kwargs)
+            if res == 256:
+                x_256, img_256 = x, img      # neither is modified in place afterwards, so no clone is needed
+
+        if gt_parsing is not None:
+            parsing_index = gt_parsing
+        else:   # softmax is monotone per pixel, so argmax(softmax(p)) == argmax(p) (networks.py:2301-2302)
+            parsing_index = torch.argmax(pred_parsing.detach(), dim=1)[:, None, ...].float()
+
+        upper_mask = (parsing_index == 1).float() + (parsing_index == 4).float()
+        lower_mask = (parsing_index == 2).float() + (parsing_index == 3).float()
+        spade_upper_feat = self.get_spade_feat(upper_mask.detach(), denorm_upper_mask, denorm_upper_input)
+        spade_lower_feat = self.get_spade_feat(lower_mask.detach(), denorm_lower_mask, denorm_lower_input)
+        upper_mask_256 = (_half_nearest(upper_mask) > 0.9).to(upper_mask.dtype)
+        lower_mask_256 = (_half_nearest(lower_mask) > 0.9).to(upper_mask.dtype)
+        spade_feat = spade_upper_feat * upper_mask_256 + spade_lower_feat * lower_mask_256
+
+        x_spade_256 = self.spade_b256_1(x_256, spade_feat)
+        x_spade_256 = self.spade_b256_2(x_spade_256, spade_feat)
+        _, finetune_img, _ = self.texture_b512(x_spade_256, img_256, block_ws[-1], pose_feat, cat_feat, parsing_index,
+                                               force_fp32=True, **block_kwargs)
+        return img, finetune_img, pred_parsing

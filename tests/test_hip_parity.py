@@ -1,0 +1,475 @@
+"""GPU parity tests: the HIP path (through the C ABI) against (a) the golden vectors made by the
+reference itself and (b) the CPU oracle on seeded inputs, plus size-independent properties
+(linearity, adjointness) at full BASELINE sizes.  Run with ``-m gpu`` on an MI355X.
+
+Tolerances (float32): ops that only reorder a short sum are held to 2e-5 rel / 2e-6 abs of the
+output scale; convolutions (K up to 4608 products, different summation order than oneDNN) to
+2e-4 of the output scale; the stacked network to north_star's bound scaled to the output range
+(1e-3 of max|out|, see test_synthesis_*)."""
+
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import cases as C
+from detgen import det_tensor, fill_module_, synthesis_inputs
+
+pytestmark = pytest.mark.gpu
+
+DEV = 'cuda'
+
+
+@pytest.fixture(scope='module', autouse=True)
+def _require_gpu_and_native():
+    assert torch.cuda.is_available(), 'these tests need the MI355X'
+    from torch_utils import custom_ops
+    custom_ops.verbosity = 'none'
+    from torch_utils.ops import bias_act, upfirdn2d, conv2d_mfma
+    assert bias_act._init() and upfirdn2d._init() and conv2d_mfma._init() is not None   # native code loaded, or fail loudly
+
+
+def close(a, b, rtol, atol):
+    a = a.detach().double().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a, dtype=np.float64)
+    b = b.detach().double().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
+
+
+def scale_of(t):
+    t = t.detach().double().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+    return max(1.0, float(np.abs(t).max()))
+
+
+def _filter(spec, name):
+    from torch_utils.ops import upfirdn2d
+    if spec is None:
+        return None
+    kind, v = spec
+    return upfirdn2d.setup_filter(v) if kind == 'taps' else det_tensor(name + '.f', v, 'uniform')
+
+
+# =============================================================== upfirdn2d
+
+@pytest.mark.parametrize('case', C.UPFIRDN2D_CASES, ids=[c[0] for c in C.UPFIRDN2D_CASES])
+def test_upfirdn2d_golden(golden, case):
+    from torch_utils.ops import upfirdn2d
+    g = golden('g1_upfirdn2d.npz')
+    name, xs, fspec, up, down, pad, flip, gain = case
+    f = _filter(fspec, name)
+    fd = f.to(DEV) if f is not None else None
+    x = det_tensor(name + '.x', xs).to(DEV).requires_grad_(True)
+    y = upfirdn2d.upfirdn2d(x, fd, up=up, down=down, padding=pad, flip_filter=flip, gain=gain)
+    s = scale_of(g[f'{name}/y'])
+    close(y, g[f'{name}/y'], 2e-5, 3e-6 * s)
+    dx, = torch.autograd.grad(y, x, det_tensor(name + '.dy', y.shape).to(DEV))
+    close(dx, g[f'{name}/dx'], 2e-5, 3e-6 * s)
+    if name in C.UPFIRDN2D_DTYPE_CASES:
+        for dt, tag, tol in ((torch.float64, 'f64', 1e-9), (torch.float16, 'f16', 4e-3), (torch.bfloat16, 'bf16', 3e-2)):
+            yd = upfirdn2d.upfirdn2d(x.detach().to(dt), fd, up=up, down=down, padding=pad, flip_filter=flip, gain=gain)
+            assert yd.dtype == dt
+            close(yd, g[f'{name}/y_{tag}'], tol, tol * s)
+
+
+@pytest.mark.parametrize('shape,up,down,pad,gain', [
+    ([2, 8, 129, 129], 1, 1, [1, 1, 1, 1], 4),      # odd 2H+1 -> 2H blur (the 513 -> 512 case in small)
+    ([1, 3, 64, 64], 2, 1, [2, 1, 2, 1], 4),
+    ([2, 5, 130, 70], 1, 2, [1, 1, 1, 1], 1),
+    ([1, 4, 64, 200], 1, 1, [2, 2, 2, 2], 1),
+])
+def test_upfirdn2d_vs_oracle_multi_tile(shape, up, down, pad, gain):
+    """Shapes that span several 64x16 tiles with ragged edges, against the CPU oracle."""
+    from torch_utils.ops import upfirdn2d
+    from oracle import ops_ref as R
+    f = upfirdn2d.setup_filter(C.FIR_1331)
+    x = det_tensor(f'mt.{shape}.{up}.{down}', shape)
+    ref = R.upfirdn2d(x, f, up=up, down=down, padding=pad, gain=gain)
+    y = upfirdn2d.upfirdn2d(x.to(DEV), f.to(DEV), up=up, down=down, padding=pad, gain=gain)
+    close(y, ref, 2e-5, 3e-6 * scale_of(ref))
+    # channels_last input takes the generic kernel and keeps its layout
+    xcl = x.to(DEV).contiguous(memory_format=torch.channels_last)
+    ycl = upfirdn2d.upfirdn2d(xcl, f.to(DEV), up=up, down=down, padding=pad, gain=gain)
+    assert ycl.is_contiguous(memory_format=torch.channels_last)
+    close(ycl, ref, 2e-5, 3e-6 * scale_of(ref))
+
+
+def test_upfirdn2d_helpers_and_separable_vs_oracle():
+    from torch_utils.ops import upfirdn2d
+    from oracle import ops_ref as R
+    x = det_tensor('helpers.x', [2, 3, 40, 36])
+    f2, f12 = upfirdn2d.setup_filter(C.FIR_1331), upfirdn2d.setup_filter(C.FIR_12)
+    for f in (f2, f12):
+        close(upfirdn2d.upsample2d(x.to(DEV), f.to(DEV)), R.upsample2d(x, f), 3e-5, 3e-5)
+        close(upfirdn2d.downsample2d(x.to(DEV), f.to(DEV)), R.downsample2d(x, f), 3e-5, 3e-5)
+        close(upfirdn2d.filter2d(x.to(DEV), f.to(DEV)), R.filter2d(x, f), 3e-5, 3e-5)
+    close(upfirdn2d.downsample2d(x.to(DEV), f12.to(DEV), padding=-6, flip_filter=True), R.downsample2d(x, f12, padding=-6, flip_filter=True), 3e-5, 3e-5)
+
+
+def test_upfirdn2d_full_size_properties():
+    """[8,64,513,513] -> 512 blur (config 2's hottest FIR): linearity and adjointness <Ax, y> = <x, A^T y>,
+    where A^T is the op's own backward (upfirdn2d.py:245-264)."""
+    from torch_utils.ops import upfirdn2d
+    f = upfirdn2d.setup_filter(C.FIR_1331).to(DEV)
+    gen = torch.Generator(device=DEV).manual_seed(1)
+    x1 = torch.randn([8, 64, 513, 513], device=DEV, generator=gen)
+    x2 = torch.randn([8, 64, 513, 513], device=DEV, generator=gen)
+    op = lambda t: upfirdn2d.upfirdn2d(t, f, padding=[1, 1, 1, 1], gain=4)
+    y1, y2 = op(x1), op(x2)
+    assert y1.shape == (8, 64, 512, 512)
+    lin = op(x1 * 0.5 + x2 * 2.0)
+    assert float((lin - (y1 * 0.5 + y2 * 2.0)).abs().max()) < 1e-4
+    x1r = x1[:1].clone().requires_grad_(True)
+    yy = op(x1r)
+    v = torch.randn(yy.shape, device=DEV, generator=gen)
+    aty, = torch.autograd.grad(yy, x1r, v)
+    lhs, rhs = float((yy.double() * v.double()).sum()), float((x1r.double() * aty.double()).sum())
+    assert abs(lhs - rhs) <= 1e-5 * max(1.0, abs(lhs))
+    # a constant image stays constant away from the border (unit DC gain x gain 4)
+    c = op(torch.ones([1, 1, 513, 513], device=DEV))
+    assert float((c[:, :, 4:-4, 4:-4] - 4.0).abs().max()) < 1e-5
+
+
+def test_upfirdn2d_argument_errors():
+    from torch_utils.ops import upfirdn2d
+    from torch_utils.ops._native import NativeOpError
+    x = torch.zeros([1, 1, 4, 4], device=DEV)
+    f = upfirdn2d.setup_filter(C.FIR_1331).to(DEV)
+    with pytest.raises(NativeOpError):
+        upfirdn2d.upfirdn2d(x, f, padding=-3)                 # output smaller than 1x1
+    with pytest.raises(NativeOpError):
+        upfirdn2d.upfirdn2d(x, f.cpu())                       # filter on another device
+    with pytest.raises(AssertionError):
+        upfirdn2d.upfirdn2d(x, f.double())                    # filter must be float32
+    with pytest.raises(AssertionError):
+        upfirdn2d.upfirdn2d(x[0], f)                          # rank 4 only
+
+
+# =============================================================== bias_act
+
+@pytest.mark.parametrize('act', C.ACTS)
+def test_bias_act_golden(golden, act):
+    from torch_utils.ops import bias_act
+    g = golden('g2_bias_act.npz')
+    for vname, has_b, gain, clamp, dim, xs in C.BIAS_ACT_VARIANTS:
+        name = f'{act}.{vname}'
+        x = det_tensor(name + '.x', xs, scale=2.0).to(DEV).requires_grad_(True)
+        b = det_tensor(name + '.b', [xs[dim]]).to(DEV).requires_grad_(True) if has_b else None
+        y = bias_act.bias_act(x, b, dim=dim, act=act, gain=gain, clamp=clamp)
+        close(y, g[f'{name}/y'], 2e-5, 2e-6)
+        dy = det_tensor(name + '.dy', xs).to(DEV).requires_grad_(True)
+        grads = torch.autograd.grad(y, [x] + ([b] if has_b else []), dy, create_graph=True)
+        close(grads[0], g[f'{name}/dx'], 3e-5, 3e-6)
+        if has_b:
+            close(grads[1], g[f'{name}/db'], 1e-4, 1e-5)
+        if f'{name}/d_dy' in g and grads[0].requires_grad:
+            v = det_tensor(name + '.v', xs).to(DEV)
+            g2 = torch.autograd.grad(grads[0], [dy, x], v, allow_unused=True)
+            close(g2[0], g[f'{name}/d_dy'], 3e-5, 3e-6)
+            d_x = g2[1] if g2[1] is not None else torch.zeros(xs)
+            close(d_x, g[f'{name}/d_x'], 1e-4, 1e-5)
+        if vname in ('bias', 'bias_clamp'):
+            for dt, tag, tol in ((torch.float64, 'f64', 1e-9), (torch.float16, 'f16', 4e-3), (torch.bfloat16, 'bf16', 3e-2)):
+                yd = bias_act.bias_act(x.detach().to(dt), b.detach().to(dt), dim=dim, act=act, gain=gain, clamp=clamp)
+                close(yd, g[f'{name}/y_{tag}'], tol, tol)
+
+
+@pytest.mark.parametrize('shape', [[2, 7, 33, 17], [1, 64, 128, 128], [3, 5, 1, 1], [4, 9]])
+def test_bias_act_vs_oracle_layouts(shape):
+    """Odd sizes (scalar tail, bias runs not a multiple of the vector width), channels_last, views."""
+    from torch_utils.ops import bias_act
+    from oracle import ops_ref as R
+    x = det_tensor(f'ba.{shape}', shape, scale=3.0)
+    b = det_tensor(f'ba.b.{shape}', [shape[1]])
+    ref = R.bias_act(x, b, act='lrelu', clamp=2.5)
+    close(bias_act.bias_act(x.to(DEV), b.to(DEV), act='lrelu', clamp=2.5), ref, 2e-6, 2e-6)
+    if len(shape) == 4:
+        xcl = x.to(DEV).contiguous(memory_format=torch.channels_last)
+        ycl = bias_act.bias_act(xcl, b.to(DEV), act='lrelu', clamp=2.5)
+        assert ycl.stride() == xcl.stride()
+        close(ycl, ref, 2e-6, 2e-6)
+        xv = torch.cat([x, x], dim=3).to(DEV)[:, :, :, :shape[3]]         # non-dense view -> densified by the op
+        close(bias_act.bias_act(xv, b.to(DEV), act='lrelu', clamp=2.5), ref, 2e-6, 2e-6)
+    off = torch.zeros(x.numel() + 1, device=DEV)                          # 4-byte-offset storage -> unaligned path
+    off[1:] = x.flatten().to(DEV)
+    xo = off[1:].view(shape)
+    close(bias_act.bias_act(xo, b.to(DEV), act='lrelu', clamp=2.5), ref, 2e-6, 2e-6)
+    assert bias_act.bias_act(torch.zeros([0, 3], device=DEV), None, act='relu').shape == (0, 3)   # empty input
+
+
+def test_bias_act_full_size_properties():
+    """[8,64,512,512] (config 2's largest bias_act): idempotence of relu, positive homogeneity of lrelu,
+    agreement with the torch expression of the same formula on the GPU."""
+    from torch_utils.ops import bias_act
+    gen = torch.Generator(device=DEV).manual_seed(2)
+    x = torch.randn([8, 64, 512, 512], device=DEV, generator=gen)
+    b = torch.randn([64], device=DEV, generator=gen)
+    r = bias_act.bias_act(x, None, act='relu', gain=1)
+    assert torch.equal(bias_act.bias_act(r, None, act='relu', gain=1), r)
+    l1 = bias_act.bias_act(x, None, act='lrelu', gain=1)
+    l3 = bias_act.bias_act(x * 3, None, act='lrelu', gain=1)
+    assert float((l3 - 3 * l1).abs().max()) < 1e-5
+    y = bias_act.bias_act(x, b, act='lrelu', clamp=256)
+    ref = torch.nn.functional.leaky_relu(x + b.view(1, -1, 1, 1), 0.2) * math.sqrt(2)
+    assert float((y - ref.clamp(-256, 256)).abs().max()) < 1e-5
+
+
+# =============================================================== conv2d (MFMA implicit GEMM)
+
+CONV_CASES = [
+    # name, N, Cin, Cout, H, W, k, stride, pad
+    ('k3_small',      2, 5, 6, 9, 9, 3, 1, 1),
+    ('k3_c64',        2, 64, 64, 40, 33, 3, 1, 1),
+    ('k3_c128_odd',   1, 128, 128, 17, 45, 3, 1, 1),
+    ('k3_c96',        1, 24, 96, 20, 20, 3, 1, 1),
+    ('k3_cin1',       2, 1, 64, 32, 32, 3, 1, 1),
+    ('k3_nopad',      1, 8, 16, 12, 12, 3, 1, 0),
+    ('k1_torgb',      2, 64, 3, 32, 32, 1, 1, 0),
+    ('k1_merge',      1, 192, 128, 24, 24, 1, 1, 0),
+    ('k1_c7',         2, 37, 7, 19, 21, 1, 1, 0),
+    ('k7_enc',        2, 3, 64, 40, 40, 7, 1, 3),
+    ('k3_s2',         2, 64, 128, 35, 35, 3, 2, 0),
+    ('k1_s2',         1, 16, 24, 20, 20, 1, 2, 0),
+    ('k3_c512_lowres', 2, 512, 512, 8, 8, 3, 1, 1),
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv2d_vs_oracle(case):
+    from torch_utils.ops import conv2d_gradfix
+    import torch.nn.functional as F
+    name, n, cin, cout, h, w, k, stride, pad = case
+    x = det_tensor(name + '.x', [n, cin, h, w])
+    wt = det_tensor(name + '.w', [cout, cin, k, k], scale=1 / math.sqrt(cin * k * k))
+    b = det_tensor(name + '.b', [cout])
+    ref = F.conv2d(x.double(), wt.double(), b.double(), stride=stride, padding=pad)
+    xd, wd = x.to(DEV).requires_grad_(True), wt.to(DEV).requires_grad_(True)
+    y = conv2d_gradfix.conv2d(xd, wd, b.to(DEV), stride=stride, padding=pad)
+    close(y, ref, 1e-4, 2e-5 * scale_of(ref))
+    # gradients (aten convolution_backward behind the native forward)
+    dy = det_tensor(name + '.dy', y.shape)
+    xr, wr = x.double().requires_grad_(True), wt.double().requires_grad_(True)
+    gx, gw = torch.autograd.grad(F.conv2d(xr, wr, stride=stride, padding=pad), [xr, wr], dy.double())
+    dx, dw = torch.autograd.grad(y, [xd, wd], dy.to(DEV))
+    close(dx, gx, 1e-3, 1e-4 * scale_of(gx))
+    close(dw, gw, 1e-3, 1e-4 * scale_of(gw))
+
+
+@pytest.mark.parametrize('n,cin,cout,h,w,k,pad,opad', [(2, 6, 5, 8, 8, 3, 0, 0), (1, 64, 64, 16, 19, 3, 0, 0), (2, 8, 12, 7, 9, 3, 1, 0), (1, 16, 8, 6, 6, 3, 1, 1)])
+def test_conv_transpose2d_vs_oracle(n, cin, cout, h, w, k, pad, opad):
+    from torch_utils.ops import conv2d_gradfix
+    import torch.nn.functional as F
+    x = det_tensor(f'ct.x.{cin}.{h}', [n, cin, h, w])
+    wt = det_tensor(f'ct.w.{cin}.{cout}', [cin, cout, k, k], scale=1 / math.sqrt(cin * k * k))
+    ref = F.conv_transpose2d(x.double(), wt.double(), stride=2, padding=pad, output_padding=opad)
+    y = conv2d_gradfix.conv_transpose2d(x.to(DEV), wt.to(DEV), stride=2, padding=pad, output_padding=opad)
+    close(y, ref, 1e-4, 2e-5 * scale_of(ref))
+
+
+def test_conv2d_fused_prologue_epilogue_vs_oracle():
+    """Every fused stage of pg_conv2d_forward against the unfused oracle composition."""
+    from torch_utils.ops import conv2d_mfma
+    from oracle import ops_ref as R
+    import torch.nn.functional as F
+    n, cin, cout, h, w = 2, 20, 70, 19, 37
+    x = det_tensor('fz.x', [n, cin, h, w])
+    wt = det_tensor('fz.w', [cout, cin, 3, 3], scale=0.1)
+    styles = det_tensor('fz.s', [n, cin]) + 1
+    dco = det_tensor('fz.d', [n, cout]).abs() + 0.5
+    in_b, out_b = det_tensor('fz.ib', [cin]), det_tensor('fz.ob', [cout])
+    noise = det_tensor('fz.noise', [n, 1, h, w])
+    res = det_tensor('fz.res', [n, cout, h, w])
+    packed = conv2d_mfma.pack_weight(wt.to(DEV), scale=0.5)
+    y = conv2d_mfma.conv2d_forward(x.to(DEV), packed, cout, 3, 3, pad=(1, 1),
+                                   in_scale=styles.to(DEV), in_bias=in_b.to(DEV), in_act='relu', in_gain=1.3, in_clamp=2.0,
+                                   out_scale=dco.to(DEV), noise=noise.to(DEV), noise_gain=0.7, bias=out_b.to(DEV), act='lrelu', alpha=0.2,
+                                   gain=math.sqrt(2), clamp=3.0, residual=res.to(DEV))
+    xr = R.bias_act(x * styles[:, :, None, None], in_b, act='relu', gain=1.3, clamp=2.0)
+    ref = F.conv2d(xr, wt * 0.5, padding=1) * dco[:, :, None, None] + noise * 0.7
+    ref = R.bias_act(ref, out_b, act='lrelu', gain=math.sqrt(2), clamp=3.0) + res
+    close(y, ref, 1e-4, 1e-4)
+    # flipped packing == true convolution
+    yf = conv2d_mfma.conv2d_forward(x.to(DEV), conv2d_mfma.pack_weight(wt.to(DEV), flip=True), cout, 3, 3, pad=(1, 1))
+    close(yf, F.conv2d(x, wt.flip([2, 3]), padding=1), 1e-4, 1e-4)
+
+
+def test_conv2d_full_size_linearity_and_delta():
+    """config-2 hottest conv shape, [8,64,512,512] * [64,64,3,3]: linearity in x and a delta-kernel identity."""
+    from torch_utils.ops import conv2d_gradfix
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    x1 = torch.randn([8, 64, 512, 512], device=DEV, generator=gen)
+    x2 = torch.randn([8, 64, 512, 512], device=DEV, generator=gen)
+    w = torch.randn([64, 64, 3, 3], device=DEV, generator=gen) / 24
+    y1, y2 = conv2d_gradfix.conv2d(x1, w, padding=1), conv2d_gradfix.conv2d(x2, w, padding=1)
+    y12 = conv2d_gradfix.conv2d(x1 + 2 * x2, w, padding=1)
+    assert float((y12 - (y1 + 2 * y2)).abs().max()) < 2e-4
+    delta = torch.zeros([64, 64, 3, 3], device=DEV)
+    delta[torch.arange(64), torch.arange(64), 1, 1] = 1
+    assert torch.equal(conv2d_gradfix.conv2d(x1, delta, padding=1), x1)
+    shift = torch.zeros([64, 64, 3, 3], device=DEV)
+    shift[torch.arange(64), torch.arange(64), 0, 2] = 1        # y[oy,ox] = x[oy-1, ox+1]
+    ys = conv2d_gradfix.conv2d(x1, shift, padding=1)
+    assert torch.equal(ys[:, :, 1:, :-1], x1[:, :, :-1, 1:])
+
+
+def test_support_kernels_vs_oracle():
+    from torch_utils.ops import conv2d_mfma
+    from oracle import network_ref as NR
+    x = det_tensor('in.x', [2, 6, 37, 41], scale=3.0) + 5.0
+    gamma, beta = det_tensor('in.g', x.shape), det_tensor('in.b', x.shape)
+    mean, rstd = conv2d_mfma.instance_norm_stats(x.to(DEV))
+    y = conv2d_mfma.spade_norm(x.to(DEV), mean, rstd, gamma.to(DEV), beta.to(DEV))
+    close(y, NR.instance_norm(x) * (1 + gamma) + beta, 2e-5, 2e-5)
+    close(mean.view(2, 6), x.mean(dim=(2, 3)), 1e-6, 1e-6)
+    w = det_tensor('dc.w', [10, 7, 3, 3])
+    s = det_tensor('dc.s', [3, 7]) + 1
+    d = conv2d_mfma.modconv_dcoefs(w.to(DEV), s.to(DEV))
+    ref = ((w[None] * s[:, None, :, None, None]).square().sum(dim=(2, 3, 4)) + 1e-8).rsqrt()
+    close(d, ref, 1e-5, 1e-6)
+
+
+# =============================================================== conv2d_resample / modulated_conv2d
+
+@pytest.mark.parametrize('case', C.CONV2D_RESAMPLE_CASES, ids=[c[0] for c in C.CONV2D_RESAMPLE_CASES])
+def test_conv2d_resample_golden(golden, case):
+    from torch_utils.ops import conv2d_resample, upfirdn2d
+    g = golden('g3_conv2d_resample.npz')
+    name, xs, wsh, taps, up, down, pad, groups, flipw = case
+    f = upfirdn2d.setup_filter(taps).to(DEV)
+    x = det_tensor(name + '.x', xs).to(DEV).requires_grad_(True)
+    w = det_tensor(name + '.w', wsh, scale=1 / math.sqrt(wsh[1] * wsh[2] * wsh[3])).to(DEV).requires_grad_(True)
+    y = conv2d_resample.conv2d_resample(x, w, f=f, up=up, down=down, padding=pad, groups=groups, flip_weight=flipw)
+    close(y, g[f'{name}/y'], 1e-4, 2e-5)
+    dx, dw = torch.autograd.grad(y, [x, w], det_tensor(name + '.dy', y.shape).to(DEV))
+    close(dx, g[f'{name}/dx'], 1e-3, 5e-5)
+    close(dw, g[f'{name}/dw'], 1e-3, 1e-4)
+
+
+@pytest.mark.parametrize('grad', [False, True], ids=['inference_route', 'graph_route'])
+@pytest.mark.parametrize('case', C.MODCONV_CASES, ids=[c[0] for c in C.MODCONV_CASES])
+def test_modulated_conv2d_golden(golden, case, grad):
+    from training import networks
+    from torch_utils.ops import upfirdn2d
+    g = golden('g4_modconv.npz')
+    name, n, cin, cout, k, h, up, demod, fused, noise_kind = case
+    f = upfirdn2d.setup_filter(C.FIR_1331).to(DEV)
+    x = det_tensor(name + '.x', [n, cin, h, h]).to(DEV)
+    w = det_tensor(name + '.w', [cout, cin, k, k]).to(DEV).requires_grad_(grad)
+    s = (det_tensor(name + '.s', [n, cin]) + 1.0).to(DEV)
+    hh = h * up
+    noise = {'none': None, 'const': det_tensor(name + '.noise', [hh, hh]) * 0.1,
+             'per_sample': det_tensor(name + '.noise', [n, 1, hh, hh]) * 0.1}[noise_kind]
+    noise = noise.to(DEV) if noise is not None else None
+    y = networks.modulated_conv2d(x=x.clone(), weight=w, styles=s, noise=noise, up=up, padding=k // 2, resample_filter=f,
+                                  demodulate=demod, flip_weight=(up == 1), fused_modconv=fused)
+    close(y, g[f'{name}/y'], 2e-4, 5e-5)
+
+
+# =============================================================== blocks and the synthesis network
+
+def _load(mod_cls, ref_mod):
+    """Build the product module with the oracle module's parameters/buffers (same names)."""
+    missing, unexpected = mod_cls.load_state_dict(ref_mod.state_dict(), strict=False)
+    assert not [m for m in missing if 'resample_filter' not in m], missing
+    assert not unexpected, unexpected
+    return mod_cls.to(DEV).eval()
+
+
+def test_blocks_golden(golden):
+    from training import networks as PN
+    from oracle import network_ref as NR
+    g = golden('g5_blocks.npz')
+    tol = dict(rtol=3e-4, atol=5e-5)
+    with torch.no_grad():
+        blk = _load(PN.Spade_ResBlockV4_512(8, 8, spade_channels=5), fill_module_(NR.Spade_ResBlockV4_512(8, 8, spade_channels=5), 'g5.spade.'))
+        close(blk(det_tensor('g5.spade.x', [2, 8, 24, 24]).to(DEV), det_tensor('g5.spade.feat', [2, 5, 24, 24]).to(DEV)), g['spade/y'], **tol)
+        rb = _load(PN.ResBlock(6, 10, kernel_size=4, activation='relu', down=2), fill_module_(NR.ResBlock(6, 10, activation='relu', down=2), 'g5.resdown.'))
+        close(rb(det_tensor('g5.resdown.x', [2, 6, 32, 32]).to(DEV)), g['resdown/y'], **tol)
+        rb1 = _load(PN.ResBlock(6, 6, kernel_size=4, activation='relu'), fill_module_(NR.ResBlock(6, 6, activation='relu'), 'g5.res.'))
+        close(rb1(det_tensor('g5.res.x', [2, 6, 20, 20]).to(DEV)), g['res/y'], **tol)
+        c7 = _load(PN.Conv2dLayer(3, 8, kernel_size=7, activation='relu'), fill_module_(NR.Conv2dLayer(3, 8, kernel_size=7, activation='relu'), 'g5.conv7.'))
+        close(c7(det_tensor('g5.conv7.x', [2, 3, 20, 20]).to(DEV)), g['conv7/y'], **tol)
+        cup = _load(PN.Conv2dLayer(4, 6, kernel_size=3, activation='lrelu', up=2, conv_clamp=0.5),
+                    fill_module_(NR.Conv2dLayer(4, 6, kernel_size=3, activation='lrelu', up=2, conv_clamp=0.5), 'g5.convup.'))
+        close(cup(det_tensor('g5.convup.x', [2, 4, 8, 8]).to(DEV), gain=math.sqrt(0.5)), g['convup/y'], **tol)
+        fc = _load(PN.FullyConnectedLayer(12, 7, bias_init=1), fill_module_(NR.FullyConnectedLayer(12, 7, bias_init=1), 'g5.fc.'))
+        close(fc(det_tensor('g5.fc.x', [3, 12]).to(DEV)), g['fc/y'], **tol)
+        fca = _load(PN.FullyConnectedLayer(12, 7, activation='lrelu', lr_multiplier=0.01),
+                    fill_module_(NR.FullyConnectedLayer(12, 7, activation='lrelu', lr_multiplier=0.01), 'g5.fca.'))
+        close(fca(det_tensor('g5.fca.x', [3, 12]).to(DEV)), g['fca/y'], **tol)
+        sl = _load(PN.SynthesisLayer(5, 6, w_dim=12, resolution=16, up=2, conv_clamp=256),
+                   fill_module_(NR.SynthesisLayer(5, 6, w_dim=12, resolution=16, up=2, conv_clamp=256), 'g5.synup.'))
+        xw = det_tensor('g5.synup.x', [2, 5, 8, 8]).to(DEV), det_tensor('g5.synup.w', [2, 12]).to(DEV)
+        close(sl(*xw, noise_mode='const', fused_modconv=True), g['synup_fused/y'], **tol)
+        close(sl(*xw, noise_mode='const', fused_modconv=False, gain=math.sqrt(0.5)), g['synup_nonfused/y'], **tol)
+        tr = _load(PN.ToRGBLayerFull_v1_v5(6, 3, w_dim=12, conv_clamp=256, is_last=True, is_style=True),
+                   fill_module_(NR.ToRGBLayerFull(6, 3, w_dim=12, conv_clamp=256, is_last=True, is_style=True), 'g5.torgb.'))
+        yi, yp = tr(det_tensor('g5.torgb.x', [2, 6, 16, 16]).to(DEV), det_tensor('g5.torgb.w', [2, 12]).to(DEV))
+        close(yi, g['torgb/img'], **tol)
+        close(yp, g['torgb/parsing'], **tol)
+
+
+def test_blocks_graph_route_matches_inference_route():
+    """The differentiable composition and the fused single-launch route agree, and gradients flow."""
+    from training import networks as PN
+    blk = fill_module_(PN.Spade_ResBlockV4_512(8, 8, spade_channels=5), 'gr.spade.').to(DEV)
+    x, feat = det_tensor('gr.x', [2, 8, 24, 24]).to(DEV), det_tensor('gr.f', [2, 5, 24, 24]).to(DEV)
+    with torch.no_grad():
+        y_fast = blk(x, feat)
+    y_graph = blk(x.clone().requires_grad_(True), feat)
+    close(y_graph, y_fast, 2e-4, 5e-5)
+    y_graph.square().mean().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in blk.parameters())
+    sl = fill_module_(PN.SynthesisLayer(5, 6, w_dim=12, resolution=16, up=2, conv_clamp=256), 'gr.syn.').to(DEV)
+    xw = det_tensor('gr.sx', [2, 5, 8, 8]).to(DEV), det_tensor('gr.sw', [2, 12]).to(DEV)
+    with torch.no_grad():
+        a = sl(*xw, noise_mode='const')
+    b = sl(*xw, noise_mode='const', fused_modconv=False)
+    close(b, a, 2e-4, 5e-5)
+    b.sum().backward()
+    assert sl.weight.grad is not None and sl.affine.weight.grad is not None
+
+
+@pytest.mark.parametrize('variant,labels', [('labels', True), ('argmax', False)])
+def test_synthesis_reduced_golden(golden, variant, labels):
+    """512x512, reduced-width SynthesisNetworkFull_v18 on the GPU vs the REFERENCE's own classes (G6)."""
+    from training import networks as PN
+    from oracle import network_ref as NR
+    g = golden('g6_synthesis.npz')
+    torch.manual_seed(0)
+    ref_net = fill_module_(NR.SynthesisNetworkFull_v18(**C.G6_KW), 'g6.')
+    net = _load(PN.SynthesisNetworkFull_v18(**C.G6_KW), ref_net)
+    assert sorted(n for n, _ in net.named_parameters()) == list(g['param_names'])
+    inp = synthesis_inputs(1, w_dim=C.G6_KW['w_dim'], num_ws=net.num_ws, feat_ch=C.G6_FEAT_CH, seed_tag='g6', labels=labels)
+    to = lambda t: t.to(DEV) if t is not None else None
+    with torch.no_grad():
+        img, fimg, pp = net(to(inp['ws']), to(inp['pose_feat']), {k: v.to(DEV) for k, v in inp['cat_feat'].items()},
+                            to(inp['denorm_upper_input']), to(inp['denorm_lower_input']), to(inp['denorm_upper_mask']),
+                            to(inp['denorm_lower_mask']), to(inp['gt_parsing']), noise_mode='const')
+    y0, y1, x0, x1 = C.G6_CROP
+    for nm, t in (('img', img), ('finetune_img', fimg), ('pred_parsing', pp)):
+        s = scale_of(g[f'{variant}/{nm}_sub'])
+        close(t[..., ::C.G6_SUB, ::C.G6_SUB], g[f'{variant}/{nm}_sub'], 1e-3, 1e-3 * s)     # north_star: <= 1e-3 of the pixel range
+        close(t[..., y0:y1, x0:x1], g[f'{variant}/{nm}_crop'], 1e-3, 1e-3 * s)
+        np.testing.assert_allclose(float(t.double().abs().sum()), float(g[f'{variant}/{nm}_abssum']), rtol=1e-4)
+
+
+def test_synthesis_full_width_vs_oracle():
+    """BASELINE config 2's network (channel_base 32768, 27.6 M parameters), N=1, against the CPU oracle."""
+    from training import networks as PN
+    from oracle import network_ref as NR
+    kw = dict(w_dim=512, img_resolution=512, img_channels=3, channel_base=32768, channel_max=512, conv_clamp=256)
+    torch.manual_seed(0)
+    ref_net = fill_module_(NR.SynthesisNetworkFull_v18(**kw), 'cfg2.').eval()
+    net = _load(PN.SynthesisNetworkFull_v18(**kw), ref_net)
+    assert sum(p.numel() for p in net.parameters()) == sum(p.numel() for p in ref_net.parameters())
+    inp = synthesis_inputs(1, labels=True)
+    args = lambda f: (f(inp['ws']), f(inp['pose_feat']), {k: f(v) for k, v in inp['cat_feat'].items()}, f(inp['denorm_upper_input']),
+                      f(inp['denorm_lower_input']), f(inp['denorm_upper_mask']), f(inp['denorm_lower_mask']), f(inp['gt_parsing']))
+    with torch.no_grad():
+        out = net(*args(lambda t: t.to(DEV)), noise_mode='const')
+        ref = ref_net(*args(lambda t: t), noise_mode='const')
+    for nm, a, b in zip(('img', 'finetune_img', 'pred_parsing'), out, ref):
+        s = scale_of(b)
+        delta = float((a.cpu().double() - b.double()).abs().max())
+        assert delta <= 1e-3 * s, f'{nm}: max-abs delta {delta:.3e} vs output range {s:.3e}'

@@ -1,0 +1,132 @@
+"""CPU-only checks of the product's host side: the C-ABI libraries load and export every
+symbol include/pasta_gan_ops.h declares; argument algebra; the transposed-conv phase
+decomposition (emulated with torch CPU ops standing in for one pg_conv2d_forward launch);
+and the HIP-only contract (CPU tensors and impl='ref' raise, never fall back)."""
+
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, 'include', 'pasta_gan_ops.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(pg_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_header_declares_expected_entry_points():
+    syms = declared_symbols()
+    for s in ('pg_bias_act', 'pg_upfirdn2d', 'pg_conv2d_forward', 'pg_conv2d_pack_weight', 'pg_conv2d_packed_size',
+              'pg_modconv_dcoefs', 'pg_instance_norm_stats', 'pg_spade_norm'):
+        assert s in syms
+
+
+def test_c_abi_libraries_export_every_declared_symbol():
+    from torch_utils import custom_ops
+    custom_ops.verbosity = 'none'
+    libs = [ctypes.CDLL(custom_ops.get_plugin(n, build_only=True)) for n in custom_ops.PLUGIN_SOURCES]
+    for sym in declared_symbols():
+        assert any(hasattr(lib, sym) for lib in libs), f'{sym} declared in include/pasta_gan_ops.h but exported by no plugin'
+    for lib, name in zip(libs, custom_ops.PLUGIN_SOURCES):
+        fn = getattr(lib, 'pg_' + name.replace('_plugin', '') + '_abi_version')
+        fn.restype = ctypes.c_int
+        assert fn() == 1
+    # host-only entry point: packed-weight size needs no GPU
+    conv = libs[list(custom_ops.PLUGIN_SOURCES).index('conv2d_plugin')]
+    conv.pg_conv2d_packed_size.restype = ctypes.c_int64
+    assert conv.pg_conv2d_packed_size(64, 3, 7, 7) == 16 * 49 * 64
+    assert conv.pg_conv2d_packed_size(3, 64, 1, 1) == 64 * 1 * 32
+    assert conv.pg_conv2d_packed_size(0, 64, 1, 1) == 0
+
+
+def test_product_has_no_cpu_fallback():
+    from torch_utils.ops import bias_act, upfirdn2d, conv2d_gradfix
+    from torch_utils.ops._native import NativeOpError
+    x = torch.zeros(1, 2, 4, 4)
+    with pytest.raises(NativeOpError):
+        bias_act.bias_act(x, act='relu')
+    with pytest.raises(NotImplementedError):
+        bias_act.bias_act(x, act='relu', impl='ref')
+    with pytest.raises(NativeOpError):
+        upfirdn2d.upfirdn2d(x, upfirdn2d.setup_filter([1, 3, 3, 1]))
+    with pytest.raises(NotImplementedError):
+        upfirdn2d.upfirdn2d(x, None, impl='ref')
+    with pytest.raises(NativeOpError):
+        conv2d_gradfix.conv2d(x, torch.zeros(3, 2, 3, 3), padding=1)
+    with pytest.raises(AssertionError):
+        bias_act.bias_act(x, impl='bogus')
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, 'pasta-gan-plusplus_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith(('.py', '.hip', '.h')):
+                text = open(os.path.join(dirpath, fn)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle', text, flags=re.M), f'{fn} imports the oracle'
+
+
+def test_setup_filter_and_padding_algebra(golden):
+    import numpy as np
+    import cases as C
+    from torch_utils.ops import upfirdn2d
+    g = golden('g1_upfirdn2d.npz')
+    np.testing.assert_allclose(upfirdn2d.setup_filter(C.FIR_1331).numpy(), g['setup/1331'], rtol=1e-7)
+    np.testing.assert_allclose(upfirdn2d.setup_filter(C.FIR_12).numpy(), g['setup/12'], rtol=1e-7)
+    np.testing.assert_allclose(upfirdn2d.setup_filter([1, 2, 3, 4], flip_filter=True, gain=3).numpy(), g['setup/1331_flip_gain'], rtol=1e-6)
+    np.testing.assert_allclose(upfirdn2d.setup_filter(C.FIR_1331, separable=True, gain=2).numpy(), g['setup/sep_forced'], rtol=1e-6)
+    assert upfirdn2d._parse_padding(3) == (3, 3, 3, 3)
+    assert upfirdn2d._parse_padding([1, 2]) == (1, 1, 2, 2)
+    assert upfirdn2d._parse_padding([1, 2, 3, 4]) == (1, 2, 3, 4)
+    assert upfirdn2d._parse_scaling(2) == (2, 2)
+    assert upfirdn2d._get_filter_size(None) == (1, 1)
+    assert upfirdn2d._get_filter_size(torch.zeros(3, 5)) == (5, 3)
+
+
+@pytest.mark.parametrize('k,stride,pad,h,w,opad', [(3, 2, 0, 8, 8, 0), (3, 2, 1, 7, 9, 0), (3, 2, 1, 6, 5, 1), (4, 2, 1, 5, 6, 0), (2, 2, 0, 4, 4, 0), (3, 3, 1, 5, 4, 0)])
+def test_transposed_phase_decomposition(k, stride, pad, h, w, opad):
+    """conv_transpose2d == union over output phases of small gather-form correlations."""
+    from torch_utils.ops import conv2d_mfma
+    torch.manual_seed(0)
+    cin, cout = 3, 4
+    x = torch.randn(2, cin, h, w, dtype=torch.float64)
+    wt = torch.randn(cin, cout, k, k, dtype=torch.float64)
+    ref = F.conv_transpose2d(x, wt, stride=stride, padding=pad, output_padding=opad)
+    out_hw = ((h - 1) * stride - 2 * pad + k + opad, (w - 1) * stride - 2 * pad + k + opad)
+    assert tuple(ref.shape[2:]) == out_hw
+    phases = conv2d_mfma.transposed_phases(k, k, stride, pad, pad, (h, w), out_hw)
+    y = torch.full_like(ref, float('nan'))
+    for ph in phases:
+        wsel = wt[:, :, ph['ky'], :][:, :, :, ph['kx']].transpose(0, 1)          # OIHW gather-form weights
+        jy, jx = len(ph['ky']), len(ph['kx'])
+        oh, ow = ph['out_hw']
+        py, px = ph['pad']
+        # emulate one pg_conv2d_forward launch: y[oy] = sum_t w[t] * x[oy + t - pad], zero outside
+        big = F.pad(x, (max(px, 0) + jx, jx + ow, max(py, 0) + jy, jy + oh))
+        oy0, ox0 = max(py, 0) + jy - py, max(px, 0) + jx - px
+        part = F.conv2d(big, wsel)[:, :, oy0:oy0 + oh, ox0:ox0 + ow]
+        y[:, :, ph['off'][0]::stride, ph['off'][1]::stride][:, :, :oh, :ow] = part
+    assert not torch.isnan(y).any(), 'some output position is covered by no phase'
+    torch.testing.assert_close(y, ref, rtol=1e-10, atol=1e-10)
+
+
+def test_transposed_phases_rejects_kernel_smaller_than_stride():
+    from torch_utils.ops import conv2d_mfma
+    assert conv2d_mfma.transposed_phases(1, 1, 2, 0, 0, (4, 4), (7, 7)) is None
+
+
+def test_infinite_sampler_partitions_ranks():
+    from torch_utils import misc
+    data = list(range(10))
+    streams = []
+    for rank in range(2):
+        it = iter(misc.InfiniteSampler(data, rank=rank, num_replicas=2, shuffle=True, seed=3, window_size=0))
+        streams.append([int(next(it)) for _ in range(10)])
+    merged = [v for pair in zip(*streams) for v in pair]
+    assert sorted(merged[:10]) == data      # one epoch split across ranks covers every index once

@@ -60,27 +60,30 @@ def init_weights(net):
     return fill_module_(net, 'cfg2.')      # name-keyed N(0,1) weights, noise_strength 0.1
 
 
-def cpu_baseline(max_seconds=45.0):
-    """Oracle network on the host cores, N=1, fp32: 1 warm-up + up to 2 timed images (bounded)."""
+def cpu_baseline(max_seconds=40.0):
+    """Oracle network on the host cores, N=1, fp32, bounded: one cold image, then up to 2 more while
+    the budget lasts; the fastest is reported.  Threads are capped at 16 (the box reports 256 logical
+    CPUs, where oneDNN's small convolutions oversubscribe badly)."""
     from oracle import network_ref as NR
-    threads = os.cpu_count() or 1
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    threads = max(1, min(16, avail))
     torch.set_num_threads(threads)
     net = init_weights(NR.SynthesisNetworkFull_v18(**CFG2)).eval()
     inp = make_inputs(1, 'cpu', seed=0)
     times = []
     t_start = time.perf_counter()
     with torch.no_grad():
-        run_net(net, inp)                                   # warm-up (oneDNN primitive creation)
-        while len(times) < 2 and time.perf_counter() - t_start < max_seconds:
+        while len(times) < 3 and (not times or time.perf_counter() - t_start + min(times) < max_seconds):
             t0 = time.perf_counter()
             run_net(net, inp)
             times.append(time.perf_counter() - t0)
-    if not times:
-        times = [time.perf_counter() - t_start]
-    times.sort()
-    med = times[len(times) // 2]
-    return dict(value=1.0 / med, unit='images/s', cores=threads, kind='port',
-                sample=f'oracle/network_ref.py SynthesisNetworkFull_v18 fwd, N=1, 512^2, fp32, 1 warm-up + {len(times)} timed image(s), median')
+    best = min(times)
+    return dict(value=round(1.0 / best, 5), unit='images/s', cores=threads, kind='port',
+                sample=f'oracle/network_ref.py SynthesisNetworkFull_v18 fwd, N=1, 512^2, fp32, {len(times)} image(s) timed one by one '
+                       f'({", ".join(f"{t:.1f}s" for t in times)}), fastest reported; host reports {avail} logical CPUs')
 
 
 def main():

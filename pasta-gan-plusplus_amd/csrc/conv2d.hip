@@ -149,6 +149,11 @@ PG_EXPORT int pg_conv2d_forward(const float* x, const float* packed_w, float* y,
     if (N <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0 || OH <= 0 || OW <= 0) return PG_ERR_INVALID_ARG;
     if (out_step_y < 1 || out_step_x < 1) return PG_ERR_INVALID_ARG;
     if ((int64_t)Cin * H * W > 0x7fffffffLL || (int64_t)16 * H * W > 0x7fffffffLL) return PG_ERR_TOO_LARGE;
+    {   // the epilogue indexes y (and residual / noise) with 32-bit element offsets
+        int64_t ext = 1 + (int64_t)(N - 1) * ystride[0] + (int64_t)(Cout - 1) * ystride[1] +
+                      ((int64_t)(OH - 1) * out_step_y + out_off_y) * ystride[2] + ((int64_t)(OW - 1) * out_step_x + out_off_x) * ystride[3];
+        if (ext > 0x7fffffffLL || (int64_t)N * OH * OW > 0x7fffffffLL) return PG_ERR_TOO_LARGE;
+    }
     ConvParams p;
     p.x = x; p.wp = packed_w; p.y = y;
     p.N = N; p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout; p.CoutP = round_up(Cout, 32); p.OH = OH; p.OW = OW;
@@ -167,6 +172,7 @@ PG_EXPORT int pg_conv2d_forward(const float* x, const float* packed_w, float* y,
     if (p.f.in_act == 0) p.f.in_act = PG_ACT_LINEAR;
     if (p.f.act == 0) p.f.act = PG_ACT_LINEAR;
     if (p.f.in_act < PG_ACT_LINEAR || p.f.in_act > PG_ACT_SWISH || p.f.act < PG_ACT_LINEAR || p.f.act > PG_ACT_SWISH) return PG_ERR_INVALID_ARG;
+    if (p.f.in_act > PG_ACT_LRELU || p.f.act > PG_ACT_LRELU) return PG_ERR_UNSUPPORTED;   // fused stages: linear / relu / lrelu only
     p.in_xform = (p.f.in_bias || p.f.in_act != PG_ACT_LINEAR || p.f.in_gain != 1.f || p.f.in_clamp >= 0.f) ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
 

@@ -43,3 +43,16 @@ def no_ref(opname):
     raise NotImplementedError(
         f"{opname}(impl='ref'): the product ships no reference implementation; "
         "use oracle/ops_ref.py (test infrastructure) for the CPU restatement.")
+
+
+def is_dense(t):
+    """True if `t` occupies one gap-free, non-overlapping block of memory in some dimension order
+    (what the reference plugin checks with is_non_overlapping_and_dense(), bias_act.cpp:48)."""
+    if t.numel() == 0:
+        return True
+    expected = 1
+    for st, sz in sorted((st, sz) for sz, st in zip(t.shape, t.stride()) if sz != 1):
+        if st != expected:
+            return False
+        expected *= sz
+    return True

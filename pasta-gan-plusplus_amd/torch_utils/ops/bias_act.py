@@ -65,7 +65,7 @@ def _native_bias_act(x, b, xref, yref, dy, grad, dim, act_idx, alpha, gain, clam
     for name, t in (('xref', xref), ('yref', yref), ('dy', dy)):
         if t is not None and (t.dtype != x.dtype or t.device != x.device or not _same_layout(t, x)):
             raise nat.NativeOpError(f'bias_act: {name} must have the same shape, dtype, device and layout as x')
-    if not x.is_non_overlapping_and_dense():
+    if not nat.is_dense(x):
         raise nat.NativeOpError('bias_act: x must be non-overlapping and dense')
     if b is not None:
         if b.ndim != 1 or b.dtype != x.dtype or b.device != x.device or not b.is_contiguous():
@@ -112,7 +112,7 @@ def bias_act(x, b=None, dim=1, act='linear', alpha=None, gain=None, clamp=None, 
 
 def _dense(t):
     """Contiguous in its own memory format (channels_last kept, like bias_act.py:148)."""
-    if t.is_non_overlapping_and_dense():
+    if nat.is_dense(t):
         return t
     fmt = torch.channels_last if t.ndim == 4 and t.stride(1) == 1 else torch.contiguous_format
     return t.contiguous(memory_format=fmt)

@@ -16,6 +16,8 @@ from . import _native as nat
 
 ACT_INDEX = {'linear': 1, 'relu': 2, 'lrelu': 3, 'tanh': 4, 'sigmoid': 5, 'elu': 6, 'selu': 7, 'softplus': 8, 'swish': 9}
 
+FUSED_ACTS = ('linear', 'relu', 'lrelu')     # activations the conv prologue/epilogue can apply (csrc/conv2d_kernel.h)
+
 # (KH, KW, stride) geometries instantiated in csrc/conv2d_inst_*.hip
 SUPPORTED = {(3, 3, 1), (1, 1, 1), (2, 2, 1), (2, 1, 1), (1, 2, 1), (7, 7, 1), (3, 3, 2), (1, 1, 2)}
 

@@ -228,7 +228,7 @@ class _ConvBase(nn.Module):
 
     def _fast_geometry(self):
         k = int(self.weight.shape[2])
-        return self.up == 1 and conv2d_mfma.supported(k, k, self.down)
+        return self.up == 1 and conv2d_mfma.supported(k, k, self.down) and self.activation in conv2d_mfma.FUSED_ACTS
 
 
 class Conv2dLayer(_ConvBase):
@@ -378,7 +378,7 @@ class SynthesisLayer(nn.Module):
             noise = self.noise_const * self.noise_strength
         act_gain = self.act_gain * gain
         act_clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
-        if _fast_ok(x, self.weight, self.bias, styles, noise):
+        if _fast_ok(x, self.weight, self.bias, styles, noise) and self.activation in conv2d_mfma.FUSED_ACTS:
             ep = dict(bias=self.bias, act=self.activation, alpha=bias_act.activation_funcs[self.activation].def_alpha, gain=act_gain, clamp=act_clamp)
             return modulated_conv2d(x=x, weight=self.weight, styles=styles, noise=noise, up=self.up, padding=self.padding,
                                     resample_filter=self.resample_filter, flip_weight=(self.up == 1), fused_modconv=fused_modconv,

@@ -24,6 +24,7 @@
 // TFLOP/s f32 matrix peak.
 
 #pragma once
+#include <type_traits>
 #include "pg_act.h"
 
 namespace pgconv {
@@ -39,12 +40,35 @@ struct ConvParams {
     int pad_y, pad_x;
     int64_t ys[4];
     int osy, osx, ooy, oox;
-    int tilesX, tilesY, mblocks;
+    int tilesX, tilesY, mblocks, total_tiles;
     int in_xform;          // prologue bias/act/gain/clamp stage on
     pg_conv2d_fusion f;
 };
 
 constexpr int TH = 8, TW = 32;   // output tile of one workgroup (rows x cols)
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// ---- LDS-DMA (global -> LDS without staging registers), issued from inline asm.
+// hipcc (ROCm 7.2) tracks the builtin forms so conservatively that it puts `s_waitcnt vmcnt(0)` in front of every
+// global_load_lds, serialising the transfers; from asm the compiler counts nothing, so the kernel waits itself
+// (`dma_wait_all()` before the barrier that precedes the first ds_read of the landed buffer).
+// LDS destination = M0 (wave-uniform byte offset) + lane * size; M0 is written in the same statement that uses it
+// and restored, as it is compiler-reserved (cdna_hip_programming.md section 5.7).
+__device__ __forceinline__ unsigned lds_offset(const float* p) {
+    return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) float*)p;
+}
+__device__ __forceinline__ void dma_dword(i32x4 rsrc, unsigned lds_byte, unsigned voff_bytes, int soff_bytes) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dword %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_byte), "v"(voff_bytes), "s"(rsrc), "s"(soff_bytes) : "memory");
+}
+__device__ __forceinline__ void dma_dwordx4(const float* gsrc, unsigned lds_byte) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_byte), "v"(gsrc) : "memory");
+}
+__device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 template <int KH, int KW, int S, int BM, int KC>
 struct Geo {
@@ -53,14 +77,14 @@ struct Geo {
     static constexpr int IW_T = (TW - 1) * S + KW;
     static constexpr int PLANE = IH_T * IW_T;
     static constexpr int NX = KC * PLANE;                 // staged input floats per chunk
-    static constexpr int XPT = (NX + 255) / 256;          // per thread
+    static constexpr int XPT = (NX + 255) / 256;          // dword DMA instructions per thread per chunk
     static constexpr int NW4 = KC * T * BM / 4;           // staged weight float4s per chunk
-    static constexpr int WPT = (NW4 + 255) / 256;
+    static constexpr int WPT = (NW4 + 255) / 256;         // 16-byte DMA instructions per thread per chunk
     static constexpr int MT = BM / 32;
     static constexpr int NT = 2;
-    static constexpr int LDS_X = NX;                      // floats
-    static constexpr int LDS_W = KC * T * BM;
-    static constexpr int LDS_BUF = LDS_X + LDS_W;          // one staging buffer (floats)
+    static constexpr int LDS_X = XPT * 256;               // floats; padded to whole wave-instructions
+    static constexpr int LDS_W = WPT * 256 * 4;
+    static constexpr int LDS_BUF = LDS_X + LDS_W;         // one staging buffer (floats)
     static constexpr size_t LDS_BYTES = (size_t)2 * LDS_BUF * 4;   // double buffered
 };
 
@@ -69,139 +93,101 @@ struct Geo {
 // run bias_act separately for those.
 __device__ __forceinline__ float act_slope(int act, float alpha) { return act == PG_ACT_LINEAR ? 1.f : (act == PG_ACT_RELU ? 0.f : alpha); }
 
-template <int KH, int KW, int S, int BM, int KC>
+template <int KH, int KW, int S, int BM, int KC, bool XF>
 __global__ __launch_bounds__(256, 4) void conv2d_mfma(ConvParams p) {
     typedef Geo<KH, KW, S, BM, KC> G;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    // two staging buffers, each { xs[KC][IH_T][IW_T], ws[KC][T][BM] }, then the per-channel constants
-    float* cs = smem + 2 * G::LDS_BUF;          // [cin_loop] prologue scale  (1 where off)
+    // LDS (one array): two staging buffers { xs[KC][IH_T][IW_T] (+pad), ws[KC][T][BM] (+pad) }, the prologue
+    // scale of two consecutive tiles cs[2][cin_loop], the epilogue constants ep_scale/ep_bias[BM].
     const int cin_loop = ((p.Cin + KC - 1) / KC) * KC;
-    float* cb = cs + cin_loop;                  // [cin_loop] prologue bias   (0 where off)
+    const int nchunks = cin_loop / KC;
+    float* cs0 = smem + 2 * G::LDS_BUF;
+    float* ep_scale = cs0 + 2 * cin_loop;
+    float* ep_bias = ep_scale + BM;
 
-    // ---- workgroup -> (n, tile, m-block), XCD-aware: each XCD gets a contiguous range of
-    // logical tiles so neighbouring tiles / m-blocks of one tile share that XCD's L2.
-    const int total = gridDim.x, id = blockIdx.x;
-    const int q = total >> 3, r8 = total & 7, xcd = id & 7;
-    int L = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (id >> 3);
-    const int mb = L % p.mblocks; L /= p.mblocks;
-    const int tx = L % p.tilesX; L /= p.tilesX;
-    const int ty = L % p.tilesY;
-    const int n = L / p.tilesY;
-
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const unsigned smem_b = __builtin_amdgcn_readfirstlane(lds_offset(smem));
     const int half = lane >> 5, l31 = lane & 31;
-    const int oy0 = ty * TH, ox0 = tx * TW, m0 = mb * BM;
     const int HW = p.H * p.W;
+    const int total = p.total_tiles;
+    const int q8 = total >> 3, r8 = total & 7;
 
-    // ---- per-channel prologue constants -> LDS (so the staging loop has no dependent global loads)
-    {
-        const float* in_scale = p.f.in_scale ? p.f.in_scale + (int64_t)n * p.Cin : nullptr;
-        for (int c = t; c < cin_loop; c += 256) {
-            const bool ok = c < p.Cin;
-            cs[c] = (in_scale && ok) ? in_scale[c] : 1.f;
-            cb[c] = (p.f.in_bias && ok) ? p.f.in_bias[c] : 0.f;
-        }
-    }
-
-    // ---- per-thread staging map of the input halo tile (independent of the chunk): BYTE offsets into
-    // image n, or a sentinel >= 2^31 for halo elements outside the image.  The tile is fetched with raw
-    // buffer loads whose hardware range check returns 0 for the sentinel AND for channels >= Cin, so zero
-    // padding costs neither a branch nor a select.
+    // ---- state of the tile whose chunks are being requested
+    int n = 0, oy0 = 0, ox0 = 0, m0 = 0;
     unsigned xoff[G::XPT];
-    unsigned xok = 0;
+    i32x4 xrsrc;
+
+    // Tile -> (n, tile_y, tile_x, m-block), XCD-aware: workgroups sharing an XCD (id % 8) walk one contiguous
+    // range of logical tiles, so neighbouring tiles and the m-blocks of one tile hit the same L2.
+    // Staging map of the halo tile: BYTE offsets into image n, or a sentinel >= 2^31 for halo elements outside
+    // the image.  The tile is fetched by buffer loads whose hardware range check returns 0 for the sentinel AND
+    // for channels >= Cin, so zero padding costs neither a branch nor a select.
+    auto prep_tile = [&](int tile, float* cs) {
+        const int xcd = tile & 7;
+        int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (tile >> 3);
+        const int mb = L % p.mblocks; L /= p.mblocks;
+        const int tx = L % p.tilesX; L /= p.tilesX;
+        const int ty = L % p.tilesY;
+        n = L / p.tilesY;
+        oy0 = ty * TH; ox0 = tx * TW; m0 = mb * BM;
+        const float* in_scale = p.f.in_scale ? p.f.in_scale + (int64_t)n * p.Cin : nullptr;
+        for (int c = t; c < cin_loop; c += 256) cs[c] = (in_scale && c < p.Cin) ? in_scale[c] : 1.f;
+        // Opaque copy of the thread id: without it the compiler hoists the tile-independent index maths of every
+        // element out of the persistent loop and keeps ~20 values live in VGPRs (spilling at 4 waves/SIMD).
+        int tt = t;
+        asm volatile("" : "+v"(tt));
 #pragma unroll
-    for (int i = 0; i < G::XPT; i++) {
-        const int e = t + 256 * i;
-        const int c = e / G::PLANE, rem = e % G::PLANE;
-        const int rr = rem / G::IW_T, cc = rem % G::IW_T;
-        const int gy = oy0 * S - p.pad_y + rr, gx = ox0 * S - p.pad_x + cc;
-        const bool ok = e < G::NX && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-        xoff[i] = ok ? (unsigned)(c * HW + gy * p.W + gx) * 4u : 0x80000000u;
-        xok |= ok ? (1u << i) : 0u;
-    }
-    const float* xn = p.x + (int64_t)n * p.Cin * HW;
-    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xn, 0, p.Cin * HW * 4, 0x00020000);
+        for (int i = 0; i < G::XPT; i++) {
+            const int e = tt + 256 * i;
+            const int c = e / G::PLANE, rem = e % G::PLANE;
+            const int rr = rem / G::IW_T, cc = rem % G::IW_T;
+            const int gy = oy0 * S - p.pad_y + rr, gx = ox0 * S - p.pad_x + cc;
+            const bool ok = e < G::NX && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+            xoff[i] = ok ? (unsigned)(c * HW + gy * p.W + gx) * 4u : 0x80000000u;
+        }
+        // raw buffer descriptor of image n: base, stride 0, num_records = bytes, flags as make_buffer_rsrc's 0x00020000
+        const uint64_t base = (uint64_t)(uintptr_t)(p.x + (int64_t)n * p.Cin * HW);
+        xrsrc[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)base);
+        xrsrc[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(base >> 32) & 0xffff);
+        xrsrc[2] = p.Cin * HW * 4;
+        xrsrc[3] = 0x00020000;
+    };
 
-    float xr[G::XPT];
-    f32x4 wr[G::WPT];
-
-    // Unconditional loads from always-valid addresses + selects: no exec-mask branches, so the
-    // compiler issues the whole batch back to back and waits once.
-    auto load_chunk = [&](int c0) {
+    // Request one K chunk: global -> LDS directly (no staging registers, no ds_write).  Each wave-instruction
+    // writes 64 lanes x 4 B (input) or 64 x 16 B (weights) contiguously at a wave-uniform LDS base; the input
+    // gather address is per lane.
+    auto issue_chunk = [&](int c0, int buf) {
+        const unsigned xs_b = smem_b + (unsigned)(buf * G::LDS_BUF + 64 * wave) * 4u;            // bytes, wave-uniform
+        const unsigned ws_b = smem_b + (unsigned)(buf * G::LDS_BUF + G::LDS_X + 256 * wave) * 4u;
         const int soff = c0 * HW * 4;                       // wave-uniform chunk offset
 #pragma unroll
-        for (int i = 0; i < G::XPT; i++)
-            xr[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, xoff[i], soff, 0));
+        for (int i = 0; i < G::XPT; i++) dma_dword(xrsrc, xs_b + 1024u * i, xoff[i], soff);
         const float* wb = p.wp + (int64_t)c0 * G::T * p.CoutP + m0;
 #pragma unroll
         for (int i = 0; i < G::WPT; i++) {
             int e4 = t + 256 * i;
-            if (G::NW4 % 256 != 0 && e4 >= G::NW4) e4 = G::NW4 - 1;     // clamp: harmless duplicate read
+            if (G::NW4 % 256 != 0 && e4 >= G::NW4) e4 = G::NW4 - 1;     // clamp: the pad lanes copy a duplicate
             const int row = (e4 * 4) / BM, col = (e4 * 4) % BM;
-            wr[i] = *(const f32x4*)(wb + (int64_t)row * p.CoutP + col);
+            dma_dwordx4(wb + (int64_t)row * p.CoutP + col, ws_b + 4096u * i);
         }
     };
 
     const float in_slope = act_slope(p.f.in_act, p.f.in_alpha);
     const float in_cl = p.f.in_clamp >= 0.f ? p.f.in_clamp : __builtin_inff();
-
-    auto store_chunk = [&](int c0, int buf) {
-        float* xs = smem + buf * G::LDS_BUF;
-        float* ws = xs + G::LDS_X;
-        if (!p.in_xform) {
-#pragma unroll
-            for (int i = 0; i < G::XPT; i++) {
-                const int e = t + 256 * i;
-                const float v = xr[i] * cs[c0 + e / G::PLANE];             // padding is 0 and stays 0
-                if (G::NX % 256 == 0 || e < G::NX) xs[e] = v;
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < G::XPT; i++) {
-                const int e = t + 256 * i;
-                const int c = c0 + e / G::PLANE;
-                float v = xr[i] * cs[c] + cb[c];
-                v = v > 0.f ? v : v * in_slope;
-                v = fminf(fmaxf(v * p.f.in_gain, -in_cl), in_cl);
-                const bool ok = ((xok >> i) & 1u) && c < p.Cin;            // zero padding stays zero (conv pads AFTER the activation)
-                if (G::NX % 256 == 0 || e < G::NX) xs[e] = ok ? v : 0.f;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < G::WPT; i++) {
-            const int e4 = t + 256 * i;
-            if (G::NW4 % 256 == 0 || e4 < G::NW4) *(f32x4*)(ws + e4 * 4) = wr[i];
-        }
-    };
+    const float in_gain = p.f.in_gain;
 
     f32x16 acc[G::MT][G::NT];
-#pragma unroll
-    for (int mt = 0; mt < G::MT; mt++)
-#pragma unroll
-        for (int nt = 0; nt < G::NT; nt++)
-#pragma unroll
-            for (int k = 0; k < 16; k++) acc[mt][nt][k] = 0.f;
 
-    // operand base addresses inside LDS buffer 0 (floats)
-    const float* a_base0 = smem + G::LDS_X + half * (G::T * BM) + l31;
-    const float* b_base0 = smem + half * G::PLANE + (wave * 2 * S) * G::IW_T + l31 * S;
-
-    // Pipeline (one barrier per chunk): while chunk k is multiplied out of buffer k&1, chunk k+1 -- fetched
-    // during the previous iteration -- is written to the other buffer, and chunk k+2 is in flight to registers.
-    const int nchunks = cin_loop / KC;
-    load_chunk(0);
-    __syncthreads();                                       // cs / cb visible
-    store_chunk(0, 0);
-    if (nchunks > 1) load_chunk(KC);
-    __syncthreads();
-
-    for (int k = 0; k < nchunks; k++) {
-        if (k + 1 < nchunks) store_chunk((k + 1) * KC, (k + 1) & 1);   // that buffer was last read in iteration k-1 (barrier below)
-        if (k + 2 < nchunks) load_chunk((k + 2) * KC);                 // lands during the MFMAs
-        const float* a_base = a_base0 + (k & 1) * G::LDS_BUF;
-        const float* b_base = b_base0 + (k & 1) * G::LDS_BUF;
+    // Multiply one chunk out of LDS buffer `buf`.  The prologue (modulation scale, SPADE pre-activation without
+    // bias: act(0) = 0 keeps the zero padding) is applied to the B operand as it is read: a few VALU ops per
+    // 64-cycle MFMA pair, on the otherwise idle vector pipe.
+    auto compute_chunk = [&](int buf, const float* cs, int c0) {
+        const float* a_base = smem + buf * G::LDS_BUF + G::LDS_X + half * (G::T * BM) + l31;
+        const float* b_base = smem + buf * G::LDS_BUF + half * G::PLANE + (wave * 2 * S) * G::IW_T + l31 * S;
 #pragma unroll
         for (int cp = 0; cp < KC / 2; cp++) {
+            const float sc = cs[c0 + 2 * cp + half];
 #pragma unroll
             for (int ky = 0; ky < KH; ky++) {
 #pragma unroll
@@ -210,104 +196,174 @@ __global__ __launch_bounds__(256, 4) void conv2d_mfma(ConvParams p) {
 #pragma unroll
                     for (int mt = 0; mt < G::MT; mt++) a[mt] = a_base[((2 * cp) * G::T + ky * KW + kx) * BM + mt * 32];
 #pragma unroll
-                    for (int nt = 0; nt < G::NT; nt++) b[nt] = b_base[(2 * cp) * G::PLANE + (nt * S + ky) * G::IW_T + kx];
+                    for (int nt = 0; nt < G::NT; nt++) {
+                        float v = b_base[(2 * cp) * G::PLANE + (nt * S + ky) * G::IW_T + kx] * sc;
+                        if (XF) {
+                            v = v > 0.f ? v : v * in_slope;
+                            v = fminf(fmaxf(v * in_gain, -in_cl), in_cl);
+                        }
+                        b[nt] = v;
+                    }
 #pragma unroll
                     for (int mt = 0; mt < G::MT; mt++)
 #pragma unroll
                         for (int nt = 0; nt < G::NT; nt++)
                             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
                 }
+                // keep the scheduler from hoisting every LDS read of the chunk to the top (that costs > 100 VGPRs
+                // and forces spills at 4 waves/SIMD); one kernel row of operands in flight is plenty
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
-        __syncthreads();
-    }
+    };
 
-    // ---- epilogue.  Per-cout constants go through LDS (free now); every load below is unconditional
-    // from a clamped, always-valid address, so nothing serialises behind a branch.
-    float* ep_scale = smem;            // [BM]
-    float* ep_bias = smem + BM;        // [BM]
-    if (t < BM) {
-        const int co = m0 + t;
-        const bool ok = co < p.Cout;
-        const int cc = ok ? co : 0;
-        const float sc = p.f.out_scale ? p.f.out_scale[(int64_t)n * p.Cout + cc] : 1.f;
-        const float bi = p.f.bias ? p.f.bias[cc] : 0.f;
-        ep_scale[t] = ok ? sc : 0.f;
-        ep_bias[t] = ok ? bi : 0.f;
-    }
-    __syncthreads();
-
-    const int ox = ox0 + l31;
-    const int oxc = ox < p.OW ? ox : p.OW - 1;
     const float gain = p.f.gain;
     const float cl = p.f.clamp >= 0.f ? p.f.clamp : __builtin_inff();
     const float slope = act_slope(p.f.act, p.f.alpha);
+
+    // ---- persistent loop over this workgroup's tiles: one continuous stream of K chunks through the two LDS
+    // buffers, one barrier per chunk.  While chunk g is multiplied, chunk g+1 is in flight -- the next chunk of
+    // the same tile or, on a tile's last chunk, the FIRST chunk of the next tile, so the next tile's load latency
+    // and this tile's output stores both hide behind MFMAs.
+    int tile = blockIdx.x;
+    int par = 0;                       // which cs[] half the current tile uses
+    int g = 0;                         // running chunk counter -> LDS buffer g & 1
+    prep_tile(tile, cs0);
+    issue_chunk(0, 0);
+    dma_wait_all();
+    __syncthreads();                   // DMA landed, cs published
+    while (true) {
 #pragma unroll
-    for (int nt = 0; nt < G::NT; nt++) {
-        const int oy = oy0 + wave * 2 + nt;
-        const bool pix_ok = oy < p.OH && ox < p.OW;
-        const int oyc = oy < p.OH ? oy : p.OH - 1;
-        float nz = 0.f;
-        if (p.f.noise) nz = p.f.noise[(int)(n * p.f.noise_batch_stride) + oyc * p.OW + oxc] * p.f.noise_gain;
-        const int pix_off = (int)((int64_t)n * p.ys[0] + (int64_t)(oyc * p.osy + p.ooy) * p.ys[2] + (int64_t)(oxc * p.osx + p.oox) * p.ys[3]);
-        const int cstride = (int)p.ys[1];
+        for (int mt = 0; mt < G::MT; mt++)
 #pragma unroll
-        for (int mt = 0; mt < G::MT; mt++) {
+            for (int nt = 0; nt < G::NT; nt++)
 #pragma unroll
-            for (int kq = 0; kq < 4; kq++) {                 // 4 consecutive couts at a time keeps the live state small
-                const int row0 = mt * 32 + 8 * kq + 4 * half;
-                const f32x4 sc4 = *(const f32x4*)(ep_scale + row0);
-                const f32x4 bi4 = *(const f32x4*)(ep_bias + row0);
-                int off[4];
-                float rv[4];
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const int co = m0 + row0 + j;
-                    off[j] = pix_off + (co < p.Cout ? co : p.Cout - 1) * cstride;
-                    rv[j] = 0.f;
+                for (int k = 0; k < 16; k++) acc[mt][nt][k] = 0.f;
+
+        int e_n = n, e_oy0 = oy0, e_ox0 = ox0, e_m0 = m0;
+        bool has_next = false;
+        int next = tile;
+        const float* cs_cur = cs0 + par * cin_loop;
+        for (int k = 0; k < nchunks; k++, g++) {
+            const int buf = g & 1;
+            if (k + 1 < nchunks) {
+                issue_chunk((k + 1) * KC, buf ^ 1);        // that buffer was last read in the previous iteration (barrier below)
+            } else {
+                // last chunk of this tile: publish its epilogue constants, then stage the next tile
+                e_n = n; e_oy0 = oy0; e_ox0 = ox0; e_m0 = m0;
+                if (t < BM) {
+                    const int co = e_m0 + t;
+                    const bool ok = co < p.Cout;
+                    const int cc = ok ? co : 0;
+                    const float sc = p.f.out_scale ? p.f.out_scale[(int64_t)e_n * p.Cout + cc] : 1.f;
+                    const float bi = p.f.bias ? p.f.bias[cc] : 0.f;
+                    ep_scale[t] = ok ? sc : 0.f;
+                    ep_bias[t] = ok ? bi : 0.f;
                 }
-                if (p.f.residual) {
-#pragma unroll
-                    for (int j = 0; j < 4; j++) rv[j] = p.f.residual[off[j]];
+                next = tile + gridDim.x;
+                has_next = next < total;
+                if (has_next) {
+                    prep_tile(next, cs0 + (par ^ 1) * cin_loop);
+                    issue_chunk(0, buf ^ 1);
                 }
+            }
+            compute_chunk(buf, cs_cur, k * KC);
+            dma_wait_all();            // the chunk requested above has landed (also drains this wave's older stores)
+            __syncthreads();
+        }
+
+        // ---- epilogue of this tile: D layout col = lane&31 (pixel), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (cout).
+        // Per-cout constants come from LDS; every load is unconditional from a clamped, always-valid address.
+        const int ox = e_ox0 + l31;
+        const int oxc = ox < p.OW ? ox : p.OW - 1;
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    float v = acc[mt][nt][4 * kq + j] * sc4[j] + nz + bi4[j];
-                    v = v > 0.f ? v : v * slope;
-                    v = fminf(fmaxf(v * gain, -cl), cl) + rv[j];
-                    if (pix_ok && m0 + row0 + j < p.Cout) p.y[off[j]] = v;
+        for (int nt = 0; nt < G::NT; nt++) {
+            const int oy = e_oy0 + wave * 2 + nt;
+            const bool pix_ok = oy < p.OH && ox < p.OW;
+            const int oyc = oy < p.OH ? oy : p.OH - 1;
+            float nz = 0.f;
+            if (p.f.noise) nz = p.f.noise[(int)(e_n * p.f.noise_batch_stride) + oyc * p.OW + oxc] * p.f.noise_gain;
+            const int pix_off = (int)((int64_t)e_n * p.ys[0] + (int64_t)(oyc * p.osy + p.ooy) * p.ys[2] + (int64_t)(oxc * p.osx + p.oox) * p.ys[3]);
+            const int cstride = (int)p.ys[1];
+#pragma unroll
+            for (int mt = 0; mt < G::MT; mt++) {
+#pragma unroll
+                for (int kq = 0; kq < 4; kq++) {                 // 4 consecutive couts at a time keeps the live state small
+                    const int row0 = mt * 32 + 8 * kq + 4 * half;
+                    const f32x4 sc4 = *(const f32x4*)(ep_scale + row0);
+                    const f32x4 bi4 = *(const f32x4*)(ep_bias + row0);
+                    int off[4];
+                    float rv[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const int co = e_m0 + row0 + j;
+                        off[j] = pix_off + (co < p.Cout ? co : p.Cout - 1) * cstride;
+                        rv[j] = 0.f;
+                    }
+                    if (p.f.residual) {
+#pragma unroll
+                        for (int j = 0; j < 4; j++) rv[j] = p.f.residual[off[j]];
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        float v = acc[mt][nt][4 * kq + j] * sc4[j] + nz + bi4[j];
+                        v = v > 0.f ? v : v * slope;
+                        v = fminf(fmaxf(v * gain, -cl), cl) + rv[j];
+                        if (pix_ok && e_m0 + row0 + j < p.Cout) p.y[off[j]] = v;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);   // do not hoist the next groups' constant reads (register pressure)
                 }
             }
         }
+        if (!has_next) break;
+        tile = next;
+        par ^= 1;
     }
 }
 
-template <int KH, int KW, int S, int BM, int KC>
-int launch_conv(const ConvParams& p0, hipStream_t s) {
+template <int KH, int KW, int S, int BM, int KC, bool XF>
+int launch_conv_xf(const ConvParams& p0, hipStream_t s) {
     typedef Geo<KH, KW, S, BM, KC> G;
     ConvParams p = p0;
     p.tilesX = (p.OW + TW - 1) / TW;
     p.tilesY = (p.OH + TH - 1) / TH;
     p.mblocks = p.CoutP / BM;
-    const int64_t blocks = (int64_t)p.N * p.tilesX * p.tilesY * p.mblocks;
-    if (blocks > 0x7fffffffLL) return PG_ERR_TOO_LARGE;
+    const int64_t tiles = (int64_t)p.N * p.tilesX * p.tilesY * p.mblocks;
+    if (tiles > 0x7fffffffLL) return PG_ERR_TOO_LARGE;
+    p.total_tiles = (int)tiles;
+    const int cin_loop = ((p.Cin + KC - 1) / KC) * KC;
+    const size_t lds = G::LDS_BYTES + ((size_t)2 * cin_loop + 2 * BM) * sizeof(float);
+    if (lds > 160 * 1024) return PG_ERR_UNSUPPORTED;
+    // persistent grid: as many workgroups as stay resident (4 per CU by registers; fewer if LDS-limited);
+    // every workgroup walks tiles id, id + grid, ...
+    int per_cu = (int)((160 * 1024) / lds);
+    if (per_cu > 4) per_cu = 4;
+    if (per_cu < 1) per_cu = 1;
+    const int64_t blocks = tiles < (int64_t)kNumCU * per_cu ? tiles : (int64_t)kNumCU * per_cu;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv2d_mfma<KH, KW, S, BM, KC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void*)conv2d_mfma<KH, KW, S, BM, KC, XF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    const int cin_loop = ((p.Cin + KC - 1) / KC) * KC;
-    const size_t lds = G::LDS_BYTES + (size_t)2 * cin_loop * sizeof(float);
-    if (lds > 160 * 1024) return PG_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL((conv2d_mfma<KH, KW, S, BM, KC>), dim3((unsigned)blocks), dim3(256), lds, s, p);
+    hipLaunchKernelGGL((conv2d_mfma<KH, KW, S, BM, KC, XF>), dim3((unsigned)blocks), dim3(256), lds, s, p);
     return launch_status();
 }
 
-template <int KH, int KW, int S, int KC>
+// XFORM: also instantiate the variant with the prologue activation (only the geometries SPADE layers use).
+template <int KH, int KW, int S, int BM, int KC, bool XFORM>
+int launch_conv(const ConvParams& p, hipStream_t s) {
+    if (p.in_xform) {
+        if constexpr (XFORM) return launch_conv_xf<KH, KW, S, BM, KC, true>(p, s);
+        else return PG_ERR_UNSUPPORTED;
+    }
+    return launch_conv_xf<KH, KW, S, BM, KC, false>(p, s);
+}
+
+template <int KH, int KW, int S, int KC, bool XFORM = false>
 int launch_bm(const ConvParams& p, hipStream_t s) {
-    if (p.CoutP % 64 == 0) return launch_conv<KH, KW, S, 64, KC>(p, s);
-    return launch_conv<KH, KW, S, 32, KC>(p, s);
+    if (p.CoutP % 64 == 0) return launch_conv<KH, KW, S, 64, KC, XFORM>(p, s);
+    return launch_conv<KH, KW, S, 32, KC, XFORM>(p, s);
 }
 
 

@@ -287,8 +287,9 @@ class Spade_Conv2dLayer(_ConvBase):
         act_gain = self.act_gain * gain
         act_clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
         cout, _, k, _ = self.weight.shape
-        if _fast_ok(x, self.weight, self.bias, residual) and self._fast_geometry() and self.down == 1:
-            pro = {} if no_act else dict(in_bias=self.bias, in_act=self.activation, in_gain=act_gain, in_clamp=act_clamp,
+        # a pre-activation bias cannot ride in the conv prologue (zero padding); none of the generator's SPADE convs has one
+        if _fast_ok(x, self.weight, self.bias, residual) and self._fast_geometry() and self.down == 1 and (no_act or self.bias is None):
+            pro = {} if no_act else dict(in_act=self.activation, in_gain=act_gain, in_clamp=act_clamp,
                                          in_alpha=bias_act.activation_funcs[self.activation].def_alpha)
             return conv2d_mfma.conv2d_forward(x, self._packed(False), cout, k, k, pad=(self.padding, self.padding), act=post_act, residual=residual, **pro)
         w = self.weight * self.weight_gain

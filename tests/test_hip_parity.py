@@ -281,13 +281,21 @@ def test_conv2d_fused_prologue_epilogue_vs_oracle():
     res = det_tensor('fz.res', [n, cout, h, w])
     packed = conv2d_mfma.pack_weight(wt.to(DEV), scale=0.5)
     y = conv2d_mfma.conv2d_forward(x.to(DEV), packed, cout, 3, 3, pad=(1, 1),
-                                   in_scale=styles.to(DEV), in_bias=in_b.to(DEV), in_act='relu', in_gain=1.3, in_clamp=2.0,
+                                   in_scale=styles.to(DEV), in_act='relu', in_gain=1.3, in_clamp=2.0,
                                    out_scale=dco.to(DEV), noise=noise.to(DEV), noise_gain=0.7, bias=out_b.to(DEV), act='lrelu', alpha=0.2,
                                    gain=math.sqrt(2), clamp=3.0, residual=res.to(DEV))
-    xr = R.bias_act(x * styles[:, :, None, None], in_b, act='relu', gain=1.3, clamp=2.0)
+    xr = R.bias_act(x * styles[:, :, None, None], None, act='relu', gain=1.3, clamp=2.0)
     ref = F.conv2d(xr, wt * 0.5, padding=1) * dco[:, :, None, None] + noise * 0.7
     ref = R.bias_act(ref, out_b, act='lrelu', gain=math.sqrt(2), clamp=3.0) + res
     close(y, ref, 1e-4, 1e-4)
+    # a prologue bias cannot be fused (act(0 + b) != 0 would corrupt the zero padding): rejected, never silently wrong
+    from torch_utils.ops._native import NativeOpError
+    with pytest.raises(NativeOpError):
+        conv2d_mfma.conv2d_forward(x.to(DEV), packed, cout, 3, 3, pad=(1, 1), in_bias=in_b.to(DEV), in_act='relu')
+    # lrelu prologue with modulation, 1x1 kernel (the SPADE skip path)
+    p1 = conv2d_mfma.pack_weight(wt[:, :, :1, :1].contiguous().to(DEV))
+    y1 = conv2d_mfma.conv2d_forward(x.to(DEV), p1, cout, 1, 1, in_act='lrelu', in_alpha=0.2, in_gain=math.sqrt(2))
+    close(y1, F.conv2d(R.bias_act(x, None, act='lrelu'), wt[:, :, :1, :1]), 1e-4, 1e-4)
     # flipped packing == true convolution
     yf = conv2d_mfma.conv2d_forward(x.to(DEV), conv2d_mfma.pack_weight(wt.to(DEV), flip=True), cout, 3, 3, pad=(1, 1))
     close(yf, F.conv2d(x, wt.flip([2, 3]), padding=1), 1e-4, 1e-4)

@@ -6,7 +6,7 @@
  *   bias_act_plugin.so   pg_bias_act
  *   upfirdn2d_plugin.so  pg_upfirdn2d
  *   conv2d_plugin.so     pg_conv2d_pack_weight, pg_conv2d_forward,
- *                        pg_modconv_prepare, pg_instance_norm_stats, pg_spade_norm
+ *                        pg_modconv_dcoefs, pg_instance_norm_stats, pg_spade_norm
  * plus pg_<plugin>_abi_version() in each.  They are what the reference's L1
  * Python ops bind in place of its pybind plugins (see INTEGRATION.md for the
  * ctypes stub a maintainer adds to the reference tree).
@@ -86,7 +86,7 @@ int pg_upfirdn2d_abi_version(void);
  * v_mfma_f32_32x32x2_f32 with fused prologue/epilogue.
  *
  * Weight packing: OIHW [Cout, Cin, KH, KW] -> the kernel's [CinP][KH*KW][CoutP] layout
- * (CinP = Cin rounded up to 8, CoutP = Cout rounded up to 32, zero filled), scaled by
+ * (CinP = Cin rounded up to 16, CoutP = Cout rounded up to 32, zero filled), scaled by
  * `scale` (the layers' runtime weight_gain, networks.py:171) and optionally flipped in
  * both spatial axes (flip_weight=False in conv2d_resample.py:34-35) or transposed
  * O<->I (the conv_transpose2d weight view, conv2d_resample.py:127).
@@ -99,9 +99,10 @@ int pg_conv2d_pack_weight(const float* w, float* packed, int Cout, int Cin, int 
 /* Optional fused stages of pg_conv2d_forward; every pointer may be NULL (= stage off). */
 typedef struct pg_conv2d_fusion {
     /* prologue, applied to each in-image input element before the contraction
-       (zero padding stays zero):  x' = in_act(x * in_scale[n,ci] + in_bias[ci]) * in_gain   */
+       (zero padding stays zero):  x' = clamp(in_act(x * in_scale[n,ci]) * in_gain); in_gain > 0, in_act in {linear, relu, lrelu} */
     const float* in_scale;      /* [N, Cin]  style modulation (networks.py:74)                  */
-    const float* in_bias;       /* [Cin]     Spade_Conv2dLayer pre-activation (networks.py:1627) */
+    const float* in_bias;       /* [Cin]     must be NULL: a pre-activation bias would turn the zero padding into act(b)
+                                             (PG_ERR_UNSUPPORTED); none of the generator's SPADE convs has one          */
     int          in_act;        /* pg_act; 0 or PG_ACT_LINEAR = none                             */
     float        in_alpha;
     float        in_gain;       /* used only when in_act/in_bias/in_gain stage is on (0 => 1)    */
@@ -118,6 +119,13 @@ typedef struct pg_conv2d_fusion {
     float        gain;          /* 0 => 1 */
     float        clamp;         /* < 0 = off */
     const float* residual;      /* same shape/strides as y: y += residual (ResBlock add, img.add_) */
+    /* SPADE combine mode (all three set, Cout = 2*C packed as alternating blocks of 32 gamma rows / 32 beta rows of the
+       same channels): y[n,c] = (spade_x[n,c] - spade_mean[n,c]) * spade_rstd[n,c] * (1 + gamma[n,c]) + beta[n,c]
+       (Spade_Norm_Block, networks.py:1715-1722); y and spade_x are [N, C, OH, OW] with the strides passed for y;
+       the other epilogue stages are not applied. */
+    const float* spade_x;
+    const float* spade_mean;    /* [N, C] */
+    const float* spade_rstd;    /* [N, C] */
 } pg_conv2d_fusion;
 
 /*

@@ -173,8 +173,13 @@ PG_EXPORT int pg_conv2d_forward(const float* x, const float* packed_w, float* y,
     if (p.f.act == 0) p.f.act = PG_ACT_LINEAR;
     if (p.f.in_act < PG_ACT_LINEAR || p.f.in_act > PG_ACT_SWISH || p.f.act < PG_ACT_LINEAR || p.f.act > PG_ACT_SWISH) return PG_ERR_INVALID_ARG;
     if (p.f.in_act > PG_ACT_LRELU || p.f.act > PG_ACT_LRELU) return PG_ERR_UNSUPPORTED;   // fused stages: linear / relu / lrelu only
+    if (p.f.spade_x) {
+        if (!p.f.spade_mean || !p.f.spade_rstd) return PG_ERR_INVALID_ARG;
+        if (Cout % 64 != 0 || out_step_y != 1 || out_step_x != 1) return PG_ERR_UNSUPPORTED;   // 32 gamma + 32 beta rows per 64-row tile
+    }
     if (p.f.in_bias) return PG_ERR_UNSUPPORTED;   // the prologue runs on the zero-padded tile: act(0 + b) != 0 would corrupt the padding
-    p.in_xform = (p.f.in_bias || p.f.in_act != PG_ACT_LINEAR || p.f.in_gain != 1.f || p.f.in_clamp >= 0.f) ? 1 : 0;
+    p.in_xform = (p.f.in_act != PG_ACT_LINEAR || p.f.in_gain != 1.f || p.f.in_clamp >= 0.f) ? 1 : 0;
+    if (p.in_xform && (!(p.f.in_gain > 0.f) || p.f.in_alpha < 0.f || p.f.in_alpha > 1.f)) return PG_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
 
     if (stride == 1) {

@@ -173,9 +173,11 @@ __global__ __launch_bounds__(256, 4) void conv2d_mfma(ConvParams p) {
         }
     };
 
+    // prologue activation folded to 3-4 VALU ops per operand: t = x * (scale * gain); lrelu/relu/linear(t) = max(t, t * slope)
+    // for gain > 0 and 0 <= slope <= 1 (the host guarantees both); clamp by one v_med3.
     const float in_slope = act_slope(p.f.in_act, p.f.in_alpha);
     const float in_cl = p.f.in_clamp >= 0.f ? p.f.in_clamp : __builtin_inff();
-    const float in_gain = p.f.in_gain;
+    const float in_gain = XF ? p.f.in_gain : 1.f;
 
     f32x16 acc[G::MT][G::NT];
 
@@ -187,7 +189,7 @@ __global__ __launch_bounds__(256, 4) void conv2d_mfma(ConvParams p) {
         const float* b_base = smem + buf * G::LDS_BUF + half * G::PLANE + (wave * 2 * S) * G::IW_T + l31 * S;
 #pragma unroll
         for (int cp = 0; cp < KC / 2; cp++) {
-            const float sc = cs[c0 + 2 * cp + half];
+            const float sc = cs[c0 + 2 * cp + half] * in_gain;
 #pragma unroll
             for (int ky = 0; ky < KH; ky++) {
 #pragma unroll
@@ -198,10 +200,7 @@ __global__ __launch_bounds__(256, 4) void conv2d_mfma(ConvParams p) {
 #pragma unroll
                     for (int nt = 0; nt < G::NT; nt++) {
                         float v = b_base[(2 * cp) * G::PLANE + (nt * S + ky) * G::IW_T + kx] * sc;
-                        if (XF) {
-                            v = v > 0.f ? v : v * in_slope;
-                            v = fminf(fmaxf(v * in_gain, -in_cl), in_cl);
-                        }
+                        if (XF) v = __builtin_amdgcn_fmed3f(fmaxf(v, v * in_slope), -in_cl, in_cl);
                         b[nt] = v;
                     }
 #pragma unroll
@@ -251,7 +250,13 @@ __global__ __launch_bounds__(256, 4) void conv2d_mfma(ConvParams p) {
             } else {
                 // last chunk of this tile: publish its epilogue constants, then stage the next tile
                 e_n = n; e_oy0 = oy0; e_ox0 = ox0; e_m0 = m0;
-                if (t < BM) {
+                if (p.f.spade_x) {                          // SPADE mode: per-(n, channel) mean / rstd of the normalised tensor
+                    if (t < 32) {
+                        const int ch = (e_m0 >> 1) + t;     // this tile's 32 output channels
+                        ep_scale[t] = p.f.spade_mean[e_n * (p.Cout >> 1) + ch];
+                        ep_bias[t] = p.f.spade_rstd[e_n * (p.Cout >> 1) + ch];
+                    }
+                } else if (t < BM) {
                     const int co = e_m0 + t;
                     const bool ok = co < p.Cout;
                     const int cc = ok ? co : 0;
@@ -285,6 +290,30 @@ __global__ __launch_bounds__(256, 4) void conv2d_mfma(ConvParams p) {
             if (p.f.noise) nz = p.f.noise[(int)(e_n * p.f.noise_batch_stride) + oyc * p.OW + oxc] * p.f.noise_gain;
             const int pix_off = (int)((int64_t)e_n * p.ys[0] + (int64_t)(oyc * p.osy + p.ooy) * p.ys[2] + (int64_t)(oxc * p.osx + p.oox) * p.ys[3]);
             const int cstride = (int)p.ys[1];
+            if (G::MT == 2 && p.f.spade_x) {
+                // SPADE combine: the packed weights interleave 32 gamma rows (M-tile 0) with the 32 beta rows of the
+                // same channels (M-tile 1), so one lane holds gamma and beta of one (channel, pixel):
+                //   y = (x - mean) * rstd * (1 + gamma) + beta          (networks.py:1715-1722)
+#pragma unroll
+                for (int kq = 0; kq < 4; kq++) {
+                    const int r0 = 8 * kq + 4 * half;
+                    const f32x4 mu4 = *(const f32x4*)(ep_scale + r0);
+                    const f32x4 rs4 = *(const f32x4*)(ep_bias + r0);
+                    int off[4];
+                    float xv[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) off[j] = pix_off + ((e_m0 >> 1) + r0 + j) * cstride;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) xv[j] = p.f.spade_x[off[j]];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const float v = (xv[j] - mu4[j]) * rs4[j] * (1.f + acc[0][nt][4 * kq + j]) + acc[G::MT - 1][nt][4 * kq + j];
+                        if (pix_ok) p.y[off[j]] = v;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                continue;
+            }
 #pragma unroll
             for (int mt = 0; mt < G::MT; mt++) {
 #pragma unroll

@@ -30,6 +30,7 @@ class Fusion(ctypes.Structure):
         ('out_scale', ctypes.c_void_p), ('noise', ctypes.c_void_p), ('noise_batch_stride', ctypes.c_int64), ('noise_gain', ctypes.c_float),
         ('bias', ctypes.c_void_p), ('act', ctypes.c_int), ('alpha', ctypes.c_float), ('gain', ctypes.c_float), ('clamp', ctypes.c_float),
         ('residual', ctypes.c_void_p),
+        ('spade_x', ctypes.c_void_p), ('spade_mean', ctypes.c_void_p), ('spade_rstd', ctypes.c_void_p),
     ]
 
 
@@ -104,10 +105,13 @@ def pack_weight(w, scale=1.0, flip=False, transpose_oi=False):
 def conv2d_forward(x, packed, cout, kh, kw, stride=1, pad=(0, 0), out_hw=None, y=None, out_step=(1, 1), out_off=(0, 0),
                    in_scale=None, in_bias=None, in_act='linear', in_alpha=0.0, in_gain=1.0, in_clamp=None,
                    out_scale=None, noise=None, noise_gain=1.0, bias=None, act='linear', alpha=0.0, gain=1.0, clamp=None,
-                   residual=None):
+                   residual=None, spade=None):
     """One launch of the MFMA convolution.  `x` [N,Cin,H,W] float32 contiguous; `packed` from
     `pack_weight`.  Writes y[n, co, oy*step+off, ox*step+off] for oy < out_hw[0], ox < out_hw[1]
-    (allocating a dense [N,Cout,OH,OW] `y` when none is given) and returns `y`."""
+    (allocating a dense [N,Cout,OH,OW] `y` when none is given) and returns `y`.
+    `spade=(x_norm, mean, rstd)` selects the SPADE combine epilogue: `packed` holds interleaved gamma/beta rows
+    (`pack_spade_gamma_beta`), `cout` = 2*C, and the result is the [N, C, OH, OW] tensor
+    (x_norm - mean) * rstd * (1 + gamma) + beta."""
     lib = _init().lib
     x = _f32c(x, 'x')
     n, cin, h, w = x.shape
@@ -115,11 +119,12 @@ def conv2d_forward(x, packed, cout, kh, kw, stride=1, pad=(0, 0), out_hw=None, y
     if out_hw is None:
         out_hw = ((h + 2 * pad_y - kh) // stride + 1, (w + 2 * pad_x - kw) // stride + 1)
     oh, ow = out_hw
+    ychan = cout // 2 if spade is not None else cout
     if y is None:
         assert tuple(out_step) == (1, 1) and tuple(out_off) == (0, 0)
-        y = torch.empty([n, cout, oh, ow], dtype=torch.float32, device=x.device)
+        y = torch.empty([n, ychan, oh, ow], dtype=torch.float32, device=x.device)
     else:
-        assert y.dtype == torch.float32 and y.device == x.device and y.shape[0] == n and y.shape[1] == cout
+        assert y.dtype == torch.float32 and y.device == x.device and y.shape[0] == n and y.shape[1] == ychan
     fz = Fusion()
     keep = []
 
@@ -156,6 +161,12 @@ def conv2d_forward(x, packed, cout, kh, kw, stride=1, pad=(0, 0), out_hw=None, y
             raise nat.NativeOpError('conv2d_mfma: residual must match y in dtype, shape and strides')
         keep.append(residual)
         fz.residual = residual.data_ptr()
+    if spade is not None:
+        sx, smean, srstd = spade
+        if sx.dtype != torch.float32 or sx.shape != y.shape or sx.stride() != y.stride() or smean.numel() != n * ychan or srstd.numel() != n * ychan:
+            raise nat.NativeOpError('conv2d_mfma: spade tensors must match the [N, C, OH, OW] output')
+        keep += [sx, smean, srstd]
+        fz.spade_x, fz.spade_mean, fz.spade_rstd = sx.data_ptr(), smean.data_ptr(), srstd.data_ptr()
     with torch.cuda.device(x.device):
         if _timeline is not None:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -168,6 +179,17 @@ def conv2d_forward(x, packed, cout, kh, kw, stride=1, pad=(0, 0), out_hw=None, y
             _timeline.append(((kh, kw, int(stride)), 2.0 * n * cout * oh * ow * cin * kh * kw, ev0, ev1))
     nat.check(st, 'pg_conv2d_forward')
     return y
+
+
+def pack_spade_gamma_beta(w_gamma, w_beta, scale_gamma=1.0, scale_beta=1.0):
+    """Packed weights of the fused gamma/beta convolution of a Spade_Norm_Block: rows [64j, 64j+32) are gamma channels
+    [32j, 32j+32), rows [64j+32, 64j+64) the beta rows of the same channels, so that the two M-tiles of one 64-row
+    workgroup tile hold gamma and beta of the same (channel, pixel) in the same lane."""
+    c = int(w_gamma.shape[0])
+    assert w_gamma.shape == w_beta.shape and c % 32 == 0
+    g = (w_gamma.detach() * scale_gamma).reshape(c // 32, 32, *w_gamma.shape[1:])
+    b = (w_beta.detach() * scale_beta).reshape(c // 32, 32, *w_beta.shape[1:])
+    return pack_weight(torch.cat([g, b], dim=1).reshape(2 * c, *w_gamma.shape[1:]).contiguous())
 
 
 def transposed_phases(kh, kw, stride, pad_y, pad_x, in_hw, out_hw):

@@ -311,13 +311,21 @@ class Spade_Norm_Block(nn.Module):
         self.conv_gamma = Spade_Conv2dLayer(norm_channels, norm_channels, kernel_size=3, bias=False)
         self.conv_beta = Spade_Conv2dLayer(norm_channels, norm_channels, kernel_size=3, bias=False)
         self.param_free_norm = nn.InstanceNorm2d(norm_channels, affine=False)
+        self._cache = _PackCache()
 
     def forward(self, x, denorm_feats):
         if _fast_ok(x, denorm_feats, self.conv_mlp.weight):
             mean, rstd = conv2d_mfma.instance_norm_stats(x, eps=self.param_free_norm.eps)
             actv = self.conv_mlp(denorm_feats, no_act=True, post_act='relu')     # conv + ReLU in one launch
-            gamma = self.conv_gamma(actv, no_act=True)
-            beta = self.conv_beta(actv, no_act=True)
+            g, b = self.conv_gamma, self.conv_beta
+            c = int(g.weight.shape[0])
+            if c % 32 == 0 and g._fast_geometry() and g.down == 1 and x.is_contiguous():
+                # gamma and beta convolutions as ONE launch (they share `actv`) whose epilogue applies the normalisation
+                packed = self._cache.get('gamma_beta', [g.weight, b.weight],
+                                         lambda: conv2d_mfma.pack_spade_gamma_beta(g.weight, b.weight, g.weight_gain, b.weight_gain))
+                return conv2d_mfma.conv2d_forward(actv, packed, 2 * c, 3, 3, pad=(g.padding, g.padding), spade=(x, mean, rstd))
+            gamma = g(actv, no_act=True)
+            beta = b(actv, no_act=True)
             return conv2d_mfma.spade_norm(x, mean, rstd, gamma, beta)
         normalized = self.param_free_norm(x)
         actv = self.conv_mlp_act(self.conv_mlp(denorm_feats, no_act=True))

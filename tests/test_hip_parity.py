@@ -417,6 +417,22 @@ def test_blocks_golden(golden):
         close(yp, g['torgb/parsing'], **tol)
 
 
+@pytest.mark.parametrize('c,feat_c,h,w', [(64, 5, 24, 40), (128, 16, 17, 33), (32, 1, 32, 32)])
+def test_spade_norm_block_fused_gamma_beta(c, feat_c, h, w):
+    """C % 32 == 0 takes the single-launch gamma/beta convolution with the SPADE combine epilogue."""
+    from training import networks as PN
+    from oracle import network_ref as NR
+    ref = fill_module_(NR.Spade_Norm_Block(feat_c, c), f'snb.{c}.')
+    net = _load(PN.Spade_Norm_Block(feat_c, c), ref)
+    x = det_tensor(f'snb.x.{c}', [2, c, h, w], scale=2.0) + 0.5
+    feat = det_tensor(f'snb.f.{c}', [2, feat_c, h, w])
+    with torch.no_grad():
+        y = net(x.to(DEV), feat.to(DEV))
+        want = ref(x, feat)
+    close(y, want, 2e-4, 2e-5 * scale_of(want))
+    assert 'gamma_beta' in net._cache._store        # the fused route really ran
+
+
 def test_blocks_graph_route_matches_inference_route():
     """The differentiable composition and the fused single-launch route agree, and gradients flow."""
     from training import networks as PN

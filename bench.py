@@ -103,14 +103,14 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or 'RANK' in os.environ:                   # launched by torch.distributed.run: one rank per GPU
         import torch.distributed as dist
         dist.init_process_group('nccl', device_id=dev)      # RCCL over xGMI
 
     from torch_utils import custom_ops
     custom_ops.verbosity = 'none'
     from torch_utils.ops import conv2d_mfma
-    from training import networks
+    from training import networks, replicas
 
     net = init_weights(networks.SynthesisNetworkFull_v18(**CFG2)).to(dev).eval()
     inp = make_inputs(args.batch, dev, seed=rank)           # inputs resident in HBM before the timed region
@@ -136,10 +136,7 @@ def main():
         conv2d_mfma.stop_timeline()
     assert all(torch.isfinite(o).all() for o in out)
 
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = replicas.max_over_ranks(elapsed, device=dev)   # slowest rank defines the step time
 
     if rank == 0:
         images = args.batch * args.steps * world

@@ -13,7 +13,8 @@ of the timed region.  Rank 0 prints ONE JSON line.
 Extra objects on that line:
   roofline     -- dominant kernel = conv2d_mfma<3,3,1> (the 3x3 implicit-GEMM conv, 96 % of the
                   FLOPs): sum of algorithmic FLOPs of its launches in the timed region / sum of
-                  their durations measured with HIP events on the launch stream, vs 157.3 TFLOP/s.
+                  their durations measured with HIP events on the launch stream, vs 157.3 TFLOP/s;
+                  `traffic` = measured HBM bytes per launch (profiles/r01_traffic.json).
   cpu_baseline -- the CPU oracle (oracle/network_ref.py, a port) timed on this host at N=1 on a
                   bounded sample (rank 0, --gpus 1 only).
 """
@@ -145,9 +146,15 @@ def main():
         allk = [(fl, e0.elapsed_time(e1) * 1e-3) for geo, fl, e0, e1 in timeline]
         k3_flops, k3_time = sum(f for f, _ in k3), sum(t for _, t in k3)
         achieved = k3_flops / k3_time / 1e12 if k3_time > 0 else 0.0
-        roofline = dict(bound='mfma', kernel='conv2d_mfma<3,3,1,BM,8> (3x3 stride-1 implicit GEMM, v_mfma_f32_32x32x2_f32)',
+        traffic = None      # HBM bytes per launch of that kernel: PMC counters cannot be read in-process; taken from the committed
+        try:                # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command (profiles/r01_traffic.json)
+            with open(os.path.join(ROOT, 'profiles', 'r01_traffic.json')) as f:
+                traffic = round(json.load(f)['hbm_bytes_per_launch'])
+        except (OSError, KeyError, ValueError):
+            pass
+        roofline = dict(bound='mfma', kernel='conv2d_mfma<3,3,1,BM,4,XF> (3x3 stride-1 implicit GEMM, v_mfma_f32_32x32x2_f32)',
                         achieved=round(achieved, 2), peak=F32_MFMA_PEAK_TFLOPS, unit='TFLOP/s', frac=round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
-                        traffic=None, launches_per_step=len(k3) // max(args.steps, 1), avg_launch_ms=round(1e3 * k3_time / max(len(k3), 1), 4),
+                        traffic=traffic, launches_per_step=len(k3) // max(args.steps, 1), avg_launch_ms=round(1e3 * k3_time / max(len(k3), 1), 4),
                         all_conv_tflops=round(sum(f for f, _ in allk) / max(sum(t for _, t in allk), 1e-12) / 1e12, 2),
                         conv_time_frac_of_step=round(sum(t for _, t in allk) / elapsed, 4),
                         end_to_end_frac=round(value / world * GFLOP_PER_IMAGE / 1e3 / F32_MFMA_PEAK_TFLOPS, 4))

@@ -343,3 +343,127 @@ class SynthesisNetworkFull_v18(nn.Module):
         y = self.spade_b256_2(y, spade_feat)
         _, finetune_img, _ = self.texture_b512(y, img_256, block_ws[-1], pose_feat, cat_feat, parsing=parsing_index, **block_kwargs)
         return img, finetune_img, pred_parsing
+
+
+# ==========================================================================
+# "next" row f1: what runs immediately upstream of synthesis in test.py:151-153.
+
+
+def normalize_2nd_moment(x, dim=1, eps=1e-8):
+    """networks.py:31-33."""
+    return x * (x.square().mean(dim=dim, keepdim=True) + eps).rsqrt()
+
+
+class MappingNetwork(nn.Module):
+    """networks.py:184-259 (z and/or c -> embed/normalise -> FC stack -> broadcast to num_ws -> truncation)."""
+
+    def __init__(self, z_dim, c_dim, w_dim, num_ws, num_layers=8, embed_features=None, layer_features=None,
+                 activation='lrelu', lr_multiplier=0.01, w_avg_beta=0.995):
+        super().__init__()
+        self.z_dim, self.c_dim, self.w_dim, self.num_ws, self.num_layers, self.w_avg_beta = z_dim, c_dim, w_dim, num_ws, num_layers, w_avg_beta
+        embed_features = (w_dim if embed_features is None else embed_features) if c_dim > 0 else 0
+        layer_features = w_dim if layer_features is None else layer_features
+        feats = [z_dim + embed_features] + [layer_features] * (num_layers - 1) + [w_dim]
+        if c_dim > 0:
+            self.embed = FullyConnectedLayer(c_dim, embed_features)
+        for i in range(num_layers):
+            setattr(self, f'fc{i}', FullyConnectedLayer(feats[i], feats[i + 1], activation=activation, lr_multiplier=lr_multiplier))
+        if num_ws is not None and w_avg_beta is not None:
+            self.register_buffer('w_avg', torch.zeros([w_dim]))
+
+    def forward(self, z, c, truncation_psi=1, truncation_cutoff=None, skip_w_avg_update=False):
+        x = None
+        if self.z_dim > 0:
+            x = normalize_2nd_moment(z.to(torch.float32))
+        if self.c_dim > 0:
+            y = normalize_2nd_moment(self.embed(c.to(torch.float32)))
+            x = y if x is None else torch.cat([x, y], dim=1)
+        for i in range(self.num_layers):
+            x = getattr(self, f'fc{i}')(x)
+        if self.w_avg_beta is not None and self.training and not skip_w_avg_update:
+            self.w_avg.copy_(x.detach().mean(dim=0).lerp(self.w_avg, self.w_avg_beta))
+        if self.num_ws is not None:
+            x = x.unsqueeze(1).repeat([1, self.num_ws, 1])
+        if truncation_psi != 1:
+            if self.num_ws is None or truncation_cutoff is None:
+                x = self.w_avg.lerp(x, truncation_psi)
+            else:
+                x[:, :truncation_cutoff] = self.w_avg.lerp(x[:, :truncation_cutoff], truncation_psi)
+        return x
+
+
+class ConstEncoderNetwork(nn.Module):
+    """networks.py:357-375: 1x1 stem then stride-2 3x3 Conv2dLayers down to the 8x8 pose feature."""
+
+    def __init__(self, input_nc, output_nc, ngf=64, n_downsampling=4):
+        super().__init__()
+        mult_ins, mult_outs = [1, 2, 4, 4, 4, 8], [2, 4, 4, 4, 8, 8]
+        layers = [Conv2dLayer(input_nc, ngf, kernel_size=1)]
+        for i in range(n_downsampling):
+            layers.append(Conv2dLayer(ngf * mult_ins[i], ngf * mult_outs[i], kernel_size=3, down=2))
+        self.model = nn.Sequential(*layers)
+
+    def forward(self, x):
+        return self.model(x)
+
+
+class Dense(nn.Module):
+    """networks.py:391-408: per-pixel Linear -> InstanceNorm2d -> LeakyReLU(0.01)."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.linear = nn.Linear(in_channels, out_channels)
+
+    def forward(self, x):
+        y = F.linear(x.permute(0, 2, 3, 1), self.linear.weight, self.linear.bias).permute(0, 3, 1, 2)
+        return F.leaky_relu(instance_norm(y), 0.01)
+
+
+class StyleEncoderNetworkV18(nn.Module):
+    """networks.py:1727-1774: garment-part encoder -> style vector, plus the 4-scale 64-channel feature pyramid of
+    the retained-region image that the synthesis blocks concatenate."""
+
+    def __init__(self, input_nc, output_nc, ngf=64, n_downsampling=4):
+        super().__init__()
+        enc = [Conv2dLayer(input_nc, ngf, kernel_size=1)]
+        for mi, mo in zip([1, 2, 4], [2, 4, 8]):
+            enc += [Dense(ngf * mi, ngf * mi), Conv2dLayer(ngf * mi, ngf * mo, kernel_size=3, down=2)]
+        for _ in range(3):
+            enc += [Dense(ngf * 8, ngf * 8), Conv2dLayer(ngf * 8, ngf * 8, kernel_size=3)]
+        enc += [nn.AdaptiveAvgPool2d(1)]
+        self.model = nn.Sequential(*enc)
+        self.fc = FullyConnectedLayer(output_nc, output_nc)
+        feat = [Conv2dLayer(6, ngf, kernel_size=3)]
+        for _ in range(3):
+            feat.append(Conv2dLayer(ngf, ngf, kernel_size=3, down=2))
+        self.feat_enc = nn.Sequential(*feat)
+
+    def forward(self, x, const_input):
+        feats = []
+        for m in self.feat_enc:
+            const_input = m(const_input)
+            feats.append(const_input)
+        x = self.model(x)
+        return self.fc(x.view(x.size(0), -1)), feats
+
+
+class GeneratorFull_v20(nn.Module):
+    """networks.py:2330-2366."""
+
+    def __init__(self, z_dim, c_dim, w_dim, img_resolution, img_channels, mapping_kwargs={}, synthesis_kwargs={}):
+        super().__init__()
+        self.z_dim, self.c_dim, self.w_dim, self.img_resolution, self.img_channels = z_dim, c_dim, w_dim, img_resolution, img_channels
+        self.synthesis = SynthesisNetworkFull_v18(w_dim=w_dim, img_resolution=img_resolution, img_channels=img_channels, **synthesis_kwargs)
+        self.num_ws = self.synthesis.num_ws
+        self.mapping = MappingNetwork(z_dim=z_dim, c_dim=c_dim, w_dim=w_dim, num_ws=self.num_ws, **mapping_kwargs)
+        self.const_encoding = ConstEncoderNetwork(input_nc=3 + 2, output_nc=512, ngf=64, n_downsampling=6)
+        self.style_encoding = StyleEncoderNetworkV18(input_nc=(10 * 3 + 5 * 3), output_nc=512, ngf=64, n_downsampling=6)
+
+    def forward(self, z, c, retain, pose, denorm_upper_input, denorm_lower_input, denorm_upper_mask, denorm_lower_mask,
+                gt_parsing=None, truncation_psi=1, truncation_cutoff=None, **synthesis_kwargs):
+        pose_feat = self.const_encoding(pose)
+        stylecode, feats = self.style_encoding(c, retain)
+        ws = self.mapping(z, stylecode, truncation_psi=truncation_psi, truncation_cutoff=truncation_cutoff)
+        cat_feats = {str(f.shape[2]): f for f in feats}
+        return self.synthesis(ws, pose_feat, cat_feats, denorm_upper_input, denorm_lower_input, denorm_upper_mask,
+                              denorm_lower_mask, gt_parsing, **synthesis_kwargs)

@@ -622,3 +622,145 @@ class SynthesisNetworkFull_v18(nn.Module):
         _, finetune_img, _ = self.texture_b512(x_spade_256, img_256, block_ws[-1], pose_feat, cat_feat, parsing_index,
                                                force_fp32=True, **block_kwargs)
         return img, finetune_img, pred_parsing
+
+
+# ============================================================================
+# Upstream of synthesis in test.py:151-153 / loss_fullbody.py:75-98: the pose ("const")
+# encoder, the garment-part style encoder with its 4-scale feature pyramid, the mapping MLP and the full generator.
+# They are built from the same ops, so every convolution below is the MFMA kernel with its bias/activation folded in.
+
+class MappingNetwork(nn.Module):
+    """reference networks.py:184-259."""
+
+    def __init__(self, z_dim, c_dim, w_dim, num_ws, num_layers=8, embed_features=None, layer_features=None,
+                 activation='lrelu', lr_multiplier=0.01, w_avg_beta=0.995):
+        super().__init__()
+        self.z_dim, self.c_dim, self.w_dim, self.num_ws, self.num_layers, self.w_avg_beta = z_dim, c_dim, w_dim, num_ws, num_layers, w_avg_beta
+        if embed_features is None:
+            embed_features = w_dim
+        if c_dim == 0:
+            embed_features = 0
+        if layer_features is None:
+            layer_features = w_dim
+        features_list = [z_dim + embed_features] + [layer_features] * (num_layers - 1) + [w_dim]
+        if c_dim > 0:
+            self.embed = FullyConnectedLayer(c_dim, embed_features)
+        for idx in range(num_layers):
+            setattr(self, f'fc{idx}', FullyConnectedLayer(features_list[idx], features_list[idx + 1], activation=activation, lr_multiplier=lr_multiplier))
+        if num_ws is not None and w_avg_beta is not None:
+            self.register_buffer('w_avg', torch.zeros([w_dim]))
+
+    def forward(self, z, c, truncation_psi=1, truncation_cutoff=None, skip_w_avg_update=False):
+        x = None
+        with torch.autograd.profiler.record_function('input'):
+            if self.z_dim > 0:
+                misc.assert_shape(z, [None, self.z_dim])
+                x = normalize_2nd_moment(z.to(torch.float32))
+            if self.c_dim > 0:
+                misc.assert_shape(c, [None, self.c_dim])
+                y = normalize_2nd_moment(self.embed(c.to(torch.float32)))
+                x = torch.cat([x, y], dim=1) if x is not None else y
+        for idx in range(self.num_layers):
+            x = getattr(self, f'fc{idx}')(x)
+        if self.w_avg_beta is not None and self.training and not skip_w_avg_update:
+            with torch.autograd.profiler.record_function('update_w_avg'):
+                self.w_avg.copy_(x.detach().mean(dim=0).lerp(self.w_avg, self.w_avg_beta))
+        if self.num_ws is not None:
+            with torch.autograd.profiler.record_function('broadcast'):
+                x = x.unsqueeze(1).repeat([1, self.num_ws, 1])
+        if truncation_psi != 1:
+            with torch.autograd.profiler.record_function('truncate'):
+                assert self.w_avg_beta is not None
+                if self.num_ws is None or truncation_cutoff is None:
+                    x = self.w_avg.lerp(x, truncation_psi)
+                else:
+                    x[:, :truncation_cutoff] = self.w_avg.lerp(x[:, :truncation_cutoff], truncation_psi)
+        return x
+
+
+class ConstEncoderNetwork(nn.Module):
+    """reference networks.py:357-375: pose map [N,5,512,512] -> [N,512,8,8]."""
+
+    def __init__(self, input_nc, output_nc, ngf=64, n_downsampling=4):
+        super().__init__()
+        encoder = [Conv2dLayer(input_nc, ngf, kernel_size=1)]
+        mult_ins, mult_outs = [1, 2, 4, 4, 4, 8], [2, 4, 4, 4, 8, 8]
+        for i in range(n_downsampling):
+            encoder += [Conv2dLayer(ngf * mult_ins[i], ngf * mult_outs[i], kernel_size=3, down=2)]
+        self.model = nn.Sequential(*encoder)
+
+    def forward(self, x):
+        return self.model(x)
+
+
+class Dense(nn.Module):
+    """reference networks.py:391-408: per-pixel Linear -> InstanceNorm2d -> LeakyReLU (slope 0.01).  The Linear is a
+    1x1 convolution: on the inference route it runs the MFMA kernel with the bias in its epilogue."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.bn = nn.InstanceNorm2d(out_channels)
+        self.activation = nn.LeakyReLU()
+        self.linear = nn.Linear(in_channels, out_channels)
+        self._cache = _PackCache()
+
+    def forward(self, x):
+        if _fast_ok(x, self.linear.weight, self.linear.bias):
+            w = self.linear.weight
+            packed = self._cache.get('w', [w], lambda: conv2d_mfma.pack_weight(w.detach().reshape(self.out_channels, self.in_channels, 1, 1)))
+            out = conv2d_mfma.conv2d_forward(x, packed, self.out_channels, 1, 1, bias=self.linear.bias)
+        else:
+            out = self.linear(x.permute((0, 2, 3, 1))).permute((0, 3, 1, 2))
+        return self.activation(self.bn(out))
+
+
+class StyleEncoderNetworkV18(nn.Module):
+    """reference networks.py:1727-1774."""
+
+    def __init__(self, input_nc, output_nc, ngf=64, n_downsampling=4):
+        super().__init__()
+        encoder = [Conv2dLayer(input_nc, ngf, kernel_size=1)]
+        for mult_in, mult_out in zip([1, 2, 4], [2, 4, 8]):
+            encoder += [Dense(ngf * mult_in, ngf * mult_in), Conv2dLayer(ngf * mult_in, ngf * mult_out, kernel_size=3, down=2)]
+        for mult_in, mult_out in zip([8, 8, 8], [8, 8, 8]):
+            encoder += [Dense(ngf * mult_in, ngf * mult_in), Conv2dLayer(ngf * mult_in, ngf * mult_out, kernel_size=3)]
+        encoder += [nn.AdaptiveAvgPool2d(1)]
+        self.model = nn.Sequential(*encoder)
+        self.fc = FullyConnectedLayer(output_nc, output_nc)
+        feat_enc = [Conv2dLayer(6, ngf, kernel_size=3)]
+        for _ in range(3):
+            feat_enc += [Conv2dLayer(ngf, ngf, kernel_size=3, down=2)]
+        self.feat_enc = nn.Sequential(*feat_enc)
+
+    def forward(self, x, const_input):
+        const_feats = []
+        for module in self.feat_enc:
+            const_input = module(const_input)
+            const_feats.append(const_input)
+        for module in self.model:
+            x = module(x)
+        x = self.fc(x.view(x.size(0), -1))
+        return x, const_feats
+
+
+class GeneratorFull_v20(nn.Module):
+    """reference networks.py:2330-2366."""
+
+    def __init__(self, z_dim, c_dim, w_dim, img_resolution, img_channels, mapping_kwargs={}, synthesis_kwargs={}):
+        super().__init__()
+        self.z_dim, self.c_dim, self.w_dim, self.img_resolution, self.img_channels = z_dim, c_dim, w_dim, img_resolution, img_channels
+        self.synthesis = SynthesisNetworkFull_v18(w_dim=w_dim, img_resolution=img_resolution, img_channels=img_channels, **synthesis_kwargs)
+        self.num_ws = self.synthesis.num_ws
+        self.mapping = MappingNetwork(z_dim=z_dim, c_dim=c_dim, w_dim=w_dim, num_ws=self.num_ws, **mapping_kwargs)
+        self.const_encoding = ConstEncoderNetwork(input_nc=3 + 2, output_nc=512, ngf=64, n_downsampling=6)
+        self.style_encoding = StyleEncoderNetworkV18(input_nc=(10 * 3 + 5 * 3), output_nc=512, ngf=64, n_downsampling=6)
+
+    def forward(self, z, c, retain, pose, denorm_upper_input, denorm_lower_input, denorm_upper_mask, denorm_lower_mask,
+                gt_parsing=None, truncation_psi=1, truncation_cutoff=None, **synthesis_kwargs):
+        pose_feat = self.const_encoding(pose)
+        stylecode, feats = self.style_encoding(c, retain)
+        ws = self.mapping(z, stylecode, truncation_psi=truncation_psi, truncation_cutoff=truncation_cutoff)
+        cat_feats = {str(feat.shape[2]): feat for feat in feats}
+        return self.synthesis(ws, pose_feat, cat_feats, denorm_upper_input, denorm_lower_input, denorm_upper_mask,
+                              denorm_lower_mask, gt_parsing, **synthesis_kwargs)

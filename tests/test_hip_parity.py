@@ -497,3 +497,56 @@ def test_synthesis_full_width_vs_oracle():
         s = scale_of(b)
         delta = float((a.cpu().double() - b.double()).abs().max())
         assert delta <= 1e-3 * s, f'{nm}: max-abs delta {delta:.3e} vs output range {s:.3e}'
+
+
+# =============================================================== "next" row f1: encoders, mapping, full generator
+
+def test_encoders_and_mapping_golden(golden):
+    from training import networks as PN
+    from oracle import network_ref as NR
+    g = golden('g7_encoders.npz')
+    tol = dict(rtol=3e-4, atol=5e-5)
+    with torch.no_grad():
+        ce = _load(PN.ConstEncoderNetwork(input_nc=5, output_nc=64, ngf=8, n_downsampling=6),
+                   fill_module_(NR.ConstEncoderNetwork(input_nc=5, output_nc=64, ngf=8, n_downsampling=6), 'g7.const.'))
+        close(ce(det_tensor('g7.const.x', [2, 5, 128, 128], 'uniform').to(DEV)), g['const/y'], **tol)
+        se = _load(PN.StyleEncoderNetworkV18(input_nc=45, output_nc=64, ngf=8, n_downsampling=6),
+                   fill_module_(NR.StyleEncoderNetworkV18(input_nc=45, output_nc=64, ngf=8, n_downsampling=6), 'g7.style.'))
+        code, feats = se(det_tensor('g7.style.parts', [2, 45, 32, 32], 'uniform').to(DEV), det_tensor('g7.style.retain', [2, 6, 64, 64], 'uniform').to(DEV))
+        close(code, g['style/code'], rtol=2e-3, atol=2e-4)
+        for i, f in enumerate(feats):
+            close(f, g[f'style/feat{i}'], **tol)
+        mp = _load(PN.MappingNetwork(z_dim=0, c_dim=64, w_dim=32, num_ws=14, num_layers=1),
+                   fill_module_(NR.MappingNetwork(z_dim=0, c_dim=64, w_dim=32, num_ws=14, num_layers=1), 'g7.map.'))
+        close(mp(torch.zeros([2, 0], device=DEV), det_tensor('g7.map.c', [2, 64]).to(DEV)), g['map/ws'], **tol)
+        ref2 = fill_module_(NR.MappingNetwork(z_dim=16, c_dim=8, w_dim=32, num_ws=5, num_layers=3), 'g7.map2.')
+        ref2.w_avg.copy_(det_tensor('g7.map2.w_avg', [32]))
+        mp2 = _load(PN.MappingNetwork(z_dim=16, c_dim=8, w_dim=32, num_ws=5, num_layers=3), ref2)
+        close(mp2(det_tensor('g7.map2.z', [3, 16]).to(DEV), det_tensor('g7.map2.c', [3, 8]).to(DEV), truncation_psi=0.7, truncation_cutoff=3), g['map2/ws'], **tol)
+        dn = _load(PN.Dense(6, 10), fill_module_(NR.Dense(6, 10), 'g7.dense.'))
+        close(dn(det_tensor('g7.dense.x', [2, 6, 9, 11]).to(DEV)), g['dense/y'], **tol)
+
+
+def test_full_generator_vs_oracle():
+    """BASELINE config 3's network (GeneratorFull_v20: encoders + mapping + synthesis, full width) at N=1 vs the CPU oracle."""
+    from training import networks as PN
+    from oracle import network_ref as NR
+    kw = dict(z_dim=0, c_dim=512, w_dim=512, img_resolution=512, img_channels=3, mapping_kwargs=dict(num_layers=1),
+              synthesis_kwargs=dict(channel_base=32768, channel_max=512, conv_clamp=256))
+    torch.manual_seed(0)
+    ref = fill_module_(NR.GeneratorFull_v20(**kw), 'cfg3.').eval()
+    net = _load(PN.GeneratorFull_v20(**kw), ref)
+    n = 1
+    inp = dict(z=torch.zeros([n, 0]), c=det_tensor('cfg3.parts', [n, 45, 128, 128], 'uniform'), retain=det_tensor('cfg3.retain', [n, 6, 512, 512], 'uniform'),
+               pose=det_tensor('cfg3.pose', [n, 5, 512, 512], 'uniform'), du=det_tensor('cfg3.du', [n, 3, 512, 512], 'uniform'),
+               dl=det_tensor('cfg3.dl', [n, 3, 512, 512], 'uniform'), mu=det_tensor('cfg3.mu', [n, 1, 512, 512], 'blockmask'),
+               ml=det_tensor('cfg3.ml', [n, 1, 512, 512], 'blockmask'), gt=det_tensor('cfg3.gt', [n, 1, 512, 512], 'labels7'))
+    call = lambda m, f: m(f(inp['z']), f(inp['c']), f(inp['retain']), f(inp['pose']), f(inp['du']), f(inp['dl']), f(inp['mu']), f(inp['ml']),
+                          gt_parsing=f(inp['gt']), noise_mode='const')
+    with torch.no_grad():
+        out = call(net, lambda t: t.to(DEV))
+        want = call(ref, lambda t: t)
+    for nm, a, b in zip(('img', 'finetune_img', 'pred_parsing'), out, want):
+        s = scale_of(b)
+        delta = float((a.cpu().double() - b.double()).abs().max())
+        assert delta <= 1e-3 * s, f'{nm}: max-abs delta {delta:.3e} vs output range {s:.3e}'

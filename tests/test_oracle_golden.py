@@ -165,3 +165,24 @@ def test_synthesis_network_reduced(golden, variant, labels, fused):
         close(t[..., ::C.G6_SUB, ::C.G6_SUB], g[f'{variant}/{nm}_sub'], rtol=1e-3, atol=2e-4 * scale)
         close(t[..., y0:y1, x0:x1], g[f'{variant}/{nm}_crop'], rtol=1e-3, atol=2e-4 * scale)
         np.testing.assert_allclose(float(t.double().abs().sum()), float(g[f'{variant}/{nm}_abssum']), rtol=1e-4)
+
+
+def test_encoders_and_mapping(golden):
+    """Rows of SURVEY section 8f (f1): encoders + mapping of the reference, reduced widths."""
+    g = golden('g7_encoders.npz')
+    tol = dict(rtol=3e-4, atol=3e-5)
+    with torch.no_grad():
+        ce = fill_module_(NR.ConstEncoderNetwork(input_nc=5, output_nc=64, ngf=8, n_downsampling=6), 'g7.const.')
+        close(ce(det_tensor('g7.const.x', [2, 5, 128, 128], 'uniform')), g['const/y'], **tol)
+        se = fill_module_(NR.StyleEncoderNetworkV18(input_nc=45, output_nc=64, ngf=8, n_downsampling=6), 'g7.style.')
+        code, feats = se(det_tensor('g7.style.parts', [2, 45, 32, 32], 'uniform'), det_tensor('g7.style.retain', [2, 6, 64, 64], 'uniform'))
+        close(code, g['style/code'], rtol=1e-3, atol=1e-4)
+        for i, f in enumerate(feats):
+            close(f, g[f'style/feat{i}'], **tol)
+        mp = fill_module_(NR.MappingNetwork(z_dim=0, c_dim=64, w_dim=32, num_ws=14, num_layers=1), 'g7.map.').eval()
+        close(mp(torch.zeros([2, 0]), det_tensor('g7.map.c', [2, 64])), g['map/ws'], **tol)
+        mp2 = fill_module_(NR.MappingNetwork(z_dim=16, c_dim=8, w_dim=32, num_ws=5, num_layers=3), 'g7.map2.').eval()
+        mp2.w_avg.copy_(det_tensor('g7.map2.w_avg', [32]))
+        close(mp2(det_tensor('g7.map2.z', [3, 16]), det_tensor('g7.map2.c', [3, 8]), truncation_psi=0.7, truncation_cutoff=3), g['map2/ws'], **tol)
+        dn = fill_module_(NR.Dense(6, 10), 'g7.dense.')
+        close(dn(det_tensor('g7.dense.x', [2, 6, 9, 11])), g['dense/y'], **tol)

@@ -78,6 +78,25 @@ int pg_upfirdn2d(const void* x, const float* f, void* y, int dtype,
                  int outH, int outW, const int64_t ystride[4],
                  int upx, int upy, int downx, int downy, int padx0, int pady0,
                  int flip, float gain, void* stream);
+/* upfirdn2d followed, in the same pass, by the tail of a SynthesisLayer: v = fir(x) * gain + noise * noise_gain + bias[c];
+ * y = clamp(act(v) * act_gain) with act in {linear, relu, lrelu}.  float32, dense NCHW, the filter sizes / factors of the
+ * tiled kernel only (PG_ERR_UNSUPPORTED otherwise -- callers then run pg_upfirdn2d and pg_bias_act separately). */
+typedef struct pg_fir_epilogue {
+    const float* noise;         /* [outH, outW] (noise_batch_stride 0) or [N, outH, outW]; NULL = none */
+    int64_t      noise_batch_stride;
+    float        noise_gain;
+    const float* bias;          /* [C]; NULL = none */
+    int          act;           /* pg_act */
+    float        alpha;
+    float        act_gain;      /* 0 => 1 */
+    float        clamp;         /* < 0 = off */
+} pg_fir_epilogue;
+int pg_upfirdn2d_bias_act(const void* x, const float* f, void* y, int dtype,
+                          int N, int C, int inH, int inW, const int64_t xstride[4],
+                          int fh, int fw, const int64_t fstride[2],
+                          int outH, int outW, const int64_t ystride[4],
+                          int upx, int upy, int downx, int downy, int padx0, int pady0,
+                          int flip, float gain, const pg_fir_epilogue* epilogue, void* stream);
 int pg_upfirdn2d_abi_version(void);
 
 /* ------------------------------------------------------------------------
@@ -126,6 +145,11 @@ typedef struct pg_conv2d_fusion {
     const float* spade_x;
     const float* spade_mean;    /* [N, C] */
     const float* spade_rstd;    /* [N, C] */
+    /* Second input (channel concatenation without the copy): input channels [cin_split, Cin) are read from x2
+       ([N, Cin - cin_split, H, W], contiguous) instead of x ([N, cin_split, H, W]) -- the `torch.cat([x, feat], 1)` in
+       front of merge_conv (networks.py:2179-2181).  cin_split must be a multiple of 16. */
+    const float* x2;
+    int          cin_split;
 } pg_conv2d_fusion;
 
 /*

@@ -70,29 +70,30 @@ __device__ __forceinline__ float block_sum_1024(float v, float* red) {
     return red[0];
 }
 
+// One pass: sums of (x - K) and (x - K)^2 with K = the plane's first element (shifted-data variance: immune to the
+// cancellation of E[x^2] - E[x]^2 when |mean| >> std), 1024 threads per (n, c) plane, 16-byte loads.
 __global__ __launch_bounds__(IN_THREADS) void instance_norm_stats_kernel(const float* __restrict__ x, float* __restrict__ mean, float* __restrict__ rstd, int64_t HW, float eps) {
     __shared__ float red[IN_THREADS / 64];
     const float* xp = x + (int64_t)blockIdx.x * HW;
-    float s = 0.f;
-    const bool vec = (HW % 4 == 0) && aligned16(xp);
-    if (vec) {
-        for (int64_t i = threadIdx.x; i < HW / 4; i += IN_THREADS) { const f32x4 v = ((const f32x4*)xp)[i]; s += (v[0] + v[1]) + (v[2] + v[3]); }
-    } else {
-        for (int64_t i = threadIdx.x; i < HW; i += IN_THREADS) s += xp[i];
-    }
-    const float m = block_sum_1024(s, red) / (float)HW;
-    float q = 0.f;
-    if (vec) {
+    const float K = xp[0];
+    float s = 0.f, q = 0.f;
+    if ((HW % 4 == 0) && aligned16(xp)) {
         for (int64_t i = threadIdx.x; i < HW / 4; i += IN_THREADS) {
             const f32x4 v = ((const f32x4*)xp)[i];
-            const float a = v[0] - m, b = v[1] - m, c = v[2] - m, d = v[3] - m;
+            const float a = v[0] - K, b = v[1] - K, c = v[2] - K, d = v[3] - K;
+            s += (a + b) + (c + d);
             q += (a * a + b * b) + (c * c + d * d);
         }
     } else {
-        for (int64_t i = threadIdx.x; i < HW; i += IN_THREADS) { const float a = xp[i] - m; q += a * a; }
+        for (int64_t i = threadIdx.x; i < HW; i += IN_THREADS) { const float a = xp[i] - K; s += a; q += a * a; }
     }
-    const float var = block_sum_1024(q, red) / (float)HW;
-    if (threadIdx.x == 0) { mean[blockIdx.x] = m; rstd[blockIdx.x] = 1.0f / sqrtf(var + eps); }
+    const float S = block_sum_1024(s, red), Q = block_sum_1024(q, red);
+    if (threadIdx.x == 0) {
+        const float ms = S / (float)HW;                          // mean of the shifted data
+        const float var = fmaxf(Q / (float)HW - ms * ms, 0.f);
+        mean[blockIdx.x] = K + ms;
+        rstd[blockIdx.x] = 1.0f / sqrtf(var + eps);
+    }
 }
 
 // out = (x - mean) * rstd * (1 + gamma) + beta
@@ -177,6 +178,8 @@ PG_EXPORT int pg_conv2d_forward(const float* x, const float* packed_w, float* y,
         if (!p.f.spade_mean || !p.f.spade_rstd) return PG_ERR_INVALID_ARG;
         if (Cout % 64 != 0 || out_step_y != 1 || out_step_x != 1) return PG_ERR_UNSUPPORTED;   // 32 gamma + 32 beta rows per 64-row tile
     }
+    if (p.f.x2 && (p.f.cin_split <= 0 || p.f.cin_split >= Cin || p.f.cin_split % 16 != 0)) return PG_ERR_INVALID_ARG;
+    if (!p.f.x2) p.f.cin_split = 0;
     if (p.f.in_bias) return PG_ERR_UNSUPPORTED;   // the prologue runs on the zero-padded tile: act(0 + b) != 0 would corrupt the padding
     p.in_xform = (p.f.in_act != PG_ACT_LINEAR || p.f.in_gain != 1.f || p.f.in_clamp >= 0.f) ? 1 : 0;
     if (p.in_xform && (!(p.f.in_gain > 0.f) || p.f.in_alpha < 0.f || p.f.in_alpha > 1.f)) return PG_ERR_UNSUPPORTED;

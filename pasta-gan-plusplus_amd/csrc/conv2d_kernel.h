@@ -116,7 +116,8 @@ __global__ __launch_bounds__(256, 4) void conv2d_mfma(ConvParams p) {
     // ---- state of the tile whose chunks are being requested
     int n = 0, oy0 = 0, ox0 = 0, m0 = 0;
     unsigned xoff[G::XPT];
-    i32x4 xrsrc;
+    i32x4 xrsrc, xrsrc2;             // image n of x (channels [0, split)) and of the optional second source x2
+    const int split = p.f.x2 ? p.f.cin_split : p.Cin;
 
     // Tile -> (n, tile_y, tile_x, m-block), XCD-aware: workgroups sharing an XCD (id % 8) walk one contiguous
     // range of logical tiles, so neighbouring tiles and the m-blocks of one tile hit the same L2.
@@ -147,11 +148,18 @@ __global__ __launch_bounds__(256, 4) void conv2d_mfma(ConvParams p) {
             xoff[i] = ok ? (unsigned)(c * HW + gy * p.W + gx) * 4u : 0x80000000u;
         }
         // raw buffer descriptor of image n: base, stride 0, num_records = bytes, flags as make_buffer_rsrc's 0x00020000
-        const uint64_t base = (uint64_t)(uintptr_t)(p.x + (int64_t)n * p.Cin * HW);
+        const uint64_t base = (uint64_t)(uintptr_t)(p.x + (int64_t)n * split * HW);
         xrsrc[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)base);
         xrsrc[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(base >> 32) & 0xffff);
-        xrsrc[2] = p.Cin * HW * 4;
+        xrsrc[2] = split * HW * 4;
         xrsrc[3] = 0x00020000;
+        xrsrc2 = xrsrc;
+        if (p.f.x2) {                      // channels [split, Cin) come from x2: conv(cat([x, x2], 1)) without the copy
+            const uint64_t base2 = (uint64_t)(uintptr_t)(p.f.x2 + (int64_t)n * (p.Cin - split) * HW);
+            xrsrc2[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)base2);
+            xrsrc2[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(base2 >> 32) & 0xffff);
+            xrsrc2[2] = (p.Cin - split) * HW * 4;
+        }
     };
 
     // Request one K chunk: global -> LDS directly (no staging registers, no ds_write).  Each wave-instruction
@@ -160,9 +168,15 @@ __global__ __launch_bounds__(256, 4) void conv2d_mfma(ConvParams p) {
     auto issue_chunk = [&](int c0, int buf) {
         const unsigned xs_b = smem_b + (unsigned)(buf * G::LDS_BUF + 64 * wave) * 4u;            // bytes, wave-uniform
         const unsigned ws_b = smem_b + (unsigned)(buf * G::LDS_BUF + G::LDS_X + 256 * wave) * 4u;
-        const int soff = c0 * HW * 4;                       // wave-uniform chunk offset
+        if (c0 < split) {                                   // wave-uniform: split is a multiple of the chunk size
+            const int soff = c0 * HW * 4;
 #pragma unroll
-        for (int i = 0; i < G::XPT; i++) dma_dword(xrsrc, xs_b + 1024u * i, xoff[i], soff);
+            for (int i = 0; i < G::XPT; i++) dma_dword(xrsrc, xs_b + 1024u * i, xoff[i], soff);
+        } else {
+            const int soff = (c0 - split) * HW * 4;
+#pragma unroll
+            for (int i = 0; i < G::XPT; i++) dma_dword(xrsrc2, xs_b + 1024u * i, xoff[i], soff);
+        }
         const float* wb = p.wp + (int64_t)c0 * G::T * p.CoutP + m0;
 #pragma unroll
         for (int i = 0; i < G::WPT; i++) {

@@ -27,6 +27,10 @@ struct Params {
     int64_t xs[4], ys[4], fs[2];
     int upx, upy, dnx, dny, padx0, pady0, flip;
     float gain;
+    // optional fused tail (tiled float32 path only)
+    int has_ep;
+    const float* noise; int64_t noise_bs; float noise_gain;
+    const float* bias; float slope, act_gain, clamp;
 };
 
 __device__ __forceinline__ int floor_div(int a, int b) {   // b > 0
@@ -142,7 +146,17 @@ __global__ __launch_bounds__(256) void upfirdn2d_tiled(Params p, int tilesX, int
                 acc += sx[cy + jy][cx + jx] * sf[ky0 + jy * UPY][kx0 + jx * UPX];
             }
         }
-        if (ox < p.outW && oy < p.outH) yp[(int64_t)oy * p.outW + ox] = (T)(acc * p.gain);
+        if (ox < p.outW && oy < p.outH) {
+            float v = acc * p.gain;
+            if (p.has_ep) {       // SynthesisLayer tail: + noise, + bias, linear/relu/lrelu, gain, clamp
+                const int c = (int)(plane % p.C), n = (int)(plane / p.C);
+                if (p.noise) v += p.noise[n * p.noise_bs + (int64_t)oy * p.outW + ox] * p.noise_gain;
+                if (p.bias) v += p.bias[c];
+                v = (v > 0.f ? v : v * p.slope) * p.act_gain;
+                v = fminf(fmaxf(v, -p.clamp), p.clamp);
+            }
+            yp[(int64_t)oy * p.outW + ox] = (T)v;
+        }
     }
 }
 
@@ -182,6 +196,7 @@ int run(const Params& p, hipStream_t s, bool allow_tiled) {
                             p.ys[1] == (int64_t)p.outH * p.outW && p.ys[0] == (int64_t)p.C * p.outH * p.outW;
     int st = PG_OK;
     if (allow_tiled && dense_nchw && try_tiled<T>(p, s, &st)) return st;
+    if (p.has_ep) return PG_ERR_UNSUPPORTED;
     const int64_t total = (int64_t)p.N * p.C * p.outH * p.outW;
     int64_t blocks = (total + 255) / 256;
     if (blocks > kMaxStreamBlocks * 4) blocks = kMaxStreamBlocks * 4;
@@ -193,12 +208,12 @@ int run(const Params& p, hipStream_t s, bool allow_tiled) {
 
 PG_EXPORT int pg_upfirdn2d_abi_version(void) { return PG_ABI_VERSION; }
 
-PG_EXPORT int pg_upfirdn2d(const void* x, const float* f, void* y, int dtype,
-                           int N, int C, int inH, int inW, const int64_t xstride[4],
-                           int fh, int fw, const int64_t fstride[2],
-                           int outH, int outW, const int64_t ystride[4],
-                           int upx, int upy, int downx, int downy, int padx0, int pady0,
-                           int flip, float gain, void* stream) {
+static int upfirdn2d_impl(const void* x, const float* f, void* y, int dtype,
+                          int N, int C, int inH, int inW, const int64_t xstride[4],
+                          int fh, int fw, const int64_t fstride[2],
+                          int outH, int outW, const int64_t ystride[4],
+                          int upx, int upy, int downx, int downy, int padx0, int pady0,
+                          int flip, float gain, const pg_fir_epilogue* ep, void* stream) {
     if (!x || !f || !y || !xstride || !fstride || !ystride) return PG_ERR_INVALID_ARG;
     if (N <= 0 || C <= 0 || inH <= 0 || inW <= 0 || outH <= 0 || outW <= 0 || fh <= 0 || fw <= 0) return PG_ERR_INVALID_ARG;
     if (upx < 1 || upy < 1 || downx < 1 || downy < 1) return PG_ERR_INVALID_ARG;
@@ -213,6 +228,15 @@ PG_EXPORT int pg_upfirdn2d(const void* x, const float* f, void* y, int dtype,
     p.fs[0] = fstride[0]; p.fs[1] = fstride[1];
     p.upx = upx; p.upy = upy; p.dnx = downx; p.dny = downy; p.padx0 = padx0; p.pady0 = pady0;
     p.flip = flip ? 1 : 0; p.gain = gain;
+    p.has_ep = 0; p.noise = nullptr; p.bias = nullptr; p.noise_bs = 0; p.noise_gain = 0.f; p.slope = 1.f; p.act_gain = 1.f; p.clamp = __builtin_inff();
+    if (ep) {
+        if (dtype != PG_F32) return PG_ERR_UNSUPPORTED;
+        if (ep->act != 0 && (ep->act < PG_ACT_LINEAR || ep->act > PG_ACT_LRELU)) return PG_ERR_UNSUPPORTED;
+        p.has_ep = 1; p.noise = ep->noise; p.noise_bs = ep->noise_batch_stride; p.noise_gain = ep->noise_gain; p.bias = ep->bias;
+        p.slope = (ep->act == PG_ACT_RELU) ? 0.f : (ep->act == PG_ACT_LRELU ? ep->alpha : 1.f);
+        p.act_gain = ep->act_gain == 0.f ? 1.f : ep->act_gain;
+        p.clamp = ep->clamp >= 0.f ? ep->clamp : __builtin_inff();
+    }
     hipStream_t s = (hipStream_t)stream;
     switch (dtype) {
         case PG_F32: return run<float>(p, s, true);
@@ -221,4 +245,25 @@ PG_EXPORT int pg_upfirdn2d(const void* x, const float* f, void* y, int dtype,
         case PG_F64: return run<double>(p, s, false);
     }
     return PG_ERR_INVALID_ARG;
+}
+
+PG_EXPORT int pg_upfirdn2d(const void* x, const float* f, void* y, int dtype,
+                           int N, int C, int inH, int inW, const int64_t xstride[4],
+                           int fh, int fw, const int64_t fstride[2],
+                           int outH, int outW, const int64_t ystride[4],
+                           int upx, int upy, int downx, int downy, int padx0, int pady0,
+                           int flip, float gain, void* stream) {
+    return upfirdn2d_impl(x, f, y, dtype, N, C, inH, inW, xstride, fh, fw, fstride, outH, outW, ystride,
+                          upx, upy, downx, downy, padx0, pady0, flip, gain, nullptr, stream);
+}
+
+PG_EXPORT int pg_upfirdn2d_bias_act(const void* x, const float* f, void* y, int dtype,
+                                    int N, int C, int inH, int inW, const int64_t xstride[4],
+                                    int fh, int fw, const int64_t fstride[2],
+                                    int outH, int outW, const int64_t ystride[4],
+                                    int upx, int upy, int downx, int downy, int padx0, int pady0,
+                                    int flip, float gain, const pg_fir_epilogue* epilogue, void* stream) {
+    if (!epilogue) return PG_ERR_INVALID_ARG;
+    return upfirdn2d_impl(x, f, y, dtype, N, C, inH, inW, xstride, fh, fw, fstride, outH, outW, ystride,
+                          upx, upy, downx, downy, padx0, pady0, flip, gain, epilogue, stream);
 }

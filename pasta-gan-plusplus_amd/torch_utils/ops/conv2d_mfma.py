@@ -31,6 +31,7 @@ class Fusion(ctypes.Structure):
         ('bias', ctypes.c_void_p), ('act', ctypes.c_int), ('alpha', ctypes.c_float), ('gain', ctypes.c_float), ('clamp', ctypes.c_float),
         ('residual', ctypes.c_void_p),
         ('spade_x', ctypes.c_void_p), ('spade_mean', ctypes.c_void_p), ('spade_rstd', ctypes.c_void_p),
+        ('x2', ctypes.c_void_p), ('cin_split', ctypes.c_int),
     ]
 
 
@@ -105,7 +106,7 @@ def pack_weight(w, scale=1.0, flip=False, transpose_oi=False):
 def conv2d_forward(x, packed, cout, kh, kw, stride=1, pad=(0, 0), out_hw=None, y=None, out_step=(1, 1), out_off=(0, 0),
                    in_scale=None, in_bias=None, in_act='linear', in_alpha=0.0, in_gain=1.0, in_clamp=None,
                    out_scale=None, noise=None, noise_gain=1.0, bias=None, act='linear', alpha=0.0, gain=1.0, clamp=None,
-                   residual=None, spade=None):
+                   residual=None, spade=None, x2=None):
     """One launch of the MFMA convolution.  `x` [N,Cin,H,W] float32 contiguous; `packed` from
     `pack_weight`.  Writes y[n, co, oy*step+off, ox*step+off] for oy < out_hw[0], ox < out_hw[1]
     (allocating a dense [N,Cout,OH,OW] `y` when none is given) and returns `y`.
@@ -115,6 +116,12 @@ def conv2d_forward(x, packed, cout, kh, kw, stride=1, pad=(0, 0), out_hw=None, y
     lib = _init().lib
     x = _f32c(x, 'x')
     n, cin, h, w = x.shape
+    cin_split = 0
+    if x2 is not None:          # conv(torch.cat([x, x2], 1)) without materialising the concatenation
+        x2 = _f32c(x2, 'x2')
+        if x2.shape[0] != n or x2.shape[2:] != x.shape[2:] or cin % 16 != 0:
+            raise nat.NativeOpError('conv2d_mfma: x2 must match x in N, H, W and x must have a multiple of 16 channels')
+        cin_split, cin = cin, cin + x2.shape[1]
     pad_y, pad_x = pad
     if out_hw is None:
         out_hw = ((h + 2 * pad_y - kh) // stride + 1, (w + 2 * pad_x - kw) // stride + 1)
@@ -167,6 +174,9 @@ def conv2d_forward(x, packed, cout, kh, kw, stride=1, pad=(0, 0), out_hw=None, y
             raise nat.NativeOpError('conv2d_mfma: spade tensors must match the [N, C, OH, OW] output')
         keep += [sx, smean, srstd]
         fz.spade_x, fz.spade_mean, fz.spade_rstd = sx.data_ptr(), smean.data_ptr(), srstd.data_ptr()
+    if x2 is not None:
+        keep.append(x2)
+        fz.x2, fz.cin_split = x2.data_ptr(), cin_split
     with torch.cuda.device(x.device):
         if _timeline is not None:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

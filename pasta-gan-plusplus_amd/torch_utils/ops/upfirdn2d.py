@@ -30,8 +30,61 @@ def _init():
         i, p64 = ctypes.c_int, ctypes.POINTER(ctypes.c_int64)
         fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, i, i, i, i, i, p64, i, i, p64, i, i, p64,
                        i, i, i, i, i, i, i, ctypes.c_float, ctypes.c_void_p]
+        fn2 = plugin.lib.pg_upfirdn2d_bias_act
+        fn2.restype = ctypes.c_int
+        fn2.argtypes = fn.argtypes[:-1] + [ctypes.POINTER(_FirEpilogue), ctypes.c_void_p]
         _plugin = plugin
     return True
+
+
+class _FirEpilogue(ctypes.Structure):
+    """Mirror of ``pg_fir_epilogue`` (include/pasta_gan_ops.h)."""
+    _fields_ = [('noise', ctypes.c_void_p), ('noise_batch_stride', ctypes.c_int64), ('noise_gain', ctypes.c_float),
+                ('bias', ctypes.c_void_p), ('act', ctypes.c_int), ('alpha', ctypes.c_float), ('act_gain', ctypes.c_float), ('clamp', ctypes.c_float)]
+
+
+_FUSED_ACTS = {'linear': 1, 'relu': 2, 'lrelu': 3}
+
+
+def upfirdn2d_bias_act(x, f, up=1, down=1, padding=0, flip_filter=False, gain=1, noise=None, b=None, act='linear', alpha=0.2,
+                       act_gain=1.0, clamp=None):
+    """`bias_act(upfirdn2d(x, f, ...) + noise, b, act, gain=act_gain, clamp)` in ONE pass (the tail of an up-sampling
+    SynthesisLayer: FIR -> +noise -> bias_act).  Inference only (no autograd); float32 dense NCHW and a 2-D filter the
+    tiled kernel covers, otherwise returns None and the caller composes the separate ops."""
+    nat.require_gpu(x, 'upfirdn2d_bias_act')
+    _init()
+    if x.dtype != torch.float32 or x.ndim != 4 or f is None or f.ndim != 2 or act not in _FUSED_ACTS or not x.is_contiguous():
+        return None
+    upx, upy = _parse_scaling(up)
+    downx, downy = _parse_scaling(down)
+    padx0, padx1, pady0, pady1 = _parse_padding(padding)
+    n, c, ih, iw = x.shape
+    fh, fw = f.shape
+    ow = (iw * upx + padx0 + padx1 - fw + downx) // downx
+    oh = (ih * upy + pady0 + pady1 - fh + downy) // downy
+    assert ow >= 1 and oh >= 1
+    y = torch.empty([n, c, oh, ow], dtype=x.dtype, device=x.device)
+    ep = _FirEpilogue()
+    keep = []
+    if noise is not None:
+        noise = noise.to(torch.float32).contiguous()
+        assert noise.numel() in (oh * ow, n * oh * ow)
+        ep.noise, ep.noise_batch_stride, ep.noise_gain = noise.data_ptr(), (0 if noise.numel() == oh * ow else oh * ow), 1.0
+        keep.append(noise)
+    if b is not None:
+        b = b.to(torch.float32).contiguous()
+        assert b.numel() == c
+        ep.bias = b.data_ptr()
+        keep.append(b)
+    ep.act, ep.alpha, ep.act_gain, ep.clamp = _FUSED_ACTS[act], float(alpha), float(act_gain), (-1.0 if clamp is None else float(clamp))
+    with torch.cuda.device(x.device):
+        st = _plugin.lib.pg_upfirdn2d_bias_act(nat.ptr(x), nat.ptr(f), nat.ptr(y), nat.PG_DTYPE[x.dtype], n, c, ih, iw, nat.i64arr(x.stride()),
+                                               fh, fw, nat.i64arr(f.stride()), oh, ow, nat.i64arr(y.stride()),
+                                               upx, upy, downx, downy, padx0, pady0, int(bool(flip_filter)), float(gain), ctypes.byref(ep), nat.stream_of(x))
+    if st == -2:
+        return None
+    nat.check(st, 'pg_upfirdn2d_bias_act')
+    return y
 
 
 # ---------------------------------------------------------------------------- argument algebra

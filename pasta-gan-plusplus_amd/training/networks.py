@@ -132,6 +132,11 @@ def _modconv_fast(x, weight, styles, noise, up, padding, resample_filter, demodu
     if phases is None:
         return None
     y = conv2d_mfma.conv_transpose2d_forward(x, phases, cout, out_hw, stride=2, in_scale=styles, out_scale=dcoefs)
+    if ep.get('residual') is None:      # FIR + noise + bias_act in one pass over the tensor
+        fused = upfirdn2d.upfirdn2d_bias_act(y, resample_filter, padding=fir_pad, gain=4, noise=noise, b=ep.get('bias'), act=ep.get('act', 'linear'),
+                                             alpha=ep.get('alpha') or 0.0, act_gain=ep.get('gain', 1.0), clamp=ep.get('clamp'))
+        if fused is not None:
+            return fused
     y = upfirdn2d.upfirdn2d(y, resample_filter, padding=fir_pad, gain=4)
     if noise is not None:
         y = y.add_(noise)
@@ -234,10 +239,18 @@ class _ConvBase(nn.Module):
 class Conv2dLayer(_ConvBase):
     """conv2d_resample -> bias_act (networks.py:170-179); `residual` (private) is added to the result."""
 
-    def forward(self, x, gain=1, residual=None):
+    def forward(self, x, gain=1, residual=None, x2=None):
+        """`x2` (private): a second input whose channels follow x's -- `layer(torch.cat([x, x2], 1))` without the copy."""
         act_gain = self.act_gain * gain
         act_clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
         cout, _, k, _ = self.weight.shape
+        if _fast_ok(x, self.weight, self.bias, residual, x2) and self._fast_geometry():
+            ep = dict(bias=self.bias, act=self.activation, alpha=bias_act.activation_funcs[self.activation].def_alpha, gain=act_gain,
+                      clamp=act_clamp, residual=residual)
+            if self.down == 1 and (x2 is None or x.shape[1] % 16 == 0):
+                return conv2d_mfma.conv2d_forward(x, self._packed(False), cout, k, k, pad=(self.padding, self.padding), x2=x2, **ep)
+        if x2 is not None:
+            x, x2 = torch.cat([x, x2], dim=1), None
         if _fast_ok(x, self.weight, self.bias, residual) and self._fast_geometry():
             ep = dict(bias=self.bias, act=self.activation, alpha=bias_act.activation_funcs[self.activation].def_alpha, gain=act_gain,
                       clamp=act_clamp, residual=residual)
@@ -504,8 +517,7 @@ class _SynthesisBlockBase(nn.Module):
             x = self.conv0(x, next(w_iter), fused_modconv=fused_modconv, **layer_kwargs)
             x = self.conv1(x, next(w_iter), fused_modconv=fused_modconv, **layer_kwargs)
             if x.shape[2] > 32:      # concatenate the warped-garment feature map and mix it in (networks.py:2179-2181)
-                x = torch.cat([x, cat_feat[str(x.shape[2])].to(dtype=dtype, memory_format=memory_format)], dim=1)
-                x = self.merge_conv(x)
+                x = self.merge_conv(x, x2=cat_feat[str(x.shape[2])].to(dtype=dtype, memory_format=memory_format))   # conv(cat([x, feat])) without the copy
             if self.TEXTURE:
                 x = self.spade_b512(x, parsing)
 

@@ -301,6 +301,38 @@ def test_conv2d_fused_prologue_epilogue_vs_oracle():
     close(yf, F.conv2d(x, wt.flip([2, 3]), padding=1), 1e-4, 1e-4)
 
 
+def test_conv2d_two_source_equals_concat():
+    """x2 / cin_split: conv over channels of two tensors == conv of their concatenation (merge_conv, networks.py:2179-2181)."""
+    from torch_utils.ops import conv2d_mfma
+    import torch.nn.functional as F
+    for c1, c2, k in ((64, 64, 1), (128, 64, 1), (32, 5, 3), (16, 40, 3)):
+        a, b = det_tensor(f'ts.a.{c1}', [2, c1, 19, 37]), det_tensor(f'ts.b.{c2}', [2, c2, 19, 37])
+        w = det_tensor(f'ts.w.{c1}.{c2}', [70, c1 + c2, k, k], scale=0.1)
+        s = det_tensor(f'ts.s.{c1}', [2, c1 + c2]) + 1
+        y = conv2d_mfma.conv2d_forward(a.to(DEV), conv2d_mfma.pack_weight(w.to(DEV)), 70, k, k, pad=(k // 2, k // 2), x2=b.to(DEV), in_scale=s.to(DEV))
+        ref = F.conv2d(torch.cat([a, b], 1) * s[:, :, None, None], w, padding=k // 2)
+        close(y, ref, 1e-4, 1e-4)
+
+
+def test_upfirdn2d_bias_act_fused_tail():
+    from torch_utils.ops import upfirdn2d
+    from oracle import ops_ref as R
+    f = upfirdn2d.setup_filter(C.FIR_1331)
+    x = det_tensor('ft.x', [2, 6, 33, 65])
+    noise, noise_n = det_tensor('ft.n', [32, 64]), det_tensor('ft.nn', [2, 1, 32, 64])
+    b = det_tensor('ft.b', [6])
+    for nz in (None, noise, noise_n):
+        for act, clamp in (('lrelu', 0.9), ('linear', None), ('relu', None)):
+            y = upfirdn2d.upfirdn2d_bias_act(x.to(DEV), f.to(DEV), padding=[1, 1, 1, 1], gain=4, noise=None if nz is None else nz.to(DEV), b=b.to(DEV),
+                                             act=act, alpha=0.2, act_gain=1.3, clamp=clamp)
+            ref = R.upfirdn2d(x, f, padding=[1, 1, 1, 1], gain=4)
+            if nz is not None:
+                ref = ref + nz
+            ref = R.bias_act(ref, b, act=act, alpha=0.2, gain=1.3, clamp=clamp)
+            close(y, ref, 2e-5, 2e-5)
+    assert upfirdn2d.upfirdn2d_bias_act(x.to(DEV), f.to(DEV), act='tanh') is None          # not fusable -> caller composes
+
+
 def test_conv2d_full_size_linearity_and_delta():
     """config-2 hottest conv shape, [8,64,512,512] * [64,64,3,3]: linearity in x and a delta-kernel identity."""
     from torch_utils.ops import conv2d_gradfix

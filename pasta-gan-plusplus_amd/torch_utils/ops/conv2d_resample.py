@@ -1,12 +1,23 @@
 """2-D convolution with optional FIR up/down-sampling on MI355X.
 
 ``conv2d_resample(x, w, f, up, down, padding, groups, flip_weight, flip_filter)`` with the
-reference's semantics and branch structure (torch_utils/ops/conv2d_resample.py:59-154):
-padding is applied once, up front; 1x1 kernels resample on the cheap side (:107-116);
-down > 1 = FIR then strided conv (:119-122); up > 1 = stride-`up` transposed conv then FIR
-with gain up^2 (:125-142); otherwise a plain padded conv (:145-147) or the generic
-upfirdn2d/conv/upfirdn2d chain (:150-154).  The pieces are this package's HIP ops.
+semantics of the reference op (torch_utils/ops/conv2d_resample.py:59-154): padding is applied
+once, up front, relative to the up-sampled image; which composition of FIR and convolution is
+used depends only on (kernel size, up, down, padding) and fixes where rounding happens, so the
+routes below are the reference's:
+
+    pointwise_down   1x1 kernel, down > 1       FIR-decimate, then mix channels        (:107-110)
+    pointwise_up     1x1 kernel, up > 1         mix channels, then FIR-interpolate     (:113-116)
+    strided          down > 1                   blur, then stride-`down` conv          (:119-122)
+    transposed       up > 1                     stride-`up` transposed conv, then blur (:125-142)
+    plain            symmetric non-negative pad one padded conv                        (:145-147)
+    generic          anything else              pad/crop by upfirdn2d, conv, decimate  (:150-154)
+
+The route is chosen by ``_plan`` (pure integer algebra, testable on its own); the pieces are this
+package's HIP ops (``upfirdn2d`` and the MFMA convolution behind ``conv2d_gradfix``).
 """
+
+import collections
 
 import torch
 
@@ -16,11 +27,42 @@ from . import upfirdn2d
 from .upfirdn2d import _get_filter_size
 from .upfirdn2d import _parse_padding
 
+_Plan = collections.namedtuple('_Plan', 'route fir_pad conv_pad')
+
 
 def _get_weight_shape(w):
     shape = [int(sz) for sz in w.shape]
     misc.assert_shape(w, shape)
     return shape
+
+
+def _plan(kh, kw, fw, fh, up, down, padding):
+    """Route and paddings for one call: `fir_pad` = [x0, x1, y0, y1] handed to upfirdn2d, `conv_pad` = (y, x) of the conv."""
+    pad = list(_parse_padding(padding))                      # x0, x1, y0, y1
+    ext = (fw, fw, fh, fh)
+    for i in range(4):                                       # footprint of the resampling filters, split lo/hi
+        lo = (i % 2 == 0)
+        if up > 1:
+            pad[i] += (ext[i] + up - 1) // 2 if lo else (ext[i] - up) // 2
+        if down > 1:
+            pad[i] += (ext[i] - down + 1) // 2 if lo else (ext[i] - down) // 2
+    pointwise = (kh == 1 and kw == 1)
+    if pointwise and up == 1 and down > 1:
+        return _Plan('pointwise_down', pad, (0, 0))
+    if pointwise and down == 1 and up > 1:
+        return _Plan('pointwise_up', pad, (0, 0))
+    if up == 1 and down > 1:
+        return _Plan('strided', pad, (0, 0))
+    if up > 1:
+        ker = (kw, kw, kh, kh)
+        for i in range(4):                                   # what the transposed conv itself adds on each side
+            pad[i] -= (ker[i] - 1) if i % 2 == 0 else (ker[i] - up)
+        tx = max(min(-pad[0], -pad[1]), 0)                   # the part of a negative pad the conv can absorb
+        ty = max(min(-pad[2], -pad[3]), 0)
+        return _Plan('transposed', [pad[0] + tx, pad[1] + tx, pad[2] + ty, pad[3] + ty], (ty, tx))
+    if pad[0] == pad[1] and pad[2] == pad[3] and pad[0] >= 0 and pad[2] >= 0:
+        return _Plan('plain', pad, (pad[2], pad[0]))
+    return _Plan('generic', pad, (0, 0))
 
 
 def _conv2d_wrapper(x, w, stride=1, padding=0, groups=1, transpose=False, flip_weight=True):
@@ -39,60 +81,30 @@ def conv2d_resample(x, w, f=None, up=1, down=1, padding=0, groups=1, flip_weight
     assert isinstance(up, int) and (up >= 1)
     assert isinstance(down, int) and (down >= 1)
     assert isinstance(groups, int) and (groups >= 1)
-    out_channels, in_channels_per_group, kh, kw = _get_weight_shape(w)
+    cout, cin_per_group, kh, kw = _get_weight_shape(w)
     fw, fh = _get_filter_size(f)
-    px0, px1, py0, py1 = _parse_padding(padding)
+    plan = _plan(kh, kw, fw, fh, up, down, padding)
+    fir = lambda t, **kw_: upfirdn2d.upfirdn2d(x=t, f=f, flip_filter=flip_filter, **kw_)
+    conv = lambda t, **kw_: _conv2d_wrapper(x=t, w=w, groups=groups, flip_weight=flip_weight, **kw_)
 
-    # fold the resampling filters' own footprint into the padding
-    if up > 1:
-        px0 += (fw + up - 1) // 2
-        px1 += (fw - up) // 2
-        py0 += (fh + up - 1) // 2
-        py1 += (fh - up) // 2
-    if down > 1:
-        px0 += (fw - down + 1) // 2
-        px1 += (fw - down) // 2
-        py0 += (fh - down + 1) // 2
-        py1 += (fh - down) // 2
-
-    pointwise = (kw == 1 and kh == 1)
-    if pointwise and down > 1 and up == 1:        # shrink first, then mix channels
-        x = upfirdn2d.upfirdn2d(x=x, f=f, down=down, padding=[px0, px1, py0, py1], flip_filter=flip_filter)
-        return _conv2d_wrapper(x=x, w=w, groups=groups, flip_weight=flip_weight)
-
-    if pointwise and up > 1 and down == 1:        # mix channels first, then grow
-        x = _conv2d_wrapper(x=x, w=w, groups=groups, flip_weight=flip_weight)
-        return upfirdn2d.upfirdn2d(x=x, f=f, up=up, padding=[px0, px1, py0, py1], gain=up ** 2, flip_filter=flip_filter)
-
-    if down > 1 and up == 1:                      # blur, then strided conv
-        x = upfirdn2d.upfirdn2d(x=x, f=f, padding=[px0, px1, py0, py1], flip_filter=flip_filter)
-        return _conv2d_wrapper(x=x, w=w, stride=down, groups=groups, flip_weight=flip_weight)
-
-    if up > 1:                                    # transposed strided conv, then blur
+    if plan.route == 'pointwise_down':
+        return conv(fir(x, down=down, padding=plan.fir_pad))
+    if plan.route == 'pointwise_up':
+        return fir(conv(x), up=up, padding=plan.fir_pad, gain=up ** 2)
+    if plan.route == 'strided':
+        return conv(fir(x, padding=plan.fir_pad), stride=down)
+    if plan.route == 'transposed':
         if groups == 1:
-            w = w.transpose(0, 1)
-        else:
-            w = w.reshape(groups, out_channels // groups, in_channels_per_group, kh, kw)
-            w = w.transpose(1, 2)
-            w = w.reshape(groups * in_channels_per_group, out_channels // groups, kh, kw)
-        px0 -= kw - 1
-        px1 -= kw - up
-        py0 -= kh - 1
-        py1 -= kh - up
-        pxt = max(min(-px0, -px1), 0)
-        pyt = max(min(-py0, -py1), 0)
-        x = _conv2d_wrapper(x=x, w=w, stride=up, padding=[pyt, pxt], groups=groups, transpose=True, flip_weight=(not flip_weight))
-        x = upfirdn2d.upfirdn2d(x=x, f=f, padding=[px0 + pxt, px1 + pxt, py0 + pyt, py1 + pyt], gain=up ** 2, flip_filter=flip_filter)
-        if down > 1:
-            x = upfirdn2d.upfirdn2d(x=x, f=f, down=down, flip_filter=flip_filter)
-        return x
-
-    if up == 1 and down == 1 and px0 == px1 and py0 == py1 and px0 >= 0 and py0 >= 0:
-        return _conv2d_wrapper(x=x, w=w, padding=[py0, px0], groups=groups, flip_weight=flip_weight)
-
-    # anything else: explicit pad/crop through upfirdn2d, conv without padding, optional decimation
-    x = upfirdn2d.upfirdn2d(x=x, f=(f if up > 1 else None), up=up, padding=[px0, px1, py0, py1], gain=up ** 2, flip_filter=flip_filter)
-    x = _conv2d_wrapper(x=x, w=w, groups=groups, flip_weight=flip_weight)
-    if down > 1:
-        x = upfirdn2d.upfirdn2d(x=x, f=f, down=down, flip_filter=flip_filter)
-    return x
+            wt = w.transpose(0, 1)
+        else:                                                # per-group O<->I swap
+            wt = w.reshape(groups, cout // groups, cin_per_group, kh, kw).transpose(1, 2)
+            wt = wt.reshape(groups * cin_per_group, cout // groups, kh, kw)
+        y = _conv2d_wrapper(x=x, w=wt, stride=up, padding=list(plan.conv_pad), groups=groups, transpose=True, flip_weight=(not flip_weight))
+        y = fir(y, padding=plan.fir_pad, gain=up ** 2)
+        return fir(y, down=down) if down > 1 else y
+    if plan.route == 'plain':
+        return conv(x, padding=list(plan.conv_pad))
+    # generic: explicit pad/crop (and zero-stuffing) through upfirdn2d, unpadded conv, optional decimation
+    y = upfirdn2d.upfirdn2d(x=x, f=(f if up > 1 else None), up=up, padding=plan.fir_pad, gain=up ** 2, flip_filter=flip_filter)
+    y = conv(y)
+    return fir(y, down=down) if down > 1 else y

@@ -130,3 +130,26 @@ def test_infinite_sampler_partitions_ranks():
         streams.append([int(next(it)) for _ in range(10)])
     merged = [v for pair in zip(*streams) for v in pair]
     assert sorted(merged[:10]) == data      # one epoch split across ranks covers every index once
+
+
+def test_conv2d_resample_plan():
+    """Route / padding algebra of conv2d_resample (pure integers), against hand-derived values of the reference's
+    formulas (conv2d_resample.py:92-147)."""
+    from torch_utils.ops.conv2d_resample import _plan
+    # SynthesisLayer up=2: 3x3 kernel, 4x4 FIR, padding 1 -> transposed conv without padding, FIR pad 1 (2H+1 -> 2H)
+    p = _plan(3, 3, 4, 4, 2, 1, 1)
+    assert p.route == 'transposed' and p.conv_pad == (0, 0) and p.fir_pad == [1, 1, 1, 1]
+    # Conv2dLayer down=2, 3x3, padding 1 -> blur with pad 2 then stride-2 conv
+    p = _plan(3, 3, 4, 4, 1, 2, 1)
+    assert p.route == 'strided' and p.fir_pad == [2, 2, 2, 2]
+    # 1x1 skip with down=2 / up=2
+    assert _plan(1, 1, 4, 4, 1, 2, 0) == ('pointwise_down', [1, 1, 1, 1], (0, 0))
+    assert _plan(1, 1, 4, 4, 2, 1, 0) == ('pointwise_up', [2, 1, 2, 1], (0, 0))
+    # plain convs
+    assert _plan(3, 3, 4, 4, 1, 1, 1) == ('plain', [1, 1, 1, 1], (1, 1))
+    assert _plan(7, 7, 4, 4, 1, 1, 3).conv_pad == (3, 3)
+    # asymmetric padding falls to the generic route
+    assert _plan(3, 3, 4, 4, 1, 1, [1, 0, 2, 1]).route == 'generic'
+    # a transposed conv with a larger kernel absorbs part of the (negative) FIR padding itself
+    p = _plan(5, 5, 4, 4, 2, 1, 0)
+    assert p.route == 'transposed' and p.conv_pad == (2, 2) and p.fir_pad == [0, 0, 0, 0]

@@ -467,3 +467,107 @@ class GeneratorFull_v20(nn.Module):
         cat_feats = {str(f.shape[2]): f for f in feats}
         return self.synthesis(ws, pose_feat, cat_feats, denorm_upper_input, denorm_lower_input, denorm_upper_mask,
                               denorm_lower_mask, gt_parsing, **synthesis_kwargs)
+
+
+# ==========================================================================
+# "next" row f2: the discriminators of the training step (networks.py:444-666).
+
+
+class DiscriminatorBlock(nn.Module):
+    """networks.py:444-523 ('resnet' architecture; fp32)."""
+
+    def __init__(self, in_channels, tmp_channels, out_channels, resolution, img_channels, first_layer_idx, architecture='resnet',
+                 activation='lrelu', resample_filter=(1, 3, 3, 1), conv_clamp=None, **_unused):
+        super().__init__()
+        assert architecture == 'resnet' and in_channels in (0, tmp_channels)
+        self.in_channels, self.resolution, self.img_channels = in_channels, resolution, img_channels
+        self.register_buffer('resample_filter', R.setup_filter(list(resample_filter)))
+        self.num_layers = 0
+        if in_channels == 0:
+            self.fromrgb = Conv2dLayer(img_channels, tmp_channels, kernel_size=1, activation=activation, conv_clamp=conv_clamp)
+            self.num_layers += 1
+        self.conv0 = Conv2dLayer(tmp_channels, tmp_channels, kernel_size=3, activation=activation, conv_clamp=conv_clamp)
+        self.conv1 = Conv2dLayer(tmp_channels, out_channels, kernel_size=3, activation=activation, down=2, resample_filter=resample_filter, conv_clamp=conv_clamp)
+        self.skip = Conv2dLayer(tmp_channels, out_channels, kernel_size=1, bias=False, down=2, resample_filter=resample_filter)
+        self.num_layers += 3
+
+    def forward(self, x, img):
+        if self.in_channels == 0:
+            y = self.fromrgb(img.to(torch.float32))
+            x = y if x is None else x + y
+            img = None
+        y = self.skip(x, gain=SQRT_HALF)
+        x = self.conv0(x)
+        x = self.conv1(x, gain=SQRT_HALF)
+        return y + x, img
+
+
+class MinibatchStdLayer(nn.Module):
+    """networks.py:528-549."""
+
+    def __init__(self, group_size, num_channels=1):
+        super().__init__()
+        self.group_size, self.num_channels = group_size, num_channels
+
+    def forward(self, x):
+        n, c, h, w = x.shape
+        g = min(self.group_size, n) if self.group_size is not None else n
+        f = self.num_channels
+        y = x.reshape(g, -1, f, c // f, h, w)
+        y = y - y.mean(dim=0)
+        y = (y.square().mean(dim=0) + 1e-8).sqrt()
+        y = y.mean(dim=[2, 3, 4]).reshape(-1, f, 1, 1).repeat(g, 1, h, w)
+        return torch.cat([x, y], dim=1)
+
+
+class DiscriminatorEpilogue(nn.Module):
+    """networks.py:554-607 ('resnet')."""
+
+    def __init__(self, in_channels, cmap_dim, resolution, img_channels, architecture='resnet', mbstd_group_size=4, mbstd_num_channels=1,
+                 activation='lrelu', conv_clamp=None):
+        super().__init__()
+        self.cmap_dim = cmap_dim
+        self.mbstd = MinibatchStdLayer(mbstd_group_size, mbstd_num_channels) if mbstd_num_channels > 0 else None
+        self.conv = Conv2dLayer(in_channels + mbstd_num_channels, in_channels, kernel_size=3, activation=activation, conv_clamp=conv_clamp)
+        self.fc = FullyConnectedLayer(in_channels * resolution ** 2, in_channels, activation=activation)
+        self.out = FullyConnectedLayer(in_channels, 1 if cmap_dim == 0 else cmap_dim)
+
+    def forward(self, x, img, cmap):
+        x = x.to(torch.float32)
+        if self.mbstd is not None:
+            x = self.mbstd(x)
+        x = self.out(self.fc(self.conv(x).flatten(1)))
+        if self.cmap_dim > 0:
+            x = (x * cmap).sum(dim=1, keepdim=True) * (1 / math.sqrt(self.cmap_dim))
+        return x
+
+
+class Discriminator(nn.Module):
+    """networks.py:612-666."""
+
+    def __init__(self, c_dim, img_resolution, img_channels, architecture='resnet', channel_base=32768, channel_max=512, num_fp16_res=0,
+                 conv_clamp=None, cmap_dim=None, block_kwargs={}, mapping_kwargs={}, epilogue_kwargs={}):
+        super().__init__()
+        self.c_dim, self.img_resolution, self.img_channels = c_dim, img_resolution, img_channels
+        self.block_resolutions = [2 ** i for i in range(int(math.log2(img_resolution)), 2, -1)]
+        ch = {res: min(channel_base // res, channel_max) for res in self.block_resolutions + [4]}
+        if cmap_dim is None:
+            cmap_dim = ch[4]
+        if c_dim == 0:
+            cmap_dim = 0
+        common = dict(img_channels=img_channels, architecture=architecture, conv_clamp=conv_clamp)
+        idx = 0
+        for res in self.block_resolutions:
+            block = DiscriminatorBlock(ch[res] if res < img_resolution else 0, ch[res], ch[res // 2], resolution=res, first_layer_idx=idx, **block_kwargs, **common)
+            setattr(self, f'b{res}', block)
+            idx += block.num_layers
+        if c_dim > 0:
+            self.mapping = MappingNetwork(z_dim=0, c_dim=c_dim, w_dim=cmap_dim, num_ws=None, w_avg_beta=None, **mapping_kwargs)
+        self.b4 = DiscriminatorEpilogue(ch[4], cmap_dim=cmap_dim, resolution=4, **epilogue_kwargs, **common)
+
+    def forward(self, img, c, **_):
+        x = None
+        for res in self.block_resolutions:
+            x, img = getattr(self, f'b{res}')(x, img)
+        cmap = self.mapping(None, c) if self.c_dim > 0 else None
+        return self.b4(x, img, cmap)

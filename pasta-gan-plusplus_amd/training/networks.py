@@ -776,3 +776,145 @@ class GeneratorFull_v20(nn.Module):
         cat_feats = {str(feat.shape[2]): feat for feat in feats}
         return self.synthesis(ws, pose_feat, cat_feats, denorm_upper_input, denorm_lower_input, denorm_upper_mask,
                               denorm_lower_mask, gt_parsing, **synthesis_kwargs)
+
+
+# ============================================================================
+# Downstream of synthesis in the training step: the two discriminators
+# (image+pose, 6 channels; parsing+pose, 10 channels).  Same ops again; fp16 blocks (num_fp16_res > 0) run their
+# convolutions through PyTorch-ROCm (the MFMA kernel is fp32), bias_act / upfirdn2d stay on the HIP kernels.
+
+class DiscriminatorBlock(nn.Module):
+    """reference networks.py:444-523."""
+
+    def __init__(self, in_channels, tmp_channels, out_channels, resolution, img_channels, first_layer_idx, architecture='resnet',
+                 activation='lrelu', resample_filter=[1, 3, 3, 1], conv_clamp=None, use_fp16=False, fp16_channels_last=False, freeze_layers=0):
+        assert in_channels in [0, tmp_channels]
+        assert architecture in ['orig', 'skip', 'resnet']
+        super().__init__()
+        self.in_channels, self.resolution, self.img_channels = in_channels, resolution, img_channels
+        self.first_layer_idx, self.architecture, self.use_fp16 = first_layer_idx, architecture, use_fp16
+        self.channels_last = (use_fp16 and fp16_channels_last)
+        self.register_buffer('resample_filter', upfirdn2d.setup_filter(resample_filter))
+        self.num_layers = 0
+
+        def next_trainable():
+            trainable = (self.first_layer_idx + self.num_layers >= freeze_layers)
+            self.num_layers += 1
+            return trainable
+        kw = dict(conv_clamp=conv_clamp, channels_last=self.channels_last)
+        if in_channels == 0 or architecture == 'skip':
+            self.fromrgb = Conv2dLayer(img_channels, tmp_channels, kernel_size=1, activation=activation, trainable=next_trainable(), **kw)
+        self.conv0 = Conv2dLayer(tmp_channels, tmp_channels, kernel_size=3, activation=activation, trainable=next_trainable(), **kw)
+        self.conv1 = Conv2dLayer(tmp_channels, out_channels, kernel_size=3, activation=activation, down=2, trainable=next_trainable(),
+                                 resample_filter=resample_filter, **kw)
+        if architecture == 'resnet':
+            self.skip = Conv2dLayer(tmp_channels, out_channels, kernel_size=1, bias=False, down=2, trainable=next_trainable(),
+                                    resample_filter=resample_filter, channels_last=self.channels_last)
+
+    def forward(self, x, img, force_fp32=False):
+        dtype = torch.float16 if self.use_fp16 and not force_fp32 else torch.float32
+        memory_format = torch.channels_last if self.channels_last and not force_fp32 else torch.contiguous_format
+        if x is not None:
+            misc.assert_shape(x, [None, self.in_channels, self.resolution, self.resolution])
+            x = x.to(dtype=dtype, memory_format=memory_format)
+        if self.in_channels == 0 or self.architecture == 'skip':
+            misc.assert_shape(img, [None, self.img_channels, self.resolution, self.resolution])
+            img = img.to(dtype=dtype, memory_format=memory_format)
+            y = self.fromrgb(img)
+            x = x + y if x is not None else y
+            img = upfirdn2d.downsample2d(img, self.resample_filter) if self.architecture == 'skip' else None
+        if self.architecture == 'resnet':
+            y = self.skip(x, gain=SQRT_HALF)
+            x = self.conv0(x)
+            x = self.conv1(x, gain=SQRT_HALF, residual=y)
+        else:
+            x = self.conv0(x)
+            x = self.conv1(x)
+        assert x.dtype == dtype
+        return x, img
+
+
+class MinibatchStdLayer(nn.Module):
+    """reference networks.py:528-549: per-group stddev over the batch as an extra feature map."""
+
+    def __init__(self, group_size, num_channels=1):
+        super().__init__()
+        self.group_size, self.num_channels = group_size, num_channels
+
+    def forward(self, x):
+        N, C, H, W = x.shape
+        G = min(int(self.group_size), int(N)) if self.group_size is not None else int(N)
+        F = self.num_channels
+        c = C // F
+        y = x.reshape(G, -1, F, c, H, W)
+        y = y - y.mean(dim=0)
+        y = (y.square().mean(dim=0) + 1e-8).sqrt()
+        y = y.mean(dim=[2, 3, 4]).reshape(-1, F, 1, 1).repeat(G, 1, H, W)
+        return torch.cat([x, y], dim=1)
+
+
+class DiscriminatorEpilogue(nn.Module):
+    """reference networks.py:554-607."""
+
+    def __init__(self, in_channels, cmap_dim, resolution, img_channels, architecture='resnet', mbstd_group_size=4, mbstd_num_channels=1,
+                 activation='lrelu', conv_clamp=None):
+        assert architecture in ['orig', 'skip', 'resnet']
+        super().__init__()
+        self.in_channels, self.cmap_dim, self.resolution, self.img_channels, self.architecture = in_channels, cmap_dim, resolution, img_channels, architecture
+        if architecture == 'skip':
+            self.fromrgb = Conv2dLayer(img_channels, in_channels, kernel_size=1, activation=activation)
+        self.mbstd = MinibatchStdLayer(group_size=mbstd_group_size, num_channels=mbstd_num_channels) if mbstd_num_channels > 0 else None
+        self.conv = Conv2dLayer(in_channels + mbstd_num_channels, in_channels, kernel_size=3, activation=activation, conv_clamp=conv_clamp)
+        self.fc = FullyConnectedLayer(in_channels * (resolution ** 2), in_channels, activation=activation)
+        self.out = FullyConnectedLayer(in_channels, 1 if cmap_dim == 0 else cmap_dim)
+
+    def forward(self, x, img, cmap, force_fp32=False):
+        misc.assert_shape(x, [None, self.in_channels, self.resolution, self.resolution])
+        x = x.to(dtype=torch.float32, memory_format=torch.contiguous_format)
+        if self.architecture == 'skip':
+            misc.assert_shape(img, [None, self.img_channels, self.resolution, self.resolution])
+            x = x + self.fromrgb(img.to(dtype=torch.float32, memory_format=torch.contiguous_format))
+        if self.mbstd is not None:
+            x = self.mbstd(x)
+        x = self.conv(x)
+        x = self.fc(x.flatten(1))
+        x = self.out(x)
+        if self.cmap_dim > 0:
+            misc.assert_shape(cmap, [None, self.cmap_dim])
+            x = (x * cmap).sum(dim=1, keepdim=True) * (1 / np.sqrt(self.cmap_dim))
+        return x
+
+
+class Discriminator(nn.Module):
+    """reference networks.py:612-666."""
+
+    def __init__(self, c_dim, img_resolution, img_channels, architecture='resnet', channel_base=32768, channel_max=512, num_fp16_res=0,
+                 conv_clamp=None, cmap_dim=None, block_kwargs={}, mapping_kwargs={}, epilogue_kwargs={}):
+        super().__init__()
+        self.c_dim, self.img_resolution, self.img_channels = c_dim, img_resolution, img_channels
+        self.img_resolution_log2 = int(np.log2(img_resolution))
+        self.block_resolutions = [2 ** i for i in range(self.img_resolution_log2, 2, -1)]
+        channels_dict = {res: min(channel_base // res, channel_max) for res in self.block_resolutions + [4]}
+        fp16_resolution = max(2 ** (self.img_resolution_log2 + 1 - num_fp16_res), 8)
+        if cmap_dim is None:
+            cmap_dim = channels_dict[4]
+        if c_dim == 0:
+            cmap_dim = 0
+        common_kwargs = dict(img_channels=img_channels, architecture=architecture, conv_clamp=conv_clamp)
+        cur_layer_idx = 0
+        for res in self.block_resolutions:
+            in_channels = channels_dict[res] if res < img_resolution else 0
+            block = DiscriminatorBlock(in_channels, channels_dict[res], channels_dict[res // 2], resolution=res, first_layer_idx=cur_layer_idx,
+                                       use_fp16=(res >= fp16_resolution), **block_kwargs, **common_kwargs)
+            setattr(self, f'b{res}', block)
+            cur_layer_idx += block.num_layers
+        if c_dim > 0:
+            self.mapping = MappingNetwork(z_dim=0, c_dim=c_dim, w_dim=cmap_dim, num_ws=None, w_avg_beta=None, **mapping_kwargs)
+        self.b4 = DiscriminatorEpilogue(channels_dict[4], cmap_dim=cmap_dim, resolution=4, **epilogue_kwargs, **common_kwargs)
+
+    def forward(self, img, c, **block_kwargs):
+        x = None
+        for res in self.block_resolutions:
+            x, img = getattr(self, f'b{res}')(x, img, **block_kwargs)
+        cmap = self.mapping(None, c) if self.c_dim > 0 else None
+        return self.b4(x, img, cmap)

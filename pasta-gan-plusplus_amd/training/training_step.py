@@ -1,0 +1,84 @@
+"""One iteration of the full-body training schedule (reference training/training_loop_fullbody.py:468-481, 604-650),
+data-parallel over the GPUs of one node.
+
+Phases, in order (each with its own Adam; lazy regularisation rescales lr/betas by interval/(interval+1)):
+    Gmain (1)  Greg (G_reg_interval)  Dmain (1)  Dreg (D_reg_interval)  D_parsingmain (1)  D_parsingreg (D_reg_interval)
+    D_parsingmain (1)  D_parsingreg (D_reg_interval)        -- D_parsing is listed twice in the reference (:470-471)
+Per due phase: zero grads -> only the phase's module requires grad -> accumulate over the rounds of this rank's
+share of the batch -> ONE flat-bucket gradient all-reduce (training.ddp.GradBucket) -> nan_to_num -> Adam step.
+Then the G_ema update (:642-650).  ADA / ticks / snapshots / metrics are outside the hot path and not restated.
+"""
+
+import copy
+
+import torch
+
+from . import ddp
+
+
+class Phase:
+    def __init__(self, name, modules, opt, interval, bucket):
+        self.name, self.modules, self.opt, self.interval, self.bucket = name, modules, opt, interval, bucket
+
+
+class TrainingStep:
+    def __init__(self, G_parts, D, D_parsing, loss, lr=0.0005, betas=(0.0, 0.99), eps=1e-8, G_reg_interval=4, D_reg_interval=16,
+                 batch_size=32, ema_kimg=10, ema_rampup=None, G_ema_parts=None):
+        """`G_parts`: dict name -> module for G_mapping / G_synthesis / G_const_encoding / G_style_encoding."""
+        self.G_parts, self.D, self.D_parsing, self.loss = G_parts, D, D_parsing, loss
+        self.batch_size, self.ema_kimg, self.ema_rampup = batch_size, ema_kimg, ema_rampup
+        self.G_ema_parts = G_ema_parts if G_ema_parts is not None else {k: copy.deepcopy(m).eval().requires_grad_(False) for k, m in G_parts.items()}
+        self.all_modules = list(G_parts.values()) + [D, D_parsing]
+        for m in self.all_modules:
+            m.requires_grad_(False)
+        self.phases = []
+        for name, modules, interval in (('G', list(G_parts.values()), G_reg_interval), ('D', [D], D_reg_interval),
+                                        ('D_parsing', [D_parsing], D_reg_interval), ('D_parsing', [D_parsing], D_reg_interval)):
+            params = [p for m in modules for p in m.parameters()]
+            bucket = ddp.GradBucket(params)
+            if interval is None:
+                opt = torch.optim.Adam(params, lr=lr, betas=tuple(betas), eps=eps)
+                self.phases.append(Phase(name + 'both', modules, opt, 1, bucket))
+            else:
+                ratio = interval / (interval + 1)
+                opt = torch.optim.Adam(params, lr=lr * ratio, betas=tuple(b ** ratio for b in betas), eps=eps)
+                self.phases.append(Phase(name + 'main', modules, opt, 1, bucket))
+                self.phases.append(Phase(name + 'reg', modules, opt, interval, bucket))
+        self.cur_nimg = 0
+        self.batch_idx = 0
+
+    def due_phases(self):
+        return [ph for ph in self.phases if self.batch_idx % ph.interval == 0]
+
+    def run(self, rounds):
+        """`rounds`: this rank's accumulation rounds, each a dict of the tensors accumulate_gradients takes
+        (real_img, gen_z, style_input, retain, pose, denorm_*_input, denorm_*_mask, gt_parsing)."""
+        for ph in self.due_phases():
+            ph.opt.zero_grad(set_to_none=True)
+            for m in ph.modules:
+                m.requires_grad_(True)
+            for r, batch in enumerate(rounds):
+                self.loss.accumulate_gradients(phase=ph.name, sync=(r == len(rounds) - 1), gain=ph.interval, **batch)
+            for m in ph.modules:
+                m.requires_grad_(False)
+            ph.bucket.all_reduce_mean()                          # the one exchange step of the phase (RCCL over xGMI)
+            for p in ph.bucket.params:
+                if p.grad is not None:
+                    torch.nan_to_num(p.grad, nan=0, posinf=1e5, neginf=-1e5, out=p.grad)
+            ph.opt.step()
+        self._update_ema()
+        self.cur_nimg += self.batch_size
+        self.batch_idx += 1
+
+    @torch.no_grad()
+    def _update_ema(self):
+        ema_nimg = self.ema_kimg * 1000
+        if self.ema_rampup is not None:
+            ema_nimg = min(ema_nimg, self.cur_nimg * self.ema_rampup)
+        beta = 0.5 ** (self.batch_size / max(ema_nimg, 1e-8))
+        for name, m in self.G_parts.items():
+            ema = self.G_ema_parts[name]
+            for p_ema, p in zip(ema.parameters(), m.parameters()):
+                p_ema.copy_(p.lerp(p_ema, beta))
+            for b_ema, b in zip(ema.buffers(), m.buffers()):
+                b_ema.copy_(b)

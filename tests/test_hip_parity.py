@@ -582,3 +582,104 @@ def test_full_generator_vs_oracle():
         s = scale_of(b)
         delta = float((a.cpu().double() - b.double()).abs().max())
         assert delta <= 1e-3 * s, f'{nm}: max-abs delta {delta:.3e} vs output range {s:.3e}'
+
+
+def test_discriminator_with_r1_double_backward_golden(golden):
+    """Row f2 on the GPU: training-mode Discriminator (graph route) incl. the R1 double backward through the HIP ops'
+    own gradient kernels (bias_act grad 1 re-applied, upfirdn2d transposed) and aten's conv double-backward."""
+    from training import networks as PN
+    from oracle import network_ref as NR
+    g = golden('g8_discriminator.npz')
+    kw = dict(c_dim=16, img_resolution=32, img_channels=6, channel_base=512, channel_max=32, conv_clamp=256,
+              mapping_kwargs=dict(num_layers=2), epilogue_kwargs=dict(mbstd_group_size=2))
+    d = PN.Discriminator(**kw)
+    d.load_state_dict(fill_module_(NR.Discriminator(**kw), 'g8.d.').state_dict(), strict=False)
+    d = d.to(DEV).train()
+    assert [n for n, _ in d.named_parameters()] == list(g['r1_grad_names'])
+    img = det_tensor('g8.img', [4, 6, 32, 32], 'uniform').to(DEV).requires_grad_(True)
+    c = det_tensor('g8.c', [4, 16]).to(DEV)
+    logits = d(img, c)
+    close(logits, g['logits'], 1e-3, 1e-4)
+    with torch.no_grad():
+        close(d(img.detach(), c), g['logits'], 1e-3, 1e-4)          # inference route gives the same logits
+    gi, = torch.autograd.grad(logits.sum(), img, create_graph=True)
+    pen = gi.square().sum([1, 2, 3])
+    close(pen, g['r1_penalty'], 2e-3, 1e-6)
+    grads = torch.autograd.grad(pen.sum(), list(d.parameters()), allow_unused=True)
+    got = np.array([float(x.abs().sum()) if x is not None else 0.0 for x in grads])
+    np.testing.assert_allclose(got, g['r1_grad_abssum'], rtol=5e-3, atol=1e-6)
+
+
+# =============================================================== training step (config 4 rows)
+
+def _d_kw(img_channels):
+    return dict(c_dim=6, img_resolution=16, img_channels=img_channels, channel_base=256, channel_max=32, conv_clamp=256,
+                mapping_kwargs=dict(num_layers=1), epilogue_kwargs=dict(mbstd_group_size=2))
+
+
+@pytest.mark.parametrize('phase', ['Dboth', 'D_parsingboth', 'Gmain'])
+def test_training_phase_gradients_vs_oracle(phase):
+    """The product discriminators (HIP ops, graph route, R1 double backward) inside the product loss on the GPU against the
+    oracle discriminators inside the same loss on the CPU; generator side = the plain-torch stub networks."""
+    import stubs
+    from training import networks as PN
+    from training.loss import StyleGAN2Loss
+    from oracle import network_ref as NR
+
+    def run(device, D_cls):
+        nets = stubs.build(device)
+        for name, ch in (('D', 6), ('D_parsing', 10)):
+            ref = fill_module_(NR.Discriminator(**_d_kw(ch)), f'tp.{name}.')
+            d = D_cls(**_d_kw(ch))
+            d.load_state_dict(ref.state_dict(), strict=False)
+            nets[name] = d.to(device).train()
+        loss = StyleGAN2Loss(device=torch.device(device), **nets, style_mixing_prob=0, r1_gamma=10, l1_weight=50, mask_weight=1.0)
+        stubs.zero_grads(nets)
+        stubs.set_phase_trainable(nets, phase)
+        loss.accumulate_gradients(phase=phase, gain=1, **stubs.batch(4, device))
+        return stubs.grad_signature(nets)
+
+    got, want = run(DEV, PN.Discriminator), run('cpu', NR.Discriminator)
+    assert got.keys() == want.keys()
+    for k in want:
+        assert abs(got[k] - want[k]) <= 3e-3 * abs(want[k]) + 1e-6, (k, got[k], want[k])
+    assert any(v > 0 for v in got.values())
+
+
+def test_full_width_training_iteration_smoke():
+    """One iteration of the 8-phase schedule (all phases due) with the full-width generator and both discriminators at
+    N=2 on one GPU: finite gradients, every module updated, EMA tracking; exercises GradBucket's single-rank path."""
+    import time
+    from training import networks as PN
+    from training.loss import StyleGAN2Loss
+    from training.training_step import TrainingStep
+    torch.manual_seed(0)
+    G = PN.GeneratorFull_v20(z_dim=0, c_dim=512, w_dim=512, img_resolution=512, img_channels=3, mapping_kwargs=dict(num_layers=1),
+                             synthesis_kwargs=dict(channel_base=32768, channel_max=512, conv_clamp=256)).to(DEV).train()
+    dkw = dict(c_dim=512, img_resolution=512, channel_base=32768, channel_max=512, conv_clamp=256, epilogue_kwargs=dict(mbstd_group_size=2))
+    D, DP = PN.Discriminator(img_channels=6, **dkw).to(DEV).train(), PN.Discriminator(img_channels=10, **dkw).to(DEV).train()
+    with torch.no_grad():
+        for m in (G, D, DP):
+            for name, p in m.named_parameters():
+                if name.endswith('noise_strength'):
+                    p.fill_(0.1)
+    parts = dict(G_mapping=G.mapping, G_synthesis=G.synthesis, G_const_encoding=G.const_encoding, G_style_encoding=G.style_encoding)
+    loss = StyleGAN2Loss(device=torch.device(DEV), **parts, D=D, D_parsing=DP, style_mixing_prob=0.9, r1_gamma=10, l1_weight=50, mask_weight=1.0)
+    step = TrainingStep(parts, D, DP, loss, batch_size=2)
+    n = 2
+    gen = torch.Generator(device='cpu').manual_seed(1)
+    u = lambda *s: (torch.rand(*s, generator=gen) * 2 - 1).to(DEV)
+    batch = dict(real_img=u(n, 3, 512, 512), gen_z=torch.zeros([n, 0], device=DEV), style_input=u(n, 45, 128, 128), retain=u(n, 6, 512, 512),
+                 pose=u(n, 5, 512, 512), denorm_upper_input=u(n, 3, 512, 512), denorm_lower_input=u(n, 3, 512, 512),
+                 denorm_upper_mask=(u(n, 1, 512, 512) > 0).float(), denorm_lower_mask=(u(n, 1, 512, 512) > 0).float(),
+                 gt_parsing=torch.randint(0, 7, [n, 1, 512, 512], generator=gen).float().to(DEV))
+    before = [p.detach().clone() for p in list(G.synthesis.parameters())[:8]] + [p.detach().clone() for p in list(D.parameters())[:4]]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    step.run([batch])
+    torch.cuda.synchronize()
+    print(f'full-width training iteration (all 8 phases, N={n}): {time.perf_counter() - t0:.2f} s')
+    after = list(G.synthesis.parameters())[:8] + list(D.parameters())[:4]
+    assert all(torch.isfinite(p).all() for m in (G, D, DP) for p in m.parameters())
+    assert sum(int(not torch.equal(a, b)) for a, b in zip(before, after)) >= 8
+    assert step.batch_idx == 1

@@ -186,3 +186,23 @@ def test_encoders_and_mapping(golden):
         close(mp2(det_tensor('g7.map2.z', [3, 16]), det_tensor('g7.map2.c', [3, 8]), truncation_psi=0.7, truncation_cutoff=3), g['map2/ws'], **tol)
         dn = fill_module_(NR.Dense(6, 10), 'g7.dense.')
         close(dn(det_tensor('g7.dense.x', [2, 6, 9, 11])), g['dense/y'], **tol)
+
+
+G8_KW = dict(c_dim=16, img_resolution=32, img_channels=6, channel_base=512, channel_max=32, conv_clamp=256,
+             mapping_kwargs=dict(num_layers=2), epilogue_kwargs=dict(mbstd_group_size=2))
+
+
+def test_discriminator_with_r1_double_backward(golden):
+    """Row f2: Discriminator logits and the R1 penalty's parameter gradients (double backward, loss_fullbody.py:262-274)."""
+    g = golden('g8_discriminator.npz')
+    d = fill_module_(NR.Discriminator(**G8_KW), 'g8.d.')
+    assert [n for n, _ in d.named_parameters()] == list(g['r1_grad_names'])
+    img = det_tensor('g8.img', [4, 6, 32, 32], 'uniform').requires_grad_(True)
+    logits = d(img, det_tensor('g8.c', [4, 16]))
+    close(logits, g['logits'], rtol=1e-3, atol=1e-4)
+    gi, = torch.autograd.grad(logits.sum(), img, create_graph=True)
+    pen = gi.square().sum([1, 2, 3])
+    close(pen, g['r1_penalty'], rtol=2e-3, atol=1e-6)
+    grads = torch.autograd.grad(pen.sum(), list(d.parameters()), allow_unused=True)
+    got = np.array([float(x.abs().sum()) if x is not None else 0.0 for x in grads])
+    np.testing.assert_allclose(got, g['r1_grad_abssum'], rtol=5e-3, atol=1e-6)

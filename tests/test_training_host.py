@@ -1,0 +1,104 @@
+"""CPU tests of the training step's host logic (loss / phase orchestration, flat-bucket gradient exchange), with tiny
+stub networks: the product's loss is pinned against the REFERENCE's StyleGAN2Loss (golden G9), and the 2-rank gloo
+run must reproduce the single-process averaged gradients."""
+
+import os
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import stubs
+
+PKG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'pasta-gan-plusplus_amd')
+
+
+def _loss(nets):
+    from training.loss import StyleGAN2Loss
+    return StyleGAN2Loss(device=torch.device('cpu'), **nets, augment_pipe=None, style_mixing_prob=0, r1_gamma=10, pl_weight=0,
+                         l1_weight=50, vgg_weight=0, contextual_weight=0, mask_weight=1.0)
+
+
+@pytest.mark.parametrize('phase', stubs.PHASES)
+def test_loss_phases_match_reference(golden, phase):
+    g = golden('g9_loss.npz')
+    nets = stubs.build()
+    loss = _loss(nets)
+    stubs.zero_grads(nets)
+    stubs.set_phase_trainable(nets, phase)
+    loss.accumulate_gradients(phase=phase, sync=True, gain=(16 if phase.endswith('reg') else 1), **stubs.batch())
+    sig = stubs.grad_signature(nets)
+    assert list(sig.keys()) == list(g[f'{phase}/names'])
+    np.testing.assert_allclose(np.array(list(sig.values())), g[f'{phase}/abssum'], rtol=2e-4, atol=1e-7)
+
+
+def test_vgg_terms_are_refused():
+    from training.loss import StyleGAN2Loss
+    with pytest.raises(NotImplementedError):
+        StyleGAN2Loss(device=torch.device('cpu'), **stubs.build(), vgg_weight=50)
+
+
+def test_training_step_schedule_and_ema():
+    from training.training_step import TrainingStep
+    nets = stubs.build()
+    G_parts = {k: v for k, v in nets.items() if k.startswith('G_')}
+    step = TrainingStep(G_parts, nets['D'], nets['D_parsing'], _loss(nets), batch_size=4)
+    assert [p.name for p in step.phases] == ['Gmain', 'Greg', 'Dmain', 'Dreg', 'D_parsingmain', 'D_parsingreg', 'D_parsingmain', 'D_parsingreg']
+    assert [p.interval for p in step.phases] == [1, 4, 1, 16, 1, 16, 1, 16]
+    g_opt = step.phases[0].opt.param_groups[0]
+    assert abs(g_opt['lr'] - 0.0005 * 4 / 5) < 1e-12 and abs(g_opt['betas'][1] - 0.99 ** (4 / 5)) < 1e-12
+    d_opt = step.phases[2].opt.param_groups[0]
+    assert abs(d_opt['lr'] - 0.0005 * 16 / 17) < 1e-12
+    before = {k: [p.clone() for p in m.parameters()] for k, m in nets.items()}
+    ema_before = [p.clone() for p in step.G_ema_parts['G_synthesis'].parameters()]
+    b = stubs.batch()
+    step.run([b])                                   # batch_idx 0: every phase is due
+    assert step.batch_idx == 1 and [p.name for p in step.due_phases()] == ['Gmain', 'Dmain', 'D_parsingmain', 'D_parsingmain']
+    for k, m in nets.items():
+        assert any(not torch.equal(a, p) for a, p in zip(before[k], m.parameters())), f'{k} was not updated'
+        assert all(not p.requires_grad for p in m.parameters())
+    assert any(not torch.equal(a, p) for a, p in zip(ema_before, step.G_ema_parts['G_synthesis'].parameters()))
+    step.run([b])
+    assert step.batch_idx == 2 and all(torch.isfinite(p).all() for m in nets.values() for p in m.parameters())
+
+
+def _ddp_worker(rank, world, init_file, out_file):
+    sys.path.insert(0, PKG)
+    from training import ddp
+    torch.set_num_threads(2)
+    dist.init_process_group('gloo', init_method=f'file://{init_file}', rank=rank, world_size=world)
+    nets = stubs.build()
+    loss = _loss(nets)
+    full = stubs.batch(4)
+    mine = {k: v[rank::world] for k, v in full.items()}            # rank-strided shard of the batch
+    stubs.set_phase_trainable(nets, 'Dboth')
+    loss.accumulate_gradients(phase='Dboth', **mine)
+    params = list(nets['D'].parameters())
+    assert params[0].grad is not None
+    extra = torch.nn.Parameter(torch.zeros(3))                      # a parameter that never receives a gradient
+    bucket = ddp.GradBucket(params + [extra])
+    bucket.all_reduce_mean()
+    assert extra.grad is not None and float(extra.grad.abs().sum()) == 0.0
+    if rank == 0:
+        np.savez(out_file, **{f'p{i}': p.grad.numpy() for i, p in enumerate(params)})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_bucket_all_reduce_two_ranks():
+    """mean over 2 ranks of per-shard gradients == gradient of the mean loss over the whole batch (the StubD has no
+    cross-sample coupling), for a phase with a double-backward term (R1)."""
+    with tempfile.TemporaryDirectory() as tmp:
+        init_file, out_file = os.path.join(tmp, 'rdzv'), os.path.join(tmp, 'g.npz')
+        mp.spawn(_ddp_worker, args=(2, init_file, out_file), nprocs=2, join=True)
+        got = np.load(out_file)
+    nets = stubs.build()
+    loss = _loss(nets)
+    stubs.set_phase_trainable(nets, 'Dboth')
+    loss.accumulate_gradients(phase='Dboth', **stubs.batch(4))
+    for i, p in enumerate(nets['D'].parameters()):
+        np.testing.assert_allclose(got[f'p{i}'], p.grad.numpy(), rtol=2e-4, atol=1e-6)

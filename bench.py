@@ -87,6 +87,53 @@ def cpu_baseline(max_seconds=40.0):
                        f'({", ".join(f"{t:.1f}s" for t in times)}), fastest reported; host reports {avail} logical CPUs')
 
 
+def run_train(args, rank, world, dev, dist):
+    """BASELINE config 4 (secondary, --mode train): iterations/s of the 8-phase fullbody G+D step incl. lazy R1, batch 4 per
+    GPU, flat-bucket gradient all-reduce over RCCL.  VGG/contextual losses omitted (weights unavailable offline); the
+    convolution backward passes are aten::convolution_backward (MIOpen) -- hand-written backward kernels are a later row."""
+    from training import networks, replicas
+    from training.loss import StyleGAN2Loss
+    from training.training_step import TrainingStep
+    from training import ddp
+    torch.manual_seed(0)                                       # same initial weights on every rank
+    G = networks.GeneratorFull_v20(z_dim=0, c_dim=512, w_dim=512, img_resolution=512, img_channels=3, mapping_kwargs=dict(num_layers=1),
+                                   synthesis_kwargs=dict(channel_base=32768, channel_max=512, conv_clamp=256)).to(dev).train()
+    dkw = dict(c_dim=512, img_resolution=512, channel_base=32768, channel_max=512, conv_clamp=256, epilogue_kwargs=dict(mbstd_group_size=4))
+    D = networks.Discriminator(img_channels=6, **dkw).to(dev).train()
+    DP = networks.Discriminator(img_channels=10, **dkw).to(dev).train()
+    ddp.broadcast_parameters([G, D, DP])
+    parts = dict(G_mapping=G.mapping, G_synthesis=G.synthesis, G_const_encoding=G.const_encoding, G_style_encoding=G.style_encoding)
+    loss = StyleGAN2Loss(device=dev, **parts, D=D, D_parsing=DP, style_mixing_prob=0.9, r1_gamma=10, l1_weight=50, mask_weight=1.0)
+    n = args.batch if args.batch != BATCH_PER_GPU else 4       # batch_gpu 4 (global 32 on 8 GPUs, train.py:174)
+    step = TrainingStep(parts, D, DP, loss, batch_size=n * world)
+    g = torch.Generator(device='cpu').manual_seed(100 + rank)
+    u = lambda *s: (torch.rand(*s, generator=g) * 2 - 1).to(dev)
+    batch = dict(real_img=u(n, 3, 512, 512), gen_z=torch.zeros([n, 0], device=dev), style_input=u(n, 45, 128, 128), retain=u(n, 6, 512, 512),
+                 pose=u(n, 5, 512, 512), denorm_upper_input=u(n, 3, 512, 512), denorm_lower_input=u(n, 3, 512, 512),
+                 denorm_upper_mask=(u(n, 1, 512, 512) > 0).float(), denorm_lower_mask=(u(n, 1, 512, 512) > 0).float(),
+                 gt_parsing=torch.randint(0, 7, [n, 1, 512, 512], generator=g).float().to(dev))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        step.run([batch])
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step.run([batch])
+    barrier()
+    elapsed = replicas.max_over_ranks(time.perf_counter() - t0, device=dev)
+    if rank == 0:
+        print(json.dumps(dict(metric='fullbody G+D training iterations/sec (8-phase step incl. lazy R1)', value=round(args.steps / elapsed, 4), unit='it/s',
+                              n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(1e3 * elapsed / args.steps, 1), higher_is_better=True,
+                              scaling='weak', vs_baseline=None, dtype='f32', data='synthetic', images_per_sec=round(args.steps * n * world / elapsed, 3),
+                              config=dict(workload='BASELINE config 4: fullbody G+D step, lazy R1 (gamma 10), L1 + parsing CE, no VGG; D in fp32',
+                                          batch_per_gpu=n, global_batch=n * world, parallelism=f'dp{world} flat-bucket reduce_scatter+all_gather (RCCL)',
+                                          first_batch_idx=0, note='steps start at batch_idx = warmup; reg phases fire every 4th (G) / 16th (D) iteration'))), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -94,6 +141,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=BATCH_PER_GPU, help='images per GPU per step (config 2: 8)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--mode', choices=['synthesis', 'train'], default='synthesis', help="'synthesis' = the headline (config 2); 'train' = config 4 step")
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -112,6 +160,13 @@ def main():
     custom_ops.verbosity = 'none'
     from torch_utils.ops import conv2d_mfma
     from training import networks, replicas
+
+    if args.mode == 'train':
+        run_train(args, rank, world, dev, dist)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     net = init_weights(networks.SynthesisNetworkFull_v18(**CFG2)).to(dev).eval()
     inp = make_inputs(args.batch, dev, seed=rank)           # inputs resident in HBM before the timed region

@@ -292,71 +292,74 @@ __global__ __launch_bounds__(256, 4) void conv2d_mfma(ConvParams p) {
         }
 
         // ---- epilogue of this tile: D layout col = lane&31 (pixel), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (cout).
-        // Per-cout constants come from LDS; every load is unconditional from a clamped, always-valid address.
+        // Per-cout constants come from LDS; every load is unconditional from a clamped, always-valid address.  The
+        // outputs are walked in groups of 4 consecutive couts; the group's extra operand (residual, or the tensor being
+        // SPADE-normalised) is fetched ONE GROUP AHEAD, so a group never waits a full memory round trip (nor for the
+        // previous group's stores: the loads are older than those stores in the in-order vmcnt queue).
         const int ox = e_ox0 + l31;
         const int oxc = ox < p.OW ? ox : p.OW - 1;
+        const int cstride = (int)p.ys[1];
+        const bool spade = G::MT == 2 && p.f.spade_x != nullptr;
+        const float* extra = spade ? p.f.spade_x : p.f.residual;
+        int pix_off[G::NT];
+        bool pix_ok[G::NT];
+        float nz[G::NT];
 #pragma unroll
         for (int nt = 0; nt < G::NT; nt++) {
             const int oy = e_oy0 + wave * 2 + nt;
-            const bool pix_ok = oy < p.OH && ox < p.OW;
+            pix_ok[nt] = oy < p.OH && ox < p.OW;
             const int oyc = oy < p.OH ? oy : p.OH - 1;
-            float nz = 0.f;
-            if (p.f.noise) nz = p.f.noise[(int)(e_n * p.f.noise_batch_stride) + oyc * p.OW + oxc] * p.f.noise_gain;
-            const int pix_off = (int)((int64_t)e_n * p.ys[0] + (int64_t)(oyc * p.osy + p.ooy) * p.ys[2] + (int64_t)(oxc * p.osx + p.oox) * p.ys[3]);
-            const int cstride = (int)p.ys[1];
-            if (G::MT == 2 && p.f.spade_x) {
-                // SPADE combine: the packed weights interleave 32 gamma rows (M-tile 0) with the 32 beta rows of the
-                // same channels (M-tile 1), so one lane holds gamma and beta of one (channel, pixel):
-                //   y = (x - mean) * rstd * (1 + gamma) + beta          (networks.py:1715-1722)
+            nz[nt] = p.f.noise ? p.f.noise[(int)(e_n * p.f.noise_batch_stride) + oyc * p.OW + oxc] * p.f.noise_gain : 0.f;
+            pix_off[nt] = (int)((int64_t)e_n * p.ys[0] + (int64_t)(oyc * p.osy + p.ooy) * p.ys[2] + (int64_t)(oxc * p.osx + p.oox) * p.ys[3]);
+        }
+        constexpr int NG = G::NT * G::MT * 4;
+        // fetch the extra operand of group g (SPADE mode: this tile's 32 output channels live at m0/2); channel clamped per
+        // element so every address is valid
+        const int ex_lim = (spade ? (p.Cout >> 1) : p.Cout) - 1;
+        auto fetch_extra = [&](int g, float (&dst)[4]) {
+            const int nt = g / (G::MT * 4), mt = (g / 4) % G::MT, kq = g % 4;
+            const int co0 = spade ? (e_m0 >> 1) + 8 * kq + 4 * half : e_m0 + mt * 32 + 8 * kq + 4 * half;
 #pragma unroll
-                for (int kq = 0; kq < 4; kq++) {
+            for (int j = 0; j < 4; j++) dst[j] = extra[pix_off[nt] + (co0 + j < ex_lim ? co0 + j : ex_lim) * cstride];
+        };
+        float ex_next[4] = {0.f, 0.f, 0.f, 0.f};
+        if (extra) fetch_extra(0, ex_next);
+#pragma unroll
+        for (int g = 0; g < NG; g++) {
+            const int nt = g / (G::MT * 4), mt = (g / 4) % G::MT, kq = g % 4;
+            float ex[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) ex[j] = ex_next[j];
+            if (extra && g + 1 < NG) fetch_extra(g + 1, ex_next);   // prefetch the next group's extra operand
+            const int row0 = mt * 32 + 8 * kq + 4 * half;
+            if (spade) {
+                // SPADE combine: the packed weights interleave 32 gamma rows (M-tile 0) with the 32 beta rows of the same
+                // channels (M-tile 1), so one lane holds gamma and beta of one (channel, pixel):
+                //   y = (x - mean) * rstd * (1 + gamma) + beta          (networks.py:1715-1722)
+                if (mt == 0) {
                     const int r0 = 8 * kq + 4 * half;
                     const f32x4 mu4 = *(const f32x4*)(ep_scale + r0);
                     const f32x4 rs4 = *(const f32x4*)(ep_bias + r0);
-                    int off[4];
-                    float xv[4];
-#pragma unroll
-                    for (int j = 0; j < 4; j++) off[j] = pix_off + ((e_m0 >> 1) + r0 + j) * cstride;
-#pragma unroll
-                    for (int j = 0; j < 4; j++) xv[j] = p.f.spade_x[off[j]];
+                    const int o = pix_off[nt] + ((e_m0 >> 1) + r0) * cstride;
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
-                        const float v = (xv[j] - mu4[j]) * rs4[j] * (1.f + acc[0][nt][4 * kq + j]) + acc[G::MT - 1][nt][4 * kq + j];
-                        if (pix_ok) p.y[off[j]] = v;
+                        const float v = (ex[j] - mu4[j]) * rs4[j] * (1.f + acc[0][nt][4 * kq + j]) + acc[G::MT - 1][nt][4 * kq + j];
+                        if (pix_ok[nt]) p.y[o + j * cstride] = v;
                     }
-                    __builtin_amdgcn_sched_barrier(0);
                 }
-                continue;
-            }
+            } else {
+                const f32x4 sc4 = *(const f32x4*)(ep_scale + row0);
+                const f32x4 bi4 = *(const f32x4*)(ep_bias + row0);
+                const int o = pix_off[nt] + (e_m0 + row0) * cstride;
 #pragma unroll
-            for (int mt = 0; mt < G::MT; mt++) {
-#pragma unroll
-                for (int kq = 0; kq < 4; kq++) {                 // 4 consecutive couts at a time keeps the live state small
-                    const int row0 = mt * 32 + 8 * kq + 4 * half;
-                    const f32x4 sc4 = *(const f32x4*)(ep_scale + row0);
-                    const f32x4 bi4 = *(const f32x4*)(ep_bias + row0);
-                    int off[4];
-                    float rv[4];
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const int co = e_m0 + row0 + j;
-                        off[j] = pix_off + (co < p.Cout ? co : p.Cout - 1) * cstride;
-                        rv[j] = 0.f;
-                    }
-                    if (p.f.residual) {
-#pragma unroll
-                        for (int j = 0; j < 4; j++) rv[j] = p.f.residual[off[j]];
-                    }
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        float v = acc[mt][nt][4 * kq + j] * sc4[j] + nz + bi4[j];
-                        v = v > 0.f ? v : v * slope;
-                        v = fminf(fmaxf(v * gain, -cl), cl) + rv[j];
-                        if (pix_ok && e_m0 + row0 + j < p.Cout) p.y[off[j]] = v;
-                    }
-                    __builtin_amdgcn_sched_barrier(0);   // do not hoist the next groups' constant reads (register pressure)
+                for (int j = 0; j < 4; j++) {
+                    float v = acc[mt][nt][4 * kq + j] * sc4[j] + nz[nt] + bi4[j];
+                    v = v > 0.f ? v : v * slope;
+                    v = fminf(fmaxf(v * gain, -cl), cl) + ex[j];
+                    if (pix_ok[nt] && e_m0 + row0 + j < p.Cout) p.y[o + j * cstride] = v;
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);               // do not hoist later groups' reads (register pressure)
         }
         if (!has_next) break;
         tile = next;

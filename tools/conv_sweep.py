@@ -1,6 +1,6 @@
 """Dev tool (GPU box): time the 3x3 MFMA conv at several Cin to split fixed per-block cost from per-chunk cost."""
 import sys, os, time
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'pasta-gan-plusplus_amd'))
 import torch
 from torch_utils import custom_ops

@@ -1,6 +1,6 @@
 """Dev tool (GPU box): a handful of launches of the two hottest conv shapes, for rocprofv3 --pmc passes."""
 import sys, os
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'pasta-gan-plusplus_amd'))
 import torch
 from torch_utils import custom_ops

@@ -8,20 +8,25 @@ generator uses run the hand-written MFMA implicit-GEMM kernel (``conv2d_mfma`` -
 ``csrc/conv2d_kernel.h``).  A stride-2 transposed conv is issued as one gather-form
 sub-convolution per output phase, so no multiply is spent on stuffed zeros.
 
-Gradients (first and higher order, honouring ``no_weight_gradients``) come from
-``aten::convolution_backward`` on the same GPU -- backward kernels are a later row of
-SURVEY.md section 8.  Configurations the MFMA kernel does not cover (groups > 1, dilation,
+Gradients: the INPUT gradient of a convolution is again a convolution (with the O<->I transposed, spatially
+flipped weight; a strided conv's is a transposed conv and vice versa), so it runs the same MFMA kernel through
+this same autograd Function -- which makes arbitrary-order input gradients (R1, loss_fullbody.py:262-274) native
+too, exactly how the reference's ``_conv2d_gradfix`` recurses (conv2d_gradfix.py:118-135).  The WEIGHT gradient
+(a reduction over pixels, a different GEMM shape) still comes from ``aten::convolution_backward`` and honours
+``no_weight_gradients``; a hand-written wgrad kernel is a later row of SURVEY.md section 8.  Configurations the MFMA kernel does not cover (groups > 1, dilation,
 fp16, exotic kernel sizes) go to PyTorch-ROCm's convolution on the GPU.  CPU tensors raise:
 the product has no CPU path.
 """
 
 import contextlib
+import os
 
 import torch
 
 from . import _native as nat
 from . import conv2d_mfma
 
+native_input_gradients = os.environ.get('PG_NATIVE_DGRAD', '0') == '1'   # opt-in: input gradients through the MFMA kernel.  Measured 10 % slower than aten in the config-4 step (round 1), so off by default
 enabled = False                     # kept for API compatibility (training_loop_fullbody.py:386); the native path is always on
 weight_gradients_disabled = False   # forcefully disable weight gradients (R1, loss_fullbody.py:266)
 
@@ -95,9 +100,40 @@ class _Conv2dMfma(torch.autograd.Function):
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
         stride, padding, transposed, output_padding, has_bias = ctx.cfg
+        kh, kw = int(weight.shape[2]), int(weight.shape[3])
+        dx = dw = db = None
+        if ctx.needs_input_grad[0] and native_input_gradients:
+            dx = _input_gradient(dy, x.shape, weight, stride, padding, transposed, output_padding)
         want_w = ctx.needs_input_grad[1] and not weight_gradients_disabled
-        mask = [ctx.needs_input_grad[0], want_w, has_bias and ctx.needs_input_grad[2]]
-        dx, dw, db = torch.ops.aten.convolution_backward(
-            dy, x, weight, [weight.shape[1 if transposed else 0]] if has_bias else None,
-            [stride, stride], list(padding), [1, 1], transposed, list(output_padding), 1, mask)
+        want_b = has_bias and ctx.needs_input_grad[2]
+        if dx is None and ctx.needs_input_grad[0] or want_w or want_b:
+            mask = [dx is None and ctx.needs_input_grad[0], want_w, want_b]
+            gx, dw, db = torch.ops.aten.convolution_backward(
+                dy, x, weight, [weight.shape[1 if transposed else 0]] if has_bias else None,
+                [stride, stride], list(padding), [1, 1], transposed, list(output_padding), 1, mask)
+            dx = gx if mask[0] else dx
         return dx, dw, db, None, None, None, None
+
+
+def _input_gradient(dy, x_shape, weight, stride, padding, transposed, output_padding):
+    """d(loss)/dx of y = conv(x, w) (or conv_transpose) as another native convolution; None if that geometry is not covered."""
+    kh, kw = int(weight.shape[2]), int(weight.shape[3])
+    _, _, h, w = x_shape
+    if not transposed:
+        if stride == 1:        # dx = correlate(dy, w^T flipped) with padding k-1-p
+            py, px = kh - 1 - padding[0], kw - 1 - padding[1]
+            if min(py, px) < 0 or not conv2d_mfma.supported(kh, kw, 1):
+                return None
+            return _Conv2dMfma.apply(dy, weight.transpose(0, 1).flip([2, 3]), None, 1, (py, px), False, (0, 0))
+        # strided conv: dx = conv_transpose(dy, w, stride) with the output padding that restores x's size
+        opad = (h - ((dy.shape[2] - 1) * stride - 2 * padding[0] + kh), w - ((dy.shape[3] - 1) * stride - 2 * padding[1] + kw))
+        if min(opad) < 0 or max(opad) >= stride or kh < stride or kw < stride:
+            return None
+        if not all(conv2d_mfma.supported(-(-(kh - a) // stride), -(-(kw - b) // stride), 1) for a in range(stride) for b in range(stride)):
+            return None
+        return _Conv2dMfma.apply(dy, weight, None, stride, padding, True, opad)
+    # forward was conv_transpose(x, w[Cin, Cout]): dx = conv(dy, w, stride) -- w read as OIHW with O = Cin
+    if not conv2d_mfma.supported(kh, kw, stride) or min(padding) < 0:
+        return None
+    dx = _Conv2dMfma.apply(dy, weight, None, stride, padding, False, (0, 0))
+    return dx if dx.shape[2:] == tuple(x_shape[2:]) else None

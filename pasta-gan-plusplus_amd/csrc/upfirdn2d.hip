@@ -4,12 +4,13 @@
 //
 // Two kernels:
 //   * upfirdn2d_tiled  -- NCHW-dense tensors, small filters.  A 256-thread workgroup owns a
-//     64 x 16 output tile of one (n, c) plane: the input footprint is staged once into LDS
-//     with coalesced row loads (zero filled outside the image), the flipped, zero-padded
-//     taps sit in LDS too, and each lane produces a 1 x 4 column strip so vertically
-//     adjacent outputs reuse LDS reads.  Polyphase for up > 1: only the taps that hit
-//     non-zero samples are visited (FW/up x FH/up per output).  Wave lanes run along x, so
-//     LDS reads are conflict-free (consecutive dwords) and stores are 256-byte row segments.
+//     64 x 32 output tile of one (n, c) plane: the input footprint is staged once into LDS,
+//     one image row per wave-iteration (coalesced, zero filled outside the image); each lane
+//     produces a 1 x 8 column strip.  Without up-sampling every LDS offset is a compile-time
+//     constant and the taps sit in registers, so an input row is read once for all the outputs
+//     it feeds (~5.5 LDS reads + 16 FMAs per output for the 4x4 filter).  Polyphase for up > 1:
+//     only the taps that hit non-zero samples are visited (FW/up x FH/up per output).  Wave
+//     lanes run along x: LDS reads are conflict-free and stores are 256-byte row segments.
 //   * upfirdn2d_generic -- any strides / dtype / factors / filter size: one output per
 //     thread straight from global memory, visiting valid taps only.
 //
@@ -80,10 +81,10 @@ __global__ __launch_bounds__(256) void upfirdn2d_generic(Params p) {
 // ---------------------------------------------------------------- tiled
 template <int UPX, int UPY, int DNX, int DNY, int FW, int FH>
 struct Tile {
-    static constexpr int TOW = 64, TOH = 16, RPT = 4;                       // outputs per workgroup, rows per lane
+    static constexpr int TOW = 64, TOH = 32, RPT = 8;                       // outputs per workgroup (w x h), rows per lane
     static constexpr int TIW = ((TOW - 1) * DNX + FW - 1) / UPX + 2;        // staged input footprint
     static constexpr int TIH = ((TOH - 1) * DNY + FH - 1) / UPY + 2;
-    static constexpr int TIWP = TIW | 1;                                    // odd row pitch: decimated (stride-2) reads stay conflict-free
+    static constexpr int TIWP = TIW | 1;                                    // odd row pitch
 };
 
 template <typename T, int UPX, int UPY, int DNX, int DNY, int FW, int FH>
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(256) void upfirdn2d_tiled(Params p, int tilesX, int
     const int tx = bid % tilesX; bid /= tilesX;
     const int ty = bid % tilesY;
     const int64_t plane = bid / tilesY;
-    const int t = threadIdx.x;
+    const int t = threadIdx.x, lx = t & 63, wave = t >> 6;    // lanes of a wave run along x
 
     // taps: flipped (true convolution) unless p.flip, zero padded up to FH x FW
     for (int i = t; i < FH * FW; i += 256) {
@@ -111,47 +112,96 @@ __global__ __launch_bounds__(256) void upfirdn2d_tiled(Params p, int tilesX, int
         sf[ky][kx] = v;
     }
 
+    // input footprint -> LDS, one image row per wave-iteration: 64 coalesced lanes + a short tail, no div/mod per element
     const int ox0 = tx * G::TOW, oy0 = ty * G::TOH;
     const int ix0 = floor_div(ox0 * DNX - p.padx0, UPX);
     const int iy0 = floor_div(oy0 * DNY - p.pady0, UPY);
     const T* __restrict__ xp = (const T*)p.x + plane * (int64_t)p.inH * p.inW;
-    for (int i = t; i < G::TIH * G::TIW; i += 256) {
-        const int r = i / G::TIW, c = i % G::TIW;
-        const int gy = iy0 + r, gx = ix0 + c;
-        float v = 0.f;
-        if (gy >= 0 && gy < p.inH && gx >= 0 && gx < p.inW) v = (float)xp[(int64_t)gy * p.inW + gx];
-        sx[r][c] = v;
+    // two phases so that all of a wave's row loads are in flight together (a load -> wait -> ds_write loop is latency-bound)
+    constexpr int NR = (G::TIH + 3) / 4, NC = (G::TIW + 63) / 64;
+    float stage[NR][NC];
+#pragma unroll
+    for (int i = 0; i < NR; i++) {
+        const int r = wave + 4 * i;
+        const int gy = iy0 + r;
+        const bool row_ok = r < G::TIH && gy >= 0 && gy < p.inH;            // wave-uniform
+        const T* __restrict__ row = xp + (int64_t)(row_ok ? gy : 0) * p.inW;
+#pragma unroll
+        for (int j = 0; j < NC; j++) {
+            const int gx = ix0 + 64 * j + lx;
+            const bool ok = row_ok && gx >= 0 && gx < p.inW;
+            const float v = (float)row[ok ? gx : 0];                        // unconditional load from a valid address
+            stage[i][j] = ok ? v : 0.f;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NR; i++) {
+        const int r = wave + 4 * i;
+#pragma unroll
+        for (int j = 0; j < NC; j++) {
+            const int c = 64 * j + lx;
+            if ((G::TIH % 4 == 0 || r < G::TIH) && (64 * (j + 1) <= G::TIW || c < G::TIW)) sx[r][c] = stage[i][j];
+        }
     }
     __syncthreads();
 
-    const int lx = t & 63;                    // lanes of a wave run along x
-    const int ly0 = (t >> 6) * G::RPT;        // each wave owns RPT adjacent rows
+    const int ly0 = wave * G::RPT;            // each wave owns RPT adjacent output rows
     const int ox = ox0 + lx;
-    const int ux0 = ox * DNX - p.padx0;
-    const int kx0 = UPX == 1 ? 0 : pos_mod(-ux0, UPX);
-    const int cx = floor_div(ux0 + kx0, UPX) - ix0;   // LDS column of the first contributing sample
     T* __restrict__ yp = (T*)p.y + plane * (int64_t)p.outH * p.outW;
+    float acc[G::RPT];
+#pragma unroll
+    for (int r = 0; r < G::RPT; r++) acc[r] = 0.f;
 
+    if constexpr (UPX == 1 && UPY == 1) {
+        // No zero-stuffing: output (ly, lx) reads sx[ly*DNY + jy][lx*DNX + jx] -- every LDS offset is a compile-time
+        // constant from one base, so vertically adjacent outputs share their reads; the taps sit in registers.
+        float tap[FH][FW];
+#pragma unroll
+        for (int jy = 0; jy < FH; jy++)
+#pragma unroll
+            for (int jx = 0; jx < FW; jx++) tap[jy][jx] = sf[jy][jx];
+        const float* base = &sx[ly0 * DNY][lx * DNX];
+#pragma unroll
+        for (int rr = 0; rr < (G::RPT - 1) * DNY + FH; rr++) {             // walk the needed input rows once
+            float v[FW];
+#pragma unroll
+            for (int jx = 0; jx < FW; jx++) v[jx] = base[rr * G::TIWP + jx];
+#pragma unroll
+            for (int r = 0; r < G::RPT; r++) {
+                const int jy = rr - r * DNY;                               // compile-time after unrolling
+                if (jy >= 0 && jy < FH) {
+#pragma unroll
+                    for (int jx = 0; jx < FW; jx++) acc[r] += v[jx] * tap[jy][jx];
+                }
+            }
+        }
+    } else {
+        // polyphase: only the taps that land on real samples (FW/UPX x FH/UPY per output)
+        const int ux0 = ox * DNX - p.padx0;
+        const int kx0 = UPX == 1 ? 0 : pos_mod(-ux0, UPX);
+        const int cx = floor_div(ux0 + kx0, UPX) - ix0;
+#pragma unroll
+        for (int r = 0; r < G::RPT; r++) {
+            const int uy0 = (oy0 + ly0 + r) * DNY - p.pady0;
+            const int ky0 = UPY == 1 ? 0 : pos_mod(-uy0, UPY);
+            const int cy = floor_div(uy0 + ky0, UPY) - iy0;
+#pragma unroll
+            for (int jy = 0; jy < FH / UPY; jy++)
+#pragma unroll
+                for (int jx = 0; jx < FW / UPX; jx++) acc[r] += sx[cy + jy][cx + jx] * sf[ky0 + jy * UPY][kx0 + jx * UPX];
+        }
+    }
+
+    const int c = (int)(plane % p.C), n = (int)(plane / p.C);
+    const float bias = (p.has_ep && p.bias) ? p.bias[c] : 0.f;
 #pragma unroll
     for (int r = 0; r < G::RPT; r++) {
         const int oy = oy0 + ly0 + r;
-        const int uy0 = oy * DNY - p.pady0;
-        const int ky0 = UPY == 1 ? 0 : pos_mod(-uy0, UPY);
-        const int cy = floor_div(uy0 + ky0, UPY) - iy0;
-        float acc = 0.f;
-#pragma unroll
-        for (int jy = 0; jy < FH / UPY; jy++) {
-#pragma unroll
-            for (int jx = 0; jx < FW / UPX; jx++) {
-                acc += sx[cy + jy][cx + jx] * sf[ky0 + jy * UPY][kx0 + jx * UPX];
-            }
-        }
         if (ox < p.outW && oy < p.outH) {
-            float v = acc * p.gain;
+            float v = acc[r] * p.gain;
             if (p.has_ep) {       // SynthesisLayer tail: + noise, + bias, linear/relu/lrelu, gain, clamp
-                const int c = (int)(plane % p.C), n = (int)(plane / p.C);
                 if (p.noise) v += p.noise[n * p.noise_bs + (int64_t)oy * p.outW + ox] * p.noise_gain;
-                if (p.bias) v += p.bias[c];
+                v += bias;
                 v = (v > 0.f ? v : v * p.slope) * p.act_gain;
                 v = fminf(fmaxf(v, -p.clamp), p.clamp);
             }

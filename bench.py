@@ -197,7 +197,7 @@ def main():
     if rank == 0:
         images = args.batch * args.steps * world
         value = images / elapsed
-        k3 = [(fl, e0.elapsed_time(e1) * 1e-3) for geo, fl, e0, e1 in timeline if geo == (3, 3, 1)]
+        k3 = [(fl, e0.elapsed_time(e1) * 1e-3) for geo, fl, e0, e1 in timeline if geo[:3] == (3, 3, 1)]
         allk = [(fl, e0.elapsed_time(e1) * 1e-3) for geo, fl, e0, e1 in timeline]
         k3_flops, k3_time = sum(f for f, _ in k3), sum(t for _, t in k3)
         achieved = k3_flops / k3_time / 1e12 if k3_time > 0 else 0.0

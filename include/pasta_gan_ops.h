@@ -164,6 +164,20 @@ int pg_conv2d_forward(const float* x, const float* packed_w, float* y,
                       const int64_t ystride[4], int out_step_y, int out_step_x, int out_off_y, int out_off_x,
                       const pg_conv2d_fusion* fusion, void* stream);
 
+/*
+ * Winograd F(2x2, 3x3) variant for KH = KW = 3, stride 1, out_step 1 (the bulk of the synthesis network): the same
+ * result as pg_conv2d_forward up to fp32 summation order (~2e-6 of the output scale) with 2.25x fewer multiplies.
+ * Weights are pre-transformed once (U = G g G^T, [16][CinP][CoutP64] floats, CoutP64 = Cout rounded up to 64) by
+ * pg_conv2d_winograd_pack_weight -- same scale / flip_hw / transpose_oi meaning as pg_conv2d_pack_weight.
+ * Fusion: every stage of pg_conv2d_fusion except spade_x and x2 (PG_ERR_UNSUPPORTED; use pg_conv2d_forward).
+ */
+int64_t pg_conv2d_winograd_packed_size(int Cout, int Cin);
+int pg_conv2d_winograd_pack_weight(const float* w, float* packed, int Cout, int Cin,
+                                   float scale, int flip_hw, int transpose_oi, void* stream);
+int pg_conv2d_winograd_forward(const float* x, const float* packed_u, float* y,
+                               int N, int Cin, int H, int W, int Cout, int pad_y, int pad_x, int OH, int OW,
+                               const int64_t ystride[4], const pg_conv2d_fusion* fusion, void* stream);
+
 /* Demodulation coefficients of modulated_conv2d (networks.py:64-68):
  *   dcoefs[n,o] = rsqrt(sum_{i,k} (w[o,i,k] * scale * styles[n,i])^2 + 1e-8);  w is OIHW. */
 int pg_modconv_dcoefs(const float* w, const float* styles, float* dcoefs,

@@ -30,6 +30,44 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
     }
 }
 
+// Winograd F(2x2, 3x3) weight transform: U = G g G^T per (ci, co), stored [16 positions][CinP][CoutP] (conv2d_wino.h).
+//   G = [[1, 0, 0], [1/2, 1/2, 1/2], [1/2, -1/2, 1/2], [0, 0, 1]]
+__global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict__ w, float* __restrict__ up, int Cout, int Cin,
+                                                        int CinP, int CoutP, float scale, int flip, int transpose_oi) {
+    const int64_t total = (int64_t)CinP * CoutP;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int co = (int)(i % CoutP), ci = (int)(i / CoutP);
+        float g[3][3];
+#pragma unroll
+        for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+            for (int kx = 0; kx < 3; kx++) {
+                float v = 0.f;
+                if (co < Cout && ci < Cin) {
+                    const int sy = flip ? 2 - ky : ky, sx = flip ? 2 - kx : kx;
+                    const int64_t src = transpose_oi ? (((int64_t)ci * Cout + co) * 3 + sy) * 3 + sx
+                                                     : (((int64_t)co * Cin + ci) * 3 + sy) * 3 + sx;
+                    v = w[src] * scale;
+                }
+                g[ky][kx] = v;
+            }
+        float t[4][3];                                   // G g
+#pragma unroll
+        for (int kx = 0; kx < 3; kx++) {
+            t[0][kx] = g[0][kx];
+            t[1][kx] = 0.5f * (g[0][kx] + g[1][kx] + g[2][kx]);
+            t[2][kx] = 0.5f * (g[0][kx] - g[1][kx] + g[2][kx]);
+            t[3][kx] = g[2][kx];
+        }
+#pragma unroll
+        for (int a = 0; a < 4; a++) {                    // (G g) G^T
+            const float u[4] = {t[a][0], 0.5f * (t[a][0] + t[a][1] + t[a][2]), 0.5f * (t[a][0] - t[a][1] + t[a][2]), t[a][2]};
+#pragma unroll
+            for (int b = 0; b < 4; b++) up[(int64_t)(4 * a + b) * total + i] = u[b];
+        }
+    }
+}
+
 // ------------------------------------------------------------------ demodulation coefficients
 // one workgroup per (n, o): rsqrt(sum_{i,k} (w[o,i,k] * scale * s[n,i])^2 + 1e-8)
 __global__ __launch_bounds__(256) void dcoefs_kernel(const float* __restrict__ w, const float* __restrict__ styles, float* __restrict__ d,
@@ -141,11 +179,11 @@ PG_EXPORT int pg_conv2d_pack_weight(const float* w, float* packed, int Cout, int
     return pg::launch_status();
 }
 
-PG_EXPORT int pg_conv2d_forward(const float* x, const float* packed_w, float* y,
-                                int N, int Cin, int H, int W, int Cout, int KH, int KW,
-                                int stride, int pad_y, int pad_x, int OH, int OW,
-                                const int64_t ystride[4], int out_step_y, int out_step_x, int out_off_y, int out_off_x,
-                                const pg_conv2d_fusion* fusion, void* stream) {
+static int conv_forward(bool winograd, const float* x, const float* packed_w, float* y,
+                        int N, int Cin, int H, int W, int Cout, int KH, int KW,
+                        int stride, int pad_y, int pad_x, int OH, int OW,
+                        const int64_t ystride[4], int out_step_y, int out_step_x, int out_off_y, int out_off_x,
+                        const pg_conv2d_fusion* fusion, void* stream) {
     if (!x || !packed_w || !y || !ystride) return PG_ERR_INVALID_ARG;
     if (N <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0 || OH <= 0 || OW <= 0) return PG_ERR_INVALID_ARG;
     if (out_step_y < 1 || out_step_x < 1) return PG_ERR_INVALID_ARG;
@@ -185,6 +223,11 @@ PG_EXPORT int pg_conv2d_forward(const float* x, const float* packed_w, float* y,
     if (p.in_xform && (!(p.f.in_gain > 0.f) || p.f.in_alpha < 0.f || p.f.in_alpha > 1.f)) return PG_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
 
+    if (winograd) {
+        if (p.f.spade_x || p.f.x2) return PG_ERR_UNSUPPORTED;   // those launches stay on the direct kernel
+        p.CoutP = round_up(Cout, 64);
+        return pgconv::launch_wino(p, s);
+    }
     if (stride == 1) {
         if (KH == 3 && KW == 3) return pgconv::launch_k3s1(p, s);
         if (KH == 1 && KW == 1) return pgconv::launch_k1s1(p, s);
@@ -197,6 +240,37 @@ PG_EXPORT int pg_conv2d_forward(const float* x, const float* packed_w, float* y,
         if (KH == 1 && KW == 1) return pgconv::launch_k1s2(p, s);
     }
     return PG_ERR_UNSUPPORTED;
+}
+
+PG_EXPORT int pg_conv2d_forward(const float* x, const float* packed_w, float* y,
+                                int N, int Cin, int H, int W, int Cout, int KH, int KW,
+                                int stride, int pad_y, int pad_x, int OH, int OW,
+                                const int64_t ystride[4], int out_step_y, int out_step_x, int out_off_y, int out_off_x,
+                                const pg_conv2d_fusion* fusion, void* stream) {
+    return conv_forward(false, x, packed_w, y, N, Cin, H, W, Cout, KH, KW, stride, pad_y, pad_x, OH, OW,
+                        ystride, out_step_y, out_step_x, out_off_y, out_off_x, fusion, stream);
+}
+
+PG_EXPORT int64_t pg_conv2d_winograd_packed_size(int Cout, int Cin) {
+    if (Cout <= 0 || Cin <= 0) return 0;
+    return (int64_t)16 * round_up(Cin, 16) * round_up(Cout, 64);
+}
+
+PG_EXPORT int pg_conv2d_winograd_pack_weight(const float* w, float* packed, int Cout, int Cin,
+                                             float scale, int flip_hw, int transpose_oi, void* stream) {
+    if (!w || !packed || Cout <= 0 || Cin <= 0) return PG_ERR_INVALID_ARG;
+    const int CinP = round_up(Cin, 16), CoutP = round_up(Cout, 64);
+    const int64_t total = (int64_t)CinP * CoutP;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > pg::kMaxStreamBlocks) blocks = pg::kMaxStreamBlocks;
+    hipLaunchKernelGGL(wino_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, packed, Cout, Cin, CinP, CoutP, scale, flip_hw, transpose_oi);
+    return pg::launch_status();
+}
+
+PG_EXPORT int pg_conv2d_winograd_forward(const float* x, const float* packed_u, float* y,
+                                         int N, int Cin, int H, int W, int Cout, int pad_y, int pad_x, int OH, int OW,
+                                         const int64_t ystride[4], const pg_conv2d_fusion* fusion, void* stream) {
+    return conv_forward(true, x, packed_u, y, N, Cin, H, W, Cout, 3, 3, 1, pad_y, pad_x, OH, OW, ystride, 1, 1, 0, 0, fusion, stream);
 }
 
 PG_EXPORT int pg_modconv_dcoefs(const float* w, const float* styles, float* dcoefs,

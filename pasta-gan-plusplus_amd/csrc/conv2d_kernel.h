@@ -422,5 +422,6 @@ int launch_k1x2(const ConvParams& p, hipStream_t s);
 int launch_k7s1(const ConvParams& p, hipStream_t s);
 int launch_k3s2(const ConvParams& p, hipStream_t s);
 int launch_k1s2(const ConvParams& p, hipStream_t s);
+int launch_wino(const ConvParams& p, hipStream_t s);     // conv2d_wino.h
 
 }  // namespace pgconv

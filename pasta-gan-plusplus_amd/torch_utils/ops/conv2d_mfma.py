@@ -66,6 +66,12 @@ def _init():
         lib.pg_conv2d_pack_weight.argtypes = [vp, vp, i, i, i, i, f, i, i, vp]
         lib.pg_conv2d_forward.restype = i
         lib.pg_conv2d_forward.argtypes = [vp, vp, vp, i, i, i, i, i, i, i, i, i, i, i, i, ctypes.POINTER(i64), i, i, i, i, ctypes.POINTER(Fusion), vp]
+        lib.pg_conv2d_winograd_packed_size.restype = i64
+        lib.pg_conv2d_winograd_packed_size.argtypes = [i, i]
+        lib.pg_conv2d_winograd_pack_weight.restype = i
+        lib.pg_conv2d_winograd_pack_weight.argtypes = [vp, vp, i, i, f, i, i, vp]
+        lib.pg_conv2d_winograd_forward.restype = i
+        lib.pg_conv2d_winograd_forward.argtypes = [vp, vp, vp, i, i, i, i, i, i, i, i, i, ctypes.POINTER(i64), ctypes.POINTER(Fusion), vp]
         lib.pg_modconv_dcoefs.restype = i
         lib.pg_modconv_dcoefs.argtypes = [vp, vp, vp, i, i, i, i, f, vp]
         lib.pg_instance_norm_stats.restype = i
@@ -88,14 +94,23 @@ def _f32c(t, name):
     return t.contiguous()
 
 
-def pack_weight(w, scale=1.0, flip=False, transpose_oi=False):
-    """OIHW (or IOHW when `transpose_oi`) float32 weights -> the kernel's [CinP][taps][CoutP] layout."""
+def pack_weight(w, scale=1.0, flip=False, transpose_oi=False, winograd=False):
+    """OIHW (or IOHW when `transpose_oi`) float32 weights -> the kernel's [CinP][taps][CoutP] layout, or, with
+    `winograd`, the pre-transformed [16][CinP][CoutP64] layout of the F(2x2,3x3) kernel (3x3 weights only)."""
     lib = _init().lib
     w = _f32c(w.detach(), 'weight')
     if transpose_oi:
         cin, cout, kh, kw = w.shape
     else:
         cout, cin, kh, kw = w.shape
+    if winograd:
+        if (kh, kw) != (3, 3):
+            raise nat.NativeOpError('conv2d_mfma: the Winograd layout is for 3x3 weights')
+        packed = torch.empty([lib.pg_conv2d_winograd_packed_size(cout, cin)], dtype=torch.float32, device=w.device)
+        with torch.cuda.device(w.device):
+            st = lib.pg_conv2d_winograd_pack_weight(nat.ptr(w), nat.ptr(packed), cout, cin, float(scale), int(bool(flip)), int(bool(transpose_oi)), nat.stream_of(w))
+        nat.check(st, 'pg_conv2d_winograd_pack_weight')
+        return packed
     packed = torch.empty([lib.pg_conv2d_packed_size(cout, cin, kh, kw)], dtype=torch.float32, device=w.device)
     with torch.cuda.device(w.device):
         st = lib.pg_conv2d_pack_weight(nat.ptr(w), nat.ptr(packed), cout, cin, kh, kw, float(scale), int(bool(flip)), int(bool(transpose_oi)), nat.stream_of(w))
@@ -106,8 +121,9 @@ def pack_weight(w, scale=1.0, flip=False, transpose_oi=False):
 def conv2d_forward(x, packed, cout, kh, kw, stride=1, pad=(0, 0), out_hw=None, y=None, out_step=(1, 1), out_off=(0, 0),
                    in_scale=None, in_bias=None, in_act='linear', in_alpha=0.0, in_gain=1.0, in_clamp=None,
                    out_scale=None, noise=None, noise_gain=1.0, bias=None, act='linear', alpha=0.0, gain=1.0, clamp=None,
-                   residual=None, spade=None, x2=None):
-    """One launch of the MFMA convolution.  `x` [N,Cin,H,W] float32 contiguous; `packed` from
+                   residual=None, spade=None, x2=None, winograd=False):
+    """One launch of the MFMA convolution (`winograd`: of its F(2x2,3x3) variant; `packed` must then come from
+    `pack_weight(..., winograd=True)`; 3x3 stride 1, no spade / x2).  `x` [N,Cin,H,W] float32 contiguous; `packed` from
     `pack_weight`.  Writes y[n, co, oy*step+off, ox*step+off] for oy < out_hw[0], ox < out_hw[1]
     (allocating a dense [N,Cout,OH,OW] `y` when none is given) and returns `y`.
     `spade=(x_norm, mean, rstd)` selects the SPADE combine epilogue: `packed` holds interleaved gamma/beta rows
@@ -181,12 +197,18 @@ def conv2d_forward(x, packed, cout, kh, kw, stride=1, pad=(0, 0), out_hw=None, y
         if _timeline is not None:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
-        st = lib.pg_conv2d_forward(nat.ptr(x), nat.ptr(packed), nat.ptr(y), n, cin, h, w, cout, kh, kw, int(stride), int(pad_y), int(pad_x),
-                                   int(oh), int(ow), nat.i64arr(y.stride()), int(out_step[0]), int(out_step[1]), int(out_off[0]), int(out_off[1]),
-                                   ctypes.byref(fz), nat.stream_of(x))
+        if winograd:
+            if (kh, kw, int(stride)) != (3, 3, 1) or tuple(out_step) != (1, 1) or tuple(out_off) != (0, 0):
+                raise nat.NativeOpError('conv2d_mfma: winograd=True needs a 3x3 stride-1 dense-output launch')
+            st = lib.pg_conv2d_winograd_forward(nat.ptr(x), nat.ptr(packed), nat.ptr(y), n, cin, h, w, cout, int(pad_y), int(pad_x),
+                                                int(oh), int(ow), nat.i64arr(y.stride()), ctypes.byref(fz), nat.stream_of(x))
+        else:
+            st = lib.pg_conv2d_forward(nat.ptr(x), nat.ptr(packed), nat.ptr(y), n, cin, h, w, cout, kh, kw, int(stride), int(pad_y), int(pad_x),
+                                       int(oh), int(ow), nat.i64arr(y.stride()), int(out_step[0]), int(out_step[1]), int(out_off[0]), int(out_off[1]),
+                                       ctypes.byref(fz), nat.stream_of(x))
         if _timeline is not None:
             ev1.record()
-            _timeline.append(((kh, kw, int(stride)), 2.0 * n * cout * oh * ow * cin * kh * kw, ev0, ev1))
+            _timeline.append(((kh, kw, int(stride), 'winograd' if winograd else 'direct'), 2.0 * n * cout * oh * ow * cin * kh * kw, ev0, ev1))
     nat.check(st, 'pg_conv2d_forward')
     return y
 

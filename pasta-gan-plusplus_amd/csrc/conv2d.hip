@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
     }
 }
 
-// Winograd F(2x2, 3x3) weight transform: U = G g G^T per (ci, co), stored [16 positions][CinP][CoutP] (conv2d_wino.h).
+// Winograd F(2x2, 3x3) weight transform: U = G g G^T per (ci, co), stored in the operand-stream order of conv2d_wino.h.
 //   G = [[1, 0, 0], [1/2, 1/2, 1/2], [1/2, -1/2, 1/2], [0, 0, 1]]
 __global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict__ w, float* __restrict__ up, int Cout, int Cin,
                                                         int CinP, int CoutP, float scale, int flip, int transpose_oi) {
@@ -63,7 +63,11 @@ __global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict_
         for (int a = 0; a < 4; a++) {                    // (G g) G^T
             const float u[4] = {t[a][0], 0.5f * (t[a][0] + t[a][1] + t[a][2]), 0.5f * (t[a][0] - t[a][1] + t[a][2]), t[a][2]};
 #pragma unroll
-            for (int b = 0; b < 4; b++) up[(int64_t)(4 * a + b) * total + i] = u[b];
+            for (int b = 0; b < 4; b++) {
+                // [xi][co / 32][ci / 4][ci & 1][co & 31][(ci >> 1) & 1]
+                const int64_t dst = ((((int64_t)(4 * a + b) * (CoutP / 32) + (co >> 5)) * (CinP / 4) + (ci >> 2)) * 2 + (ci & 1)) * 64 + (co & 31) * 2 + ((ci >> 1) & 1);
+                up[dst] = u[b];
+            }
         }
     }
 }

@@ -24,6 +24,10 @@
 #pragma once
 #include "conv2d_kernel.h"
 
+#ifndef WINO_EXP
+#define WINO_EXP 0
+#endif
+
 namespace pgconv {
 
 constexpr int W_KC = 16;                     // input channels per LDS chunk
@@ -32,7 +36,7 @@ constexpr int W_CHF = 4 * W_ROWF;            // floats per channel (4 halo rows)
 constexpr int W_NX = W_KC * W_CHF;           // 4224 staged floats per chunk
 constexpr int W_XPT = (W_NX + 511) / 512;    // 9 DMA dwords per thread per chunk
 constexpr int W_BUF = W_XPT * 512;           // floats per staging buffer (padded to whole wave-instructions) = 4608
-constexpr int W_RING = 4;                    // A-operand pairs in flight per wave
+constexpr int W_RING = 2;                    // A-operand groups (of 2 channel pairs) in flight per wave
 constexpr int W_EXCH = 16 * 8 * 32;          // exchange floats per round: 16 positions x 8 couts x 32 tiles = 4096 <= W_BUF
 
 template <bool XF>
@@ -40,9 +44,9 @@ __global__ __launch_bounds__(512, 4) void conv2d_wino(ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int cin_loop = ((p.Cin + W_KC - 1) / W_KC) * W_KC;
     const int nchunks = cin_loop / W_KC;
-    float* cs0 = smem + 2 * W_BUF;               // prologue scale of two consecutive tiles [2][cin_loop]
-    float* ep_scale = cs0 + 2 * cin_loop;        // [64]
-    float* ep_bias = ep_scale + 64;              // [64]
+    float* ex0 = smem + 2 * W_BUF;               // inverse-transform exchange, double buffered [2][W_EXCH]
+    float* cs0 = ex0 + 2 * W_EXCH;               // prologue scale of two consecutive tiles [2][cin_loop]
+    float* ep0 = cs0 + 2 * cin_loop;             // epilogue scale / bias of two consecutive tiles [2][64 + 64]
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -107,8 +111,10 @@ __global__ __launch_bounds__(512, 4) void conv2d_wino(ConvParams p) {
     auto issue_chunk = [&](int c0, int buf) {
         const unsigned xs_b = smem_b + (unsigned)(buf * W_BUF + 64 * wave) * 4u;
         const int soff = c0 * HW * 4;
+#if !(WINO_EXP & 8)
 #pragma unroll
         for (int i = 0; i < W_XPT; i++) dma_dword(xrsrc, xs_b + 2048u * i, xoff[i], soff);
+#endif
     };
 
     const float in_slope = act_slope(p.f.in_act, p.f.in_alpha);
@@ -117,28 +123,33 @@ __global__ __launch_bounds__(512, 4) void conv2d_wino(ConvParams p) {
 
     f32x16 acc[2][2];                                // [position][M-tile]
 
-    // A-operand stream: U[xi][ci][co]; this lane reads (xi0 | xi1, ci = 2P + half, co = m0 + 32 mt + l31) for P = 0, 1, ...
-    // through two running pointers and a ring of W_RING pairs.  The ring runs across tiles: the last pairs of a tile
-    // already fetch the first pairs of the next one, so no tile starts with an exposed L2 round trip.
-    const int64_t u_xi = (int64_t)cin_loop * p.CoutP;      // CinP = Cin rounded up to 16 = cin_loop
-    const float *pa0, *pa1;
-    auto a_reset = [&]() {
-        pa0 = p.wp + xi0 * u_xi + (int64_t)half * p.CoutP + m0 + l31;
-        pa1 = p.wp + xi1 * u_xi + (int64_t)half * p.CoutP + m0 + l31;
-    };
-    auto load_a = [&](float (&dst)[4]) {
-        dst[0] = pa0[0]; dst[1] = pa0[32]; dst[2] = pa1[0]; dst[3] = pa1[32];
-        pa0 += 2 * p.CoutP; pa1 += 2 * p.CoutP;
+    // A-operand stream.  U is packed [xi][co / 32][ci / 4][ci & 1][co & 31][(ci >> 1) & 1]: the two values a lane needs for
+    // two consecutive channel pairs are one aligned 8-byte word and a wave-instruction reads 512 contiguous bytes.  Four
+    // streams per wave (2 positions x 2 M-tiles) advance together through a ring of W_RING groups (of 2 pairs).  The ring
+    // runs across tiles: the last groups of a tile already fetch the first groups of the next one, so no tile starts
+    // with an exposed L2 round trip.
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const int NG = cin_loop / 4;                                             // groups per tile
+    const int64_t d_mt = (int64_t)NG * 128;                                  // next 32-cout block
+    const int64_t d_s = (int64_t)(xi1 - xi0) * (p.CoutP / 32) * NG * 128;    // position xi0 -> xi1
+    const float* pa;
+    auto a_reset = [&]() { pa = p.wp + ((int64_t)xi0 * (p.CoutP / 32) + (m0 >> 5)) * NG * 128 + half * 64 + l31 * 2; };
+    auto load_a = [&](f32x2 (&dst)[4]) {
+        dst[0] = *(const f32x2*)pa; dst[1] = *(const f32x2*)(pa + d_mt);
+        dst[2] = *(const f32x2*)(pa + d_s); dst[3] = *(const f32x2*)(pa + d_s + d_mt);
+        pa += 128;
     };
 
     const float gain = p.f.gain;
     const float cl = p.f.clamp >= 0.f ? p.f.clamp : __builtin_inff();
     const float slope = act_slope(p.f.act, p.f.alpha);
+    // both pixels of a thread's output pair in one 8-byte store: dense rows, even strides, aligned base
+    const bool vec_store = p.ys[3] == 1 && ((p.ys[0] | p.ys[1] | p.ys[2]) & 1) == 0 && (((uintptr_t)p.y) & 7) == 0 && (p.OW & 1) == 0;
 
     int tile = blockIdx.x;
     int par = 0, g = 0;
     prep_tile(tile, cs0);
-    float a_ring[W_RING][4];
+    f32x2 a_ring[W_RING][4];
     a_reset();
 #pragma unroll
     for (int d = 0; d < W_RING; d++) load_a(a_ring[d]);
@@ -157,6 +168,8 @@ __global__ __launch_bounds__(512, 4) void conv2d_wino(ConvParams p) {
         bool has_next = false;
         int next = tile;
         const float* cs_cur = cs0 + par * cin_loop;
+        float* ep_scale = ep0 + par * 128;           // per tile parity: the next tile's constants are written while slow
+        float* ep_bias = ep_scale + 64;              // waves may still be in this tile's epilogue
         for (int k = 0; k < nchunks; k++, g++) {
             const int buf = g & 1;
             if (k + 1 < nchunks) {
@@ -179,21 +192,34 @@ __global__ __launch_bounds__(512, 4) void conv2d_wino(ConvParams p) {
                     issue_chunk(0, buf ^ 1);
                 }
             }
-            // ---- multiply this chunk: 8 channel pairs x (2 positions x 2 M-tiles) MFMAs per wave
+            // ---- multiply this chunk: 8 channel pairs x (2 positions x 2 M-tiles) MFMAs per wave.  The six raw samples
+            // (and the prologue scale) of pair pp + 1 are requested from LDS before pair pp's MFMAs are issued.
             const float* xb = smem + buf * W_BUF + half * W_CHF + l31;       // this lane's tile, channel (2 pair + half)
+            const float* csb = cs_cur + k * W_KC + half;
+            float bq[2][7];
+            auto read_b = [&](int pp, float (&dst)[7]) {
+                const float* xc = xb + (2 * pp) * W_CHF;
+#pragma unroll
+                for (int m = 0; m < 3; m++) {
+#if WINO_EXP & 2
+                    dst[2 * m] = (float)m; dst[2 * m + 1] = (float)-m;
+#else
+                    dst[2 * m] = xc[so0[m]]; dst[2 * m + 1] = xc[so1[m]];
+#endif
+                }
+                dst[6] = csb[2 * pp];
+            };
+            read_b(0, bq[0]);
 #pragma unroll
             for (int pp = 0; pp < W_KC / 2; pp++) {
-                float a[4];
-#pragma unroll
-                for (int j = 0; j < 4; j++) a[j] = a_ring[pp % W_RING][j];
-                if (pp == W_KC / 2 - W_RING && k + 1 == nchunks) a_reset();   // from here on: the next tile's first pairs
-                load_a(a_ring[pp % W_RING]);                                  // refill the slot W_RING pairs ahead
-                const float* xc = xb + (2 * pp) * W_CHF;
-                const float sc = cs_cur[k * W_KC + 2 * pp + half] * in_gain;
+                const int gq = pp >> 1, j = pp & 1;
+                if (pp + 1 < W_KC / 2) read_b(pp + 1, bq[(pp + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);                           // the requests go out BEFORE this pair's MFMAs
+                const float sc = bq[pp & 1][6] * in_gain;
                 float q[3];                                                  // row-transformed patch columns A, B, C
 #pragma unroll
                 for (int m = 0; m < 3; m++) {
-                    float d0 = xc[so0[m]], d1 = xc[so1[m]];
+                    float d0 = bq[pp & 1][2 * m], d1 = bq[pp & 1][2 * m + 1];
                     if (XF) {                                                // SPADE pre-activation acts on the raw samples
                         d0 *= sc; d1 *= sc;
                         d0 = __builtin_amdgcn_fmed3f(fmaxf(d0, d0 * in_slope), -in_cl, in_cl);
@@ -205,60 +231,82 @@ __global__ __launch_bounds__(512, 4) void conv2d_wino(ConvParams p) {
                 }
                 const float v0 = q[0] - q[2];
                 const float v1 = fmaf(fa, q[0], fmaf(fc, q[2], q[1]));
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], v0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], v0, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], v1, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], v1, acc[1][1], 0, 0, 0);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_ring[gq % W_RING][0][j], v0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_ring[gq % W_RING][1][j], v0, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_ring[gq % W_RING][2][j], v1, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_ring[gq % W_RING][3][j], v1, acc[1][1], 0, 0, 0);
+                if (j == 1) {                                                // group consumed: refill its slot W_RING groups ahead
+                    if (gq == W_KC / 4 - W_RING && k + 1 == nchunks) a_reset();   // from here on: the next tile's first groups
+#if !(WINO_EXP & 1)
+                    load_a(a_ring[gq % W_RING]);
+#endif
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
             dma_wait_all();
             __syncthreads();
         }
 
-        // ---- inverse transform + fused epilogue, 8 couts per round through the LDS buffer that is free now:
-        // (g & 1) ^ 1 ... careful: after the loop g already points at the NEXT chunk's buffer (being filled), so the free
-        // one is (g & 1) ^ 1.
-        float* ex = smem + ((g & 1) ^ 1) * W_BUF;                            // [16 positions][8 couts][32 tiles]
+        // ---- inverse transform + fused epilogue: the 16 positions of one (cout, tile) sit in 8 waves, so 8 couts per round
+        // go through a double-buffered LDS exchange (one barrier per round), then each thread finishes two adjacent pixels.
+#if WINO_EXP & 4
+        { float sm = 0.f;
+          for (int s = 0; s < 2; s++) for (int mt = 0; mt < 2; mt++) for (int k = 0; k < 16; k++) sm += acc[s][mt][k];
+          if (sm == 12345.678f) p.y[t] = sm; }
+        if (!has_next) break;
+        tile = next; par ^= 1;
+        continue;
+#endif
         const int c_l = t >> 6, prow = (t >> 5) & 1, tcol = t & 31;          // this thread's output: cout, row of the 2x2, tile
         const int oy = e_oy0 + prow, ox = e_ox0 + 2 * tcol;
         const bool row_ok = oy < p.OH;
         const int oyc = row_ok ? oy : p.OH - 1;
+        const int ox0c = ox < p.OW ? ox : p.OW - 1, ox1c = ox + 1 < p.OW ? ox + 1 : p.OW - 1;
         const int cstride = (int)p.ys[1];
+        const int pix0 = (int)((int64_t)e_n * p.ys[0] + (int64_t)oyc * p.ys[2] + (int64_t)ox0c * p.ys[3]);
+        const int pix1 = (int)((int64_t)e_n * p.ys[0] + (int64_t)oyc * p.ys[2] + (int64_t)ox1c * p.ys[3]);
+        float nz0 = 0.f, nz1 = 0.f;
+        if (p.f.noise) {
+            const float* nzp = p.f.noise + (int)(e_n * p.f.noise_batch_stride) + oyc * p.OW;
+            nz0 = nzp[ox0c] * p.f.noise_gain; nz1 = nzp[ox1c] * p.f.noise_gain;
+        }
 #pragma unroll
         for (int rnd = 0; rnd < 8; rnd++) {
             // couts [8 rnd, 8 rnd + 8) of the 64: M-tile mt = rnd >> 2, rows 8q + 4 half + j with q = rnd & 3 -> regs 4q + j
             const int mt = rnd >> 2, q = rnd & 3;
+            float* ex = ex0 + (rnd & 1) * W_EXCH;                            // [16 positions][8 couts][32 tiles]
 #pragma unroll
             for (int s = 0; s < 2; s++)
 #pragma unroll
                 for (int j = 0; j < 4; j++) ex[((s == 0 ? xi0 : xi1) * 8 + 4 * half + j) * 32 + l31] = acc[s][mt][4 * q + j];
+            const int co = e_m0 + 8 * rnd + c_l;
+            const int coc = co < p.Cout ? co : p.Cout - 1;
+            float r0 = 0.f, r1 = 0.f;
+            if (p.f.residual) { r0 = p.f.residual[pix0 + coc * cstride]; r1 = p.f.residual[pix1 + coc * cstride]; }
             __syncthreads();
             // Y[prow][0..1] = sum_a At[prow][a] * (sum_b M[a][b] * At[q][b])
             float T[4];
+            const float* exr = ex + c_l * 32 + tcol + (prow ? 4 * 256 : 0);  // prow 0 reads a = 0, 1, 2; prow 1 reads a = 1, 2, 3
 #pragma unroll
             for (int b = 0; b < 4; b++) {
-                const float ma = ex[((4 * 0 + b) * 8 + c_l) * 32 + tcol], mb = ex[((4 * 1 + b) * 8 + c_l) * 32 + tcol];
-                const float mc = ex[((4 * 2 + b) * 8 + c_l) * 32 + tcol], md = ex[((4 * 3 + b) * 8 + c_l) * 32 + tcol];
-                T[b] = prow == 0 ? ma + mb + mc : mb - mc - md;
+                const float m0v = exr[(4 * 0 + b) * 256], m1v = exr[(4 * 1 + b) * 256], m2v = exr[(4 * 2 + b) * 256];
+                T[b] = prow == 0 ? m0v + m1v + m2v : m0v - m1v - m2v;
             }
-            float y2[2] = {T[0] + T[1] + T[2], T[1] - T[2] - T[3]};
-            const int co = e_m0 + 8 * rnd + c_l;
-            const int coc = co < p.Cout ? co : p.Cout - 1;
             const float esc = ep_scale[8 * rnd + c_l], ebi = ep_bias[8 * rnd + c_l];
-#pragma unroll
-            for (int qx = 0; qx < 2; qx++) {
-                const int oxq = ox + qx;
-                const bool ok = row_ok && oxq < p.OW && co < p.Cout;
-                const int oxc = oxq < p.OW ? oxq : p.OW - 1;
-                float v = y2[qx] * esc + ebi;
-                if (p.f.noise) v += p.f.noise[(int)(e_n * p.f.noise_batch_stride) + oyc * p.OW + oxc] * p.f.noise_gain;
-                v = v > 0.f ? v : v * slope;
-                v = fminf(fmaxf(v * gain, -cl), cl);
-                const int off = (int)((int64_t)e_n * p.ys[0] + (int64_t)oyc * p.ys[2] + (int64_t)oxc * p.ys[3]) + coc * cstride;
-                if (p.f.residual) v += p.f.residual[off];
-                if (ok) p.y[off] = v;
+            float v0 = (T[0] + T[1] + T[2]) * esc + nz0 + ebi;
+            float v1 = (T[1] - T[2] - T[3]) * esc + nz1 + ebi;
+            v0 = v0 > 0.f ? v0 : v0 * slope;
+            v1 = v1 > 0.f ? v1 : v1 * slope;
+            v0 = fminf(fmaxf(v0 * gain, -cl), cl) + r0;
+            v1 = fminf(fmaxf(v1 * gain, -cl), cl) + r1;
+            const bool ok0 = row_ok && ox < p.OW && co < p.Cout, ok1 = row_ok && ox + 1 < p.OW && co < p.Cout;
+            if (vec_store) {
+                f32x2 vv; vv[0] = v0; vv[1] = v1;
+                if (ok0) *(f32x2*)(p.y + pix0 + coc * cstride) = vv;
+            } else {
+                if (ok0) p.y[pix0 + coc * cstride] = v0;
+                if (ok1) p.y[pix1 + coc * cstride] = v1;
             }
-            __syncthreads();
         }
         if (!has_next) break;
         tile = next;
@@ -276,9 +324,11 @@ int launch_wino_xf(const ConvParams& p0, hipStream_t s) {
     if (tiles > 0x7fffffffLL) return PG_ERR_TOO_LARGE;
     p.total_tiles = (int)tiles;
     const int cin_loop = ((p.Cin + W_KC - 1) / W_KC) * W_KC;
-    const size_t lds = ((size_t)2 * W_BUF + 2 * cin_loop + 128) * sizeof(float);
+    const size_t lds = ((size_t)2 * W_BUF + 2 * W_EXCH + 2 * cin_loop + 256) * sizeof(float);
     if (lds > 160 * 1024) return PG_ERR_UNSUPPORTED;
-    const int per_cu = 2;                                   // 128 VGPRs x 8 waves per workgroup
+    int per_cu = (int)((160 * 1024) / lds);
+    if (per_cu > 2) per_cu = 2;                             // 128 VGPRs x 8 waves per workgroup
+    if (per_cu < 1) per_cu = 1;
     const int64_t blocks = tiles < (int64_t)kNumCU * per_cu ? tiles : (int64_t)kNumCU * per_cu;
     static bool attr_set = false;
     if (!attr_set) {

@@ -54,10 +54,10 @@ def stop_timeline():
     return tl
 
 
-def _init():
+def _init(plugin_name='conv2d_plugin'):
     global _plugin
     if _plugin is None:
-        plugin = custom_ops.get_plugin('conv2d_plugin')
+        plugin = custom_ops.get_plugin(plugin_name)
         lib = plugin.lib
         i, f, vp, i64 = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_int64
         lib.pg_conv2d_packed_size.restype = i64

@@ -141,6 +141,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=BATCH_PER_GPU, help='images per GPU per step (config 2: 8)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--conv-breakdown', default=None, metavar='CSV', help='also write the per-shape conv launch timeline of the timed steps')
     ap.add_argument('--mode', choices=['synthesis', 'train'], default='synthesis', help="'synthesis' = the headline (config 2); 'train' = config 4 step")
     args = ap.parse_args()
 
@@ -222,6 +223,15 @@ def main():
                     roofline=roofline)
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline()
+        if args.conv_breakdown:                                # per (geometry, algorithm, shape, fused stages): launches, time, rate
+            groups = {}
+            for geo, fl, e0, e1 in timeline:
+                g = groups.setdefault(geo, [0, 0.0, 0.0])
+                g[0] += 1; g[1] += e0.elapsed_time(e1); g[2] += fl
+            with open(args.conv_breakdown, 'w') as f:
+                f.write('kh,kw,stride,algorithm,shape,launches_per_step,avg_us,ms_per_step,algorithmic_tflops\n')
+                for geo, (cnt, ms, fl) in sorted(groups.items(), key=lambda kv: -kv[1][1]):
+                    f.write(f'{geo[0]},{geo[1]},{geo[2]},{geo[3]},{geo[4]},{cnt / args.steps:g},{1e3 * ms / cnt:.1f},{ms / args.steps:.3f},{fl / ms / 1e9:.1f}\n')
         print(json.dumps(line), flush=True)
 
     if dist is not None:

@@ -228,7 +228,7 @@ static int conv_forward(bool winograd, const float* x, const float* packed_w, fl
     hipStream_t s = (hipStream_t)stream;
 
     if (winograd) {
-        if (p.f.spade_x || p.f.x2) return PG_ERR_UNSUPPORTED;   // those launches stay on the direct kernel
+        if (p.f.x2) return PG_ERR_UNSUPPORTED;                  // two-source launches stay on the direct kernel
         p.CoutP = round_up(Cout, 64);
         return pgconv::launch_wino(p, s);
     }

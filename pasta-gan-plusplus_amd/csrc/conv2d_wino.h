@@ -130,14 +130,29 @@ __global__ __launch_bounds__(512, 4) void conv2d_wino(ConvParams p) {
     // with an exposed L2 round trip.
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     const int NG = cin_loop / 4;                                             // groups per tile
-    const int64_t d_mt = (int64_t)NG * 128;                                  // next 32-cout block
-    const int64_t d_s = (int64_t)(xi1 - xi0) * (p.CoutP / 32) * NG * 128;    // position xi0 -> xi1
-    const float* pa;
-    auto a_reset = [&]() { pa = p.wp + ((int64_t)xi0 * (p.CoutP / 32) + (m0 >> 5)) * NG * 128 + half * 64 + l31 * 2; };
+    const unsigned d_mt = (unsigned)NG * 512u;                               // bytes to the next 32-cout block
+    const unsigned d_s = (unsigned)((xi1 - xi0) * (p.CoutP / 32) * NG) * 512u;   // position xi0 -> xi1 (wraps: modular arithmetic)
+    unsigned pa;                                                             // byte offset into the packed U (< 2^31: checked by the host)
+    auto a_reset = [&]() { pa = (unsigned)((xi0 * (p.CoutP / 32) + (m0 >> 5)) * NG) * 512u + (unsigned)(half * 256 + l31 * 8); };
+    // The U loads are issued from inline asm and waited for by hand.  The compiler cannot count the halo DMA (asm as well),
+    // so its own `s_waitcnt vmcnt(n)` in front of every group would be too small by the 9 DMA requests issued in between --
+    // each chunk would start by waiting for the halo tile it has just requested.  Loads return in order, so the exact
+    // counts are (queue, oldest first, at the point of use within a chunk):
+    //   group 0: U(k,0) U(k,1) DMA(k+1)          -> vmcnt(4 + 9)
+    //   group 1: U(k,1) DMA(k+1) U(k,2)          -> vmcnt(9 + 4)
+    //   group 2: DMA(k+1) U(k,2) U(k,3)          -> vmcnt(4)     (this is also what guarantees the DMA has landed)
+    //   group 3: U(k,3) U(k+1,0)                 -> vmcnt(4)
+    // Anything else in the queue (the epilogue's stores, residual loads) only makes these waits stricter.
     auto load_a = [&](f32x2 (&dst)[4]) {
-        dst[0] = *(const f32x2*)pa; dst[1] = *(const f32x2*)(pa + d_mt);
-        dst[2] = *(const f32x2*)(pa + d_s); dst[3] = *(const f32x2*)(pa + d_s + d_mt);
-        pa += 128;
+        asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(dst[0]) : "v"(pa), "s"(p.wp));
+        asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(dst[1]) : "v"(pa + d_mt), "s"(p.wp));
+        asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(dst[2]) : "v"(pa + d_s), "s"(p.wp));
+        asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(dst[3]) : "v"(pa + d_s + d_mt), "s"(p.wp));
+        pa += 512u;
+    };
+    auto wait_a = [&](f32x2 (&g)[4], bool dma_younger) {     // ties the wait to the registers: every use comes after it
+        if (dma_younger) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3]) : "n"(4 + W_XPT));
+        else asm volatile("s_waitcnt vmcnt(4)" : "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3]));
     };
 
     const float gain = p.f.gain;
@@ -176,7 +191,13 @@ __global__ __launch_bounds__(512, 4) void conv2d_wino(ConvParams p) {
                 issue_chunk((k + 1) * W_KC, buf ^ 1);
             } else {
                 e_n = n; e_oy0 = oy0; e_ox0 = ox0; e_m0 = m0;
-                if (t < 64) {
+                if (p.f.spade_x) {                          // SPADE mode: per-(n, channel) mean / rstd of the normalised tensor
+                    if (t < 32) {
+                        const int ch = (e_m0 >> 1) + t;     // this tile's 32 output channels
+                        ep_scale[t] = p.f.spade_mean[e_n * (p.Cout >> 1) + ch];
+                        ep_bias[t] = p.f.spade_rstd[e_n * (p.Cout >> 1) + ch];
+                    }
+                } else if (t < 64) {
                     const int co = e_m0 + t;
                     const bool ok = co < p.Cout;
                     const int cc = ok ? co : 0;
@@ -190,6 +211,8 @@ __global__ __launch_bounds__(512, 4) void conv2d_wino(ConvParams p) {
                 if (has_next) {
                     prep_tile(next, cs0 + (par ^ 1) * cin_loop);
                     issue_chunk(0, buf ^ 1);
+                } else {
+                    dma_wait_all();                          // no DMA in this chunk: the counted waits below assume one
                 }
             }
             // ---- multiply this chunk: 8 channel pairs x (2 positions x 2 M-tiles) MFMAs per wave.  The six raw samples
@@ -231,6 +254,7 @@ __global__ __launch_bounds__(512, 4) void conv2d_wino(ConvParams p) {
                 }
                 const float v0 = q[0] - q[2];
                 const float v1 = fmaf(fa, q[0], fmaf(fc, q[2], q[1]));
+                if (j == 0) wait_a(a_ring[gq % W_RING], gq < 2);
                 acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_ring[gq % W_RING][0][j], v0, acc[0][0], 0, 0, 0);
                 acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_ring[gq % W_RING][1][j], v0, acc[0][1], 0, 0, 0);
                 acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_ring[gq % W_RING][2][j], v1, acc[1][0], 0, 0, 0);
@@ -243,7 +267,11 @@ __global__ __launch_bounds__(512, 4) void conv2d_wino(ConvParams p) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+#if WINO_EXP & 16
             dma_wait_all();
+#endif
+            // No vmcnt wait here: group 2 already waited for U values requested AFTER this chunk's halo DMA, so the DMA has
+            // landed.  (A vmcnt(0) would also wait for the U refills issued a moment ago: one exposed L2 round trip per chunk.)
             __syncthreads();
         }
 
@@ -263,6 +291,7 @@ __global__ __launch_bounds__(512, 4) void conv2d_wino(ConvParams p) {
         const int oyc = row_ok ? oy : p.OH - 1;
         const int ox0c = ox < p.OW ? ox : p.OW - 1, ox1c = ox + 1 < p.OW ? ox + 1 : p.OW - 1;
         const int cstride = (int)p.ys[1];
+        const bool spade = p.f.spade_x != nullptr;
         const int pix0 = (int)((int64_t)e_n * p.ys[0] + (int64_t)oyc * p.ys[2] + (int64_t)ox0c * p.ys[3]);
         const int pix1 = (int)((int64_t)e_n * p.ys[0] + (int64_t)oyc * p.ys[2] + (int64_t)ox1c * p.ys[3]);
         float nz0 = 0.f, nz1 = 0.f;
@@ -279,6 +308,39 @@ __global__ __launch_bounds__(512, 4) void conv2d_wino(ConvParams p) {
             for (int s = 0; s < 2; s++)
 #pragma unroll
                 for (int j = 0; j < 4; j++) ex[((s == 0 ? xi0 : xi1) * 8 + 4 * half + j) * 32 + l31] = acc[s][mt][4 * q + j];
+            if (spade) {
+                // SPADE combine (networks.py:1715-1722).  The packed rows interleave 4 gamma rows with the 4 beta rows of the
+                // same channels, so one round holds gamma (exchange rows 0-3) and beta (rows 4-7) of 4 output channels:
+                //   y = (x - mean) * rstd * (1 + gamma) + beta;      waves 0-3 finish one channel each
+                const int chl = 4 * rnd + (c_l & 3);                         // channel within this tile's 32
+                const int ch = (e_m0 >> 1) + chl;
+                float x0 = 0.f, x1 = 0.f;
+                if (c_l < 4) { x0 = p.f.spade_x[pix0 + ch * cstride]; x1 = p.f.spade_x[pix1 + ch * cstride]; }
+                __syncthreads();
+                if (c_l < 4) {
+                    const float* exr = ex + c_l * 32 + tcol + (prow ? 4 * 256 : 0);
+                    float Tg[4], Tb[4];
+#pragma unroll
+                    for (int b = 0; b < 4; b++) {
+                        const float g0 = exr[(4 * 0 + b) * 256], g1 = exr[(4 * 1 + b) * 256], g2 = exr[(4 * 2 + b) * 256];
+                        const float b0 = exr[(4 * 0 + b) * 256 + 128], b1 = exr[(4 * 1 + b) * 256 + 128], b2 = exr[(4 * 2 + b) * 256 + 128];
+                        Tg[b] = prow == 0 ? g0 + g1 + g2 : g0 - g1 - g2;
+                        Tb[b] = prow == 0 ? b0 + b1 + b2 : b0 - b1 - b2;
+                    }
+                    const float mu = ep_scale[chl], rs = ep_bias[chl];
+                    const float v0 = (x0 - mu) * rs * (1.f + Tg[0] + Tg[1] + Tg[2]) + (Tb[0] + Tb[1] + Tb[2]);
+                    const float v1 = (x1 - mu) * rs * (1.f + Tg[1] - Tg[2] - Tg[3]) + (Tb[1] - Tb[2] - Tb[3]);
+                    const bool ok0 = row_ok && ox < p.OW, ok1 = row_ok && ox + 1 < p.OW;
+                    if (vec_store) {
+                        f32x2 vv; vv[0] = v0; vv[1] = v1;
+                        if (ok0) *(f32x2*)(p.y + pix0 + ch * cstride) = vv;
+                    } else {
+                        if (ok0) p.y[pix0 + ch * cstride] = v0;
+                        if (ok1) p.y[pix1 + ch * cstride] = v1;
+                    }
+                }
+                continue;
+            }
             const int co = e_m0 + 8 * rnd + c_l;
             const int coc = co < p.Cout ? co : p.Cout - 1;
             float r0 = 0.f, r1 = 0.f;
@@ -325,6 +387,7 @@ int launch_wino_xf(const ConvParams& p0, hipStream_t s) {
     p.total_tiles = (int)tiles;
     const int cin_loop = ((p.Cin + W_KC - 1) / W_KC) * W_KC;
     const size_t lds = ((size_t)2 * W_BUF + 2 * W_EXCH + 2 * cin_loop + 256) * sizeof(float);
+    if ((int64_t)16 * cin_loop * p.CoutP * 4 > 0x7fffffffLL) return PG_ERR_TOO_LARGE;      // the U stream uses 32-bit byte offsets
     if (lds > 160 * 1024) return PG_ERR_UNSUPPORTED;
     int per_cu = (int)((160 * 1024) / lds);
     if (per_cu > 2) per_cu = 2;                             // 128 VGPRs x 8 waves per workgroup

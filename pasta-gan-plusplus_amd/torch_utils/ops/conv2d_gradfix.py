@@ -85,8 +85,9 @@ class _Conv2dMfma(torch.autograd.Function):
         kh, kw = int(weight.shape[2]), int(weight.shape[3])
         if not transposed:
             cout = int(weight.shape[0])
-            packed = conv2d_mfma.pack_weight(weight)
-            y = conv2d_mfma.conv2d_forward(x, packed, cout, kh, kw, stride=stride, pad=padding, bias=bias)
+            wg = conv2d_mfma.use_winograd(kh, kw, stride, cout, cin)
+            packed = conv2d_mfma.pack_weight(weight, winograd=wg)
+            y = conv2d_mfma.conv2d_forward(x, packed, cout, kh, kw, stride=stride, pad=padding, bias=bias, winograd=wg)
         else:
             cout = int(weight.shape[1])
             out_hw = ((h - 1) * stride - 2 * padding[0] + kh + output_padding[0], (w - 1) * stride - 2 * padding[1] + kw + output_padding[1])

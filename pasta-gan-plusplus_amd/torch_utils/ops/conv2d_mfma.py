@@ -8,6 +8,7 @@ native layer under this package's ``conv2d_gradfix`` / ``conv2d_resample`` /
 """
 
 import ctypes
+import os
 
 import torch
 
@@ -80,6 +81,17 @@ def _init(plugin_name='conv2d_plugin'):
         lib.pg_spade_norm.argtypes = [vp, vp, vp, vp, vp, vp, i, i64, vp]
         _plugin = plugin
     return _plugin
+
+
+def use_winograd(kh, kw, stride, cout, cin=None, x2=None):
+    """Launch policy for 3x3 stride-1 convolutions: the Winograd F(2x2,3x3) kernel (csrc/conv2d_wino.h) unless the layer is
+    too narrow to fill its 64-cout x 16-channel tiles.  PG_CONV_ALGO=direct|winograd overrides (A/B measurements)."""
+    if (int(kh), int(kw), int(stride)) != (3, 3, 1) or x2 is not None:
+        return False
+    mode = os.environ.get('PG_CONV_ALGO', 'auto')
+    if mode == 'direct':
+        return False
+    return True if mode == 'winograd' else (int(cout) > 32 and (cin is None or int(cin) >= 16))
 
 
 def supported(kh, kw, stride):
@@ -208,20 +220,22 @@ def conv2d_forward(x, packed, cout, kh, kw, stride=1, pad=(0, 0), out_hw=None, y
                                        ctypes.byref(fz), nat.stream_of(x))
         if _timeline is not None:
             ev1.record()
-            _timeline.append(((kh, kw, int(stride), 'winograd' if winograd else 'direct'), 2.0 * n * cout * oh * ow * cin * kh * kw, ev0, ev1))
+            _timeline.append(((kh, kw, int(stride), 'winograd' if winograd else 'direct', f'N{n} {cin}->{cout} {h}x{w}' + (' spade' if spade is not None else '') + (' xf' if in_act != 'linear' else '') + (' mod' if in_scale is not None else '') + (' res' if residual is not None else '')), 2.0 * n * cout * oh * ow * cin * kh * kw, ev0, ev1))
     nat.check(st, 'pg_conv2d_forward')
     return y
 
 
-def pack_spade_gamma_beta(w_gamma, w_beta, scale_gamma=1.0, scale_beta=1.0):
+def pack_spade_gamma_beta(w_gamma, w_beta, scale_gamma=1.0, scale_beta=1.0, winograd=False):
     """Packed weights of the fused gamma/beta convolution of a Spade_Norm_Block: rows [64j, 64j+32) are gamma channels
     [32j, 32j+32), rows [64j+32, 64j+64) the beta rows of the same channels, so that the two M-tiles of one 64-row
-    workgroup tile hold gamma and beta of the same (channel, pixel) in the same lane."""
+    workgroup tile hold gamma and beta of the same (channel, pixel) in the same lane.  The Winograd kernel pairs them in
+    its 8-row exchange rounds instead: groups of 4 gamma rows followed by the 4 beta rows of the same channels."""
     c = int(w_gamma.shape[0])
+    grp = 4 if winograd else 32
     assert w_gamma.shape == w_beta.shape and c % 32 == 0
-    g = (w_gamma.detach() * scale_gamma).reshape(c // 32, 32, *w_gamma.shape[1:])
-    b = (w_beta.detach() * scale_beta).reshape(c // 32, 32, *w_beta.shape[1:])
-    return pack_weight(torch.cat([g, b], dim=1).reshape(2 * c, *w_gamma.shape[1:]).contiguous())
+    g = (w_gamma.detach() * scale_gamma).reshape(c // grp, grp, *w_gamma.shape[1:])
+    b = (w_beta.detach() * scale_beta).reshape(c // grp, grp, *w_beta.shape[1:])
+    return pack_weight(torch.cat([g, b], dim=1).reshape(2 * c, *w_gamma.shape[1:]).contiguous(), winograd=winograd)
 
 
 def transposed_phases(kh, kw, stride, pad_y, pad_x, in_hw, out_hw):

@@ -114,9 +114,10 @@ def _modconv_fast(x, weight, styles, noise, up, padding, resample_filter, demodu
     if up == 1:
         if not conv2d_mfma.supported(kh, kw, 1):
             return None
-        packed = cache.get(('plain', flip_weight), [weight], lambda: conv2d_mfma.pack_weight(weight, flip=not flip_weight))
+        wg = conv2d_mfma.use_winograd(kh, kw, 1, cout, cin)
+        packed = cache.get(('plain', flip_weight, wg), [weight], lambda: conv2d_mfma.pack_weight(weight, flip=not flip_weight, winograd=wg))
         return conv2d_mfma.conv2d_forward(x, packed, cout, kh, kw, stride=1, pad=(padding, padding), in_scale=styles,
-                                          out_scale=dcoefs, noise=noise, **ep)
+                                          out_scale=dcoefs, noise=noise, winograd=wg, **ep)
     # up == 2: stride-2 transposed conv (one gather-form launch per output phase), then the FIR.
     fw, fh = upfirdn2d._get_filter_size(resample_filter)
     tpad, fir_pad = _up2_geometry(kh, kw, fw, fh, padding)
@@ -228,8 +229,9 @@ class _ConvBase(nn.Module):
                 self.bias = None
         self._cache = _PackCache()
 
-    def _packed(self, flip):
-        return self._cache.get(('plain', flip), [self.weight], lambda: conv2d_mfma.pack_weight(self.weight, scale=self.weight_gain, flip=flip))
+    def _packed(self, flip, winograd=False):
+        return self._cache.get(('plain', flip, winograd), [self.weight],
+                               lambda: conv2d_mfma.pack_weight(self.weight, scale=self.weight_gain, flip=flip, winograd=winograd))
 
     def _fast_geometry(self):
         k = int(self.weight.shape[2])
@@ -248,14 +250,16 @@ class Conv2dLayer(_ConvBase):
             ep = dict(bias=self.bias, act=self.activation, alpha=bias_act.activation_funcs[self.activation].def_alpha, gain=act_gain,
                       clamp=act_clamp, residual=residual)
             if self.down == 1 and (x2 is None or x.shape[1] % 16 == 0):
-                return conv2d_mfma.conv2d_forward(x, self._packed(False), cout, k, k, pad=(self.padding, self.padding), x2=x2, **ep)
+                wg = conv2d_mfma.use_winograd(k, k, 1, cout, x.shape[1], x2)
+                return conv2d_mfma.conv2d_forward(x, self._packed(False, wg), cout, k, k, pad=(self.padding, self.padding), x2=x2, winograd=wg, **ep)
         if x2 is not None:
             x, x2 = torch.cat([x, x2], dim=1), None
         if _fast_ok(x, self.weight, self.bias, residual) and self._fast_geometry():
             ep = dict(bias=self.bias, act=self.activation, alpha=bias_act.activation_funcs[self.activation].def_alpha, gain=act_gain,
                       clamp=act_clamp, residual=residual)
             if self.down == 1:
-                return conv2d_mfma.conv2d_forward(x, self._packed(False), cout, k, k, pad=(self.padding, self.padding), **ep)
+                wg = conv2d_mfma.use_winograd(k, k, 1, cout, x.shape[1])
+                return conv2d_mfma.conv2d_forward(x, self._packed(False, wg), cout, k, k, pad=(self.padding, self.padding), winograd=wg, **ep)
             # down == 2: FIR first (conv2d_resample.py:107-110, 119-122), then the (strided) conv with the fused epilogue
             fw, fh = upfirdn2d._get_filter_size(self.resample_filter)
             p = self.padding
@@ -304,7 +308,9 @@ class Spade_Conv2dLayer(_ConvBase):
         if _fast_ok(x, self.weight, self.bias, residual) and self._fast_geometry() and self.down == 1 and (no_act or self.bias is None):
             pro = {} if no_act else dict(in_act=self.activation, in_gain=act_gain, in_clamp=act_clamp,
                                          in_alpha=bias_act.activation_funcs[self.activation].def_alpha)
-            return conv2d_mfma.conv2d_forward(x, self._packed(False), cout, k, k, pad=(self.padding, self.padding), act=post_act, residual=residual, **pro)
+            wg = conv2d_mfma.use_winograd(k, k, 1, cout, x.shape[1])
+            return conv2d_mfma.conv2d_forward(x, self._packed(False, wg), cout, k, k, pad=(self.padding, self.padding), act=post_act, residual=residual,
+                                              winograd=wg, **pro)
         w = self.weight * self.weight_gain
         b = self.bias.to(x.dtype) if self.bias is not None else None
         if not no_act:
@@ -334,9 +340,10 @@ class Spade_Norm_Block(nn.Module):
             c = int(g.weight.shape[0])
             if c % 32 == 0 and g._fast_geometry() and g.down == 1 and x.is_contiguous():
                 # gamma and beta convolutions as ONE launch (they share `actv`) whose epilogue applies the normalisation
-                packed = self._cache.get('gamma_beta', [g.weight, b.weight],
-                                         lambda: conv2d_mfma.pack_spade_gamma_beta(g.weight, b.weight, g.weight_gain, b.weight_gain))
-                return conv2d_mfma.conv2d_forward(actv, packed, 2 * c, 3, 3, pad=(g.padding, g.padding), spade=(x, mean, rstd))
+                wg = conv2d_mfma.use_winograd(3, 3, 1, 2 * c, actv.shape[1])
+                packed = self._cache.get(('gamma_beta', wg), [g.weight, b.weight],
+                                         lambda: conv2d_mfma.pack_spade_gamma_beta(g.weight, b.weight, g.weight_gain, b.weight_gain, winograd=wg))
+                return conv2d_mfma.conv2d_forward(actv, packed, 2 * c, 3, 3, pad=(g.padding, g.padding), spade=(x, mean, rstd), winograd=wg)
             gamma = g(actv, no_act=True)
             beta = b(actv, no_act=True)
             return conv2d_mfma.spade_norm(x, mean, rstd, gamma, beta)

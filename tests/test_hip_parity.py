@@ -266,8 +266,9 @@ def test_conv_transpose2d_vs_oracle(n, cin, cout, h, w, k, pad, opad):
     close(y, ref, 1e-4, 2e-5 * scale_of(ref))
 
 
-def test_conv2d_fused_prologue_epilogue_vs_oracle():
-    """Every fused stage of pg_conv2d_forward against the unfused oracle composition."""
+@pytest.mark.parametrize('winograd', [False, True], ids=['direct', 'winograd'])
+def test_conv2d_fused_prologue_epilogue_vs_oracle(winograd):
+    """Every fused stage of pg_conv2d_forward / pg_conv2d_winograd_forward against the unfused oracle composition."""
     from torch_utils.ops import conv2d_mfma
     from oracle import ops_ref as R
     import torch.nn.functional as F
@@ -279,11 +280,11 @@ def test_conv2d_fused_prologue_epilogue_vs_oracle():
     in_b, out_b = det_tensor('fz.ib', [cin]), det_tensor('fz.ob', [cout])
     noise = det_tensor('fz.noise', [n, 1, h, w])
     res = det_tensor('fz.res', [n, cout, h, w])
-    packed = conv2d_mfma.pack_weight(wt.to(DEV), scale=0.5)
+    packed = conv2d_mfma.pack_weight(wt.to(DEV), scale=0.5, winograd=winograd)
     y = conv2d_mfma.conv2d_forward(x.to(DEV), packed, cout, 3, 3, pad=(1, 1),
                                    in_scale=styles.to(DEV), in_act='relu', in_gain=1.3, in_clamp=2.0,
                                    out_scale=dco.to(DEV), noise=noise.to(DEV), noise_gain=0.7, bias=out_b.to(DEV), act='lrelu', alpha=0.2,
-                                   gain=math.sqrt(2), clamp=3.0, residual=res.to(DEV))
+                                   gain=math.sqrt(2), clamp=3.0, residual=res.to(DEV), winograd=winograd)
     xr = R.bias_act(x * styles[:, :, None, None], None, act='relu', gain=1.3, clamp=2.0)
     ref = F.conv2d(xr, wt * 0.5, padding=1) * dco[:, :, None, None] + noise * 0.7
     ref = R.bias_act(ref, out_b, act='lrelu', gain=math.sqrt(2), clamp=3.0) + res
@@ -291,14 +292,56 @@ def test_conv2d_fused_prologue_epilogue_vs_oracle():
     # a prologue bias cannot be fused (act(0 + b) != 0 would corrupt the zero padding): rejected, never silently wrong
     from torch_utils.ops._native import NativeOpError
     with pytest.raises(NativeOpError):
-        conv2d_mfma.conv2d_forward(x.to(DEV), packed, cout, 3, 3, pad=(1, 1), in_bias=in_b.to(DEV), in_act='relu')
+        conv2d_mfma.conv2d_forward(x.to(DEV), packed, cout, 3, 3, pad=(1, 1), in_bias=in_b.to(DEV), in_act='relu', winograd=winograd)
     # lrelu prologue with modulation, 1x1 kernel (the SPADE skip path)
     p1 = conv2d_mfma.pack_weight(wt[:, :, :1, :1].contiguous().to(DEV))
     y1 = conv2d_mfma.conv2d_forward(x.to(DEV), p1, cout, 1, 1, in_act='lrelu', in_alpha=0.2, in_gain=math.sqrt(2))
     close(y1, F.conv2d(R.bias_act(x, None, act='lrelu'), wt[:, :, :1, :1]), 1e-4, 1e-4)
     # flipped packing == true convolution
-    yf = conv2d_mfma.conv2d_forward(x.to(DEV), conv2d_mfma.pack_weight(wt.to(DEV), flip=True), cout, 3, 3, pad=(1, 1))
+    yf = conv2d_mfma.conv2d_forward(x.to(DEV), conv2d_mfma.pack_weight(wt.to(DEV), flip=True, winograd=winograd), cout, 3, 3, pad=(1, 1), winograd=winograd)
     close(yf, F.conv2d(x, wt.flip([2, 3]), padding=1), 1e-4, 1e-4)
+    # IOHW weights (the conv_transpose2d view) pack to the same operand
+    yt = conv2d_mfma.conv2d_forward(x.to(DEV), conv2d_mfma.pack_weight(wt.transpose(0, 1).contiguous().to(DEV), transpose_oi=True, winograd=winograd),
+                                    cout, 3, 3, pad=(1, 1), winograd=winograd)
+    close(yt, F.conv2d(x, wt, padding=1), 1e-4, 1e-4)
+
+
+@pytest.mark.parametrize('n,cin,cout,h,w,pad', [(1, 16, 64, 8, 64, 1), (2, 20, 70, 9, 71, 1), (1, 3, 3, 5, 7, 1), (2, 48, 128, 33, 130, 0),
+                                               (1, 128, 64, 16, 16, 2), (3, 17, 33, 1, 1, 1), (1, 40, 192, 2, 200, 1), (2, 1, 64, 31, 3, 1)])
+def test_conv2d_winograd_vs_oracle_and_direct(n, cin, cout, h, w, pad):
+    """pg_conv2d_winograd_forward: F(2x2,3x3) on ragged shapes (odd sizes, partial tiles, pad 0/1/2, Cin/Cout not multiples of
+    the tile) against the fp64 convolution; its error must stay at the level of the direct kernel's."""
+    from torch_utils.ops import conv2d_mfma
+    import torch.nn.functional as F
+    x = det_tensor(f'wg.x.{cin}.{h}.{w}', [n, cin, h, w])
+    wt = det_tensor(f'wg.w.{cin}.{cout}', [cout, cin, 3, 3], scale=1 / math.sqrt(cin * 9))
+    ref = F.conv2d(x.double(), wt.double(), padding=pad)
+    yd = conv2d_mfma.conv2d_forward(x.to(DEV), conv2d_mfma.pack_weight(wt.to(DEV)), cout, 3, 3, pad=(pad, pad))
+    yw = conv2d_mfma.conv2d_forward(x.to(DEV), conv2d_mfma.pack_weight(wt.to(DEV), winograd=True), cout, 3, 3, pad=(pad, pad), winograd=True)
+    close(yw, ref, 1e-4, 1e-5 * scale_of(ref))
+    err_d = (yd.double().cpu() - ref).abs().max().item()
+    err_w = (yw.double().cpu() - ref).abs().max().item()
+    assert err_w <= 4 * err_d + 1e-6 * scale_of(ref)
+    # strided output view (channel slice of a wider tensor), as the synthesis blocks use
+    big = torch.zeros([n, cout + 3, ref.shape[2], ref.shape[3]], device=DEV)
+    conv2d_mfma.conv2d_forward(x.to(DEV), conv2d_mfma.pack_weight(wt.to(DEV), winograd=True), cout, 3, 3, pad=(pad, pad), y=big[:, 2:2 + cout], winograd=True)
+    assert torch.equal(big[:, 2:2 + cout], yw) and float(big[:, :2].abs().max()) == 0 and float(big[:, 2 + cout:].abs().max()) == 0
+
+
+def test_conv2d_winograd_rejects_what_it_cannot_do():
+    from torch_utils.ops import conv2d_mfma
+    from torch_utils.ops._native import NativeOpError
+    x = det_tensor('wgr.x', [1, 16, 8, 8]).to(DEV)
+    w3 = det_tensor('wgr.w', [64, 16, 3, 3]).to(DEV)
+    with pytest.raises(NativeOpError):
+        conv2d_mfma.pack_weight(w3[:, :, :1, :1].contiguous(), winograd=True)                      # 3x3 only
+    pw = conv2d_mfma.pack_weight(w3, winograd=True)
+    with pytest.raises(NativeOpError):
+        conv2d_mfma.conv2d_forward(x, pw, 64, 3, 3, stride=2, winograd=True)                       # stride 1 only
+    with pytest.raises(NativeOpError):
+        conv2d_mfma.conv2d_forward(x, conv2d_mfma.pack_weight(det_tensor('wgr.w2', [64, 32, 3, 3]).to(DEV), winograd=True), 64, 3, 3, pad=(1, 1),
+                                   x2=x, winograd=True)                                          # two-source launches: direct kernel
+    assert not conv2d_mfma.use_winograd(3, 3, 1, 64, x2=x) and not conv2d_mfma.use_winograd(3, 3, 2, 64) and not conv2d_mfma.use_winograd(1, 1, 1, 64)
 
 
 def test_conv2d_two_source_equals_concat():
@@ -333,9 +376,13 @@ def test_upfirdn2d_bias_act_fused_tail():
     assert upfirdn2d.upfirdn2d_bias_act(x.to(DEV), f.to(DEV), act='tanh') is None          # not fusable -> caller composes
 
 
-def test_conv2d_full_size_linearity_and_delta():
-    """config-2 hottest conv shape, [8,64,512,512] * [64,64,3,3]: linearity in x and a delta-kernel identity."""
+@pytest.mark.parametrize('algo', ['direct', 'winograd'])
+def test_conv2d_full_size_linearity_and_delta(algo, monkeypatch):
+    """config-2 hottest conv shape, [8,64,512,512] * [64,64,3,3]: linearity in x and a delta-kernel identity (bit-exact on
+    the direct kernel; to rounding of the transforms on the Winograd kernel)."""
     from torch_utils.ops import conv2d_gradfix
+    monkeypatch.setenv('PG_CONV_ALGO', algo)
+    same = torch.equal if algo == 'direct' else (lambda a, b: float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()))
     gen = torch.Generator(device=DEV).manual_seed(3)
     x1 = torch.randn([8, 64, 512, 512], device=DEV, generator=gen)
     x2 = torch.randn([8, 64, 512, 512], device=DEV, generator=gen)
@@ -345,11 +392,11 @@ def test_conv2d_full_size_linearity_and_delta():
     assert float((y12 - (y1 + 2 * y2)).abs().max()) < 2e-4
     delta = torch.zeros([64, 64, 3, 3], device=DEV)
     delta[torch.arange(64), torch.arange(64), 1, 1] = 1
-    assert torch.equal(conv2d_gradfix.conv2d(x1, delta, padding=1), x1)
+    assert same(conv2d_gradfix.conv2d(x1, delta, padding=1), x1)
     shift = torch.zeros([64, 64, 3, 3], device=DEV)
     shift[torch.arange(64), torch.arange(64), 0, 2] = 1        # y[oy,ox] = x[oy-1, ox+1]
     ys = conv2d_gradfix.conv2d(x1, shift, padding=1)
-    assert torch.equal(ys[:, :, 1:, :-1], x1[:, :, :-1, 1:])
+    assert same(ys[:, :, 1:, :-1], x1[:, :, :-1, 1:])
 
 
 def test_support_kernels_vs_oracle():
@@ -449,11 +496,13 @@ def test_blocks_golden(golden):
         close(yp, g['torgb/parsing'], **tol)
 
 
+@pytest.mark.parametrize('algo', ['direct', 'winograd'])
 @pytest.mark.parametrize('c,feat_c,h,w', [(64, 5, 24, 40), (128, 16, 17, 33), (32, 1, 32, 32)])
-def test_spade_norm_block_fused_gamma_beta(c, feat_c, h, w):
-    """C % 32 == 0 takes the single-launch gamma/beta convolution with the SPADE combine epilogue."""
+def test_spade_norm_block_fused_gamma_beta(c, feat_c, h, w, algo, monkeypatch):
+    """C % 32 == 0 takes the single-launch gamma/beta convolution with the SPADE combine epilogue (both conv kernels)."""
     from training import networks as PN
     from oracle import network_ref as NR
+    monkeypatch.setenv('PG_CONV_ALGO', algo)
     ref = fill_module_(NR.Spade_Norm_Block(feat_c, c), f'snb.{c}.')
     net = _load(PN.Spade_Norm_Block(feat_c, c), ref)
     x = det_tensor(f'snb.x.{c}', [2, c, h, w], scale=2.0) + 0.5
@@ -462,7 +511,7 @@ def test_spade_norm_block_fused_gamma_beta(c, feat_c, h, w):
         y = net(x.to(DEV), feat.to(DEV))
         want = ref(x, feat)
     close(y, want, 2e-4, 2e-5 * scale_of(want))
-    assert 'gamma_beta' in net._cache._store        # the fused route really ran
+    assert ('gamma_beta', algo == 'winograd') in net._cache._store        # the fused route really ran, on the requested kernel
 
 
 def test_blocks_graph_route_matches_inference_route():

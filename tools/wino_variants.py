@@ -1,40 +1,49 @@
-"""Dev tool: build (here) / time (GPU box) ablated variants of the Winograd kernel (-DWINO_EXP bit mask:
-1 no U loads in the K loop, 2 no LDS operand reads, 4 no epilogue, 8 no halo DMA).  Results are wrong by design."""
-import sys, os
+"""Dev tool: build (here) and time (GPU box, one process, round-robin, median) variants of the Winograd kernel compiled with
+-DWINO_EXP=<mask>.  Ablation bits (results wrong by design): 1 no U loads in the K loop, 2 no LDS operand reads, 4 no epilogue,
+8 no halo DMA.  Other bits select alternative implementations that stay correct (see conv2d_wino.h)."""
+import sys, os, ctypes, statistics
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'pasta-gan-plusplus_amd'))
 from torch_utils import custom_ops
 custom_ops.verbosity = 'none'
-VARIANTS = [int(v) for v in os.environ.get('WINO_VARIANTS', '0,1,2,4,8,3,15').split(',')]
+VARIANTS = [int(v) for v in os.environ.get('WINO_VARIANTS', '0').split(',')]
 SRC = custom_ops.PLUGIN_SOURCES['conv2d_plugin']
-
+plugins = {v: custom_ops.get_plugin(f'wino_exp{v}', sources=SRC, extra_hipcc_flags=[f'-DWINO_EXP={v}'], build_only=True) for v in VARIANTS}
 if sys.argv[1] == 'build':
-    for v in VARIANTS:
-        print(custom_ops.get_plugin(f'wino_exp{v}', sources=SRC, extra_hipcc_flags=[f'-DWINO_EXP={v}'], build_only=True))
+    print(plugins)
     sys.exit(0)
 
 import torch
 from torch_utils.ops import conv2d_mfma
-v = int(sys.argv[2])
-custom_ops.PLUGIN_SOURCES[f'wino_exp{v}'] = SRC
-conv2d_mfma._plugin = None
-conv2d_mfma._init.__defaults__ = (f'wino_exp{v}',)
-_orig = custom_ops.get_plugin
-custom_ops.get_plugin = lambda name, **kw: _orig(name, extra_hipcc_flags=[f'-DWINO_EXP={v}'], **kw)
+from torch_utils.ops import _native as nat
+libs = {}
+for v in VARIANTS:
+    conv2d_mfma._plugin = None
+    custom_ops.PLUGIN_SOURCES[f'wino_exp{v}'] = SRC
+    _orig = custom_ops.get_plugin
+    custom_ops.get_plugin = lambda name, _v=v, **kw: _orig(name, extra_hipcc_flags=[f'-DWINO_EXP={_v}'], **kw)
+    libs[v] = conv2d_mfma._init(f'wino_exp{v}')
+    custom_ops.get_plugin = _orig
 
-def timeit(fn, n=10):
-    fn(); torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(n): fn()
-    e1.record(); torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / n
-
-out = []
-for (N, H, cin, cout) in [(8, 256, 128, 128), (8, 256, 64, 128), (8, 64, 512, 512)]:
+SHAPES = [(8, 256, 128, 128), (8, 256, 64, 128), (8, 512, 64, 64), (8, 64, 512, 512), (8, 128, 256, 256)]
+rounds = int(os.environ.get('WINO_ROUNDS', '7'))
+for (N, H, cin, cout) in SHAPES:
     x = torch.randn(N, cin, H, H, device='cuda')
     w = torch.randn(cout, cin, 3, 3, device='cuda') / (3 * cin ** 0.5)
-    pw = conv2d_mfma.pack_weight(w, winograd=True)
-    mw = timeit(lambda: conv2d_mfma.conv2d_forward(x, pw, cout, 3, 3, pad=(1, 1), winograd=True))
-    out.append(f'{mw*1e3:8.1f}')
-print(f'variant {v:2d}: ' + ' '.join(out) + '  us  (H256 c128->128 | H256 c64->128 | H64 c512->512)', flush=True)
+    times = {v: [] for v in VARIANTS}
+    packed = {}
+    for v in VARIANTS:
+        conv2d_mfma._plugin = libs[v]
+        packed[v] = conv2d_mfma.pack_weight(w, winograd=True)
+    for r in range(rounds + 1):
+        for v in VARIANTS:
+            conv2d_mfma._plugin = libs[v]
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(4):
+                conv2d_mfma.conv2d_forward(x, packed[v], cout, 3, 3, pad=(1, 1), winograd=True)
+            e1.record(); torch.cuda.synchronize()
+            if r > 0:
+                times[v].append(e0.elapsed_time(e1) / 4 * 1e3)
+    fl = 2.0 * N * cout * H * H * cin * 9
+    print(f'N{N} H{H} {cin}->{cout}: ' + '  '.join(f'[{v}] {statistics.median(times[v]):7.1f}us {fl / statistics.median(times[v]) / 1e6:5.1f}TF' for v in VARIANTS), flush=True)

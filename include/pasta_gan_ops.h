@@ -167,11 +167,10 @@ int pg_conv2d_forward(const float* x, const float* packed_w, float* y,
 /*
  * Winograd F(2x2, 3x3) variant for KH = KW = 3, stride 1, out_step 1 (the bulk of the synthesis network): the same
  * result as pg_conv2d_forward up to fp32 summation order (~2e-6 of the output scale) with 2.25x fewer multiplies.
- * Weights are pre-transformed once (U = G g G^T, [16][CinP][CoutP64] floats, CoutP64 = Cout rounded up to 64) by
+ * Weights are pre-transformed once (U = G g G^T, 16 * CinP * CoutP64 floats, CoutP64 = Cout rounded up to 64) by
  * pg_conv2d_winograd_pack_weight -- same scale / flip_hw / transpose_oi meaning as pg_conv2d_pack_weight.
- * Fusion: every stage of pg_conv2d_fusion except x2 (PG_ERR_UNSUPPORTED; use pg_conv2d_forward).  In SPADE mode
- * (spade_x != NULL, Cout = 2C, C % 32 == 0) the weight rows are interleaved at a granularity of FOUR: rows
- * [8j, 8j+4) are gamma channels [4j, 4j+4), rows [8j+4, 8j+8) the beta rows of the same channels.
+ * Fusion: every stage of pg_conv2d_fusion except x2 (PG_ERR_UNSUPPORTED; use pg_conv2d_forward); SPADE mode uses
+ * the same 32/32 gamma/beta row interleave as pg_conv2d_forward.  pad_x must be in [0, 4].
  */
 int64_t pg_conv2d_winograd_packed_size(int Cout, int Cin);
 int pg_conv2d_winograd_pack_weight(const float* w, float* packed, int Cout, int Cin,

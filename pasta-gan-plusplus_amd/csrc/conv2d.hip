@@ -64,8 +64,8 @@ __global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict_
             const float u[4] = {t[a][0], 0.5f * (t[a][0] + t[a][1] + t[a][2]), 0.5f * (t[a][0] - t[a][1] + t[a][2]), t[a][2]};
 #pragma unroll
             for (int b = 0; b < 4; b++) {
-                // [xi][co / 32][ci / 4][ci & 1][co & 31][(ci >> 1) & 1]
-                const int64_t dst = ((((int64_t)(4 * a + b) * (CoutP / 32) + (co >> 5)) * (CinP / 4) + (ci >> 2)) * 2 + (ci & 1)) * 64 + (co & 31) * 2 + ((ci >> 1) & 1);
+                // [a][co / 32][ci / 2][ci & 1][co & 31][b]: the four b values of one MFMA lane are one 16-byte word
+                const int64_t dst = ((((int64_t)a * (CoutP / 32) + (co >> 5)) * (CinP / 2) + (ci >> 1)) * 2 + (ci & 1)) * 128 + (co & 31) * 4 + b;
                 up[dst] = u[b];
             }
         }
@@ -229,6 +229,7 @@ static int conv_forward(bool winograd, const float* x, const float* packed_w, fl
 
     if (winograd) {
         if (p.f.x2) return PG_ERR_UNSUPPORTED;                  // two-source launches stay on the direct kernel
+        if (pad_x < 0 || pad_x > 4) return PG_ERR_UNSUPPORTED;  // the LDS halo row starts 4 columns left of the tile
         p.CoutP = round_up(Cout, 64);
         return pgconv::launch_wino(p, s);
     }

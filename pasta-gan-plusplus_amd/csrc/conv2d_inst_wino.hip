@@ -3,6 +3,9 @@
 
 namespace pgconv {
 int launch_wino(const ConvParams& p, hipStream_t s) {
-    return p.in_xform ? launch_wino_xf<true>(p, s) : launch_wino_xf<false>(p, s);
+    // 16-byte halo DMA needs every 4-column word of a row to be inside or outside the image as a whole
+    const bool vec = p.W % 4 == 0 && (((uintptr_t)p.x) & 15) == 0;
+    if (p.in_xform) return vec ? launch_wino_xf<true, true>(p, s) : launch_wino_xf<true, false>(p, s);
+    return vec ? launch_wino_xf<false, true>(p, s) : launch_wino_xf<false, false>(p, s);
 }
 }  // namespace pgconv

@@ -228,10 +228,10 @@ def conv2d_forward(x, packed, cout, kh, kw, stride=1, pad=(0, 0), out_hw=None, y
 def pack_spade_gamma_beta(w_gamma, w_beta, scale_gamma=1.0, scale_beta=1.0, winograd=False):
     """Packed weights of the fused gamma/beta convolution of a Spade_Norm_Block: rows [64j, 64j+32) are gamma channels
     [32j, 32j+32), rows [64j+32, 64j+64) the beta rows of the same channels, so that the two M-tiles of one 64-row
-    workgroup tile hold gamma and beta of the same (channel, pixel) in the same lane.  The Winograd kernel pairs them in
-    its 8-row exchange rounds instead: groups of 4 gamma rows followed by the 4 beta rows of the same channels."""
+    workgroup tile hold gamma and beta of the same (channel, pixel) in the same lane (the Winograd kernel exchanges
+    8 rows of each M-tile per round, so the same order serves it)."""
     c = int(w_gamma.shape[0])
-    grp = 4 if winograd else 32
+    grp = 32
     assert w_gamma.shape == w_beta.shape and c % 32 == 0
     g = (w_gamma.detach() * scale_gamma).reshape(c // grp, grp, *w_gamma.shape[1:])
     b = (w_beta.detach() * scale_beta).reshape(c // grp, grp, *w_beta.shape[1:])

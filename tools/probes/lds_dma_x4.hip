@@ -14,7 +14,7 @@ __global__ void k(const float* x, float* y, int nbytes, const unsigned* voffs) {
     rsrc[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)base);
     rsrc[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(base >> 32) & 0xffff);
     rsrc[2] = nbytes; rsrc[3] = 0x00020000;
-    unsigned keep; unsigned lds = 64; unsigned voff = voffs[threadIdx.x]; int soff = 0;
+    unsigned keep; unsigned lds = 68; unsigned voff = voffs[threadIdx.x]; int soff = 0;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "s"(lds), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -35,7 +35,7 @@ int main() {
     hipLaunchKernelGGL(k, dim3(1), dim3(64), 4096, 0, dx, dy, 1000 * 4, dv);
     std::vector<float> hy(1024); hipMemcpy(hy.data(), dy, 1024 * 4, hipMemcpyDeviceToHost);
     printf("before M0 region (floats 12..15): %g %g %g %g\n", hy[12], hy[13], hy[14], hy[15]);
-    for (int l : {0, 1, 2, 3, 4, 5, 6, 7, 8, 63}) printf("lane %2d -> LDS floats %d..: %g %g %g %g\n", l, 16 + 4 * l, hy[16 + 4 * l], hy[17 + 4 * l], hy[18 + 4 * l], hy[19 + 4 * l]);
+    for (int l : {0, 1, 2, 3, 4, 5, 6, 7, 8, 63}) printf("(M0 = 68: +1 float) lane %2d -> LDS floats %d+1..: %g %g %g %g\n", l, 16 + 4 * l, hy[17 + 4 * l], hy[18 + 4 * l], hy[19 + 4 * l], hy[20 + 4 * l]);
     printf("after (float %d): %g\n", 16 + 256, hy[16 + 256]);
     return 0;
 }

@@ -96,8 +96,11 @@ __global__ __launch_bounds__(512, 4) void conv2d_wino(ConvParams p) {
         const int ty = L % p.tilesY;
         n = L / p.tilesY;
         oy0 = ty * 2; ox0 = tx * 64; m0 = mb * 64;
+#if WINO_EXP & 64
+        n = 0; oy0 = 0; ox0 = 0;                       // timing probe: every tile reads the same (L2-resident) halo tile
+#endif
         const float* in_scale = p.f.in_scale ? p.f.in_scale + (int64_t)n * p.Cin : nullptr;
-        for (int c = t; c < cin_loop; c += 512) cs[c] = (in_scale && c < p.Cin) ? in_scale[c] : 1.f;
+        for (int c = t; c < cin_loop; c += 512) cs[c] = ((in_scale && c < p.Cin) ? in_scale[c] : 1.f) * p.f.in_gain;     // host: in_gain defaults to 1
         int tt = t;
         asm volatile("" : "+v"(tt));                 // keep the index maths inside the tile loop (see conv2d_kernel.h)
         // gather map: element f of the buffer = (channel f / 288, LDS row (f % 288) / 72, LDS column f % 72)
@@ -136,7 +139,6 @@ __global__ __launch_bounds__(512, 4) void conv2d_wino(ConvParams p) {
 
     const float in_slope = act_slope(p.f.in_act, p.f.in_alpha);
     const float in_cl = p.f.in_clamp >= 0.f ? p.f.in_clamp : __builtin_inff();
-    const float in_gain = XF ? p.f.in_gain : 1.f;
 
     f32x16 acc[4];                                   // [b]
 
@@ -145,13 +147,16 @@ __global__ __launch_bounds__(512, 4) void conv2d_wino(ConvParams p) {
     // The loads are inline asm, waited for by hand.  Loads return in order, so at the use of pair pp of a chunk the queue
     // holds, after the needed word, the 3 younger ring words plus -- for pp < 4, whose words were requested before this
     // chunk's halo DMA -- the NDMA DMA requests: vmcnt(3 + NDMA), else vmcnt(3); the latter also guarantees that the DMA
-    // has landed before the chunk's barrier.  Other queue entries (epilogue stores, residual loads) only make it stricter.
+    // has landed before the chunk's barrier.  Other queue entries (epilogue stores, residual loads) only make it stricter;
+    // the first four pairs of a tile need no wait at all (their words are waited for before the previous epilogue's stores).
     const int NP = cin_loop / 2;                                             // pairs per tile
     unsigned pa;                                                             // byte offset into the packed U (< 2^31: checked by the host)
     auto a_reset = [&]() { pa = (unsigned)((ta * (p.CoutP / 32) + (m0 >> 5) + mt) * NP) * 1024u + (unsigned)(half * 512 + l31 * 16); };
-    auto load_a = [&](f32x4& dst) {
-        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(pa), "s"(p.wp));
-        pa += 1024u;
+    auto load_a = [&](f32x4& dst, int slot) {                // slot = pair & 3: immediate offset; the base moves every 4th pair
+        if (slot == 0) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(pa), "s"(p.wp));
+        else if (slot == 1) asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(dst) : "v"(pa), "s"(p.wp));
+        else if (slot == 2) asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "=v"(dst) : "v"(pa), "s"(p.wp));
+        else { asm volatile("global_load_dwordx4 %0, %1, %2 offset:3072" : "=v"(dst) : "v"(pa), "s"(p.wp)); pa += 4096u; }
     };
     auto wait_a = [&](f32x4& g, bool dma_younger) {          // ties the wait to the registers: every use comes after it
         if (dma_younger) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(g) : "n"(W_RING - 1 + NDMA));
@@ -170,7 +175,7 @@ __global__ __launch_bounds__(512, 4) void conv2d_wino(ConvParams p) {
     f32x4 a_ring[W_RING];
     a_reset();
 #pragma unroll
-    for (int d = 0; d < W_RING; d++) load_a(a_ring[d]);
+    for (int d = 0; d < W_RING; d++) load_a(a_ring[d], d);
     issue_chunk(0, 0);
     dma_wait_all();
     __syncthreads();
@@ -218,48 +223,60 @@ __global__ __launch_bounds__(512, 4) void conv2d_wino(ConvParams p) {
             }
             // ---- multiply this chunk: 8 channel pairs x 4 positions per wave.  The samples (and the prologue scale) of
             // pair pp + 1 are requested from LDS before pair pp's MFMAs are issued.
-            const float* xb = smem + buf * W_BUFS + b_lane;                  // this lane's (row rp, j = 0) of channel `half`
+            typedef const __attribute__((address_space(3))) float* lds_cptr;
+            typedef const __attribute__((address_space(3))) f32x2* lds_cptr2;
+            lds_cptr xc = (lds_cptr)smem + buf * W_BUFS + b_lane;            // this lane's (row rp, j = 0) of channel `half`
             const float* csb = cs_cur + k * W_KC + half;
             f32x2 bq[2][4];                                                  // [row rp | rp + 1][columns (0,1) | (2,3)]
             float bs[2];
             auto read_b = [&](int pp, f32x2 (&dst)[4], float& sc) {
-                const float* xc = xb + (2 * pp) * W_CHF;
+                // one VGPR base per pair (advanced by a single add) so that the four 8-byte reads fit ds_read2_b64's offsets
+                asm volatile("" : "+v"(xc));
 #if WINO_EXP & 2
                 dst[0] = (f32x2){1.f, 2.f}; dst[1] = (f32x2){3.f, 4.f}; dst[2] = (f32x2){5.f, 6.f}; dst[3] = (f32x2){7.f, 8.f};
 #else
-                dst[0] = *(const f32x2*)xc; dst[1] = *(const f32x2*)(xc + 2);
-                dst[2] = *(const f32x2*)(xc + W_LROW); dst[3] = *(const f32x2*)(xc + W_LROW + 2);
+                dst[0] = *(lds_cptr2)xc; dst[1] = *(lds_cptr2)(xc + 2);
+                dst[2] = *(lds_cptr2)(xc + W_LROW); dst[3] = *(lds_cptr2)(xc + W_LROW + 2);
 #endif
                 sc = csb[2 * pp];
+                xc += 2 * W_CHF;
             };
             read_b(0, bq[0], bs[0]);
 #pragma unroll
             for (int pp = 0; pp < W_KC / 2; pp++) {
                 if (pp + 1 < W_KC / 2) read_b(pp + 1, bq[(pp + 1) & 1], bs[(pp + 1) & 1]);
                 __builtin_amdgcn_sched_barrier(0);                           // the requests go out BEFORE this pair's MFMAs
-                const float sc = bs[pp & 1] * in_gain;
-                float q[4];                                                  // row-transformed patch columns j = 0..3
+                // row transform on column pairs (packed fp32 math): q = (row rp) + s1 * (row rp + 1), scaled by the prologue scale
+                const float sc = bs[pp & 1];
+                f32x2 q01, q23;
+                if (XF) {                                                    // SPADE pre-activation acts on the raw samples
+                    f32x2 d[4];
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    float d0 = bq[pp & 1][j >> 1][j & 1], d1 = bq[pp & 1][2 + (j >> 1)][j & 1];
-                    if (XF) {                                                // SPADE pre-activation acts on the raw samples
-                        d0 *= sc; d1 *= sc;
-                        d0 = __builtin_amdgcn_fmed3f(fmaxf(d0, d0 * in_slope), -in_cl, in_cl);
-                        d1 = __builtin_amdgcn_fmed3f(fmaxf(d1, d1 * in_slope), -in_cl, in_cl);
-                        q[j] = fmaf(d1, s1, d0);
-                    } else {
-                        q[j] = fmaf(d1, sc * s1, d0 * sc);
-                    }
+                    for (int i = 0; i < 4; i++)
+#pragma unroll
+                        for (int e = 0; e < 2; e++) {
+                            const float v = bq[pp & 1][i][e] * sc;
+                            d[i][e] = __builtin_amdgcn_fmed3f(fmaxf(v, v * in_slope), -in_cl, in_cl);
+                        }
+                    q01 = d[2] * s1 + d[0]; q23 = d[3] * s1 + d[1];
+                } else {
+                    const float ss = sc * s1;
+                    q01 = bq[pp & 1][2] * ss + bq[pp & 1][0] * sc; q23 = bq[pp & 1][3] * ss + bq[pp & 1][1] * sc;
                 }
-                const float v0 = q[0] - q[2], v1 = q[1] + q[2], v2 = q[2] - q[1], v3 = q[1] - q[3];      // B^T d B, row a
+                const float v0 = q01[0] - q23[0], v1 = q01[1] + q23[0], v2 = q23[0] - q01[1], v3 = q01[1] - q23[1];      // B^T d B, row a
+#if WINO_EXP & 32
                 wait_a(a_ring[pp % W_RING], pp < W_RING);
+#else
+                if (pp >= W_RING) wait_a(a_ring[pp % W_RING], false);
+                else if (k > 0) wait_a(a_ring[pp % W_RING], true);           // k == 0: landed before the previous epilogue's stores
+#endif
                 acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_ring[pp % W_RING][0], v0, acc[0], 0, 0, 0);
                 acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_ring[pp % W_RING][1], v1, acc[1], 0, 0, 0);
                 acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_ring[pp % W_RING][2], v2, acc[2], 0, 0, 0);
                 acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_ring[pp % W_RING][3], v3, acc[3], 0, 0, 0);
                 if (pp == W_KC / 2 - W_RING && k + 1 == nchunks) a_reset();  // from here on: the next tile's first pairs
 #if !(WINO_EXP & 1)
-                load_a(a_ring[pp % W_RING]);                                 // refill the slot W_RING pairs ahead
+                load_a(a_ring[pp % W_RING], pp % W_RING);                    // refill the slot W_RING pairs ahead
 #endif
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -325,6 +342,12 @@ __global__ __launch_bounds__(512, 4) void conv2d_wino(ConvParams p) {
                 r10 = p.f.residual[pix0 + c1 * cstride]; r11 = p.f.residual[pix1 + c1 * cstride];
             }
             __syncthreads();
+            if (rnd == 0 && !(WINO_EXP & 32)) {
+                // The U words of the next tile's first pairs (requested during the last chunk) must be home before this tile's
+                // stores enter the queue: vmcnt counts stores as well, so the counted waits of the next tile's first pairs
+                // would otherwise wait for these stores to reach memory.  They have had the whole round to arrive.
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(a_ring[0]), "+v"(a_ring[1]), "+v"(a_ring[2]), "+v"(a_ring[3]));
+            }
             // Y[prow][q] = sum_a At[prow][a] Y'[a][q]:  prow 0 -> a = 0, 1, 2 (+ + +);  prow 1 -> a = 1, 2, 3 (+ - -)
             float yv[2][2];                                                  // [M-tile][q]
             const float* exr = ex + (2 * prow) * 16 * 32 + c_l * 32 + tcol;

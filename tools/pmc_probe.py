@@ -1,4 +1,4 @@
-"""Dev tool (GPU box): a handful of launches of the two hottest conv shapes, for rocprofv3 --pmc passes."""
+"""Dev tool (GPU box): a handful of launches of the two hottest conv shapes, for rocprofv3 --pmc passes (argv[1] = winograd: that kernel)."""
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'pasta-gan-plusplus_amd'))
@@ -7,11 +7,12 @@ from torch_utils import custom_ops
 custom_ops.verbosity = 'none'
 from torch_utils.ops import conv2d_mfma
 dev = 'cuda'
+wg = len(sys.argv) > 1 and sys.argv[1] == 'winograd'
 for (N, H, cin, cout) in [(8, 256, 128, 128), (8, 512, 64, 64)]:
     x = torch.randn(N, cin, H, H, device=dev)
     w = torch.randn(cout, cin, 3, 3, device=dev) / (3 * cin ** 0.5)
-    pk = conv2d_mfma.pack_weight(w)
+    pk = conv2d_mfma.pack_weight(w, winograd=wg)
     for _ in range(6):
-        y = conv2d_mfma.conv2d_forward(x, pk, cout, 3, 3, pad=(1, 1))
+        y = conv2d_mfma.conv2d_forward(x, pk, cout, 3, 3, pad=(1, 1), winograd=wg)
     torch.cuda.synchronize()
 print('done')

@@ -263,7 +263,16 @@ __global__ __launch_bounds__(512, 4) void conv2d_wino(ConvParams p) {
                     const float ss = sc * s1;
                     q01 = bq[pp & 1][2] * ss + bq[pp & 1][0] * sc; q23 = bq[pp & 1][3] * ss + bq[pp & 1][1] * sc;
                 }
+#if WINO_EXP & 512
+                { static_assert(true, ""); float dmy = sc;                        // timing probe: 8 independent VALU ops per pair
+                  asm volatile("v_add_f32 %0, %0, %0\n\tv_add_f32 %0, %0, %0\n\tv_add_f32 %0, %0, %0\n\tv_add_f32 %0, %0, %0\n\t"
+                               "v_add_f32 %0, %0, %0\n\tv_add_f32 %0, %0, %0\n\tv_add_f32 %0, %0, %0\n\tv_add_f32 %0, %0, %0" : "+v"(dmy)); }
+#endif
+#if WINO_EXP & 256
+                const float v0 = bq[pp & 1][0][0], v1 = bq[pp & 1][0][1], v2 = bq[pp & 1][1][0], v3 = bq[pp & 1][1][1];   // timing probe: no transform
+#else
                 const float v0 = q01[0] - q23[0], v1 = q01[1] + q23[0], v2 = q23[0] - q01[1], v3 = q01[1] - q23[1];      // B^T d B, row a
+#endif
 #if WINO_EXP & 32
                 wait_a(a_ring[pp % W_RING], pp < W_RING);
 #else
@@ -282,7 +291,9 @@ __global__ __launch_bounds__(512, 4) void conv2d_wino(ConvParams p) {
             }
             // No vmcnt wait here: pair 4 already waited for a U word requested AFTER this chunk's halo DMA, so the DMA has
             // landed.  (A vmcnt(0) would also wait for the U refills issued a moment ago: one exposed L2 round trip per chunk.)
+#if !(WINO_EXP & 128)
             __syncthreads();
+#endif
         }
 
         // ---- inverse transform + fused epilogue.  Column half in registers: Y'[a][q] = sum_b M[a][b] At[q][b]; the row half

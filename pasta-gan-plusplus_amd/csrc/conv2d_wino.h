@@ -54,10 +54,16 @@ __device__ __forceinline__ void dma_dwordx4_buf(i32x4 rsrc, unsigned lds_byte, u
                  : "=&s"(keep) : "s"(lds_byte), "v"(voff_bytes), "s"(rsrc), "s"(soff_bytes) : "memory");
 }
 
-// VEC: 16-byte halo DMA (W % 4 == 0 and a 16-byte aligned x); otherwise dwords.  NDMA = requests per thread per chunk.
-template <bool XF, bool VEC>
+// MODE: 0 = plain input, 1 = per-(n, channel) input scale (modulated convolution), 2 = scale + pre-activation (SPADE convs).
+// VEC: 16-byte halo DMA (W % 4 == 0 and a 16-byte aligned x), issued by waves 0-3 only; otherwise dwords from all waves.
+// Why one half issues the whole DMA: a wave's U words requested after its DMA cannot return before it (loads return in
+// order), so a DMA that misses to HBM stalls its issuer 4 pairs later.  With all waves issuing, the whole workgroup stalls
+// together; with waves 0-3 issuing, waves 4-7 (one per SIMD) keep the matrix pipe busy through that window.
+// NDMA = requests per issuing thread per chunk.
+template <int MODE, bool VEC>
 __global__ __launch_bounds__(512, 4) void conv2d_wino(ConvParams p) {
-    constexpr int NDMA = VEC ? 3 : 9;
+    constexpr bool XF = MODE == 2;
+    constexpr int NDMA = VEC ? 6 : 9;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int cin_loop = ((p.Cin + W_KC - 1) / W_KC) * W_KC;
     const int nchunks = cin_loop / W_KC;
@@ -104,16 +110,18 @@ __global__ __launch_bounds__(512, 4) void conv2d_wino(ConvParams p) {
         int tt = t;
         asm volatile("" : "+v"(tt));                 // keep the index maths inside the tile loop (see conv2d_kernel.h)
         // gather map: element f of the buffer = (channel f / 288, LDS row (f % 288) / 72, LDS column f % 72)
+        if (!VEC || wave < 4) {
 #pragma unroll
-        for (int i = 0; i < NDMA; i++) {
-            const bool wide = VEC && i < 2;          // VEC: two 16-byte requests (floats 4e .. 4e+3) + one dword (floats 4096 + t)
-            const int f = wide ? 4 * (tt + 512 * i) : (VEC ? 4096 + tt : tt + 512 * i);
-            const int c = f / W_CHF, rem = f % W_CHF;
-            const int rl = rem / W_LROW, lc = rem % W_LROW;
-            const int hr = rl == 1 ? 2 : (rl == 2 ? 1 : rl);                 // LDS row -> halo row
-            const int gy = oy0 - p.pad_y + hr, gx = ox0 - 4 + lc;
-            const bool ok = gy >= 0 && gy < p.H && gx >= 0 && gx + (wide ? 4 : 1) <= p.W;
-            xoff[i] = ok ? (unsigned)(c * HW + gy * p.W + gx) * 4u : 0x80000000u;
+            for (int i = 0; i < NDMA; i++) {
+                const bool wide = VEC && i < 4;      // VEC: four 16-byte requests (floats 4e .. 4e+3, e < 1024) + two dwords (floats 4096 ..)
+                const int f = wide ? 4 * (tt + 256 * i) : (VEC ? 4096 + tt + 256 * (i - 4) : tt + 512 * i);
+                const int c = f / W_CHF, rem = f % W_CHF;
+                const int rl = rem / W_LROW, lc = rem % W_LROW;
+                const int hr = rl == 1 ? 2 : (rl == 2 ? 1 : rl);             // LDS row -> halo row
+                const int gy = oy0 - p.pad_y + hr, gx = ox0 - 4 + lc;
+                const bool ok = gy >= 0 && gy < p.H && gx >= 0 && gx + (wide ? 4 : 1) <= p.W;
+                xoff[i] = ok ? (unsigned)(c * HW + gy * p.W + gx) * 4u : 0x80000000u;
+            }
         }
         const uint64_t base = (uint64_t)(uintptr_t)(p.x + (int64_t)n * p.Cin * HW);
         xrsrc[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)base);
@@ -127,9 +135,12 @@ __global__ __launch_bounds__(512, 4) void conv2d_wino(ConvParams p) {
         const int soff = c0 * HW * 4;
 #if !(WINO_EXP & 8)
         if (VEC) {
-            dma_dwordx4_buf(xrsrc, xs_b + (unsigned)(64 * wave) * 16u, xoff[0], soff);
-            dma_dwordx4_buf(xrsrc, xs_b + (unsigned)(512 + 64 * wave) * 16u, xoff[1], soff);
-            dma_dword(xrsrc, xs_b + (unsigned)(4096 + 64 * wave) * 4u, xoff[NDMA - 1], soff);
+            if (wave < 4) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) dma_dwordx4_buf(xrsrc, xs_b + (unsigned)(256 * i + 64 * wave) * 16u, xoff[i], soff);
+#pragma unroll
+                for (int i = 4; i < 6; i++) dma_dword(xrsrc, xs_b + (unsigned)(4096 + 256 * (i - 4) + 64 * wave) * 4u, xoff[i], soff);
+            }
         } else {
 #pragma unroll
             for (int i = 0; i < NDMA; i++) dma_dword(xrsrc, xs_b + (unsigned)(512 * i + 64 * wave) * 4u, xoff[i], soff);
@@ -158,8 +169,9 @@ __global__ __launch_bounds__(512, 4) void conv2d_wino(ConvParams p) {
         else if (slot == 2) asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "=v"(dst) : "v"(pa), "s"(p.wp));
         else { asm volatile("global_load_dwordx4 %0, %1, %2 offset:3072" : "=v"(dst) : "v"(pa), "s"(p.wp)); pa += 4096u; }
     };
+    const bool issues_dma = !VEC || wave < 4;
     auto wait_a = [&](f32x4& g, bool dma_younger) {          // ties the wait to the registers: every use comes after it
-        if (dma_younger) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(g) : "n"(W_RING - 1 + NDMA));
+        if (dma_younger && issues_dma) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(g) : "n"(W_RING - 1 + NDMA));
         else asm volatile("s_waitcnt vmcnt(%1)" : "+v"(g) : "n"(W_RING - 1));
     };
 
@@ -238,7 +250,7 @@ __global__ __launch_bounds__(512, 4) void conv2d_wino(ConvParams p) {
                 dst[0] = *(lds_cptr2)xc; dst[1] = *(lds_cptr2)(xc + 2);
                 dst[2] = *(lds_cptr2)(xc + W_LROW); dst[3] = *(lds_cptr2)(xc + W_LROW + 2);
 #endif
-                sc = csb[2 * pp];
+                if (MODE != 0) sc = csb[2 * pp];
                 xc += 2 * W_CHF;
             };
             read_b(0, bq[0], bs[0]);
@@ -259,9 +271,11 @@ __global__ __launch_bounds__(512, 4) void conv2d_wino(ConvParams p) {
                             d[i][e] = __builtin_amdgcn_fmed3f(fmaxf(v, v * in_slope), -in_cl, in_cl);
                         }
                     q01 = d[2] * s1 + d[0]; q23 = d[3] * s1 + d[1];
-                } else {
+                } else if (MODE == 1) {
                     const float ss = sc * s1;
                     q01 = bq[pp & 1][2] * ss + bq[pp & 1][0] * sc; q23 = bq[pp & 1][3] * ss + bq[pp & 1][1] * sc;
+                } else {
+                    q01 = bq[pp & 1][2] * s1 + bq[pp & 1][0]; q23 = bq[pp & 1][3] * s1 + bq[pp & 1][1];
                 }
 #if WINO_EXP & 512
                 { static_assert(true, ""); float dmy = sc;                        // timing probe: 8 independent VALU ops per pair
@@ -396,7 +410,7 @@ __global__ __launch_bounds__(512, 4) void conv2d_wino(ConvParams p) {
     }
 }
 
-template <bool XF, bool VEC>
+template <int MODE, bool VEC>
 int launch_wino_xf(const ConvParams& p0, hipStream_t s) {
     ConvParams p = p0;
     p.tilesX = (p.OW + 63) / 64;
@@ -415,11 +429,11 @@ int launch_wino_xf(const ConvParams& p0, hipStream_t s) {
     const int64_t blocks = tiles < (int64_t)kNumCU * per_cu ? tiles : (int64_t)kNumCU * per_cu;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv2d_wino<XF, VEC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void*)conv2d_wino<MODE, VEC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv2d_wino<XF, VEC>), dim3((unsigned)blocks), dim3(512), lds, s, p);
+    hipLaunchKernelGGL((conv2d_wino<MODE, VEC>), dim3((unsigned)blocks), dim3(512), lds, s, p);
     return launch_status();
 }
 

@@ -17,6 +17,13 @@ import torch
 from torch_utils.ops import conv2d_mfma
 from torch_utils.ops import _native as nat
 libs = {}
+if os.environ.get('WINO_PREV'):                  # a prebuilt csrc/wino_prev.so (older revision of the sources) as variant -1
+    prev = custom_ops.NativePlugin('wino_prev', os.path.join(custom_ops.CSRC_DIR, 'wino_prev.so'))
+    _orig0 = custom_ops.get_plugin
+    custom_ops.get_plugin = lambda name, **kw: prev
+    conv2d_mfma._plugin = None
+    libs[-1] = conv2d_mfma._init('wino_prev')
+    custom_ops.get_plugin = _orig0
 for v in VARIANTS:
     conv2d_mfma._plugin = None
     custom_ops.PLUGIN_SOURCES[f'wino_exp{v}'] = SRC
@@ -30,13 +37,14 @@ rounds = int(os.environ.get('WINO_ROUNDS', '7'))
 for (N, H, cin, cout) in SHAPES:
     x = torch.randn(N, cin, H, H, device='cuda')
     w = torch.randn(cout, cin, 3, 3, device='cuda') / (3 * cin ** 0.5)
-    times = {v: [] for v in VARIANTS}
+    ALL = ([-1] if -1 in libs else []) + VARIANTS
+    times = {v: [] for v in ALL}
     packed = {}
-    for v in VARIANTS:
+    for v in ALL:
         conv2d_mfma._plugin = libs[v]
         packed[v] = conv2d_mfma.pack_weight(w, winograd=True)
     for r in range(rounds + 1):
-        for v in VARIANTS:
+        for v in ALL:
             conv2d_mfma._plugin = libs[v]
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -46,4 +54,4 @@ for (N, H, cin, cout) in SHAPES:
             if r > 0:
                 times[v].append(e0.elapsed_time(e1) / 4 * 1e3)
     fl = 2.0 * N * cout * H * H * cin * 9
-    print(f'N{N} H{H} {cin}->{cout}: ' + '  '.join(f'[{v}] {statistics.median(times[v]):7.1f}us {fl / statistics.median(times[v]) / 1e6:5.1f}TF' for v in VARIANTS), flush=True)
+    print(f'N{N} H{H} {cin}->{cout}: ' + '  '.join(f'[{v}] {statistics.median(times[v]):7.1f}us {fl / statistics.median(times[v]) / 1e6:5.1f}TF' for v in ALL), flush=True)

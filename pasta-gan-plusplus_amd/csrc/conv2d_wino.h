@@ -175,11 +175,15 @@ __global__ __launch_bounds__(512, 4) void conv2d_wino(ConvParams p) {
         else asm volatile("s_waitcnt vmcnt(%1)" : "+v"(g) : "n"(W_RING - 1));
     };
 
-    const float gain = p.f.gain;
-    const float cl = p.f.clamp >= 0.f ? p.f.clamp : __builtin_inff();
-    const float slope = act_slope(p.f.act, p.f.alpha);
-    // both pixels of a thread's output pair in one 8-byte store: dense rows, even strides, aligned base
-    const bool vec_store = p.ys[3] == 1 && ((p.ys[0] | p.ys[1] | p.ys[2]) & 1) == 0 && (((uintptr_t)p.y) & 7) == 0 && (p.OW & 1) == 0;
+    // The tail's uniforms (pointers, strides, activation constants) are re-read from the kernel-argument segment where they
+    // are used: kept live across the K loop they overflow the SGPR file, and every spilled SGPR comes back through a
+    // v_readlane -- a VALU instruction, i.e. matrix-pipe time.  The opaque asm keeps the compiler from hoisting the loads.
+    typedef const __attribute__((address_space(4))) ConvParams* kernarg_t;
+    auto fresh_args = [&]() {
+        kernarg_t a = (kernarg_t)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(a));
+        return a;
+    };
 
     int tile = blockIdx.x;
     int par = 0, g = 0;
@@ -209,18 +213,19 @@ __global__ __launch_bounds__(512, 4) void conv2d_wino(ConvParams p) {
                 issue_chunk((k + 1) * W_KC, buf ^ 1);
             } else {
                 e_n = n; e_oy0 = oy0; e_ox0 = ox0; e_m0 = m0;
-                if (p.f.spade_x) {                          // SPADE mode: per-(n, channel) mean / rstd of the normalised tensor
+                const auto& q = *fresh_args();
+                if (q.f.spade_x) {                          // SPADE mode: per-(n, channel) mean / rstd of the normalised tensor
                     if (t < 32) {
                         const int ch = (e_m0 >> 1) + t;     // this tile's 32 output channels
-                        ep_scale[t] = p.f.spade_mean[e_n * (p.Cout >> 1) + ch];
-                        ep_bias[t] = p.f.spade_rstd[e_n * (p.Cout >> 1) + ch];
+                        ep_scale[t] = q.f.spade_mean[e_n * (q.Cout >> 1) + ch];
+                        ep_bias[t] = q.f.spade_rstd[e_n * (q.Cout >> 1) + ch];
                     }
                 } else if (t < 64) {
                     const int co = e_m0 + t;
-                    const bool ok = co < p.Cout;
+                    const bool ok = co < q.Cout;
                     const int cc = ok ? co : 0;
-                    const float sc = p.f.out_scale ? p.f.out_scale[(int64_t)e_n * p.Cout + cc] : 1.f;
-                    const float bi = p.f.bias ? p.f.bias[cc] : 0.f;
+                    const float sc = q.f.out_scale ? q.f.out_scale[(int64_t)e_n * q.Cout + cc] : 1.f;
+                    const float bi = q.f.bias ? q.f.bias[cc] : 0.f;
                     ep_scale[t] = ok ? sc : 0.f;
                     ep_bias[t] = ok ? bi : 0.f;
                 }
@@ -320,30 +325,49 @@ __global__ __launch_bounds__(512, 4) void conv2d_wino(ConvParams p) {
         tile = next; par ^= 1;
         continue;
 #endif
+        // Every VALU instruction here costs matrix-pipe time (they do not overlap on this hardware), so the tail is written for
+        // instruction count: 32-bit byte offsets against uniform bases, packed fp32 math on the pixel pair, a predicate-free path
+        // for interior tiles, and the activation chain skipped when it is the identity.
+        const auto& q = *fresh_args();
         const int c_l = t >> 6, prow = (t >> 5) & 1, tcol = t & 31;          // this thread's outputs: cout (of 8), row of the 2x2, tile
         const int oy = e_oy0 + prow, ox = e_ox0 + 2 * tcol;
-        const bool row_ok = oy < p.OH;
-        const int oyc = row_ok ? oy : p.OH - 1;
-        const int ox0c = ox < p.OW ? ox : p.OW - 1, ox1c = ox + 1 < p.OW ? ox + 1 : p.OW - 1;
-        const int cstride = (int)p.ys[1];
-        const bool spade = p.f.spade_x != nullptr;
-        const int pix0 = (int)((int64_t)e_n * p.ys[0] + (int64_t)oyc * p.ys[2] + (int64_t)ox0c * p.ys[3]);
-        const int pix1 = (int)((int64_t)e_n * p.ys[0] + (int64_t)oyc * p.ys[2] + (int64_t)ox1c * p.ys[3]);
-        const bool ok0 = row_ok && ox < p.OW, ok1 = row_ok && ox + 1 < p.OW;
-        float nz0 = 0.f, nz1 = 0.f;
-        if (p.f.noise) {
-            const float* nzp = p.f.noise + (int)(e_n * p.f.noise_batch_stride) + oyc * p.OW;
-            nz0 = nzp[ox0c] * p.f.noise_gain; nz1 = nzp[ox1c] * p.f.noise_gain;
+        const bool spade = q.f.spade_x != nullptr;
+        const float gain = q.f.gain, slope = act_slope(q.f.act, q.f.alpha);
+        const float cl = q.f.clamp >= 0.f ? q.f.clamp : __builtin_inff();
+        const bool vec_store = q.ys[3] == 1 && ((q.ys[0] | q.ys[1] | q.ys[2]) & 1) == 0 && (((uintptr_t)q.y) & 7) == 0 && (q.OW & 1) == 0;
+        const bool full = vec_store && e_oy0 + 2 <= q.OH && e_ox0 + 64 <= q.OW && e_m0 + 64 <= q.Cout;      // wave-uniform
+        const bool row_ok = oy < q.OH;
+        const int oyc = row_ok ? oy : q.OH - 1;
+        const int ox0c = ox < q.OW ? ox : q.OW - 1, ox1c = ox + 1 < q.OW ? ox + 1 : q.OW - 1;
+        const bool ok0 = row_ok && ox < q.OW, ok1 = row_ok && ox + 1 < q.OW;
+        const unsigned cstride_b = (unsigned)q.ys[1] * 4u;
+        const unsigned pix0_b = (unsigned)((int64_t)e_n * q.ys[0] + (int64_t)oyc * q.ys[2] + (int64_t)ox0c * q.ys[3]) * 4u;
+        const unsigned pix1_b = (unsigned)((int64_t)e_n * q.ys[0] + (int64_t)oyc * q.ys[2] + (int64_t)ox1c * q.ys[3]) * 4u;
+        const float sg = prow ? -1.f : 1.f;                                   // A^T row: prow 0 -> (+ + +), prow 1 -> (+ - -)
+        const bool plain_tail = slope == 1.f && gain == 1.f && q.f.clamp < 0.f;                                // wave-uniform
+        f32x2 nz = {0.f, 0.f};
+        if (q.f.noise) {
+            const float* nzp = q.f.noise + (int)(e_n * q.f.noise_batch_stride) + oyc * q.OW;
+            nz[0] = nzp[ox0c] * q.f.noise_gain; nz[1] = nzp[ox1c] * q.f.noise_gain;
         }
-        auto store2 = [&](int off, float v0, float v1, bool chan_ok) {
-            if (vec_store) {
-                f32x2 vv; vv[0] = v0; vv[1] = v1;
-                if (ok0 && chan_ok) *(f32x2*)(p.y + off) = vv;
+        auto ld = [&](const float* base, unsigned off_b) { return *(const float*)((const char*)base + off_b); };
+        auto ld2 = [&](const float* base, unsigned off_b) {                   // the pixel pair of one channel
+            f32x2 r;
+            if (full) r = *(const f32x2*)((const char*)base + off_b);
+            else { r[0] = ld(base, off_b); r[1] = ld(base, off_b + (pix1_b - pix0_b)); }
+            return r;
+        };
+        auto store2 = [&](unsigned off_b, f32x2 v, bool chan_ok) {
+            if (full) {
+                *(f32x2*)((char*)q.y + off_b) = v;
+            } else if (vec_store) {
+                if (ok0 && chan_ok) *(f32x2*)((char*)q.y + off_b) = v;
             } else {
-                if (ok0 && chan_ok) p.y[off] = v0;
-                if (ok1 && chan_ok) p.y[off + (pix1 - pix0)] = v1;
+                if (ok0 && chan_ok) *(float*)((char*)q.y + off_b) = v[0];
+                if (ok1 && chan_ok) *(float*)((char*)q.y + off_b + (pix1_b - pix0_b)) = v[1];
             }
         };
+        const float* exr0 = ex0 + (2 * prow) * 16 * 32 + c_l * 32 + tcol;
 #pragma unroll
         for (int rnd = 0; rnd < 4; rnd++) {
             // couts 8 rnd + 4 half + j of this wave's M-tile live in accumulator registers 4 rnd + j
@@ -352,19 +376,19 @@ __global__ __launch_bounds__(512, 4) void conv2d_wino(ConvParams p) {
             for (int j = 0; j < 4; j++) {
                 const float m0v = acc[0][4 * rnd + j], m1v = acc[1][4 * rnd + j], m2v = acc[2][4 * rnd + j], m3v = acc[3][4 * rnd + j];
                 float* dst = ex + ((2 * ta) * 16 + mt * 8 + 4 * half + j) * 32 + l31;
-                dst[0] = m0v + m1v + m2v;                                    // q = 0
-                dst[16 * 32] = m1v - m2v - m3v;                              // q = 1
+                const float m12 = m1v + m2v;
+                dst[0] = m0v + m12;                                          // q = 0:  M0 + M1 + M2
+                dst[16 * 32] = (m1v - m2v) - m3v;                            // q = 1:  M1 - M2 - M3
             }
             // the extra operand of this round's outputs, requested before the barrier
             const int chl = 8 * rnd + c_l;                                   // cout within an M-tile
-            float r00 = 0.f, r01 = 0.f, r10 = 0.f, r11 = 0.f;
+            f32x2 r0 = {0.f, 0.f}, r1 = {0.f, 0.f};
             if (spade) {
-                const int ch = (e_m0 >> 1) + chl;
-                r00 = p.f.spade_x[pix0 + ch * cstride]; r01 = p.f.spade_x[pix1 + ch * cstride];
-            } else if (p.f.residual) {
-                const int c0 = e_m0 + chl < p.Cout ? e_m0 + chl : p.Cout - 1, c1 = e_m0 + 32 + chl < p.Cout ? e_m0 + 32 + chl : p.Cout - 1;
-                r00 = p.f.residual[pix0 + c0 * cstride]; r01 = p.f.residual[pix1 + c0 * cstride];
-                r10 = p.f.residual[pix0 + c1 * cstride]; r11 = p.f.residual[pix1 + c1 * cstride];
+                r0 = ld2(q.f.spade_x, pix0_b + (unsigned)((e_m0 >> 1) + chl) * cstride_b);
+            } else if (q.f.residual) {
+                const int c0 = (full || e_m0 + chl < q.Cout) ? e_m0 + chl : q.Cout - 1, c1 = (full || e_m0 + 32 + chl < q.Cout) ? e_m0 + 32 + chl : q.Cout - 1;
+                r0 = ld2(q.f.residual, pix0_b + (unsigned)c0 * cstride_b);
+                r1 = ld2(q.f.residual, pix0_b + (unsigned)c1 * cstride_b);
             }
             __syncthreads();
             if (rnd == 0 && !(WINO_EXP & 32)) {
@@ -373,34 +397,33 @@ __global__ __launch_bounds__(512, 4) void conv2d_wino(ConvParams p) {
                 // would otherwise wait for these stores to reach memory.  They have had the whole round to arrive.
                 asm volatile("s_waitcnt vmcnt(0)" : "+v"(a_ring[0]), "+v"(a_ring[1]), "+v"(a_ring[2]), "+v"(a_ring[3]));
             }
-            // Y[prow][q] = sum_a At[prow][a] Y'[a][q]:  prow 0 -> a = 0, 1, 2 (+ + +);  prow 1 -> a = 1, 2, 3 (+ - -)
-            float yv[2][2];                                                  // [M-tile][q]
-            const float* exr = ex + (2 * prow) * 16 * 32 + c_l * 32 + tcol;
+            // Y[prow][q] = Y'[a0][q] + sg * (Y'[a0 + 1][q] + Y'[a0 + 2][q]),  a0 = prow
+            f32x2 yv[2];                                                     // [M-tile](q = 0, 1)
+            const float* exr = exr0 + (rnd & 1) * W_EXCH;
 #pragma unroll
             for (int kk = 0; kk < 2; kk++)
 #pragma unroll
                 for (int q = 0; q < 2; q++) {
                     const float* e3 = exr + (q * 16 + kk * 8) * 32;
-                    const float v0 = e3[0], v1 = e3[2 * 16 * 32], v2 = e3[4 * 16 * 32];
-                    yv[kk][q] = prow == 0 ? v0 + v1 + v2 : v0 - v1 - v2;
+                    yv[kk][q] = fmaf(sg, e3[2 * 16 * 32] + e3[4 * 16 * 32], e3[0]);
                 }
             if (spade) {
                 // SPADE combine (networks.py:1715-1722): M-tile 0 rows are gamma, M-tile 1 rows the beta rows of the same 32
                 // channels:  y = (x - mean) * rstd * (1 + gamma) + beta
-                const int ch = (e_m0 >> 1) + chl;
                 const float mu = ep_scale[chl], rs = ep_bias[chl];
-                store2(pix0 + ch * cstride, (r00 - mu) * rs * (1.f + yv[0][0]) + yv[1][0], (r01 - mu) * rs * (1.f + yv[0][1]) + yv[1][1], true);
+                store2(pix0_b + (unsigned)((e_m0 >> 1) + chl) * cstride_b, (r0 - mu) * rs * (yv[0] + 1.f) + yv[1], true);
             } else {
 #pragma unroll
                 for (int kk = 0; kk < 2; kk++) {
                     const int co = e_m0 + 32 * kk + chl;
                     const float esc = ep_scale[32 * kk + chl], ebi = ep_bias[32 * kk + chl];
-                    float v0 = yv[kk][0] * esc + nz0 + ebi, v1 = yv[kk][1] * esc + nz1 + ebi;
-                    v0 = v0 > 0.f ? v0 : v0 * slope;
-                    v1 = v1 > 0.f ? v1 : v1 * slope;
-                    v0 = fminf(fmaxf(v0 * gain, -cl), cl) + (kk ? r10 : r00);
-                    v1 = fminf(fmaxf(v1 * gain, -cl), cl) + (kk ? r11 : r01);
-                    store2(pix0 + (co < p.Cout ? co : p.Cout - 1) * cstride, v0, v1, co < p.Cout);
+                    f32x2 v = yv[kk] * esc + (nz + ebi);
+                    if (!plain_tail) {
+#pragma unroll
+                        for (int e = 0; e < 2; e++) v[e] = __builtin_amdgcn_fmed3f((v[e] > 0.f ? v[e] : v[e] * slope) * gain, -cl, cl);
+                    }
+                    v += kk ? r1 : r0;
+                    store2(pix0_b + (unsigned)((full || co < q.Cout) ? co : q.Cout - 1) * cstride_b, v, co < q.Cout);
                 }
             }
         }

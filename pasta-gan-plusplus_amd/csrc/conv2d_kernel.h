@@ -408,7 +408,10 @@ int launch_conv(const ConvParams& p, hipStream_t s) {
 
 template <int KH, int KW, int S, int KC, bool XFORM = false>
 int launch_bm(const ConvParams& p, hipStream_t s) {
-    if (p.CoutP % 64 == 0) return launch_conv<KH, KW, S, 64, KC, XFORM>(p, s);
+    // 64-cout tiles unless that leaves most of the chip idle (low-resolution layers: a handful of pixel tiles, latency-bound
+    // K loops): 32-cout tiles double the number of workgroups
+    const int64_t tiles64 = (int64_t)p.N * ((p.OW + TW - 1) / TW) * ((p.OH + TH - 1) / TH) * (p.CoutP / 64);
+    if (p.CoutP % 64 == 0 && (tiles64 >= 2 * kNumCU || p.f.spade_x)) return launch_conv<KH, KW, S, 64, KC, XFORM>(p, s);
     return launch_conv<KH, KW, S, 32, KC, XFORM>(p, s);
 }
 

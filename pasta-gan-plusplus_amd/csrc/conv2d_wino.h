@@ -33,7 +33,8 @@
 #include "conv2d_kernel.h"
 
 #ifndef WINO_EXP
-#define WINO_EXP 0       // dev ablations (tools/wino_variants.py): 1 no U loads, 2 no LDS operand reads, 4 no epilogue, 8 no halo DMA
+#define WINO_EXP 0       // dev ablations (tools/wino_variants.py; results wrong by design): 1 no U loads, 2 no LDS operand reads, 4 no tail,
+                         // 8 no halo DMA, 128 no chunk barrier, 256 no transform VALU, 512 eight extra independent VALU ops per channel pair
 #endif
 
 namespace pgconv {
@@ -102,9 +103,6 @@ __global__ __launch_bounds__(512, 4) void conv2d_wino(ConvParams p) {
         const int ty = L % p.tilesY;
         n = L / p.tilesY;
         oy0 = ty * 2; ox0 = tx * 64; m0 = mb * 64;
-#if WINO_EXP & 64
-        n = 0; oy0 = 0; ox0 = 0;                       // timing probe: every tile reads the same (L2-resident) halo tile
-#endif
         const float* in_scale = p.f.in_scale ? p.f.in_scale + (int64_t)n * p.Cin : nullptr;
         for (int c = t; c < cin_loop; c += 512) cs[c] = ((in_scale && c < p.Cin) ? in_scale[c] : 1.f) * p.f.in_gain;     // host: in_gain defaults to 1
         int tt = t;
@@ -244,8 +242,9 @@ __global__ __launch_bounds__(512, 4) void conv2d_wino(ConvParams p) {
             typedef const __attribute__((address_space(3))) f32x2* lds_cptr2;
             lds_cptr xc = (lds_cptr)smem + buf * W_BUFS + b_lane;            // this lane's (row rp, j = 0) of channel `half`
             const float* csb = cs_cur + k * W_KC + half;
-            f32x2 bq[2][4];                                                  // [row rp | rp + 1][columns (0,1) | (2,3)]
-            float bs[2];
+            constexpr int PD = 1;                                            // LDS operand requests run PD pairs ahead (2 measured no faster)
+            f32x2 bq[PD + 1][4];                                             // [row rp | rp + 1][columns (0,1) | (2,3)]
+            float bs[PD + 1];
             auto read_b = [&](int pp, f32x2 (&dst)[4], float& sc) {
                 // one VGPR base per pair (advanced by a single add) so that the four 8-byte reads fit ds_read2_b64's offsets
                 asm volatile("" : "+v"(xc));
@@ -258,13 +257,14 @@ __global__ __launch_bounds__(512, 4) void conv2d_wino(ConvParams p) {
                 if (MODE != 0) sc = csb[2 * pp];
                 xc += 2 * W_CHF;
             };
-            read_b(0, bq[0], bs[0]);
+#pragma unroll
+            for (int d = 0; d < PD; d++) read_b(d, bq[d], bs[d]);
 #pragma unroll
             for (int pp = 0; pp < W_KC / 2; pp++) {
-                if (pp + 1 < W_KC / 2) read_b(pp + 1, bq[(pp + 1) & 1], bs[(pp + 1) & 1]);
+                if (pp + PD < W_KC / 2) read_b(pp + PD, bq[(pp + PD) % (PD + 1)], bs[(pp + PD) % (PD + 1)]);
                 __builtin_amdgcn_sched_barrier(0);                           // the requests go out BEFORE this pair's MFMAs
                 // row transform on column pairs (packed fp32 math): q = (row rp) + s1 * (row rp + 1), scaled by the prologue scale
-                const float sc = bs[pp & 1];
+                const float sc = bs[pp % (PD + 1)];
                 f32x2 q01, q23;
                 if (XF) {                                                    // SPADE pre-activation acts on the raw samples
                     f32x2 d[4];
@@ -272,15 +272,15 @@ __global__ __launch_bounds__(512, 4) void conv2d_wino(ConvParams p) {
                     for (int i = 0; i < 4; i++)
 #pragma unroll
                         for (int e = 0; e < 2; e++) {
-                            const float v = bq[pp & 1][i][e] * sc;
+                            const float v = bq[pp % (PD + 1)][i][e] * sc;
                             d[i][e] = __builtin_amdgcn_fmed3f(fmaxf(v, v * in_slope), -in_cl, in_cl);
                         }
                     q01 = d[2] * s1 + d[0]; q23 = d[3] * s1 + d[1];
                 } else if (MODE == 1) {
                     const float ss = sc * s1;
-                    q01 = bq[pp & 1][2] * ss + bq[pp & 1][0] * sc; q23 = bq[pp & 1][3] * ss + bq[pp & 1][1] * sc;
+                    q01 = bq[pp % (PD + 1)][2] * ss + bq[pp % (PD + 1)][0] * sc; q23 = bq[pp % (PD + 1)][3] * ss + bq[pp % (PD + 1)][1] * sc;
                 } else {
-                    q01 = bq[pp & 1][2] * s1 + bq[pp & 1][0]; q23 = bq[pp & 1][3] * s1 + bq[pp & 1][1];
+                    q01 = bq[pp % (PD + 1)][2] * s1 + bq[pp % (PD + 1)][0]; q23 = bq[pp % (PD + 1)][3] * s1 + bq[pp % (PD + 1)][1];
                 }
 #if WINO_EXP & 512
                 { static_assert(true, ""); float dmy = sc;                        // timing probe: 8 independent VALU ops per pair
@@ -288,16 +288,12 @@ __global__ __launch_bounds__(512, 4) void conv2d_wino(ConvParams p) {
                                "v_add_f32 %0, %0, %0\n\tv_add_f32 %0, %0, %0\n\tv_add_f32 %0, %0, %0\n\tv_add_f32 %0, %0, %0" : "+v"(dmy)); }
 #endif
 #if WINO_EXP & 256
-                const float v0 = bq[pp & 1][0][0], v1 = bq[pp & 1][0][1], v2 = bq[pp & 1][1][0], v3 = bq[pp & 1][1][1];   // timing probe: no transform
+                const float v0 = bq[pp % (PD + 1)][0][0], v1 = bq[pp % (PD + 1)][0][1], v2 = bq[pp % (PD + 1)][1][0], v3 = bq[pp % (PD + 1)][1][1];   // timing probe: no transform
 #else
                 const float v0 = q01[0] - q23[0], v1 = q01[1] + q23[0], v2 = q23[0] - q01[1], v3 = q01[1] - q23[1];      // B^T d B, row a
 #endif
-#if WINO_EXP & 32
-                wait_a(a_ring[pp % W_RING], pp < W_RING);
-#else
                 if (pp >= W_RING) wait_a(a_ring[pp % W_RING], false);
                 else if (k > 0) wait_a(a_ring[pp % W_RING], true);           // k == 0: landed before the previous epilogue's stores
-#endif
                 acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_ring[pp % W_RING][0], v0, acc[0], 0, 0, 0);
                 acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_ring[pp % W_RING][1], v1, acc[1], 0, 0, 0);
                 acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_ring[pp % W_RING][2], v2, acc[2], 0, 0, 0);
@@ -391,7 +387,7 @@ __global__ __launch_bounds__(512, 4) void conv2d_wino(ConvParams p) {
                 r1 = ld2(q.f.residual, pix0_b + (unsigned)c1 * cstride_b);
             }
             __syncthreads();
-            if (rnd == 0 && !(WINO_EXP & 32)) {
+            if (rnd == 0) {
                 // The U words of the next tile's first pairs (requested during the last chunk) must be home before this tile's
                 // stores enter the queue: vmcnt counts stores as well, so the counted waits of the next tile's first pairs
                 // would otherwise wait for these stores to reach memory.  They have had the whole round to arrive.

@@ -189,6 +189,19 @@ int pg_modconv_dcoefs(const float* w, const float* styles, float* dcoefs,
 int pg_instance_norm_stats(const float* x, float* mean, float* rstd, int NC, int64_t HW, float eps, void* stream);
 int pg_spade_norm(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
                   float* y, int NC, int64_t HW, void* stream);
+
+/* Garment-feature assembly of the synthesis network (get_spade_feat + the merge, networks.py:2253-2276, 2311-2316) in two
+ * launches instead of ~60 elementwise ones.  feat_*: [N,C,H,W]; masks: [N,1,2H,2W], sampled at the even pixels; with
+ *   m = mask > 0.9,  v = m && denorm_mask > 0.9,  r = m - v,  count[n] = sum_p v,  sums[n,c] = sum_p feat * v:
+ *   B   = feat * (1 - r) + sums / (count > 10 ? count : 256*256) * r
+ *   out = B_upper * m_upper + B_lower * m_lower
+ * pg_spade_masked_sums fills sums [N*C] and counts [N] of one branch. */
+int pg_spade_masked_sums(const float* feat, const float* mask, const float* denorm_mask, float* sums, float* counts,
+                         int N, int C, int H, int W, void* stream);
+int pg_spade_feat_assemble(const float* feat_upper, const float* feat_lower, const float* mask_upper, const float* mask_lower,
+                           const float* denorm_mask_upper, const float* denorm_mask_lower,
+                           const float* sums_upper, const float* sums_lower, const float* counts_upper, const float* counts_lower,
+                           float* out, int N, int C, int H, int W, void* stream);
 int pg_conv2d_abi_version(void);
 
 #ifdef __cplusplus

@@ -161,6 +161,59 @@ __global__ __launch_bounds__(256) void spade_norm_scalar_kernel(const float* __r
     }
 }
 
+
+// ------------------------------------------------------------------ SPADE feature assembly (networks.py:2253-2276, 2311-2316)
+// Garment features of the upper / lower branch are inpainted where the predicted parsing mask exceeds the warped-garment
+// mask, then merged:  with m = (mask[2y,2x] > 0.9), v = m && (denorm_mask[2y,2x] > 0.9), r = m - v
+//   B   = feat * (1 - r) + (sum_p feat*v / count) * r          count = sum_p v, replaced by 256*256 when <= 10
+//   out = B_upper * m_upper + B_lower * m_lower
+// Kernel 1: per (n, c) plane the masked sum (and per n the count); kernel 2: the blend.  Masks are [N,1,2H,2W], read at the
+// even pixels ("nearest" down-sampling by 2); every product with a 0/1 mask is exact, so the only rounding differences to
+// the unfused composition are in the order of the plane sum.
+__global__ __launch_bounds__(IN_THREADS) void spade_masked_sums_kernel(const float* __restrict__ feat, const float* __restrict__ mask, const float* __restrict__ dmask,
+                                                                       float* __restrict__ sums, float* __restrict__ counts, int C, int H, int W) {
+    __shared__ float red[IN_THREADS / 64];
+    const int n = blockIdx.x / C;
+    const float* fp = feat + (int64_t)blockIdx.x * H * W;
+    const float* mp = mask + (int64_t)n * 4 * H * W;
+    const float* dp = dmask + (int64_t)n * 4 * H * W;
+    float s = 0.f, cnt = 0.f;
+    for (int i = threadIdx.x; i < H * W; i += IN_THREADS) {
+        const int y = i / W, x = i - y * W;
+        const int64_t mi = (int64_t)(2 * y) * (2 * W) + 2 * x;
+        const float v = (mp[mi] > 0.9f && dp[mi] > 0.9f) ? 1.f : 0.f;
+        s += fp[i] * v;
+        cnt += v;
+    }
+    const float S = block_sum_1024(s, red), Cn = block_sum_1024(cnt, red);
+    if (threadIdx.x == 0) {
+        sums[blockIdx.x] = S;
+        if (blockIdx.x % C == 0) counts[n] = Cn;
+    }
+}
+
+__global__ __launch_bounds__(256) void spade_feat_assemble_kernel(const float* __restrict__ fu, const float* __restrict__ fl,
+                                                                  const float* __restrict__ mu, const float* __restrict__ ml,
+                                                                  const float* __restrict__ du, const float* __restrict__ dl,
+                                                                  const float* __restrict__ su, const float* __restrict__ sl,
+                                                                  const float* __restrict__ cu, const float* __restrict__ cl,
+                                                                  float* __restrict__ out, int C, int H, int W) {
+    const int plane = blockIdx.x, n = plane / C;
+    const float nu = cu[n] > 10.f ? cu[n] : 65536.f, nl = cl[n] > 10.f ? cl[n] : 65536.f;      // the reference's literal 256 * 256
+    const float au = su[plane] / nu, al = sl[plane] / nl;
+    const int64_t pb = (int64_t)plane * H * W, mb = (int64_t)n * 4 * H * W;
+    for (int i = blockIdx.y * 256 + threadIdx.x; i < H * W; i += gridDim.y * 256) {
+        const int y = i / W, x = i - y * W;
+        const int64_t mi = mb + (int64_t)(2 * y) * (2 * W) + 2 * x;
+        const float m_u = mu[mi] > 0.9f ? 1.f : 0.f, m_l = ml[mi] > 0.9f ? 1.f : 0.f;
+        const float v_u = (m_u != 0.f && du[mi] > 0.9f) ? 1.f : 0.f, v_l = (m_l != 0.f && dl[mi] > 0.9f) ? 1.f : 0.f;
+        const float r_u = m_u - v_u, r_l = m_l - v_l;
+        const float b_u = fu[pb + i] * (1.f - r_u) + au * r_u;
+        const float b_l = fl[pb + i] * (1.f - r_l) + al * r_l;
+        out[pb + i] = b_u * m_u + b_l * m_l;
+    }
+}
+
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 }  // namespace
@@ -302,5 +355,29 @@ PG_EXPORT int pg_spade_norm(const float* x, const float* mean, const float* rstd
         hipLaunchKernelGGL(spade_norm_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, mean, rstd, gamma, beta, y, HW / 4, total / 4);
     else
         hipLaunchKernelGGL(spade_norm_scalar_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, mean, rstd, gamma, beta, y, HW, total);
+    return pg::launch_status();
+}
+
+PG_EXPORT int pg_spade_masked_sums(const float* feat, const float* mask, const float* denorm_mask, float* sums, float* counts,
+                                   int N, int C, int H, int W, void* stream) {
+    if (!feat || !mask || !denorm_mask || !sums || !counts || N <= 0 || C <= 0 || H <= 0 || W <= 0) return PG_ERR_INVALID_ARG;
+    if ((int64_t)H * W > 0x3fffffffLL) return PG_ERR_TOO_LARGE;
+    hipLaunchKernelGGL(spade_masked_sums_kernel, dim3((unsigned)(N * C)), dim3(IN_THREADS), 0, (hipStream_t)stream, feat, mask, denorm_mask, sums, counts, C, H, W);
+    return pg::launch_status();
+}
+
+PG_EXPORT int pg_spade_feat_assemble(const float* feat_upper, const float* feat_lower, const float* mask_upper, const float* mask_lower,
+                                     const float* denorm_mask_upper, const float* denorm_mask_lower,
+                                     const float* sums_upper, const float* sums_lower, const float* counts_upper, const float* counts_lower,
+                                     float* out, int N, int C, int H, int W, void* stream) {
+    if (!feat_upper || !feat_lower || !mask_upper || !mask_lower || !denorm_mask_upper || !denorm_mask_lower || !sums_upper || !sums_lower ||
+        !counts_upper || !counts_lower || !out || N <= 0 || C <= 0 || H <= 0 || W <= 0) return PG_ERR_INVALID_ARG;
+    if ((int64_t)H * W > 0x3fffffffLL) return PG_ERR_TOO_LARGE;
+    int chunks = (int)(((int64_t)H * W + 256 * 16 - 1) / (256 * 16));
+    if (chunks < 1) chunks = 1;
+    if (chunks > 64) chunks = 64;
+    hipLaunchKernelGGL(spade_feat_assemble_kernel, dim3((unsigned)(N * C), (unsigned)chunks), dim3(256), 0, (hipStream_t)stream,
+                       feat_upper, feat_lower, mask_upper, mask_lower, denorm_mask_upper, denorm_mask_lower,
+                       sums_upper, sums_lower, counts_upper, counts_lower, out, C, H, W);
     return pg::launch_status();
 }

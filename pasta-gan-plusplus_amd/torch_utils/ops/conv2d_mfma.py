@@ -73,6 +73,10 @@ def _init(plugin_name='conv2d_plugin'):
         lib.pg_conv2d_winograd_pack_weight.argtypes = [vp, vp, i, i, f, i, i, vp]
         lib.pg_conv2d_winograd_forward.restype = i
         lib.pg_conv2d_winograd_forward.argtypes = [vp, vp, vp, i, i, i, i, i, i, i, i, i, ctypes.POINTER(i64), ctypes.POINTER(Fusion), vp]
+        lib.pg_spade_masked_sums.restype = i
+        lib.pg_spade_masked_sums.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, vp]
+        lib.pg_spade_feat_assemble.restype = i
+        lib.pg_spade_feat_assemble.argtypes = [vp] * 11 + [i, i, i, i, vp]
         lib.pg_modconv_dcoefs.restype = i
         lib.pg_modconv_dcoefs.argtypes = [vp, vp, vp, i, i, i, i, f, vp]
         lib.pg_instance_norm_stats.restype = i
@@ -333,3 +337,25 @@ def spade_norm(x, mean, rstd, gamma, beta):
         st = lib.pg_spade_norm(nat.ptr(x), nat.ptr(mean), nat.ptr(rstd), nat.ptr(gamma), nat.ptr(beta), nat.ptr(y), n * c, h * w, nat.stream_of(x))
     nat.check(st, 'pg_spade_norm')
     return y
+
+
+def spade_feat_assemble(feat_upper, feat_lower, mask_upper, mask_lower, denorm_mask_upper, denorm_mask_lower):
+    """The masked-mean inpainting of both garment feature maps and their merge (networks.py:2253-2276, 2311-2316) as three
+    launches.  feat_*: [N,C,H,W]; the four masks: [N,1,2H,2W] (thresholded at 0.9 and sampled at the even pixels here)."""
+    lib = _init().lib
+    fu, fl = _f32c(feat_upper, 'feat_upper'), _f32c(feat_lower, 'feat_lower')
+    masks = [_f32c(m, 'mask') for m in (mask_upper, mask_lower, denorm_mask_upper, denorm_mask_lower)]
+    n, c, h, w = fu.shape
+    if fl.shape != fu.shape or any(tuple(m.shape) != (n, 1, 2 * h, 2 * w) for m in masks):
+        raise nat.NativeOpError('spade_feat_assemble: feat [N,C,H,W] x2 and masks [N,1,2H,2W] x4 expected')
+    mu, ml, du, dl = masks
+    sums = torch.empty([2, n * c], dtype=torch.float32, device=fu.device)
+    counts = torch.empty([2, n], dtype=torch.float32, device=fu.device)
+    out = torch.empty_like(fu)
+    with torch.cuda.device(fu.device):
+        st = nat.stream_of(fu)
+        nat.check(lib.pg_spade_masked_sums(nat.ptr(fu), nat.ptr(mu), nat.ptr(du), nat.ptr(sums[0]), nat.ptr(counts[0]), n, c, h, w, st), 'pg_spade_masked_sums')
+        nat.check(lib.pg_spade_masked_sums(nat.ptr(fl), nat.ptr(ml), nat.ptr(dl), nat.ptr(sums[1]), nat.ptr(counts[1]), n, c, h, w, st), 'pg_spade_masked_sums')
+        nat.check(lib.pg_spade_feat_assemble(nat.ptr(fu), nat.ptr(fl), nat.ptr(mu), nat.ptr(ml), nat.ptr(du), nat.ptr(dl), nat.ptr(sums[0]), nat.ptr(sums[1]),
+                                             nat.ptr(counts[0]), nat.ptr(counts[1]), nat.ptr(out), n, c, h, w, st), 'pg_spade_feat_assemble')
+    return out

@@ -19,6 +19,7 @@ Two execution routes, chosen per call:
 Both run only on the GPU; there is no CPU path.
 """
 
+import os
 import numpy as np
 import torch
 import torch.nn as nn
@@ -630,11 +631,18 @@ class SynthesisNetworkFull_v18(nn.Module):
 
         upper_mask = (parsing_index == 1).float() + (parsing_index == 4).float()
         lower_mask = (parsing_index == 2).float() + (parsing_index == 3).float()
-        spade_upper_feat = self.get_spade_feat(upper_mask.detach(), denorm_upper_mask, denorm_upper_input)
-        spade_lower_feat = self.get_spade_feat(lower_mask.detach(), denorm_lower_mask, denorm_lower_input)
-        upper_mask_256 = (_half_nearest(upper_mask) > 0.9).to(upper_mask.dtype)
-        lower_mask_256 = (_half_nearest(lower_mask) > 0.9).to(upper_mask.dtype)
-        spade_feat = spade_upper_feat * upper_mask_256 + spade_lower_feat * lower_mask_256
+        if _fast_ok(x_256, denorm_upper_input, denorm_lower_input, denorm_upper_mask, denorm_lower_mask) and denorm_upper_mask.dtype == torch.float32:
+            # inference route: encoder inputs as in get_spade_feat, then the inpainting + merge of both branches in three launches
+            mu, ml = (upper_mask > 0.9).float(), (lower_mask > 0.9).float()
+            feat_u = self.spade_encoder(denorm_upper_input * mu - (1 - mu))
+            feat_l = self.spade_encoder(denorm_lower_input * ml - (1 - ml))
+            spade_feat = conv2d_mfma.spade_feat_assemble(feat_u, feat_l, upper_mask, lower_mask, denorm_upper_mask, denorm_lower_mask)
+        else:
+            spade_upper_feat = self.get_spade_feat(upper_mask.detach(), denorm_upper_mask, denorm_upper_input)
+            spade_lower_feat = self.get_spade_feat(lower_mask.detach(), denorm_lower_mask, denorm_lower_input)
+            upper_mask_256 = (_half_nearest(upper_mask) > 0.9).to(upper_mask.dtype)
+            lower_mask_256 = (_half_nearest(lower_mask) > 0.9).to(upper_mask.dtype)
+            spade_feat = spade_upper_feat * upper_mask_256 + spade_lower_feat * lower_mask_256
 
         x_spade_256 = self.spade_b256_1(x_256, spade_feat)
         x_spade_256 = self.spade_b256_2(x_spade_256, spade_feat)

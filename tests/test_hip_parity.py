@@ -399,6 +399,35 @@ def test_conv2d_full_size_linearity_and_delta(algo, monkeypatch):
     assert same(ys[:, :, 1:, :-1], x1[:, :, :-1, 1:])
 
 
+@pytest.mark.parametrize('n,c,h,w,sparse', [(2, 8, 16, 16, False), (1, 128, 64, 48, False), (3, 5, 9, 7, True)])
+def test_spade_feat_assemble_vs_unfused_composition(n, c, h, w, sparse):
+    """pg_spade_masked_sums + pg_spade_feat_assemble against the reference's elementwise composition
+    (get_spade_feat, networks.py:2253-2276, and the merge, :2311-2316) evaluated on the CPU."""
+    from torch_utils.ops import conv2d_mfma
+    fu, fl = det_tensor(f'sfa.fu.{c}', [n, c, h, w]), det_tensor(f'sfa.fl.{c}', [n, c, h, w])
+    thr = 1.2 if sparse else 0.0                 # sparse: almost no valid pixels -> the count <= 10 branch (divide by 256 * 256)
+    mk = lambda name: (det_tensor(f'sfa.{name}.{c}', [n, 1, 2 * h, 2 * w]) > thr).float()
+    mu, ml, du, dl = mk('mu'), mk('ml') * (1 - mk('mu')), mk('du'), mk('dl')
+
+    def branch(feat, mask_512, denorm_mask):
+        mask_256 = (mask_512[:, :, ::2, ::2] > 0.9).float()
+        denorm_256 = (denorm_mask[:, :, ::2, ::2] > 0.9).float()
+        valid = ((mask_256 + denorm_256) == 2.0).float()
+        res = mask_256 - valid
+        vsum = torch.sum(feat * valid, dim=(2, 3), keepdim=True)
+        cnt = torch.sum(valid, dim=(2, 3), keepdim=True)
+        idx = (cnt > 10).float()
+        cnt = cnt * idx + (256 * 256) * (1 - idx)
+        return feat * (1 - res) + (vsum / cnt) * res, mask_256
+    bu, m_u = branch(fu, mu, du)
+    bl, m_l = branch(fl, ml, dl)
+    want = bu * m_u + bl * m_l
+    got = conv2d_mfma.spade_feat_assemble(fu.to(DEV), fl.to(DEV), mu.to(DEV), ml.to(DEV), du.to(DEV), dl.to(DEV))
+    close(got, want, 1e-5, 1e-6)
+    untouched = ((m_u + m_l) == 0).expand_as(want)
+    assert float(got.cpu()[untouched].abs().max()) == 0.0          # outside both masks the result is exactly zero
+
+
 def test_support_kernels_vs_oracle():
     from torch_utils.ops import conv2d_mfma
     from oracle import network_ref as NR

@@ -141,6 +141,8 @@ typedef struct pg_conv2d_fusion {
     /* SPADE combine mode (all three set, Cout = 2*C packed as alternating blocks of 32 gamma rows / 32 beta rows of the
        same channels): y[n,c] = (spade_x[n,c] - spade_mean[n,c]) * spade_rstd[n,c] * (1 + gamma[n,c]) + beta[n,c]
        (Spade_Norm_Block, networks.py:1715-1722); y and spade_x are [N, C, OH, OW] with the strides passed for y;
+       act / alpha / gain / clamp then apply to that result (the pre-activation of the Spade_Conv2dLayer consuming it,
+       networks.py:1627-1633); out_scale / noise / bias / residual are ignored in this mode;
        the other epilogue stages are not applied. */
     const float* spade_x;
     const float* spade_mean;    /* [N, C] */

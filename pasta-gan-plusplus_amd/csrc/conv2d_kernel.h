@@ -343,7 +343,9 @@ __global__ __launch_bounds__(256, 4) void conv2d_mfma(ConvParams p) {
                     const int o = pix_off[nt] + ((e_m0 >> 1) + r0) * cstride;
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
-                        const float v = (ex[j] - mu4[j]) * rs4[j] * (1.f + acc[0][nt][4 * kq + j]) + acc[G::MT - 1][nt][4 * kq + j];
+                        float v = (ex[j] - mu4[j]) * rs4[j] * (1.f + acc[0][nt][4 * kq + j]) + acc[G::MT - 1][nt][4 * kq + j];
+                        v = v > 0.f ? v : v * slope;                 // the consumer's pre-activation (Spade_Conv2dLayer), when folded in
+                        v = fminf(fmaxf(v * gain, -cl), cl);
                         if (pix_ok[nt]) p.y[o + j * cstride] = v;
                     }
                 }

@@ -407,7 +407,12 @@ __global__ __launch_bounds__(512, 4) void conv2d_wino(ConvParams p) {
                 // SPADE combine (networks.py:1715-1722): M-tile 0 rows are gamma, M-tile 1 rows the beta rows of the same 32
                 // channels:  y = (x - mean) * rstd * (1 + gamma) + beta
                 const float mu = ep_scale[chl], rs = ep_bias[chl];
-                store2(pix0_b + (unsigned)((e_m0 >> 1) + chl) * cstride_b, (r0 - mu) * rs * (yv[0] + 1.f) + yv[1], true);
+                f32x2 v = (r0 - mu) * rs * (yv[0] + 1.f) + yv[1];
+                if (!plain_tail) {                                           // the consumer's pre-activation (Spade_Conv2dLayer) folded in
+#pragma unroll
+                    for (int e = 0; e < 2; e++) v[e] = __builtin_amdgcn_fmed3f((v[e] > 0.f ? v[e] : v[e] * slope) * gain, -cl, cl);
+                }
+                store2(pix0_b + (unsigned)((e_m0 >> 1) + chl) * cstride_b, v, true);
             } else {
 #pragma unroll
                 for (int kk = 0; kk < 2; kk++) {

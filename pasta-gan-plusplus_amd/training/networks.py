@@ -301,6 +301,11 @@ class Spade_Conv2dLayer(_ConvBase):
     def __init__(self, in_channels, out_channels, kernel_size, bias=True, activation='relu', **kw):
         super().__init__(in_channels, out_channels, kernel_size, bias=bias, activation=activation, **kw)
 
+    def pre_activation(self, gain=1):
+        """The bias-free pre-activation of forward() as epilogue arguments for the producer of its input."""
+        return dict(act=self.activation, alpha=bias_act.activation_funcs[self.activation].def_alpha, gain=self.act_gain * gain,
+                    clamp=self.conv_clamp * gain if self.conv_clamp is not None else None)
+
     def forward(self, x, gain=1, no_act=False, post_act='linear', residual=None):
         act_gain = self.act_gain * gain
         act_clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
@@ -333,8 +338,11 @@ class Spade_Norm_Block(nn.Module):
         self.param_free_norm = nn.InstanceNorm2d(norm_channels, affine=False)
         self._cache = _PackCache()
 
-    def forward(self, x, denorm_feats):
+    def forward(self, x, denorm_feats, post=None):
+        """`post` (private): dict(act, alpha, gain, clamp) -- the pre-activation of the one Spade_Conv2dLayer consuming the
+        result (networks.py:1627-1633), applied here so that the consumer runs without a prologue."""
         if _fast_ok(x, denorm_feats, self.conv_mlp.weight):
+            post = post or {}
             mean, rstd = conv2d_mfma.instance_norm_stats(x, eps=self.param_free_norm.eps)
             actv = self.conv_mlp(denorm_feats, no_act=True, post_act='relu')     # conv + ReLU in one launch
             g, b = self.conv_gamma, self.conv_beta
@@ -344,10 +352,12 @@ class Spade_Norm_Block(nn.Module):
                 wg = conv2d_mfma.use_winograd(3, 3, 1, 2 * c, actv.shape[1])
                 packed = self._cache.get(('gamma_beta', wg), [g.weight, b.weight],
                                          lambda: conv2d_mfma.pack_spade_gamma_beta(g.weight, b.weight, g.weight_gain, b.weight_gain, winograd=wg))
-                return conv2d_mfma.conv2d_forward(actv, packed, 2 * c, 3, 3, pad=(g.padding, g.padding), spade=(x, mean, rstd), winograd=wg)
+                return conv2d_mfma.conv2d_forward(actv, packed, 2 * c, 3, 3, pad=(g.padding, g.padding), spade=(x, mean, rstd), winograd=wg, **post)
             gamma = g(actv, no_act=True)
             beta = b(actv, no_act=True)
-            return conv2d_mfma.spade_norm(x, mean, rstd, gamma, beta)
+            y = conv2d_mfma.spade_norm(x, mean, rstd, gamma, beta)
+            return bias_act.bias_act(y, act=post['act'], alpha=post['alpha'], gain=post['gain'], clamp=post['clamp']) if post else y
+        assert post is None
         normalized = self.param_free_norm(x)
         actv = self.conv_mlp_act(self.conv_mlp(denorm_feats, no_act=True))
         gamma = self.conv_gamma(actv, no_act=True)
@@ -371,6 +381,12 @@ class Spade_ResBlockV4_512(nn.Module):
 
     def forward(self, x, denorm_feat):
         x = self.conv(x, no_act=True)
+        if _fast_ok(x, denorm_feat, self.conv0.weight) and all(l.bias is None and l.activation in conv2d_mfma.FUSED_ACTS for l in (self.skip, self.conv0, self.conv1)):
+            # inference route: each SPADE output feeds exactly one convolution, so that convolution's pre-activation is applied
+            # where the SPADE output is produced and the convolutions run without a prologue
+            y = self.skip(self.spade_skip(x, denorm_feat, post=self.skip.pre_activation(SQRT_HALF)), no_act=True)
+            x = self.conv0(self.spade0(x, denorm_feat, post=self.conv0.pre_activation()), no_act=True)
+            return self.conv1(self.spade1(x, denorm_feat, post=self.conv1.pre_activation(SQRT_HALF)), no_act=True, residual=y)
         y = self.skip(self.spade_skip(x, denorm_feat), gain=SQRT_HALF)
         x = self.conv0(self.spade0(x, denorm_feat))
         return self.conv1(self.spade1(x, denorm_feat), gain=SQRT_HALF, residual=y)

@@ -120,7 +120,20 @@ __global__ __launch_bounds__(IN_THREADS) void instance_norm_stats_kernel(const f
     const float K = xp[0];
     float s = 0.f, q = 0.f;
     if ((HW % 4 == 0) && aligned16(xp)) {
-        for (int64_t i = threadIdx.x; i < HW / 4; i += IN_THREADS) {
+        const int64_t n4 = HW / 4;
+        int64_t i = threadIdx.x;
+        for (; i + 3 * IN_THREADS < n4; i += 4 * IN_THREADS) {        // four 16-byte loads in flight per thread
+            f32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) v[u] = ((const f32x4*)xp)[i + u * IN_THREADS];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const float a = v[u][0] - K, b = v[u][1] - K, c = v[u][2] - K, d = v[u][3] - K;
+                s += (a + b) + (c + d);
+                q += (a * a + b * b) + (c * c + d * d);
+            }
+        }
+        for (; i < n4; i += IN_THREADS) {
             const f32x4 v = ((const f32x4*)xp)[i];
             const float a = v[0] - K, b = v[1] - K, c = v[2] - K, d = v[3] - K;
             s += (a + b) + (c + d);
@@ -170,20 +183,53 @@ __global__ __launch_bounds__(256) void spade_norm_scalar_kernel(const float* __r
 // Kernel 1: per (n, c) plane the masked sum (and per n the count); kernel 2: the blend.  Masks are [N,1,2H,2W], read at the
 // even pixels ("nearest" down-sampling by 2); every product with a 0/1 mask is exact, so the only rounding differences to
 // the unfused composition are in the order of the plane sum.
+// even elements of 8 consecutive mask floats (row 2y, columns 2x .. 2x+7) thresholded at 0.9
+__device__ __forceinline__ f32x4 even_mask4(const float* __restrict__ row8) {
+    const f32x4 a = ((const f32x4*)row8)[0], b = ((const f32x4*)row8)[1];
+    f32x4 m;
+    m[0] = a[0] > 0.9f ? 1.f : 0.f; m[1] = a[2] > 0.9f ? 1.f : 0.f; m[2] = b[0] > 0.9f ? 1.f : 0.f; m[3] = b[2] > 0.9f ? 1.f : 0.f;
+    return m;
+}
+
 __global__ __launch_bounds__(IN_THREADS) void spade_masked_sums_kernel(const float* __restrict__ feat, const float* __restrict__ mask, const float* __restrict__ dmask,
-                                                                       float* __restrict__ sums, float* __restrict__ counts, int C, int H, int W) {
+                                                                       float* __restrict__ sums, float* __restrict__ counts, int C, int H, int W, int vec) {
     __shared__ float red[IN_THREADS / 64];
     const int n = blockIdx.x / C;
     const float* fp = feat + (int64_t)blockIdx.x * H * W;
     const float* mp = mask + (int64_t)n * 4 * H * W;
     const float* dp = dmask + (int64_t)n * 4 * H * W;
     float s = 0.f, cnt = 0.f;
-    for (int i = threadIdx.x; i < H * W; i += IN_THREADS) {
-        const int y = i / W, x = i - y * W;
-        const int64_t mi = (int64_t)(2 * y) * (2 * W) + 2 * x;
-        const float v = (mp[mi] > 0.9f && dp[mi] > 0.9f) ? 1.f : 0.f;
-        s += fp[i] * v;
-        cnt += v;
+    if (vec) {                                   // W % 4 == 0, 16-byte aligned planes: 4 pixels per step, two steps in flight
+        const int W4 = W / 4, n4 = H * W4;
+        for (int i0 = threadIdx.x; i0 < n4; i0 += 2 * IN_THREADS) {
+            f32x4 f[2], m[2], d[2];
+            bool ok[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int i = i0 + u * IN_THREADS;
+                ok[u] = i < n4;
+                const int ic = ok[u] ? i : 0;
+                const int y = ic / W4, x4 = ic - y * W4;
+                const int64_t mi = (int64_t)(2 * y) * (2 * W) + 8 * x4;
+                f[u] = ((const f32x4*)fp)[ic];
+                m[u] = even_mask4(mp + mi);
+                d[u] = even_mask4(dp + mi);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; u++)
+                if (ok[u]) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) { const float v = m[u][k] * d[u][k]; s += f[u][k] * v; cnt += v; }
+                }
+        }
+    } else {
+        for (int i = threadIdx.x; i < H * W; i += IN_THREADS) {
+            const int y = i / W, x = i - y * W;
+            const int64_t mi = (int64_t)(2 * y) * (2 * W) + 2 * x;
+            const float v = (mp[mi] > 0.9f && dp[mi] > 0.9f) ? 1.f : 0.f;
+            s += fp[i] * v;
+            cnt += v;
+        }
     }
     const float S = block_sum_1024(s, red), Cn = block_sum_1024(cnt, red);
     if (threadIdx.x == 0) {
@@ -197,11 +243,30 @@ __global__ __launch_bounds__(256) void spade_feat_assemble_kernel(const float* _
                                                                   const float* __restrict__ du, const float* __restrict__ dl,
                                                                   const float* __restrict__ su, const float* __restrict__ sl,
                                                                   const float* __restrict__ cu, const float* __restrict__ cl,
-                                                                  float* __restrict__ out, int C, int H, int W) {
+                                                                  float* __restrict__ out, int C, int H, int W, int vec) {
     const int plane = blockIdx.x, n = plane / C;
     const float nu = cu[n] > 10.f ? cu[n] : 65536.f, nl = cl[n] > 10.f ? cl[n] : 65536.f;      // the reference's literal 256 * 256
     const float au = su[plane] / nu, al = sl[plane] / nl;
     const int64_t pb = (int64_t)plane * H * W, mb = (int64_t)n * 4 * H * W;
+    if (vec) {
+        const int W4 = W / 4, n4 = H * W4;
+        for (int i = blockIdx.y * 256 + threadIdx.x; i < n4; i += gridDim.y * 256) {
+            const int y = i / W4, x4 = i - y * W4;
+            const int64_t mi = mb + (int64_t)(2 * y) * (2 * W) + 8 * x4;
+            const f32x4 a = ((const f32x4*)(fu + pb))[i], b = ((const f32x4*)(fl + pb))[i];
+            const f32x4 m_u = even_mask4(mu + mi), m_l = even_mask4(ml + mi), d_u = even_mask4(du + mi), d_l = even_mask4(dl + mi);
+            f32x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const float r_u = m_u[k] - m_u[k] * d_u[k], r_l = m_l[k] - m_l[k] * d_l[k];
+                const float b_u = a[k] * (1.f - r_u) + au * r_u;
+                const float b_l = b[k] * (1.f - r_l) + al * r_l;
+                o[k] = b_u * m_u[k] + b_l * m_l[k];
+            }
+            ((f32x4*)(out + pb))[i] = o;
+        }
+        return;
+    }
     for (int i = blockIdx.y * 256 + threadIdx.x; i < H * W; i += gridDim.y * 256) {
         const int y = i / W, x = i - y * W;
         const int64_t mi = mb + (int64_t)(2 * y) * (2 * W) + 2 * x;
@@ -362,7 +427,8 @@ PG_EXPORT int pg_spade_masked_sums(const float* feat, const float* mask, const f
                                    int N, int C, int H, int W, void* stream) {
     if (!feat || !mask || !denorm_mask || !sums || !counts || N <= 0 || C <= 0 || H <= 0 || W <= 0) return PG_ERR_INVALID_ARG;
     if ((int64_t)H * W > 0x3fffffffLL) return PG_ERR_TOO_LARGE;
-    hipLaunchKernelGGL(spade_masked_sums_kernel, dim3((unsigned)(N * C)), dim3(IN_THREADS), 0, (hipStream_t)stream, feat, mask, denorm_mask, sums, counts, C, H, W);
+    const int vec = (W % 4 == 0 && pg::aligned16(feat) && pg::aligned16(mask) && pg::aligned16(denorm_mask)) ? 1 : 0;
+    hipLaunchKernelGGL(spade_masked_sums_kernel, dim3((unsigned)(N * C)), dim3(IN_THREADS), 0, (hipStream_t)stream, feat, mask, denorm_mask, sums, counts, C, H, W, vec);
     return pg::launch_status();
 }
 
@@ -373,11 +439,13 @@ PG_EXPORT int pg_spade_feat_assemble(const float* feat_upper, const float* feat_
     if (!feat_upper || !feat_lower || !mask_upper || !mask_lower || !denorm_mask_upper || !denorm_mask_lower || !sums_upper || !sums_lower ||
         !counts_upper || !counts_lower || !out || N <= 0 || C <= 0 || H <= 0 || W <= 0) return PG_ERR_INVALID_ARG;
     if ((int64_t)H * W > 0x3fffffffLL) return PG_ERR_TOO_LARGE;
+    const int vec = (W % 4 == 0 && pg::aligned16(feat_upper) && pg::aligned16(feat_lower) && pg::aligned16(out) && pg::aligned16(mask_upper) && pg::aligned16(mask_lower) &&
+                     pg::aligned16(denorm_mask_upper) && pg::aligned16(denorm_mask_lower)) ? 1 : 0;
     int chunks = (int)(((int64_t)H * W + 256 * 16 - 1) / (256 * 16));
     if (chunks < 1) chunks = 1;
     if (chunks > 64) chunks = 64;
     hipLaunchKernelGGL(spade_feat_assemble_kernel, dim3((unsigned)(N * C), (unsigned)chunks), dim3(256), 0, (hipStream_t)stream,
                        feat_upper, feat_lower, mask_upper, mask_lower, denorm_mask_upper, denorm_mask_lower,
-                       sums_upper, sums_lower, counts_upper, counts_lower, out, C, H, W);
+                       sums_upper, sums_lower, counts_upper, counts_lower, out, C, H, W, vec);
     return pg::launch_status();
 }

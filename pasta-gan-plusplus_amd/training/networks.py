@@ -338,12 +338,13 @@ class Spade_Norm_Block(nn.Module):
         self.param_free_norm = nn.InstanceNorm2d(norm_channels, affine=False)
         self._cache = _PackCache()
 
-    def forward(self, x, denorm_feats, post=None):
+    def forward(self, x, denorm_feats, post=None, stats=None):
         """`post` (private): dict(act, alpha, gain, clamp) -- the pre-activation of the one Spade_Conv2dLayer consuming the
-        result (networks.py:1627-1633), applied here so that the consumer runs without a prologue."""
+        result (networks.py:1627-1633), applied here so that the consumer runs without a prologue.  `stats` (private):
+        (mean, rstd) of x when the caller already has them (two norm blocks of a res-block normalise the same tensor)."""
         if _fast_ok(x, denorm_feats, self.conv_mlp.weight):
             post = post or {}
-            mean, rstd = conv2d_mfma.instance_norm_stats(x, eps=self.param_free_norm.eps)
+            mean, rstd = stats if stats is not None else conv2d_mfma.instance_norm_stats(x, eps=self.param_free_norm.eps)
             actv = self.conv_mlp(denorm_feats, no_act=True, post_act='relu')     # conv + ReLU in one launch
             g, b = self.conv_gamma, self.conv_beta
             c = int(g.weight.shape[0])
@@ -357,7 +358,7 @@ class Spade_Norm_Block(nn.Module):
             beta = b(actv, no_act=True)
             y = conv2d_mfma.spade_norm(x, mean, rstd, gamma, beta)
             return bias_act.bias_act(y, act=post['act'], alpha=post['alpha'], gain=post['gain'], clamp=post['clamp']) if post else y
-        assert post is None
+        assert post is None and stats is None
         normalized = self.param_free_norm(x)
         actv = self.conv_mlp_act(self.conv_mlp(denorm_feats, no_act=True))
         gamma = self.conv_gamma(actv, no_act=True)
@@ -384,8 +385,10 @@ class Spade_ResBlockV4_512(nn.Module):
         if _fast_ok(x, denorm_feat, self.conv0.weight) and all(l.bias is None and l.activation in conv2d_mfma.FUSED_ACTS for l in (self.skip, self.conv0, self.conv1)):
             # inference route: each SPADE output feeds exactly one convolution, so that convolution's pre-activation is applied
             # where the SPADE output is produced and the convolutions run without a prologue
-            y = self.skip(self.spade_skip(x, denorm_feat, post=self.skip.pre_activation(SQRT_HALF)), no_act=True)
-            x = self.conv0(self.spade0(x, denorm_feat, post=self.conv0.pre_activation()), no_act=True)
+            assert self.spade_skip.param_free_norm.eps == self.spade0.param_free_norm.eps
+            stats = conv2d_mfma.instance_norm_stats(x, eps=self.spade0.param_free_norm.eps)      # spade_skip and spade0 normalise the same x
+            y = self.skip(self.spade_skip(x, denorm_feat, post=self.skip.pre_activation(SQRT_HALF), stats=stats), no_act=True)
+            x = self.conv0(self.spade0(x, denorm_feat, post=self.conv0.pre_activation(), stats=stats), no_act=True)
             return self.conv1(self.spade1(x, denorm_feat, post=self.conv1.pre_activation(SQRT_HALF)), no_act=True, residual=y)
         y = self.skip(self.spade_skip(x, denorm_feat), gain=SQRT_HALF)
         x = self.conv0(self.spade0(x, denorm_feat))

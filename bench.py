@@ -214,7 +214,7 @@ def main():
         except (OSError, KeyError, ValueError):
             pass
         roofline = dict(bound='mfma',
-                        kernel=('conv2d_wino<XF,VEC> (Winograd F(2x2,3x3) stride-1 3x3 convolution, v_mfma_f32_32x32x2_f32)' if wino else
+                        kernel=('conv2d_wino<MODE,VEC> (Winograd F(2x2,3x3) stride-1 3x3 convolution, v_mfma_f32_32x32x2_f32)' if wino else
                                 'conv2d_mfma<3,3,1,BM,4,XF> (3x3 stride-1 implicit GEMM, v_mfma_f32_32x32x2_f32)'),
                         achieved=round(achieved, 2), peak=F32_MFMA_PEAK_TFLOPS, unit='TFLOP/s', frac=round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
                         traffic=traffic, flops_counted=('Winograd-domain GEMM flops = 4/9 of the direct-convolution flops' if wino else 'direct-convolution flops'),

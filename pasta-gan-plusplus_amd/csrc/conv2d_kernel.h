@@ -102,8 +102,8 @@ __global__ __launch_bounds__(256, 4) void conv2d_mfma(ConvParams p) {
     const int cin_loop = ((p.Cin + KC - 1) / KC) * KC;
     const int nchunks = cin_loop / KC;
     float* cs0 = smem + 2 * G::LDS_BUF;
-    float* ep_scale = cs0 + 2 * cin_loop;
-    float* ep_bias = ep_scale + BM;
+    float* ep0 = cs0 + 2 * cin_loop;           // epilogue constants of two consecutive tiles [2][BM + BM]: the next tile's are written
+                                               // (single-chunk tiles: immediately) while slow waves still read this tile's
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -257,6 +257,8 @@ __global__ __launch_bounds__(256, 4) void conv2d_mfma(ConvParams p) {
         bool has_next = false;
         int next = tile;
         const float* cs_cur = cs0 + par * cin_loop;
+        float* ep_scale = ep0 + par * 2 * BM;
+        float* ep_bias = ep_scale + BM;
         for (int k = 0; k < nchunks; k++, g++) {
             const int buf = g & 1;
             if (k + 1 < nchunks) {
@@ -380,7 +382,7 @@ int launch_conv_xf(const ConvParams& p0, hipStream_t s) {
     if (tiles > 0x7fffffffLL) return PG_ERR_TOO_LARGE;
     p.total_tiles = (int)tiles;
     const int cin_loop = ((p.Cin + KC - 1) / KC) * KC;
-    const size_t lds = G::LDS_BYTES + ((size_t)2 * cin_loop + 2 * BM) * sizeof(float);
+    const size_t lds = G::LDS_BYTES + ((size_t)2 * cin_loop + 4 * BM) * sizeof(float);
     if (lds > 160 * 1024) return PG_ERR_UNSUPPORTED;
     // persistent grid: as many workgroups as stay resident (4 per CU by registers; fewer if LDS-limited);
     // every workgroup walks tiles id, id + grid, ...

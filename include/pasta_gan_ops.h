@@ -167,6 +167,20 @@ int pg_conv2d_forward(const float* x, const float* packed_w, float* y,
                       const pg_conv2d_fusion* fusion, void* stream);
 
 /*
+ * Split-K form of pg_conv2d_forward for launches with too few output tiles to occupy the chip (the 8x8 .. 32x32 layers of the
+ * style branch: a workgroup's K loop is then a serial chain of 512 channels).  `ksplit` workgroups per tile each reduce
+ * Cin / ksplit channels into their own slice of `workspace` (ksplit * N * Cout * OH * OW floats, caller-provided: this library
+ * never allocates), then one elementwise pass sums the slices in fixed order and applies the fused epilogue.
+ * pg_conv2d_splitk_plan returns the ksplit this library would choose (1 = use pg_conv2d_forward); not for spade_x / x2 launches.
+ */
+int pg_conv2d_splitk_plan(int N, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride);
+int pg_conv2d_forward_splitk(const float* x, const float* packed_w, float* y,
+                             int N, int Cin, int H, int W, int Cout, int KH, int KW,
+                             int stride, int pad_y, int pad_x, int OH, int OW,
+                             const int64_t ystride[4], int out_step_y, int out_step_x, int out_off_y, int out_off_x,
+                             const pg_conv2d_fusion* fusion, float* workspace, int ksplit, void* stream);
+
+/*
  * Winograd F(2x2, 3x3) variant for KH = KW = 3, stride 1, out_step 1 (the bulk of the synthesis network): the same
  * result as pg_conv2d_forward up to fp32 summation order (~2e-6 of the output scale) with 2.25x fewer multiplies.
  * Weights are pre-transformed once (U = G g G^T, 16 * CinP * CoutP64 floats, CoutP64 = Cout rounded up to 64) by

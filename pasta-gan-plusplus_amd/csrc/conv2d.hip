@@ -279,6 +279,30 @@ __global__ __launch_bounds__(256) void spade_feat_assemble_kernel(const float* _
     }
 }
 
+// ------------------------------------------------------------------ split-K finish
+// y[n, co, oy*osy+ooy, ox*osx+oox] = epilogue(sum_z ws[z][n, co, oy, ox]): the fused epilogue of pg_conv2d_forward applied to the
+// sum of the partial convolutions (fixed order z = 0, 1, ...: deterministic, no atomics).
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ ws, float* __restrict__ y, int ksplit, int64_t slice,
+                                                            int N, int Cout, int OH, int OW, int64_t ys0, int64_t ys1, int64_t ys2, int64_t ys3,
+                                                            int osy, int osx, int ooy, int oox, pg_conv2d_fusion f) {
+    const int64_t total = (int64_t)N * Cout * OH * OW;
+    const float slope = f.act == PG_ACT_LINEAR ? 1.f : (f.act == PG_ACT_RELU ? 0.f : f.alpha);
+    const float cl = f.clamp >= 0.f ? f.clamp : __builtin_inff();
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int ox = (int)(i % OW), oy = (int)((i / OW) % OH), co = (int)((i / ((int64_t)OW * OH)) % Cout), n = (int)(i / ((int64_t)OW * OH * Cout));
+        float v = 0.f;
+        for (int z = 0; z < ksplit; z++) v += ws[(int64_t)z * slice + i];
+        if (f.out_scale) v *= f.out_scale[(int64_t)n * Cout + co];
+        if (f.noise) v += f.noise[n * f.noise_batch_stride + (int64_t)oy * OW + ox] * f.noise_gain;
+        if (f.bias) v += f.bias[co];
+        v = v > 0.f ? v : v * slope;
+        v = fminf(fmaxf(v * f.gain, -cl), cl);
+        const int64_t off = n * ys0 + co * ys1 + (int64_t)(oy * osy + ooy) * ys2 + (int64_t)(ox * osx + oox) * ys3;
+        if (f.residual) v += f.residual[off];
+        y[off] = v;
+    }
+}
+
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 }  // namespace
@@ -305,7 +329,7 @@ static int conv_forward(bool winograd, const float* x, const float* packed_w, fl
                         int N, int Cin, int H, int W, int Cout, int KH, int KW,
                         int stride, int pad_y, int pad_x, int OH, int OW,
                         const int64_t ystride[4], int out_step_y, int out_step_x, int out_off_y, int out_off_x,
-                        const pg_conv2d_fusion* fusion, void* stream) {
+                        const pg_conv2d_fusion* fusion, void* stream, float* workspace = nullptr, int ksplit = 1) {
     if (!x || !packed_w || !y || !ystride) return PG_ERR_INVALID_ARG;
     if (N <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0 || OH <= 0 || OW <= 0) return PG_ERR_INVALID_ARG;
     if (out_step_y < 1 || out_step_x < 1) return PG_ERR_INVALID_ARG;
@@ -316,6 +340,7 @@ static int conv_forward(bool winograd, const float* x, const float* packed_w, fl
         if (ext > 0x7fffffffLL || (int64_t)N * OH * OW > 0x7fffffffLL) return PG_ERR_TOO_LARGE;
     }
     ConvParams p;
+    p.ksplit = 1; p.kpart = 0; p.ws_slice = 0;
     p.x = x; p.wp = packed_w; p.y = y;
     p.N = N; p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout; p.CoutP = round_up(Cout, 32); p.OH = OH; p.OW = OW;
     p.pad_y = pad_y; p.pad_x = pad_x;
@@ -351,18 +376,39 @@ static int conv_forward(bool winograd, const float* x, const float* packed_w, fl
         p.CoutP = round_up(Cout, 64);
         return pgconv::launch_wino(p, s);
     }
-    if (stride == 1) {
-        if (KH == 3 && KW == 3) return pgconv::launch_k3s1(p, s);
-        if (KH == 1 && KW == 1) return pgconv::launch_k1s1(p, s);
-        if (KH == 2 && KW == 2) return pgconv::launch_k2x2(p, s);     // polyphase pieces of a stride-2 transposed 3x3
-        if (KH == 2 && KW == 1) return pgconv::launch_k2x1(p, s);
-        if (KH == 1 && KW == 2) return pgconv::launch_k1x2(p, s);
-        if (KH == 7 && KW == 7) return pgconv::launch_k7s1(p, s);
-    } else if (stride == 2) {
-        if (KH == 3 && KW == 3) return pgconv::launch_k3s2(p, s);
-        if (KH == 1 && KW == 1) return pgconv::launch_k1s2(p, s);
+    pg_conv2d_fusion tail = p.f;
+    const int64_t slice = (int64_t)N * Cout * OH * OW;
+    if (ksplit > 1) {
+        // split-K: `ksplit` workgroups per output tile each reduce a share of the input channels into their own workspace slice
+        // (prologue kept, epilogue off), then one elementwise pass sums the slices and applies the epilogue
+        const int kc = pgconv::kc_for(KH, KW, stride);
+        const int nchunks = round_up(Cin, kc) / kc;
+        if (!workspace || p.f.spade_x || p.f.x2 || nchunks % ksplit != 0 || slice * ksplit > 0x7fffffffLL) return PG_ERR_INVALID_ARG;
+        p.ksplit = ksplit; p.kpart = nchunks / ksplit * kc; p.ws_slice = slice;
+        p.y = workspace;
+        p.ys[0] = (int64_t)Cout * OH * OW; p.ys[1] = (int64_t)OH * OW; p.ys[2] = OW; p.ys[3] = 1;
+        p.osy = p.osx = 1; p.ooy = p.oox = 0;
+        p.f.out_scale = nullptr; p.f.noise = nullptr; p.f.bias = nullptr; p.f.residual = nullptr;
+        p.f.act = PG_ACT_LINEAR; p.f.gain = 1.f; p.f.clamp = -1.f;
     }
-    return PG_ERR_UNSUPPORTED;
+    int st = PG_ERR_UNSUPPORTED;
+    if (stride == 1) {
+        if (KH == 3 && KW == 3) st = pgconv::launch_k3s1(p, s);
+        else if (KH == 1 && KW == 1) st = pgconv::launch_k1s1(p, s);
+        else if (KH == 2 && KW == 2) st = pgconv::launch_k2x2(p, s);     // polyphase pieces of a stride-2 transposed 3x3
+        else if (KH == 2 && KW == 1) st = pgconv::launch_k2x1(p, s);
+        else if (KH == 1 && KW == 2) st = pgconv::launch_k1x2(p, s);
+        else if (KH == 7 && KW == 7) st = pgconv::launch_k7s1(p, s);
+    } else if (stride == 2) {
+        if (KH == 3 && KW == 3) st = pgconv::launch_k3s2(p, s);
+        else if (KH == 1 && KW == 1) st = pgconv::launch_k1s2(p, s);
+    }
+    if (st != PG_OK || ksplit <= 1) return st;
+    int64_t blocks = (slice + 255) / 256;
+    if (blocks > pg::kMaxStreamBlocks) blocks = pg::kMaxStreamBlocks;
+    hipLaunchKernelGGL(splitk_finish_kernel, dim3((unsigned)blocks), dim3(256), 0, s, workspace, y, ksplit, slice, N, Cout, OH, OW,
+                       ystride[0], ystride[1], ystride[2], ystride[3], out_step_y, out_step_x, out_off_y, out_off_x, tail);
+    return pg::launch_status();
 }
 
 PG_EXPORT int pg_conv2d_forward(const float* x, const float* packed_w, float* y,
@@ -372,6 +418,30 @@ PG_EXPORT int pg_conv2d_forward(const float* x, const float* packed_w, float* y,
                                 const pg_conv2d_fusion* fusion, void* stream) {
     return conv_forward(false, x, packed_w, y, N, Cin, H, W, Cout, KH, KW, stride, pad_y, pad_x, OH, OW,
                         ystride, out_step_y, out_step_x, out_off_y, out_off_x, fusion, stream);
+}
+
+PG_EXPORT int pg_conv2d_splitk_plan(int N, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride) {
+    if (N <= 0 || Cin <= 0 || OH <= 0 || OW <= 0 || Cout <= 0) return 1;
+    if (!((stride == 1 && ((KH == 3 && KW == 3) || (KH == 1 && KW == 1) || (KH == 2 && KW == 2) || (KH == 2 && KW == 1) || (KH == 1 && KW == 2) || (KH == 7 && KW == 7))) ||
+          (stride == 2 && ((KH == 3 && KW == 3) || (KH == 1 && KW == 1))))) return 1;
+    const int kc = pgconv::kc_for(KH, KW, stride);
+    const int nchunks = round_up(Cin, kc) / kc;
+    const int64_t tiles64 = (int64_t)N * ((OW + pgconv::TW - 1) / pgconv::TW) * ((OH + pgconv::TH - 1) / pgconv::TH) * ((round_up(Cout, 32) + 63) / 64);
+    if (tiles64 >= pg::kNumCU || nchunks < 8) return 1;            // enough tiles to occupy the chip, or too short a K loop to share
+    int best = 1;                                                  // largest divisor of nchunks that keeps >= 4 chunks per share and does not
+    for (int k = 2; k <= 16; k++)                                  // overshoot ~4 workgroups per CU
+        if (nchunks % k == 0 && nchunks / k >= 4 && tiles64 * k <= 4 * pg::kNumCU) best = k;
+    return best;
+}
+
+PG_EXPORT int pg_conv2d_forward_splitk(const float* x, const float* packed_w, float* y,
+                                       int N, int Cin, int H, int W, int Cout, int KH, int KW,
+                                       int stride, int pad_y, int pad_x, int OH, int OW,
+                                       const int64_t ystride[4], int out_step_y, int out_step_x, int out_off_y, int out_off_x,
+                                       const pg_conv2d_fusion* fusion, float* workspace, int ksplit, void* stream) {
+    if (ksplit < 1 || (ksplit > 1 && !workspace)) return PG_ERR_INVALID_ARG;
+    return conv_forward(false, x, packed_w, y, N, Cin, H, W, Cout, KH, KW, stride, pad_y, pad_x, OH, OW,
+                        ystride, out_step_y, out_step_x, out_off_y, out_off_x, fusion, stream, workspace, ksplit);
 }
 
 PG_EXPORT int64_t pg_conv2d_winograd_packed_size(int Cout, int Cin) {

@@ -1,5 +1,5 @@
 // conv2d_mfma<KH, KW, STRIDE, BM, KC> instantiations for geometry k2x2 (see conv2d_kernel.h).
 #include "conv2d_kernel.h"
 namespace pgconv {
-int launch_k2x2(const ConvParams& p, hipStream_t s) { return launch_bm<2, 2, 1, 8>(p, s); }
+int launch_k2x2(const ConvParams& p, hipStream_t s) { return launch_bm<2, 2, 1, kc_for(2, 2, 1)>(p, s); }
 }

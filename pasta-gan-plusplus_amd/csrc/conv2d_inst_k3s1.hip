@@ -1,5 +1,5 @@
 // conv2d_mfma<KH, KW, STRIDE, BM, KC> instantiations for geometry k3s1 (see conv2d_kernel.h).
 #include "conv2d_kernel.h"
 namespace pgconv {
-int launch_k3s1(const ConvParams& p, hipStream_t s) { return launch_bm<3, 3, 1, 4, true>(p, s); }
+int launch_k3s1(const ConvParams& p, hipStream_t s) { return launch_bm<3, 3, 1, kc_for(3, 3, 1), true>(p, s); }
 }

@@ -42,6 +42,8 @@ struct ConvParams {
     int osy, osx, ooy, oox;
     int tilesX, tilesY, mblocks, total_tiles;
     int in_xform;          // prologue bias/act/gain/clamp stage on
+    int ksplit, kpart;     // split-K: `ksplit` workgroups share one output tile, each reducing `kpart` input channels into its own
+    int64_t ws_slice;      // slice (ws_slice floats apart) of the partial-sum workspace that y then points to; 1 = off
     pg_conv2d_fusion f;
 };
 
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(256, 4) void conv2d_mfma(ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // LDS (one array): two staging buffers { xs[KC][IH_T][IW_T] (+pad), ws[KC][T][BM] (+pad) }, the prologue
     // scale of two consecutive tiles cs[2][cin_loop], the epilogue constants ep_scale/ep_bias[BM].
-    const int cin_loop = ((p.Cin + KC - 1) / KC) * KC;
+    const int cin_loop = p.ksplit > 1 ? p.kpart : ((p.Cin + KC - 1) / KC) * KC;      // channels this workgroup reduces per tile
     const int nchunks = cin_loop / KC;
     float* cs0 = smem + 2 * G::LDS_BUF;
     float* ep0 = cs0 + 2 * cin_loop;           // epilogue constants of two consecutive tiles [2][BM + BM]: the next tile's are written
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(256, 4) void conv2d_mfma(ConvParams p) {
     const int q8 = total >> 3, r8 = total & 7;
 
     // ---- state of the tile whose chunks are being requested
-    int n = 0, oy0 = 0, ox0 = 0, m0 = 0;
+    int n = 0, oy0 = 0, ox0 = 0, m0 = 0, cbeg = 0, zsl = 0;      // cbeg / zsl: first channel and workspace slice of a split-K share
     unsigned xoff[G::XPT];
     i32x4 xrsrc, xrsrc2;             // image n of x (channels [0, split)) and of the optional second source x2
     const int split = p.f.x2 ? p.f.cin_split : p.Cin;
@@ -127,13 +129,14 @@ __global__ __launch_bounds__(256, 4) void conv2d_mfma(ConvParams p) {
     auto prep_tile = [&](int tile, float* cs) {
         const int xcd = tile & 7;
         int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (tile >> 3);
+        if (p.ksplit > 1) { zsl = L % p.ksplit; L /= p.ksplit; cbeg = zsl * p.kpart; }     // the shares of one tile run side by side
         const int mb = L % p.mblocks; L /= p.mblocks;
         const int tx = L % p.tilesX; L /= p.tilesX;
         const int ty = L % p.tilesY;
         n = L / p.tilesY;
         oy0 = ty * TH; ox0 = tx * TW; m0 = mb * BM;
-        const float* in_scale = p.f.in_scale ? p.f.in_scale + (int64_t)n * p.Cin : nullptr;
-        for (int c = t; c < cin_loop; c += 256) cs[c] = (in_scale && c < p.Cin) ? in_scale[c] : 1.f;
+        const float* in_scale = p.f.in_scale ? p.f.in_scale + (int64_t)n * p.Cin + cbeg : nullptr;
+        for (int c = t; c < cin_loop; c += 256) cs[c] = (in_scale && cbeg + c < p.Cin) ? in_scale[c] : 1.f;
         // Opaque copy of the thread id: without it the compiler hoists the tile-independent index maths of every
         // element out of the persistent loop and keeps ~20 values live in VGPRs (spilling at 4 waves/SIMD).
         int tt = t;
@@ -148,10 +151,10 @@ __global__ __launch_bounds__(256, 4) void conv2d_mfma(ConvParams p) {
             xoff[i] = ok ? (unsigned)(c * HW + gy * p.W + gx) * 4u : 0x80000000u;
         }
         // raw buffer descriptor of image n: base, stride 0, num_records = bytes, flags as make_buffer_rsrc's 0x00020000
-        const uint64_t base = (uint64_t)(uintptr_t)(p.x + (int64_t)n * split * HW);
+        const uint64_t base = (uint64_t)(uintptr_t)(p.x + ((int64_t)n * split + cbeg) * HW);
         xrsrc[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)base);
         xrsrc[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(base >> 32) & 0xffff);
-        xrsrc[2] = split * HW * 4;
+        xrsrc[2] = (split - cbeg > 0 ? split - cbeg : 0) * HW * 4;
         xrsrc[3] = 0x00020000;
         xrsrc2 = xrsrc;
         if (p.f.x2) {                      // channels [split, Cin) come from x2: conv(cat([x, x2], 1)) without the copy
@@ -177,7 +180,7 @@ __global__ __launch_bounds__(256, 4) void conv2d_mfma(ConvParams p) {
 #pragma unroll
             for (int i = 0; i < G::XPT; i++) dma_dword(xrsrc2, xs_b + 1024u * i, xoff[i], soff);
         }
-        const float* wb = p.wp + (int64_t)c0 * G::T * p.CoutP + m0;
+        const float* wb = p.wp + (int64_t)(cbeg + c0) * G::T * p.CoutP + m0;
 #pragma unroll
         for (int i = 0; i < G::WPT; i++) {
             int e4 = t + 256 * i;
@@ -253,7 +256,7 @@ __global__ __launch_bounds__(256, 4) void conv2d_mfma(ConvParams p) {
 #pragma unroll
                 for (int k = 0; k < 16; k++) acc[mt][nt][k] = 0.f;
 
-        int e_n = n, e_oy0 = oy0, e_ox0 = ox0, e_m0 = m0;
+        int e_n = n, e_oy0 = oy0, e_ox0 = ox0, e_m0 = m0, e_z = zsl;
         bool has_next = false;
         int next = tile;
         const float* cs_cur = cs0 + par * cin_loop;
@@ -265,7 +268,7 @@ __global__ __launch_bounds__(256, 4) void conv2d_mfma(ConvParams p) {
                 issue_chunk((k + 1) * KC, buf ^ 1);        // that buffer was last read in the previous iteration (barrier below)
             } else {
                 // last chunk of this tile: publish its epilogue constants, then stage the next tile
-                e_n = n; e_oy0 = oy0; e_ox0 = ox0; e_m0 = m0;
+                e_n = n; e_oy0 = oy0; e_ox0 = ox0; e_m0 = m0; e_z = zsl;
                 if (p.f.spade_x) {                          // SPADE mode: per-(n, channel) mean / rstd of the normalised tensor
                     if (t < 32) {
                         const int ch = (e_m0 >> 1) + t;     // this tile's 32 output channels
@@ -312,7 +315,7 @@ __global__ __launch_bounds__(256, 4) void conv2d_mfma(ConvParams p) {
             pix_ok[nt] = oy < p.OH && ox < p.OW;
             const int oyc = oy < p.OH ? oy : p.OH - 1;
             nz[nt] = p.f.noise ? p.f.noise[(int)(e_n * p.f.noise_batch_stride) + oyc * p.OW + oxc] * p.f.noise_gain : 0.f;
-            pix_off[nt] = (int)((int64_t)e_n * p.ys[0] + (int64_t)(oyc * p.osy + p.ooy) * p.ys[2] + (int64_t)(oxc * p.osx + p.oox) * p.ys[3]);
+            pix_off[nt] = (int)((int64_t)e_z * p.ws_slice + (int64_t)e_n * p.ys[0] + (int64_t)(oyc * p.osy + p.ooy) * p.ys[2] + (int64_t)(oxc * p.osx + p.oox) * p.ys[3]);
         }
         constexpr int NG = G::NT * G::MT * 4;
         // fetch the extra operand of group g (SPADE mode: this tile's 32 output channels live at m0/2); channel clamped per
@@ -378,10 +381,11 @@ int launch_conv_xf(const ConvParams& p0, hipStream_t s) {
     p.tilesX = (p.OW + TW - 1) / TW;
     p.tilesY = (p.OH + TH - 1) / TH;
     p.mblocks = p.CoutP / BM;
-    const int64_t tiles = (int64_t)p.N * p.tilesX * p.tilesY * p.mblocks;
+    const int64_t tiles = (int64_t)p.N * p.tilesX * p.tilesY * p.mblocks * (p.ksplit > 1 ? p.ksplit : 1);
     if (tiles > 0x7fffffffLL) return PG_ERR_TOO_LARGE;
     p.total_tiles = (int)tiles;
-    const int cin_loop = ((p.Cin + KC - 1) / KC) * KC;
+    const int cin_loop = p.ksplit > 1 ? p.kpart : ((p.Cin + KC - 1) / KC) * KC;
+    if (p.ksplit > 1 && (p.kpart % KC != 0 || p.f.x2)) return PG_ERR_INVALID_ARG;
     const size_t lds = G::LDS_BYTES + ((size_t)2 * cin_loop + 4 * BM) * sizeof(float);
     if (lds > 160 * 1024) return PG_ERR_UNSUPPORTED;
     // persistent grid: as many workgroups as stay resident (4 per CU by registers; fewer if LDS-limited);
@@ -414,11 +418,17 @@ template <int KH, int KW, int S, int KC, bool XFORM = false>
 int launch_bm(const ConvParams& p, hipStream_t s) {
     // 64-cout tiles unless that leaves most of the chip idle (low-resolution layers: a handful of pixel tiles, latency-bound
     // K loops): 32-cout tiles double the number of workgroups
-    const int64_t tiles64 = (int64_t)p.N * ((p.OW + TW - 1) / TW) * ((p.OH + TH - 1) / TH) * (p.CoutP / 64);
+    const int64_t tiles64 = (int64_t)p.N * ((p.OW + TW - 1) / TW) * ((p.OH + TH - 1) / TH) * (p.CoutP / 64) * (p.ksplit > 1 ? p.ksplit : 1);
     if (p.CoutP % 64 == 0 && (tiles64 >= 2 * kNumCU || p.f.spade_x)) return launch_conv<KH, KW, S, 64, KC, XFORM>(p, s);
     return launch_conv<KH, KW, S, 32, KC, XFORM>(p, s);
 }
 
+
+// Input channels per LDS chunk of each geometry family (the instantiations below and the split-K planner share it).
+constexpr int kc_for(int kh, int kw, int stride) {
+    return stride == 1 ? (kh == 3 && kw == 3 ? 4 : kh == 1 && kw == 1 ? 16 : kh == 7 ? 2 : 8)      // 2x2, 2x1, 1x2: 8
+                       : (kh == 3 ? 2 : 8);
+}
 
 // One entry per geometry family, each compiled in its own translation unit (conv2d_inst_*.hip).
 int launch_k3s1(const ConvParams& p, hipStream_t s);

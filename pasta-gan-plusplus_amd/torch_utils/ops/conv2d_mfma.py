@@ -67,6 +67,10 @@ def _init(plugin_name='conv2d_plugin'):
         lib.pg_conv2d_pack_weight.argtypes = [vp, vp, i, i, i, i, f, i, i, vp]
         lib.pg_conv2d_forward.restype = i
         lib.pg_conv2d_forward.argtypes = [vp, vp, vp, i, i, i, i, i, i, i, i, i, i, i, i, ctypes.POINTER(i64), i, i, i, i, ctypes.POINTER(Fusion), vp]
+        lib.pg_conv2d_splitk_plan.restype = i
+        lib.pg_conv2d_splitk_plan.argtypes = [i] * 8
+        lib.pg_conv2d_forward_splitk.restype = i
+        lib.pg_conv2d_forward_splitk.argtypes = [vp, vp, vp, i, i, i, i, i, i, i, i, i, i, i, i, ctypes.POINTER(i64), i, i, i, i, ctypes.POINTER(Fusion), vp, i, vp]
         lib.pg_conv2d_winograd_packed_size.restype = i64
         lib.pg_conv2d_winograd_packed_size.argtypes = [i, i]
         lib.pg_conv2d_winograd_pack_weight.restype = i
@@ -219,9 +223,18 @@ def conv2d_forward(x, packed, cout, kh, kw, stride=1, pad=(0, 0), out_hw=None, y
             st = lib.pg_conv2d_winograd_forward(nat.ptr(x), nat.ptr(packed), nat.ptr(y), n, cin, h, w, cout, int(pad_y), int(pad_x),
                                                 int(oh), int(ow), nat.i64arr(y.stride()), ctypes.byref(fz), nat.stream_of(x))
         else:
-            st = lib.pg_conv2d_forward(nat.ptr(x), nat.ptr(packed), nat.ptr(y), n, cin, h, w, cout, kh, kw, int(stride), int(pad_y), int(pad_x),
-                                       int(oh), int(ow), nat.i64arr(y.stride()), int(out_step[0]), int(out_step[1]), int(out_off[0]), int(out_off[1]),
-                                       ctypes.byref(fz), nat.stream_of(x))
+            ksplit = 1
+            if spade is None and x2 is None and os.environ.get('PG_CONV_SPLITK', '1') != '0':
+                ksplit = lib.pg_conv2d_splitk_plan(n, cin, int(oh), int(ow), cout, kh, kw, int(stride))
+            if ksplit > 1:      # few output tiles (low-resolution layers): share each tile's K loop among `ksplit` workgroups
+                ws = torch.empty([ksplit * n * cout * int(oh) * int(ow)], dtype=torch.float32, device=x.device)
+                st = lib.pg_conv2d_forward_splitk(nat.ptr(x), nat.ptr(packed), nat.ptr(y), n, cin, h, w, cout, kh, kw, int(stride), int(pad_y), int(pad_x),
+                                                  int(oh), int(ow), nat.i64arr(y.stride()), int(out_step[0]), int(out_step[1]), int(out_off[0]), int(out_off[1]),
+                                                  ctypes.byref(fz), nat.ptr(ws), ksplit, nat.stream_of(x))
+            else:
+                st = lib.pg_conv2d_forward(nat.ptr(x), nat.ptr(packed), nat.ptr(y), n, cin, h, w, cout, kh, kw, int(stride), int(pad_y), int(pad_x),
+                                           int(oh), int(ow), nat.i64arr(y.stride()), int(out_step[0]), int(out_step[1]), int(out_off[0]), int(out_off[1]),
+                                           ctypes.byref(fz), nat.stream_of(x))
         if _timeline is not None:
             ev1.record()
             _timeline.append(((kh, kw, int(stride), 'winograd' if winograd else 'direct', f'N{n} {cin}->{cout} {h}x{w}' + (' spade' if spade is not None else '') + (' xf' if in_act != 'linear' else '') + (' mod' if in_scale is not None else '') + (' res' if residual is not None else '')), 2.0 * n * cout * oh * ow * cin * kh * kw, ev0, ev1))

@@ -344,6 +344,43 @@ def test_conv2d_winograd_rejects_what_it_cannot_do():
     assert not conv2d_mfma.use_winograd(3, 3, 1, 64, x2=x) and not conv2d_mfma.use_winograd(3, 3, 2, 64) and not conv2d_mfma.use_winograd(1, 1, 1, 64)
 
 
+@pytest.mark.parametrize('n,cin,cout,h,w,kh,kw,pad,step', [(8, 512, 512, 8, 8, 2, 2, 1, 2), (4, 512, 96, 16, 16, 1, 1, 0, 1), (2, 256, 512, 32, 32, 3, 3, 1, 1),
+                                                          (8, 512, 3, 16, 16, 1, 1, 0, 1), (3, 144, 40, 9, 13, 1, 2, 0, 2)])
+def test_conv2d_split_k_matches_single_pass(n, cin, cout, h, w, kh, kw, pad, step, monkeypatch):
+    """pg_conv2d_forward_splitk (low-resolution layers: several workgroups share a tile's K loop, fixed-order reduction + epilogue
+    pass) against the fp64 convolution and against the single-pass kernel, with every epilogue stage and a strided phase write."""
+    from torch_utils.ops import conv2d_mfma
+    import torch.nn.functional as F
+    lib = conv2d_mfma._init().lib
+    oh, ow = h + 2 * pad - kh + 1, w + 2 * pad - kw + 1
+    assert lib.pg_conv2d_splitk_plan(n, cin, oh, ow, cout, kh, kw, 1) > 1            # these shapes are the ones the planner splits
+    x = det_tensor(f'sk.x.{cin}.{h}', [n, cin, h, w])
+    wt = det_tensor(f'sk.w.{cin}.{cout}.{kh}{kw}', [cout, cin, kh, kw], scale=1 / math.sqrt(cin * kh * kw))
+    styles = det_tensor(f'sk.s.{cin}', [n, cin]) + 1
+    dco = det_tensor(f'sk.d.{cout}', [n, cout]).abs() + 0.5
+    b = det_tensor(f'sk.b.{cout}', [cout])
+    noise = det_tensor(f'sk.nz.{oh}', [oh, ow])
+    big = det_tensor(f'sk.big.{cout}.{oh}', [n, cout, oh * step + 1, ow * step + 1])       # residual == output buffer layout (phase write)
+    packed = conv2d_mfma.pack_weight(wt.to(DEV))
+    kw_ = dict(in_scale=styles.to(DEV), out_scale=dco.to(DEV), noise=noise.to(DEV), noise_gain=0.7, bias=b.to(DEV), act='lrelu', alpha=0.2,
+               gain=math.sqrt(2), clamp=3.0, out_hw=(oh, ow), out_step=(step, step), out_off=(step - 1, 0))
+    outs = {}
+    for mode in ('1', '0'):
+        monkeypatch.setenv('PG_CONV_SPLITK', mode)
+        y = big.to(DEV).clone()
+        conv2d_mfma.conv2d_forward(x.to(DEV), packed, cout, kh, kw, pad=(pad, pad), y=y, residual=y, **kw_)
+        outs[mode] = y
+    ref = F.conv2d((x * styles[:, :, None, None]).double(), wt.double(), padding=pad) * dco[:, :, None, None].double() + noise.double() * 0.7
+    ref = torch.clamp(F.leaky_relu(ref + b.double()[None, :, None, None], 0.2) * math.sqrt(2), -3.0, 3.0)
+    want = big.double().clone()
+    want[:, :, step - 1::step, 0::step][:, :, :oh, :ow] += ref
+    close(outs['1'], want, 1e-4, 1e-5 * scale_of(want))
+    close(outs['1'], outs['0'], 1e-4, 5e-5)               # two fp32 summation orders of a K = Cin*taps dot product
+    untouched = torch.ones_like(big, dtype=torch.bool)
+    untouched[:, :, step - 1::step, 0::step][:, :, :oh, :ow] = False
+    assert torch.equal(outs['1'].cpu()[untouched], big[untouched])                   # nothing outside the phase is written
+
+
 def test_conv2d_two_source_equals_concat():
     """x2 / cin_split: conv over channels of two tensors == conv of their concatenation (merge_conv, networks.py:2179-2181)."""
     from torch_utils.ops import conv2d_mfma

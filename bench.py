@@ -87,6 +87,44 @@ def cpu_baseline(max_seconds=40.0):
                        f'({", ".join(f"{t:.1f}s" for t in times)}), fastest reported; host reports {avail} logical CPUs')
 
 
+def run_generator(args, rank, world, dev, dist):
+    """BASELINE config 3 (secondary, --mode generator): full GeneratorFull_v20 inference -- pose encoder, garment-part style encoder
+    with its feature pyramid, mapping MLP, then the synthesis network -- at N=16 per GPU on synthetic tensors of the shapes test.py
+    feeds it (the patch-routing warp upstream is not part of this path)."""
+    from training import networks, replicas
+    n = args.batch if args.batch != BATCH_PER_GPU else 16
+    G = networks.GeneratorFull_v20(z_dim=0, c_dim=512, w_dim=512, img_resolution=512, img_channels=3, mapping_kwargs=dict(num_layers=1),
+                                   synthesis_kwargs=dict(channel_base=32768, channel_max=512, conv_clamp=256))
+    G = init_weights(G).to(dev).eval()
+    g = torch.Generator(device='cpu').manual_seed(200 + rank)
+    u = lambda *s: (torch.rand(*s, generator=g) * 2 - 1).to(dev)
+    inp = dict(z=torch.zeros([n, 0], device=dev), c=u(n, 45, 128, 128), retain=u(n, 6, 512, 512), pose=u(n, 5, 512, 512),
+               denorm_upper_input=u(n, 3, 512, 512), denorm_lower_input=u(n, 3, 512, 512),
+               denorm_upper_mask=(u(n, 1, 512, 512) > 0).float(), denorm_lower_mask=(u(n, 1, 512, 512) > 0).float())
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            out = G(**inp, noise_mode='const')
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = G(**inp, noise_mode='const')
+        barrier()
+    assert all(torch.isfinite(o).all() for o in out)
+    elapsed = replicas.max_over_ranks(time.perf_counter() - t0, device=dev)
+    if rank == 0:
+        print(json.dumps(dict(metric='512-res try-on images/sec (full generator: encoders + mapping + synthesis)', value=round(args.steps * n * world / elapsed, 3),
+                              unit='images/s', n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(1e3 * elapsed / args.steps, 2),
+                              higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
+                              config=dict(workload='BASELINE config 3: GeneratorFull_v20 forward (ConstEncoderNetwork + StyleEncoderNetworkV18 + MappingNetwork + '
+                                                   'SynthesisNetworkFull_v18), 512x512, fp32, eval, noise_mode=const, argmax parsing, random-init weights',
+                                          images_per_gpu_per_step=n, global_batch=n * world, parallelism=f'replicas x{world}'))), flush=True)
+
+
 def run_train(args, rank, world, dev, dist):
     """BASELINE config 4 (secondary, --mode train): iterations/s of the 8-phase fullbody G+D step incl. lazy R1, batch 4 per
     GPU, flat-bucket gradient all-reduce over RCCL.  VGG/contextual losses omitted (weights unavailable offline); the
@@ -142,7 +180,8 @@ def main():
     ap.add_argument('--batch', type=int, default=BATCH_PER_GPU, help='images per GPU per step (config 2: 8)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--conv-breakdown', default=None, metavar='CSV', help='also write the per-shape conv launch timeline of the timed steps')
-    ap.add_argument('--mode', choices=['synthesis', 'train'], default='synthesis', help="'synthesis' = the headline (config 2); 'train' = config 4 step")
+    ap.add_argument('--mode', choices=['synthesis', 'generator', 'train'], default='synthesis',
+                    help="'synthesis' = the headline (config 2); 'generator' = config 3 (encoders + mapping + synthesis, N=16); 'train' = config 4 step")
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -162,8 +201,8 @@ def main():
     from torch_utils.ops import conv2d_mfma
     from training import networks, replicas
 
-    if args.mode == 'train':
-        run_train(args, rank, world, dev, dist)
+    if args.mode in ('train', 'generator'):
+        (run_train if args.mode == 'train' else run_generator)(args, rank, world, dev, dist)
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()

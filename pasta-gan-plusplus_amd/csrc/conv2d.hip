@@ -333,7 +333,8 @@ static int conv_forward(bool winograd, const float* x, const float* packed_w, fl
     if (!x || !packed_w || !y || !ystride) return PG_ERR_INVALID_ARG;
     if (N <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0 || OH <= 0 || OW <= 0) return PG_ERR_INVALID_ARG;
     if (out_step_y < 1 || out_step_x < 1) return PG_ERR_INVALID_ARG;
-    if ((int64_t)Cin * H * W > 0x7fffffffLL || (int64_t)16 * H * W > 0x7fffffffLL) return PG_ERR_TOO_LARGE;
+    // one image of x is addressed through a 32-bit buffer descriptor: byte offsets (and the sentinel 2^31) must stay below 2^31
+    if ((int64_t)Cin * H * W * 4 > 0x7fffffffLL || (int64_t)16 * H * W * 4 > 0x7fffffffLL) return PG_ERR_TOO_LARGE;
     {   // the epilogue indexes y (and residual / noise) with 32-bit element offsets
         int64_t ext = 1 + (int64_t)(N - 1) * ystride[0] + (int64_t)(Cout - 1) * ystride[1] +
                       ((int64_t)(OH - 1) * out_step_y + out_off_y) * ystride[2] + ((int64_t)(OW - 1) * out_step_x + out_off_x) * ystride[3];

@@ -43,6 +43,24 @@ def test_c_abi_libraries_export_every_declared_symbol():
     assert conv.pg_conv2d_packed_size(64, 3, 7, 7) == 16 * 49 * 64
     assert conv.pg_conv2d_packed_size(3, 64, 1, 1) == 64 * 1 * 32
     assert conv.pg_conv2d_packed_size(0, 64, 1, 1) == 0
+    conv.pg_conv2d_winograd_packed_size.restype = ctypes.c_int64
+    assert conv.pg_conv2d_winograd_packed_size(70, 20) == 16 * 32 * 128            # [16 positions][CinP = 32][CoutP64 = 128]
+    # host-only: the split-K planner (no GPU touched)
+    plan = conv.pg_conv2d_splitk_plan
+    plan.restype = ctypes.c_int
+    assert plan(8, 512, 8, 8, 512, 1, 1, 1) > 1 and 32 % plan(8, 512, 8, 8, 512, 1, 1, 1) == 0     # 64 tiles for 256 CUs: split; divides the 32 chunks
+    assert plan(8, 512, 9, 9, 512, 2, 2, 1) > 1
+    assert plan(8, 64, 512, 512, 64, 3, 3, 1) == 1 and plan(8, 512, 8, 8, 512, 5, 5, 1) == 1 and plan(8, 24, 8, 8, 512, 1, 1, 1) == 1
+    # argument validation returns before any launch: sizes a 32-bit buffer descriptor cannot address are refused, not wrapped
+    i64x4 = (ctypes.c_int64 * 4)(1, 1, 1, 1)
+    dummy = ctypes.c_void_p(64)                                                      # non-null, never dereferenced on these paths
+    fwd = conv.pg_conv2d_forward
+    fwd.restype = ctypes.c_int
+    argt = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 12 + [ctypes.POINTER(ctypes.c_int64)] + [ctypes.c_int] * 4 + [ctypes.c_void_p] * 2
+    fwd.argtypes = argt
+    assert fwd(dummy, dummy, dummy, 1, 64, 4096, 4096, 8, 3, 3, 1, 1, 1, 4096, 4096, i64x4, 1, 1, 0, 0, None, None) == -3      # PG_ERR_TOO_LARGE: 4 GiB image
+    assert fwd(None, dummy, dummy, 1, 64, 8, 8, 8, 3, 3, 1, 1, 1, 8, 8, i64x4, 1, 1, 0, 0, None, None) == -1                    # PG_ERR_INVALID_ARG
+    assert fwd(dummy, dummy, dummy, 1, 64, 8, 8, 8, 3, 3, 1, 1, 1, 8, 8, i64x4, 0, 1, 0, 0, None, None) == -1
 
 
 def test_product_has_no_cpu_fallback():

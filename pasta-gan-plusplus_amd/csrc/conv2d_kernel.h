@@ -25,6 +25,9 @@
 
 #pragma once
 #include <type_traits>
+#ifndef DIRECT_EXP
+#define DIRECT_EXP 0     // dev ablations (tools/direct_variants.py; results wrong by design): 1 no output stores, 2 no halo DMA
+#endif
 #include "pg_act.h"
 
 namespace pgconv {
@@ -174,7 +177,7 @@ __global__ __launch_bounds__(256, 4) void conv2d_mfma(ConvParams p) {
         if (c0 < split) {                                   // wave-uniform: split is a multiple of the chunk size
             const int soff = c0 * HW * 4;
 #pragma unroll
-            for (int i = 0; i < G::XPT; i++) dma_dword(xrsrc, xs_b + 1024u * i, xoff[i], soff);
+            for (int i = 0; i < G::XPT; i++) if (!(DIRECT_EXP & 2)) dma_dword(xrsrc, xs_b + 1024u * i, xoff[i], soff);
         } else {
             const int soff = (c0 - split) * HW * 4;
 #pragma unroll
@@ -236,6 +239,7 @@ __global__ __launch_bounds__(256, 4) void conv2d_mfma(ConvParams p) {
     const float gain = p.f.gain;
     const float cl = p.f.clamp >= 0.f ? p.f.clamp : __builtin_inff();
     const float slope = act_slope(p.f.act, p.f.alpha);
+    const bool plain_tail = !p.f.noise && slope == 1.f && gain == 1.f && p.f.clamp < 0.f;      // wave-uniform
 
     // ---- persistent loop over this workgroup's tiles: one continuous stream of K chunks through the two LDS
     // buffers, one barrier per chunk.  While chunk g is multiplied, chunk g+1 is in flight -- the next chunk of
@@ -358,12 +362,21 @@ __global__ __launch_bounds__(256, 4) void conv2d_mfma(ConvParams p) {
                 const f32x4 sc4 = *(const f32x4*)(ep_scale + row0);
                 const f32x4 bi4 = *(const f32x4*)(ep_bias + row0);
                 const int o = pix_off[nt] + (e_m0 + row0) * cstride;
+                if (plain_tail) {                  // no noise, identity activation chain: one fma (+ the residual add) per value --
+                                                   // VALU instructions are matrix-pipe time, and a 1x1 layer has one output per 64 MACs
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    float v = acc[mt][nt][4 * kq + j] * sc4[j] + nz[nt] + bi4[j];
-                    v = v > 0.f ? v : v * slope;
-                    v = fminf(fmaxf(v * gain, -cl), cl) + ex[j];
-                    if (pix_ok[nt] && e_m0 + row0 + j < p.Cout) p.y[o + j * cstride] = v;
+                    for (int j = 0; j < 4; j++) {
+                        const float v = fmaf(acc[mt][nt][4 * kq + j], sc4[j], bi4[j]) + ex[j];
+                        if ((DIRECT_EXP & 1) ? (v == 12345.678f) : (pix_ok[nt] && e_m0 + row0 + j < p.Cout)) p.y[o + j * cstride] = v;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        float v = acc[mt][nt][4 * kq + j] * sc4[j] + nz[nt] + bi4[j];
+                        v = v > 0.f ? v : v * slope;
+                        v = fminf(fmaxf(v * gain, -cl), cl) + ex[j];
+                        if ((DIRECT_EXP & 1) ? (v == 12345.678f) : (pix_ok[nt] && e_m0 + row0 + j < p.Cout)) p.y[o + j * cstride] = v;
+                    }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);               // do not hoist later groups' reads (register pressure)

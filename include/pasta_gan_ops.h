@@ -220,6 +220,28 @@ int pg_spade_feat_assemble(const float* feat_upper, const float* feat_lower, con
                            float* out, int N, int C, int H, int W, void* stream);
 int pg_conv2d_abi_version(void);
 
+/* ------------------------------------------------------------------------
+ * patch_routing_plugin.so -- the perspective warps of the data loader's patch routing (training/dataset.py:2555-2700; there:
+ * cv2.warpPerspective / cv2.erode on the DataLoader thread).  8-bit interleaved (HWC) images.
+ *
+ * pg_warp_perspective_u8: `njobs` independent warps in one launch.  Each job maps a destination pixel (x, y) through `minv`
+ * (the INVERSE of the matrix cv2.warpPerspective is given, row major, double) with OpenCV's arithmetic: block-wise coordinate
+ * evaluation (block_w = the WarpPerspectiveInvoker block width for this destination size), 5 fractional bits, 15-bit bilinear
+ * weights, taps outside the source read 0 (INTER_LINEAR, BORDER_CONSTANT 0).  `jobs_device` lives in device memory.
+ * pg_patch_compose_u8: canvas[p] = erode8x8(mask[..., 0])[p] == 255 ? patch[p] : canvas[p] (and the same into canvas2 if given):
+ * the paste step of the de-normalisation (dataset.py:2624-2633); patch / canvas are HxWx3, mask HxWxmask_channels.
+ */
+typedef struct {
+    const unsigned char* src;
+    unsigned char*       dst;
+    int    src_h, src_w, dst_h, dst_w, channels, block_w;
+    double minv[9];
+} pg_warp_job;
+int pg_warp_perspective_u8(const pg_warp_job* jobs_device, int njobs, int max_dst_pixels, void* stream);
+int pg_patch_compose_u8(const unsigned char* patch, const unsigned char* mask, unsigned char* canvas, unsigned char* canvas2,
+                        int h, int w, int mask_channels, void* stream);
+int pg_patch_routing_abi_version(void);
+
 #ifdef __cplusplus
 }
 #endif

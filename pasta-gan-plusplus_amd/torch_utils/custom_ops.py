@@ -35,6 +35,7 @@ HIPCC_FLAGS = ['-O3', '-std=c++17', '-fPIC', '-fvisibility=hidden', f'--offload-
 PLUGIN_SOURCES = {
     'bias_act_plugin': ['bias_act.hip'],
     'upfirdn2d_plugin': ['upfirdn2d.hip'],
+    'patch_routing_plugin': ['patch_routing.hip'],
     'conv2d_plugin': ['conv2d.hip', 'conv2d_inst_k3s1.hip', 'conv2d_inst_k1s1.hip', 'conv2d_inst_k2x2.hip', 'conv2d_inst_k2x1.hip',
                       'conv2d_inst_k1x2.hip', 'conv2d_inst_k7s1.hip', 'conv2d_inst_k3s2.hip', 'conv2d_inst_k1s2.hip', 'conv2d_inst_wino.hip'],
 }

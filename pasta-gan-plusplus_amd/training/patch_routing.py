@@ -1,0 +1,305 @@
+"""Patch routing on the GPU: the 10-part perspective normalise / de-normalise of the reference's data loader
+(training/dataset.py:2373-2542 ``get_crop``, :2555-2700 ``normalize``).
+
+The reference does this per sample with ~44 ``cv2.warpPerspective`` calls, 15 ``cv2.erode`` calls and NumPy compositing on the
+DataLoader's main thread.  Here the keypoint geometry stays on the host (18 joints, 20 tiny 8x8 solves), and the pixel work runs
+as three batched launches of ``patch_routing_plugin`` (csrc/patch_routing.hip) plus the paste kernels:
+
+1. every image -> patch warp of the sample (up to 30 jobs, 128x128 patches) in one launch,
+2. every patch -> canvas warp (up to 30 jobs, 512x512) in one launch,
+3. the erode-and-paste of each part, in the reference's order (later parts overwrite earlier ones).
+
+Images are uint8 HxWx3 tensors on the GPU (NumPy arrays are uploaded); the five results have the reference's shapes and dtype.
+There is no CPU path.
+"""
+
+import ctypes
+
+import numpy as np
+import torch
+
+from torch_utils import custom_ops
+from torch_utils.ops import _native as nat
+
+ORDER = ['cnose', 'cneck', 'rshoulder', 'relbow', 'rwrist', 'lshoulder', 'lelbow', 'lwrist', 'rhip', 'rknee', 'rankle', 'lhip', 'lknee',
+         'lankle', 'reye', 'leye', 'rear', 'lear']
+BPARTS = [["rshoulder", "rhip", "lhip", "lshoulder"], ["lshoulder", "rshoulder", "cnose"], ["lshoulder", "lelbow"], ["lelbow", "lwrist"],
+          ["rshoulder", "relbow"], ["relbow", "rwrist"], ["lhip", "lknee"], ["lknee", "lankle"], ["rhip", "rknee"], ["rknee", "rankle"]]
+SLEEVE_PARTS = (2, 3, 4, 5)
+_J = {name: i for i, name in enumerate(ORDER)}
+
+
+class WarpJob(ctypes.Structure):
+    """Mirror of ``pg_warp_job`` (include/pasta_gan_ops.h)."""
+    _fields_ = [('src', ctypes.c_void_p), ('dst', ctypes.c_void_p), ('src_h', ctypes.c_int), ('src_w', ctypes.c_int), ('dst_h', ctypes.c_int),
+                ('dst_w', ctypes.c_int), ('channels', ctypes.c_int), ('block_w', ctypes.c_int), ('minv', ctypes.c_double * 9)]
+
+
+_plugin = None
+
+
+def _init():
+    global _plugin
+    if _plugin is None:
+        plugin = custom_ops.get_plugin('patch_routing_plugin')
+        lib = plugin.lib
+        lib.pg_warp_perspective_u8.restype = ctypes.c_int
+        lib.pg_warp_perspective_u8.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+        lib.pg_patch_compose_u8.restype = ctypes.c_int
+        lib.pg_patch_compose_u8.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 3 + [ctypes.c_void_p]
+        _plugin = plugin
+    return _plugin
+
+
+# ------------------------------------------------------------------------------------------- host geometry
+
+def get_perspective_transform(src, dst):
+    """cv2.getPerspectiveTransform: the homography through four point pairs (8 unknowns, m22 = 1)."""
+    src, dst = np.asarray(src, np.float64), np.asarray(dst, np.float64)
+    x, y, X, Y = src[:, 0], src[:, 1], dst[:, 0], dst[:, 1]
+    zero, one = np.zeros(4), np.ones(4)
+    a = np.concatenate([np.stack([x, y, one, zero, zero, zero, -x * X, -y * X], 1), np.stack([zero, zero, zero, x, y, one, -x * Y, -y * Y], 1)])
+    return np.append(np.linalg.solve(a, np.concatenate([X, Y])), 1.0).reshape(3, 3)
+
+
+def invert3x3(m):
+    """The adjugate formula cv::invert uses for 3x3 matrices (so the kernel sees the matrix OpenCV's warp would see)."""
+    m = np.asarray(m, np.float64)
+    c = lambda r0, c0, r1, c1: m[r0, c0] * m[r1, c1]
+    det = m[0, 0] * (c(1, 1, 2, 2) - c(1, 2, 2, 1)) - m[0, 1] * (c(1, 0, 2, 2) - c(1, 2, 2, 0)) + m[0, 2] * (c(1, 0, 2, 1) - c(1, 1, 2, 0))
+    if det == 0:
+        return np.zeros((3, 3))
+    d = 1.0 / det
+    return np.array([[(c(1, 1, 2, 2) - c(1, 2, 2, 1)) * d, (c(0, 2, 2, 1) - c(0, 1, 2, 2)) * d, (c(0, 1, 1, 2) - c(0, 2, 1, 1)) * d],
+                     [(c(1, 2, 2, 0) - c(1, 0, 2, 2)) * d, (c(0, 0, 2, 2) - c(0, 2, 2, 0)) * d, (c(0, 2, 1, 0) - c(0, 0, 1, 2)) * d],
+                     [(c(1, 0, 2, 1) - c(1, 1, 2, 0)) * d, (c(0, 1, 2, 0) - c(0, 0, 2, 1)) * d, (c(0, 0, 1, 1) - c(0, 1, 1, 0)) * d]])
+
+
+def _valid(joints, names):
+    return bool((joints[[_J[n] for n in names], 2] >= 0.1).all())
+
+
+_LEG_FALLBACK = {('lhip', 'lknee'): ('lhip', 'lknee', 0.85), ('rhip', 'rknee'): ('rhip', 'rknee', 0.85),
+                 ('lknee', 'lankle'): ('lknee', 'lankle', 0.80), ('rknee', 'rankle'): ('rknee', 'rankle', 0.80)}
+
+def get_crop(keypoints, bpart, wh, o_w, o_h, ar=1.0):
+    """Homographies (image -> patch, patch -> image) of one body part, or (None, None) when its joints are missing.
+    Same decisions as dataset.py:2373-2542: joint-confidence fall-backs, leg completion from the torso length, widened torso
+    and neck quadrilaterals, limb strips of aspect ratio `ar` with side-dependent widening."""
+    kp = np.asarray(keypoints)
+    names = list(bpart)
+    pts = lambda ns: np.float32(kp[[_J[n] for n in ns], :2])
+    quad = None
+    if not _valid(kp, names):
+        if tuple(names) in _LEG_FALLBACK:
+            root, missing, factor = _LEG_FALLBACK[tuple(names)]
+            if not _valid(kp, [root]) or not _valid(kp, ['lhip', 'rhip', 'cneck']):
+                return None, None
+            a = pts([root])[0]
+            torso = pts(['lhip', 'rhip', 'cneck'])
+            length = (np.linalg.norm(torso[2] - torso[1]) + np.linalg.norm(torso[2] - torso[0])) / 2
+            far = kp[_J[missing]]
+            if far[2] > 0:                                   # a low-confidence joint still gives the direction
+                b = a + length * ((far[0:2] - a) / np.linalg.norm(a - far[0:2])) * factor
+            else:
+                b = np.float32([a[0], a[1] + length * factor])
+            names, src = [root], np.float32([a, b])
+        elif names == ['lshoulder', 'rshoulder', 'cnose']:
+            names = ['lshoulder', 'rshoulder', 'rshoulder']
+            if not _valid(kp, names):
+                return None, None
+            src = pts(names)
+        else:
+            return None, None
+    else:
+        src = pts(names)
+
+    inside = lambda q: q[0] > 0 and q[1] > 0 and q[0] < o_w and q[1] < o_h
+
+    def widen(i_left, i_right, frac):                        # push two corners apart by `frac` of their distance, if that stays inside
+        seg = (src[i_right] - src[i_left]) / frac
+        lo, hi = src[i_left] - seg, src[i_right] + seg
+        if inside(lo):
+            src[i_left] = lo
+        if inside(hi):
+            src[i_right] = hi
+
+    if src.shape[0] == 4:
+        widen(1, 2, 4)
+        widen(0, 3, 5)
+        quad = src
+    elif src.shape[0] == 3:
+        widen(1, 0, 5)
+        seg = src[1] - src[0]
+        normal = np.array([-seg[1], seg[0]])
+        if normal[1] > 0.0:
+            normal = -normal
+        a, b, c, d = src[0] + normal, src[0], src[1], src[1] + normal
+        lift = ((c[1] + b[1]) / 2 - (a[1] + d[1]) / 2) / 2
+        a[1] += lift
+        d[1] += lift
+        quad = np.float32([d, c, b, a])
+    else:
+        seg = src[1] - src[0]
+        normal = np.array([-seg[1], seg[0]])
+        a, b, c, d = _limb_corners(src, normal, ar / 2.0, names)
+        quad = np.float32([a, d, c, b])
+
+    part_dst = np.float32(wh * np.float32([[0.0, 0.0], [0.0, 1.0], [1.0, 1.0], [1.0, 0.0]]))
+    return get_perspective_transform(quad, part_dst), get_perspective_transform(part_dst, quad)
+
+
+def _limb_corners(src, normal, alpha, names):
+    """Corners of a limb strip: +-alpha * normal around the bone, then side-dependent widening in the reference's order (:2513-2535)."""
+    a, b = src[0] + alpha * normal, src[0] - alpha * normal
+    c, d = src[1] - alpha * normal, src[1] + alpha * normal
+    for group, (up, down) in ((('rhip', 'rknee'), (1.0, None)), (('lhip', 'lknee'), (None, 1.0)),
+                              (('relbow', 'rwrist'), (0.45, 0.1)), (('lelbow', 'lwrist'), (0.1, 0.45))):
+        if any(g in names for g in group):
+            if up is not None:
+                a, d = a + alpha * normal * up, d + alpha * normal * up
+            if down is not None:
+                b, c = b - alpha * normal * down, c - alpha * normal * down
+    return a, b, c, d
+
+
+# ------------------------------------------------------------------------------------------- device work
+
+def _block_width(dst_h, dst_w):
+    bh0 = min(16, dst_h)
+    return min(1024 // bh0, dst_w)
+
+
+def _gpu_u8(img, device):
+    if isinstance(img, torch.Tensor):
+        t = img
+    else:
+        t = torch.from_numpy(np.ascontiguousarray(img))
+    if t.dtype != torch.uint8:
+        raise nat.NativeOpError('patch_routing: images must be uint8')
+    t = t.to(device)
+    nat.require_gpu(t, 'patch_routing')
+    return t.contiguous()
+
+
+def warp_perspective_batch(jobs):
+    """jobs: list of (src uint8 [H,W,C] GPU tensor, forward 3x3 matrix as cv2.warpPerspective takes it, (w, h)) -> list of outputs."""
+    lib = _init().lib
+    if not jobs:
+        return []
+    dev = jobs[0][0].device
+    table = (WarpJob * len(jobs))()
+    outs, keep = [], []
+    maxpix = 0
+    for k, (src, m, (w, h)) in enumerate(jobs):
+        src = src.contiguous()
+        c = src.shape[2] if src.ndim == 3 else 1
+        dst = torch.empty([h, w, c] if src.ndim == 3 else [h, w], dtype=torch.uint8, device=dev)
+        minv = invert3x3(m).reshape(9)
+        j = table[k]
+        j.src, j.dst = src.data_ptr(), dst.data_ptr()
+        j.src_h, j.src_w, j.dst_h, j.dst_w, j.channels, j.block_w = int(src.shape[0]), int(src.shape[1]), int(h), int(w), int(c), _block_width(h, w)
+        for i in range(9):
+            j.minv[i] = float(minv[i])
+        outs.append(dst)
+        keep.append(src)
+        maxpix = max(maxpix, h * w)
+    raw = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8).to(dev)       # the job table in device memory
+    with torch.cuda.device(dev):
+        st = lib.pg_warp_perspective_u8(raw.data_ptr(), len(jobs), int(maxpix), nat.stream_of(outs[0]))
+    nat.check(st, 'pg_warp_perspective_u8')
+    return outs
+
+
+def patch_compose_(canvas, patch, mask, canvas2=None):
+    """canvas[p] = patch[p] where erode8x8(mask[..., 0]) == 255 (also into canvas2), in place."""
+    lib = _init().lib
+    h, w = canvas.shape[:2]
+    mc = mask.shape[2] if mask.ndim == 3 else 1
+    with torch.cuda.device(canvas.device):
+        st = lib.pg_patch_compose_u8(patch.data_ptr(), mask.data_ptr(), canvas.data_ptr(), canvas2.data_ptr() if canvas2 is not None else None,
+                                     int(h), int(w), int(mc), nat.stream_of(canvas))
+    nat.check(st, 'pg_patch_compose_u8')
+    return canvas
+
+
+def normalize(upper_img, lower_img, upper_clothes_mask, lower_clothes_mask, sleeve_mask, clothes_keypoints, person_keypoints, box_factor, device='cuda'):
+    """The reference's ``normalize`` (dataset.py:2555-2700): returns (img [h,w,30], img_lower [h,w,15], denorm_upper_img,
+    denorm_upper_img_wo_sleeve, denorm_lower_img) as uint8 GPU tensors."""
+    dev = torch.device(device)
+    up, lo = _gpu_u8(upper_img, dev), _gpu_u8(lower_img, dev)
+    um, lm = _gpu_u8(upper_clothes_mask, dev), _gpu_u8(lower_clothes_mask, dev)
+    o_h, o_w = int(up.shape[0]), int(up.shape[1])
+    h, w = o_h // 2 ** box_factor, o_w // 2 ** box_factor
+    wh = np.expand_dims(np.array([w, h]), 0)
+    if sleeve_mask is not None:
+        sl = _gpu_u8(sleeve_mask, dev)
+        src_sleeve, src_body = (up * sl, um * sl), (up * (1 - sl), um * (1 - sl))
+    else:
+        src_sleeve = src_body = (up, um)
+
+    crops = []
+    for ii, bpart in enumerate(BPARTS):
+        ar = 0.5 if ii < 6 else 0.4
+        crops.append((get_crop(clothes_keypoints, bpart, wh, o_w, o_h, ar), get_crop(person_keypoints, bpart, wh, o_w, o_h, ar)))
+
+    # stage 1: image -> patch
+    jobs, slot = [], {}
+    for ii, ((c_m, _), (p_m, _)) in enumerate(crops):
+        if c_m is not None:
+            img_s, mask_s = src_sleeve if ii in SLEEVE_PARTS else src_body
+            slot[('img', ii)], slot[('mask', ii)] = len(jobs), len(jobs) + 1
+            jobs += [(img_s, c_m, (w, h)), (mask_s, c_m, (w, h))]
+        if (ii == 0 or ii >= 6) and p_m is not None:
+            slot[('img_lower', ii)], slot[('mask_lower', ii)] = len(jobs), len(jobs) + 1
+            jobs += [(lo, p_m, (w, h)), (lm, p_m, (w, h))]
+    out1 = warp_perspective_batch(jobs)
+    zeros = lambda: torch.zeros([h, w, 3], dtype=torch.uint8, device=dev)
+    get = lambda kind, ii: out1[slot[(kind, ii)]] if (kind, ii) in slot else zeros()
+    part_imgs = [get('img', ii) for ii in range(10)]
+    part_masks = [get('mask', ii) for ii in range(10)]
+    lower_ids = [0, 6, 7, 8, 9]
+    part_imgs_lower = [get('img_lower', ii) for ii in lower_ids]
+    part_masks_lower = [get('mask_lower', ii) for ii in lower_ids]
+
+    # stage 2: patch -> canvas
+    jobs, slot2 = [], {}
+    for ii, ((c_m, _), (p_m, p_inv)) in enumerate(crops):
+        if c_m is not None and p_inv is not None:
+            slot2[('up', ii)] = len(jobs)
+            jobs += [(part_imgs[ii], p_inv, (o_w, o_h)), (part_masks[ii], p_inv, (o_w, o_h))]
+        if (ii == 0 or ii >= 6) and p_m is not None and p_inv is not None:
+            k = lower_ids.index(ii)
+            slot2[('lo', ii)] = len(jobs)
+            jobs += [(part_imgs_lower[k], p_inv, (o_w, o_h)), (part_masks_lower[k], p_inv, (o_w, o_h))]
+    out2 = warp_perspective_batch(jobs)
+
+    # stage 3: erode + paste, in part order
+    denorm_upper = torch.zeros_like(up)
+    denorm_upper_wo_sleeve = torch.zeros_like(up)
+    denorm_lower = torch.zeros_like(up)
+    for ii in range(10):
+        if ('up', ii) in slot2:
+            k = slot2[('up', ii)]
+            patch_compose_(denorm_upper, out2[k], out2[k + 1], None if ii in SLEEVE_PARTS else denorm_upper_wo_sleeve)
+        if ('lo', ii) in slot2:
+            k = slot2[('lo', ii)]
+            patch_compose_(denorm_lower, out2[k], out2[k + 1])
+
+    # lower-garment parts give way to the upper garment; a missing sleeve is mirrored from the other side (:2655-2693)
+    for lower_i, upper_i in ((0, 0), (1, 6), (3, 8)):
+        keep = 1 - (part_masks[upper_i].to(torch.int32).sum(dim=2, keepdim=True) > 0).to(torch.uint8)
+        part_imgs_lower[lower_i] = part_imgs_lower[lower_i] * keep
+        part_masks_lower[lower_i] = part_masks_lower[lower_i] * keep
+    has = [bool(m.any()) for m in part_masks]
+    flip = lambda t: torch.flip(t, dims=[1])
+    if not has[2] and has[4]:
+        part_imgs[2], part_masks[2] = flip(part_imgs[4]), flip(part_masks[4])
+    elif not has[4] and has[2]:
+        part_imgs[4], part_masks[4] = flip(part_imgs[2]), flip(part_masks[2])
+    if not has[3] and has[5]:                                # as written in the reference: the image mirrored is part 3's own
+        part_imgs[3], part_masks[3] = flip(part_imgs[3]), flip(part_masks[5])
+    elif not has[5] and has[3]:
+        part_imgs[5], part_masks[5] = flip(part_imgs[5]), flip(part_masks[3])
+
+    return torch.cat(part_imgs, dim=2), torch.cat(part_imgs_lower, dim=2), denorm_upper, denorm_upper_wo_sleeve, denorm_lower

@@ -168,9 +168,14 @@ __global__ __launch_bounds__(512, 4) void conv2d_wino(ConvParams p) {
         else { asm volatile("global_load_dwordx4 %0, %1, %2 offset:3072" : "=v"(dst) : "v"(pa), "s"(p.wp)); pa += 4096u; }
     };
     const bool issues_dma = !VEC || wave < 4;
-    auto wait_a = [&](f32x4& g, bool dma_younger) {          // ties the wait to the registers: every use comes after it
-        if (dma_younger && issues_dma) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(g) : "n"(W_RING - 1 + NDMA));
-        else asm volatile("s_waitcnt vmcnt(%1)" : "+v"(g) : "n"(W_RING - 1));
+    auto wait_a = [&](f32x4& g, bool dma_younger, bool skip) {
+        // the s_waitcnt itself carries no register operand (inside a branch it would make the compiler merge register copies);
+        // the empty asm after it ties the ring word to the wait: volatile asms keep their order, every use of g comes after
+        if (!skip) {
+            if (dma_younger && issues_dma) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(W_RING - 1 + NDMA));
+            else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(W_RING - 1));
+        }
+        asm volatile("" : "+v"(g));
     };
 
     // The tail's uniforms (pointers, strides, activation constants) are re-read from the kernel-argument segment where they
@@ -292,8 +297,7 @@ __global__ __launch_bounds__(512, 4) void conv2d_wino(ConvParams p) {
 #else
                 const float v0 = q01[0] - q23[0], v1 = q01[1] + q23[0], v2 = q23[0] - q01[1], v3 = q01[1] - q23[1];      // B^T d B, row a
 #endif
-                if (pp >= W_RING) wait_a(a_ring[pp % W_RING], false);
-                else if (k > 0) wait_a(a_ring[pp % W_RING], true);           // k == 0: landed before the previous epilogue's stores
+                wait_a(a_ring[pp % W_RING], pp < W_RING, pp < W_RING && k == 0);   // first pairs of a tile: landed before the previous epilogue's stores
                 acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_ring[pp % W_RING][0], v0, acc[0], 0, 0, 0);
                 acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_ring[pp % W_RING][1], v1, acc[1], 0, 0, 0);
                 acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_ring[pp % W_RING][2], v2, acc[2], 0, 0, 0);

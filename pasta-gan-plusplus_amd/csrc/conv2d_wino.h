@@ -104,7 +104,8 @@ __global__ __launch_bounds__(512, 4) void conv2d_wino(ConvParams p) {
         n = L / p.tilesY;
         oy0 = ty * 2; ox0 = tx * 64; m0 = mb * 64;
         const float* in_scale = p.f.in_scale ? p.f.in_scale + (int64_t)n * p.Cin : nullptr;
-        for (int c = t; c < cin_loop; c += 512) cs[c] = ((in_scale && c < p.Cin) ? in_scale[c] : 1.f) * p.f.in_gain;     // host: in_gain defaults to 1
+        if (MODE != 0)                                 // the plain variant never reads the scale
+            for (int c = t; c < cin_loop; c += 512) cs[c] = ((in_scale && c < p.Cin) ? in_scale[c] : 1.f) * p.f.in_gain;     // host: in_gain defaults to 1
         int tt = t;
         asm volatile("" : "+v"(tt));                 // keep the index maths inside the tile loop (see conv2d_kernel.h)
         // gather map: element f of the buffer = (channel f / 288, LDS row (f % 288) / 72, LDS column f % 72)

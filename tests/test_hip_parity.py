@@ -328,6 +328,22 @@ def test_conv2d_winograd_vs_oracle_and_direct(n, cin, cout, h, w, pad):
     assert torch.equal(big[:, 2:2 + cout], yw) and float(big[:, :2].abs().max()) == 0 and float(big[:, 2 + cout:].abs().max()) == 0
 
 
+def test_conv2d_empty_batch_returns_empty_like_the_reference():
+    """F.conv2d / F.conv_transpose2d on an empty batch return an empty tensor of the right shape (what the reference's
+    conv2d_gradfix.py:35-43 forwards to); so do the drop-in ops, and gradients flow."""
+    from torch_utils.ops import conv2d_gradfix, conv2d_resample, upfirdn2d
+    w = det_tensor('empty.w', [6, 4, 3, 3]).to(DEV).requires_grad_(True)
+    x = torch.zeros([0, 4, 9, 9], device=DEV, requires_grad=True)
+    y = conv2d_gradfix.conv2d(x, w, padding=1)
+    assert tuple(y.shape) == (0, 6, 9, 9)
+    y.sum().backward()
+    assert float(w.grad.abs().max()) == 0.0
+    assert tuple(conv2d_gradfix.conv_transpose2d(x.detach(), w.detach().transpose(0, 1).contiguous(), stride=2).shape) == (0, 6, 19, 19)
+    f = upfirdn2d.setup_filter(C.FIR_1331).to(DEV)
+    one = conv2d_resample.conv2d_resample(torch.zeros([1, 4, 9, 9], device=DEV), w.detach(), f=f, down=2, padding=1)
+    assert tuple(conv2d_resample.conv2d_resample(x.detach(), w.detach(), f=f, down=2, padding=1).shape) == (0,) + tuple(one.shape[1:])
+
+
 def test_conv2d_winograd_rejects_what_it_cannot_do():
     from torch_utils.ops import conv2d_mfma
     from torch_utils.ops._native import NativeOpError

@@ -258,6 +258,7 @@ def main():
                         achieved=round(achieved, 2), peak=F32_MFMA_PEAK_TFLOPS, unit='TFLOP/s', frac=round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
                         traffic=traffic, flops_counted=('Winograd-domain GEMM flops = 4/9 of the direct-convolution flops' if wino else 'direct-convolution flops'),
                         direct_equivalent_tflops=round(dom_flops / max(dom_time, 1e-12) / 1e12, 2),
+                        direct_equivalent_frac=round(dom_flops / max(dom_time, 1e-12) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),    # SURVEY 8d count / peak (> 1: fewer multiplies than counted)
                         launches_per_step=len(dom) // max(args.steps, 1), avg_launch_ms=round(1e3 * dom_time / max(len(dom), 1), 4),
                         all_conv_direct_equivalent_tflops=round(sum(f for f, _ in allk) / max(sum(t for _, t in allk), 1e-12) / 1e12, 2),
                         conv_time_frac_of_step=round(sum(t for _, t in allk) / elapsed, 4),

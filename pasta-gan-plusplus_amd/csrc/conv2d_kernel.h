@@ -98,8 +98,11 @@ struct Geo {
 // run bias_act separately for those.
 __device__ __forceinline__ float act_slope(int act, float alpha) { return act == PG_ACT_LINEAR ? 1.f : (act == PG_ACT_RELU ? 0.f : alpha); }
 
-template <int KH, int KW, int S, int BM, int KC, bool XF>
+// MODE: 0 = plain input (the B operand goes from LDS to the MFMA untouched: VALU instructions cost matrix-pipe time),
+//       1 = per-(n, channel) input scale (modulated convolution), 2 = scale + pre-activation (XF).
+template <int KH, int KW, int S, int BM, int KC, int MODE>
 __global__ __launch_bounds__(256, 4) void conv2d_mfma(ConvParams p) {
+    constexpr bool XF = MODE == 2;
     typedef Geo<KH, KW, S, BM, KC> G;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // LDS (one array): two staging buffers { xs[KC][IH_T][IW_T] (+pad), ws[KC][T][BM] (+pad) }, the prologue
@@ -139,7 +142,8 @@ __global__ __launch_bounds__(256, 4) void conv2d_mfma(ConvParams p) {
         n = L / p.tilesY;
         oy0 = ty * TH; ox0 = tx * TW; m0 = mb * BM;
         const float* in_scale = p.f.in_scale ? p.f.in_scale + (int64_t)n * p.Cin + cbeg : nullptr;
-        for (int c = t; c < cin_loop; c += 256) cs[c] = (in_scale && cbeg + c < p.Cin) ? in_scale[c] : 1.f;
+        if (MODE != 0)
+            for (int c = t; c < cin_loop; c += 256) cs[c] = (in_scale && cbeg + c < p.Cin) ? in_scale[c] : 1.f;
         // Opaque copy of the thread id: without it the compiler hoists the tile-independent index maths of every
         // element out of the persistent loop and keeps ~20 values live in VGPRs (spilling at 4 waves/SIMD).
         int tt = t;
@@ -209,7 +213,7 @@ __global__ __launch_bounds__(256, 4) void conv2d_mfma(ConvParams p) {
         const float* b_base = smem + buf * G::LDS_BUF + half * G::PLANE + (wave * 2 * S) * G::IW_T + l31 * S;
 #pragma unroll
         for (int cp = 0; cp < KC / 2; cp++) {
-            const float sc = cs[c0 + 2 * cp + half] * in_gain;
+            const float sc = MODE != 0 ? cs[c0 + 2 * cp + half] * in_gain : 1.f;
 #pragma unroll
             for (int ky = 0; ky < KH; ky++) {
 #pragma unroll
@@ -219,7 +223,8 @@ __global__ __launch_bounds__(256, 4) void conv2d_mfma(ConvParams p) {
                     for (int mt = 0; mt < G::MT; mt++) a[mt] = a_base[((2 * cp) * G::T + ky * KW + kx) * BM + mt * 32];
 #pragma unroll
                     for (int nt = 0; nt < G::NT; nt++) {
-                        float v = b_base[(2 * cp) * G::PLANE + (nt * S + ky) * G::IW_T + kx] * sc;
+                        float v = b_base[(2 * cp) * G::PLANE + (nt * S + ky) * G::IW_T + kx];
+                        if (MODE != 0) v *= sc;
                         if (XF) v = __builtin_amdgcn_fmed3f(fmaxf(v, v * in_slope), -in_cl, in_cl);
                         b[nt] = v;
                     }
@@ -387,7 +392,7 @@ __global__ __launch_bounds__(256, 4) void conv2d_mfma(ConvParams p) {
     }
 }
 
-template <int KH, int KW, int S, int BM, int KC, bool XF>
+template <int KH, int KW, int S, int BM, int KC, int MODE>
 int launch_conv_xf(const ConvParams& p0, hipStream_t s) {
     typedef Geo<KH, KW, S, BM, KC> G;
     ConvParams p = p0;
@@ -409,11 +414,11 @@ int launch_conv_xf(const ConvParams& p0, hipStream_t s) {
     const int64_t blocks = tiles < (int64_t)kNumCU * per_cu ? tiles : (int64_t)kNumCU * per_cu;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv2d_mfma<KH, KW, S, BM, KC, XF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void*)conv2d_mfma<KH, KW, S, BM, KC, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv2d_mfma<KH, KW, S, BM, KC, XF>), dim3((unsigned)blocks), dim3(256), lds, s, p);
+    hipLaunchKernelGGL((conv2d_mfma<KH, KW, S, BM, KC, MODE>), dim3((unsigned)blocks), dim3(256), lds, s, p);
     return launch_status();
 }
 
@@ -421,10 +426,11 @@ int launch_conv_xf(const ConvParams& p0, hipStream_t s) {
 template <int KH, int KW, int S, int BM, int KC, bool XFORM>
 int launch_conv(const ConvParams& p, hipStream_t s) {
     if (p.in_xform) {
-        if constexpr (XFORM) return launch_conv_xf<KH, KW, S, BM, KC, true>(p, s);
+        if constexpr (XFORM) return launch_conv_xf<KH, KW, S, BM, KC, 2>(p, s);
         else return PG_ERR_UNSUPPORTED;
     }
-    return launch_conv_xf<KH, KW, S, BM, KC, false>(p, s);
+    if (p.f.in_scale) return launch_conv_xf<KH, KW, S, BM, KC, 1>(p, s);
+    return launch_conv_xf<KH, KW, S, BM, KC, 0>(p, s);
 }
 
 template <int KH, int KW, int S, int KC, bool XFORM = false>

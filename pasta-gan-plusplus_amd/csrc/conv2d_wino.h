@@ -34,7 +34,8 @@
 
 #ifndef WINO_EXP
 #define WINO_EXP 0       // dev ablations (tools/wino_variants.py; results wrong by design): 1 no U loads, 2 no LDS operand reads, 4 no tail,
-                         // 8 no halo DMA, 128 no chunk barrier, 256 no transform VALU, 512 eight extra independent VALU ops per channel pair
+                         // 8 no halo DMA, 128 no chunk barrier, 256 no transform VALU, 512 eight extra independent VALU ops per channel pair,
+                         // 1024 no LDS exchange in the tail, 2048 no output stores
 #endif
 
 namespace pgconv {
@@ -359,7 +360,9 @@ __global__ __launch_bounds__(512, 4) void conv2d_wino(ConvParams p) {
             return r;
         };
         auto store2 = [&](unsigned off_b, f32x2 v, bool chan_ok) {
-            if (full) {
+            if (WINO_EXP & 2048) {
+                if (v[0] == 12345.678f) *(f32x2*)((char*)q.y + off_b) = v;
+            } else if (full) {
                 *(f32x2*)((char*)q.y + off_b) = v;
             } else if (vec_store) {
                 if (ok0 && chan_ok) *(f32x2*)((char*)q.y + off_b) = v;
@@ -378,8 +381,12 @@ __global__ __launch_bounds__(512, 4) void conv2d_wino(ConvParams p) {
                 const float m0v = acc[0][4 * rnd + j], m1v = acc[1][4 * rnd + j], m2v = acc[2][4 * rnd + j], m3v = acc[3][4 * rnd + j];
                 float* dst = ex + ((2 * ta) * 16 + mt * 8 + 4 * half + j) * 32 + l31;
                 const float m12 = m1v + m2v;
+#if WINO_EXP & 1024
+                if (m0v + m12 == 12345.678f) dst[0] = (m1v - m2v) - m3v;
+#else
                 dst[0] = m0v + m12;                                          // q = 0:  M0 + M1 + M2
                 dst[16 * 32] = (m1v - m2v) - m3v;                            // q = 1:  M1 - M2 - M3
+#endif
             }
             // the extra operand of this round's outputs, requested before the barrier
             const int chl = 8 * rnd + c_l;                                   // cout within an M-tile
@@ -406,7 +413,11 @@ __global__ __launch_bounds__(512, 4) void conv2d_wino(ConvParams p) {
 #pragma unroll
                 for (int q = 0; q < 2; q++) {
                     const float* e3 = exr + (q * 16 + kk * 8) * 32;
+#if WINO_EXP & 1024
+                    yv[kk][q] = sg + (float)(kk + q);
+#else
                     yv[kk][q] = fmaf(sg, e3[2 * 16 * 32] + e3[4 * 16 * 32], e3[0]);
+#endif
                 }
             if (spade) {
                 // SPADE combine (networks.py:1715-1722): M-tile 0 rows are gamma, M-tile 1 rows the beta rows of the same 32

@@ -86,7 +86,7 @@ class _Conv2dMfma(torch.autograd.Function):
         kh, kw = int(weight.shape[2]), int(weight.shape[3])
         if not transposed:
             cout = int(weight.shape[0])
-            wg = conv2d_mfma.use_winograd(kh, kw, stride, cout, cin)
+            wg = conv2d_mfma.use_winograd(kh, kw, stride, cout, cin, pad=padding)
             packed = conv2d_mfma.pack_weight(weight, winograd=wg)
             y = conv2d_mfma.conv2d_forward(x, packed, cout, kh, kw, stride=stride, pad=padding, bias=bias, winograd=wg)
         else:

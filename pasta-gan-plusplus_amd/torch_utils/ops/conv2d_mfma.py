@@ -91,10 +91,12 @@ def _init(plugin_name='conv2d_plugin'):
     return _plugin
 
 
-def use_winograd(kh, kw, stride, cout, cin=None, x2=None):
+def use_winograd(kh, kw, stride, cout, cin=None, x2=None, pad=None):
     """Launch policy for 3x3 stride-1 convolutions: the Winograd F(2x2,3x3) kernel (csrc/conv2d_wino.h) unless the layer is
     too narrow to fill its 64-cout x 16-channel tiles.  PG_CONV_ALGO=direct|winograd overrides (A/B measurements)."""
     if (int(kh), int(kw), int(stride)) != (3, 3, 1) or x2 is not None:
+        return False
+    if pad is not None and not 0 <= int(pad[1]) <= 4:         # the kernel's LDS halo row starts 4 columns left of the tile
         return False
     mode = os.environ.get('PG_CONV_ALGO', 'auto')
     if mode == 'direct':

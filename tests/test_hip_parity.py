@@ -307,7 +307,8 @@ def test_conv2d_fused_prologue_epilogue_vs_oracle(winograd):
 
 
 @pytest.mark.parametrize('n,cin,cout,h,w,pad', [(1, 16, 64, 8, 64, 1), (2, 20, 70, 9, 71, 1), (1, 3, 3, 5, 7, 1), (2, 48, 128, 33, 130, 0),
-                                               (1, 128, 64, 16, 16, 2), (3, 17, 33, 1, 1, 1), (1, 40, 192, 2, 200, 1), (2, 1, 64, 31, 3, 1)])
+                                               (1, 128, 64, 16, 16, 2), (3, 17, 33, 1, 1, 1), (1, 40, 192, 2, 200, 1), (2, 1, 64, 31, 3, 1),
+                                               (1, 16, 64, 12, 68, 3), (2, 32, 96, 7, 130, 4)])
 def test_conv2d_winograd_vs_oracle_and_direct(n, cin, cout, h, w, pad):
     """pg_conv2d_winograd_forward: F(2x2,3x3) on ragged shapes (odd sizes, partial tiles, pad 0/1/2, Cin/Cout not multiples of
     the tile) against the fp64 convolution; its error must stay at the level of the direct kernel's."""
@@ -358,6 +359,13 @@ def test_conv2d_winograd_rejects_what_it_cannot_do():
         conv2d_mfma.conv2d_forward(x, conv2d_mfma.pack_weight(det_tensor('wgr.w2', [64, 32, 3, 3]).to(DEV), winograd=True), 64, 3, 3, pad=(1, 1),
                                    x2=x, winograd=True)                                          # two-source launches: direct kernel
     assert not conv2d_mfma.use_winograd(3, 3, 1, 64, x2=x) and not conv2d_mfma.use_winograd(3, 3, 2, 64) and not conv2d_mfma.use_winograd(1, 1, 1, 64)
+    assert conv2d_mfma.use_winograd(3, 3, 1, 64, 16, pad=(9, 4)) and not conv2d_mfma.use_winograd(3, 3, 1, 64, 16, pad=(1, 5))
+    with pytest.raises(NativeOpError):
+        conv2d_mfma.conv2d_forward(x, pw, 64, 3, 3, pad=(1, 5), winograd=True)                  # halo wider than the LDS row: direct kernel
+    from torch_utils.ops import conv2d_gradfix
+    import torch.nn.functional as F
+    y5 = conv2d_gradfix.conv2d(x, w3, padding=5)                                                 # the operator falls back by itself
+    close(y5, F.conv2d(x.double().cpu(), w3.double().cpu(), padding=5), 1e-4, 1e-5)
 
 
 @pytest.mark.parametrize('n,cin,cout,h,w,kh,kw,pad,step', [(8, 512, 512, 8, 8, 2, 2, 1, 2), (4, 512, 96, 16, 16, 1, 1, 0, 1), (2, 256, 512, 32, 32, 3, 3, 1, 1),

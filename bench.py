@@ -175,8 +175,8 @@ def run_train(args, rank, world, dev, dist):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=20)         # warm-up 5, time 20 iterations
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=BATCH_PER_GPU, help='images per GPU per step (config 2: 8)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--conv-breakdown', default=None, metavar='CSV', help='also write the per-shape conv launch timeline of the timed steps')

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 1
+#define PG_ABI_VERSION 2
 
 enum pg_dtype { PG_F32 = 0, PG_F16 = 1, PG_BF16 = 2, PG_F64 = 3 };
 
@@ -219,6 +219,72 @@ int pg_spade_feat_assemble(const float* feat_upper, const float* feat_lower, con
                            const float* sums_upper, const float* sums_lower, const float* counts_upper, const float* counts_lower,
                            float* out, int N, int C, int H, int W, void* stream);
 int pg_conv2d_abi_version(void);
+
+/* ------------------------------------------------------------------------
+ * 16-bit convolution (bf16 / fp16 storage, fp32 accumulation) on v_mfma_f32_32x32x16_{bf16,f16}: what cuDNN does behind
+ * conv2d_gradfix.py:35-43 for the reference's half-precision blocks (discriminator `use_fp16`, networks.py:444-523;
+ * the StyleGAN2 synthesis blocks with use_fp16, networks.py:2147-2194).  Activations are NHWC ("channels_last", the
+ * layout the reference's --nhwc option selects): x is [N, H, W, Cin] dense with Cin % 16 == 0.
+ *
+ * Weights are packed once per parameter version -- and, for a modulated convolution, once per style batch -- by
+ * pg_conv2d16_pack_weight into [ceil(Cin/32)*2][KH*KW][2][CoutP][8] (CoutP = Cout rounded up to 64; zero filled):
+ *   packed[n][ci/16][tap][(ci/8)&1][co][ci&7] = T(w[co][ci][tap] * scale * styles[n][ci] * dcoefs[n][co])
+ * with w float32 OIHW (IOHW when transpose_oi), optionally flipped in both spatial axes; styles [nsamples, Cin] /
+ * dcoefs [nsamples, Cout] float32 or NULL (= 1).  This is the reference's fused modulated convolution
+ * (networks.py:85-94: per-sample weights w * styles * dcoefs cast to the activation dtype) without the grouped-conv
+ * reshape.  `taps_y` / `taps_x` (NULL = all) select kernel rows / columns in the given order: the gather-form
+ * sub-kernels of a stride-2 transposed convolution.  pg_conv2d16_packed_size = 16-bit elements per sample.
+ */
+int64_t pg_conv2d16_packed_size(int Cout, int Cin, int KH, int KW);
+int pg_conv2d16_pack_weight(const float* w, void* packed, int dtype, int Cout, int Cin, int KH, int KW,
+                            const int* taps_y, int ntaps_y, const int* taps_x, int ntaps_x,
+                            float scale, int flip_hw, int transpose_oi,
+                            const float* styles, const float* dcoefs, int nsamples, void* stream);
+
+/* Fused epilogue of pg_conv2d16_forward:  v = acc * out_scale[n,co] + noise[n?,oy,ox] * noise_gain + bias[co];
+ * v = clamp(act(v) * gain);  y = T(v + residual).  Every pointer may be NULL; all vectors are float32. */
+typedef struct pg_conv2d16_fusion {
+    const float* out_scale;     /* [N, Cout] */
+    const float* noise;         /* [OH, OW] (noise_batch_stride 0) or [N, OH, OW] */
+    int64_t      noise_batch_stride;
+    float        noise_gain;
+    const float* bias;          /* [Cout] */
+    int          act;           /* pg_act: linear / relu / lrelu */
+    float        alpha;
+    float        gain;          /* 0 => 1 */
+    float        clamp;         /* < 0 = off */
+    const void*  residual;      /* dtype / strides of y */
+} pg_conv2d16_fusion;
+
+/*
+ * y[n, co, oy*osy + ooy, ox*osx + oox] = epilogue(sum_{ci,ky,kx} packed[n * w_sample_stride ...][ci][ky,kx][co] *
+ *                                                  x[n, oy*stride + ky - pad_y, ox*stride + kx - pad_x, ci])
+ * (KH, KW, stride) in {(3,3,1), (1,1,1), (2,2,1), (2,1,1), (1,2,1), (3,3,2)}.  w_sample_stride = 0 (shared weights) or
+ * pg_conv2d16_packed_size (per-sample weights).  y has dtype `out_dtype` -- the activation dtype or PG_F32 -- and strides
+ * ystride[4] = (n, c, y, x) in elements: channels_last 16-bit outputs with Cout % 8 == 0 are written as 16-byte vectors,
+ * anything else (a float32 NCHW image from a ToRGB layer, say) element by element.
+ */
+int pg_conv2d16_forward(const void* x, const void* packed, void* y, int dtype, int out_dtype,
+                        int N, int Cin, int H, int W, int Cout, int KH, int KW,
+                        int stride, int pad_y, int pad_x, int OH, int OW, int64_t w_sample_stride,
+                        const int64_t ystride[4], int out_step_y, int out_step_x, int out_off_y, int out_off_x,
+                        const pg_conv2d16_fusion* fusion, void* stream);
+
+/* Split-K form for launches with fewer output tiles than CUs: `ksplit` launches-worth of workgroups each reduce Cin/ksplit
+ * channels into float32 [ksplit][N][Cout][OH][OW] `workspace`; one pass sums the slices in fixed order, applies the
+ * epilogue and writes y.  pg_conv2d16_splitk_plan returns the ksplit this library would choose (1 = do not split). */
+int pg_conv2d16_splitk_plan(int N, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride);
+int pg_conv2d16_forward_splitk(const void* x, const void* packed, void* y, int dtype, int out_dtype,
+                               int N, int Cin, int H, int W, int Cout, int KH, int KW,
+                               int stride, int pad_y, int pad_x, int OH, int OW, int64_t w_sample_stride,
+                               const int64_t ystride[4], int out_step_y, int out_step_x, int out_off_y, int out_off_x,
+                               const pg_conv2d16_fusion* fusion, float* workspace, int ksplit, void* stream);
+
+/* 1x1 modulated convolution to a handful of output channels (ToRGB / parsing heads, networks.py:1957-1967) as a streaming
+ * dot product: y[n, o, p] = clamp(sum_c x[n, p, c] * w[o, c] * styles[n, c] + bias[o]) + skip[n, o, p], x 16-bit NHWC,
+ * w float32 [Cout, Cin] (already scaled by weight_gain), y / skip float32 NCHW; Cout <= 8, Cin % 8 == 0. */
+int pg_conv1x1_small16(const void* x, const float* w, const float* styles, const float* bias, const float* skip, float* y,
+                       int dtype, int N, int Cin, int64_t HW, int Cout, float clamp, void* stream);
 
 /* ------------------------------------------------------------------------
  * patch_routing_plugin.so -- the perspective warps of the data loader's patch routing (training/dataset.py:2555-2700; there:

@@ -163,14 +163,14 @@ int launch(const Params& p, hipStream_t stream) {
     if (vec_ok) {
         const int64_t nvec = p.sizeX / VEC;
         int64_t blocks = (nvec + block - 1) / block;
-        int grid = (int)(blocks < 1 ? 1 : (blocks > kMaxStreamBlocks ? kMaxStreamBlocks : blocks));
+        int grid = (int)(blocks < 1 ? 1 : (blocks > max_stream_blocks() ? max_stream_blocks() : blocks));
         if (!p.b || p.stepB % VEC == 0)
             hipLaunchKernelGGL((bias_act_kernel<T, A, G, VEC, true>), dim3(grid), dim3(block), 0, stream, p);
         else
             hipLaunchKernelGGL((bias_act_kernel<T, A, G, VEC, false>), dim3(grid), dim3(block), 0, stream, p);
     } else {
         int64_t blocks = (p.sizeX + block - 1) / block;
-        int grid = (int)(blocks > kMaxStreamBlocks ? kMaxStreamBlocks : blocks);
+        int grid = (int)(blocks > max_stream_blocks() ? max_stream_blocks() : blocks);
         hipLaunchKernelGGL((bias_act_kernel<T, A, G, 1, true>), dim3(grid), dim3(block), 0, stream, p);
     }
     return launch_status();

@@ -320,7 +320,7 @@ PG_EXPORT int pg_conv2d_pack_weight(const float* w, float* packed, int Cout, int
     const int CinP = round_up(Cin, 16), CoutP = round_up(Cout, 32);
     const int64_t total = (int64_t)CinP * KH * KW * CoutP;
     int64_t blocks = (total + 255) / 256;
-    if (blocks > pg::kMaxStreamBlocks) blocks = pg::kMaxStreamBlocks;
+    if (blocks > pg::max_stream_blocks()) blocks = pg::max_stream_blocks();
     hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, packed, Cout, Cin, KH, KW, CinP, CoutP, scale, flip_hw, transpose_oi);
     return pg::launch_status();
 }
@@ -406,7 +406,7 @@ static int conv_forward(bool winograd, const float* x, const float* packed_w, fl
     }
     if (st != PG_OK || ksplit <= 1) return st;
     int64_t blocks = (slice + 255) / 256;
-    if (blocks > pg::kMaxStreamBlocks) blocks = pg::kMaxStreamBlocks;
+    if (blocks > pg::max_stream_blocks()) blocks = pg::max_stream_blocks();
     hipLaunchKernelGGL(splitk_finish_kernel, dim3((unsigned)blocks), dim3(256), 0, s, workspace, y, ksplit, slice, N, Cout, OH, OW,
                        ystride[0], ystride[1], ystride[2], ystride[3], out_step_y, out_step_x, out_off_y, out_off_x, tail);
     return pg::launch_status();
@@ -428,10 +428,10 @@ PG_EXPORT int pg_conv2d_splitk_plan(int N, int Cin, int OH, int OW, int Cout, in
     const int kc = pgconv::kc_for(KH, KW, stride);
     const int nchunks = round_up(Cin, kc) / kc;
     const int64_t tiles64 = (int64_t)N * ((OW + pgconv::TW - 1) / pgconv::TW) * ((OH + pgconv::TH - 1) / pgconv::TH) * ((round_up(Cout, 32) + 63) / 64);
-    if (tiles64 >= pg::kNumCU || nchunks < 8) return 1;            // enough tiles to occupy the chip, or too short a K loop to share
+    if (tiles64 >= pg::num_cu() || nchunks < 8) return 1;            // enough tiles to occupy the chip, or too short a K loop to share
     int best = 1;                                                  // largest divisor of nchunks that keeps >= 4 chunks per share and does not
     for (int k = 2; k <= 16; k++)                                  // overshoot ~4 workgroups per CU
-        if (nchunks % k == 0 && nchunks / k >= 4 && tiles64 * k <= 4 * pg::kNumCU) best = k;
+        if (nchunks % k == 0 && nchunks / k >= 4 && tiles64 * k <= 4 * pg::num_cu()) best = k;
     return best;
 }
 
@@ -456,7 +456,7 @@ PG_EXPORT int pg_conv2d_winograd_pack_weight(const float* w, float* packed, int 
     const int CinP = round_up(Cin, 16), CoutP = round_up(Cout, 64);
     const int64_t total = (int64_t)CinP * CoutP;
     int64_t blocks = (total + 255) / 256;
-    if (blocks > pg::kMaxStreamBlocks) blocks = pg::kMaxStreamBlocks;
+    if (blocks > pg::max_stream_blocks()) blocks = pg::max_stream_blocks();
     hipLaunchKernelGGL(wino_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, packed, Cout, Cin, CinP, CoutP, scale, flip_hw, transpose_oi);
     return pg::launch_status();
 }
@@ -486,7 +486,7 @@ PG_EXPORT int pg_spade_norm(const float* x, const float* mean, const float* rstd
     const int64_t total = (int64_t)NC * HW;
     const bool vec = HW % 4 == 0 && pg::aligned16(x) && pg::aligned16(gamma) && pg::aligned16(beta) && pg::aligned16(y);
     int64_t blocks = ((vec ? total / 4 : total) + 255) / 256;
-    if (blocks > pg::kMaxStreamBlocks) blocks = pg::kMaxStreamBlocks;
+    if (blocks > pg::max_stream_blocks()) blocks = pg::max_stream_blocks();
     if (vec)
         hipLaunchKernelGGL(spade_norm_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, mean, rstd, gamma, beta, y, HW / 4, total / 4);
     else

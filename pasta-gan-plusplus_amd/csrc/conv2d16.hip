@@ -1,0 +1,316 @@
+// C ABI of the 16-bit (bf16 / fp16) convolution + its support kernels: weight packing with the style modulation and
+// demodulation folded in, the split-K finish pass and the streaming 1x1 head.  The MFMA kernel itself lives in
+// conv2d_kernel16.h and is instantiated per geometry in conv2d16_inst_*.hip.
+#include "conv2d_kernel16.h"
+
+namespace {
+
+using namespace pg;
+using pgconv16::Conv16Params;
+using pgconv16::Half16;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+struct TapSel { int ny, nx; int ys[8], xs[8]; };
+
+// packed[n][ci/16][tap][(ci/8)&1][co][ci&7] = T(w[co][ci][ky][kx] * scale * styles[n][ci] * dcoefs[n][co])
+template <typename T>
+__global__ __launch_bounds__(256) void pack16_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, int Cout, int Cin, int KH, int KW, TapSel sel,
+                                                     int CinP, int CoutP, float scale, int flip, int transpose_oi,
+                                                     const float* __restrict__ styles, const float* __restrict__ dcoefs, int64_t per_sample) {
+    const int n = blockIdx.y;
+    const int T_ = sel.ny * sel.nx;
+    unsigned short* dst = out + (int64_t)n * per_sample;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per_sample; i += (int64_t)gridDim.x * 256) {
+        const int j = (int)(i & 7);
+        const int co = (int)((i >> 3) % CoutP);
+        const int h = (int)((i / ((int64_t)8 * CoutP)) & 1);
+        const int tap = (int)((i / ((int64_t)16 * CoutP)) % T_);
+        const int k16 = (int)(i / ((int64_t)16 * CoutP * T_));
+        const int ci = k16 * 16 + h * 8 + j;
+        float v = 0.f;
+        if (co < Cout && ci < Cin) {
+            int ky = sel.ys[tap / sel.nx], kx = sel.xs[tap % sel.nx];
+            if (flip) { ky = KH - 1 - ky; kx = KW - 1 - kx; }
+            const int64_t src = transpose_oi ? (((int64_t)ci * Cout + co) * KH + ky) * KW + kx
+                                             : (((int64_t)co * Cin + ci) * KH + ky) * KW + kx;
+            v = w[src] * scale;
+            if (styles) v *= styles[(int64_t)n * Cin + ci];
+            if (dcoefs) v *= dcoefs[(int64_t)n * Cout + co];
+        }
+        dst[i] = (unsigned short)(Half16<T>::pack(v, 0.f) & 0xffff);
+    }
+}
+
+// y[n, co, oy*osy+ooy, ox*osx+oox] = T(epilogue(sum_z ws[z][n, co, oy, ox])), fixed order z = 0, 1, ... (deterministic).
+// Threads walk the OUTPUT in its own memory order when it is channels-last (co fastest) so the 16-bit stores coalesce.
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_finish16_kernel(const float* __restrict__ ws, void* __restrict__ y, int out_f32, int ksplit, int64_t slice,
+                                                              int N, int Cout, int OH, int OW, int64_t ys0, int64_t ys1, int64_t ys2, int64_t ys3,
+                                                              int osy, int osx, int ooy, int oox, pg_conv2d16_fusion f) {
+    const int64_t total = (int64_t)N * Cout * OH * OW;
+    const float slope = f.act == PG_ACT_LINEAR ? 1.f : (f.act == PG_ACT_RELU ? 0.f : f.alpha);
+    const float cl = f.clamp >= 0.f ? f.clamp : __builtin_inff();
+    const bool cl_last = ys1 == 1;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        int ox, oy, co, n;
+        if (cl_last) { co = (int)(i % Cout); ox = (int)((i / Cout) % OW); oy = (int)((i / ((int64_t)Cout * OW)) % OH); n = (int)(i / ((int64_t)Cout * OW * OH)); }
+        else { ox = (int)(i % OW); oy = (int)((i / OW) % OH); co = (int)((i / ((int64_t)OW * OH)) % Cout); n = (int)(i / ((int64_t)OW * OH * Cout)); }
+        const int64_t src = (((int64_t)n * Cout + co) * OH + oy) * OW + ox;
+        float v = 0.f;
+        for (int z = 0; z < ksplit; z++) v += ws[(int64_t)z * slice + src];
+        if (f.out_scale) v *= f.out_scale[(int64_t)n * Cout + co];
+        if (f.noise) v += f.noise[n * f.noise_batch_stride + (int64_t)oy * OW + ox] * f.noise_gain;
+        if (f.bias) v += f.bias[co];
+        v = v > 0.f ? v : v * slope;
+        v = fminf(fmaxf(v * f.gain, -cl), cl);
+        const int64_t off = n * ys0 + co * ys1 + (int64_t)(oy * osy + ooy) * ys2 + (int64_t)(ox * osx + oox) * ys3;
+        if (out_f32) {
+            if (f.residual) v += ((const float*)f.residual)[off];
+            ((float*)y)[off] = v;
+        } else {
+            if (f.residual) v += Half16<T>::widen(((const unsigned short*)f.residual)[off]);
+            ((unsigned short*)y)[off] = (unsigned short)(Half16<T>::pack(v, 0.f) & 0xffff);
+        }
+    }
+}
+
+// Streaming 1x1 head: one pixel per thread, all its channels in flight as 16-byte loads, the (<= 8) x Cin modulated weights
+// of the block's image in LDS (broadcast reads).  HBM-bound: 2*Cin bytes read + 4*Cout (+ 4*Cout skip) per pixel.
+template <typename T, int COUT>
+__global__ __launch_bounds__(256) void conv1x1_small16_kernel(const unsigned short* __restrict__ x, const float* __restrict__ w, const float* __restrict__ styles,
+                                                              const float* __restrict__ bias, const float* __restrict__ skip, float* __restrict__ y,
+                                                              int Cin, int64_t HW, float clamp) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];       // [COUT][Cin]
+    const int n = blockIdx.y;
+    for (int e = threadIdx.x; e < COUT * Cin; e += 256) {
+        const int c = e % Cin;
+        wl[e] = w[e] * (styles ? styles[(int64_t)n * Cin + c] : 1.f);
+    }
+    __syncthreads();
+    const float cl = clamp >= 0.f ? clamp : __builtin_inff();
+    const unsigned short* xn = x + (int64_t)n * HW * Cin;
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < HW; p += (int64_t)gridDim.x * 256) {
+        const u32x4* px = (const u32x4*)(xn + p * Cin);
+        float acc[COUT];
+#pragma unroll
+        for (int o = 0; o < COUT; o++) acc[o] = 0.f;
+        for (int c8 = 0; c8 < Cin / 8; c8 += 4) {                      // up to four 16-byte loads in flight per pass
+            u32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) if (c8 + u < Cin / 8) v[u] = px[c8 + u];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (c8 + u >= Cin / 8) break;
+                float xv[8];
+#pragma unroll
+                for (int d = 0; d < 4; d++) {
+                    xv[2 * d] = Half16<T>::widen((unsigned short)(v[u][d] & 0xffff));
+                    xv[2 * d + 1] = Half16<T>::widen((unsigned short)(v[u][d] >> 16));
+                }
+#pragma unroll
+                for (int o = 0; o < COUT; o++) {
+                    const f32x4 w0 = *(const f32x4*)(wl + o * Cin + (c8 + u) * 8), w1 = *(const f32x4*)(wl + o * Cin + (c8 + u) * 8 + 4);
+#pragma unroll
+                    for (int d = 0; d < 4; d++) acc[o] = fmaf(xv[d], w0[d], acc[o]);
+#pragma unroll
+                    for (int d = 0; d < 4; d++) acc[o] = fmaf(xv[4 + d], w1[d], acc[o]);
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < COUT; o++) {
+            float v = acc[o] + (bias ? bias[o] : 0.f);
+            v = fminf(fmaxf(v, -cl), cl);
+            const int64_t off = ((int64_t)n * COUT + o) * HW + p;
+            if (skip) v += skip[off];
+            y[off] = v;
+        }
+    }
+}
+
+template <typename T>
+int launch_small(int cout, dim3 grid, size_t lds, hipStream_t s, const unsigned short* x, const float* w, const float* styles, const float* bias,
+                 const float* skip, float* y, int Cin, int64_t HW, float clamp) {
+#define PG_SMALL(C) case C: hipLaunchKernelGGL((conv1x1_small16_kernel<T, C>), grid, dim3(256), lds, s, x, w, styles, bias, skip, y, Cin, HW, clamp); break;
+    switch (cout) { PG_SMALL(1) PG_SMALL(2) PG_SMALL(3) PG_SMALL(4) PG_SMALL(5) PG_SMALL(6) PG_SMALL(7) PG_SMALL(8) default: return PG_ERR_UNSUPPORTED; }
+#undef PG_SMALL
+    return pg::launch_status();
+}
+
+int kc_for16(int kh, int kw) { return kh * kw <= 2 ? 32 : 16; }
+
+bool geometry_ok(int KH, int KW, int stride) {
+    return (stride == 1 && ((KH == 3 && KW == 3) || (KH == 1 && KW == 1) || (KH == 2 && KW == 2) || (KH == 2 && KW == 1) || (KH == 1 && KW == 2))) ||
+           (stride == 2 && KH == 3 && KW == 3);
+}
+
+int conv16_forward(const void* x, const void* packed, void* y, int dtype, int out_dtype,
+                   int N, int Cin, int H, int W, int Cout, int KH, int KW,
+                   int stride, int pad_y, int pad_x, int OH, int OW, int64_t w_sample_stride,
+                   const int64_t ystride[4], int osy, int osx, int ooy, int oox,
+                   const pg_conv2d16_fusion* fusion, void* stream, float* workspace, int ksplit) {
+    if (!x || !packed || !y || !ystride) return PG_ERR_INVALID_ARG;
+    if (dtype != PG_BF16 && dtype != PG_F16) return PG_ERR_INVALID_ARG;
+    if (out_dtype != dtype && out_dtype != PG_F32) return PG_ERR_INVALID_ARG;
+    if (N <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0 || OH <= 0 || OW <= 0 || osy < 1 || osx < 1 || w_sample_stride < 0) return PG_ERR_INVALID_ARG;
+    if (!geometry_ok(KH, KW, stride)) return PG_ERR_UNSUPPORTED;
+    if (Cin % 16 != 0 || (((uintptr_t)x) & 15) != 0 || (((uintptr_t)packed) & 15) != 0) return PG_ERR_UNSUPPORTED;   // 16-byte channel vectors
+    // one image of x and the whole weight buffer are addressed through 32-bit buffer descriptors
+    if ((int64_t)H * W * Cin * 2 > 0x7fffffffLL) return PG_ERR_TOO_LARGE;
+    const int T_ = KH * KW;
+    const int CoutP = round_up(Cout, 64), CinP = round_up(Cin, 32);
+    const int64_t per_sample = (int64_t)CinP * T_ * CoutP;
+    if (w_sample_stride != 0 && w_sample_stride != per_sample) return PG_ERR_INVALID_ARG;
+    const int64_t w_bytes = (w_sample_stride ? (int64_t)N * per_sample : per_sample) * 2;
+    if (w_bytes > 0x7fffffffLL) return PG_ERR_TOO_LARGE;
+    const int64_t ext = 1 + (int64_t)(N - 1) * ystride[0] + (int64_t)(Cout - 1) * ystride[1] +
+                        ((int64_t)(OH - 1) * osy + ooy) * ystride[2] + ((int64_t)(OW - 1) * osx + oox) * ystride[3];
+    if (ext > 0x3fffffffLL) return PG_ERR_TOO_LARGE;
+
+    Conv16Params p;
+    p.x = x; p.wp = packed; p.y = y;
+    p.w_nstride = w_sample_stride; p.w_bytes = w_bytes;
+    p.y_bytes = ext * (out_dtype == PG_F32 ? 4 : 2);
+    p.N = N; p.Cin = Cin; p.xC = Cin; p.H = H; p.W = W; p.Cout = Cout; p.CoutP = CoutP; p.OH = OH; p.OW = OW;
+    p.pad_y = pad_y; p.pad_x = pad_x;
+    p.ksplit = 1; p.kpart = 0; p.ws_slice = 0;
+    for (int i = 0; i < 4; i++) p.ys[i] = ystride[i];
+    p.osy = osy; p.osx = osx; p.ooy = ooy; p.oox = oox;
+    if (fusion) {
+        p.f = *fusion;
+    } else {
+        pg_conv2d16_fusion z = {};
+        z.clamp = -1.f;
+        p.f = z;
+    }
+    if (p.f.gain == 0.f) p.f.gain = 1.f;
+    if (p.f.act == 0) p.f.act = PG_ACT_LINEAR;
+    if (p.f.act < PG_ACT_LINEAR || p.f.act > PG_ACT_SWISH) return PG_ERR_INVALID_ARG;
+    if (p.f.act > PG_ACT_LRELU) return PG_ERR_UNSUPPORTED;
+    if (p.f.act == PG_ACT_LRELU && (p.f.alpha < 0.f || p.f.alpha > 1.f)) return PG_ERR_UNSUPPORTED;
+    if (out_dtype == PG_F32) p.out_mode = pgconv16::OUT_SCALAR32;
+    else p.out_mode = (ystride[1] == 1 && Cout % 8 == 0 && ystride[3] % 8 == 0 && ystride[2] % 8 == 0 && ystride[0] % 8 == 0 &&
+                       (((uintptr_t)y) & 15) == 0 && (!p.f.residual || (((uintptr_t)p.f.residual) & 7) == 0)) ? pgconv16::OUT_VEC16 : pgconv16::OUT_SCALAR16;
+    hipStream_t s = (hipStream_t)stream;
+
+    const pg_conv2d16_fusion tail = p.f;
+    const int64_t slice = (int64_t)N * Cout * OH * OW;
+    if (ksplit > 1) {
+        const int kc = kc_for16(KH, KW);
+        if (!workspace || Cin % (ksplit * kc) != 0 || slice * ksplit > 0x3fffffffLL) return PG_ERR_INVALID_ARG;
+        p.ksplit = ksplit; p.kpart = Cin / ksplit; p.ws_slice = slice;
+        p.y = workspace; p.y_bytes = slice * ksplit * 4;
+        p.ys[0] = (int64_t)Cout * OH * OW; p.ys[1] = (int64_t)OH * OW; p.ys[2] = OW; p.ys[3] = 1;
+        p.osy = p.osx = 1; p.ooy = p.oox = 0;
+        p.out_mode = pgconv16::OUT_SCALAR32;
+        pg_conv2d16_fusion z = {};
+        z.clamp = -1.f; z.gain = 1.f; z.act = PG_ACT_LINEAR;
+        p.f = z;
+    }
+    int st = PG_ERR_UNSUPPORTED;
+    if (stride == 1) {
+        if (KH == 3 && KW == 3) st = pgconv16::launch16_k3s1(p, dtype, s);
+        else if (KH == 1 && KW == 1) st = pgconv16::launch16_k1s1(p, dtype, s);
+        else if (KH == 2 && KW == 2) st = pgconv16::launch16_k2x2(p, dtype, s);
+        else if (KH == 2 && KW == 1) st = pgconv16::launch16_k2x1(p, dtype, s);
+        else if (KH == 1 && KW == 2) st = pgconv16::launch16_k1x2(p, dtype, s);
+    } else if (KH == 3 && KW == 3) {
+        st = pgconv16::launch16_k3s2(p, dtype, s);
+    }
+    if (st != PG_OK || ksplit <= 1) return st;
+    int64_t blocks = (slice + 255) / 256;
+    if (blocks > pg::max_stream_blocks()) blocks = pg::max_stream_blocks();
+    if (dtype == PG_BF16)
+        hipLaunchKernelGGL((splitk_finish16_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), 0, s, workspace, y, out_dtype == PG_F32, ksplit, slice, N, Cout, OH, OW,
+                           ystride[0], ystride[1], ystride[2], ystride[3], osy, osx, ooy, oox, tail);
+    else
+        hipLaunchKernelGGL((splitk_finish16_kernel<f16_t>), dim3((unsigned)blocks), dim3(256), 0, s, workspace, y, out_dtype == PG_F32, ksplit, slice, N, Cout, OH, OW,
+                           ystride[0], ystride[1], ystride[2], ystride[3], osy, osx, ooy, oox, tail);
+    return pg::launch_status();
+}
+
+}  // namespace
+
+PG_EXPORT int64_t pg_conv2d16_packed_size(int Cout, int Cin, int KH, int KW) {
+    if (Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0) return 0;
+    return (int64_t)round_up(Cin, 32) * KH * KW * round_up(Cout, 64);
+}
+
+PG_EXPORT int pg_conv2d16_pack_weight(const float* w, void* packed, int dtype, int Cout, int Cin, int KH, int KW,
+                                      const int* taps_y, int ntaps_y, const int* taps_x, int ntaps_x,
+                                      float scale, int flip_hw, int transpose_oi,
+                                      const float* styles, const float* dcoefs, int nsamples, void* stream) {
+    if (!w || !packed || Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0 || nsamples <= 0) return PG_ERR_INVALID_ARG;
+    if (dtype != PG_BF16 && dtype != PG_F16) return PG_ERR_INVALID_ARG;
+    TapSel sel;
+    sel.ny = taps_y ? ntaps_y : KH;
+    sel.nx = taps_x ? ntaps_x : KW;
+    if (sel.ny <= 0 || sel.nx <= 0 || sel.ny > 8 || sel.nx > 8) return PG_ERR_UNSUPPORTED;
+    for (int i = 0; i < 8; i++) {
+        sel.ys[i] = i < sel.ny ? (taps_y ? taps_y[i] : i) : 0;
+        sel.xs[i] = i < sel.nx ? (taps_x ? taps_x[i] : i) : 0;
+        if (sel.ys[i] < 0 || sel.ys[i] >= KH || sel.xs[i] < 0 || sel.xs[i] >= KW) return PG_ERR_INVALID_ARG;
+    }
+    const int CinP = round_up(Cin, 32), CoutP = round_up(Cout, 64);
+    const int64_t per_sample = (int64_t)CinP * sel.ny * sel.nx * CoutP;
+    int64_t bx = (per_sample + 255) / 256;
+    if (bx > pg::max_stream_blocks()) bx = pg::max_stream_blocks();
+    const dim3 grid((unsigned)bx, (unsigned)nsamples);
+    if (dtype == PG_BF16)
+        hipLaunchKernelGGL((pack16_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, w, (unsigned short*)packed, Cout, Cin, KH, KW, sel, CinP, CoutP,
+                           scale, flip_hw, transpose_oi, styles, dcoefs, per_sample);
+    else
+        hipLaunchKernelGGL((pack16_kernel<f16_t>), grid, dim3(256), 0, (hipStream_t)stream, w, (unsigned short*)packed, Cout, Cin, KH, KW, sel, CinP, CoutP,
+                           scale, flip_hw, transpose_oi, styles, dcoefs, per_sample);
+    return pg::launch_status();
+}
+
+PG_EXPORT int pg_conv2d16_forward(const void* x, const void* packed, void* y, int dtype, int out_dtype,
+                                  int N, int Cin, int H, int W, int Cout, int KH, int KW,
+                                  int stride, int pad_y, int pad_x, int OH, int OW, int64_t w_sample_stride,
+                                  const int64_t ystride[4], int out_step_y, int out_step_x, int out_off_y, int out_off_x,
+                                  const pg_conv2d16_fusion* fusion, void* stream) {
+    return conv16_forward(x, packed, y, dtype, out_dtype, N, Cin, H, W, Cout, KH, KW, stride, pad_y, pad_x, OH, OW, w_sample_stride,
+                          ystride, out_step_y, out_step_x, out_off_y, out_off_x, fusion, stream, nullptr, 1);
+}
+
+PG_EXPORT int pg_conv2d16_splitk_plan(int N, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride) {
+    if (N <= 0 || Cin <= 0 || OH <= 0 || OW <= 0 || Cout <= 0 || !geometry_ok(KH, KW, stride)) return 1;
+    const int kc = kc_for16(KH, KW);
+    if (Cin % kc != 0) return 1;
+    const int nchunks = Cin / kc;
+    const int th = stride == 2 ? 8 : 16;                               // output rows of one workgroup tile (conv2d16_inst_*.hip)
+    const int64_t tiles = (int64_t)N * ((OW + 31) / 32) * ((OH + th - 1) / th) * ((Cout <= 32 ? 1 : (round_up(Cout, 64) / 64)));
+    if (tiles >= pg::num_cu() || nchunks < 8) return 1;
+    int best = 1;                                                      // largest divisor of nchunks that keeps >= 4 chunks per share and
+    for (int k = 2; k <= 16; k++)                                      // does not overshoot ~2 workgroups per CU
+        if (nchunks % k == 0 && nchunks / k >= 4 && tiles * k <= 2 * pg::num_cu()) best = k;
+    return best;
+}
+
+PG_EXPORT int pg_conv2d16_forward_splitk(const void* x, const void* packed, void* y, int dtype, int out_dtype,
+                                         int N, int Cin, int H, int W, int Cout, int KH, int KW,
+                                         int stride, int pad_y, int pad_x, int OH, int OW, int64_t w_sample_stride,
+                                         const int64_t ystride[4], int out_step_y, int out_step_x, int out_off_y, int out_off_x,
+                                         const pg_conv2d16_fusion* fusion, float* workspace, int ksplit, void* stream) {
+    if (ksplit < 1 || (ksplit > 1 && !workspace)) return PG_ERR_INVALID_ARG;
+    return conv16_forward(x, packed, y, dtype, out_dtype, N, Cin, H, W, Cout, KH, KW, stride, pad_y, pad_x, OH, OW, w_sample_stride,
+                          ystride, out_step_y, out_step_x, out_off_y, out_off_x, fusion, stream, workspace, ksplit);
+}
+
+PG_EXPORT int pg_conv1x1_small16(const void* x, const float* w, const float* styles, const float* bias, const float* skip, float* y,
+                                 int dtype, int N, int Cin, int64_t HW, int Cout, float clamp, void* stream) {
+    if (!x || !w || !y || N <= 0 || Cin <= 0 || HW <= 0 || Cout <= 0) return PG_ERR_INVALID_ARG;
+    if (dtype != PG_BF16 && dtype != PG_F16) return PG_ERR_INVALID_ARG;
+    if (Cout > 8 || Cin % 8 != 0 || (((uintptr_t)x) & 15) != 0 || (size_t)Cout * Cin * 4 > 64 * 1024) return PG_ERR_UNSUPPORTED;
+    int64_t bx = (HW + 255) / 256;
+    const int64_t cap = (int64_t)pg::max_stream_blocks() / N > 0 ? (int64_t)pg::max_stream_blocks() / N : 1;
+    if (bx > cap) bx = cap;
+    const dim3 grid((unsigned)bx, (unsigned)N);
+    const size_t lds = (size_t)Cout * Cin * 4;
+    if (dtype == PG_BF16) return launch_small<bf16_t>(Cout, grid, lds, (hipStream_t)stream, (const unsigned short*)x, w, styles, bias, skip, y, Cin, HW, clamp);
+    return launch_small<f16_t>(Cout, grid, lds, (hipStream_t)stream, (const unsigned short*)x, w, styles, bias, skip, y, Cin, HW, clamp);
+}

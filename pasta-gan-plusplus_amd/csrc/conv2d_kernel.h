@@ -28,7 +28,7 @@
 #ifndef DIRECT_EXP
 #define DIRECT_EXP 0     // dev ablations (tools/direct_variants.py; results wrong by design): 1 no output stores, 2 no halo DMA
 #endif
-#include "pg_act.h"
+#include "pg_common.h"
 
 namespace pgconv {
 
@@ -411,13 +411,10 @@ int launch_conv_xf(const ConvParams& p0, hipStream_t s) {
     int per_cu = (int)((160 * 1024) / lds);
     if (per_cu > 4) per_cu = 4;
     if (per_cu < 1) per_cu = 1;
-    const int64_t blocks = tiles < (int64_t)kNumCU * per_cu ? tiles : (int64_t)kNumCU * per_cu;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv2d_mfma<KH, KW, S, BM, KC, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    const int64_t blocks = tiles < (int64_t)num_cu() * per_cu ? tiles : (int64_t)num_cu() * per_cu;
+    static PerDeviceOnce lds_attr;
+    const hipError_t e = lds_attr.run([] { return hipFuncSetAttribute((const void*)conv2d_mfma<KH, KW, S, BM, KC, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+    if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL((conv2d_mfma<KH, KW, S, BM, KC, MODE>), dim3((unsigned)blocks), dim3(256), lds, s, p);
     return launch_status();
 }
@@ -438,7 +435,7 @@ int launch_bm(const ConvParams& p, hipStream_t s) {
     // 64-cout tiles unless that leaves most of the chip idle (low-resolution layers: a handful of pixel tiles, latency-bound
     // K loops): 32-cout tiles double the number of workgroups
     const int64_t tiles64 = (int64_t)p.N * ((p.OW + TW - 1) / TW) * ((p.OH + TH - 1) / TH) * (p.CoutP / 64) * (p.ksplit > 1 ? p.ksplit : 1);
-    if (p.CoutP % 64 == 0 && (tiles64 >= 2 * kNumCU || p.f.spade_x)) return launch_conv<KH, KW, S, 64, KC, XFORM>(p, s);
+    if (p.CoutP % 64 == 0 && (tiles64 >= 2 * num_cu() || p.f.spade_x)) return launch_conv<KH, KW, S, 64, KC, XFORM>(p, s);
     return launch_conv<KH, KW, S, 32, KC, XFORM>(p, s);
 }
 

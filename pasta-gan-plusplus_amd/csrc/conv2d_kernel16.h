@@ -1,0 +1,527 @@
+// 16-bit (bf16 / fp16) channels-last convolution for gfx950 as an implicit GEMM on v_mfma_f32_32x32x16_{bf16,f16}
+// with fp32 accumulation and the StyleGAN2 elementwise tail (demodulation scale, noise, bias, activation, gain, clamp,
+// residual) folded into its epilogue.
+//
+// What it replaces in the reference: the cuDNN call behind conv2d_gradfix.conv2d / conv_transpose2d
+// (torch_utils/ops/conv2d_gradfix.py:35-43) for half-precision tensors -- the discriminator's fp16 blocks
+// (training/networks.py:444-523, `use_fp16`, conv_clamp 256) and the half-precision synthesis blocks of the StyleGAN2
+// stack (networks.py:2147-2194 with use_fp16; BASELINE config 5 runs them in bf16 at 1024^2) -- plus the
+// `fma` / `bias_act` that follow it (networks.py:73-94, 170-179).
+//
+// Layout: activations are NHWC ("channels_last", the layout the reference's --nhwc option selects for fp16): the
+// K = 8 consecutive input channels one MFMA lane consumes are one aligned 16-byte word in HBM and in LDS, for every
+// tap shift.  GEMM view:
+//     M = Cout   A = weights, packed [Cin/16][tap][k-half][Cout][8]: a lane's fragment is one 16-byte LDS read
+//     N = pixels B = activations, halo tile [rows][cols][KC channels] in LDS, 16 bytes per (pixel, 8 channels);
+//                the 16-byte slot index is XOR-swizzled with the pixel index so that the ds_read_b128 of 32
+//                consecutive pixels is bank-conflict free; LDS-DMA writes lane-linear, so the swizzle sits in the
+//                per-lane SOURCE address (cdna_hip_programming.md rule 21)
+//     D          col = lane & 31 = pixel, rows = couts 8g + 4*(lane>>5) + j: after the conversion to 16 bit one
+//                v_permlane32_swap per register pair leaves 8 consecutive couts of one pixel in a lane ->
+//                16-byte stores into the NHWC output (guide T21).
+// Workgroup = 512 threads = 8 waves (2 per SIMD, 256 VGPRs each), one workgroup per CU; output tile = BM couts x
+// (TH rows x TW cols); all waves share the weight slab of a K chunk, so a weight byte is read from L2 once per 512
+// pixels.  One continuous stream of K chunks runs through THREE LDS staging buffers with TWO chunks in flight
+// (global -> LDS by 16-byte LDS-DMA issued from inline asm, counted s_waitcnt vmcnt, one s_barrier per chunk); the
+// stream runs across tile boundaries, so a tile's epilogue stores and the next tile's first loads overlap MFMAs.
+// Per-cout epilogue constants and the tile's noise samples travel by LDS-DMA too: the K loop and the epilogue
+// contain no compiler-visible global load (one would make hipcc drain the whole DMA queue with vmcnt(0)).
+//
+// Roofline: near the ridge.  Algorithmic FLOPs 2*N*Cout*OH*OW*Cin*KH*KW against the 2.5 PFLOP/s dense 16-bit matrix
+// peak; algorithmic bytes 2*(numel(x) + numel(y)) + weights against 8 TB/s HBM: 3x3 C=64 has 288 FLOP/B (ridge 312),
+// C=32 is HBM-bound, C>=128 MFMA-bound.
+
+#pragma once
+#include "pg_common.h"
+
+namespace pgconv16 {
+
+using namespace pg;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+// dtype traits: the MFMA, fp32 -> packed pair, 16-bit -> fp32
+template <typename T> struct Half16;
+template <> struct Half16<bf16_t> {
+    static __device__ __forceinline__ f32x16 mma(i32x4 a, i32x4 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ unsigned pack(float lo, float hi) {
+        const f32x2 v = {lo, hi};
+        return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+    }
+    static __device__ __forceinline__ float widen(unsigned short u) { return __builtin_bit_cast(float, (unsigned)u << 16); }
+};
+template <> struct Half16<f16_t> {
+    static __device__ __forceinline__ f32x16 mma(i32x4 a, i32x4 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ unsigned pack(float lo, float hi) {
+        const f32x2 v = {lo, hi};
+        return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
+    }
+    static __device__ __forceinline__ float widen(unsigned short u) { return (float)__builtin_bit_cast(f16_t, u); }
+};
+
+enum { OUT_VEC16 = 0, OUT_SCALAR16 = 1, OUT_SCALAR32 = 2 };
+
+struct Conv16Params {
+    const void* x;          // [N, H, W, Cin] 16-bit, dense
+    const void* wp;         // packed weights, sample n at wp + n * w_nstride (elements); 0 = shared
+    void* y;
+    int64_t w_nstride;
+    int64_t w_bytes;        // extent of the packed weight buffer (range check of the DMA descriptor)
+    int64_t y_bytes;        // extent of y in bytes (range check of the vector epilogue's store descriptor; < 2^31 in that mode)
+    int N, Cin, H, W, Cout, CoutP, OH, OW;
+    int xC;                 // channels per pixel of x (>= Cin; the pixel stride)
+    int pad_y, pad_x;
+    int ksplit, kpart;      // split-K: `ksplit` workgroups share one output tile, each reducing `kpart` channels into
+    int64_t ws_slice;       // its own slice (ws_slice elements apart) of the float32 workspace that y then points to
+    int64_t ys[4];          // (n, c, y, x) strides of the output in ELEMENTS of its dtype
+    int osy, osx, ooy, oox; // output pixel (oy, ox) is written at (oy*osy + ooy, ox*osx + oox)
+    int out_mode;
+    int tilesX, tilesY, mblocks, total_tiles;
+    pg_conv2d16_fusion f;
+};
+
+constexpr int THREADS = 512, WAVES = 8;
+
+__device__ __forceinline__ unsigned lds_offset(const void* p) {
+    return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) unsigned char*)p;
+}
+// LDS-DMA (no staging registers); LDS destination = M0 + lane * size.  M0 is written in the statement that uses it and
+// restored (compiler-reserved, cdna_hip_programming.md 5.7).  The range check of the buffer descriptor returns zeros for
+// offsets beyond num_records: zero padding, channel padding and "this lane has nothing to load" are all the sentinel offset.
+__device__ __forceinline__ void dma16(i32x4 rsrc, unsigned lds_byte, unsigned voff_bytes, unsigned soff_bytes) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_byte), "v"(voff_bytes), "s"(rsrc), "s"(soff_bytes) : "memory");
+}
+__device__ __forceinline__ void dma4(i32x4 rsrc, unsigned lds_byte, unsigned voff_bytes) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dword %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_byte), "v"(voff_bytes), "s"(rsrc) : "memory");
+}
+template <int N> __device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" :: "i"(N) : "memory"); }
+
+constexpr unsigned SENTINEL = 0x80000000u;
+
+__device__ __forceinline__ i32x4 make_rsrc(const void* base, int64_t bytes) {
+    const uint64_t b = (uint64_t)(uintptr_t)base;
+    i32x4 r;
+    r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)b);
+    r[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32) & 0xffff);
+    r[2] = __builtin_amdgcn_readfirstlane((int)(bytes > 0x7fffffffLL ? 0x7fffffffLL : (bytes < 0 ? 0 : bytes)));
+    r[3] = 0x00020000;
+    return r;
+}
+
+template <int KH, int KW, int S, int TWL, int WM, int MT, int NT, int KC, int NB>
+struct Geo16 {
+    static constexpr int T = KH * KW;
+    static constexpr int WP = WAVES / WM;                 // waves along pixels
+    static constexpr int RP = 32 / TWL;                   // rows of one 32-pixel N tile
+    static constexpr int TH = WP * NT * RP, TW = TWL;     // output tile of one workgroup
+    static constexpr int BM = WM * MT * 32;
+    static constexpr int IH_T = (TH - 1) * S + KH, IW_T = (TW - 1) * S + KW;
+    static constexpr int SLOTS = KC / 8;                  // 16-byte slots per pixel per chunk
+    static constexpr int PER = 16 / SLOTS;                // pixels per 256-byte LDS bank row
+    static constexpr int KS = KC / 16;                    // MFMA k-steps per tap per chunk
+    static constexpr int NXS = IH_T * IW_T * SLOTS;       // halo slots
+    static constexpr int NXS_PAD = (NXS + 63) / 64 * 64;  // the halo / weight boundary is wave-instruction aligned
+    static constexpr int NWS = KS * T * 2 * BM;           // weight slots
+    static constexpr int DPC = (NXS_PAD + NWS + THREADS - 1) / THREADS;      // DMA instructions per thread per chunk
+    static constexpr int LDS_BUF = DPC * THREADS;         // slots
+    static constexpr int NBUF = NB;                       // staging buffers; NBUF - 1 chunks in flight
+    static constexpr int EPS = (BM + 63) / 64 * 64;       // per-cout constants: [scale EPS][bias EPS] floats
+    static constexpr int EP_FLOATS = 2 * EPS + THREADS;   // + the tile's noise samples; one extra 64-float pad for idle waves
+    static constexpr size_t LDS_BYTES = (size_t)NBUF * LDS_BUF * 16 + (size_t)2 * EP_FLOATS * 4 + 256;
+    static_assert(SLOTS == 2 || SLOTS == 4 || SLOTS == 8, "KC must be 16, 32 or 64");
+    static_assert(TH * TW <= THREADS && 2 * EPS <= THREADS, "tile / cout block too large for the per-tile side loads");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+};
+
+__device__ __forceinline__ float act_slope(int act, float alpha) { return act == PG_ACT_LINEAR ? 1.f : (act == PG_ACT_RELU ? 0.f : alpha); }
+
+template <typename T, int KH, int KW, int S, int TWL, int WM, int MT, int NT, int KC, int NB>
+__global__ __launch_bounds__(THREADS, 2) void conv2d_mfma16(Conv16Params p) {
+    typedef Geo16<KH, KW, S, TWL, WM, MT, NT, KC, NB> G;
+    typedef Half16<T> HT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef const __attribute__((address_space(3))) i32x4* lds_v4;
+    typedef const __attribute__((address_space(3))) f32x4* lds_f4;
+    typedef const __attribute__((address_space(3))) float* lds_f;
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const unsigned smem_b = __builtin_amdgcn_readfirstlane(lds_offset(smem));
+    const unsigned side_b = smem_b + (unsigned)(G::NBUF * G::LDS_BUF) * 16u;       // [2][EP_FLOATS] floats, then a 256-byte dump
+    const unsigned dump_b = side_b + 2u * G::EP_FLOATS * 4u;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int wpx = wave % G::WP, wmx = wave / G::WP;
+    const int total = p.total_tiles;
+    const int q8 = total >> 3, r8 = total & 7;
+    const int cin_loop = p.ksplit > 1 ? p.kpart : p.Cin;  // channels one workgroup reduces per tile
+    const int nchunks = (cin_loop + KC - 1) / KC;
+    const int tail_ch = cin_loop % KC;                    // channels of a partial last chunk (0 = none)
+
+    // ---- descriptors that never change
+    const i32x4 wrsrc = make_rsrc(p.wp, p.w_bytes);
+    const i32x4 brsrc = make_rsrc(p.f.bias, p.f.bias ? (int64_t)p.Cout * 4 : 0);
+    // the vector epilogue stores through a range-checked descriptor: every wave issues exactly EP_STORES store instructions
+    // per tile (masked-off lanes carry the sentinel offset), which the counted waits below rely on
+    const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)(p.y_bytes > 0x7fffffffLL ? 0x7fffffffLL : p.y_bytes), 0x00020000);
+
+    // ---- per-thread DMA maps.  Instruction i of a chunk moves 16-byte slot  s = (i * 8 + wave) * 64 + lane  of the staging
+    // buffer: slots below NXS_PAD are the halo tile (gathered, re-mapped per tile), the rest the weight slab (fixed map).
+    unsigned voff[G::DPC];
+    unsigned tailmask = 0;                                // bit i: this lane's halo slot i holds channels >= tail_ch of a chunk
+#pragma unroll
+    for (int i = 0; i < G::DPC; i++) {
+        const int sb = (i * WAVES + wave) * 64;
+        voff[i] = SENTINEL;
+        if (sb >= G::NXS_PAD) {
+            const int e = sb + lane - G::NXS_PAD;
+            const int row = e / G::BM, col = e % G::BM;
+            if (e < G::NWS) voff[i] = (unsigned)(row * p.CoutP + col) * 16u;
+        } else {
+            const int s = sb + lane;
+            const int q = s / G::SLOTS;
+            const int c = (s % G::SLOTS) ^ ((q / G::PER) & (G::SLOTS - 1));
+            if (tail_ch && c * 8 >= tail_ch) tailmask |= 1u << i;
+        }
+    }
+
+    // ---- tile descriptors: [parity] of the tile being multiplied / the next one
+    int d_z0 = 0, d_z1 = 0, d_n0 = 0, d_n1 = 0, d_oy00 = 0, d_oy01 = 0, d_ox00 = 0, d_ox01 = 0, d_m00 = 0, d_m01 = 0;      // (explicit pairs: a runtime-indexed array would live in scratch)
+    i32x4 xrsrc, srsrc, nrsrc;                            // image n of x; out_scale row n; noise plane n  (tile being requested)
+    unsigned w_soff = 0, x_soff0 = 0;
+    unsigned side_voff = SENTINEL, noise_voff = SENTINEL;
+
+    // Tile -> (n, tile_y, tile_x, m-block), XCD-aware: workgroups that share an XCD (id % 8) walk one contiguous range of
+    // logical tiles, so vertically / horizontally adjacent halos and the weight slabs hit the same L2.
+    auto prep_tile = [&](int tile, int par) __attribute__((always_inline)) {
+        const int xcd = tile & 7;
+        int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (tile >> 3);
+        int zsl = 0;
+        if (p.ksplit > 1) { zsl = L % p.ksplit; L /= p.ksplit; }      // the shares of one tile run side by side
+        const int cbeg = zsl * p.kpart;
+        const int mb = L % p.mblocks; L /= p.mblocks;
+        const int tx = L % p.tilesX; L /= p.tilesX;
+        const int ty = L % p.tilesY;
+        const int n = L / p.tilesY;
+        const int oy0 = ty * G::TH, ox0 = tx * G::TW, m0 = mb * G::BM;
+        // value selects, not control flow: stores through a selected address would put the descriptors into scratch
+        d_z1 = par ? zsl : d_z1;   d_z0 = par ? d_z0 : zsl;
+        d_n1 = par ? n : d_n1;     d_n0 = par ? d_n0 : n;
+        d_oy01 = par ? oy0 : d_oy01; d_oy00 = par ? d_oy00 : oy0;
+        d_ox01 = par ? ox0 : d_ox01; d_ox00 = par ? d_ox00 : ox0;
+        d_m01 = par ? m0 : d_m01;  d_m00 = par ? d_m00 : m0;
+        int tt = t;
+        asm volatile("" : "+v"(tt));                      // keep the tile-independent index maths out of long-lived registers
+        const int lane_ = tt & 63;
+#pragma unroll
+        for (int i = 0; i < G::DPC; i++) {
+            const int sb = (i * WAVES + wave) * 64;
+            if (sb < G::NXS_PAD) {                        // wave-uniform
+                const int s = sb + lane_;
+                const int q = s / G::SLOTS;
+                const int c = (s % G::SLOTS) ^ ((q / G::PER) & (G::SLOTS - 1));
+                const int hy = q / G::IW_T, hx = q % G::IW_T;
+                const int gy = oy0 * S - p.pad_y + hy, gx = ox0 * S - p.pad_x + hx;
+                const bool ok = s < G::NXS && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+                voff[i] = ok ? (unsigned)((gy * p.W + gx) * p.xC + c * 8) * 2u : SENTINEL;
+            }
+        }
+        xrsrc = make_rsrc((const unsigned short*)p.x + (int64_t)n * p.H * p.W * p.xC, (int64_t)p.H * p.W * p.xC * 2);
+        x_soff0 = (unsigned)cbeg * 2u;
+        srsrc = make_rsrc(p.f.out_scale ? p.f.out_scale + (int64_t)n * p.Cout : nullptr, p.f.out_scale ? (int64_t)p.Cout * 4 : 0);
+        nrsrc = make_rsrc(p.f.noise ? p.f.noise + (int64_t)n * p.f.noise_batch_stride : nullptr, p.f.noise ? (int64_t)p.OH * p.OW * 4 : 0);
+        w_soff = (unsigned)(((int64_t)n * p.w_nstride + (int64_t)m0 * 8) * 2) + (unsigned)((cbeg / 16) * G::T * 2) * (unsigned)p.CoutP * 16u;
+        // side loads of the tile: wave w < EPS/64 fetches 64 demodulation scales, the next EPS/64 waves 64 biases; every
+        // thread one noise sample (tile pixel t)
+        const int seg = wave * 64 + lane_;
+        side_voff = (unsigned)(m0 + (seg % G::EPS)) * 4u;
+        const int ny = oy0 + tt / G::TW, nx = ox0 + tt % G::TW;
+        noise_voff = (tt < G::TH * G::TW && ny < p.OH && nx < p.OW) ? (unsigned)(ny * p.OW + nx) * 4u : SENTINEL;
+    };
+
+    // ---- the chunk stream
+    int c_tile = blockIdx.x, c_chunk = 0, c_ahead = 0;    // request cursor: tile, chunk, tiles ahead of the one being multiplied
+    bool c_done = false;
+    int ibuf = 0, cbuf = 0;                               // staging buffer of the next request / of the next chunk to multiply
+    int inflight = 0;                                     // chunks requested and not yet multiplied
+    int dpar = 0;                                         // descriptor parity of the tile being multiplied
+
+    auto issue_next = [&]() __attribute__((always_inline)) {
+        if (c_done || (c_chunk == 0 && c_ahead > 1)) return;
+        const int par = dpar ^ (c_ahead & 1);
+        if (c_chunk == 0) {
+            prep_tile(c_tile, par);
+            const unsigned sb_ = side_b + (unsigned)(par * G::EP_FLOATS) * 4u;
+            // scales | biases | (idle waves write zeros into the dump area)
+            const bool is_scale = wave < G::EPS / 64, is_bias = !is_scale && wave < 2 * (G::EPS / 64);
+            const i32x4 r = is_scale ? srsrc : brsrc;
+            dma4(r, (is_scale || is_bias) ? sb_ + (unsigned)(wave * 64) * 4u : dump_b, (is_scale || is_bias) ? side_voff : SENTINEL);
+            dma4(nrsrc, sb_ + (unsigned)(2 * G::EPS + wave * 64) * 4u, noise_voff);
+        }
+        const int c0 = c_chunk * KC;
+        const bool partial = tail_ch != 0 && c_chunk == nchunks - 1;
+        const unsigned x_soff = x_soff0 + (unsigned)c0 * 2u;
+        const unsigned wk_soff = w_soff + (unsigned)((c0 / 16) * G::T * 2) * (unsigned)p.CoutP * 16u;
+        const unsigned buf_b = smem_b + (unsigned)(ibuf * G::LDS_BUF) * 16u;
+#pragma unroll
+        for (int i = 0; i < G::DPC; i++) {
+            const int sb = (i * WAVES + wave) * 64;
+            const bool is_w = sb >= G::NXS_PAD;           // wave-uniform
+            unsigned vo = voff[i];
+            if (partial && ((tailmask >> i) & 1)) vo = SENTINEL;
+            dma16(is_w ? wrsrc : xrsrc, buf_b + (unsigned)sb * 16u, vo, is_w ? wk_soff : x_soff);
+        }
+        ibuf = ibuf == G::NBUF - 1 ? 0 : ibuf + 1;
+        inflight++;
+        if (++c_chunk == nchunks) {
+            c_chunk = 0;
+            c_tile += gridDim.x;
+            c_ahead++;
+            if (c_tile >= total) c_done = true;
+        }
+    };
+
+    // ---- operand addresses: constant for the whole kernel
+    int qrow[NT];                                          // halo pixel index of this lane's output pixel, tap (0, 0)
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) {
+        const int row_l = (wpx * NT + nt) * G::RP + l31 / TWL, col_l = l31 % TWL;
+        qrow[nt] = row_l * S * G::IW_T + col_l * S;
+    }
+    const int a_lane = G::NXS_PAD + half * G::BM + (wmx * MT) * 32 + l31;
+
+    f32x16 acc[MT][NT];
+
+    // One chunk out of staging buffer `buf`.  With unit stride and one row per N tile the wave's NT output rows share
+    // KH + NT - 1 halo rows: each B fragment is read once and feeds every (row, ky) pair it belongs to, and the KH weight
+    // fragments of a kernel column are held across those rows -- (KH*MT + KH+NT-1) LDS reads per KH*MT*NT MFMAs.
+    auto compute_chunk = [&](int buf) __attribute__((always_inline)) {
+        const unsigned char* base = smem + (size_t)buf * G::LDS_BUF * 16;
+        auto b_frag = [&](int q, int ks) __attribute__((always_inline)) {
+            const int slot = q * G::SLOTS + ((ks * 2 + half) ^ ((q / G::PER) & (G::SLOTS - 1)));
+            return *(lds_v4)(base + (size_t)slot * 16);
+        };
+        auto a_frag = [&](int ks, int tap, int mt) __attribute__((always_inline)) {
+            return *(lds_v4)(base + (size_t)(a_lane + ((ks * G::T + tap) * 2) * G::BM + mt * 32) * 16);
+        };
+#pragma unroll
+        for (int ks = 0; ks < G::KS; ks++) {
+            if constexpr (S == 1 && G::RP == 1) {
+#pragma unroll
+                for (int kx = 0; kx < KW; kx++) {
+                    i32x4 a[KH][MT];
+#pragma unroll
+                    for (int ky = 0; ky < KH; ky++)
+#pragma unroll
+                        for (int mt = 0; mt < MT; mt++) a[ky][mt] = a_frag(ks, ky * KW + kx, mt);
+#pragma unroll
+                    for (int hr = 0; hr < KH + NT - 1; hr++) {
+                        const i32x4 b = b_frag(qrow[0] + hr * G::IW_T + kx, ks);
+#pragma unroll
+                        for (int nt = 0; nt < NT; nt++) {
+                            const int ky = hr - nt;
+                            if (ky < 0 || ky >= KH) continue;
+#pragma unroll
+                            for (int mt = 0; mt < MT; mt++) acc[mt][nt] = HT::mma(a[ky][mt], b, acc[mt][nt]);
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int ky = 0; ky < KH; ky++) {
+#pragma unroll
+                    for (int kx = 0; kx < KW; kx++) {
+                        i32x4 a[MT], b[NT];
+#pragma unroll
+                        for (int mt = 0; mt < MT; mt++) a[mt] = a_frag(ks, ky * KW + kx, mt);
+#pragma unroll
+                        for (int nt = 0; nt < NT; nt++) b[nt] = b_frag(qrow[nt] + ky * G::IW_T + kx, ks);
+#pragma unroll
+                        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                            for (int nt = 0; nt < NT; nt++) acc[mt][nt] = HT::mma(a[mt], b[nt], acc[mt][nt]);
+                    }
+                }
+            }
+        }
+    };
+
+    const float gain = p.f.gain;
+    const float cl = p.f.clamp >= 0.f ? p.f.clamp : __builtin_inff();
+    const float slope = act_slope(p.f.act, p.f.alpha);
+    const bool has_scale = p.f.out_scale != nullptr;
+    const float noise_gain = p.f.noise ? p.f.noise_gain : 0.f;
+    constexpr int EP_STORES = MT * NT * 2;                // 16-byte stores of the vector epilogue per wave
+
+    issue_next();
+    if (G::NBUF > 2) issue_next();
+    int tile = blockIdx.x;
+    bool after_ep = false;
+    while (true) {
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+                for (int k = 0; k < 16; k++) acc[mt][nt][k] = 0.f;
+
+        for (int k = 0; k < nchunks; k++) {
+            // chunk `cbuf` must have landed: everything younger in this wave's queue may stay in flight -- the next chunk's
+            // DMAs (inflight == 2) and, right after a tile's vector epilogue, its stores
+            if (inflight > 1) { if (after_ep && p.out_mode == OUT_VEC16) vm_wait<G::DPC + EP_STORES>(); else vm_wait<G::DPC>(); }
+            else              { if (after_ep && p.out_mode == OUT_VEC16) vm_wait<EP_STORES>(); else vm_wait<0>(); }
+            after_ep = false;
+            __builtin_amdgcn_s_barrier();                  // every wave's share has landed; every wave is done with the buffer requested next
+            issue_next();
+            compute_chunk(cbuf);
+            cbuf = cbuf == G::NBUF - 1 ? 0 : cbuf + 1;
+            inflight--;
+        }
+
+        // ---- epilogue: D col = lane & 31 (pixel), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) (cout)
+        const int e_z = dpar ? d_z1 : d_z0;
+        const int e_n = dpar ? d_n1 : d_n0, e_oy0 = dpar ? d_oy01 : d_oy00, e_ox0 = dpar ? d_ox01 : d_ox00, e_m0 = dpar ? d_m01 : d_m00;
+        const unsigned char* side = smem + (size_t)G::NBUF * G::LDS_BUF * 16 + (size_t)dpar * G::EP_FLOATS * 4;
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) {
+            const int row_l = (wpx * NT + nt) * G::RP + l31 / TWL, col_l = l31 % TWL;
+            const int oy = e_oy0 + row_l, ox = e_ox0 + col_l;
+            const bool pix_ok = oy < p.OH && ox < p.OW;
+            const float nz = *(lds_f)(side + (size_t)(2 * G::EPS + row_l * G::TW + col_l) * 4) * noise_gain;
+            const int64_t pix_off = (int64_t)e_z * p.ws_slice + (int64_t)e_n * p.ys[0] + (int64_t)(oy * p.osy + p.ooy) * p.ys[2] + (int64_t)(ox * p.osx + p.oox) * p.ys[3];
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) {
+                const int mloc = (wmx * MT + mt) * 32;
+                float v[16];
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const int r0 = mloc + 8 * g + 4 * half;
+                    f32x4 sc4 = *(lds_f4)(side + (size_t)r0 * 4);
+                    const f32x4 bi4 = *(lds_f4)(side + (size_t)(G::EPS + r0) * 4);
+                    if (!has_scale) sc4 = f32x4{1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        float u = acc[mt][nt][4 * g + j] * sc4[j] + nz + bi4[j];
+                        u = u > 0.f ? u : u * slope;
+                        v[4 * g + j] = fminf(fmaxf(u * gain, -cl), cl);
+                    }
+                }
+                if (p.out_mode == OUT_VEC16) {
+                    // ys[1] == 1, Cout % 8 == 0: 8 consecutive couts of one pixel per lane after the half-wave exchange
+                    const unsigned short* rp = (const unsigned short*)p.f.residual;
+                    u32x2 o[4];
+#pragma unroll
+                    for (int g = 0; g < 4; g++) {
+                        const int co = e_m0 + mloc + 8 * g + 4 * half;
+                        if (rp) {
+                            const bool ok = pix_ok && co < p.Cout;
+                            const u32x2 rv = *(const u32x2*)(rp + (ok ? pix_off + co : 0));
+                            v[4 * g + 0] += HT::widen((unsigned short)(rv[0] & 0xffff));
+                            v[4 * g + 1] += HT::widen((unsigned short)(rv[0] >> 16));
+                            v[4 * g + 2] += HT::widen((unsigned short)(rv[1] & 0xffff));
+                            v[4 * g + 3] += HT::widen((unsigned short)(rv[1] >> 16));
+                        }
+                        o[g][0] = HT::pack(v[4 * g + 0], v[4 * g + 1]);
+                        o[g][1] = HT::pack(v[4 * g + 2], v[4 * g + 3]);
+                    }
+#pragma unroll
+                    for (int g0 = 0; g0 < 4; g0 += 2) {
+                        // lanes 32-63 of group g0 <-> lanes 0-31 of group g0+1: lower half then holds couts 8*g0 .. +7,
+                        // upper half couts 8*(g0+1) .. +7 of its pixel
+                        u32x2 a = o[g0], b = o[g0 + 1];
+#pragma unroll
+                        for (int d = 0; d < 2; d++) {
+                            const auto r = __builtin_amdgcn_permlane32_swap(a[d], b[d], false, false);
+                            a[d] = r[0]; b[d] = r[1];
+                        }
+                        const int co = e_m0 + mloc + 8 * (g0 + half);
+                        const unsigned so = (pix_ok && co < p.Cout) ? (unsigned)(pix_off + co) * 2u : SENTINEL;
+                        __builtin_amdgcn_raw_buffer_store_b128(u32x4{a[0], a[1], b[0], b[1]}, yrsrc, (int)so, 0, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 16; i++) {
+                        const int co = e_m0 + mloc + (i & 3) + 8 * (i >> 2) + 4 * half;
+                        if (pix_ok && co < p.Cout) {
+                            const int64_t off = pix_off + (int64_t)co * p.ys[1];
+                            if (p.out_mode == OUT_SCALAR32) {
+                                float u = v[i];
+                                if (p.f.residual) u += ((const float*)p.f.residual)[off];
+                                ((float*)p.y)[off] = u;
+                            } else {
+                                float u = v[i];
+                                if (p.f.residual) u += HT::widen(((const unsigned short*)p.f.residual)[off]);
+                                ((unsigned short*)p.y)[off] = (unsigned short)(HT::pack(u, 0.f) & 0xffff);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        after_ep = true;
+        if (tile + (int)gridDim.x >= total) break;
+        tile += gridDim.x;
+        dpar ^= 1;
+        c_ahead--;
+    }
+}
+
+template <typename T, int KH, int KW, int S, int TWL, int WM, int MT, int NT, int KC, int NB>
+int launch16(const Conv16Params& p0, hipStream_t s) {
+    typedef Geo16<KH, KW, S, TWL, WM, MT, NT, KC, NB> G;
+    Conv16Params p = p0;
+    p.tilesX = (p.OW + G::TW - 1) / G::TW;
+    p.tilesY = (p.OH + G::TH - 1) / G::TH;
+    p.mblocks = (p.CoutP + G::BM - 1) / G::BM;
+    const int64_t tiles = (int64_t)p.N * p.tilesX * p.tilesY * p.mblocks * (p.ksplit > 1 ? p.ksplit : 1);
+    if (tiles > 0x7fffffffLL) return PG_ERR_TOO_LARGE;
+    p.total_tiles = (int)tiles;
+    if (p.ksplit > 1 && p.kpart % KC != 0) return PG_ERR_INVALID_ARG;
+    const int64_t blocks = tiles < (int64_t)num_cu() ? tiles : (int64_t)num_cu();       // persistent: one workgroup per CU
+    auto kern = conv2d_mfma16<T, KH, KW, S, TWL, WM, MT, NT, KC, NB>;
+    static PerDeviceOnce lds_attr;
+    const hipError_t e = lds_attr.run([&] { return hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(THREADS), G::LDS_BYTES, s, p);
+    return launch_status();
+}
+
+// M-tile count by the width of the layer (32-cout blocks for narrow layers: no MFMA spent on padding rows)
+template <typename T, int KH, int KW, int S, int NT, int KC, int NB>
+int launch16_mt(const Conv16Params& p, hipStream_t s) {
+    if (p.Cout <= 32) return launch16<T, KH, KW, S, 32, 1, 1, NT, KC, NB>(p, s);
+    return launch16<T, KH, KW, S, 32, 1, 2, NT, KC, NB>(p, s);
+}
+
+template <int KH, int KW, int S, int NT, int KC, int NB = 3>
+int launch16_dt(const Conv16Params& p, int dtype, hipStream_t s) {
+    if (dtype == PG_BF16) return launch16_mt<bf16_t, KH, KW, S, NT, KC, NB>(p, s);
+    if (dtype == PG_F16) return launch16_mt<f16_t, KH, KW, S, NT, KC, NB>(p, s);
+    return PG_ERR_INVALID_ARG;
+}
+
+// One entry per geometry family, each compiled in its own translation unit (conv2d16_inst_*.hip).
+int launch16_k3s1(const Conv16Params& p, int dtype, hipStream_t s);
+int launch16_k1s1(const Conv16Params& p, int dtype, hipStream_t s);
+int launch16_k2x2(const Conv16Params& p, int dtype, hipStream_t s);
+int launch16_k2x1(const Conv16Params& p, int dtype, hipStream_t s);
+int launch16_k1x2(const Conv16Params& p, int dtype, hipStream_t s);
+int launch16_k3s2(const Conv16Params& p, int dtype, hipStream_t s);
+
+}  // namespace pgconv16

@@ -466,13 +466,10 @@ int launch_wino_xf(const ConvParams& p0, hipStream_t s) {
     int per_cu = (int)((160 * 1024) / lds);
     if (per_cu > 2) per_cu = 2;                             // 128 VGPRs x 8 waves per workgroup
     if (per_cu < 1) per_cu = 1;
-    const int64_t blocks = tiles < (int64_t)kNumCU * per_cu ? tiles : (int64_t)kNumCU * per_cu;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv2d_wino<MODE, VEC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    const int64_t blocks = tiles < (int64_t)num_cu() * per_cu ? tiles : (int64_t)num_cu() * per_cu;
+    static PerDeviceOnce lds_attr;
+    const hipError_t e = lds_attr.run([] { return hipFuncSetAttribute((const void*)conv2d_wino<MODE, VEC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+    if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL((conv2d_wino<MODE, VEC>), dim3((unsigned)blocks), dim3(512), lds, s, p);
     return launch_status();
 }

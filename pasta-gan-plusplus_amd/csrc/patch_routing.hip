@@ -97,7 +97,7 @@ PG_EXPORT int pg_patch_compose_u8(const uint8_t* patch, const uint8_t* mask, uin
     if (!patch || !mask || !canvas || h <= 0 || w <= 0 || mask_channels <= 0) return PG_ERR_INVALID_ARG;
     if ((int64_t)h * w > 0x3fffffffLL) return PG_ERR_TOO_LARGE;
     int bx = (h * w + 255) / 256;
-    if (bx > pg::kMaxStreamBlocks) bx = pg::kMaxStreamBlocks;
+    if (bx > pg::max_stream_blocks()) bx = pg::max_stream_blocks();
     hipLaunchKernelGGL(patch_compose_u8_kernel, dim3((unsigned)bx), dim3(256), 0, (hipStream_t)stream, patch, mask, canvas, canvas2, h, w, mask_channels);
     return pg::launch_status();
 }

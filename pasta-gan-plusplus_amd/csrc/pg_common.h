@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include "pasta_gan_ops.h"
 
 #define PG_EXPORT extern "C" __attribute__((visibility("default")))
@@ -25,8 +26,35 @@ static inline int launch_status() {
 
 __host__ __device__ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-// MI355X: 256 CUs; memory-bound grids are capped at 256 CUs x 8 blocks and grid-stride the rest.
-constexpr int kNumCU = 256;
-constexpr int kMaxStreamBlocks = kNumCU * 8;
+// Compute units of the CURRENT device (256 on MI355X), queried once per device; memory-bound grids are capped at
+// CUs x 8 blocks and grid-stride the rest.
+constexpr int kMaxDevices = 64;
+inline int current_device() {
+    int d = 0;
+    return hipGetDevice(&d) == hipSuccess && d >= 0 && d < kMaxDevices ? d : 0;
+}
+inline int num_cu() {
+    static std::atomic<int> cached[kMaxDevices];
+    const int d = current_device();
+    int v = cached[d].load(std::memory_order_relaxed);
+    if (v <= 0) {
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || v <= 0) v = 256;
+        cached[d].store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+inline int max_stream_blocks() { return num_cu() * 8; }
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute of a kernel: one flag per (kernel, device).
+struct PerDeviceOnce {
+    std::atomic<bool> done[kMaxDevices];
+    template <typename F> hipError_t run(F&& f) {
+        const int d = current_device();
+        if (done[d].load(std::memory_order_acquire)) return hipSuccess;
+        const hipError_t e = f();
+        if (e == hipSuccess) done[d].store(true, std::memory_order_release);
+        return e;
+    }
+};
 
 }  // namespace pg

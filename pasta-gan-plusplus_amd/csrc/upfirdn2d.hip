@@ -14,6 +14,14 @@
 //   * upfirdn2d_generic -- any strides / dtype / factors / filter size: one output per
 //     thread straight from global memory, visiting valid taps only.
 //
+//   * upfirdn2d_cl     -- channels-last (NHWC) dense tensors, no up-sampling, filters up to 4 x 4 (the blur behind every
+//     transposed convolution and in front of every strided one, and the 2x decimation of the discriminator's skip path,
+//     for the half-precision blocks whose convolutions run channels-last: conv2d_kernel16.h).  A thread owns one
+//     16-byte channel vector of one output column and walks RPT output rows: consecutive threads = consecutive channel
+//     vectors, then pixels, so every load and store is a coalesced 16-byte access; an input row is fetched once for all
+//     the output rows it feeds; fp32 accumulation; the SynthesisLayer tail (noise, bias, activation, gain, clamp) rides
+//     in the same pass.
+//
 // Roofline: HBM streaming; algorithmic bytes per call = sizeof(T) * (numel(x) + numel(y))
 // (SURVEY.md section 8d).
 #include "pg_common.h"
@@ -239,17 +247,163 @@ bool try_tiled(const Params& p, hipStream_t s, int* st) {
     return false;
 }
 
+// ---------------------------------------------------------------- channels-last
+// 16 bytes of channels as a register vector (plain ext-vector registers: element-wise writes to a struct of 16-bit values
+// would send it to scratch), widened to / narrowed from fp32 with bit operations
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+template <typename T> struct Vec16;
+template <> struct Vec16<float> {
+    static constexpr int N = 4;
+    static __device__ __forceinline__ void widen(u32x4 r, float (&o)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) o[i] = __builtin_bit_cast(float, r[i]);
+    }
+    static __device__ __forceinline__ u32x4 narrow(const float (&v)[4]) {
+        return u32x4{__builtin_bit_cast(unsigned, v[0]), __builtin_bit_cast(unsigned, v[1]), __builtin_bit_cast(unsigned, v[2]), __builtin_bit_cast(unsigned, v[3])};
+    }
+};
+template <> struct Vec16<bf16_t> {
+    static constexpr int N = 8;
+    static __device__ __forceinline__ void widen(u32x4 r, float (&o)[8]) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) { o[2 * i] = __builtin_bit_cast(float, r[i] << 16); o[2 * i + 1] = __builtin_bit_cast(float, r[i] & 0xffff0000u); }
+    }
+    static __device__ __forceinline__ u32x4 narrow(const float (&v)[8]) {
+        u32x4 r;
+#pragma unroll
+        for (int i = 0; i < 4; i++) { const f32x2v t = {v[2 * i], v[2 * i + 1]}; r[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(t, bf16x2v)); }
+        return r;
+    }
+};
+template <> struct Vec16<f16_t> {
+    static constexpr int N = 8;
+    static __device__ __forceinline__ void widen(u32x4 r, float (&o)[8]) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) { const f16x2v h = __builtin_bit_cast(f16x2v, r[i]); o[2 * i] = (float)h[0]; o[2 * i + 1] = (float)h[1]; }
+    }
+    static __device__ __forceinline__ u32x4 narrow(const float (&v)[8]) {
+        u32x4 r;
+#pragma unroll
+        for (int i = 0; i < 4; i++) { const f32x2v t = {v[2 * i], v[2 * i + 1]}; r[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(t, f16x2v)); }
+        return r;
+    }
+};
+
+template <typename T, int FH, int FW, int DN, int RPT>
+__global__ __launch_bounds__(256, 4) void upfirdn2d_cl(Params p) {
+    constexpr int V = Vec16<T>::N;
+    const int CV = p.C / V;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int cv = (int)(idx % CV);
+    const int ox = (int)(idx / CV);
+    if (ox >= p.outW) return;
+    const int n = blockIdx.z, oy0 = blockIdx.y * RPT;
+    const int ix0 = ox * DN - p.padx0, iy0 = oy0 * DN - p.pady0;
+    float tap[FH][FW];                                   // flipped (true convolution) unless p.flip, zero padded to FH x FW
+#pragma unroll
+    for (int ky = 0; ky < FH; ky++)
+#pragma unroll
+        for (int kx = 0; kx < FW; kx++) {
+            const int fy = p.flip ? ky : p.fh - 1 - ky, fx = p.flip ? kx : p.fw - 1 - kx;
+            tap[ky][kx] = (ky < p.fh && kx < p.fw) ? p.f[fy * p.fs[0] + fx * p.fs[1]] : 0.f;
+        }
+    const T* __restrict__ xn = (const T*)p.x + (int64_t)n * p.inH * p.inW * p.C + cv * V;
+    float acc[RPT][V];
+#pragma unroll
+    for (int r = 0; r < RPT; r++)
+#pragma unroll
+        for (int c = 0; c < V; c++) acc[r][c] = 0.f;
+    auto load_row = [&](int rr, u32x4 (&raw)[FW]) __attribute__((always_inline)) {
+        const int iy = iy0 + rr;
+        const bool row_ok = iy >= 0 && iy < p.inH;
+#pragma unroll
+        for (int kx = 0; kx < FW; kx++) {
+            const int ix = ix0 + kx;
+            const bool ok = row_ok && ix >= 0 && ix < p.inW;
+            const u32x4 v = *(const u32x4*)(xn + ((int64_t)(ok ? iy : 0) * p.inW + (ok ? ix : 0)) * p.C);    // always a valid address
+            raw[kx] = ok ? v : u32x4{0u, 0u, 0u, 0u};
+        }
+    };
+    constexpr int NROWS = (RPT - 1) * DN + FH;            // input rows of the strip's footprint: each is fetched once,
+    u32x4 cur[FW], nxt[FW];                               // one row ahead of the one being accumulated
+    load_row(0, cur);
+#pragma unroll
+    for (int rr = 0; rr < NROWS; rr++) {
+        if (rr + 1 < NROWS) load_row(rr + 1, nxt);
+#pragma unroll
+        for (int kx = 0; kx < FW; kx++) {
+            float xv[V];
+            Vec16<T>::widen(cur[kx], xv);
+#pragma unroll
+            for (int r = 0; r < RPT; r++) {
+                const int ky = rr - r * DN;               // compile-time after unrolling
+                if (ky >= 0 && ky < FH) {
+#pragma unroll
+                    for (int c = 0; c < V; c++) acc[r][c] = fmaf(xv[c], tap[ky][kx], acc[r][c]);
+                }
+            }
+        }
+#pragma unroll
+        for (int kx = 0; kx < FW; kx++) cur[kx] = nxt[kx];
+        __builtin_amdgcn_sched_barrier(0);                // keep the scheduler from hoisting every row's loads to the top (spills)
+    }
+    float bias[V];
+#pragma unroll
+    for (int c = 0; c < V; c++) bias[c] = (p.has_ep && p.bias) ? p.bias[cv * V + c] : 0.f;
+    T* __restrict__ yn = (T*)p.y + (int64_t)n * p.outH * p.outW * p.C + cv * V;
+#pragma unroll
+    for (int r = 0; r < RPT; r++) {
+        const int oy = oy0 + r;
+        if (oy >= p.outH) break;
+        const float nz = (p.has_ep && p.noise) ? p.noise[n * p.noise_bs + (int64_t)oy * p.outW + ox] * p.noise_gain : 0.f;
+        float out[V];
+#pragma unroll
+        for (int c = 0; c < V; c++) {
+            float v = acc[r][c] * p.gain;
+            if (p.has_ep) {
+                v += nz + bias[c];
+                v = (v > 0.f ? v : v * p.slope) * p.act_gain;
+                v = fminf(fmaxf(v, -p.clamp), p.clamp);
+            }
+            out[c] = v;
+        }
+        *(u32x4*)(yn + ((int64_t)oy * p.outW + ox) * p.C) = Vec16<T>::narrow(out);
+    }
+}
+
+template <typename T>
+bool try_channels_last(const Params& p, hipStream_t s, int* st) {
+    constexpr int V = Vec16<T>::N;
+    const bool dense_cl = p.xs[1] == 1 && p.xs[3] == p.C && p.xs[2] == (int64_t)p.inW * p.C && p.xs[0] == (int64_t)p.inH * p.inW * p.C &&
+                          p.ys[1] == 1 && p.ys[3] == p.C && p.ys[2] == (int64_t)p.outW * p.C && p.ys[0] == (int64_t)p.outH * p.outW * p.C;
+    if (!dense_cl || p.C % V != 0 || p.upx != 1 || p.upy != 1 || p.dnx != p.dny || p.dnx > 2 || p.fw > 4 || p.fh > 4 ||
+        !aligned16(p.x) || !aligned16(p.y) || p.N > 65535) return false;
+    constexpr int RPT = 4;                                 // output rows per thread: (RPT*DN + 3) x 4 16-byte loads in flight
+    const int64_t bx = ((int64_t)p.outW * (p.C / V) + 255) / 256;
+    const int by = (p.outH + RPT - 1) / RPT;
+    if (bx > 0x7fffffffLL || by > 65535) return false;
+    const dim3 grid((unsigned)bx, (unsigned)by, (unsigned)p.N);
+    if (p.dnx == 1) hipLaunchKernelGGL((upfirdn2d_cl<T, 4, 4, 1, RPT>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((upfirdn2d_cl<T, 4, 4, 2, RPT>), grid, dim3(256), 0, s, p);
+    *st = launch_status();
+    return true;
+}
+
 template <typename T>
 int run(const Params& p, hipStream_t s, bool allow_tiled) {
     const bool dense_nchw = p.xs[3] == 1 && p.xs[2] == p.inW && p.xs[1] == (int64_t)p.inH * p.inW &&
                             p.xs[0] == (int64_t)p.C * p.inH * p.inW && p.ys[3] == 1 && p.ys[2] == p.outW &&
                             p.ys[1] == (int64_t)p.outH * p.outW && p.ys[0] == (int64_t)p.C * p.outH * p.outW;
     int st = PG_OK;
-    if (allow_tiled && dense_nchw && try_tiled<T>(p, s, &st)) return st;
+    if (allow_tiled && dense_nchw && (!p.has_ep || sizeof(T) == 4) && try_tiled<T>(p, s, &st)) return st;
+    if constexpr (sizeof(T) <= 4) { if (allow_tiled && try_channels_last<T>(p, s, &st)) return st; }
     if (p.has_ep) return PG_ERR_UNSUPPORTED;
     const int64_t total = (int64_t)p.N * p.C * p.outH * p.outW;
     int64_t blocks = (total + 255) / 256;
-    if (blocks > kMaxStreamBlocks * 4) blocks = kMaxStreamBlocks * 4;
+    if (blocks > max_stream_blocks() * 4) blocks = max_stream_blocks() * 4;
     hipLaunchKernelGGL((upfirdn2d_generic<T>), dim3((unsigned)blocks), dim3(256), 0, s, p);
     return launch_status();
 }
@@ -280,7 +434,7 @@ static int upfirdn2d_impl(const void* x, const float* f, void* y, int dtype,
     p.flip = flip ? 1 : 0; p.gain = gain;
     p.has_ep = 0; p.noise = nullptr; p.bias = nullptr; p.noise_bs = 0; p.noise_gain = 0.f; p.slope = 1.f; p.act_gain = 1.f; p.clamp = __builtin_inff();
     if (ep) {
-        if (dtype != PG_F32) return PG_ERR_UNSUPPORTED;
+        if (dtype == PG_F64) return PG_ERR_UNSUPPORTED;
         if (ep->act != 0 && (ep->act < PG_ACT_LINEAR || ep->act > PG_ACT_LRELU)) return PG_ERR_UNSUPPORTED;
         p.has_ep = 1; p.noise = ep->noise; p.noise_bs = ep->noise_batch_stride; p.noise_gain = ep->noise_gain; p.bias = ep->bias;
         p.slope = (ep->act == PG_ACT_RELU) ? 0.f : (ep->act == PG_ACT_LRELU ? ep->alpha : 1.f);

@@ -11,7 +11,9 @@ incremental; the prebuilt library travels with the tree, so a machine without
 ``hipcc`` (or with an up-to-date .so) just loads it.
 
 There is no fallback: if the library can neither be found nor built this raises,
-and the ops built on it raise too.
+and the ops built on it raise too.  A library older than its sources is only loaded when
+``PG_ALLOW_STALE_PLUGIN=1`` says so, and every loaded library must report the ABI version the
+ctypes bindings were written against (``pg_<plugin>_abi_version()`` == ``ABI_VERSION``).
 """
 
 import concurrent.futures
@@ -37,8 +39,12 @@ PLUGIN_SOURCES = {
     'upfirdn2d_plugin': ['upfirdn2d.hip'],
     'patch_routing_plugin': ['patch_routing.hip'],
     'conv2d_plugin': ['conv2d.hip', 'conv2d_inst_k3s1.hip', 'conv2d_inst_k1s1.hip', 'conv2d_inst_k2x2.hip', 'conv2d_inst_k2x1.hip',
-                      'conv2d_inst_k1x2.hip', 'conv2d_inst_k7s1.hip', 'conv2d_inst_k3s2.hip', 'conv2d_inst_k1s2.hip', 'conv2d_inst_wino.hip'],
+                      'conv2d_inst_k1x2.hip', 'conv2d_inst_k7s1.hip', 'conv2d_inst_k3s2.hip', 'conv2d_inst_k1s2.hip', 'conv2d_inst_wino.hip',
+                      'conv2d16.hip', 'conv2d16_inst_k3s1.hip', 'conv2d16_inst_k1s1.hip', 'conv2d16_inst_k2x2.hip', 'conv2d16_inst_k2x1.hip',
+                      'conv2d16_inst_k1x2.hip', 'conv2d16_inst_k3s2.hip'],
 }
+
+ABI_VERSION = 2      # == PG_ABI_VERSION of include/pasta_gan_ops.h; bumped with every struct / signature change
 
 _cached_plugins = dict()
 
@@ -50,6 +56,12 @@ class NativePlugin:
         self.name = name
         self.path = path
         self.lib = ctypes.CDLL(path)
+        probe = getattr(self.lib, 'pg_' + name.replace('_plugin', '') + '_abi_version', None)
+        if probe is None:
+            raise RuntimeError(f'{path} does not export its ABI version; rebuild it from csrc/')
+        probe.restype = ctypes.c_int
+        if probe() != ABI_VERSION:
+            raise RuntimeError(f'{path} implements ABI version {probe()}, the bindings expect {ABI_VERSION}; rebuild it from csrc/')
 
     def __repr__(self):
         return f'<NativePlugin {self.name} at {self.path}>'
@@ -148,7 +160,10 @@ def get_plugin(module_name, sources=None, extra_hipcc_flags=(), build_only=False
         try:
             if not is_up_to_date(module_name, sources, extra_hipcc_flags):
                 if os.path.isfile(so_path) and _find_hipcc() is None:
-                    _log(f'Warning: "{module_name}" is older than its sources and hipcc is missing; loading the stale library.')
+                    if os.environ.get('PG_ALLOW_STALE_PLUGIN', '0') != '1':
+                        raise RuntimeError(f'"{module_name}" is older than its sources and hipcc is missing; '
+                                           'set PG_ALLOW_STALE_PLUGIN=1 to load the stale library anyway')
+                    _log(f'Warning: "{module_name}" is older than its sources and hipcc is missing; loading the stale library (PG_ALLOW_STALE_PLUGIN=1).')
                 else:
                     _log(f'Building native plugin "{module_name}" for {OFFLOAD_ARCH}... ', end='' if verbosity == 'brief' else '\n')
                     try:

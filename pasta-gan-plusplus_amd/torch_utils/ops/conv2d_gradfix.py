@@ -13,9 +13,11 @@ flipped weight; a strided conv's is a transposed conv and vice versa), so it run
 this same autograd Function -- which makes arbitrary-order input gradients (R1, loss_fullbody.py:262-274) native
 too, exactly how the reference's ``_conv2d_gradfix`` recurses (conv2d_gradfix.py:118-135).  The WEIGHT gradient
 (a reduction over pixels, a different GEMM shape) still comes from ``aten::convolution_backward`` and honours
-``no_weight_gradients``; a hand-written wgrad kernel is a later row of SURVEY.md section 8.  Configurations the MFMA kernel does not cover (groups > 1, dilation,
-fp16, exotic kernel sizes) go to PyTorch-ROCm's convolution on the GPU.  CPU tensors raise:
-the product has no CPU path.
+``no_weight_gradients``.  bf16 / fp16 tensors (the discriminator's fp16 blocks, networks.py:444-523; the half-precision
+synthesis stack) run the 16-bit MFMA kernel (``conv2d_mfma16`` -> ``csrc/conv2d_kernel16.h``) on channels-last storage,
+input gradients included.  Configurations the kernels do not cover (groups > 1, dilation, exotic kernel sizes) go to
+PyTorch-ROCm's convolution on the GPU, as does everything when ``enabled`` is set to False.  CPU tensors take the
+pure-torch route of ``impl='ref'`` semantics (torch.nn.functional), like the reference's own fallback (:53-56).
 """
 
 import contextlib
@@ -25,9 +27,10 @@ import torch
 
 from . import _native as nat
 from . import conv2d_mfma
+from . import conv2d_mfma16
 
 native_input_gradients = os.environ.get('PG_NATIVE_DGRAD', '0') == '1'   # opt-in: input gradients through the MFMA kernel.  Measured 10 % slower than aten in the config-4 step (round 1), so off by default
-enabled = False                     # kept for API compatibility (training_loop_fullbody.py:386); the native path is always on
+enabled = True                      # True (default here; the reference's loop sets it, training_loop_fullbody.py:386): hand-written kernels.  False: aten
 weight_gradients_disabled = False   # forcefully disable weight gradients (R1, loss_fullbody.py:266)
 
 
@@ -55,25 +58,37 @@ def _native_ok(x, w, stride, dilation, groups):
             and x.numel() > 0 and w.numel() > 0)       # empty batches / channel sets: nothing to launch, aten returns the empty result
 
 
+def _native16_ok(x, w, stride, dilation, groups):
+    return (x.dtype in conv2d_mfma16.DTYPES and w.dtype == x.dtype and x.ndim == 4 and groups == 1 and dilation == (1, 1)
+            and stride[0] == stride[1] and x.numel() > 0 and w.numel() > 0)
+
+
 def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1):
     assert isinstance(input, torch.Tensor)
-    nat.require_gpu(input, 'conv2d_gradfix.conv2d')
     stride, padding, dilation = _pair(stride), _pair(padding), _pair(dilation)
     kh, kw = int(weight.shape[2]), int(weight.shape[3])
-    if _native_ok(input, weight, stride, dilation, groups) and conv2d_mfma.supported(kh, kw, stride[0]) and min(padding) >= 0:
-        return _Conv2dMfma.apply(input, weight, bias, stride[0], padding, False, (0, 0))
+    if enabled and input.is_cuda and min(padding) >= 0:
+        if _native_ok(input, weight, stride, dilation, groups) and conv2d_mfma.supported(kh, kw, stride[0]):
+            return _Conv2dMfma.apply(input, weight, bias, stride[0], padding, False, (0, 0))
+        if _native16_ok(input, weight, stride, dilation, groups) and conv2d_mfma16.supported(kh, kw, stride[0]):
+            return _Conv2dMfma16.apply(input, weight, bias, stride[0], padding, False, (0, 0))
     return torch.nn.functional.conv2d(input=input, weight=weight, bias=bias, stride=stride, padding=padding, dilation=dilation, groups=groups)
+
+
+def _phases_supported(mod, kh, kw, s):
+    return s > 1 and kh >= s and kw >= s and all(mod.supported(jy, jx, 1) for jy in {-(-(kh - a) // s) for a in range(s)}
+                                                 for jx in {-(-(kw - a) // s) for a in range(s)})
 
 
 def conv_transpose2d(input, weight, bias=None, stride=1, padding=0, output_padding=0, groups=1, dilation=1):
     assert isinstance(input, torch.Tensor)
-    nat.require_gpu(input, 'conv2d_gradfix.conv_transpose2d')
     stride, padding, dilation, output_padding = _pair(stride), _pair(padding), _pair(dilation), _pair(output_padding)
     kh, kw = int(weight.shape[2]), int(weight.shape[3])
-    if (_native_ok(input, weight, stride, dilation, groups) and stride[0] > 1 and kh >= stride[0] and kw >= stride[0]
-            and all(conv2d_mfma.supported(jy, jx, 1) for jy in {-(-(kh - a) // stride[0]) for a in range(stride[0])}
-                    for jx in {-(-(kw - a) // stride[0]) for a in range(stride[0])})):
-        return _Conv2dMfma.apply(input, weight, bias, stride[0], padding, True, output_padding)
+    if enabled and input.is_cuda:
+        if _native_ok(input, weight, stride, dilation, groups) and _phases_supported(conv2d_mfma, kh, kw, stride[0]):
+            return _Conv2dMfma.apply(input, weight, bias, stride[0], padding, True, output_padding)
+        if _native16_ok(input, weight, stride, dilation, groups) and _phases_supported(conv2d_mfma16, kh, kw, stride[0]):
+            return _Conv2dMfma16.apply(input, weight, bias, stride[0], padding, True, output_padding)
     return torch.nn.functional.conv_transpose2d(input=input, weight=weight, bias=bias, stride=stride, padding=padding,
                                                 output_padding=output_padding, groups=groups, dilation=dilation)
 
@@ -117,8 +132,54 @@ class _Conv2dMfma(torch.autograd.Function):
         return dx, dw, db, None, None, None, None
 
 
-def _input_gradient(dy, x_shape, weight, stride, padding, transposed, output_padding):
+class _Conv2dMfma16(torch.autograd.Function):
+    """bf16 / fp16 convolution on the 16-bit MFMA kernel.  Channels are zero-padded to a multiple of 16 (the K of one
+    MFMA) when needed -- the fromrgb layers: 6 / 10 image channels.  Output: channels-last storage, x's dtype."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, padding, transposed, output_padding):
+        n, cin, h, w = x.shape
+        kh, kw = int(weight.shape[2]), int(weight.shape[3])
+        xp, wf = x, weight.detach().float()
+        if cin % 16 != 0:
+            padc = 16 - cin % 16
+            xp = torch.nn.functional.pad(x, (0, 0, 0, 0, 0, padc))
+            wf = torch.nn.functional.pad(wf, (0, 0, 0, 0, 0, 0, 0, padc) if transposed else (0, 0, 0, 0, 0, padc))
+        b32 = bias.detach().float() if bias is not None else None
+        if not transposed:
+            cout = int(weight.shape[0])
+            packed, _, _ = conv2d_mfma16.pack_weight(wf, x.dtype)
+            y = conv2d_mfma16.conv2d_forward(xp, packed, cout, kh, kw, stride=stride, pad=padding, bias=b32)
+        else:
+            cout = int(weight.shape[1])
+            out_hw = ((h - 1) * stride - 2 * padding[0] + kh + output_padding[0], (w - 1) * stride - 2 * padding[1] + kw + output_padding[1])
+            phases = conv2d_mfma16.pack_transposed(wf, x.dtype, stride, padding, (h, w), out_hw)
+            y = conv2d_mfma16.conv_transpose2d_forward(xp, phases, cout, out_hw, stride=stride, bias=b32)
+        ctx.save_for_backward(x, weight)
+        ctx.cfg = (stride, padding, transposed, output_padding, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        stride, padding, transposed, output_padding, has_bias = ctx.cfg
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = _input_gradient(dy, x.shape, weight, stride, padding, transposed, output_padding, fn=_Conv2dMfma16, mod=conv2d_mfma16)
+        want_w = ctx.needs_input_grad[1] and not weight_gradients_disabled
+        want_b = has_bias and ctx.needs_input_grad[2]
+        if dx is None and ctx.needs_input_grad[0] or want_w or want_b:
+            mask = [dx is None and ctx.needs_input_grad[0], want_w, want_b]
+            gx, dw, db = torch.ops.aten.convolution_backward(
+                dy, x, weight, [weight.shape[1 if transposed else 0]] if has_bias else None,
+                [stride, stride], list(padding), [1, 1], transposed, list(output_padding), 1, mask)
+            dx = gx if mask[0] else dx
+        return dx, dw, db, None, None, None, None
+
+
+def _input_gradient(dy, x_shape, weight, stride, padding, transposed, output_padding, fn=None, mod=None):
     """d(loss)/dx of y = conv(x, w) (or conv_transpose) as another native convolution; None if that geometry is not covered."""
+    _Conv2dMfma, conv2d_mfma = (fn or globals()['_Conv2dMfma']), (mod or globals()['conv2d_mfma'])
     kh, kw = int(weight.shape[2]), int(weight.shape[3])
     _, _, h, w = x_shape
     if not transposed:

@@ -1,0 +1,233 @@
+"""ctypes binding of the 16-bit (bf16 / fp16) MFMA convolution of ``conv2d_plugin`` (csrc/conv2d16.hip,
+csrc/conv2d_kernel16.h): channels-last activations, fp32 accumulation, the StyleGAN2 tail in the epilogue.
+
+No counterpart in the reference -- there cuDNN runs the half-precision convolutions behind ``conv2d_gradfix``
+(torch_utils/ops/conv2d_gradfix.py:35-43) for the discriminator's fp16 blocks (training/networks.py:444-523) and the
+fp16 synthesis blocks (networks.py:2147-2194).  Forward only; gradients are attached in ``conv2d_gradfix``.
+
+Tensors keep PyTorch's logical NCHW shape; the kernels want ``torch.channels_last`` storage (NHWC) and produce it.
+"""
+
+import ctypes
+import os
+
+import torch
+
+from . import _native as nat
+from . import conv2d_mfma
+
+ACT_INDEX = conv2d_mfma.ACT_INDEX
+FUSED_ACTS = conv2d_mfma.FUSED_ACTS
+
+# (KH, KW, stride) geometries instantiated in csrc/conv2d16_inst_*.hip
+SUPPORTED = {(3, 3, 1), (1, 1, 1), (2, 2, 1), (2, 1, 1), (1, 2, 1), (3, 3, 2)}
+DTYPES = (torch.bfloat16, torch.float16)
+
+
+class Fusion16(ctypes.Structure):
+    """Mirror of ``pg_conv2d16_fusion`` (include/pasta_gan_ops.h)."""
+    _fields_ = [('out_scale', ctypes.c_void_p), ('noise', ctypes.c_void_p), ('noise_batch_stride', ctypes.c_int64), ('noise_gain', ctypes.c_float),
+                ('bias', ctypes.c_void_p), ('act', ctypes.c_int), ('alpha', ctypes.c_float), ('gain', ctypes.c_float), ('clamp', ctypes.c_float),
+                ('residual', ctypes.c_void_p)]
+
+
+_lib = None
+
+
+def _init():
+    global _lib
+    if _lib is None:
+        lib = conv2d_mfma._init().lib
+        i, f, vp, i64 = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_int64
+        pi, p64 = ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int64)
+        lib.pg_conv2d16_packed_size.restype = i64
+        lib.pg_conv2d16_packed_size.argtypes = [i, i, i, i]
+        lib.pg_conv2d16_pack_weight.restype = i
+        lib.pg_conv2d16_pack_weight.argtypes = [vp, vp, i, i, i, i, i, pi, i, pi, i, f, i, i, vp, vp, i, vp]
+        fwd = [vp, vp, vp, i, i, i, i, i, i, i, i, i, i, i, i, i, i, i64, p64, i, i, i, i, ctypes.POINTER(Fusion16)]
+        lib.pg_conv2d16_forward.restype = i
+        lib.pg_conv2d16_forward.argtypes = fwd + [vp]
+        lib.pg_conv2d16_splitk_plan.restype = i
+        lib.pg_conv2d16_splitk_plan.argtypes = [i] * 8
+        lib.pg_conv2d16_forward_splitk.restype = i
+        lib.pg_conv2d16_forward_splitk.argtypes = fwd + [vp, i, vp]
+        lib.pg_conv1x1_small16.restype = i
+        lib.pg_conv1x1_small16.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, i64, i, f, vp]
+        _lib = lib
+    return _lib
+
+
+def supported(kh, kw, stride):
+    return (int(kh), int(kw), int(stride)) in SUPPORTED
+
+
+def to_channels_last(x):
+    """NHWC storage of a logical [N, C, H, W] tensor (a no-op when it already is channels-last)."""
+    return x.contiguous(memory_format=torch.channels_last)
+
+
+def _f32(t, name, numel=None):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise nat.NativeOpError(f'conv2d_mfma16: {name} must be a GPU tensor')
+    t = t.detach().to(torch.float32).contiguous()
+    if numel is not None and t.numel() != numel:
+        raise nat.NativeOpError(f'conv2d_mfma16: {name} has {t.numel()} elements, expected {numel}')
+    return t
+
+
+def pack_weight(w, dtype, scale=1.0, flip=False, transpose_oi=False, taps=None, styles=None, dcoefs=None):
+    """float32 OIHW (IOHW when `transpose_oi`) weights -> the 16-bit kernel layout, one copy per style row when `styles`
+    ([N, Cin]) and / or `dcoefs` ([N, Cout]) are given: T(w * scale * styles[n, ci] * dcoefs[n, co]) -- the per-sample
+    weights of the reference's fused modulated convolution (networks.py:85-94).  `taps` = (rows, cols) index lists
+    selects a sub-kernel (the phases of a transposed convolution).  Returns (packed, per_sample_stride or 0, (kh, kw))."""
+    lib = _init()
+    assert dtype in DTYPES
+    w = _f32(w, 'weight')
+    if transpose_oi:
+        cin, cout, kh, kw = w.shape
+    else:
+        cout, cin, kh, kw = w.shape
+    ty, tx = (list(taps[0]), list(taps[1])) if taps is not None else (list(range(kh)), list(range(kw)))
+    n = 1
+    if styles is not None:
+        styles = _f32(styles, 'styles')
+        n = styles.shape[0]
+        assert styles.shape[1] == cin
+    if dcoefs is not None:
+        dcoefs = _f32(dcoefs, 'dcoefs', None)
+        n = dcoefs.shape[0]
+        assert dcoefs.shape[1] == cout and (styles is None or styles.shape[0] == n)
+    per = lib.pg_conv2d16_packed_size(cout, cin, len(ty), len(tx))
+    packed = torch.empty([n * per], dtype=dtype, device=w.device)
+    ay, ax = (ctypes.c_int * len(ty))(*ty), (ctypes.c_int * len(tx))(*tx)
+    with torch.cuda.device(w.device):
+        st = lib.pg_conv2d16_pack_weight(nat.ptr(w), nat.ptr(packed), nat.PG_DTYPE[dtype], cout, cin, kh, kw, ay, len(ty), ax, len(tx),
+                                         float(scale), int(bool(flip)), int(bool(transpose_oi)), nat.ptr(styles), nat.ptr(dcoefs), n, nat.stream_of(w))
+    nat.check(st, 'pg_conv2d16_pack_weight')
+    return packed, (per if (styles is not None or dcoefs is not None) else 0), (len(ty), len(tx))
+
+
+def conv2d_forward(x, packed, cout, kh, kw, stride=1, pad=(0, 0), out_hw=None, y=None, out_step=(1, 1), out_off=(0, 0), sample_stride=0,
+                   out_dtype=None, out_scale=None, noise=None, noise_gain=1.0, bias=None, act='linear', alpha=0.0, gain=1.0, clamp=None, residual=None):
+    """One launch of the 16-bit MFMA convolution.  `x`: logical [N, Cin, H, W] bf16 / fp16, Cin % 16 == 0 (converted to
+    channels-last storage if it is not); `packed` from `pack_weight` (`sample_stride` = its per-sample stride for
+    modulated weights).  Writes y[n, co, oy*step+off, ox*step+off]; allocates a channels-last `y` of x's dtype (or a
+    contiguous float32 one for out_dtype=torch.float32) when none is given."""
+    lib = _init()
+    if x.dtype not in DTYPES or not x.is_cuda or x.ndim != 4:
+        raise nat.NativeOpError('conv2d_mfma16: x must be a 4-D bf16 / fp16 GPU tensor')
+    x = to_channels_last(x)
+    n, cin, h, w = x.shape
+    if cin % 16 != 0:
+        raise nat.NativeOpError('conv2d_mfma16: Cin must be a multiple of 16 (pad the channels)')
+    pad_y, pad_x = pad
+    if out_hw is None:
+        out_hw = ((h + 2 * pad_y - kh) // stride + 1, (w + 2 * pad_x - kw) // stride + 1)
+    oh, ow = int(out_hw[0]), int(out_hw[1])
+    out_dtype = out_dtype or x.dtype
+    if y is None:
+        assert tuple(out_step) == (1, 1) and tuple(out_off) == (0, 0)
+        y = torch.empty([n, cout, oh, ow], dtype=out_dtype, device=x.device,
+                        memory_format=torch.contiguous_format if out_dtype == torch.float32 else torch.channels_last)
+    else:
+        assert y.dtype == out_dtype and y.device == x.device and y.shape[0] == n and y.shape[1] == cout
+    fz = Fusion16()
+    keep = []
+
+    def dev(t, name, numel):
+        t = _f32(t, name, numel)
+        if t is None:
+            return None
+        keep.append(t)
+        return t.data_ptr()
+
+    fz.out_scale = dev(out_scale, 'out_scale', n * cout)
+    if noise is not None:
+        noise = _f32(noise, 'noise')
+        if noise.numel() == oh * ow:
+            fz.noise_batch_stride = 0
+        elif noise.numel() == n * oh * ow:
+            fz.noise_batch_stride = oh * ow
+        else:
+            raise nat.NativeOpError('conv2d_mfma16: noise must have OH*OW or N*OH*OW elements')
+        keep.append(noise)
+        fz.noise = noise.data_ptr()
+    fz.noise_gain = float(noise_gain)
+    fz.bias = dev(bias, 'bias', cout)
+    fz.act, fz.alpha, fz.gain = ACT_INDEX[act], float(alpha), float(gain)
+    fz.clamp = -1.0 if clamp is None else float(clamp)
+    if residual is not None:
+        if residual.dtype != y.dtype or residual.shape != y.shape or residual.stride() != y.stride():
+            raise nat.NativeOpError('conv2d_mfma16: residual must match y in dtype, shape and strides')
+        keep.append(residual)
+        fz.residual = residual.data_ptr()
+    args = [nat.ptr(x), nat.ptr(packed), nat.ptr(y), nat.PG_DTYPE[x.dtype], nat.PG_DTYPE[out_dtype], n, cin, h, w, cout, kh, kw, int(stride),
+            int(pad_y), int(pad_x), oh, ow, int(sample_stride), nat.i64arr(y.stride()), int(out_step[0]), int(out_step[1]), int(out_off[0]), int(out_off[1]),
+            ctypes.byref(fz)]
+    tl = conv2d_mfma._timeline
+    with torch.cuda.device(x.device):
+        if tl is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+        ksplit = 1
+        if os.environ.get('PG_CONV_SPLITK', '1') != '0':
+            ksplit = lib.pg_conv2d16_splitk_plan(n, cin, oh, ow, cout, kh, kw, int(stride))
+        if ksplit > 1:
+            ws = torch.empty([ksplit * n * cout * oh * ow], dtype=torch.float32, device=x.device)
+            st = lib.pg_conv2d16_forward_splitk(*args, nat.ptr(ws), ksplit, nat.stream_of(x))
+        else:
+            st = lib.pg_conv2d16_forward(*args, nat.stream_of(x))
+        if tl is not None:
+            ev1.record()
+            tl.append(((kh, kw, int(stride), 'mfma16', f'N{n} {cin}->{cout} {h}x{w} {str(x.dtype)[6:]}'), 2.0 * n * cout * oh * ow * cin * kh * kw, ev0, ev1,
+                       x.element_size() * (x.numel() + n * cout * oh * ow)))
+    nat.check(st, 'pg_conv2d16_forward')
+    return y
+
+
+def pack_transposed(w_iohw, dtype, stride, pad, in_hw, out_hw, scale=1.0, styles=None, dcoefs=None):
+    """Per-phase packed weights of conv_transpose2d(x, w_iohw, stride, padding=pad): list of (phase, packed, sample_stride)."""
+    kh, kw = int(w_iohw.shape[2]), int(w_iohw.shape[3])
+    phases = conv2d_mfma.transposed_phases(kh, kw, stride, pad[0], pad[1], in_hw, out_hw)
+    if phases is None or not all(supported(len(ph['ky']), len(ph['kx']), 1) for ph in phases):
+        return None
+    out = []
+    for ph in phases:
+        packed, per, _ = pack_weight(w_iohw, dtype, scale=scale, transpose_oi=True, taps=(ph['ky'], ph['kx']), styles=styles, dcoefs=dcoefs)
+        out.append((ph, packed, per))
+    return out
+
+
+def conv_transpose2d_forward(x, packed_phases, cout, out_hw, stride=2, **fusion):
+    """Run the phases of `pack_transposed` into one dense channels-last [N, Cout, OH, OW] output."""
+    n = x.shape[0]
+    y = torch.empty([n, cout, out_hw[0], out_hw[1]], dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    x = to_channels_last(x)
+    for ph, packed, per in packed_phases:
+        conv2d_forward(x, packed, cout, len(ph['ky']), len(ph['kx']), stride=1, pad=ph['pad'], out_hw=ph['out_hw'], y=y,
+                       out_step=(stride, stride), out_off=ph['off'], sample_stride=per, **fusion)
+    return y
+
+
+def conv1x1_small(x, w, styles=None, bias=None, skip=None, clamp=None):
+    """The ToRGB / parsing head (networks.py:1957-1967) as one streaming pass: float32 NCHW
+    clamp(sum_c x[n,c,p] * w[o,c] * styles[n,c] + bias[o]) + skip, x 16-bit channels-last, Cout <= 8."""
+    lib = _init()
+    x = to_channels_last(x)
+    n, cin, h, wd = x.shape
+    w = _f32(w, 'weight').reshape(w.shape[0], -1)
+    cout = w.shape[0]
+    assert w.shape[1] == cin
+    styles, bias = _f32(styles, 'styles', n * cin), _f32(bias, 'bias', cout)
+    y = torch.empty([n, cout, h, wd], dtype=torch.float32, device=x.device)
+    if skip is not None:
+        if skip.dtype != torch.float32 or skip.shape != y.shape:
+            raise nat.NativeOpError('conv1x1_small: skip must be float32 [N, Cout, H, W]')
+        skip = skip.contiguous()
+    with torch.cuda.device(x.device):
+        st = lib.pg_conv1x1_small16(nat.ptr(x), nat.ptr(w), nat.ptr(styles), nat.ptr(bias), nat.ptr(skip), nat.ptr(y), nat.PG_DTYPE[x.dtype],
+                                    n, cin, h * wd, cout, -1.0 if clamp is None else float(clamp), nat.stream_of(x))
+    nat.check(st, 'pg_conv1x1_small16')
+    return y

@@ -1,0 +1,235 @@
+"""GPU parity tests of the 16-bit (bf16 / fp16) MFMA convolution (csrc/conv2d_kernel16.h) through its C ABI.
+
+Two kinds of check:
+  * EXACT: small-integer inputs and weights make every product and every partial sum exactly representable in fp32
+    (and the 16-bit roundings of inputs lossless), so the float32-output mode must equal an fp64 convolution bit for
+    bit -- any indexing slip in the packing, the swizzled LDS image, the split-K slices or the phase decomposition
+    shows up as an integer-sized error;
+  * TOLERANCE: random inputs against an fp64 convolution of the SAME 16-bit-rounded operands; the only error left is
+    the fp32 accumulation order and the final rounding to the output dtype:  |err| <= 2^-8 |ref| + tiny for bf16,
+    2^-11 |ref| for fp16 (half an ulp each, doubled for the fused residual add).
+"""
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+DTYPES = [torch.bfloat16, torch.float16]
+ULP = {torch.bfloat16: 2.0 ** -8, torch.float16: 2.0 ** -11}
+
+
+@pytest.fixture(scope='module', autouse=True)
+def _native():
+    assert torch.cuda.is_available(), 'these tests need the MI355X'
+    from torch_utils import custom_ops
+    custom_ops.verbosity = 'none'
+    from torch_utils.ops import conv2d_mfma16
+    assert conv2d_mfma16._init() is not None
+
+
+def _ints(gen, shape, lo, hi):
+    return torch.randint(lo, hi + 1, shape, generator=gen).float()
+
+
+def _ref_conv(x, w, stride=1, padding=0, transposed=False):
+    x, w = x.double().cpu(), w.double().cpu()
+    if transposed:
+        return F.conv_transpose2d(x, w, stride=stride, padding=padding)
+    return F.conv2d(x, w, stride=stride, padding=padding)
+
+
+GEOMS = [  # (kh, kw, stride, pad)
+    (3, 3, 1, 1), (1, 1, 1, 0), (2, 2, 1, 1), (2, 1, 1, 0), (1, 2, 1, 0), (3, 3, 2, 1), (3, 3, 2, 0), (3, 3, 1, 0), (3, 3, 1, 2),
+]
+SHAPES = [  # (n, cin, cout, h, w): ragged tiles, several m-blocks, partial k chunks, odd sizes
+    (2, 32, 64, 33, 45), (1, 48, 40, 17, 17), (3, 16, 24, 8, 70), (1, 80, 136, 20, 33),
+]
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['bf16', 'fp16'])
+@pytest.mark.parametrize('geom', GEOMS, ids=[f'k{g[0]}x{g[1]}s{g[2]}p{g[3]}' for g in GEOMS])
+@pytest.mark.parametrize('shape', SHAPES, ids=[f'n{s[0]}c{s[1]}o{s[2]}_{s[3]}x{s[4]}' for s in SHAPES])
+def test_conv16_exact_f32_out(dtype, geom, shape):
+    from torch_utils.ops import conv2d_mfma16 as M
+    kh, kw, stride, pad = geom
+    n, cin, cout, h, w = shape
+    if h + 2 * pad < kh or w + 2 * pad < kw:
+        pytest.skip('image smaller than the kernel')
+    gen = torch.Generator().manual_seed(hash((geom, shape)) & 0xffff)
+    x = _ints(gen, [n, cin, h, w], -3, 3)
+    wt = _ints(gen, [cout, cin, kh, kw], -2, 2)
+    packed, per, _ = M.pack_weight(wt.to(DEV), dtype)
+    y = M.conv2d_forward(x.to(DEV, dtype), packed, cout, kh, kw, stride=stride, pad=(pad, pad), out_dtype=torch.float32)
+    ref = _ref_conv(x, wt, stride=stride, padding=pad)
+    assert y.shape == ref.shape
+    assert torch.equal(y.double().cpu(), ref), float((y.double().cpu() - ref).abs().max())
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['bf16', 'fp16'])
+@pytest.mark.parametrize('shape', [(2, 32, 64, 33, 45), (1, 64, 32, 40, 40), (2, 16, 8, 16, 16)], ids=['a', 'b', 'c'])
+def test_conv16_vector_epilogue_exact(dtype, shape):
+    """Channels-last 16-bit output (16-byte stores after the half-wave exchange): sparse small-integer weights keep every
+    result an integer of magnitude <= 256, exact in bf16 and fp16."""
+    from torch_utils.ops import conv2d_mfma16 as M
+    n, cin, cout, h, w = shape
+    gen = torch.Generator().manual_seed(7)
+    x = _ints(gen, [n, cin, h, w], -1, 1)
+    wt = _ints(gen, [cout, cin, 3, 3], -1, 1) * (torch.rand([cout, cin, 3, 3], generator=gen) < 0.1)
+    res = _ints(gen, [n, cout, h, w], -8, 8)
+    packed, _, _ = M.pack_weight(wt.to(DEV), dtype)
+    bias = _ints(gen, [cout], -4, 4)
+    r16 = res.to(DEV, dtype).contiguous(memory_format=torch.channels_last)
+    y = M.conv2d_forward(x.to(DEV, dtype), packed, cout, 3, 3, pad=(1, 1), bias=bias.to(DEV), residual=r16)
+    assert y.dtype == dtype and y.is_contiguous(memory_format=torch.channels_last)
+    ref = _ref_conv(x, wt, padding=1) + bias.double().reshape(1, -1, 1, 1) + res.double()
+    assert float(ref.abs().max()) <= 256
+    assert torch.equal(y.double().cpu(), ref), float((y.double().cpu() - ref).abs().max())
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['bf16', 'fp16'])
+def test_conv16_fused_tail_random(dtype):
+    """Per-sample (modulated, demodulated) weights + noise + bias + lrelu + gain + clamp + residual on random data."""
+    from torch_utils.ops import conv2d_mfma16 as M
+    from torch_utils.ops import conv2d_mfma
+    n, cin, cout, h, w = 3, 64, 96, 37, 50
+    gen = torch.Generator().manual_seed(11)
+    x = torch.randn([n, cin, h, w], generator=gen).to(dtype)
+    wt = torch.randn([cout, cin, 3, 3], generator=gen)
+    styles = torch.randn([n, cin], generator=gen) + 1
+    noise = torch.randn([h, w], generator=gen)
+    bias = torch.randn([cout], generator=gen)
+    res = torch.randn([n, cout, h, w], generator=gen).to(dtype)
+    dco = conv2d_mfma.modconv_dcoefs(wt.to(DEV), styles.to(DEV))
+    packed, per, _ = M.pack_weight(wt.to(DEV), dtype, styles=styles.to(DEV), dcoefs=dco)
+    assert per > 0
+    y = M.conv2d_forward(x.to(DEV), packed, cout, 3, 3, pad=(1, 1), sample_stride=per, noise=noise.to(DEV), noise_gain=0.3, bias=bias.to(DEV),
+                         act='lrelu', alpha=0.2, gain=np.sqrt(2), clamp=2.5, residual=res.to(DEV).contiguous(memory_format=torch.channels_last))
+    # reference on the same rounded operands: the per-sample weights exactly as the kernel sees them
+    wmod = (wt.double()[None] * styles.double()[:, None, :, None, None])
+    d = (wmod.square().sum(dim=[2, 3, 4]) + 1e-8).rsqrt()
+    assert torch.allclose(d.float(), dco.cpu(), rtol=1e-5)
+    w16 = ((wt[None] * styles[:, None, :, None, None]) * dco.cpu()[:, :, None, None, None]).to(dtype).double()
+    ref = torch.stack([F.conv2d(x[i:i + 1].double(), w16[i], padding=1)[0] for i in range(n)])
+    ref = ref + noise.double() * 0.3 + bias.double().reshape(1, -1, 1, 1)
+    ref = torch.where(ref > 0, ref, ref * 0.2) * np.sqrt(2)
+    ref = ref.clamp(-2.5, 2.5) + res.double()
+    err = (y.double().cpu() - ref).abs()
+    bound = 2 * ULP[dtype] * ref.abs() + 1e-3
+    assert bool((err <= bound).all()), float((err - bound).max())
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['bf16', 'fp16'])
+@pytest.mark.parametrize('hw', [(8, 8), (16, 16), (13, 21)], ids=['8', '16', '13x21'])
+def test_conv16_transposed_phases_exact(dtype, hw):
+    """Stride-2 transposed 3x3 convolution as four gather-form phase launches == conv_transpose2d."""
+    from torch_utils.ops import conv2d_mfma16 as M
+    n, cin, cout = 2, 32, 48
+    h, w = hw
+    gen = torch.Generator().manual_seed(3)
+    x = _ints(gen, [n, cin, h, w], -3, 3)
+    wt = _ints(gen, [cin, cout, 3, 3], -2, 2)          # IOHW
+    out_hw = ((h - 1) * 2 + 3, (w - 1) * 2 + 3)
+    phases = M.pack_transposed(wt.to(DEV), dtype, 2, (0, 0), (h, w), out_hw)
+    assert phases is not None and len(phases) == 4
+    # float32 view of the result through the scalar path: run each phase into a float32 NCHW tensor
+    y = torch.zeros([n, cout, *out_hw], dtype=torch.float32, device=DEV)
+    xd = x.to(DEV, dtype)
+    for ph, packed, per in phases:
+        M.conv2d_forward(xd, packed, cout, len(ph['ky']), len(ph['kx']), pad=ph['pad'], out_hw=ph['out_hw'], y=y, out_step=(2, 2), out_off=ph['off'],
+                         out_dtype=torch.float32)
+    ref = _ref_conv(x, wt, stride=2, transposed=True)
+    assert torch.equal(y.double().cpu(), ref), float((y.double().cpu() - ref).abs().max())
+    # and the 16-bit channels-last form on a value range that stays exact
+    y16 = M.conv_transpose2d_forward((x.sign()).to(DEV, dtype), M.pack_transposed((wt.sign() * (wt.abs() > 1)).to(DEV), dtype, 2, (0, 0), (h, w), out_hw), cout, out_hw)
+    ref16 = _ref_conv(x.sign(), wt.sign() * (wt.abs() > 1), stride=2, transposed=True)
+    assert float(ref16.abs().max()) <= 256
+    assert torch.equal(y16.double().cpu(), ref16)
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['bf16', 'fp16'])
+def test_conv16_splitk_exact(dtype):
+    """Low-resolution wide layers take the split-K route (few tiles, long K): same integers, bit for bit."""
+    from torch_utils.ops import conv2d_mfma16 as M
+    n, cin, cout, h, w = 1, 512, 128, 8, 8
+    lib = M._init()
+    assert lib.pg_conv2d16_splitk_plan(n, cin, h, w, cout, 3, 3, 1) > 1
+    gen = torch.Generator().manual_seed(5)
+    x = _ints(gen, [n, cin, h, w], -2, 2)
+    wt = _ints(gen, [cout, cin, 3, 3], -1, 1)
+    bias = _ints(gen, [cout], -3, 3)
+    packed, _, _ = M.pack_weight(wt.to(DEV), dtype)
+    y = M.conv2d_forward(x.to(DEV, dtype), packed, cout, 3, 3, pad=(1, 1), bias=bias.to(DEV), out_dtype=torch.float32)
+    ref = _ref_conv(x, wt, padding=1) + bias.double().reshape(1, -1, 1, 1)
+    assert torch.equal(y.double().cpu(), ref)
+    y16 = M.conv2d_forward(x.to(DEV, dtype), packed, cout, 3, 3, pad=(1, 1), bias=bias.to(DEV), act='relu', clamp=200.0)
+    ref16 = ref.clamp(0, 200)
+    err = (y16.double().cpu() - ref16).abs()
+    assert bool((err <= ULP[dtype] * ref16.abs()).all())
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['bf16', 'fp16'])
+def test_conv16_full_size_properties(dtype):
+    """BASELINE config-5 size (N=4, 32 channels, 1024^2): linearity in the input and the delta-kernel identity, which
+    need no reference at that size."""
+    from torch_utils.ops import conv2d_mfma16 as M
+    n, c, r = 4, 32, 1024
+    gen = torch.Generator().manual_seed(9)
+    x = _ints(gen, [n, c, r, r], -4, 4).to(DEV, dtype).contiguous(memory_format=torch.channels_last)
+    delta = torch.zeros([c, c, 3, 3])
+    delta[torch.arange(c), torch.arange(c), 1, 1] = 1
+    pk, _, _ = M.pack_weight(delta.to(DEV), dtype)
+    y = M.conv2d_forward(x, pk, c, 3, 3, pad=(1, 1))
+    assert torch.equal(y, x)
+    wt = _ints(gen, [c, c, 3, 3], -1, 1) * (torch.rand([c, c, 3, 3], generator=gen) < 0.15)
+    pw, _, _ = M.pack_weight(wt.to(DEV), dtype)
+    a = M.conv2d_forward(x, pw, c, 3, 3, pad=(1, 1), out_dtype=torch.float32)
+    b = M.conv2d_forward(x + x, pw, c, 3, 3, pad=(1, 1), out_dtype=torch.float32)
+    assert torch.equal(b, a + a)
+    # a crop against the reference convolution
+    ref = _ref_conv(x[:1, :, :40, :40].float(), wt, padding=1)[:, :, :38, :38]
+    assert torch.equal(a[:1, :, :38, :38].double().cpu(), ref)
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['bf16', 'fp16'])
+def test_conv1x1_small_head(dtype):
+    from torch_utils.ops import conv2d_mfma16 as M
+    n, cin, h, w = 2, 64, 33, 47
+    gen = torch.Generator().manual_seed(13)
+    x = torch.randn([n, cin, h, w], generator=gen).to(dtype)
+    for cout in (3, 7):
+        wt = torch.randn([cout, cin, 1, 1], generator=gen)
+        styles = torch.randn([n, cin], generator=gen)
+        bias = torch.randn([cout], generator=gen)
+        skip = torch.randn([n, cout, h, w], generator=gen)
+        y = M.conv1x1_small(x.to(DEV), wt.to(DEV), styles.to(DEV), bias.to(DEV), skip.to(DEV), clamp=3.0)
+        wm = wt.double()[None, :, :, 0, 0] * styles.double()[:, None, :]
+        ref = torch.einsum('nchw,noc->nohw', x.double(), wm) + bias.double().reshape(1, -1, 1, 1)
+        ref = ref.clamp(-3, 3) + skip.double()
+        assert float((y.double().cpu() - ref).abs().max()) <= 2e-4
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['bf16', 'fp16'])
+def test_conv2d_gradfix_16bit_routes_and_grads(dtype):
+    """conv2d_gradfix on half-precision tensors: native forward (also for a channel count that needs padding), native
+    input gradient, against PyTorch's own convolution in fp32 on the same rounded operands."""
+    from torch_utils.ops import conv2d_gradfix
+    gen = torch.Generator().manual_seed(17)
+    for cin, cout, k, stride, pad, transposed in ((6, 32, 1, 1, 0, False), (32, 48, 3, 1, 1, False), (32, 32, 3, 2, 1, False), (32, 16, 3, 2, 0, True)):
+        x = torch.randn([2, cin, 20, 24], generator=gen).to(DEV, dtype).requires_grad_(True)
+        wshape = [cin, cout, k, k] if transposed else [cout, cin, k, k]
+        wt = (torch.randn(wshape, generator=gen) / np.sqrt(cin * k * k)).to(DEV, dtype).requires_grad_(True)
+        op = conv2d_gradfix.conv_transpose2d if transposed else conv2d_gradfix.conv2d
+        y = op(x, wt, stride=stride, padding=pad)
+        x32, w32 = x.detach().float().requires_grad_(True), wt.detach().float().requires_grad_(True)
+        ref = (F.conv_transpose2d if transposed else F.conv2d)(x32, w32, stride=stride, padding=pad)
+        assert y.dtype == dtype and y.shape == ref.shape
+        tol = 2 * ULP[dtype]
+        assert float((y.float() - ref).abs().max()) <= tol * float(ref.abs().max()) + 1e-3
+        dy = torch.randn(ref.shape, generator=gen).to(DEV, dtype)
+        gx, gw = torch.autograd.grad(y, [x, wt], dy)
+        rx, rw = torch.autograd.grad(ref, [x32, w32], dy.float())
+        assert float((gx.float() - rx).abs().max()) <= tol * float(rx.abs().max()) + 1e-3
+        assert float((gw.float() - rw).abs().max()) <= 4 * tol * float(rw.abs().max()) + 1e-2

@@ -125,6 +125,98 @@ def run_generator(args, rank, world, dev, dist):
                                           images_per_gpu_per_step=n, global_batch=n * world, parallelism=f'replicas x{world}'))), flush=True)
 
 
+CFG5 = dict(w_dim=512, img_resolution=1024, img_channels=3, channel_base=32768, conv_clamp=256)
+BF16_MFMA_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md, "Peak BF16/FP16 MFMA" (dense)
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md, "HBM3E peak BW" (spec; 6.29 TB/s measured copy rate)
+
+
+def cpu_baseline_stack(channel_max, max_seconds=60.0):
+    """The float32 oracle stack (oracle/network_ref.py SynthesisStack, a port) on the host cores, N=1: the blocks up to 256^2 of
+    the same 1024^2 network (a bounded sample: the two top blocks alone are ~60 % of the FLOPs and minutes of CPU time)."""
+    from oracle import network_ref as NR
+    from detgen import fill_module_
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    threads = max(1, min(16, avail))
+    torch.set_num_threads(threads)
+    sample_res = 256
+    net = fill_module_(NR.SynthesisStack(**dict(CFG5, img_resolution=sample_res, channel_max=channel_max)), 'cfg5.').eval()
+    ws = torch.randn([1, net.num_ws, 512], generator=torch.Generator().manual_seed(0))
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        net(ws, noise_mode='const')
+    dt = time.perf_counter() - t0
+    return dict(value=round(1.0 / dt, 5), unit=f'{sample_res}^2-prefix images/s', cores=threads, kind='port',
+                sample=f'oracle/network_ref.py SynthesisStack fwd, N=1, fp32: blocks 8^2..{sample_res}^2 of the 1024^2 stack (same channel widths), '
+                       f'one image, {dt:.1f} s; host reports {avail} logical CPUs')
+
+
+def run_stack(args, rank, world, dev, dist):
+    """BASELINE config 5 (--mode bf16_1024): the StyleGAN2 block stack (SynthesisLayer x2 + ToRGB + skip-image upsample per
+    resolution, no SPADE) at 1024^2, N=4 per GPU, every block in bf16 with fp32 accumulation.  The 16-bit
+    convolution kernel is near the machine's ridge, so both rooflines of its launches are reported: HBM (algorithmic bytes =
+    2*(numel(x) + numel(y)) per launch) as `roofline`, the matrix rate next to it."""
+    from training import networks, replicas
+    from torch_utils.ops import conv2d_mfma
+    from detgen import fill_module_
+    n = args.batch if args.batch != BATCH_PER_GPU else 4
+    net = networks.SynthesisStack(num_fp16_res=8, half_dtype=torch.bfloat16, channel_max=args.channel_max, **CFG5)
+    net = fill_module_(net, 'cfg5.').to(dev).eval()
+    ws = torch.randn([n, net.num_ws, 512], generator=torch.Generator().manual_seed(rank)).to(dev)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            img = net(ws, noise_mode='const')
+        barrier()
+        timeline = conv2d_mfma.start_timeline()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            img = net(ws, noise_mode='const')
+        barrier()
+        elapsed = time.perf_counter() - t0
+        conv2d_mfma.stop_timeline()
+    assert torch.isfinite(img).all() and img.shape == (n, 3, 1024, 1024)
+    elapsed = replicas.max_over_ranks(elapsed, device=dev)
+    if rank != 0:
+        return
+    rows = [(geo, fl, e0.elapsed_time(e1) * 1e-3, by) for geo, fl, e0, e1, by in timeline]
+    dom = [r for r in rows if r[0][3] == 'mfma16']
+    t_dom = sum(r[2] for r in dom)
+    gbs = sum(r[3] for r in dom) / max(t_dom, 1e-12) / 1e9
+    tfl = sum(r[1] for r in dom) / max(t_dom, 1e-12) / 1e12
+    top = [r for r in dom if '1024x1024' in r[0][4] or '512x512' in r[0][4]]
+    line = dict(metric='1024-res bf16 StyleGAN2-stack images/sec (SynthesisStack fwd)', value=round(args.steps * n * world / elapsed, 3), unit='images/s',
+                n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(1e3 * elapsed / args.steps, 3), higher_is_better=True, scaling='weak',
+                vs_baseline=None, dtype='bf16', data='synthetic',
+                config=dict(workload=f'BASELINE config 5: StyleGAN2 block stack 8^2..1024^2 (SynthesisLayer x2 + ToRGB + skip upsample per resolution), '
+                                     f'channel_base 32768, channel_max {args.channel_max}, all blocks bf16 (fp32 accumulate), eval, noise_mode=const, random-init weights',
+                            images_per_gpu_per_step=n, global_batch=n * world, parallelism=f'replicas x{world}'),
+                roofline=dict(bound='hbm', kernel='conv2d_mfma16<bf16,...> (channels-last implicit GEMM, v_mfma_f32_32x32x16_bf16; all its launches of a step)',
+                              achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(gbs / HBM_PEAK_GBS, 4), traffic=None,
+                              bytes_counted='2 * (numel(x) + numel(y)) per launch (weights excluded)',
+                              mfma_tflops=round(tfl, 1), mfma_frac=round(tfl / BF16_MFMA_PEAK_TFLOPS, 4),
+                              launches_per_step=len(dom) // max(args.steps, 1), conv_time_frac_of_step=round(t_dom / elapsed, 4),
+                              top_res_gbs=round(sum(r[3] for r in top) / max(sum(r[2] for r in top), 1e-12) / 1e9, 1)))
+    if world == 1 and not args.no_cpu_baseline:
+        line['cpu_baseline'] = cpu_baseline_stack(args.channel_max)
+    if args.conv_breakdown:
+        groups = {}
+        for geo, fl, tm, by in rows:
+            g = groups.setdefault(geo, [0, 0.0, 0.0, 0.0])
+            g[0] += 1; g[1] += tm; g[2] += fl; g[3] += by
+        with open(args.conv_breakdown, 'w') as f:
+            f.write('kh,kw,stride,algorithm,shape,launches_per_step,avg_us,ms_per_step,algorithmic_tflops,algorithmic_gbs\n')
+            for geo, (cnt, tm, fl, by) in sorted(groups.items(), key=lambda kv: -kv[1][1]):
+                f.write(f'{geo[0]},{geo[1]},{geo[2]},{geo[3]},{geo[4]},{cnt / args.steps:g},{1e6 * tm / cnt:.1f},{1e3 * tm / args.steps:.3f},{fl / tm / 1e12:.1f},{by / tm / 1e9:.0f}\n')
+    print(json.dumps(line), flush=True)
+
+
 def run_train(args, rank, world, dev, dist):
     """BASELINE config 4 (secondary, --mode train): iterations/s of the 8-phase fullbody G+D step incl. lazy R1, batch 4 per
     GPU, flat-bucket gradient all-reduce over RCCL.  VGG/contextual losses omitted (weights unavailable offline); the
@@ -180,8 +272,10 @@ def main():
     ap.add_argument('--batch', type=int, default=BATCH_PER_GPU, help='images per GPU per step (config 2: 8)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--conv-breakdown', default=None, metavar='CSV', help='also write the per-shape conv launch timeline of the timed steps')
-    ap.add_argument('--mode', choices=['synthesis', 'generator', 'train'], default='synthesis',
-                    help="'synthesis' = the headline (config 2); 'generator' = config 3 (encoders + mapping + synthesis, N=16); 'train' = config 4 step")
+    ap.add_argument('--mode', choices=['synthesis', 'generator', 'train', 'bf16_1024'], default='synthesis',
+                    help="'synthesis' = the headline (config 2); 'generator' = config 3 (encoders + mapping + synthesis, N=16); 'train' = config 4 step; "
+                         "'bf16_1024' = config 5 (StyleGAN2 stack at 1024^2 in bf16, N=4)")
+    ap.add_argument('--channel-max', type=int, default=1024, help="config 5: widest layer (SURVEY 8d: 'channels 1024 -> 32')")
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -201,8 +295,8 @@ def main():
     from torch_utils.ops import conv2d_mfma
     from training import networks, replicas
 
-    if args.mode in ('train', 'generator'):
-        (run_train if args.mode == 'train' else run_generator)(args, rank, world, dev, dist)
+    if args.mode in ('train', 'generator', 'bf16_1024'):
+        dict(train=run_train, generator=run_generator, bf16_1024=run_stack)[args.mode](args, rank, world, dev, dist)
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
@@ -240,9 +334,9 @@ def main():
         # Dominant kernel = the Winograd F(2x2,3x3) convolution (csrc/conv2d_wino.h).  Its matrix work is 16 GEMMs per 2x2 output
         # tile = 4/9 of the direct convolution's multiply-adds, so the MFMA roofline is priced on THOSE flops (`achieved`);
         # the direct-convolution-equivalent rate of the same launches is reported next to it (it can exceed the matrix peak).
-        wino = [(fl, e0.elapsed_time(e1) * 1e-3) for geo, fl, e0, e1 in timeline if geo[3] == 'winograd']
-        allk = [(fl, e0.elapsed_time(e1) * 1e-3) for geo, fl, e0, e1 in timeline]
-        dom = wino if wino else [(fl, tm) for (geo, fl, e0, e1), (_, tm) in zip(timeline, allk) if geo[:3] == (3, 3, 1)]
+        wino = [(fl, e0.elapsed_time(e1) * 1e-3) for geo, fl, e0, e1, _ in timeline if geo[3] == 'winograd']
+        allk = [(fl, e0.elapsed_time(e1) * 1e-3) for geo, fl, e0, e1, _ in timeline]
+        dom = wino if wino else [(fl, tm) for (geo, fl, e0, e1, _b), (_, tm) in zip(timeline, allk) if geo[:3] == (3, 3, 1)]
         work = 4.0 / 9.0 if wino else 1.0
         dom_flops, dom_time = sum(f for f, _ in dom), sum(t for _, t in dom)
         achieved = work * dom_flops / dom_time / 1e12 if dom_time > 0 else 0.0
@@ -274,7 +368,7 @@ def main():
             line['cpu_baseline'] = cpu_baseline()
         if args.conv_breakdown:                                # per (geometry, algorithm, shape, fused stages): launches, time, rate
             groups = {}
-            for geo, fl, e0, e1 in timeline:
+            for geo, fl, e0, e1, _ in timeline:
                 g = groups.setdefault(geo, [0, 0.0, 0.0])
                 g[0] += 1; g[1] += e0.elapsed_time(e1); g[2] += fl
             with open(args.conv_breakdown, 'w') as f:

@@ -266,6 +266,48 @@ class SynthesisBlockFull(nn.Module):
         return x, img, pred_parsing
 
 
+class SynthesisStack(nn.Module):
+    """float32 statement of the plain StyleGAN2 block stack of BASELINE config 5 (SynthesisLayer x2 +
+    ToRGB + skip-image upsample per resolution, no SPADE): the reference's style-branch block (networks.py:2147-2194)
+    without the pose / garment-feature inputs, learned constant input, at any power-of-two resolution.  The reference class
+    is hard-wired to 512^2, so this is the build's own composition of the pinned layers above."""
+
+    def __init__(self, w_dim, img_resolution, img_channels=3, channel_base=32768, channel_max=512, conv_clamp=None, **_):
+        super().__init__()
+        log2 = int(math.log2(img_resolution))
+        self.block_resolutions = [1 << e for e in range(3, log2 + 1)]
+        width = lambda res: min(channel_base // res, channel_max)
+        self.num_ws = 0
+        for res in self.block_resolutions:
+            blk = nn.Module()
+            blk.register_buffer('resample_filter', R.setup_filter([1, 3, 3, 1]))
+            if res == 8:
+                blk.const = nn.Parameter(torch.randn([width(res), res, res]))
+            else:
+                blk.conv0 = SynthesisLayer(width(res // 2), width(res), w_dim=w_dim, resolution=res, up=2, conv_clamp=conv_clamp)
+            blk.conv1 = SynthesisLayer(width(res), width(res), w_dim=w_dim, resolution=res, conv_clamp=conv_clamp)
+            blk.torgb = ToRGBLayerFull(width(res), img_channels, w_dim=w_dim, conv_clamp=conv_clamp)
+            blk.num_conv = 1 if res == 8 else 2
+            setattr(self, f'b{res}', blk)
+            self.num_ws += blk.num_conv + (1 if res == img_resolution else 0)
+
+    def forward(self, ws, noise_mode='const'):
+        x = img = None
+        start = 0
+        for res in self.block_resolutions:
+            blk = getattr(self, f'b{res}')
+            if res == 8:
+                x = blk.const[None].expand(ws.shape[0], -1, -1, -1)
+                x = blk.conv1(x, ws[:, start], noise_mode=noise_mode)
+            else:
+                x = blk.conv0(x, ws[:, start], noise_mode=noise_mode)
+                x = blk.conv1(x, ws[:, start + 1], noise_mode=noise_mode)
+            y, _ = blk.torgb(x, ws[:, start + blk.num_conv])
+            img = y if img is None else R.upsample2d(img, blk.resample_filter) + y
+            start += blk.num_conv
+        return img
+
+
 def nearest_half(x):
     """F.interpolate(x, scale_factor=0.5) in its default 'nearest' mode (networks.py:2255-2256)."""
     return x[:, :, ::2, ::2]

@@ -269,7 +269,7 @@ template <> struct Vec16<bf16_t> {
     static constexpr int N = 8;
     static __device__ __forceinline__ void widen(u32x4 r, float (&o)[8]) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) { o[2 * i] = __builtin_bit_cast(float, r[i] << 16); o[2 * i + 1] = __builtin_bit_cast(float, r[i] & 0xffff0000u); }
+        for (int i = 0; i < 4; i++) { const bf16x2v h = __builtin_bit_cast(bf16x2v, r[i]); o[2 * i] = (float)h[0]; o[2 * i + 1] = (float)h[1]; }
     }
     static __device__ __forceinline__ u32x4 narrow(const float (&v)[8]) {
         u32x4 r;
@@ -293,7 +293,7 @@ template <> struct Vec16<f16_t> {
 };
 
 template <typename T, int FH, int FW, int DN, int RPT>
-__global__ __launch_bounds__(256, 4) void upfirdn2d_cl(Params p) {
+__global__ __launch_bounds__(256, 2) void upfirdn2d_cl(Params p) {
     constexpr int V = Vec16<T>::N;
     const int CV = p.C / V;
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -323,8 +323,12 @@ __global__ __launch_bounds__(256, 4) void upfirdn2d_cl(Params p) {
         for (int kx = 0; kx < FW; kx++) {
             const int ix = ix0 + kx;
             const bool ok = row_ok && ix >= 0 && ix < p.inW;
-            const u32x4 v = *(const u32x4*)(xn + ((int64_t)(ok ? iy : 0) * p.inW + (ok ? ix : 0)) * p.C);    // always a valid address
-            raw[kx] = ok ? v : u32x4{0u, 0u, 0u, 0u};
+            u32x4 v = *(const u32x4*)(xn + ((int64_t)(ok ? iy : 0) * p.inW + (ok ? ix : 0)) * p.C);    // always a valid address
+            // (element-wise: `ok ? v : u32x4{...}` with a scalar condition takes clang's OpenCL vector-select path and
+            // keeps only element 0 of v)
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] = ok ? v[e] : 0u;
+            raw[kx] = v;
         }
     };
     constexpr int NROWS = (RPT - 1) * DN + FH;            // input rows of the strip's footprint: each is fetched once,

@@ -35,14 +35,7 @@ def i64arr(vals):
 def require_gpu(x, opname):
     if x.device.type != 'cuda':
         raise NativeOpError(
-            f'{opname}: this package is MI355X/HIP-only; got a {x.device.type} tensor. '
-            'There is no CPU fallback in the product (the CPU restatement lives in oracle/ and is test-only).')
-
-
-def no_ref(opname):
-    raise NotImplementedError(
-        f"{opname}(impl='ref'): the product ships no reference implementation; "
-        "use oracle/ops_ref.py (test infrastructure) for the CPU restatement.")
+            f'{opname}: this entry point is a hand-written HIP kernel and needs a GPU tensor; got {x.device.type}.')
 
 
 def is_dense(t):

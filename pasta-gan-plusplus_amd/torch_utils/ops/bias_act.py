@@ -3,9 +3,10 @@
 Same public surface as the reference's ``torch_utils/ops/bias_act.py``
 (``bias_act(x, b, dim, act, alpha, gain, clamp, impl)`` :55-89 and the
 ``activation_funcs`` table :23-33), differentiable to second order like
-``BiasActCuda``/``BiasActCudaGrad`` (:129-210), but every evaluation runs the
-hand-written HIP kernel ``csrc/bias_act.hip`` through the C ABI ``pg_bias_act``
-(include/pasta_gan_ops.h).  There is no CPU / pure-torch path in the product.
+``BiasActCuda``/``BiasActCudaGrad`` (:129-210).  Dispatch is the reference's rule (:86-89): GPU tensors with
+``impl='cuda'`` run the hand-written HIP kernel ``csrc/bias_act.hip`` through the C ABI ``pg_bias_act``
+(include/pasta_gan_ops.h) -- and fail loudly if that library is missing; ``impl='ref'`` or a CPU tensor takes the
+plain-torch composition ``_bias_act_torch`` below (autograd differentiates it).
 """
 
 import ctypes
@@ -90,14 +91,10 @@ def _native_bias_act(x, b, xref, yref, dy, grad, dim, act_idx, alpha, gain, clam
 def bias_act(x, b=None, dim=1, act='linear', alpha=None, gain=None, clamp=None, impl='cuda'):
     r"""y = clamp(act(x + b) * gain); arguments as in the reference (bias_act.py:55-84).
 
-    `impl` is kept for signature compatibility: ``'cuda'`` (default) is the HIP kernel;
-    ``'ref'`` raises -- the product has no reference implementation.
+    ``impl='cuda'`` on a GPU tensor = the HIP kernel; ``impl='ref'`` or a CPU tensor = the plain-torch composition.
     """
     assert isinstance(x, torch.Tensor)
     assert impl in ['ref', 'cuda']
-    if impl == 'ref':
-        nat.no_ref('bias_act')
-    nat.require_gpu(x, 'bias_act')
     assert clamp is None or clamp >= 0
     spec = activation_funcs[act]
     alpha = float(alpha if alpha is not None else spec.def_alpha)
@@ -107,7 +104,22 @@ def bias_act(x, b=None, dim=1, act='linear', alpha=None, gain=None, clamp=None, 
         assert isinstance(b, torch.Tensor) and b.ndim == 1
         assert 0 <= dim < x.ndim
         assert b.shape[0] == x.shape[dim]
-    return _BiasAct.apply(x, b, dim, act, alpha, gain, clamp)
+    if impl == 'cuda' and x.device.type == 'cuda':
+        return _BiasAct.apply(x, b, dim, act, alpha, gain, clamp)
+    return _bias_act_torch(x, b, dim, act, alpha, gain, clamp)
+
+
+def _bias_act_torch(x, b, dim, act, alpha, gain, clamp):
+    """The op as four elementwise torch steps, in the order the kernel applies them (bias_act.hip; reference
+    `_bias_act_ref`, bias_act.py:93-123): add the bias along `dim`, activate, scale, clamp (clamp < 0 = off)."""
+    if b is not None:
+        shape = [1] * x.ndim
+        shape[dim] = -1
+        x = x + b.reshape(shape)
+    y = activation_funcs[act].func(x, alpha=alpha)
+    if gain != 1:
+        y = y * gain
+    return y.clamp(-clamp, clamp) if clamp >= 0 else y
 
 
 def _dense(t):

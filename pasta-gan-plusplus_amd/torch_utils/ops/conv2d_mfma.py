@@ -38,8 +38,8 @@ class Fusion(ctypes.Structure):
 
 _plugin = None
 
-# Optional launch timeline for bench.py's roofline: when a list, every pg_conv2d_forward launch appends
-# (geometry, algorithmic FLOPs, start event, end event) recorded on the launch stream.
+# Optional launch timeline for bench.py's roofline: when a list, every convolution launch appends
+# (geometry, algorithmic FLOPs, start event, end event, algorithmic bytes) recorded on the launch stream.
 _timeline = None
 
 
@@ -239,7 +239,8 @@ def conv2d_forward(x, packed, cout, kh, kw, stride=1, pad=(0, 0), out_hw=None, y
                                            ctypes.byref(fz), nat.stream_of(x))
         if _timeline is not None:
             ev1.record()
-            _timeline.append(((kh, kw, int(stride), 'winograd' if winograd else 'direct', f'N{n} {cin}->{cout} {h}x{w}' + (' spade' if spade is not None else '') + (' xf' if in_act != 'linear' else '') + (' mod' if in_scale is not None else '') + (' res' if residual is not None else '')), 2.0 * n * cout * oh * ow * cin * kh * kw, ev0, ev1))
+            _timeline.append(((kh, kw, int(stride), 'winograd' if winograd else 'direct', f'N{n} {cin}->{cout} {h}x{w}' + (' spade' if spade is not None else '') + (' xf' if in_act != 'linear' else '') + (' mod' if in_scale is not None else '') + (' res' if residual is not None else '')), 2.0 * n * cout * oh * ow * cin * kh * kw, ev0, ev1,
+                              4 * (x.numel() + (x2.numel() if x2 is not None else 0) + n * ychan * oh * ow)))
     nat.check(st, 'pg_conv2d_forward')
     return y
 

@@ -1,38 +1,31 @@
-"""a * b + c with broadcast-aware gradients (reference torch_utils/ops/fma.py:15-58).
-Stays a PyTorch-ROCm op here; on the synthesis path it is folded into the conv epilogue
-(csrc/conv2d_kernel.h, `out_scale` / `noise`) and this standalone form is not called."""
+"""``fma(a, b, c) = a * b + c`` as one fused multiply-add with gradients that respect broadcasting (API of the reference's
+torch_utils/ops/fma.py:15).  It exists for ``x * dcoefs + noise`` after a modulated convolution (networks.py:77); on the
+inference route that step lives in the convolution's epilogue (csrc/conv2d_kernel.h, `out_scale` / `noise`), so this
+standalone form only runs on the differentiable route."""
 
 import torch
 
 
-def fma(a, b, c):  # => a * b + c
-    return _Fma.apply(a, b, c)
+class _MulAdd(torch.autograd.Function):
+    """out = addcmul(c, a, b).  Each gradient is the product rule's term reduced back to the operand's own shape with
+    ``Tensor.sum_to_size`` (the inverse of broadcasting); the backward is built from differentiable ops, so higher-order
+    gradients (R1 differentiates through the generator-side fma) come from autograd itself."""
 
-
-def _sum_to_shape(t, shape):
-    """Reduce a broadcast result back to `shape`."""
-    lead = t.ndim - len(shape)
-    assert lead >= 0
-    dims = [i for i in range(t.ndim) if t.shape[i] > 1 and (i < lead or shape[i - lead] == 1)]
-    if dims:
-        t = t.sum(dim=dims, keepdim=True)
-    if lead:
-        t = t.reshape(-1, *t.shape[lead + 1:])
-    assert t.shape == shape
-    return t
-
-
-class _Fma(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b, c):
         ctx.save_for_backward(a, b)
-        ctx.c_shape = c.shape
+        ctx.shapes = (a.shape, b.shape, c.shape)
         return torch.addcmul(c, a, b)
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, grad):
         a, b = ctx.saved_tensors
-        da = _sum_to_shape(dout * b, a.shape) if ctx.needs_input_grad[0] else None
-        db = _sum_to_shape(dout * a, b.shape) if ctx.needs_input_grad[1] else None
-        dc = _sum_to_shape(dout, ctx.c_shape) if ctx.needs_input_grad[2] else None
-        return da, db, dc
+        sa, sb, sc = ctx.shapes
+        need_a, need_b, need_c = ctx.needs_input_grad
+        return ((grad * b).sum_to_size(sa) if need_a else None,
+                (grad * a).sum_to_size(sb) if need_b else None,
+                grad.sum_to_size(sc) if need_c else None)
+
+
+def fma(a, b, c):
+    return _MulAdd.apply(a, b, c)

@@ -4,9 +4,11 @@ Public surface of the reference's ``torch_utils/ops/upfirdn2d.py``: ``setup_filt
 (:72-116), ``upfirdn2d`` (:120-164), ``filter2d`` (:272-304), ``upsample2d``
 (:308-343), ``downsample2d`` (:347-382) and the private helpers its siblings import
 (``_parse_scaling``, ``_parse_padding``, ``_get_filter_size``, :37-68).  Every
-evaluation runs ``csrc/upfirdn2d.hip`` through the C ABI ``pg_upfirdn2d``; the
+GPU evaluation runs ``csrc/upfirdn2d.hip`` through the C ABI ``pg_upfirdn2d``; the
 gradient is another upfirdn2d with the factors swapped (:245-264), so arbitrary
-order derivatives work.  No CPU / pure-torch path exists in the product.
+order derivatives work.  Dispatch is the reference's rule (:161-164): ``impl='cuda'`` on a
+GPU tensor = the HIP kernels (failing loudly if the library is missing); ``impl='ref'`` or
+a CPU tensor = the plain-torch composition ``_upfirdn2d_torch``.
 """
 
 import ctypes
@@ -50,10 +52,14 @@ def upfirdn2d_bias_act(x, f, up=1, down=1, padding=0, flip_filter=False, gain=1,
                        act_gain=1.0, clamp=None):
     """`bias_act(upfirdn2d(x, f, ...) + noise, b, act, gain=act_gain, clamp)` in ONE pass (the tail of an up-sampling
     SynthesisLayer: FIR -> +noise -> bias_act).  Inference only (no autograd); float32 dense NCHW and a 2-D filter the
-    tiled kernel covers, otherwise returns None and the caller composes the separate ops."""
+    tiled kernel covers, or a channels-last tensor (float32 / fp16 / bf16, no up-sampling, filter up to 4 x 4: the
+    channels-last kernel); otherwise returns None and the caller composes the separate ops."""
     nat.require_gpu(x, 'upfirdn2d_bias_act')
     _init()
-    if x.dtype != torch.float32 or x.ndim != 4 or f is None or f.ndim != 2 or act not in _FUSED_ACTS or not x.is_contiguous():
+    if x.ndim != 4 or f is None or f.ndim != 2 or act not in _FUSED_ACTS:
+        return None
+    channels_last = x.shape[1] > 1 and x.stride(1) == 1 and x.is_contiguous(memory_format=torch.channels_last)
+    if not ((x.dtype == torch.float32 and x.is_contiguous()) or (channels_last and x.dtype in (torch.float32, torch.float16, torch.bfloat16))):
         return None
     upx, upy = _parse_scaling(up)
     downx, downy = _parse_scaling(down)
@@ -63,7 +69,8 @@ def upfirdn2d_bias_act(x, f, up=1, down=1, padding=0, flip_filter=False, gain=1,
     ow = (iw * upx + padx0 + padx1 - fw + downx) // downx
     oh = (ih * upy + pady0 + pady1 - fh + downy) // downy
     assert ow >= 1 and oh >= 1
-    y = torch.empty([n, c, oh, ow], dtype=x.dtype, device=x.device)
+    y = torch.empty([n, c, oh, ow], dtype=x.dtype, device=x.device,
+                    memory_format=torch.channels_last if (channels_last and not x.is_contiguous()) else torch.contiguous_format)
     ep = _FirEpilogue()
     keep = []
     if noise is not None:
@@ -217,14 +224,37 @@ class _Upfirdn2d(torch.autograd.Function):
 def upfirdn2d(x, f, up=1, down=1, padding=0, flip_filter=False, gain=1, impl='cuda'):
     r"""Upsample by zero insertion (`up`), pad/crop (`padding`, negative = crop), convolve with `f`
     (true convolution unless `flip_filter`), keep every `down`-th sample, scale by `gain`.
-    Arguments as in the reference (upfirdn2d.py:120-159).  `impl='ref'` raises: HIP only."""
+    Arguments as in the reference (upfirdn2d.py:120-159)."""
     assert isinstance(x, torch.Tensor)
     assert impl in ['ref', 'cuda']
-    if impl == 'ref':
-        nat.no_ref('upfirdn2d')
-    nat.require_gpu(x, 'upfirdn2d')
     assert f is None or (isinstance(f, torch.Tensor) and f.dtype == torch.float32 and not f.requires_grad)
-    return _Upfirdn2d.apply(x, f, _parse_scaling(up), _parse_scaling(down), _parse_padding(padding), bool(flip_filter), gain)
+    if impl == 'cuda' and x.device.type == 'cuda':
+        return _Upfirdn2d.apply(x, f, _parse_scaling(up), _parse_scaling(down), _parse_padding(padding), bool(flip_filter), gain)
+    return _upfirdn2d_torch(x, f, _parse_scaling(up), _parse_scaling(down), _parse_padding(padding), bool(flip_filter), gain)
+
+
+def _upfirdn2d_torch(x, f, up, down, padding, flip_filter, gain):
+    """upfirdn2d from stock torch ops (any device, differentiable to any order): scatter the samples onto the up-sampled
+    grid, pad / crop, depth-wise correlate with the (flipped) taps, keep every down-th sample.  Same arithmetic as the
+    reference's `_upfirdn2d_ref` (upfirdn2d.py:168-208): taps are cast to x's dtype, the gain is split over the passes."""
+    assert x.ndim == 4
+    (upx, upy), (downx, downy), (px0, px1, py0, py1) = up, down, padding
+    n, c, h, w = x.shape
+    if f is None:
+        f = torch.ones([1, 1], dtype=torch.float32, device=x.device)
+    grid = x.new_zeros([n, c, h * upy, w * upx])
+    grid[:, :, ::upy, ::upx] = x                                     # zero stuffing: sample first, then up-1 zeros
+    grid = torch.nn.functional.pad(grid, [max(px0, 0), max(px1, 0), max(py0, 0), max(py1, 0)])
+    grid = grid[:, :, max(-py0, 0):grid.shape[2] - max(-py1, 0), max(-px0, 0):grid.shape[3] - max(-px1, 0)]
+    taps = (f * (gain ** (f.ndim / 2))).to(x.dtype)
+    if not flip_filter:                                              # true convolution = correlation with the flipped taps
+        taps = taps.flip(list(range(taps.ndim)))
+    depthwise = lambda t, k: torch.nn.functional.conv2d(t, k[None, None].repeat(c, 1, 1, 1), groups=c)
+    if taps.ndim == 2:
+        grid = depthwise(grid, taps)
+    else:                                                            # separable: rows, then columns
+        grid = depthwise(depthwise(grid, taps[None, :]), taps[:, None])
+    return grid[:, :, ::downy, ::downx]
 
 
 def filter2d(x, f, padding=0, flip_filter=False, gain=1, impl='cuda'):

@@ -27,6 +27,7 @@ import torch.nn as nn
 from torch_utils import misc
 from torch_utils.ops import bias_act
 from torch_utils.ops import conv2d_mfma
+from torch_utils.ops import conv2d_mfma16
 from torch_utils.ops import conv2d_resample
 from torch_utils.ops import fma
 from torch_utils.ops import upfirdn2d
@@ -40,6 +41,11 @@ def _needs_graph(*tensors):
 
 def _fast_ok(x, *others):
     return x.is_cuda and x.dtype == torch.float32 and not _needs_graph(x, *others)
+
+
+def _fast16_ok(x, *others):
+    """Inference route of the half-precision blocks: bf16 / fp16 activations on the 16-bit MFMA kernel."""
+    return x.is_cuda and x.dtype in conv2d_mfma16.DTYPES and x.shape[1] % 16 == 0 and not _needs_graph(x, *others)
 
 
 class _PackCache:
@@ -77,33 +83,42 @@ def _up2_geometry(kh, kw, fw, fh, padding, up=2):
 
 
 @misc.profiled_function
-def modulated_conv2d(
-    x,                          # Input tensor of shape [batch_size, in_channels, in_height, in_width].
-    weight,                     # Weight tensor of shape [out_channels, in_channels, kernel_height, kernel_width].
-    styles,                     # Modulation coefficients of shape [batch_size, in_channels].
-    noise           = None,     # Optional noise tensor to add to the output activations.
-    up              = 1,        # Integer upsampling factor.
-    down            = 1,        # Integer downsampling factor.
-    padding         = 0,        # Padding with respect to the upsampled image.
-    resample_filter = None,     # Low-pass filter to apply when resampling activations (upfirdn2d.setup_filter()).
-    demodulate      = True,     # Apply weight demodulation?
-    flip_weight     = True,     # False = convolution, True = correlation (matches torch.nn.functional.conv2d).
-    fused_modconv   = True,     # Reference: grouped-conv form vs scale-activations form; both are one kernel here.
-    _cache          = None,     # (private) packed-weight cache of the calling layer
-    _epilogue       = None,     # (private) dict(bias, act, alpha, gain, clamp, residual) folded into the same launch
-):
-    batch_size = x.shape[0]
-    out_channels, in_channels, kh, kw = weight.shape
-    misc.assert_shape(weight, [out_channels, in_channels, kh, kw])
-    misc.assert_shape(x, [batch_size, in_channels, None, None])
-    misc.assert_shape(styles, [batch_size, in_channels])
+def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, resample_filter=None, demodulate=True,
+                     flip_weight=True, fused_modconv=True, _cache=None, _epilogue=None):
+    """StyleGAN2 weight-(de)modulated convolution; signature of the reference (training/networks.py:37-49).
 
-    if _fast_ok(x, weight, styles, noise) and down == 1 and up in (1, 2) and isinstance(padding, int):
+    x [N, I, H, W]; weight [O, I, kh, kw]; styles [N, I]; noise broadcastable to the output or None; up / down integer
+    resampling factors with `resample_filter` from upfirdn2d.setup_filter(); padding relative to the up-sampled image;
+    flip_weight=True means correlation (what F.conv2d computes).  `fused_modconv` picks between the reference's two
+    formulations (per-sample grouped weights, :85-94, or scaled activations, :73-82); they differ only in rounding and
+    both are ONE launch here.  Private: `_cache` = the calling layer's packed-weight cache, `_epilogue` =
+    dict(bias, act, alpha, gain, clamp, residual) folded into the same launch.
+    """
+    n = x.shape[0]
+    cout, cin, kh, kw = weight.shape
+    misc.assert_shape(weight, [cout, cin, kh, kw])
+    misc.assert_shape(x, [n, cin, None, None])
+    misc.assert_shape(styles, [n, cin])
+
+    plain_geometry = down == 1 and up in (1, 2) and isinstance(padding, int)
+    if plain_geometry and _fast_ok(x, weight, styles, noise):
         out = _modconv_fast(x, weight, styles, noise, up, padding, resample_filter, demodulate, flip_weight, _cache, _epilogue)
         if out is not None:
             return out
-    assert _epilogue is None
-    return _modconv_graph(x, weight, styles, noise, up, down, padding, resample_filter, demodulate, flip_weight, fused_modconv)
+    if plain_geometry and _fast16_ok(x, weight, styles, noise):
+        out = _modconv_fast16(x, weight, styles, noise, up, padding, resample_filter, demodulate, flip_weight, _epilogue)
+        if out is not None:
+            return out
+    y = _modconv_graph(x, weight, styles, noise, up, down, padding, resample_filter, demodulate, flip_weight, fused_modconv)
+    if _epilogue:                # the native layer declined (uncovered geometry): compose the tail from the ops
+        ep = dict(_epilogue)
+        res = ep.pop('residual', None)
+        b = ep.get('bias')
+        y = bias_act.bias_act(y, b.to(y.dtype) if b is not None else None, act=ep.get('act', 'linear'), alpha=ep.get('alpha'),
+                              gain=ep.get('gain', 1.0), clamp=ep.get('clamp'))
+        if res is not None:
+            y = y + res.to(y.dtype)
+    return y
 
 
 def _modconv_fast(x, weight, styles, noise, up, padding, resample_filter, demodulate, flip_weight, cache, epilogue):
@@ -150,6 +165,43 @@ def _modconv_fast(x, weight, styles, noise, up, padding, resample_filter, demodu
     return y
 
 
+def _modconv_fast16(x, weight, styles, noise, up, padding, resample_filter, demodulate, flip_weight, epilogue):
+    """bf16 / fp16 inference route: the reference's fused form (networks.py:85-94) -- per-sample weights
+    T(w * styles * dcoefs) -- packed by one small kernel, then ONE launch of the 16-bit MFMA convolution per output phase
+    with noise / bias / activation / gain / clamp (/ residual) in its epilogue; for up=2 the tail rides in the FIR pass."""
+    cout, cin, kh, kw = (int(v) for v in weight.shape)
+    n, _, h, w = x.shape
+    ep = dict(epilogue) if epilogue else {}
+    w32, s32 = weight.detach().float(), styles.detach().float()
+    dcoefs = conv2d_mfma.modconv_dcoefs(w32, s32) if demodulate else None
+    if up == 1:
+        if not conv2d_mfma16.supported(kh, kw, 1):
+            return None
+        packed, per, _ = conv2d_mfma16.pack_weight(w32, x.dtype, flip=not flip_weight, styles=s32, dcoefs=dcoefs)
+        return conv2d_mfma16.conv2d_forward(x, packed, cout, kh, kw, pad=(padding, padding), sample_stride=per, noise=noise, **ep)
+    fw, fh = upfirdn2d._get_filter_size(resample_filter)
+    tpad, fir_pad = _up2_geometry(kh, kw, fw, fh, padding)
+    out_hw = ((h - 1) * 2 - 2 * tpad[0] + kh, (w - 1) * 2 - 2 * tpad[1] + kw)
+    wt = w32.transpose(0, 1)
+    if flip_weight:
+        wt = wt.flip([2, 3])
+    phases = conv2d_mfma16.pack_transposed(wt.contiguous(), x.dtype, 2, tpad, (h, w), out_hw, styles=s32, dcoefs=dcoefs)
+    if phases is None:
+        return None
+    y = conv2d_mfma16.conv_transpose2d_forward(x, phases, cout, out_hw, stride=2)
+    res = ep.pop('residual', None)
+    b = ep.get('bias')
+    fused = upfirdn2d.upfirdn2d_bias_act(y, resample_filter, padding=fir_pad, gain=4, noise=noise, b=b, act=ep.get('act', 'linear'),
+                                         alpha=ep.get('alpha') or 0.0, act_gain=ep.get('gain', 1.0), clamp=ep.get('clamp'))
+    if fused is None:
+        y = upfirdn2d.upfirdn2d(y, resample_filter, padding=fir_pad, gain=4)
+        if noise is not None:
+            y = y.add_(noise.to(y.dtype))
+        fused = bias_act.bias_act(y, b.to(y.dtype) if b is not None else None, act=ep.get('act', 'linear'), alpha=ep.get('alpha'),
+                                  gain=ep.get('gain', 1.0), clamp=ep.get('clamp'))
+    return fused if res is None else fused.add_(res)
+
+
 def _modconv_graph(x, weight, styles, noise, up, down, padding, resample_filter, demodulate, flip_weight, fused_modconv):
     """Differentiable composition (the two forms of networks.py:61-94)."""
     n = x.shape[0]
@@ -194,15 +246,16 @@ class FullyConnectedLayer(nn.Module):
         self.bias_gain = lr_multiplier
 
     def forward(self, x):
-        w = self.weight.to(x.dtype) * self.weight_gain
-        b = self.bias
-        if b is not None:
-            b = b.to(x.dtype)
-            if self.bias_gain != 1:
-                b = b * self.bias_gain
-        if self.activation == 'linear' and b is not None:
-            return torch.addmm(b.unsqueeze(0), x, w.t())
-        return bias_act.bias_act(x.matmul(w.t()), b, act=self.activation)
+        """Equalised-LR dense layer (reference networks.py:115-128): the runtime gains scale the operands, a linear layer
+        is one GEMM with the bias in its epilogue (hipBLASLt), anything else hands bias + activation to bias_act."""
+        weight = self.weight.to(x.dtype).mul(self.weight_gain)
+        bias = None
+        if self.bias is not None:
+            bias = self.bias.to(x.dtype)
+            bias = bias if self.bias_gain == 1 else bias.mul(self.bias_gain)
+        if self.activation == 'linear':
+            return torch.nn.functional.linear(x, weight, bias)
+        return bias_act.bias_act(torch.nn.functional.linear(x, weight), bias, act=self.activation)
 
 
 class _ConvBase(nn.Module):
@@ -427,7 +480,8 @@ class SynthesisLayer(nn.Module):
             noise = self.noise_const * self.noise_strength
         act_gain = self.act_gain * gain
         act_clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
-        if _fast_ok(x, self.weight, self.bias, styles, noise) and self.activation in conv2d_mfma.FUSED_ACTS:
+        fusable = _fast_ok(x, self.weight, self.bias, styles, noise) or _fast16_ok(x, self.weight, self.bias, styles, noise)
+        if fusable and self.activation in conv2d_mfma.FUSED_ACTS:
             ep = dict(bias=self.bias, act=self.activation, alpha=bias_act.activation_funcs[self.activation].def_alpha, gain=act_gain, clamp=act_clamp)
             return modulated_conv2d(x=x, weight=self.weight, styles=styles, noise=noise, up=self.up, padding=self.padding,
                                     resample_filter=self.resample_filter, flip_weight=(self.up == 1), fused_modconv=fused_modconv,
@@ -457,6 +511,12 @@ class _ToRGBBase(nn.Module):
     def forward(self, x, w, fused_modconv=True, skip_img=None):
         """Returns (rgb, pred_parsing); `skip_img` (private) is added to rgb inside the same launch."""
         styles = self.affine(w) * self.weight_gain
+        if _fast16_ok(x, self.weight, self.bias, styles, skip_img) and self.weight.shape[2:] == (1, 1):
+            # half-precision inference: each head is one streaming pass (float32 image out, skip image added in it)
+            pred_parsing = None
+            if self.is_last and self.is_style:
+                pred_parsing = conv2d_mfma16.conv1x1_small(x, self.m_weight1, styles, self.m_bias1, clamp=self.conv_clamp)
+            return conv2d_mfma16.conv1x1_small(x, self.weight, styles, self.bias, skip=skip_img, clamp=self.conv_clamp), pred_parsing
         fast = _fast_ok(x, self.weight, self.bias, styles, skip_img)
         pred_parsing = None
         if self.is_last and self.is_style:
@@ -486,6 +546,9 @@ class ToRGBLayerFull_v1_v4(_ToRGBBase):
 
 
 class _SynthesisBlockBase(nn.Module):
+    """One resolution of the generator (reference networks.py:2086-2194 / 1971-2082): [conv0 up=2] -> conv1 ->
+    [merge_conv with the warped-garment features] -> [parsing-conditioned SPADE block] -> skip image += ToRGB.
+    Constructor arguments, sub-module names and creation order follow the reference (checkpoint contract)."""
     TORGB = ToRGBLayerFull_v1_v5
     TEXTURE = False
 
@@ -497,64 +560,59 @@ class _SynthesisBlockBase(nn.Module):
         self.is_last, self.architecture, self.use_fp16 = is_last, architecture, use_fp16
         self.channels_last = (use_fp16 and fp16_channels_last)
         self.register_buffer('resample_filter', upfirdn2d.setup_filter(resample_filter))
-        self.num_conv = 0
-        self.num_torgb = 0
-        if in_channels == 0:
-            self.const = nn.Parameter(torch.randn([out_channels, resolution, resolution]))   # kept for checkpoint parity; bypassed (networks.py:2157-2161)
-        if in_channels != 0:
-            self.conv0 = SynthesisLayer(in_channels, out_channels, w_dim=w_dim, resolution=resolution, up=2,
-                                        resample_filter=resample_filter, conv_clamp=conv_clamp, channels_last=self.channels_last, **layer_kwargs)
-            self.num_conv += 1
-        self.conv1 = SynthesisLayer(out_channels, out_channels, w_dim=w_dim, resolution=resolution,
-                                    conv_clamp=conv_clamp, channels_last=self.channels_last, **layer_kwargs)
-        self.num_conv += 1
-        if is_last or architecture == 'skip':
+        first = in_channels == 0
+        layer = dict(w_dim=w_dim, resolution=resolution, conv_clamp=conv_clamp, channels_last=self.channels_last, **layer_kwargs)
+        if first:
+            self.const = nn.Parameter(torch.randn([out_channels, resolution, resolution]))   # checkpoint parity only: the pose feature replaces it
+        else:
+            self.conv0 = SynthesisLayer(in_channels, out_channels, up=2, resample_filter=resample_filter, **layer)
+        self.conv1 = SynthesisLayer(out_channels, out_channels, **layer)
+        self.num_conv = 1 if first else 2
+        self.has_torgb = is_last or architecture == 'skip'
+        self.num_torgb = int(self.has_torgb)
+        if self.has_torgb:
             self.torgb = self.TORGB(out_channels, img_channels, w_dim=w_dim, conv_clamp=conv_clamp, channels_last=self.channels_last,
                                     is_last=is_last, is_style=is_style)
-            self.num_torgb += 1
-        if in_channels != 0 and architecture == 'resnet':
+        if not first and architecture == 'resnet':
             self.skip = Conv2dLayer(in_channels, out_channels, kernel_size=1, bias=False, up=2, resample_filter=resample_filter, channels_last=self.channels_last)
-        if self.resolution > 32:
+        if resolution > 32:
             self.merge_conv = Conv2dLayer(out_channels + 64, out_channels, kernel_size=1, resample_filter=resample_filter, channels_last=self.channels_last)
         if self.TEXTURE:
             self.spade_b512 = Spade_ResBlockV4_512(out_channels, out_channels, spade_channels=1)
 
     def _forward(self, x, img, ws, pose_feature, cat_feat, parsing, force_fp32, fused_modconv, **layer_kwargs):
         misc.assert_shape(ws, [None, self.num_conv + self.num_torgb, self.w_dim])
-        w_iter = iter(ws.unbind(dim=1))
-        dtype = torch.float16 if self.use_fp16 and not force_fp32 else torch.float32
-        memory_format = torch.channels_last if self.channels_last and not force_fp32 else torch.contiguous_format
-        if fused_modconv is None:
-            fused_modconv = (not self.training) and (dtype == torch.float32 or int(ws.shape[0]) == 1)
+        half = self.use_fp16 and not force_fp32
+        fmt = dict(dtype=torch.float16 if half else torch.float32,
+                   memory_format=torch.channels_last if (self.channels_last and not force_fp32) else torch.contiguous_format)
+        if fused_modconv is None:      # the reference's rule (networks.py:2152-2154); both forms are one launch here
+            fused_modconv = (not self.training) and (not half or int(ws.shape[0]) == 1)
+        style = lambda i: ws[:, i]
+        conv = lambda layer, t, i, **kw: layer(t, style(i), fused_modconv=fused_modconv, **kw, **layer_kwargs)
 
-        if self.in_channels == 0:
-            x = pose_feature.to(dtype=dtype, memory_format=memory_format)
+        if self.in_channels == 0:      # 8x8 block: starts from the pose encoder's feature map
+            x = conv(self.conv1, pose_feature.to(**fmt), 0)
         else:
             misc.assert_shape(x, [None, self.in_channels, self.resolution // 2, self.resolution // 2])
-            x = x.to(dtype=dtype, memory_format=memory_format)
+            x = x.to(**fmt)
+            if self.architecture == 'resnet':
+                shortcut = self.skip(x, gain=SQRT_HALF)
+                x = conv(self.conv1, conv(self.conv0, x, 0), 1, gain=SQRT_HALF)
+                x = shortcut.add_(x)
+            else:
+                x = conv(self.conv1, conv(self.conv0, x, 0), 1)
+                if self.resolution > 32:   # mix in the warped-garment feature map: conv1x1(cat([x, feat])) without the copy
+                    x = self.merge_conv(x, x2=cat_feat[str(self.resolution)].to(**fmt))
+                if self.TEXTURE:
+                    x = self.spade_b512(x, parsing)
 
-        if self.in_channels == 0:
-            x = self.conv1(x, next(w_iter), fused_modconv=fused_modconv, **layer_kwargs)
-        elif self.architecture == 'resnet':
-            y = self.skip(x, gain=SQRT_HALF)
-            x = self.conv0(x, next(w_iter), fused_modconv=fused_modconv, **layer_kwargs)
-            x = self.conv1(x, next(w_iter), fused_modconv=fused_modconv, gain=SQRT_HALF, **layer_kwargs)
-            x = y.add_(x)
-        else:
-            x = self.conv0(x, next(w_iter), fused_modconv=fused_modconv, **layer_kwargs)
-            x = self.conv1(x, next(w_iter), fused_modconv=fused_modconv, **layer_kwargs)
-            if x.shape[2] > 32:      # concatenate the warped-garment feature map and mix it in (networks.py:2179-2181)
-                x = self.merge_conv(x, x2=cat_feat[str(x.shape[2])].to(dtype=dtype, memory_format=memory_format))   # conv(cat([x, feat])) without the copy
-            if self.TEXTURE:
-                x = self.spade_b512(x, parsing)
-
-        pred_parsing = None
         if img is not None:
             misc.assert_shape(img, [None, self.img_channels, self.resolution // 2, self.resolution // 2])
             img = upfirdn2d.upsample2d(img, self.resample_filter)
-        if self.is_last or self.architecture == 'skip':
-            y, pred_parsing = self.torgb(x, next(w_iter), fused_modconv=fused_modconv, skip_img=img)   # img + torgb(x) in one launch
-            img = y.to(dtype=torch.float32, memory_format=torch.contiguous_format)
+        pred_parsing = None
+        if self.has_torgb:             # img + torgb(x) in one launch
+            rgb, pred_parsing = self.torgb(x, style(self.num_conv), fused_modconv=fused_modconv, skip_img=img)
+            img = rgb.to(dtype=torch.float32, memory_format=torch.contiguous_format)
         return x, img, pred_parsing
 
 
@@ -581,29 +639,27 @@ def _half_nearest(t):
 
 
 class SynthesisNetworkFull_v18(nn.Module):
+    """The 512^2 try-on generator body (reference networks.py:2198-2327): style branch b8..b512, garment-feature encoder,
+    two SPADE blocks at 256^2 and the texture block at 512^2.  float32 throughout, like the reference (:2223, :2294)."""
+
     def __init__(self, w_dim, img_resolution, img_channels, channel_base=32768, channel_max=512, num_fp16_res=0, **block_kwargs):
         assert img_resolution >= 8 and img_resolution & (img_resolution - 1) == 0
         super().__init__()
         self.w_dim, self.img_resolution, self.img_channels = w_dim, img_resolution, img_channels
         self.img_resolution_log2 = int(np.log2(img_resolution))
-        self.block_resolutions = [2 ** i for i in range(3, self.img_resolution_log2 + 1)]
-        channels_dict = {res: min(channel_base // res, channel_max) for res in self.block_resolutions}
+        self.block_resolutions = [1 << e for e in range(3, self.img_resolution_log2 + 1)]
+        width = lambda res: min(channel_base // res, channel_max)
+        common = dict(w_dim=w_dim, img_channels=img_channels, use_fp16=False, **block_kwargs)
         self.num_ws = 0
         for res in self.block_resolutions:
-            in_channels = channels_dict[res // 2] if res > 8 else 0
-            is_last = (res == self.img_resolution)
-            block = SynthesisBlockFull_v1_v6(in_channels, channels_dict[res], w_dim=w_dim, resolution=res, img_channels=img_channels,
-                                             is_last=is_last, is_style=True, use_fp16=False, **block_kwargs)   # fp32 everywhere (networks.py:2223)
-            self.num_ws += block.num_conv
-            if is_last:
-                self.num_ws += block.num_torgb
+            last = res == img_resolution
+            block = SynthesisBlockFull_v1_v6(width(res // 2) if res > 8 else 0, width(res), resolution=res, is_last=last, is_style=True, **common)
             setattr(self, f'b{res}', block)
-        res = self.block_resolutions[-2]
-        self.spade_b256_1 = Spade_ResBlockV4_512(channels_dict[res], channels_dict[res], spade_channels=128)
-        self.spade_b256_2 = Spade_ResBlockV4_512(channels_dict[res], channels_dict[res], spade_channels=128)
-        res = self.block_resolutions[-1]
-        self.texture_b512 = SynthesisBlockFull_v1_v4(channels_dict[res // 2], channels_dict[res], w_dim=w_dim, resolution=res,
-                                                     img_channels=img_channels, is_last=True, is_style=False, use_fp16=False, **block_kwargs)
+            self.num_ws += block.num_conv + (block.num_torgb if last else 0)
+        mid, top = self.block_resolutions[-2], self.block_resolutions[-1]
+        self.spade_b256_1 = Spade_ResBlockV4_512(width(mid), width(mid), spade_channels=128)
+        self.spade_b256_2 = Spade_ResBlockV4_512(width(mid), width(mid), spade_channels=128)
+        self.texture_b512 = SynthesisBlockFull_v1_v4(width(mid), width(top), resolution=top, is_last=True, is_style=False, **common)
         ngf = 64
         self.spade_encoder = nn.Sequential(
             Conv2dLayer(3, ngf, kernel_size=7, activation='relu'),
@@ -612,62 +668,127 @@ class SynthesisNetworkFull_v18(nn.Module):
         )
 
     def get_spade_feat(self, mask_512, denorm_mask, denorm_input):
-        dt = mask_512.dtype
-        mask_512 = (mask_512 > 0.9).to(dt)
-        mask_256 = (_half_nearest(mask_512) > 0.9).to(dt)
-        denorm_mask_256 = (_half_nearest(denorm_mask) > 0.9).to(dt)
-        valid_mask = ((mask_256 + denorm_mask_256) == 2.0).to(dt)
-        res_mask = mask_256 - valid_mask
-        feat = self.spade_encoder(denorm_input * mask_512 - (1 - mask_512))
-        valid_feat_sum = torch.sum(feat * valid_mask, dim=(2, 3), keepdim=True)
-        valid_mask_sum = torch.sum(valid_mask, dim=(2, 3), keepdim=True)
-        valid_index = (valid_mask_sum > 10).to(dt)
-        valid_mask_sum = valid_mask_sum * valid_index + (256 * 256) * (1 - valid_index)
-        return feat * (1 - res_mask) + (valid_feat_sum / valid_mask_sum) * res_mask
+        """Garment features of one branch (reference :2253-2276): encode the warped garment inside the predicted region,
+        then fill the part of that region the warp did not cover with the mean feature of the part it did cover."""
+        region = mask_512 > 0.9
+        region_256 = _half_nearest(region)
+        covered = region_256 & (_half_nearest(denorm_mask) > 0.9)
+        hole = (region_256 & ~covered).to(denorm_input.dtype)
+        feat = self.spade_encoder(torch.where(region, denorm_input, denorm_input.new_tensor(-1.0)))
+        covered = covered.to(feat.dtype)
+        count = covered.sum(dim=(2, 3), keepdim=True)
+        count = torch.where(count > 10, count, count.new_tensor(256.0 * 256.0))
+        mean = (feat * covered).sum(dim=(2, 3), keepdim=True) / count
+        return feat * (1 - hole) + mean * hole
+
+    def _block_styles(self, ws):
+        """The slice of `ws` each style block consumes: its own convolutions plus the ToRGB that shares the next block's
+        first style vector (reference :2281-2289)."""
+        misc.assert_shape(ws, [None, self.num_ws, self.w_dim])
+        ws = ws.to(torch.float32)
+        out, start = [], 0
+        for res in self.block_resolutions:
+            block = getattr(self, f'b{res}')
+            out.append(ws[:, start:start + block.num_conv + block.num_torgb])
+            start += block.num_conv
+        return out
 
     def forward(self, ws, pose_feat, cat_feat, denorm_upper_input, denorm_lower_input, denorm_upper_mask,
                 denorm_lower_mask, gt_parsing, **block_kwargs):
-        block_ws = []
-        with torch.autograd.profiler.record_function('split_ws'):
-            misc.assert_shape(ws, [None, self.num_ws, self.w_dim])
-            ws = ws.to(torch.float32)
-            w_idx = 0
-            for res in self.block_resolutions:
-                block = getattr(self, f'b{res}')
-                block_ws.append(ws.narrow(1, w_idx, block.num_conv + block.num_torgb))
-                w_idx += block.num_conv
-
-        x = img = None
-        for res, cur_ws in zip(self.block_resolutions, block_ws):
-            x, img, pred_parsing = getattr(self, f'b{res}')(x, img, cur_ws, pose_feat, cat_feat, force_fp32=True, **block_kwargs)
-            if res == 256:
-                x_256, img_256 = x, img      # neither is modified in place afterwards, so no clone is needed
+        styles = self._block_styles(ws)
+        x = img = pred_parsing = None
+        kept = {}
+        for res, w in zip(self.block_resolutions, styles):
+            x, img, pred_parsing = getattr(self, f'b{res}')(x, img, w, pose_feat, cat_feat, force_fp32=True, **block_kwargs)
+            kept[res] = (x, img)       # neither is modified in place afterwards: no clone needed
+        x_256, img_256 = kept[self.block_resolutions[-2]]
 
         if gt_parsing is not None:
             parsing_index = gt_parsing
-        else:   # softmax is monotone per pixel, so argmax(softmax(p)) == argmax(p) (networks.py:2301-2302)
-            parsing_index = torch.argmax(pred_parsing.detach(), dim=1)[:, None, ...].float()
+        else:   # softmax is monotone per pixel: argmax(softmax(p)) == argmax(p) (reference :2301-2302)
+            parsing_index = pred_parsing.detach().argmax(dim=1, keepdim=True).float()
+        upper_mask = ((parsing_index == 1) | (parsing_index == 4)).float()
+        lower_mask = ((parsing_index == 2) | (parsing_index == 3)).float()
 
-        upper_mask = (parsing_index == 1).float() + (parsing_index == 4).float()
-        lower_mask = (parsing_index == 2).float() + (parsing_index == 3).float()
         if _fast_ok(x_256, denorm_upper_input, denorm_lower_input, denorm_upper_mask, denorm_lower_mask) and denorm_upper_mask.dtype == torch.float32:
             # inference route: encoder inputs as in get_spade_feat, then the inpainting + merge of both branches in three launches
-            mu, ml = (upper_mask > 0.9).float(), (lower_mask > 0.9).float()
-            feat_u = self.spade_encoder(denorm_upper_input * mu - (1 - mu))
-            feat_l = self.spade_encoder(denorm_lower_input * ml - (1 - ml))
+            feat_u = self.spade_encoder(torch.where(upper_mask > 0.9, denorm_upper_input, denorm_upper_input.new_tensor(-1.0)))
+            feat_l = self.spade_encoder(torch.where(lower_mask > 0.9, denorm_lower_input, denorm_lower_input.new_tensor(-1.0)))
             spade_feat = conv2d_mfma.spade_feat_assemble(feat_u, feat_l, upper_mask, lower_mask, denorm_upper_mask, denorm_lower_mask)
         else:
-            spade_upper_feat = self.get_spade_feat(upper_mask.detach(), denorm_upper_mask, denorm_upper_input)
-            spade_lower_feat = self.get_spade_feat(lower_mask.detach(), denorm_lower_mask, denorm_lower_input)
-            upper_mask_256 = (_half_nearest(upper_mask) > 0.9).to(upper_mask.dtype)
-            lower_mask_256 = (_half_nearest(lower_mask) > 0.9).to(upper_mask.dtype)
-            spade_feat = spade_upper_feat * upper_mask_256 + spade_lower_feat * lower_mask_256
+            spade_feat = (self.get_spade_feat(upper_mask.detach(), denorm_upper_mask, denorm_upper_input) * (_half_nearest(upper_mask) > 0.9)
+                          + self.get_spade_feat(lower_mask.detach(), denorm_lower_mask, denorm_lower_input) * (_half_nearest(lower_mask) > 0.9))
 
-        x_spade_256 = self.spade_b256_1(x_256, spade_feat)
-        x_spade_256 = self.spade_b256_2(x_spade_256, spade_feat)
-        _, finetune_img, _ = self.texture_b512(x_spade_256, img_256, block_ws[-1], pose_feat, cat_feat, parsing_index,
-                                               force_fp32=True, **block_kwargs)
+        x_spade = self.spade_b256_2(self.spade_b256_1(x_256, spade_feat), spade_feat)
+        _, finetune_img, _ = self.texture_b512(x_spade, img_256, styles[-1], pose_feat, cat_feat, parsing_index, force_fp32=True, **block_kwargs)
         return img, finetune_img, pred_parsing
+
+
+class SynthesisStackBlock(nn.Module):
+    """One resolution of the plain StyleGAN2 stack: [conv0 up=2] -> conv1, skip image = upsample2d(img) + ToRGB(x)."""
+
+    def __init__(self, in_channels, out_channels, w_dim, resolution, img_channels, resample_filter=[1, 3, 3, 1], conv_clamp=None,
+                 half_dtype=None, **layer_kwargs):
+        super().__init__()
+        self.in_channels, self.w_dim, self.resolution, self.img_channels, self.half_dtype = in_channels, w_dim, resolution, img_channels, half_dtype
+        self.register_buffer('resample_filter', upfirdn2d.setup_filter(resample_filter))
+        layer = dict(w_dim=w_dim, resolution=resolution, conv_clamp=conv_clamp, **layer_kwargs)
+        if in_channels == 0:
+            self.const = nn.Parameter(torch.randn([out_channels, resolution, resolution]))
+        else:
+            self.conv0 = SynthesisLayer(in_channels, out_channels, up=2, resample_filter=resample_filter, **layer)
+        self.conv1 = SynthesisLayer(out_channels, out_channels, **layer)
+        self.torgb = ToRGBLayerFull_v1_v5(out_channels, img_channels, w_dim=w_dim, conv_clamp=conv_clamp)
+        self.num_conv = 1 if in_channels == 0 else 2
+        self.num_torgb = 1
+
+    def forward(self, x, img, ws, force_fp32=False, **layer_kwargs):
+        misc.assert_shape(ws, [None, self.num_conv + self.num_torgb, self.w_dim])
+        half = self.half_dtype is not None and not force_fp32
+        fmt = dict(dtype=self.half_dtype if half else torch.float32, memory_format=torch.channels_last if half else torch.contiguous_format)
+        if self.in_channels == 0:
+            x = self.const.to(fmt['dtype'])[None].expand(ws.shape[0], -1, -1, -1).contiguous(memory_format=fmt['memory_format'])
+            x = self.conv1(x, ws[:, 0], **layer_kwargs)
+        else:
+            x = self.conv1(self.conv0(x.to(**fmt), ws[:, 0], **layer_kwargs), ws[:, 1], **layer_kwargs)
+        if img is not None:
+            img = upfirdn2d.upsample2d(img, self.resample_filter)
+        rgb, _ = self.torgb(x, ws[:, self.num_conv], skip_img=img)
+        return x, rgb.to(dtype=torch.float32, memory_format=torch.contiguous_format)
+
+
+class SynthesisStack(nn.Module):
+    """The StyleGAN2 block stack the PASTA-GAN++ style branch derives from (SynthesisLayer x2 + ToRGB + skip-image upsample per
+    resolution; no pose / garment / SPADE inputs), at any power-of-two resolution and with the `num_fp16_res` highest
+    resolutions in `half_dtype` (bf16 or fp16) -- BASELINE config 5 runs it at 1024^2 entirely in bf16.  The reference class
+    is hard-wired to 512^2 float32, so this is an extension built from the same layers."""
+
+    def __init__(self, w_dim, img_resolution, img_channels=3, channel_base=32768, channel_max=512, num_fp16_res=0, half_dtype=torch.float16,
+                 conv_clamp=None, **block_kwargs):
+        assert img_resolution >= 8 and img_resolution & (img_resolution - 1) == 0
+        super().__init__()
+        self.w_dim, self.img_resolution, self.img_channels = w_dim, img_resolution, img_channels
+        log2 = int(np.log2(img_resolution))
+        self.block_resolutions = [1 << e for e in range(3, log2 + 1)]
+        width = lambda res: min(channel_base // res, channel_max)
+        half_from = max(1 << (log2 + 1 - num_fp16_res), 8) if num_fp16_res > 0 else (img_resolution * 2)
+        self.num_ws = 0
+        for res in self.block_resolutions:
+            block = SynthesisStackBlock(width(res // 2) if res > 8 else 0, width(res), w_dim=w_dim, resolution=res, img_channels=img_channels,
+                                        conv_clamp=conv_clamp, half_dtype=half_dtype if res >= half_from else None, **block_kwargs)
+            setattr(self, f'b{res}', block)
+            self.num_ws += block.num_conv + (block.num_torgb if res == img_resolution else 0)
+
+    def forward(self, ws, **block_kwargs):
+        misc.assert_shape(ws, [None, self.num_ws, self.w_dim])
+        ws = ws.to(torch.float32)
+        x = img = None
+        start = 0
+        for res in self.block_resolutions:
+            block = getattr(self, f'b{res}')
+            x, img = block(x, img, ws[:, start:start + block.num_conv + block.num_torgb], **block_kwargs)
+            start += block.num_conv
+        return img
 
 
 # ============================================================================
@@ -676,52 +797,50 @@ class SynthesisNetworkFull_v18(nn.Module):
 # They are built from the same ops, so every convolution below is the MFMA kernel with its bias/activation folded in.
 
 class MappingNetwork(nn.Module):
-    """reference networks.py:184-259."""
+    """Latent / condition -> per-layer style vectors (reference networks.py:184-259).  PASTA-GAN++ runs it with z_dim=0,
+    c_dim=512 (the garment style code) and one layer."""
 
     def __init__(self, z_dim, c_dim, w_dim, num_ws, num_layers=8, embed_features=None, layer_features=None,
                  activation='lrelu', lr_multiplier=0.01, w_avg_beta=0.995):
         super().__init__()
         self.z_dim, self.c_dim, self.w_dim, self.num_ws, self.num_layers, self.w_avg_beta = z_dim, c_dim, w_dim, num_ws, num_layers, w_avg_beta
-        if embed_features is None:
-            embed_features = w_dim
-        if c_dim == 0:
-            embed_features = 0
-        if layer_features is None:
-            layer_features = w_dim
-        features_list = [z_dim + embed_features] + [layer_features] * (num_layers - 1) + [w_dim]
+        embed = 0 if c_dim == 0 else (w_dim if embed_features is None else embed_features)
+        hidden = w_dim if layer_features is None else layer_features
+        widths = [z_dim + embed] + [hidden] * (num_layers - 1) + [w_dim]
         if c_dim > 0:
-            self.embed = FullyConnectedLayer(c_dim, embed_features)
-        for idx in range(num_layers):
-            setattr(self, f'fc{idx}', FullyConnectedLayer(features_list[idx], features_list[idx + 1], activation=activation, lr_multiplier=lr_multiplier))
+            self.embed = FullyConnectedLayer(c_dim, embed)
+        for i, (fan_in, fan_out) in enumerate(zip(widths[:-1], widths[1:])):
+            setattr(self, f'fc{i}', FullyConnectedLayer(fan_in, fan_out, activation=activation, lr_multiplier=lr_multiplier))
         if num_ws is not None and w_avg_beta is not None:
             self.register_buffer('w_avg', torch.zeros([w_dim]))
 
+    def _inputs(self, z, c):
+        parts = []
+        if self.z_dim > 0:
+            misc.assert_shape(z, [None, self.z_dim])
+            parts.append(normalize_2nd_moment(z.to(torch.float32)))
+        if self.c_dim > 0:
+            misc.assert_shape(c, [None, self.c_dim])
+            parts.append(normalize_2nd_moment(self.embed(c.to(torch.float32))))
+        return parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)
+
     def forward(self, z, c, truncation_psi=1, truncation_cutoff=None, skip_w_avg_update=False):
-        x = None
-        with torch.autograd.profiler.record_function('input'):
-            if self.z_dim > 0:
-                misc.assert_shape(z, [None, self.z_dim])
-                x = normalize_2nd_moment(z.to(torch.float32))
-            if self.c_dim > 0:
-                misc.assert_shape(c, [None, self.c_dim])
-                y = normalize_2nd_moment(self.embed(c.to(torch.float32)))
-                x = torch.cat([x, y], dim=1) if x is not None else y
-        for idx in range(self.num_layers):
-            x = getattr(self, f'fc{idx}')(x)
-        if self.w_avg_beta is not None and self.training and not skip_w_avg_update:
-            with torch.autograd.profiler.record_function('update_w_avg'):
-                self.w_avg.copy_(x.detach().mean(dim=0).lerp(self.w_avg, self.w_avg_beta))
+        w = self._inputs(z, c)
+        for i in range(self.num_layers):
+            w = getattr(self, f'fc{i}')(w)
+        track = self.w_avg_beta is not None and self.training and not skip_w_avg_update
+        if track:       # running mean of w, the truncation anchor
+            self.w_avg.copy_(torch.lerp(w.detach().mean(dim=0), self.w_avg, self.w_avg_beta))
         if self.num_ws is not None:
-            with torch.autograd.profiler.record_function('broadcast'):
-                x = x.unsqueeze(1).repeat([1, self.num_ws, 1])
+            w = w[:, None, :].repeat(1, self.num_ws, 1)
         if truncation_psi != 1:
-            with torch.autograd.profiler.record_function('truncate'):
-                assert self.w_avg_beta is not None
-                if self.num_ws is None or truncation_cutoff is None:
-                    x = self.w_avg.lerp(x, truncation_psi)
-                else:
-                    x[:, :truncation_cutoff] = self.w_avg.lerp(x[:, :truncation_cutoff], truncation_psi)
-        return x
+            assert self.w_avg_beta is not None
+            if self.num_ws is None or truncation_cutoff is None:
+                w = torch.lerp(self.w_avg, w, truncation_psi)
+            else:
+                head = w[:, :truncation_cutoff]
+                head.copy_(torch.lerp(self.w_avg, head, truncation_psi))
+        return w
 
 
 class ConstEncoderNetwork(nn.Module):
@@ -818,7 +937,9 @@ class GeneratorFull_v20(nn.Module):
 # convolutions through PyTorch-ROCm (the MFMA kernel is fp32), bias_act / upfirdn2d stay on the HIP kernels.
 
 class DiscriminatorBlock(nn.Module):
-    """reference networks.py:444-523."""
+    """One resolution of the discriminator (reference networks.py:444-523): [fromrgb] -> conv0 -> conv1 (down 2), with
+    a 1x1 down-sampling shortcut in the 'resnet' form.  Half-precision blocks keep their activations channels-last: the
+    layout of the 16-bit MFMA convolution (a storage choice only; the reference leaves it to --nhwc)."""
 
     def __init__(self, in_channels, tmp_channels, out_channels, resolution, img_channels, first_layer_idx, architecture='resnet',
                  activation='lrelu', resample_filter=[1, 3, 3, 1], conv_clamp=None, use_fp16=False, fp16_channels_last=False, freeze_layers=0):
@@ -831,64 +952,61 @@ class DiscriminatorBlock(nn.Module):
         self.register_buffer('resample_filter', upfirdn2d.setup_filter(resample_filter))
         self.num_layers = 0
 
-        def next_trainable():
-            trainable = (self.first_layer_idx + self.num_layers >= freeze_layers)
+        def layer(cin, cout, k, **kw):      # layers are numbered in creation order; the first `freeze_layers` stay fixed
+            idx = self.first_layer_idx + self.num_layers
             self.num_layers += 1
-            return trainable
-        kw = dict(conv_clamp=conv_clamp, channels_last=self.channels_last)
-        if in_channels == 0 or architecture == 'skip':
-            self.fromrgb = Conv2dLayer(img_channels, tmp_channels, kernel_size=1, activation=activation, trainable=next_trainable(), **kw)
-        self.conv0 = Conv2dLayer(tmp_channels, tmp_channels, kernel_size=3, activation=activation, trainable=next_trainable(), **kw)
-        self.conv1 = Conv2dLayer(tmp_channels, out_channels, kernel_size=3, activation=activation, down=2, trainable=next_trainable(),
-                                 resample_filter=resample_filter, **kw)
+            return Conv2dLayer(cin, cout, kernel_size=k, trainable=idx >= freeze_layers, channels_last=self.channels_last, **kw)
+        self.has_fromrgb = in_channels == 0 or architecture == 'skip'
+        if self.has_fromrgb:
+            self.fromrgb = layer(img_channels, tmp_channels, 1, activation=activation, conv_clamp=conv_clamp)
+        self.conv0 = layer(tmp_channels, tmp_channels, 3, activation=activation, conv_clamp=conv_clamp)
+        self.conv1 = layer(tmp_channels, out_channels, 3, activation=activation, down=2, resample_filter=resample_filter, conv_clamp=conv_clamp)
         if architecture == 'resnet':
-            self.skip = Conv2dLayer(tmp_channels, out_channels, kernel_size=1, bias=False, down=2, trainable=next_trainable(),
-                                    resample_filter=resample_filter, channels_last=self.channels_last)
+            self.skip = layer(tmp_channels, out_channels, 1, bias=False, down=2, resample_filter=resample_filter)
 
     def forward(self, x, img, force_fp32=False):
-        dtype = torch.float16 if self.use_fp16 and not force_fp32 else torch.float32
-        memory_format = torch.channels_last if self.channels_last and not force_fp32 else torch.contiguous_format
+        half = self.use_fp16 and not force_fp32
+        fmt = dict(dtype=torch.float16 if half else torch.float32,
+                   memory_format=torch.channels_last if (half or (self.channels_last and not force_fp32)) else torch.contiguous_format)
         if x is not None:
             misc.assert_shape(x, [None, self.in_channels, self.resolution, self.resolution])
-            x = x.to(dtype=dtype, memory_format=memory_format)
-        if self.in_channels == 0 or self.architecture == 'skip':
+            x = x.to(**fmt)
+        if self.has_fromrgb:
             misc.assert_shape(img, [None, self.img_channels, self.resolution, self.resolution])
-            img = img.to(dtype=dtype, memory_format=memory_format)
-            y = self.fromrgb(img)
-            x = x + y if x is not None else y
+            img = img.to(**fmt)
+            feat = self.fromrgb(img)
+            x = feat if x is None else x + feat
             img = upfirdn2d.downsample2d(img, self.resample_filter) if self.architecture == 'skip' else None
-        if self.architecture == 'resnet':
-            y = self.skip(x, gain=SQRT_HALF)
-            x = self.conv0(x)
-            x = self.conv1(x, gain=SQRT_HALF, residual=y)
+        if self.architecture == 'resnet':    # shortcut + conv1(conv0(x)), both scaled by sqrt(1/2); the add rides in conv1
+            x = self.conv1(self.conv0(x), gain=SQRT_HALF, residual=self.skip(x, gain=SQRT_HALF))
         else:
-            x = self.conv0(x)
-            x = self.conv1(x)
-        assert x.dtype == dtype
+            x = self.conv1(self.conv0(x))
+        assert x.dtype == fmt['dtype']
         return x, img
 
 
 class MinibatchStdLayer(nn.Module):
-    """reference networks.py:528-549: per-group stddev over the batch as an extra feature map."""
+    """Appends, per group of `group_size` samples, the mean standard deviation over the group as extra feature maps
+    (reference networks.py:528-549)."""
 
     def __init__(self, group_size, num_channels=1):
         super().__init__()
         self.group_size, self.num_channels = group_size, num_channels
 
     def forward(self, x):
-        N, C, H, W = x.shape
-        G = min(int(self.group_size), int(N)) if self.group_size is not None else int(N)
-        F = self.num_channels
-        c = C // F
-        y = x.reshape(G, -1, F, c, H, W)
-        y = y - y.mean(dim=0)
-        y = (y.square().mean(dim=0) + 1e-8).sqrt()
-        y = y.mean(dim=[2, 3, 4]).reshape(-1, F, 1, 1).repeat(G, 1, H, W)
-        return torch.cat([x, y], dim=1)
+        n, c, h, w = x.shape
+        group = n if self.group_size is None else min(int(self.group_size), int(n))
+        feats = self.num_channels
+        split = x.reshape(group, n // group, feats, c // feats, h, w)        # [group member, group, stat channel, c, h, w]
+        std = (split.var(dim=0, unbiased=False) + 1e-8).sqrt()               # spread of each value across its group
+        stat = std.mean(dim=[2, 3, 4])                                       # [groups, feats]
+        stat_map = stat.reshape(n // group, feats, 1, 1).repeat(group, 1, h, w)
+        return torch.cat([x, stat_map], dim=1)
 
 
 class DiscriminatorEpilogue(nn.Module):
-    """reference networks.py:554-607."""
+    """4x4 head (reference networks.py:554-607): minibatch-std -> conv -> two dense layers -> projection on the
+    conditioning vector."""
 
     def __init__(self, in_channels, cmap_dim, resolution, img_channels, architecture='resnet', mbstd_group_size=4, mbstd_num_channels=1,
                  activation='lrelu', conv_clamp=None):
@@ -904,51 +1022,45 @@ class DiscriminatorEpilogue(nn.Module):
 
     def forward(self, x, img, cmap, force_fp32=False):
         misc.assert_shape(x, [None, self.in_channels, self.resolution, self.resolution])
-        x = x.to(dtype=torch.float32, memory_format=torch.contiguous_format)
+        fp32 = dict(dtype=torch.float32, memory_format=torch.contiguous_format)      # the head always runs in float32
+        x = x.to(**fp32)
         if self.architecture == 'skip':
             misc.assert_shape(img, [None, self.img_channels, self.resolution, self.resolution])
-            x = x + self.fromrgb(img.to(dtype=torch.float32, memory_format=torch.contiguous_format))
+            x = x + self.fromrgb(img.to(**fp32))
         if self.mbstd is not None:
             x = self.mbstd(x)
-        x = self.conv(x)
-        x = self.fc(x.flatten(1))
-        x = self.out(x)
+        score = self.out(self.fc(self.conv(x).flatten(1)))
         if self.cmap_dim > 0:
             misc.assert_shape(cmap, [None, self.cmap_dim])
-            x = (x * cmap).sum(dim=1, keepdim=True) * (1 / np.sqrt(self.cmap_dim))
-        return x
+            score = (score * cmap).sum(dim=1, keepdim=True) / np.sqrt(self.cmap_dim)
+        return score
 
 
 class Discriminator(nn.Module):
-    """reference networks.py:612-666."""
+    """Reference networks.py:612-666.  Two instances in the training step: image + pose (6 channels) and parsing + pose (10)."""
 
     def __init__(self, c_dim, img_resolution, img_channels, architecture='resnet', channel_base=32768, channel_max=512, num_fp16_res=0,
                  conv_clamp=None, cmap_dim=None, block_kwargs={}, mapping_kwargs={}, epilogue_kwargs={}):
         super().__init__()
         self.c_dim, self.img_resolution, self.img_channels = c_dim, img_resolution, img_channels
         self.img_resolution_log2 = int(np.log2(img_resolution))
-        self.block_resolutions = [2 ** i for i in range(self.img_resolution_log2, 2, -1)]
-        channels_dict = {res: min(channel_base // res, channel_max) for res in self.block_resolutions + [4]}
-        fp16_resolution = max(2 ** (self.img_resolution_log2 + 1 - num_fp16_res), 8)
-        if cmap_dim is None:
-            cmap_dim = channels_dict[4]
-        if c_dim == 0:
-            cmap_dim = 0
-        common_kwargs = dict(img_channels=img_channels, architecture=architecture, conv_clamp=conv_clamp)
-        cur_layer_idx = 0
+        self.block_resolutions = [1 << e for e in range(self.img_resolution_log2, 2, -1)]
+        width = lambda res: min(channel_base // res, channel_max)
+        fp16_from = max(1 << (self.img_resolution_log2 + 1 - num_fp16_res), 8)        # blocks at this resolution and above run in fp16
+        cmap_dim = 0 if c_dim == 0 else (width(4) if cmap_dim is None else cmap_dim)
+        shared = dict(img_channels=img_channels, architecture=architecture, conv_clamp=conv_clamp)
+        layer_idx = 0
         for res in self.block_resolutions:
-            in_channels = channels_dict[res] if res < img_resolution else 0
-            block = DiscriminatorBlock(in_channels, channels_dict[res], channels_dict[res // 2], resolution=res, first_layer_idx=cur_layer_idx,
-                                       use_fp16=(res >= fp16_resolution), **block_kwargs, **common_kwargs)
+            block = DiscriminatorBlock(width(res) if res < img_resolution else 0, width(res), width(res // 2), resolution=res,
+                                       first_layer_idx=layer_idx, use_fp16=(res >= fp16_from), **block_kwargs, **shared)
             setattr(self, f'b{res}', block)
-            cur_layer_idx += block.num_layers
+            layer_idx += block.num_layers
         if c_dim > 0:
             self.mapping = MappingNetwork(z_dim=0, c_dim=c_dim, w_dim=cmap_dim, num_ws=None, w_avg_beta=None, **mapping_kwargs)
-        self.b4 = DiscriminatorEpilogue(channels_dict[4], cmap_dim=cmap_dim, resolution=4, **epilogue_kwargs, **common_kwargs)
+        self.b4 = DiscriminatorEpilogue(width(4), cmap_dim=cmap_dim, resolution=4, **epilogue_kwargs, **shared)
 
     def forward(self, img, c, **block_kwargs):
         x = None
         for res in self.block_resolutions:
             x, img = getattr(self, f'b{res}')(x, img, **block_kwargs)
-        cmap = self.mapping(None, c) if self.c_dim > 0 else None
-        return self.b4(x, img, cmap)
+        return self.b4(x, img, self.mapping(None, c) if self.c_dim > 0 else None)

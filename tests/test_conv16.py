@@ -233,3 +233,55 @@ def test_conv2d_gradfix_16bit_routes_and_grads(dtype):
         rx, rw = torch.autograd.grad(ref, [x32, w32], dy.float())
         assert float((gx.float() - rx).abs().max()) <= tol * float(rx.abs().max()) + 1e-3
         assert float((gw.float() - rw).abs().max()) <= 4 * tol * float(rw.abs().max()) + 1e-2
+
+
+# ---------------------------------------------------------------- the half-precision stack (BASELINE config 5) vs the fp32 oracle
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['bf16', 'fp16'])
+def test_synthesis_stack_half_vs_oracle(dtype):
+    """SynthesisStack (config 5's network at reduced size: 128^2, channels 256..32) entirely in 16-bit against the float32
+    CPU oracle.  Tolerance: every layer rounds its activations to the 16-bit type (2^-8 relative for bf16, 2^-11 for fp16)
+    and ~12 layers stack up -> 3e-2 / 4e-3 of the output range ('bf16 tolerance ~1e-2 rel')."""
+    from detgen import det_tensor, fill_module_
+    from training import networks as PN
+    from oracle import network_ref as NR
+    kw = dict(w_dim=64, img_resolution=128, img_channels=3, channel_base=4096, channel_max=256, conv_clamp=256)
+    ref = fill_module_(NR.SynthesisStack(**kw), 'stack.').eval()
+    net = PN.SynthesisStack(num_fp16_res=5, half_dtype=dtype, **kw)
+    missing, unexpected = net.load_state_dict(ref.state_dict(), strict=False)
+    assert not unexpected and all('resample_filter' in k for k in missing), (missing, unexpected)
+    net = net.to(DEV).eval()
+    ws = det_tensor('stack.ws', [2, net.num_ws, 64])
+    assert net.num_ws == ref.num_ws
+    with torch.no_grad():
+        got = net(ws.to(DEV), noise_mode='const').cpu()
+        want = ref(ws, noise_mode='const')
+    assert got.dtype == torch.float32 and got.shape == want.shape == (2, 3, 128, 128)
+    err = float((got - want).abs().max()) / float(want.abs().max())
+    assert err <= (3e-2 if dtype == torch.bfloat16 else 4e-3), err
+    # and the same network in float32 through the fp32 kernels: tight
+    with torch.no_grad():
+        got32 = net(ws.to(DEV), noise_mode='const', force_fp32=True).cpu()
+    assert float((got32 - want).abs().max()) <= 1e-4 * float(want.abs().max())
+
+
+def test_upfirdn2d_channels_last_kernel():
+    """The channels-last FIR (blur / 2x decimation, with and without the fused tail) against the NCHW kernel's result."""
+    from torch_utils.ops import upfirdn2d
+    gen = torch.Generator().manual_seed(21)
+    f = upfirdn2d.setup_filter([1, 3, 3, 1]).to(DEV)
+    for dtype in (torch.float32, torch.bfloat16, torch.float16):
+        x = torch.randn([2, 16, 37, 45], generator=gen).to(DEV, dtype)
+        xcl = x.contiguous(memory_format=torch.channels_last)
+        for kw in (dict(padding=[1, 1, 1, 1], gain=4), dict(down=2, padding=[1, 1, 1, 1]), dict(padding=[2, 2, 2, 2]), dict(down=2, padding=[0, 1, 2, 0])):
+            a = upfirdn2d.upfirdn2d(xcl, f, **kw)
+            b = upfirdn2d.upfirdn2d(x.float(), f, **kw)
+            assert a.is_contiguous(memory_format=torch.channels_last) and a.shape == b.shape
+            tol = 0 if dtype == torch.float32 else ULP[dtype]
+            assert float((a.float() - b).abs().max()) <= tol * float(b.abs().max()) + 1e-5
+        noise, bias = torch.randn([37 - 1, 45 - 1], generator=gen).to(DEV), torch.randn([16], generator=gen).to(DEV)
+        fused = upfirdn2d.upfirdn2d_bias_act(xcl, f, padding=[1, 1, 1, 1], gain=4, noise=noise, b=bias, act='lrelu', alpha=0.2, act_gain=1.4, clamp=3.0)
+        ref = upfirdn2d.upfirdn2d(x.float(), f, padding=[1, 1, 1, 1], gain=4) + noise + bias.reshape(1, -1, 1, 1)
+        ref = (torch.where(ref > 0, ref, ref * 0.2) * 1.4).clamp(-3, 3)
+        assert fused is not None and fused.dtype == dtype
+        assert float((fused.float() - ref).abs().max()) <= (1e-5 if dtype == torch.float32 else ULP[dtype] * 3.0 + 1e-5)

@@ -259,7 +259,7 @@ template <> struct Vec16<float> {
     static constexpr int N = 4;
     static __device__ __forceinline__ void widen(u32x4 r, float (&o)[4]) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) o[i] = __builtin_bit_cast(float, r[i]);
+        for (int i = 0; i < 4; i++) { const unsigned e = r[i]; o[i] = __builtin_bit_cast(float, e); }   // (bit_cast of `r[i]` itself reads element 0: a vector element is not an addressable object)
     }
     static __device__ __forceinline__ u32x4 narrow(const float (&v)[4]) {
         return u32x4{__builtin_bit_cast(unsigned, v[0]), __builtin_bit_cast(unsigned, v[1]), __builtin_bit_cast(unsigned, v[2]), __builtin_bit_cast(unsigned, v[3])};
@@ -269,7 +269,7 @@ template <> struct Vec16<bf16_t> {
     static constexpr int N = 8;
     static __device__ __forceinline__ void widen(u32x4 r, float (&o)[8]) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) { const bf16x2v h = __builtin_bit_cast(bf16x2v, r[i]); o[2 * i] = (float)h[0]; o[2 * i + 1] = (float)h[1]; }
+        for (int i = 0; i < 4; i++) { const unsigned e = r[i]; const bf16x2v h = __builtin_bit_cast(bf16x2v, e); o[2 * i] = (float)h[0]; o[2 * i + 1] = (float)h[1]; }
     }
     static __device__ __forceinline__ u32x4 narrow(const float (&v)[8]) {
         u32x4 r;
@@ -282,7 +282,7 @@ template <> struct Vec16<f16_t> {
     static constexpr int N = 8;
     static __device__ __forceinline__ void widen(u32x4 r, float (&o)[8]) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) { const f16x2v h = __builtin_bit_cast(f16x2v, r[i]); o[2 * i] = (float)h[0]; o[2 * i + 1] = (float)h[1]; }
+        for (int i = 0; i < 4; i++) { const unsigned e = r[i]; const f16x2v h = __builtin_bit_cast(f16x2v, e); o[2 * i] = (float)h[0]; o[2 * i + 1] = (float)h[1]; }
     }
     static __device__ __forceinline__ u32x4 narrow(const float (&v)[8]) {
         u32x4 r;
@@ -324,8 +324,6 @@ __global__ __launch_bounds__(256, 2) void upfirdn2d_cl(Params p) {
             const int ix = ix0 + kx;
             const bool ok = row_ok && ix >= 0 && ix < p.inW;
             u32x4 v = *(const u32x4*)(xn + ((int64_t)(ok ? iy : 0) * p.inW + (ok ? ix : 0)) * p.C);    // always a valid address
-            // (element-wise: `ok ? v : u32x4{...}` with a scalar condition takes clang's OpenCL vector-select path and
-            // keeps only element 0 of v)
 #pragma unroll
             for (int e = 0; e < 4; e++) v[e] = ok ? v[e] : 0u;
             raw[kx] = v;

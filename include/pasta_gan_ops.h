@@ -271,7 +271,7 @@ int pg_conv2d16_forward(const void* x, const void* packed, void* y, int dtype, i
                         const pg_conv2d16_fusion* fusion, void* stream);
 
 /* Split-K form for launches with fewer output tiles than CUs: `ksplit` launches-worth of workgroups each reduce Cin/ksplit
- * channels into float32 [ksplit][N][Cout][OH][OW] `workspace`; one pass sums the slices in fixed order, applies the
+ * channels into float32 [ksplit][N][OH][OW][Cout] `workspace`; one pass sums the slices in fixed order, applies the
  * epilogue and writes y.  pg_conv2d16_splitk_plan returns the ksplit this library would choose (1 = do not split). */
 int pg_conv2d16_splitk_plan(int N, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride);
 int pg_conv2d16_forward_splitk(const void* x, const void* packed, void* y, int dtype, int out_dtype,

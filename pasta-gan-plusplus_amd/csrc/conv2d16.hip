@@ -1,6 +1,7 @@
 // C ABI of the 16-bit (bf16 / fp16) convolution + its support kernels: weight packing with the style modulation and
 // demodulation folded in, the split-K finish pass and the streaming 1x1 head.  The MFMA kernel itself lives in
 // conv2d_kernel16.h and is instantiated per geometry in conv2d16_inst_*.hip.
+#include <stdlib.h>
 #include "conv2d_kernel16.h"
 
 namespace {
@@ -16,36 +17,75 @@ inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 struct TapSel { int ny, nx; int ys[8], xs[8]; };
 
 // packed[n][ci/16][tap][(ci/8)&1][co][ci&7] = T(w[co][ci][ky][kx] * scale * styles[n][ci] * dcoefs[n][co])
-template <typename T>
-__global__ __launch_bounds__(256) void pack16_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, int Cout, int Cin, int KH, int KW, TapSel sel,
+// One workgroup = one (sample, 16-channel block, 64-cout block): the weights of that block are read as 64 contiguous runs
+// of 16 * KH * KW floats (OIHW; one cache-line-coalesced run per cout), transposed through LDS, and written as T * 2 rows of
+// 64 x 16 bytes -- contiguous 1 KB segments of the packed layout.  Both sides of the transpose are coalesced.
+template <typename T, int KK>                                          // KK = KH * KW of the source weight (compile time: no runtime division)
+__global__ __launch_bounds__(256) void pack16_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, int Cout, int Cin, int KW, TapSel sel,
                                                      int CinP, int CoutP, float scale, int flip, int transpose_oi,
                                                      const float* __restrict__ styles, const float* __restrict__ dcoefs, int64_t per_sample) {
-    const int n = blockIdx.y;
-    const int T_ = sel.ny * sel.nx;
-    unsigned short* dst = out + (int64_t)n * per_sample;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per_sample; i += (int64_t)gridDim.x * 256) {
-        const int j = (int)(i & 7);
-        const int co = (int)((i >> 3) % CoutP);
-        const int h = (int)((i / ((int64_t)8 * CoutP)) & 1);
-        const int tap = (int)((i / ((int64_t)16 * CoutP)) % T_);
-        const int k16 = (int)(i / ((int64_t)16 * CoutP * T_));
-        const int ci = k16 * 16 + h * 8 + j;
-        float v = 0.f;
-        if (co < Cout && ci < Cin) {
-            int ky = sel.ys[tap / sel.nx], kx = sel.xs[tap % sel.nx];
-            if (flip) { ky = KH - 1 - ky; kx = KW - 1 - kx; }
-            const int64_t src = transpose_oi ? (((int64_t)ci * Cout + co) * KH + ky) * KW + kx
-                                             : (((int64_t)co * Cin + ci) * KH + ky) * KW + kx;
-            v = w[src] * scale;
-            if (styles) v *= styles[(int64_t)n * Cin + ci];
-            if (dcoefs) v *= dcoefs[(int64_t)n * Cout + co];
+    constexpr int RUN = 16 * KK, PITCH = RUN + 1;
+    __shared__ float tile[64 * PITCH];                                 // [64 couts][16 channels][KK] (+1 pad per cout row)
+    const int n = blockIdx.z, k16 = blockIdx.y, cb = blockIdx.x;
+    const int KH = KK / KW, T_ = sel.ny * sel.nx;
+    const int co0 = cb * 64, ci0 = k16 * 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // ---- load: OIHW keeps (ci, ky, kx) contiguous per cout; IOHW (transposed weights) keeps (co, ky, kx) contiguous per ci
+    if (!transpose_oi) {
+        for (int col = wave; col < 64; col += 4) {                     // one wave per cout: its 16 * KK floats are one contiguous run
+            const int co = co0 + col;
+            const float dsc = (co < Cout ? scale : 0.f) * ((dcoefs && co < Cout) ? dcoefs[(int64_t)n * Cout + co] : 1.f);
+            const float* src = w + ((int64_t)(co < Cout ? co : 0) * Cin + ci0) * KK;
+#pragma unroll
+            for (int r = lane; r < RUN; r += 64) {
+                const int ci = ci0 + r / KK;
+                float v = 0.f;
+                if (ci < Cin) v = src[r] * dsc * (styles ? styles[(int64_t)n * Cin + ci] : 1.f);
+                tile[col * PITCH + r] = v;
+            }
         }
-        dst[i] = (unsigned short)(Half16<T>::pack(v, 0.f) & 0xffff);
+    } else {
+        for (int c = wave; c < 16; c += 4) {                           // one wave per input channel: 64 couts x KK floats contiguous
+            const int ci = ci0 + c;
+            const float ssc = (ci < Cin ? scale : 0.f) * ((styles && ci < Cin) ? styles[(int64_t)n * Cin + ci] : 1.f);
+            const float* src = w + ((int64_t)(ci < Cin ? ci : 0) * Cout + co0) * KK;
+#pragma unroll
+            for (int e = lane; e < 64 * KK; e += 64) {
+                const int col = e / KK, kk = e % KK;
+                float v = 0.f;
+                if (co0 + col < Cout) v = src[e] * ssc * (dcoefs ? dcoefs[(int64_t)n * Cout + co0 + col] : 1.f);
+                tile[col * PITCH + c * KK + kk] = v;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- store: thread -> (row = tap * 2 + h, cout): 16 bytes = 8 consecutive channels of one tap
+    unsigned short* dst = out + (int64_t)n * per_sample + (int64_t)k16 * T_ * 2 * CoutP * 8;
+    for (int e = threadIdx.x; e < T_ * 2 * 64; e += 256) {
+        const int col = e & 63, row = e >> 6;
+        const int h = row & 1, tap = row >> 1;
+        const int ty = sel.nx == 1 ? tap : (sel.nx == 2 ? tap >> 1 : tap / 3), tx = tap - ty * sel.nx;
+        int ky = sel.ys[ty], kx = sel.xs[tx];
+        if (flip) { ky = KH - 1 - ky; kx = KW - 1 - kx; }
+        const float* src = tile + col * PITCH + (h * 8) * KK + ky * KW + kx;
+        u32x4 o;
+#pragma unroll
+        for (int d = 0; d < 4; d++) o[d] = Half16<T>::pack(src[(2 * d) * KK], src[(2 * d + 1) * KK]);
+        *(u32x4*)(dst + ((int64_t)row * CoutP + co0 + col) * 8) = o;
     }
 }
 
-// y[n, co, oy*osy+ooy, ox*osx+oox] = T(epilogue(sum_z ws[z][n, co, oy, ox])), fixed order z = 0, 1, ... (deterministic).
-// Threads walk the OUTPUT in its own memory order when it is channels-last (co fastest) so the 16-bit stores coalesce.
+template <typename T>
+int launch_pack16(int KK, dim3 grid, hipStream_t s, const float* w, unsigned short* packed, int Cout, int Cin, int KW, const TapSel& sel, int CinP, int CoutP,
+                  float scale, int flip, int transpose_oi, const float* styles, const float* dcoefs, int64_t per_sample) {
+#define PG_PACK(K) case K: hipLaunchKernelGGL((pack16_kernel<T, K>), grid, dim3(256), 0, s, w, packed, Cout, Cin, KW, sel, CinP, CoutP, scale, flip, transpose_oi, styles, dcoefs, per_sample); break;
+    switch (KK) { PG_PACK(1) PG_PACK(2) PG_PACK(3) PG_PACK(4) PG_PACK(6) PG_PACK(9) default: return PG_ERR_UNSUPPORTED; }
+#undef PG_PACK
+    return pg::launch_status();
+}
+
+// y[n, co, oy*osy+ooy, ox*osx+oox] = T(epilogue(sum_z ws[z][n, oy, ox, co])), fixed order z = 0, 1, ... (deterministic).  The
+// workspace is channels-last like the 16-bit activations, so threads that walk it in memory order also write y in order.
 template <typename T>
 __global__ __launch_bounds__(256) void splitk_finish16_kernel(const float* __restrict__ ws, void* __restrict__ y, int out_f32, int ksplit, int64_t slice,
                                                               int N, int Cout, int OH, int OW, int64_t ys0, int64_t ys1, int64_t ys2, int64_t ys3,
@@ -53,14 +93,10 @@ __global__ __launch_bounds__(256) void splitk_finish16_kernel(const float* __res
     const int64_t total = (int64_t)N * Cout * OH * OW;
     const float slope = f.act == PG_ACT_LINEAR ? 1.f : (f.act == PG_ACT_RELU ? 0.f : f.alpha);
     const float cl = f.clamp >= 0.f ? f.clamp : __builtin_inff();
-    const bool cl_last = ys1 == 1;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        int ox, oy, co, n;
-        if (cl_last) { co = (int)(i % Cout); ox = (int)((i / Cout) % OW); oy = (int)((i / ((int64_t)Cout * OW)) % OH); n = (int)(i / ((int64_t)Cout * OW * OH)); }
-        else { ox = (int)(i % OW); oy = (int)((i / OW) % OH); co = (int)((i / ((int64_t)OW * OH)) % Cout); n = (int)(i / ((int64_t)OW * OH * Cout)); }
-        const int64_t src = (((int64_t)n * Cout + co) * OH + oy) * OW + ox;
+        const int co = (int)(i % Cout), ox = (int)((i / Cout) % OW), oy = (int)((i / ((int64_t)Cout * OW)) % OH), n = (int)(i / ((int64_t)Cout * OW * OH));
         float v = 0.f;
-        for (int z = 0; z < ksplit; z++) v += ws[(int64_t)z * slice + src];
+        for (int z = 0; z < ksplit; z++) v += ws[(int64_t)z * slice + i];
         if (f.out_scale) v *= f.out_scale[(int64_t)n * Cout + co];
         if (f.noise) v += f.noise[n * f.noise_batch_stride + (int64_t)oy * OW + ox] * f.noise_gain;
         if (f.bias) v += f.bias[co];
@@ -140,6 +176,8 @@ int launch_small(int cout, dim3 grid, size_t lds, hipStream_t s, const unsigned 
     return pg::launch_status();
 }
 
+unsigned long long* g_debug_stamps = nullptr;     // dev hook, see pg_conv2d16_debug_stamps
+
 int kc_for16(int kh, int kw) { return kh * kw <= 2 ? 32 : 16; }
 
 bool geometry_ok(int KH, int KW, int stride) {
@@ -177,6 +215,7 @@ int conv16_forward(const void* x, const void* packed, void* y, int dtype, int ou
     p.N = N; p.Cin = Cin; p.xC = Cin; p.H = H; p.W = W; p.Cout = Cout; p.CoutP = CoutP; p.OH = OH; p.OW = OW;
     p.pad_y = pad_y; p.pad_x = pad_x;
     p.ksplit = 1; p.kpart = 0; p.ws_slice = 0;
+    { const char* e = getenv("PG_CONV16_DBG"); p.dbg = e ? atoi(e) : 0; p.stamps = g_debug_stamps; if (!p.stamps) p.dbg &= ~32; }
     for (int i = 0; i < 4; i++) p.ys[i] = ystride[i];
     p.osy = osy; p.osx = osx; p.ooy = ooy; p.oox = oox;
     if (fusion) {
@@ -187,6 +226,7 @@ int conv16_forward(const void* x, const void* packed, void* y, int dtype, int ou
         p.f = z;
     }
     if (p.f.gain == 0.f) p.f.gain = 1.f;
+    if (!(p.f.gain > 0.f)) return PG_ERR_UNSUPPORTED;                   // the epilogue folds the gain through the activation
     if (p.f.act == 0) p.f.act = PG_ACT_LINEAR;
     if (p.f.act < PG_ACT_LINEAR || p.f.act > PG_ACT_SWISH) return PG_ERR_INVALID_ARG;
     if (p.f.act > PG_ACT_LRELU) return PG_ERR_UNSUPPORTED;
@@ -200,12 +240,12 @@ int conv16_forward(const void* x, const void* packed, void* y, int dtype, int ou
     const int64_t slice = (int64_t)N * Cout * OH * OW;
     if (ksplit > 1) {
         const int kc = kc_for16(KH, KW);
-        if (!workspace || Cin % (ksplit * kc) != 0 || slice * ksplit > 0x3fffffffLL) return PG_ERR_INVALID_ARG;
+        if (!workspace || Cin % (ksplit * kc) != 0 || slice * ksplit > 0x1fffffffLL) return PG_ERR_INVALID_ARG;      // float32 workspace addressed with 32-bit byte offsets
         p.ksplit = ksplit; p.kpart = Cin / ksplit; p.ws_slice = slice;
         p.y = workspace; p.y_bytes = slice * ksplit * 4;
-        p.ys[0] = (int64_t)Cout * OH * OW; p.ys[1] = (int64_t)OH * OW; p.ys[2] = OW; p.ys[3] = 1;
+        p.ys[0] = (int64_t)Cout * OH * OW; p.ys[1] = 1; p.ys[2] = (int64_t)OW * Cout; p.ys[3] = Cout;        // channels-last slices
         p.osy = p.osx = 1; p.ooy = p.oox = 0;
-        p.out_mode = pgconv16::OUT_SCALAR32;
+        p.out_mode = (Cout % 4 == 0 && (((uintptr_t)workspace) & 15) == 0) ? pgconv16::OUT_VEC32 : pgconv16::OUT_SCALAR32;
         pg_conv2d16_fusion z = {};
         z.clamp = -1.f; z.gain = 1.f; z.act = PG_ACT_LINEAR;
         p.f = z;
@@ -256,17 +296,19 @@ PG_EXPORT int pg_conv2d16_pack_weight(const float* w, void* packed, int dtype, i
     }
     const int CinP = round_up(Cin, 32), CoutP = round_up(Cout, 64);
     const int64_t per_sample = (int64_t)CinP * sel.ny * sel.nx * CoutP;
-    int64_t bx = (per_sample + 255) / 256;
-    if (bx > pg::max_stream_blocks()) bx = pg::max_stream_blocks();
-    const dim3 grid((unsigned)bx, (unsigned)nsamples);
+    if (CinP / 16 > 65535 || nsamples > 65535) return PG_ERR_TOO_LARGE;
+    const dim3 grid((unsigned)(CoutP / 64), (unsigned)(CinP / 16), (unsigned)nsamples);
+    if (sel.nx > 3) return PG_ERR_UNSUPPORTED;
     if (dtype == PG_BF16)
-        hipLaunchKernelGGL((pack16_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, w, (unsigned short*)packed, Cout, Cin, KH, KW, sel, CinP, CoutP,
-                           scale, flip_hw, transpose_oi, styles, dcoefs, per_sample);
-    else
-        hipLaunchKernelGGL((pack16_kernel<f16_t>), grid, dim3(256), 0, (hipStream_t)stream, w, (unsigned short*)packed, Cout, Cin, KH, KW, sel, CinP, CoutP,
-                           scale, flip_hw, transpose_oi, styles, dcoefs, per_sample);
-    return pg::launch_status();
+        return launch_pack16<bf16_t>(KH * KW, grid, (hipStream_t)stream, w, (unsigned short*)packed, Cout, Cin, KW, sel, CinP, CoutP, scale, flip_hw, transpose_oi,
+                                     styles, dcoefs, per_sample);
+    return launch_pack16<f16_t>(KH * KW, grid, (hipStream_t)stream, w, (unsigned short*)packed, Cout, Cin, KW, sel, CinP, CoutP, scale, flip_hw, transpose_oi,
+                                styles, dcoefs, per_sample);
 }
+
+// Dev hook (not part of include/pasta_gan_ops.h): device buffer of >= 4000 uint64 that PG_CONV16_DBG=32 fills with
+// (s_memtime << 8 | tag) stamps of workgroup 0 / wave (dbg >> 8); tools/conv16_stamps.py reads it.
+PG_EXPORT void pg_conv2d16_debug_stamps(void* buf) { g_debug_stamps = (unsigned long long*)buf; }
 
 PG_EXPORT int pg_conv2d16_forward(const void* x, const void* packed, void* y, int dtype, int out_dtype,
                                   int N, int Cin, int H, int W, int Cout, int KH, int KW,

@@ -32,6 +32,7 @@
 // C=32 is HBM-bound, C>=128 MFMA-bound.
 
 #pragma once
+#include <algorithm>
 #include "pg_common.h"
 
 namespace pgconv16 {
@@ -72,7 +73,7 @@ template <> struct Half16<f16_t> {
     static __device__ __forceinline__ float widen(unsigned short u) { return (float)__builtin_bit_cast(f16_t, u); }
 };
 
-enum { OUT_VEC16 = 0, OUT_SCALAR16 = 1, OUT_SCALAR32 = 2 };
+enum { OUT_VEC16 = 0, OUT_SCALAR16 = 1, OUT_SCALAR32 = 2, OUT_VEC32 = 3 };   // VEC32: float32 channels-last rows, 4 couts per 16-byte store (split-K workspace)
 
 struct Conv16Params {
     const void* x;          // [N, H, W, Cin] 16-bit, dense
@@ -89,7 +90,10 @@ struct Conv16Params {
     int64_t ys[4];          // (n, c, y, x) strides of the output in ELEMENTS of its dtype
     int osy, osx, ooy, oox; // output pixel (oy, ox) is written at (oy*osy + ooy, ox*osx + oox)
     int out_mode;
+    unsigned long long* stamps;   // dev: s_memtime stamps of workgroup 0 / wave 0 (PG_CONV16_DBG & 32; pg_conv2d16_debug_stamps)
+    int dbg;                // dev ablations (PG_CONV16_DBG; results wrong by design): 1 no output stores, 2 no halo DMA, 4 no MFMA, 8 no epilogue maths
     int tilesX, tilesY, mblocks, total_tiles;
+    unsigned m_tilesX, m_tilesY, m_mblocks, m_ksplit;      // ceil(2^32 / d) of the tile-decomposition divisors (0 for d == 1)
     pg_conv2d16_fusion f;
 };
 
@@ -106,10 +110,10 @@ __device__ __forceinline__ void dma16(i32x4 rsrc, unsigned lds_byte, unsigned vo
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "s"(lds_byte), "v"(voff_bytes), "s"(rsrc), "s"(soff_bytes) : "memory");
 }
-__device__ __forceinline__ void dma4(i32x4 rsrc, unsigned lds_byte, unsigned voff_bytes) {
+__device__ __forceinline__ void dma4(i32x4 rsrc, unsigned lds_byte, unsigned voff_bytes, unsigned soff_bytes) {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dword %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "s"(lds_byte), "v"(voff_bytes), "s"(rsrc) : "memory");
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dword %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_byte), "v"(voff_bytes), "s"(rsrc), "s"(soff_bytes) : "memory");
 }
 template <int N> __device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" :: "i"(N) : "memory"); }
 
@@ -152,6 +156,10 @@ struct Geo16 {
 
 __device__ __forceinline__ float act_slope(int act, float alpha) { return act == PG_ACT_LINEAR ? 1.f : (act == PG_ACT_RELU ? 0.f : alpha); }
 
+// q = L / d for the tile decomposition, on the scalar unit: M = ceil(2^32 / d) from the host (0 for d == 1); exact while
+// L * d < 2^32 (launch16 checks it).
+__device__ __forceinline__ unsigned div_magic(unsigned L, unsigned M) { return M ? __umulhi(L, M) : L; }
+
 template <typename T, int KH, int KW, int S, int TWL, int WM, int MT, int NT, int KC, int NB>
 __global__ __launch_bounds__(THREADS, 2) void conv2d_mfma16(Conv16Params p) {
     typedef Geo16<KH, KW, S, TWL, WM, MT, NT, KC, NB> G;
@@ -174,51 +182,59 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_mfma16(Conv16Params p) {
     const int nchunks = (cin_loop + KC - 1) / KC;
     const int tail_ch = cin_loop % KC;                    // channels of a partial last chunk (0 = none)
 
-    // ---- descriptors that never change
+    // ---- descriptors: all of them cover a whole tensor and never change; the image / sample offset travels in the
+    // instruction's scalar offset.  (x larger than 2 GB: the host falls back to one launch per image.)
+    const i32x4 xrsrc = make_rsrc(p.x, (int64_t)p.N * p.H * p.W * p.xC * 2);
     const i32x4 wrsrc = make_rsrc(p.wp, p.w_bytes);
-    const i32x4 brsrc = make_rsrc(p.f.bias, p.f.bias ? (int64_t)p.Cout * 4 : 0);
-    // the vector epilogue stores through a range-checked descriptor: every wave issues exactly EP_STORES store instructions
+    // the vector epilogues store through a range-checked descriptor: every wave issues exactly EP_STORES store instructions
     // per tile (masked-off lanes carry the sentinel offset), which the counted waits below rely on
     const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)(p.y_bytes > 0x7fffffffLL ? 0x7fffffffLL : p.y_bytes), 0x00020000);
 
-    // ---- per-thread DMA maps.  Instruction i of a chunk moves 16-byte slot  s = (i * 8 + wave) * 64 + lane  of the staging
-    // buffer: slots below NXS_PAD are the halo tile (gathered, re-mapped per tile), the rest the weight slab (fixed map).
-    unsigned voff[G::DPC];
+    // ---- per-thread DMA maps, fixed for the whole kernel.  Instruction i of a chunk moves 16-byte slot
+    // s = (i * 8 + wave) * 64 + lane of the staging buffer: slots below NXS_PAD are the halo tile, the rest the weight slab.
+    //   rel[i]  byte offset of the slot's source relative to the tile's first halo pixel (halo) / the slab's first row (weights);
+    //           SENTINEL for padding slots
+    //   hyx[i]  halo coordinates (row | col << 16) for the border test; rows >= 0x4000 never pass it
+    unsigned rel[G::DPC], hyx[G::DPC];
     unsigned tailmask = 0;                                // bit i: this lane's halo slot i holds channels >= tail_ch of a chunk
 #pragma unroll
     for (int i = 0; i < G::DPC; i++) {
         const int sb = (i * WAVES + wave) * 64;
-        voff[i] = SENTINEL;
+        rel[i] = SENTINEL; hyx[i] = 0x4000u;
         if (sb >= G::NXS_PAD) {
             const int e = sb + lane - G::NXS_PAD;
             const int row = e / G::BM, col = e % G::BM;
-            if (e < G::NWS) voff[i] = (unsigned)(row * p.CoutP + col) * 16u;
+            if (e < G::NWS) rel[i] = (unsigned)(row * p.CoutP + col) * 16u;
         } else {
             const int s = sb + lane;
             const int q = s / G::SLOTS;
             const int c = (s % G::SLOTS) ^ ((q / G::PER) & (G::SLOTS - 1));
+            const int hy = q / G::IW_T, hx = q % G::IW_T;
+            if (s < G::NXS) {
+                rel[i] = (unsigned)((hy * p.W + hx) * p.xC + c * 8) * 2u;
+                hyx[i] = (unsigned)hy | ((unsigned)hx << 16);
+            }
             if (tail_ch && c * 8 >= tail_ch) tailmask |= 1u << i;
         }
     }
 
     // ---- tile descriptors: [parity] of the tile being multiplied / the next one
     int d_z0 = 0, d_z1 = 0, d_n0 = 0, d_n1 = 0, d_oy00 = 0, d_oy01 = 0, d_ox00 = 0, d_ox01 = 0, d_m00 = 0, d_m01 = 0;      // (explicit pairs: a runtime-indexed array would live in scratch)
-    i32x4 xrsrc, srsrc, nrsrc;                            // image n of x; out_scale row n; noise plane n  (tile being requested)
+    unsigned voff[G::DPC];                                // DMA offsets of the tile being requested (halo lanes; weight lanes = rel)
     unsigned w_soff = 0, x_soff0 = 0;
-    unsigned side_voff = SENTINEL, noise_voff = SENTINEL;
 
-    // Tile -> (n, tile_y, tile_x, m-block), XCD-aware: workgroups that share an XCD (id % 8) walk one contiguous range of
-    // logical tiles, so vertically / horizontally adjacent halos and the weight slabs hit the same L2.
+    // Tile -> (n, tile_y, tile_x, m-block[, K share]), XCD-aware: workgroups that share an XCD (id % 8) walk one contiguous
+    // range of logical tiles, so adjacent halos and the weight slabs hit the same L2.  All of it runs on the scalar unit.
     auto prep_tile = [&](int tile, int par) __attribute__((always_inline)) {
         const int xcd = tile & 7;
-        int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (tile >> 3);
+        unsigned L = (unsigned)((xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (tile >> 3));
         int zsl = 0;
-        if (p.ksplit > 1) { zsl = L % p.ksplit; L /= p.ksplit; }      // the shares of one tile run side by side
+        if (p.ksplit > 1) { const unsigned q = div_magic(L, p.m_ksplit); zsl = (int)(L - q * p.ksplit); L = q; }      // the shares of one tile run side by side
         const int cbeg = zsl * p.kpart;
-        const int mb = L % p.mblocks; L /= p.mblocks;
-        const int tx = L % p.tilesX; L /= p.tilesX;
-        const int ty = L % p.tilesY;
-        const int n = L / p.tilesY;
+        unsigned q = div_magic(L, p.m_mblocks); const int mb = (int)(L - q * p.mblocks); L = q;
+        q = div_magic(L, p.m_tilesX); const int tx = (int)(L - q * p.tilesX); L = q;
+        q = div_magic(L, p.m_tilesY); const int ty = (int)(L - q * p.tilesY);
+        const int n = (int)q;
         const int oy0 = ty * G::TH, ox0 = tx * G::TW, m0 = mb * G::BM;
         // value selects, not control flow: stores through a selected address would put the descriptors into scratch
         d_z1 = par ? zsl : d_z1;   d_z0 = par ? d_z0 : zsl;
@@ -226,33 +242,44 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_mfma16(Conv16Params p) {
         d_oy01 = par ? oy0 : d_oy01; d_oy00 = par ? d_oy00 : oy0;
         d_ox01 = par ? ox0 : d_ox01; d_ox00 = par ? d_ox00 : ox0;
         d_m01 = par ? m0 : d_m01;  d_m00 = par ? d_m00 : m0;
-        int tt = t;
-        asm volatile("" : "+v"(tt));                      // keep the tile-independent index maths out of long-lived registers
-        const int lane_ = tt & 63;
+        // halo: source offset = tile origin + rel; lanes outside the image (border tiles only) get the sentinel
+        const int ty0 = oy0 * S - p.pad_y, tx0 = ox0 * S - p.pad_x;
+        const unsigned org = (unsigned)((ty0 * p.W + tx0) * p.xC * 2);
+        const bool interior = ty0 >= 0 && tx0 >= 0 && ty0 + G::IH_T <= p.H && tx0 + G::IW_T <= p.W;      // wave-uniform
 #pragma unroll
         for (int i = 0; i < G::DPC; i++) {
             const int sb = (i * WAVES + wave) * 64;
             if (sb < G::NXS_PAD) {                        // wave-uniform
-                const int s = sb + lane_;
-                const int q = s / G::SLOTS;
-                const int c = (s % G::SLOTS) ^ ((q / G::PER) & (G::SLOTS - 1));
-                const int hy = q / G::IW_T, hx = q % G::IW_T;
-                const int gy = oy0 * S - p.pad_y + hy, gx = ox0 * S - p.pad_x + hx;
-                const bool ok = s < G::NXS && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-                voff[i] = ok ? (unsigned)((gy * p.W + gx) * p.xC + c * 8) * 2u : SENTINEL;
+                if (interior) {
+                    voff[i] = org + rel[i];               // padding slots: org + 2^31 stays out of range (0 <= org < 2^31)
+                } else {
+                    const unsigned gy = (unsigned)(ty0 + (int)(hyx[i] & 0xffffu)), gx = (unsigned)(tx0 + (int)(hyx[i] >> 16));
+                    voff[i] = (gy < (unsigned)p.H && gx < (unsigned)p.W) ? org + rel[i] : SENTINEL;
+                }
             }
         }
-        xrsrc = make_rsrc((const unsigned short*)p.x + (int64_t)n * p.H * p.W * p.xC, (int64_t)p.H * p.W * p.xC * 2);
-        x_soff0 = (unsigned)cbeg * 2u;
-        srsrc = make_rsrc(p.f.out_scale ? p.f.out_scale + (int64_t)n * p.Cout : nullptr, p.f.out_scale ? (int64_t)p.Cout * 4 : 0);
-        nrsrc = make_rsrc(p.f.noise ? p.f.noise + (int64_t)n * p.f.noise_batch_stride : nullptr, p.f.noise ? (int64_t)p.OH * p.OW * 4 : 0);
+        x_soff0 = (unsigned)(((int64_t)n * p.H * p.W * p.xC + cbeg) * 2);
         w_soff = (unsigned)(((int64_t)n * p.w_nstride + (int64_t)m0 * 8) * 2) + (unsigned)((cbeg / 16) * G::T * 2) * (unsigned)p.CoutP * 16u;
-        // side loads of the tile: wave w < EPS/64 fetches 64 demodulation scales, the next EPS/64 waves 64 biases; every
-        // thread one noise sample (tile pixel t)
-        const int seg = wave * 64 + lane_;
-        side_voff = (unsigned)(m0 + (seg % G::EPS)) * 4u;
-        const int ny = oy0 + tt / G::TW, nx = ox0 + tt % G::TW;
-        noise_voff = (tt < G::TH * G::TW && ny < p.OH && nx < p.OW) ? (unsigned)(ny * p.OW + nx) * 4u : SENTINEL;
+    };
+
+    // Per-cout epilogue constants and the tile's noise samples: wave w < EPS/64 fetches 64 demodulation scales, the next
+    // EPS/64 waves 64 biases (idle waves write zeros into the dump area); every thread one noise sample (tile pixel t).
+    // Whole-tensor descriptors (constant), the row / plane offset in the scalar offset; the per-thread parts are fixed.
+    const bool side_scale = wave < G::EPS / 64, side_bias = !side_scale && wave < 2 * (G::EPS / 64);
+    const i32x4 sbrsrc = side_scale ? make_rsrc(p.f.out_scale, p.f.out_scale ? (int64_t)p.N * p.Cout * 4 : 0)
+                                    : make_rsrc(p.f.bias, (p.f.bias && side_bias) ? (int64_t)p.Cout * 4 : 0);
+    const i32x4 nrsrc = make_rsrc(p.f.noise, p.f.noise ? ((int64_t)(p.N - 1) * p.f.noise_batch_stride + (int64_t)p.OH * p.OW) * 4 : 0);
+    const unsigned side_rel = (unsigned)((wave * 64 + lane) % G::EPS) * 4u;                 // + m0 * 4 (+ n * Cout * 4 for the scales)
+    const int noise_dy = t / G::TW, noise_dx = t % G::TW;                                   // this thread's pixel of the tile
+    auto issue_side = [&](int par) __attribute__((always_inline)) {
+        const int n = par ? d_n1 : d_n0, oy0 = par ? d_oy01 : d_oy00, ox0 = par ? d_ox01 : d_ox00, m0 = par ? d_m01 : d_m00;
+        const unsigned sb_ = side_b + (unsigned)(par * G::EP_FLOATS) * 4u;
+        const bool live = (side_scale || side_bias) && m0 + (int)(side_rel >> 2) < p.Cout;
+        dma4(sbrsrc, (side_scale || side_bias) ? sb_ + (unsigned)(wave * 64) * 4u : dump_b, live ? side_rel : SENTINEL,
+             (unsigned)(m0 + (side_scale ? n * p.Cout : 0)) * 4u);
+        const int ny = oy0 + noise_dy, nx = ox0 + noise_dx;
+        const unsigned noise_voff = (t < G::TH * G::TW && ny < p.OH && nx < p.OW) ? (unsigned)(ny * p.OW + nx) * 4u : SENTINEL;
+        dma4(nrsrc, sb_ + (unsigned)(2 * G::EPS + wave * 64) * 4u, noise_voff, (unsigned)(n * p.f.noise_batch_stride) * 4u);
     };
 
     // ---- the chunk stream
@@ -264,15 +291,10 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_mfma16(Conv16Params p) {
 
     auto issue_next = [&]() __attribute__((always_inline)) {
         if (c_done || (c_chunk == 0 && c_ahead > 1)) return;
-        const int par = dpar ^ (c_ahead & 1);
         if (c_chunk == 0) {
+            const int par = dpar ^ (c_ahead & 1);
             prep_tile(c_tile, par);
-            const unsigned sb_ = side_b + (unsigned)(par * G::EP_FLOATS) * 4u;
-            // scales | biases | (idle waves write zeros into the dump area)
-            const bool is_scale = wave < G::EPS / 64, is_bias = !is_scale && wave < 2 * (G::EPS / 64);
-            const i32x4 r = is_scale ? srsrc : brsrc;
-            dma4(r, (is_scale || is_bias) ? sb_ + (unsigned)(wave * 64) * 4u : dump_b, (is_scale || is_bias) ? side_voff : SENTINEL);
-            dma4(nrsrc, sb_ + (unsigned)(2 * G::EPS + wave * 64) * 4u, noise_voff);
+            if (!(p.dbg & 16)) issue_side(par);
         }
         const int c0 = c_chunk * KC;
         const bool partial = tail_ch != 0 && c_chunk == nchunks - 1;
@@ -283,8 +305,9 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_mfma16(Conv16Params p) {
         for (int i = 0; i < G::DPC; i++) {
             const int sb = (i * WAVES + wave) * 64;
             const bool is_w = sb >= G::NXS_PAD;           // wave-uniform
-            unsigned vo = voff[i];
+            unsigned vo = is_w ? rel[i] : voff[i];
             if (partial && ((tailmask >> i) & 1)) vo = SENTINEL;
+            if (!is_w && (p.dbg & 2)) vo = SENTINEL;
             dma16(is_w ? wrsrc : xrsrc, buf_b + (unsigned)sb * 16u, vo, is_w ? wk_soff : x_soff);
         }
         ibuf = ibuf == G::NBUF - 1 ? 0 : ibuf + 1;
@@ -369,59 +392,97 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_mfma16(Conv16Params p) {
     const float noise_gain = p.f.noise ? p.f.noise_gain : 0.f;
     constexpr int EP_STORES = MT * NT * 2;                // 16-byte stores of the vector epilogue per wave
 
-    issue_next();
-    if (G::NBUF > 2) issue_next();
+    // One loop, one issue site: the first NBUF - 1 passes only fill the pipeline (`it` < 0), every later pass waits for the oldest
+    // chunk in flight, requests one more and multiplies; a tile's epilogue runs in the pass of its last chunk.
     int tile = blockIdx.x;
+    int k_cur = 0;
     bool after_ep = false;
-    while (true) {
 #pragma unroll
-        for (int mt = 0; mt < MT; mt++)
+    for (int mt = 0; mt < MT; mt++)
 #pragma unroll
-            for (int nt = 0; nt < NT; nt++)
+        for (int nt = 0; nt < NT; nt++)
 #pragma unroll
-                for (int k = 0; k < 16; k++) acc[mt][nt][k] = 0.f;
-
-        for (int k = 0; k < nchunks; k++) {
+            for (int k = 0; k < 16; k++) acc[mt][nt][k] = 0.f;
+    int n_stamp = 0;
+    auto stamp = [&](int tag) __attribute__((always_inline)) {
+        if ((p.dbg & 32) && blockIdx.x == 0 && wave == (p.dbg >> 8) && n_stamp < 4000) {
+            const unsigned long long tm = __builtin_amdgcn_s_memtime();
+            if (lane == 0) p.stamps[n_stamp] = (tm << 8) | (unsigned)tag;
+            n_stamp++;
+        }
+    };
+#pragma unroll 1
+    for (int it = -(G::NBUF - 1);; it++) {
+        stamp(1);
+        if (it >= 0) {
             // chunk `cbuf` must have landed: everything younger in this wave's queue may stay in flight -- the next chunk's
             // DMAs (inflight == 2) and, right after a tile's vector epilogue, its stores
             if (inflight > 1) { if (after_ep && p.out_mode == OUT_VEC16) vm_wait<G::DPC + EP_STORES>(); else vm_wait<G::DPC>(); }
             else              { if (after_ep && p.out_mode == OUT_VEC16) vm_wait<EP_STORES>(); else vm_wait<0>(); }
             after_ep = false;
+            stamp(2);
             __builtin_amdgcn_s_barrier();                  // every wave's share has landed; every wave is done with the buffer requested next
-            issue_next();
-            compute_chunk(cbuf);
-            cbuf = cbuf == G::NBUF - 1 ? 0 : cbuf + 1;
-            inflight--;
+            stamp(3);
         }
+        issue_next();
+        stamp(4);
+        if (it < 0) continue;
+        if (!(p.dbg & 4)) compute_chunk(cbuf);
+        stamp(5);
+        cbuf = cbuf == G::NBUF - 1 ? 0 : cbuf + 1;
+        inflight--;
+        if (++k_cur < nchunks) continue;
+        k_cur = 0;
 
         // ---- epilogue: D col = lane & 31 (pixel), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) (cout)
         const int e_z = dpar ? d_z1 : d_z0;
         const int e_n = dpar ? d_n1 : d_n0, e_oy0 = dpar ? d_oy01 : d_oy00, e_ox0 = dpar ? d_ox01 : d_ox00, e_m0 = dpar ? d_m01 : d_m00;
         const unsigned char* side = smem + (size_t)G::NBUF * G::LDS_BUF * 16 + (size_t)dpar * G::EP_FLOATS * 4;
+        // per-cout constants of this lane's rows, gain folded in: v = clamp(act(acc * scale + noise + bias) * gain) with a
+        // positively homogeneous activation (linear / relu / lrelu, gain > 0) is med3(max(u, u * slope), -cl, cl),
+        // u = acc * (scale * gain) + (bias + noise) * gain  --  one fma, one multiply, one max, one median per value
+        f32x4 sg[MT][4], bg[MT][4];
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int r0 = (wmx * MT + mt) * 32 + 8 * g + 4 * half;
+                sg[mt][g] = *(lds_f4)(side + (size_t)r0 * 4);
+                bg[mt][g] = *(lds_f4)(side + (size_t)(G::EPS + r0) * 4);
+            }
+        float nzv[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; nt++) {
             const int row_l = (wpx * NT + nt) * G::RP + l31 / TWL, col_l = l31 % TWL;
+            nzv[nt] = *(lds_f)(side + (size_t)(2 * G::EPS + row_l * G::TW + col_l) * 4);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                if (has_scale) sg[mt][g] = sg[mt][g] * gain;
+                else sg[mt][g] = f32x4{gain, gain, gain, gain};
+                bg[mt][g] = bg[mt][g] * gain;
+            }
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) {
+            if (p.dbg & 8) break;
+            const int row_l = (wpx * NT + nt) * G::RP + l31 / TWL, col_l = l31 % TWL;
             const int oy = e_oy0 + row_l, ox = e_ox0 + col_l;
             const bool pix_ok = oy < p.OH && ox < p.OW;
-            const float nz = *(lds_f)(side + (size_t)(2 * G::EPS + row_l * G::TW + col_l) * 4) * noise_gain;
+            const float nz = nzv[nt] * noise_gain * gain;
             const int64_t pix_off = (int64_t)e_z * p.ws_slice + (int64_t)e_n * p.ys[0] + (int64_t)(oy * p.osy + p.ooy) * p.ys[2] + (int64_t)(ox * p.osx + p.oox) * p.ys[3];
 #pragma unroll
             for (int mt = 0; mt < MT; mt++) {
                 const int mloc = (wmx * MT + mt) * 32;
                 float v[16];
 #pragma unroll
-                for (int g = 0; g < 4; g++) {
-                    const int r0 = mloc + 8 * g + 4 * half;
-                    f32x4 sc4 = *(lds_f4)(side + (size_t)r0 * 4);
-                    const f32x4 bi4 = *(lds_f4)(side + (size_t)(G::EPS + r0) * 4);
-                    if (!has_scale) sc4 = f32x4{1.f, 1.f, 1.f, 1.f};
+                for (int g = 0; g < 4; g++)
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
-                        float u = acc[mt][nt][4 * g + j] * sc4[j] + nz + bi4[j];
-                        u = u > 0.f ? u : u * slope;
-                        v[4 * g + j] = fminf(fmaxf(u * gain, -cl), cl);
+                        const float u = fmaf(acc[mt][nt][4 * g + j], sg[mt][g][j], bg[mt][g][j] + nz);
+                        v[4 * g + j] = __builtin_amdgcn_fmed3f(fmaxf(u, u * slope), -cl, cl);
                     }
-                }
                 if (p.out_mode == OUT_VEC16) {
                     // ys[1] == 1, Cout % 8 == 0: 8 consecutive couts of one pixel per lane after the half-wave exchange
                     const unsigned short* rp = (const unsigned short*)p.f.residual;
@@ -451,8 +512,17 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_mfma16(Conv16Params p) {
                             a[d] = r[0]; b[d] = r[1];
                         }
                         const int co = e_m0 + mloc + 8 * (g0 + half);
-                        const unsigned so = (pix_ok && co < p.Cout) ? (unsigned)(pix_off + co) * 2u : SENTINEL;
+                        const unsigned so = (pix_ok && co < p.Cout && !(p.dbg & 1)) ? (unsigned)(pix_off + co) * 2u : SENTINEL;
                         __builtin_amdgcn_raw_buffer_store_b128(u32x4{a[0], a[1], b[0], b[1]}, yrsrc, (int)so, 0, 0);
+                    }
+                } else if (p.out_mode == OUT_VEC32) {
+                    // float32 channels-last (the split-K workspace): a lane's four consecutive couts are one 16-byte store
+#pragma unroll
+                    for (int g = 0; g < 4; g++) {
+                        const int co = e_m0 + mloc + 8 * g + 4 * half;
+                        const unsigned so = (pix_ok && co < p.Cout) ? (unsigned)(pix_off + co) * 4u : SENTINEL;
+                        __builtin_amdgcn_raw_buffer_store_b128(u32x4{__builtin_bit_cast(unsigned, v[4 * g]), __builtin_bit_cast(unsigned, v[4 * g + 1]),
+                                                                     __builtin_bit_cast(unsigned, v[4 * g + 2]), __builtin_bit_cast(unsigned, v[4 * g + 3])}, yrsrc, (int)so, 0, 0);
                     }
                 } else {
 #pragma unroll
@@ -475,10 +545,17 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_mfma16(Conv16Params p) {
             }
         }
         after_ep = true;
+        stamp(6);
         if (tile + (int)gridDim.x >= total) break;
         tile += gridDim.x;
         dpar ^= 1;
         c_ahead--;
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+                for (int k = 0; k < 16; k++) acc[mt][nt][k] = 0.f;
     }
 }
 
@@ -488,11 +565,16 @@ int launch16(const Conv16Params& p0, hipStream_t s) {
     Conv16Params p = p0;
     p.tilesX = (p.OW + G::TW - 1) / G::TW;
     p.tilesY = (p.OH + G::TH - 1) / G::TH;
-    p.mblocks = (p.CoutP + G::BM - 1) / G::BM;
+    p.mblocks = (p.Cout + G::BM - 1) / G::BM;              // (not CoutP: the packing pads to 64, a 32-cout block would be all padding)
     const int64_t tiles = (int64_t)p.N * p.tilesX * p.tilesY * p.mblocks * (p.ksplit > 1 ? p.ksplit : 1);
     if (tiles > 0x7fffffffLL) return PG_ERR_TOO_LARGE;
     p.total_tiles = (int)tiles;
     if (p.ksplit > 1 && p.kpart % KC != 0) return PG_ERR_INVALID_ARG;
+    auto magic = [&](int d) -> unsigned { return d <= 1 ? 0u : (unsigned)((0x100000000ULL + (unsigned)d - 1) / (unsigned)d); };
+    const int dmax = std::max(std::max(p.tilesX, p.tilesY), std::max(p.mblocks, p.ksplit > 1 ? p.ksplit : 1));
+    if (tiles * dmax >= 0x100000000LL) return PG_ERR_TOO_LARGE;          // exactness bound of div_magic
+    p.m_tilesX = magic(p.tilesX); p.m_tilesY = magic(p.tilesY); p.m_mblocks = magic(p.mblocks); p.m_ksplit = magic(p.ksplit);
+    if ((int64_t)p.N * p.H * p.W * p.xC * 2 > 0x7fffffffLL) return PG_ERR_TOO_LARGE;      // whole-tensor descriptor of x
     const int64_t blocks = tiles < (int64_t)num_cu() ? tiles : (int64_t)num_cu();       // persistent: one workgroup per CU
     auto kern = conv2d_mfma16<T, KH, KW, S, TWL, WM, MT, NT, KC, NB>;
     static PerDeviceOnce lds_attr;

@@ -106,7 +106,7 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, res
         if out is not None:
             return out
     if plain_geometry and _fast16_ok(x, weight, styles, noise):
-        out = _modconv_fast16(x, weight, styles, noise, up, padding, resample_filter, demodulate, flip_weight, _epilogue)
+        out = _modconv_fast16(x, weight, styles, noise, up, padding, resample_filter, demodulate, flip_weight, _cache, _epilogue)
         if out is not None:
             return out
     y = _modconv_graph(x, weight, styles, noise, up, down, padding, resample_filter, demodulate, flip_weight, fused_modconv)
@@ -165,12 +165,27 @@ def _modconv_fast(x, weight, styles, noise, up, padding, resample_filter, demodu
     return y
 
 
-def _modconv_fast16(x, weight, styles, noise, up, padding, resample_filter, demodulate, flip_weight, epilogue):
+def _up2_composite_phases(wt_iohw, f):
+    """Stride-2 transposed 3x3 convolution followed by the 4x4 FIR (gain 4, padding [1,1,1,1]) == one 6x6 kernel
+    K = 4 * (f (*) w) applied at stride 2, i.e. four 3x3 convolutions of the LOW-resolution input, one per output parity
+    (a, b):  out[2q+a, 2r+b] = sum_{ty,tx} K[1 - 2 ty + a, 1 - 2 tx + b] * x[q + ty - 1, r + tx - 1]   (index range -3..2).
+    The (2H+1)^2 intermediate of the two-step form (conv2d_resample.py:125-142) is never written or read: in half
+    precision that traffic, not the 4x multiply count, is what the layer costs.  Returns {(a, b): IOHW weights}."""
+    cin, cout = int(wt_iohw.shape[0]), int(wt_iohw.shape[1])
+    k6 = 4 * torch.nn.functional.conv2d(wt_iohw.reshape(cin * cout, 1, 3, 3), f.flip([0, 1])[None, None].to(wt_iohw.dtype), padding=3)
+    k6 = k6.reshape(cin, cout, 6, 6)
+    return {(a, b): k6[:, :, [4 + a, 2 + a, a]][:, :, :, [4 + b, 2 + b, b]].contiguous() for a in (0, 1) for b in (0, 1)}
+
+
+def _modconv_fast16(x, weight, styles, noise, up, padding, resample_filter, demodulate, flip_weight, cache, epilogue):
     """bf16 / fp16 inference route: the reference's fused form (networks.py:85-94) -- per-sample weights
     T(w * styles * dcoefs) -- packed by one small kernel, then ONE launch of the 16-bit MFMA convolution per output phase
-    with noise / bias / activation / gain / clamp (/ residual) in its epilogue; for up=2 the tail rides in the FIR pass."""
+    with noise / bias / activation / gain / clamp (/ residual) in its epilogue.  up=2 with the usual 3x3 kernel and 4-tap
+    filter runs as four 3x3 launches on composite weights (`_up2_composite_phases`); other up=2 shapes as the transposed
+    convolution's phases followed by the FIR pass that also carries the tail."""
     cout, cin, kh, kw = (int(v) for v in weight.shape)
     n, _, h, w = x.shape
+    cache = cache if cache is not None else _PackCache()
     ep = dict(epilogue) if epilogue else {}
     w32, s32 = weight.detach().float(), styles.detach().float()
     dcoefs = conv2d_mfma.modconv_dcoefs(w32, s32) if demodulate else None
@@ -182,10 +197,25 @@ def _modconv_fast16(x, weight, styles, noise, up, padding, resample_filter, demo
     fw, fh = upfirdn2d._get_filter_size(resample_filter)
     tpad, fir_pad = _up2_geometry(kh, kw, fw, fh, padding)
     out_hw = ((h - 1) * 2 - 2 * tpad[0] + kh, (w - 1) * 2 - 2 * tpad[1] + kw)
-    wt = w32.transpose(0, 1)
-    if flip_weight:
-        wt = wt.flip([2, 3])
-    phases = conv2d_mfma16.pack_transposed(wt.contiguous(), x.dtype, 2, tpad, (h, w), out_hw, styles=s32, dcoefs=dcoefs)
+
+    def transposed_weight():
+        wt = w32.transpose(0, 1)
+        return (wt.flip([2, 3]) if flip_weight else wt).contiguous()
+    if (kh, kw, fw, fh) == (3, 3, 4, 4) and tuple(tpad) == (0, 0) and list(fir_pad) == [1, 1, 1, 1] and resample_filter.ndim == 2 \
+            and os.environ.get('PG_UP2_COMPOSITE', '1') != '0':
+        phases = cache.get(('up2_composite', flip_weight), [weight], lambda: _up2_composite_phases(transposed_weight(), resample_filter.float()))
+        y = torch.empty([n, cout, 2 * h, 2 * w], dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        xcl = conv2d_mfma16.to_channels_last(x)
+        res = ep.pop('residual', None)
+        for (a, b), wab in phases.items():
+            packed, per, _ = conv2d_mfma16.pack_weight(wab, x.dtype, transpose_oi=True, styles=s32, dcoefs=dcoefs)
+            nz = None
+            if noise is not None:       # the phase's samples of the output-resolution noise map
+                nz = noise.reshape(-1, 2 * h, 2 * w)[:, a::2, b::2].contiguous()
+            conv2d_mfma16.conv2d_forward(xcl, packed, cout, 3, 3, pad=(1, 1), out_hw=(h, w), y=y, out_step=(2, 2), out_off=(a, b), sample_stride=per,
+                                         noise=nz, **ep)
+        return y if res is None else y.add_(res)
+    phases = conv2d_mfma16.pack_transposed(transposed_weight(), x.dtype, 2, tpad, (h, w), out_hw, styles=s32, dcoefs=dcoefs)
     if phases is None:
         return None
     y = conv2d_mfma16.conv_transpose2d_forward(x, phases, cout, out_hw, stride=2)

@@ -1,0 +1,34 @@
+"""Dev tool (GPU box): where one wave of the 16-bit conv kernel spends its cycles (s_memtime stamps, PG_CONV16_DBG=32)."""
+import sys, os, ctypes, collections
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'pasta-gan-plusplus_amd'))
+import torch
+from torch_utils import custom_ops
+custom_ops.verbosity = 'none'
+from torch_utils.ops import conv2d_mfma16 as M
+lib = M._init()
+buf = torch.zeros(4096, dtype=torch.int64, device='cuda')
+lib.pg_conv2d16_debug_stamps.argtypes = [ctypes.c_void_p]
+lib.pg_conv2d16_debug_stamps(ctypes.c_void_p(buf.data_ptr()))
+dt = torch.bfloat16
+names = {1: 'loop-top', 2: 'after-wait', 3: 'after-barrier', 4: 'after-issue', 5: 'after-compute', 6: 'after-epilogue'}
+for arg in sys.argv[1:] or ['4,32,32,1024,3']:
+    N, cin, cout, H, K = (int(v) for v in arg.split(','))
+    x = torch.randn(N, cin, H, H, device='cuda').to(dt).contiguous(memory_format=torch.channels_last)
+    w = torch.randn(cout, cin, K, K, device='cuda') / (K * cin ** 0.5)
+    pk, _, _ = M.pack_weight(w, dt)
+    bias = torch.randn(cout, device='cuda')
+    for wv in (0, 5):
+        os.environ['PG_CONV16_DBG'] = str(32 | (wv << 8))
+        buf.zero_()
+        M.conv2d_forward(x, pk, cout, K, K, pad=(K // 2, K // 2), bias=bias, act='lrelu', alpha=0.2, gain=1.4, clamp=256)
+        torch.cuda.synchronize()
+        st = [(int(v) >> 8, int(v) & 255) for v in buf.cpu().tolist() if v != 0]
+        seg = collections.defaultdict(list)
+        for (t0, a), (t1, b) in zip(st[:-1], st[1:]):
+            seg[(a, b)].append(t1 - t0)
+        print(f'shape {arg} wave {wv}: {len(st)} stamps, span {st[-1][0] - st[0][0]} ticks')
+        for (a, b), v in sorted(seg.items()):
+            v2 = v[len(v) // 4:]
+            print(f'   {names[a]:>15} -> {names[b]:<15} n={len(v):4d} mean={sum(v2) / len(v2):8.0f} min={min(v2):6d} max={max(v2):7d}')
+    os.environ['PG_CONV16_DBG'] = '0'

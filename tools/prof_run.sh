@@ -1,8 +1,10 @@
+# usage (on the GPU box): bash tools/prof_run.sh <tag> <bench.py args...>     -> gpurun_out/prof_<tag>/kernel_stats.csv
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof
-mkdir -p $O
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_out -- python3 $R/bench.py --no-cpu-baseline --steps 7 --warmup 2 > $O/bench_under_rocprof.log 2>&1
+R=$GRAFT_REPO_ROOT; TAG=${1:-cfg2}; shift
+O=$R/gpurun_out/prof_$TAG
+mkdir -p $O; rm -rf /tmp/prof_out
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_out -- python3 $R/bench.py --no-cpu-baseline --steps 7 --warmup 2 "$@" > $O/bench_under_rocprof.log 2>&1
 f=$(find /tmp/prof_out -name "*kernel_stats.csv" | head -1)
 cp "$f" $O/kernel_stats.csv
-tail -1 $O/bench_under_rocprof.log | cut -c1-400
-head -40 $O/kernel_stats.csv
+tail -1 $O/bench_under_rocprof.log | cut -c1-300
+head -45 $O/kernel_stats.csv

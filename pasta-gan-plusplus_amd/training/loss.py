@@ -8,8 +8,10 @@ Not restated: the VGG perceptual and contextual terms (:336-618) -- their weight
 pass ``vgg_weight=0`` semantics are the only ones supported.  Path-length regularisation is commented out
 in the reference (:200-221), so a ``Greg`` phase only runs the style encoder.
 
-Gradient synchronisation is NOT done here (the reference toggles DDP's hooks through ``ddp_sync``):
-``training.ddp.GradBucket`` all-reduces one flat bucket per phase after the last accumulation round.
+Gradient synchronisation is NOT done here (the reference toggles DDP's hooks through ``ddp_sync``, letting only the
+LAST backward of the last accumulation round reduce): ``on_last_backward``, when set, is called right before that
+backward so that ``training.ddp.GradBucket`` can arm its exchange hooks (segments of the flat bucket are then reduced
+over RCCL while the rest of that backward still runs).
 """
 
 import torch
@@ -33,6 +35,7 @@ class StyleGAN2Loss:
         self.l1_weight, self.mask_weight = l1_weight, mask_weight
         self.class_weight = torch.tensor([1, 3, 4, 4, 4, 4, 4], dtype=torch.float32, device=device)   # loss_fullbody.py:53
         self.report = report or (lambda name, value: None)
+        self.on_last_backward = None          # callable; fired once per accumulate_gradients(sync=True), before its last backward
 
     # ------------------------------------------------------------------ forward helpers (loss_fullbody.py:75-114)
     def run_G(self, z, c, pose, const_feats, denorm_upper_mask, denorm_lower_mask, denorm_upper_input, denorm_lower_input, gt_parsing):
@@ -65,6 +68,15 @@ class StyleGAN2Loss:
         do_DPmain = phase in ('D_parsingmain', 'D_parsingboth')
         do_DPr1 = phase in ('D_parsingreg', 'D_parsingboth') and self.r1_gamma != 0
 
+        # the backward calls of this round, in program order; with sync=True the last one is announced (loss_fullbody.py
+        # passes sync=False to every earlier one: "gets synced by loss_Dreal")
+        slots = [do_Gmain, do_Dmain, do_Dmain or do_Dr1, do_DPmain, do_DPmain or do_DPr1]
+        last_slot = max([i for i, on in enumerate(slots) if on], default=-1)
+
+        def before_backward(slot):
+            if sync and slot == last_slot and self.on_last_backward is not None:
+                self.on_last_backward()
+
         real_c, cat_feats = self.G_style_encoding(style_input, retain)
         gen_c = real_c                                               # the style code conditions both G and D (loss_fullbody.py:129)
         g_args = (gen_z, gen_c, pose, cat_feats, denorm_upper_mask, denorm_lower_mask, denorm_upper_input, denorm_lower_input, gt_parsing)
@@ -87,6 +99,7 @@ class StyleGAN2Loss:
             self.report('Loss/G/L1', l1)
             self.report('Loss/G/mask_loss', ce)
             self.report('Loss/G/loss_parsing', adv_parsing)
+            before_backward(0)
             loss_G.mul(gain).backward()
 
         loss_Dgen_fine = 0
@@ -94,25 +107,27 @@ class StyleGAN2Loss:
             gen_img, gen_fine, _, _ = self.run_G(*g_args)
             loss_Dgen = sat(self.run_D(gen_img, pose, gen_c))
             loss_Dgen_fine = sat(self.run_D(gen_fine, pose, gen_c))
+            before_backward(1)
             ((loss_Dgen.mean() + loss_Dgen_fine.mean()) / 2).mul(gain).backward()
 
         if do_Dmain or do_Dr1:                                       # D on real images (+ lazy R1)
             real_tmp = real_img.detach().requires_grad_(do_Dr1)
             real_logits = self.run_D(real_tmp, pose, real_c)
-            self._real_and_r1(real_logits, real_tmp, do_Dmain, do_Dr1, gain, 'D')
+            self._real_and_r1(real_logits, real_tmp, do_Dmain, do_Dr1, gain, 'D', lambda: before_backward(2))
 
         loss_DPgen = 0
         if do_DPmain:                                                # parsing discriminator on the predicted parsing
             _, _, pred_parsing, _ = self.run_G(*g_args)
             loss_DPgen = sat(self.run_D_parsing(torch.softmax(pred_parsing, dim=1), pose, gen_c))
+            before_backward(3)
             loss_DPgen.mean().mul(gain).backward()
 
         if do_DPmain or do_DPr1:                                     # ... and on the one-hot ground-truth parsing (+ lazy R1)
             onehot = torch.cat([(gt_parsing == k).to(gt_parsing.dtype) for k in range(7)], dim=1).detach().requires_grad_(do_DPr1)
             real_logits = self.run_D_parsing(onehot, pose, real_c)
-            self._real_and_r1(real_logits, onehot, do_DPmain, do_DPr1, gain, 'D_parsing')
+            self._real_and_r1(real_logits, onehot, do_DPmain, do_DPr1, gain, 'D_parsing', lambda: before_backward(4))
 
-    def _real_and_r1(self, real_logits, real_input, do_main, do_r1, gain, tag):
+    def _real_and_r1(self, real_logits, real_input, do_main, do_r1, gain, tag, announce=lambda: None):
         loss_real = F.softplus(-real_logits) if do_main else 0
         loss_r1 = 0
         if do_r1:                                                    # R1: gamma/2 * |d logits / d input|^2, without weight gradients of the inner pass
@@ -122,4 +137,5 @@ class StyleGAN2Loss:
             loss_r1 = penalty * (self.r1_gamma / 2)
             self.report(f'Loss/{tag}/r1_penalty', penalty)
         self.report(f'Loss/{tag}/real', loss_real)
+        announce()
         (real_logits * 0 + loss_real + loss_r1).mean().mul(gain).backward()

@@ -4,9 +4,12 @@ data-parallel over the GPUs of one node.
 Phases, in order (each with its own Adam; lazy regularisation rescales lr/betas by interval/(interval+1)):
     Gmain (1)  Greg (G_reg_interval)  Dmain (1)  Dreg (D_reg_interval)  D_parsingmain (1)  D_parsingreg (D_reg_interval)
     D_parsingmain (1)  D_parsingreg (D_reg_interval)        -- D_parsing is listed twice in the reference (:470-471)
-Per due phase: zero grads -> only the phase's module requires grad -> accumulate over the rounds of this rank's
-share of the batch -> ONE flat-bucket gradient all-reduce (training.ddp.GradBucket) -> nan_to_num -> Adam step.
-Then the G_ema update (:642-650).  ADA / ticks / snapshots / metrics are outside the hot path and not restated.
+Per due phase: gradients are views of the phase's flat bucket (training.ddp.GradBucket.begin) -> only the phase's
+module requires grad -> accumulate over the rounds of this rank's share of the batch; during the LAST backward of the
+last round finished segments of the bucket are already being summed over RCCL on a side stream -> finish the exchange
+-> nan_to_num -> Adam step.  A phase that produced no gradient on any rank (Greg: path-length regularisation is
+commented out in the reference, loss_fullbody.py:200-221) exchanges nothing and takes no optimizer step -- what the
+reference's Adam does with all-None gradients.  Then the G_ema update (:642-650).  ADA / ticks / snapshots / metrics are outside the hot path and not restated.
 """
 
 import copy
@@ -54,17 +57,19 @@ class TrainingStep:
         """`rounds`: this rank's accumulation rounds, each a dict of the tensors accumulate_gradients takes
         (real_img, gen_z, style_input, retain, pose, denorm_*_input, denorm_*_mask, gt_parsing)."""
         for ph in self.due_phases():
-            ph.opt.zero_grad(set_to_none=True)
+            ph.bucket.begin()                                    # zero the flat bucket; every .grad is a view into it
             for m in ph.modules:
                 m.requires_grad_(True)
             for r, batch in enumerate(rounds):
-                self.loss.accumulate_gradients(phase=ph.name, sync=(r == len(rounds) - 1), gain=ph.interval, **batch)
+                last = r == len(rounds) - 1
+                self.loss.on_last_backward = ph.bucket.last_round if last else None
+                self.loss.accumulate_gradients(phase=ph.name, sync=last, gain=ph.interval, **batch)
+            self.loss.on_last_backward = None
             for m in ph.modules:
                 m.requires_grad_(False)
-            ph.bucket.all_reduce_mean()                          # the one exchange step of the phase (RCCL over xGMI)
-            for p in ph.bucket.params:
-                if p.grad is not None:
-                    torch.nan_to_num(p.grad, nan=0, posinf=1e5, neginf=-1e5, out=p.grad)
+            if not ph.bucket.finish():                           # nobody produced a gradient (Greg): nothing to exchange, nothing to step
+                continue
+            torch.nan_to_num(ph.bucket.flat, nan=0, posinf=1e5, neginf=-1e5, out=ph.bucket.flat)
             ph.opt.step()
         self._update_ema()
         self.cur_nimg += self.batch_size

@@ -52,6 +52,9 @@ CONV2D_RESAMPLE_CASES = [
     ('grouped_up2',    [1, 8, 8, 8],   [12, 4, 3, 3], FIR_1331, 2, 1, 1, 2, False),
     ('odd_pad_generic', [1, 3, 10, 10], [4, 3, 3, 3], FIR_1331, 1, 1, [1, 0, 2, 1], 1, True),  # :150-154
     ('up2_down2',      [1, 3, 8, 8],   [4, 3, 3, 3], FIR_1331, 2, 2, 1, 1, True),
+    # wide enough (Cout > 32, Cin >= 16) for the product's Winograd F(2x2,3x3) kernel; ragged width (W % 4 != 0) takes its scalar-DMA form
+    ('plain3x3_wide',  [2, 32, 20, 24], [80, 32, 3, 3], FIR_1331, 1, 1, 1, 1, True),
+    ('plain3x3_wide_noflip_ragged', [1, 16, 13, 19], [64, 16, 3, 3], FIR_1331, 1, 1, 1, 1, False),
 ]
 
 # name, N, Cin, Cout, k, H, up, demodulate, fused, noise kind ('none' | 'const' | 'per_sample')
@@ -65,6 +68,9 @@ MODCONV_CASES = [
     ('torgb_fused',            2, 5, 3, 1, 9, 1, False, True,  'none'),
     ('torgb_nonfused',         2, 5, 3, 1, 9, 1, False, False, 'none'),
     ('nodemod_noise_nonfused', 2, 5, 6, 3, 9, 1, False, False, 'const'),
+    # wide enough for the product's Winograd kernel (modulated form: style scale in the prologue, demodulation + noise in the tail)
+    ('fused_demod_noise_wide', 2, 32, 72, 3, 16, 1, True,  True,  'const'),
+    ('nonfused_demod_wide',    2, 16, 64, 3, 12, 1, True,  False, 'per_sample'),
 ]
 
 # Reduced synthesis network for G6 (full 512^2 spatial size, small channel counts).

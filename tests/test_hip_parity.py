@@ -822,3 +822,119 @@ def test_full_width_training_iteration_smoke():
     assert all(torch.isfinite(p).all() for m in (G, D, DP) for p in m.parameters())
     assert sum(int(not torch.equal(a, b)) for a, b in zip(before, after)) >= 8
     assert step.batch_idx == 1
+
+
+# =============================================================== round-2 parity holes
+
+def test_synthesis_full_width_batch8_vs_oracle():
+    """BASELINE config 2 at its REAL batch (N=8, one launch sequence) against the CPU oracle run image by image on three of
+    the eight images (first, an odd middle one, last): the tile -> image index maths of the persistent, XCD-remapped conv
+    kernels is what an N-dependent bug would break."""
+    from training import networks as PN
+    from oracle import network_ref as NR
+    kw = dict(w_dim=512, img_resolution=512, img_channels=3, channel_base=32768, channel_max=512, conv_clamp=256)
+    ref_net = fill_module_(NR.SynthesisNetworkFull_v18(**kw), 'cfg2.').eval()
+    net = _load(PN.SynthesisNetworkFull_v18(**kw), ref_net)
+    n = 8
+    inp = synthesis_inputs(n, labels=True)
+    args = lambda f: (f(inp['ws']), f(inp['pose_feat']), {k: f(v) for k, v in inp['cat_feat'].items()}, f(inp['denorm_upper_input']),
+                      f(inp['denorm_lower_input']), f(inp['denorm_upper_mask']), f(inp['denorm_lower_mask']), f(inp['gt_parsing']))
+    with torch.no_grad():
+        out = [o.cpu() for o in net(*args(lambda t: t.to(DEV)), noise_mode='const')]
+        for i in (0, 3, 7):
+            ref = ref_net(*args(lambda t: t[i:i + 1]), noise_mode='const')
+            for nm, a, b in zip(('img', 'finetune_img', 'pred_parsing'), out, ref):
+                s = scale_of(b)
+                delta = float((a[i:i + 1].double() - b.double()).abs().max())
+                assert delta <= 1e-3 * s, f'image {i} {nm}: max-abs delta {delta:.3e} vs output range {s:.3e}'
+
+
+def test_config3_chain_patch_routing_into_generator_n16():
+    """BASELINE config 3 end to end on the product: patch routing (HIP warps) -> uint8 tensors normalised as test.py does
+    (test.py:126-147) -> GeneratorFull_v20 at N=16.  Checks: finite outputs, and every image of the batch equals the N=1 run
+    of the same sample (four distinct samples, each four times in the batch)."""
+    from training import networks as PN
+    from training import patch_routing as P
+    sys_path_ok = True
+    from test_patch_routing import keypoints
+    rng = np.random.default_rng(3)
+    samples = []
+    for k in range(4):
+        ckp, pkp = keypoints(rng, 8.0), keypoints(rng, 8.0)
+        up, lo = (rng.integers(0, 256, (512, 512, 3), dtype=np.uint8) for _ in range(2))
+        um = np.zeros((512, 512, 3), np.uint8); um[90:310, 150:370] = 255
+        lm = np.zeros((512, 512, 3), np.uint8); lm[270:505, 190:330] = 255
+        norm_img, norm_lower, den_up, _, den_lo = P.normalize(up, lo, um, lm, None, ckp, pkp, 2)
+        f = lambda t: t.permute(2, 0, 1).float() / 127.5 - 1            # HWC uint8 -> CHW in [-1, 1]
+        samples.append(dict(
+            c=torch.cat([f(norm_img), f(norm_lower)], dim=0),
+            du=f(den_up), dl=f(den_lo),
+            mu=(den_up.sum(dim=2, keepdim=True) > 0).permute(2, 0, 1).float(), ml=(den_lo.sum(dim=2, keepdim=True) > 0).permute(2, 0, 1).float(),
+            retain=torch.from_numpy(rng.uniform(-1, 1, (6, 512, 512)).astype(np.float32)).to(DEV),
+            pose=torch.from_numpy(rng.uniform(-1, 1, (5, 512, 512)).astype(np.float32)).to(DEV)))
+        assert samples[-1]['c'].shape == (45, 128, 128) and float(samples[-1]['mu'].sum()) > 0
+    kw = dict(z_dim=0, c_dim=512, w_dim=512, img_resolution=512, img_channels=3, mapping_kwargs=dict(num_layers=1),
+              synthesis_kwargs=dict(channel_base=32768, channel_max=512, conv_clamp=256))
+    net = fill_module_(PN.GeneratorFull_v20(**kw), 'cfg3.').to(DEV).eval()
+
+    def run(idx):
+        st = lambda key: torch.stack([samples[i][key] for i in idx]).to(DEV)
+        with torch.no_grad():
+            return net(torch.zeros([len(idx), 0], device=DEV), st('c'), st('retain'), st('pose'), st('du'), st('dl'), st('mu'), st('ml'), noise_mode='const')
+    order = [i % 4 for i in range(16)]
+    batch = run(order)
+    assert all(o.shape[0] == 16 and torch.isfinite(o).all() for o in batch)
+    for k in (0, 3):
+        single = run([k])
+        for nm, a, b in zip(('img', 'finetune_img', 'pred_parsing'), batch, single):
+            s = scale_of(b)
+            for pos in (k, k + 12):                                     # first and last occurrence of sample k in the batch
+                delta = float((a[pos:pos + 1] - b).abs().max())
+                assert delta <= 1e-4 * s, f'sample {k} at batch slot {pos}, {nm}: {delta:.3e} vs range {s:.3e}'
+
+
+def test_discriminator_fp16_blocks_vs_oracle():
+    """Row f2 in half precision: Discriminator(num_fp16_res=3) -- its three highest resolutions in fp16 on the 16-bit MFMA
+    convolution (channels-last), conv_clamp 256 as train.py:196-197 sets -- against the float32 CPU oracle.  Tolerance: fp16
+    activations carry 2^-11 relative rounding per layer; 3 blocks x 3 convs + the float32 tail -> 2e-2 of the logit scale."""
+    from training import networks as PN
+    from oracle import network_ref as NR
+    kw = dict(c_dim=16, img_resolution=64, img_channels=6, channel_base=1024, channel_max=64, conv_clamp=256,
+              mapping_kwargs=dict(num_layers=2), epilogue_kwargs=dict(mbstd_group_size=2))
+    ref = fill_module_(NR.Discriminator(**kw), 'dfp16.')
+    d = PN.Discriminator(num_fp16_res=3, **kw)
+    d.load_state_dict(ref.state_dict(), strict=False)
+    d = d.to(DEV).train()
+    assert [b.use_fp16 for b in (d.b64, d.b32, d.b16, d.b8)] == [True, True, True, False]
+    img = det_tensor('dfp16.img', [4, 6, 64, 64], 'uniform')
+    c = det_tensor('dfp16.c', [4, 16])
+    want = ref(img, c)
+    x = img.to(DEV).requires_grad_(True)
+    got = d(x, c.to(DEV))
+    assert got.dtype == torch.float32
+    tol = 2e-2 * scale_of(want)
+    assert float((got.detach().cpu() - want.detach()).abs().max()) <= tol
+    # the training-step use: R1 penalty through the fp16 blocks (double backward) stays finite and close to the fp32 one
+    gi, = torch.autograd.grad(got.sum(), x, create_graph=True)
+    pen = gi.square().sum([1, 2, 3])
+    pen.sum().backward()
+    xi = img.clone().requires_grad_(True)
+    gr, = torch.autograd.grad(ref(xi, c).sum(), xi, create_graph=True)
+    pen_ref = gr.square().sum([1, 2, 3])
+    assert torch.isfinite(pen).all() and all(p.grad is None or torch.isfinite(p.grad).all() for p in d.parameters())
+    assert float((pen.detach().cpu() - pen_ref.detach()).abs().max()) <= 6e-2 * float(pen_ref.abs().max())
+
+
+def test_modulated_conv2d_fp16_prenorm_golden(golden):
+    """The reference's fp16 pre-normalisation path (networks.py:57-59; golden made by the reference in fp16 on the CPU)."""
+    from training import networks
+    from torch_utils.ops import upfirdn2d
+    g = golden('g4_modconv.npz')
+    if 'fp16_prenorm/y' not in g:
+        pytest.skip('fixture lacks the fp16 case')
+    name = 'fp16_prenorm'
+    x = det_tensor(name + '.x', [2, 5, 9, 9]).half().to(DEV)
+    y = networks.modulated_conv2d(x, det_tensor(name + '.w', [6, 5, 3, 3]).to(DEV), (det_tensor(name + '.s', [2, 5]) + 1.0).to(DEV), padding=1,
+                                  resample_filter=upfirdn2d.setup_filter(C.FIR_1331).to(DEV), fused_modconv=False)
+    assert y.dtype == torch.float16
+    close(y.float(), g[f'{name}/y'], rtol=1e-2, atol=1e-2)

@@ -76,29 +76,77 @@ def _ddp_worker(rank, world, init_file, out_file):
     full = stubs.batch(4)
     mine = {k: v[rank::world] for k, v in full.items()}            # rank-strided shard of the batch
     stubs.set_phase_trainable(nets, 'Dboth')
-    loss.accumulate_gradients(phase='Dboth', **mine)
     params = list(nets['D'].parameters())
-    assert params[0].grad is not None
     extra = torch.nn.Parameter(torch.zeros(3))                      # a parameter that never receives a gradient
-    bucket = ddp.GradBucket(params + [extra])
-    bucket.all_reduce_mean()
-    assert extra.grad is not None and float(extra.grad.abs().sum()) == 0.0
+    bucket = ddp.GradBucket(params + [extra], segments=3)
+    assert len(bucket.seg_range) >= 2                               # several segments: some launch from the hooks, the rest in finish()
+    bucket.begin()
+    assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(bucket.params, bucket.views))      # gradients ARE the bucket
+    loss.on_last_backward = bucket.last_round                       # Dboth = two backward calls; only the second may exchange
+    loss.accumulate_gradients(phase='Dboth', sync=True, **mine)
+    launched_by_hooks = sum(bucket._launched)
+    assert bucket.finish() is True
+    assert extra.grad is None                                       # untouched on every rank: stays None (no zero gradient for Adam)
+    assert all(p.grad is not None for p in params)
     if rank == 0:
-        np.savez(out_file, **{f'p{i}': p.grad.numpy() for i, p in enumerate(params)})
+        np.savez(out_file, launched_by_hooks=launched_by_hooks, **{f'p{i}': p.grad.numpy() for i, p in enumerate(params)})
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_flat_bucket_all_reduce_two_ranks():
+def test_flat_bucket_overlapped_exchange_two_ranks():
     """mean over 2 ranks of per-shard gradients == gradient of the mean loss over the whole batch (the StubD has no
-    cross-sample coupling), for a phase with a double-backward term (R1)."""
+    cross-sample coupling), for a phase with two backward calls and a double-backward term (R1); at least one segment
+    of the bucket was exchanged from the autograd hooks, i.e. while the last backward was still running."""
     with tempfile.TemporaryDirectory() as tmp:
         init_file, out_file = os.path.join(tmp, 'rdzv'), os.path.join(tmp, 'g.npz')
         mp.spawn(_ddp_worker, args=(2, init_file, out_file), nprocs=2, join=True)
         got = np.load(out_file)
+    assert int(got['launched_by_hooks']) >= 1
     nets = stubs.build()
     loss = _loss(nets)
     stubs.set_phase_trainable(nets, 'Dboth')
     loss.accumulate_gradients(phase='Dboth', **stubs.batch(4))
     for i, p in enumerate(nets['D'].parameters()):
         np.testing.assert_allclose(got[f'p{i}'], p.grad.numpy(), rtol=2e-4, atol=1e-6)
+
+
+def _step_worker(rank, world, init_file, out_file):
+    sys.path.insert(0, PKG)
+    from training.training_step import TrainingStep
+    torch.set_num_threads(2)
+    if world > 1:
+        dist.init_process_group('gloo', init_method=f'file://{init_file}', rank=rank, world_size=world)
+    nets = stubs.build()
+    G_parts = {k: v for k, v in nets.items() if k.startswith('G_')}
+    step = TrainingStep(G_parts, nets['D'], nets['D_parsing'], _loss(nets), batch_size=4)
+    full = stubs.batch(4)
+    mine = {k: v[rank::world] for k, v in full.items()}
+    for _ in range(5):                                              # iterations 0 and 4 contain a Greg phase
+        step.run([mine])
+    if rank == 0:
+        g_opt = step.phases[0].opt
+        st = [g_opt.state[p] for p in g_opt.param_groups[0]['params'] if p in g_opt.state]
+        np.savez(out_file, steps=np.array([float(s_['step']) for s_ in st]), v=np.array([float(s_['exp_avg_sq'].sum()) for s_ in st]),
+                 w=np.array([float(p.double().sum()) for p in nets['G_synthesis'].parameters()]))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_training_step_is_world_size_invariant_through_greg():
+    """a Greg phase produces no gradient; it must not step Adam on zero gradients when world > 1.  Five
+    iterations on 1 rank and on 2 ranks (same global batch) must leave identical Adam step counts and (up to the
+    reduction order) identical second-moment statistics and weights."""
+    res = {}
+    for world in (1, 2):
+        with tempfile.TemporaryDirectory() as tmp:
+            init_file, out_file = os.path.join(tmp, 'rdzv'), os.path.join(tmp, 'o.npz')
+            if world == 1:
+                _step_worker(0, 1, init_file, out_file)
+            else:
+                mp.spawn(_step_worker, args=(world, init_file, out_file), nprocs=world, join=True)
+            res[world] = dict(np.load(out_file))
+    assert np.array_equal(res[1]['steps'], res[2]['steps']) and res[1]['steps'].max() == 5     # Gmain stepped 5 times, Greg never
+    np.testing.assert_allclose(res[2]['v'], res[1]['v'], rtol=1e-2)         # (stepping on zero gradients would show as ~20 %)
+    np.testing.assert_allclose(res[2]['w'], res[1]['w'], rtol=2e-3, atol=1e-4)        # two half-batch means vs one full-batch mean: reduction order only

@@ -220,6 +220,16 @@ int pg_spade_feat_assemble(const float* feat_upper, const float* feat_lower, con
                            float* out, int N, int C, int H, int W, void* stream);
 int pg_conv2d_abi_version(void);
 
+/* Weight gradient of a stride-1 float32 NCHW convolution (3x3 or 1x1) -- what conv2d_gradfix.py:137-150 asks
+ * aten::cudnn_convolution_backward_weight for:
+ *   dw[co, ci, ky, kx] = sum_{n, oy, ox} dy[n, co, oy, ox] * x[n, ci, oy + ky - pad_y, ox + kx - pad_x]
+ * A GEMM over pixels on the fp32 MFMA, split `splits` ways over the pixel axis with a fixed-order second pass (deterministic).
+ * pg_conv2d_wgrad_plan returns the `splits` to use (0 = geometry not covered); `workspace` holds splits * KH*KW * Cout * Cin floats. */
+int pg_conv2d_wgrad_plan(int N, int Cin, int OH, int OW, int Cout, int KH, int KW);
+int pg_conv2d_wgrad(const float* x, const float* dy, float* dw, float* workspace,
+                    int N, int Cin, int H, int W, int Cout, int KH, int KW, int pad_y, int pad_x, int OH, int OW,
+                    int splits, void* stream);
+
 /* ------------------------------------------------------------------------
  * 16-bit convolution (bf16 / fp16 storage, fp32 accumulation) on v_mfma_f32_32x32x16_{bf16,f16}: what cuDNN does behind
  * conv2d_gradfix.py:35-43 for the reference's half-precision blocks (discriminator `use_fp16`, networks.py:444-523;

@@ -1,0 +1,175 @@
+// Weight gradient of a stride-1 fp32 NCHW convolution for gfx950 as a GEMM over pixels on v_mfma_f32_32x32x2_f32.
+//
+// What it replaces in the reference: `aten::cudnn_convolution_backward_weight` behind conv2d_gradfix
+// (torch_utils/ops/conv2d_gradfix.py:137-150) for the geometries that carry the training step's FLOPs (3x3 and 1x1,
+// stride 1: the SPADE blocks, the style-branch conv1 layers, ToRGB, the discriminator's conv0):
+//     dw[co, ci, ky, kx] = sum_{n, oy, ox} dy[n, co, oy, ox] * x[n, ci, oy + ky - pad_y, ox + kx - pad_x]
+//
+// GEMM view:  M = Cout (A = dy: for a fixed cout the pixels are contiguous -> K-contiguous),
+//             N = Cin, once per tap (B = x shifted by the tap: K-contiguous as well),
+//             K = N * OH * OW pixels, two adjacent pixels per MFMA (lanes 0-31 hold pixel 2j, lanes 32-63 pixel 2j+1).
+// Workgroup = 4 waves = 64 couts x 64 cins x all taps; a wave owns one 32 x 32 block for every tap (KH*KW accumulators).
+// The K axis is what gives parallelism: workgroup s of `splits` walks pixel chunks s, s + splits, ... (2 rows x 32 columns of one
+// image each), stages dy[64][64] and the x halo [64][2 + KH - 1][32 + KW - 1] in LDS (odd pitches: both operand reads are
+// conflict-free) and accumulates; its partial block goes to workspace[s][tap][co][ci] and a second pass adds the partials
+// in fixed order (deterministic, no atomics).
+//
+// Roofline: MFMA.  Algorithmic FLOPs = 2 * N * OH * OW * Cout * Cin * KH * KW (the forward pass's count) against 157.3 TFLOP/s.
+#include "pg_common.h"
+
+namespace {
+
+using namespace pg;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int WG_TW = 32, WG_R = 2;            // pixel chunk: WG_R rows x WG_TW columns
+constexpr int WG_PIX = WG_TW * WG_R;
+constexpr int WG_BM = 64, WG_BN = 64;
+
+template <int KH, int KW>
+struct WGeo {
+    static constexpr int T = KH * KW;
+    static constexpr int IH = WG_R + KH - 1, IW = WG_TW + KW - 1;
+    static constexpr int PA = WG_PIX + 1;                               // dy row pitch (odd)
+    static constexpr int PB = (IH * IW) | 1;                            // x plane pitch (odd)
+    static constexpr int LDS_FLOATS = WG_BM * PA + WG_BN * PB;
+};
+
+struct WgradParams {
+    const float* x; const float* dy; float* ws;
+    int N, Cin, H, W, Cout, OH, OW, pad_y, pad_x;
+    int tilesX, tilesY, chunks, splits, coB, ciB;
+};
+
+template <int KH, int KW>
+__global__ __launch_bounds__(256, 2) void conv2d_wgrad(WgradParams p) {
+    typedef WGeo<KH, KW> G;
+    extern __shared__ float smem[];
+    float* dyt = smem;                          // [64 co][PA]
+    float* xt = smem + WG_BM * G::PA;           // [64 ci][PB]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int mt = wave & 1, nt = wave >> 1;
+    int b = blockIdx.x;
+    const int s = b % p.splits; b /= p.splits;
+    const int cib = b % p.ciB, cob = b / p.ciB;
+    const int co0 = cob * WG_BM, ci0 = cib * WG_BN;
+
+    f32x16 acc[G::T];
+#pragma unroll
+    for (int tp = 0; tp < G::T; tp++)
+#pragma unroll
+        for (int k = 0; k < 16; k++) acc[tp][k] = 0.f;
+
+    for (int ch = s; ch < p.chunks; ch += p.splits) {
+        int c = ch;
+        const int tx = c % p.tilesX; c /= p.tilesX;
+        const int ty = c % p.tilesY;
+        const int n = c / p.tilesY;
+        const int oy0 = ty * WG_R, ox0 = tx * WG_TW;
+        __syncthreads();                         // previous chunk's reads are done
+        // dy tile: 64 couts x (2 rows x 32 columns); a wave-iteration loads one cout's two 128-byte row segments
+        for (int e = t; e < WG_BM * WG_PIX; e += 256) {
+            const int co = e / WG_PIX, px = e % WG_PIX;
+            const int oy = oy0 + px / WG_TW, ox = ox0 + px % WG_TW;
+            const bool ok = co0 + co < p.Cout && oy < p.OH && ox < p.OW;
+            dyt[co * G::PA + px] = ok ? p.dy[(((int64_t)n * p.Cout + co0 + co) * p.OH + oy) * p.OW + ox] : 0.f;
+        }
+        // x halo tile: 64 cins x IH x IW, zero outside the image / beyond Cin
+        for (int e = t; e < WG_BN * G::IH * G::IW; e += 256) {
+            const int ci = e / (G::IH * G::IW), r = e % (G::IH * G::IW);
+            const int iy = oy0 - p.pad_y + r / G::IW, ix = ox0 - p.pad_x + r % G::IW;
+            const bool ok = ci0 + ci < p.Cin && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            xt[ci * G::PB + r] = ok ? p.x[(((int64_t)n * p.Cin + ci0 + ci) * p.H + iy) * p.W + ix] : 0.f;
+        }
+        __syncthreads();
+        const float* a_base = dyt + (mt * 32 + l31) * G::PA + half;
+        const float* b_base = xt + (nt * 32 + l31) * G::PB + half;
+#pragma unroll 4
+        for (int kk = 0; kk < WG_PIX / 2; kk++) {                       // two adjacent pixels per step
+            const int r = (2 * kk) / WG_TW, cc = (2 * kk) % WG_TW;
+            const float a = a_base[2 * kk];
+            float bv[G::T];
+#pragma unroll
+            for (int ky = 0; ky < KH; ky++)
+#pragma unroll
+                for (int kx = 0; kx < KW; kx++) bv[ky * KW + kx] = b_base[(r + ky) * G::IW + cc + kx];
+#pragma unroll
+            for (int tp = 0; tp < G::T; tp++) acc[tp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[tp], acc[tp], 0, 0, 0);
+        }
+    }
+    // partial block -> workspace[s][tap][co][ci]: D col = lane & 31 = ci (contiguous), row = (reg & 3) + 8 * (reg >> 2) + 4 * half = co
+    float* wsp = p.ws + (int64_t)s * G::T * p.Cout * p.Cin;
+    const int ci = ci0 + nt * 32 + l31;
+#pragma unroll
+    for (int tp = 0; tp < G::T; tp++)
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int co = co0 + mt * 32 + (k & 3) + 8 * (k >> 2) + 4 * half;
+            if (co < p.Cout && ci < p.Cin) wsp[((int64_t)tp * p.Cout + co) * p.Cin + ci] = acc[tp][k];
+        }
+}
+
+// dw[co][ci][tap] = sum_s ws[s][tap][co][ci] (s ascending)
+__global__ __launch_bounds__(256) void wgrad_reduce(const float* __restrict__ ws, float* __restrict__ dw, int splits, int T, int Cout, int Cin) {
+    const int64_t total = (int64_t)T * Cout * Cin;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int ci = (int)(i % Cin), co = (int)((i / Cin) % Cout), tp = (int)(i / ((int64_t)Cin * Cout));
+        float v = 0.f;
+        for (int z = 0; z < splits; z++) v += ws[(int64_t)z * total + i];
+        dw[((int64_t)co * Cin + ci) * T + tp] = v;
+    }
+}
+
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+}  // namespace
+
+/* Number of K splits pg_conv2d_wgrad wants (its workspace is splits * KH*KW * Cout * Cin floats); 0 = geometry not covered. */
+PG_EXPORT int pg_conv2d_wgrad_plan(int N, int Cin, int OH, int OW, int Cout, int KH, int KW) {
+    if (N <= 0 || Cin <= 0 || OH <= 0 || OW <= 0 || Cout <= 0) return 0;
+    if (!((KH == 3 && KW == 3) || (KH == 1 && KW == 1))) return 0;
+    const int64_t chunks = (int64_t)N * cdiv(OH, WG_R) * cdiv(OW, WG_TW);
+    const int blocks = cdiv(Cout, WG_BM) * cdiv(Cin, WG_BN);
+    int64_t s = (2LL * pg::num_cu() + blocks - 1) / blocks;             // ~2 workgroups per CU
+    if (s > chunks) s = chunks;
+    if (s < 1) s = 1;
+    if (s > 4096) s = 4096;
+    return (int)s;
+}
+
+PG_EXPORT int pg_conv2d_wgrad(const float* x, const float* dy, float* dw, float* workspace,
+                              int N, int Cin, int H, int W, int Cout, int KH, int KW, int pad_y, int pad_x, int OH, int OW,
+                              int splits, void* stream) {
+    if (!x || !dy || !dw || !workspace || N <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0 || OH <= 0 || OW <= 0 || splits <= 0) return PG_ERR_INVALID_ARG;
+    if (!((KH == 3 && KW == 3) || (KH == 1 && KW == 1))) return PG_ERR_UNSUPPORTED;
+    if (OH != H + 2 * pad_y - KH + 1 || OW != W + 2 * pad_x - KW + 1) return PG_ERR_INVALID_ARG;        // stride 1 only
+    WgradParams p;
+    p.x = x; p.dy = dy; p.ws = workspace;
+    p.N = N; p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout; p.OH = OH; p.OW = OW; p.pad_y = pad_y; p.pad_x = pad_x;
+    p.tilesX = cdiv(OW, WG_TW); p.tilesY = cdiv(OH, WG_R);
+    const int64_t chunks = (int64_t)N * p.tilesX * p.tilesY;
+    if (chunks > 0x7fffffffLL) return PG_ERR_TOO_LARGE;
+    p.chunks = (int)chunks; p.splits = splits;
+    p.coB = cdiv(Cout, WG_BM); p.ciB = cdiv(Cin, WG_BN);
+    const int64_t blocks = (int64_t)p.coB * p.ciB * splits;
+    if (blocks > 0x7fffffffLL) return PG_ERR_TOO_LARGE;
+    hipStream_t s = (hipStream_t)stream;
+    if (KH == 3) {
+        const size_t lds = WGeo<3, 3>::LDS_FLOATS * sizeof(float);
+        static pg::PerDeviceOnce attr;
+        const hipError_t e = attr.run([] { return hipFuncSetAttribute((const void*)conv2d_wgrad<3, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL((conv2d_wgrad<3, 3>), dim3((unsigned)blocks), dim3(256), lds, s, p);
+    } else {
+        const size_t lds = WGeo<1, 1>::LDS_FLOATS * sizeof(float);
+        hipLaunchKernelGGL((conv2d_wgrad<1, 1>), dim3((unsigned)blocks), dim3(256), lds, s, p);
+    }
+    int st = pg::launch_status();
+    if (st != PG_OK) return st;
+    const int64_t total = (int64_t)KH * KW * Cout * Cin;
+    int64_t rb = (total + 255) / 256;
+    if (rb > pg::max_stream_blocks()) rb = pg::max_stream_blocks();
+    hipLaunchKernelGGL(wgrad_reduce, dim3((unsigned)rb), dim3(256), 0, s, workspace, dw, splits, KH * KW, Cout, Cin);
+    return pg::launch_status();
+}

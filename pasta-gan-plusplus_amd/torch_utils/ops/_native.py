@@ -13,11 +13,16 @@ class NativeOpError(RuntimeError):
     pass
 
 
+class NativeNotCovered(NativeOpError):
+    """The kernels declined a VALID request (PG_ERR_UNSUPPORTED / PG_ERR_TOO_LARGE): callers holding a composed or aten
+    route for the same maths catch this and take it."""
+
+
 def check(status, what):
     """Turn a C-ABI status into a RuntimeError (TORCH_CHECK analogue of the reference plugins)."""
     if status != 0:
         msg = PG_ERRORS.get(status, f'hipError_t {status}' if status > 0 else f'error {status}')
-        raise NativeOpError(f'{what}: {msg}')
+        raise (NativeNotCovered if status in (-2, -3) else NativeOpError)(f'{what}: {msg}')
 
 
 def ptr(t):

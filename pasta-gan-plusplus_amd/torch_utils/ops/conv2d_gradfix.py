@@ -29,7 +29,8 @@ from . import _native as nat
 from . import conv2d_mfma
 from . import conv2d_mfma16
 
-native_input_gradients = os.environ.get('PG_NATIVE_DGRAD', '0') == '1'   # opt-in: input gradients through the MFMA kernel.  Measured 10 % slower than aten in the config-4 step (round 1), so off by default
+native_input_gradients = os.environ.get('PG_NATIVE_DGRAD', '1') == '1'    # input gradients through the MFMA / Winograd kernels (PG_NATIVE_DGRAD=0: aten)
+native_weight_gradients = os.environ.get('PG_NATIVE_WGRAD', '1') == '1'   # weight gradients of stride-1 3x3 / 1x1 convs through csrc/conv2d_wgrad.hip
 enabled = True                      # True (default here; the reference's loop sets it, training_loop_fullbody.py:386): hand-written kernels.  False: aten
 weight_gradients_disabled = False   # forcefully disable weight gradients (R1, loss_fullbody.py:266)
 
@@ -93,6 +94,27 @@ def conv_transpose2d(input, weight, bias=None, stride=1, padding=0, output_paddi
                                                 output_padding=output_padding, groups=groups, dilation=dilation)
 
 
+_pack_cache = {}      # (storage ptr, version, shape, strides, winograd, flip, transpose) -> packed weights; a handful of live entries per step
+
+
+def _packed(weight, winograd, flip=False, transpose_oi=False):
+    """Packed form of `weight` for the MFMA kernels, cached per parameter version: within one training step the same
+    weights are packed once for the forward and once (flipped, O<->I transposed) for the input gradient, however many
+    accumulation rounds or double-backward passes use them."""
+    base = weight._base if weight._base is not None else weight
+    key = (weight.data_ptr(), base._version, tuple(weight.shape), tuple(weight.stride()), bool(winograd), bool(flip), bool(transpose_oi))
+    hit = _pack_cache.get(key)
+    if hit is None:
+        if len(_pack_cache) > 512:
+            _pack_cache.clear()
+        w = weight.detach()
+        if not w.is_contiguous():
+            w = w.contiguous()
+        hit = conv2d_mfma.pack_weight(w, flip=flip, transpose_oi=transpose_oi, winograd=winograd)
+        _pack_cache[key] = hit
+    return hit
+
+
 class _Conv2dMfma(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, stride, padding, transposed, output_padding):
@@ -102,8 +124,7 @@ class _Conv2dMfma(torch.autograd.Function):
         if not transposed:
             cout = int(weight.shape[0])
             wg = conv2d_mfma.use_winograd(kh, kw, stride, cout, cin, pad=padding)
-            packed = conv2d_mfma.pack_weight(weight, winograd=wg)
-            y = conv2d_mfma.conv2d_forward(x, packed, cout, kh, kw, stride=stride, pad=padding, bias=bias, winograd=wg)
+            y = conv2d_mfma.conv2d_forward(x, _packed(weight, wg), cout, kh, kw, stride=stride, pad=padding, bias=bias, winograd=wg)
         else:
             cout = int(weight.shape[1])
             out_hw = ((h - 1) * stride - 2 * padding[0] + kh + output_padding[0], (w - 1) * stride - 2 * padding[1] + kw + output_padding[1])
@@ -168,12 +189,20 @@ class _Conv2dMfma16(torch.autograd.Function):
             dx = _input_gradient(dy, x.shape, weight, stride, padding, transposed, output_padding, fn=_Conv2dMfma16, mod=conv2d_mfma16)
         want_w = ctx.needs_input_grad[1] and not weight_gradients_disabled
         want_b = has_bias and ctx.needs_input_grad[2]
-        if dx is None and ctx.needs_input_grad[0] or want_w or want_b:
-            mask = [dx is None and ctx.needs_input_grad[0], want_w, want_b]
-            gx, dw, db = torch.ops.aten.convolution_backward(
+        if want_w and native_weight_gradients and not transposed and stride == 1 and not torch.is_grad_enabled():
+            dw = conv2d_mfma.weight_gradient(x, dy, weight.shape, padding)      # a GEMM over pixels (csrc/conv2d_wgrad.hip); None = not covered
+        if want_b and (dw is not None or not want_w):
+            db = dy.sum(dim=[0, 2, 3])
+        need_x = dx is None and ctx.needs_input_grad[0]
+        need_w = want_w and dw is None
+        need_b = want_b and db is None
+        if need_x or need_w or need_b:
+            gx, gw, gb = torch.ops.aten.convolution_backward(
                 dy, x, weight, [weight.shape[1 if transposed else 0]] if has_bias else None,
-                [stride, stride], list(padding), [1, 1], transposed, list(output_padding), 1, mask)
-            dx = gx if mask[0] else dx
+                [stride, stride], list(padding), [1, 1], transposed, list(output_padding), 1, [need_x, need_w, need_b])
+            dx = gx if need_x else dx
+            dw = gw if need_w else dw
+            db = gb if need_b else db
         return dx, dw, db, None, None, None, None
 
 
@@ -187,6 +216,13 @@ def _input_gradient(dy, x_shape, weight, stride, padding, transposed, output_pad
             py, px = kh - 1 - padding[0], kw - 1 - padding[1]
             if min(py, px) < 0 or not conv2d_mfma.supported(kh, kw, 1):
                 return None
+            if fn is None and not (torch.is_grad_enabled() and (dy.requires_grad or weight.requires_grad)):
+                # plain first-order backward: the flipped / transposed pack comes straight from the parameter (cached per version),
+                # no transposed copy of the weight tensor is made
+                cin_f = int(weight.shape[1])
+                wg = globals()['conv2d_mfma'].use_winograd(kh, kw, 1, cin_f, int(weight.shape[0]), pad=(py, px))
+                pk = _packed(weight, wg, flip=True, transpose_oi=True)
+                return globals()['conv2d_mfma'].conv2d_forward(dy.contiguous(), pk, cin_f, kh, kw, stride=1, pad=(py, px), winograd=wg)
             return _Conv2dMfma.apply(dy, weight.transpose(0, 1).flip([2, 3]), None, 1, (py, px), False, (0, 0))
         # strided conv: dx = conv_transpose(dy, w, stride) with the output padding that restores x's size
         opad = (h - ((dy.shape[2] - 1) * stride - 2 * padding[0] + kh), w - ((dy.shape[3] - 1) * stride - 2 * padding[1] + kw))

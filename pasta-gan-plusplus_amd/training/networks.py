@@ -25,6 +25,7 @@ import torch
 import torch.nn as nn
 
 from torch_utils import misc
+from torch_utils.ops import _native as nat
 from torch_utils.ops import bias_act
 from torch_utils.ops import conv2d_mfma
 from torch_utils.ops import conv2d_mfma16
@@ -330,35 +331,45 @@ class Conv2dLayer(_ConvBase):
         act_gain = self.act_gain * gain
         act_clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
         cout, _, k, _ = self.weight.shape
-        if _fast_ok(x, self.weight, self.bias, residual, x2) and self._fast_geometry():
-            ep = dict(bias=self.bias, act=self.activation, alpha=bias_act.activation_funcs[self.activation].def_alpha, gain=act_gain,
-                      clamp=act_clamp, residual=residual)
-            if self.down == 1 and (x2 is None or x.shape[1] % 16 == 0):
-                wg = conv2d_mfma.use_winograd(k, k, 1, cout, x.shape[1], x2)
-                return conv2d_mfma.conv2d_forward(x, self._packed(False, wg), cout, k, k, pad=(self.padding, self.padding), x2=x2, winograd=wg, **ep)
+        try:
+            y = self._forward_fused(x, act_gain, act_clamp, residual, x2)
+            if y is not None:
+                return y
+        except nat.NativeNotCovered:           # a valid request the kernels decline (size / geometry): compose it from the ops
+            pass
         if x2 is not None:
             x, x2 = torch.cat([x, x2], dim=1), None
-        if _fast_ok(x, self.weight, self.bias, residual) and self._fast_geometry():
-            ep = dict(bias=self.bias, act=self.activation, alpha=bias_act.activation_funcs[self.activation].def_alpha, gain=act_gain,
-                      clamp=act_clamp, residual=residual)
-            if self.down == 1:
-                wg = conv2d_mfma.use_winograd(k, k, 1, cout, x.shape[1])
-                return conv2d_mfma.conv2d_forward(x, self._packed(False, wg), cout, k, k, pad=(self.padding, self.padding), winograd=wg, **ep)
-            # down == 2: FIR first (conv2d_resample.py:107-110, 119-122), then the (strided) conv with the fused epilogue
-            fw, fh = upfirdn2d._get_filter_size(self.resample_filter)
-            p = self.padding
-            pads = [p + (fw - self.down + 1) // 2, p + (fw - self.down) // 2, p + (fh - self.down + 1) // 2, p + (fh - self.down) // 2]
-            if k == 1:
-                x = upfirdn2d.upfirdn2d(x, self.resample_filter, down=self.down, padding=pads)
-                return conv2d_mfma.conv2d_forward(x, self._packed(False), cout, 1, 1, **ep)
-            x = upfirdn2d.upfirdn2d(x, self.resample_filter, padding=pads)
-            return conv2d_mfma.conv2d_forward(x, self._packed(False), cout, k, k, stride=self.down, **ep)
         w = self.weight * self.weight_gain
         b = self.bias.to(x.dtype) if self.bias is not None else None
         x = conv2d_resample.conv2d_resample(x=x, w=w.to(x.dtype), f=self.resample_filter, up=self.up, down=self.down,
                                             padding=self.padding, flip_weight=(self.up == 1))
         x = bias_act.bias_act(x, b, act=self.activation, gain=act_gain, clamp=act_clamp)
         return x if residual is None else residual.add_(x) if not _needs_graph(residual, x) else residual + x
+
+    def _forward_fused(self, x, act_gain, act_clamp, residual, x2):
+        """Inference route: one launch of the MFMA convolution with bias / activation / gain / clamp / residual in its epilogue
+        (after the FIR pass for down=2); None when this layer or these tensors do not qualify."""
+        cout, _, k, _ = self.weight.shape
+        if not (_fast_ok(x, self.weight, self.bias, residual, x2) and self._fast_geometry()):
+            return None
+        ep = dict(bias=self.bias, act=self.activation, alpha=bias_act.activation_funcs[self.activation].def_alpha, gain=act_gain,
+                  clamp=act_clamp, residual=residual)
+        if self.down == 1:
+            if x2 is not None and x.shape[1] % 16 != 0:
+                x, x2 = torch.cat([x, x2], dim=1), None
+            wg = conv2d_mfma.use_winograd(k, k, 1, cout, x.shape[1], x2)
+            return conv2d_mfma.conv2d_forward(x, self._packed(False, wg), cout, k, k, pad=(self.padding, self.padding), x2=x2, winograd=wg, **ep)
+        if x2 is not None:
+            x = torch.cat([x, x2], dim=1)
+        # down == 2: FIR first (conv2d_resample.py:107-110, 119-122), then the (strided) conv with the fused epilogue
+        fw, fh = upfirdn2d._get_filter_size(self.resample_filter)
+        p = self.padding
+        pads = [p + (fw - self.down + 1) // 2, p + (fw - self.down) // 2, p + (fh - self.down + 1) // 2, p + (fh - self.down) // 2]
+        if k == 1:
+            x = upfirdn2d.upfirdn2d(x, self.resample_filter, down=self.down, padding=pads)
+            return conv2d_mfma.conv2d_forward(x, self._packed(False), cout, 1, 1, **ep)
+        x = upfirdn2d.upfirdn2d(x, self.resample_filter, padding=pads)
+        return conv2d_mfma.conv2d_forward(x, self._packed(False), cout, k, k, stride=self.down, **ep)
 
 
 class ResBlock(nn.Module):
@@ -398,8 +409,11 @@ class Spade_Conv2dLayer(_ConvBase):
             pro = {} if no_act else dict(in_act=self.activation, in_gain=act_gain, in_clamp=act_clamp,
                                          in_alpha=bias_act.activation_funcs[self.activation].def_alpha)
             wg = conv2d_mfma.use_winograd(k, k, 1, cout, x.shape[1])
-            return conv2d_mfma.conv2d_forward(x, self._packed(False, wg), cout, k, k, pad=(self.padding, self.padding), act=post_act, residual=residual,
-                                              winograd=wg, **pro)
+            try:
+                return conv2d_mfma.conv2d_forward(x, self._packed(False, wg), cout, k, k, pad=(self.padding, self.padding), act=post_act, residual=residual,
+                                                  winograd=wg, **pro)
+            except nat.NativeNotCovered:       # e.g. a pre-activation in front of a geometry without the prologue variant
+                pass
         w = self.weight * self.weight_gain
         b = self.bias.to(x.dtype) if self.bias is not None else None
         if not no_act:
@@ -425,7 +439,7 @@ class Spade_Norm_Block(nn.Module):
         """`post` (private): dict(act, alpha, gain, clamp) -- the pre-activation of the one Spade_Conv2dLayer consuming the
         result (networks.py:1627-1633), applied here so that the consumer runs without a prologue.  `stats` (private):
         (mean, rstd) of x when the caller already has them (two norm blocks of a res-block normalise the same tensor)."""
-        if _fast_ok(x, denorm_feats, self.conv_mlp.weight):
+        if _fast_ok(x, denorm_feats, self.conv_mlp.weight, self.conv_gamma.weight, self.conv_beta.weight):
             post = post or {}
             mean, rstd = stats if stats is not None else conv2d_mfma.instance_norm_stats(x, eps=self.param_free_norm.eps)
             actv = self.conv_mlp(denorm_feats, no_act=True, post_act='relu')     # conv + ReLU in one launch

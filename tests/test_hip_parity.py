@@ -938,3 +938,42 @@ def test_modulated_conv2d_fp16_prenorm_golden(golden):
                                   resample_filter=upfirdn2d.setup_filter(C.FIR_1331).to(DEV), fused_modconv=False)
     assert y.dtype == torch.float16
     close(y.float(), g[f'{name}/y'], rtol=1e-2, atol=1e-2)
+
+
+@pytest.mark.parametrize('shape', [(2, 16, 24, 20, 37, 3), (1, 70, 130, 9, 33, 3), (3, 64, 64, 17, 17, 1), (2, 5, 7, 8, 40, 1), (8, 64, 64, 64, 64, 3)],
+                         ids=['3x3_ragged', '3x3_multi_block', '1x1', '1x1_tiny', '3x3_many_chunks'])
+def test_native_weight_gradient_exact(shape):
+    """csrc/conv2d_wgrad.hip (GEMM over pixels, K-split with a fixed-order second pass) on small-integer data: every partial sum is
+    exact in fp32, so the result must equal the fp64 weight gradient bit for bit."""
+    from torch_utils.ops import conv2d_mfma
+    n, cin, cout, h, w, k = shape
+    gen = torch.Generator().manual_seed(n * 1000 + cin)
+    x = torch.randint(-3, 4, [n, cin, h, w], generator=gen).float()
+    dy = torch.randint(-2, 3, [n, cout, h, w], generator=gen).float()
+    got = conv2d_mfma.weight_gradient(x.to(DEV), dy.to(DEV), [cout, cin, k, k], (k // 2, k // 2))
+    assert got is not None
+    wref = torch.zeros([cout, cin, k, k], dtype=torch.float64, requires_grad=True)
+    torch.nn.functional.conv2d(x.double(), wref, padding=k // 2).backward(dy.double())
+    assert torch.equal(got.double().cpu(), wref.grad), float((got.double().cpu() - wref.grad).abs().max())
+
+
+def test_conv2d_gradfix_native_backward_routes():
+    """First-order backward of conv2d_gradfix.conv2d on the GPU: input gradient through the MFMA / Winograd kernels with the
+    flipped, transposed pack taken straight from the parameter, weight gradient through the native GEMM-over-pixels kernel --
+    against PyTorch's own double-precision convolution."""
+    from torch_utils.ops import conv2d_gradfix
+    assert conv2d_gradfix.native_input_gradients and conv2d_gradfix.native_weight_gradients
+    gen = torch.Generator().manual_seed(31)
+    for cin, cout, k, hw in ((32, 80, 3, (20, 24)), (16, 24, 3, (13, 19)), (64, 48, 1, (17, 21))):
+        x = torch.randn([2, cin, *hw], generator=gen)
+        wt = torch.randn([cout, cin, k, k], generator=gen) / np.sqrt(cin * k * k)
+        b = torch.randn([cout], generator=gen)
+        dy = torch.randn([2, cout, *hw], generator=gen)
+        xd, wd, bd = (t.to(DEV).requires_grad_(True) for t in (x, wt, b))
+        y = conv2d_gradfix.conv2d(xd, wd, bd, padding=k // 2)
+        gx, gw, gb = torch.autograd.grad(y, [xd, wd, bd], dy.to(DEV))
+        x64, w64, b64 = (t.double().requires_grad_(True) for t in (x, wt, b))
+        rx, rw, rb = torch.autograd.grad(torch.nn.functional.conv2d(x64, w64, b64, padding=k // 2), [x64, w64, b64], dy.double())
+        close(gx, rx, 1e-4, 1e-5 * scale_of(rx))
+        close(gw, rw, 1e-4, 1e-5 * scale_of(rw))
+        close(gb, rb, 1e-4, 1e-5 * scale_of(rb))

@@ -10,7 +10,7 @@ as three batched launches of ``patch_routing_plugin`` (csrc/patch_routing.hip) p
 3. the erode-and-paste of each part, in the reference's order (later parts overwrite earlier ones).
 
 Images are uint8 HxWx3 tensors on the GPU (NumPy arrays are uploaded); the five results have the reference's shapes and dtype.
-There is no CPU path.
+GPU tensors run the HIP kernels; CPU tensors (device='cpu': BASELINE config 1, the loader without a GPU) the same arithmetic in NumPy.
 """
 
 import ctypes
@@ -171,23 +171,81 @@ def _block_width(dst_h, dst_w):
 
 
 def _gpu_u8(img, device):
+    """uint8 image on `device` (name kept from the GPU-only version; CPU tensors take the NumPy route below)."""
     if isinstance(img, torch.Tensor):
         t = img
     else:
         t = torch.from_numpy(np.ascontiguousarray(img))
     if t.dtype != torch.uint8:
         raise nat.NativeOpError('patch_routing: images must be uint8')
-    t = t.to(device)
-    nat.require_gpu(t, 'patch_routing')
-    return t.contiguous()
+    return t.to(device).contiguous()
+
+
+def _warp_perspective_cpu(src, m, wh):
+    """The arithmetic of `warp_perspective_u8_kernel` (csrc/patch_routing.hip) in vectorised NumPy, for CPU tensors (config 1
+    runs the loader without a GPU): fp64 coordinates evaluated block origin + offset with separately rounded products and sums,
+    5 fractional bits, 15-bit bilinear weights, zero border."""
+    w, h = wh
+    a = src.numpy()
+    squeeze = a.ndim == 2
+    if squeeze:
+        a = a[:, :, None]
+    sh, sw, c = a.shape
+    mi = invert3x3(m).reshape(9)
+    bw = _block_width(h, w)
+    ys, xs = np.mgrid[0:h, 0:w]
+    xb = (xs // bw) * bw
+    x1 = (xs - xb).astype(np.float64)
+    xb, yf = xb.astype(np.float64), ys.astype(np.float64)
+    X0 = (mi[0] * xb + mi[1] * yf) + mi[2]
+    Y0 = (mi[3] * xb + mi[4] * yf) + mi[5]
+    W0 = (mi[6] * xb + mi[7] * yf) + mi[8]
+    W = W0 + mi[6] * x1
+    with np.errstate(divide='ignore', invalid='ignore'):
+        W = np.where(W != 0.0, 32.0 / W, 0.0)
+    fX = np.clip((X0 + mi[0] * x1) * W, -2147483648.0, 2147483647.0)
+    fY = np.clip((Y0 + mi[3] * x1) * W, -2147483648.0, 2147483647.0)
+    X, Y = np.rint(fX).astype(np.int64), np.rint(fY).astype(np.int64)            # round half to even, as cvRound
+    sx, sy = np.clip(X >> 5, -32768, 32767), np.clip(Y >> 5, -32768, 32767)
+    fx, fy = X & 31, Y & 31
+    w00, w01, w10, w11 = (32 - fx) * (32 - fy) * 32, fx * (32 - fy) * 32, (32 - fx) * fy * 32, fx * fy * 32
+    exact = (fx | fy) == 0
+    w00, w11 = np.where(exact, 32767, w00), np.where(exact, 1, w11)
+
+    def tap(yy, xx):
+        ok = (yy >= 0) & (yy < sh) & (xx >= 0) & (xx < sw)
+        return np.where(ok[..., None], a[np.clip(yy, 0, sh - 1), np.clip(xx, 0, sw - 1)], 0).astype(np.int64)
+    v = (tap(sy, sx) * w00[..., None] + tap(sy, sx + 1) * w01[..., None] + tap(sy + 1, sx) * w10[..., None] + tap(sy + 1, sx + 1) * w11[..., None] + (1 << 14)) >> 15
+    out = np.clip(v, 0, 255).astype(np.uint8)
+    return torch.from_numpy(out[:, :, 0] if squeeze else out)
+
+
+def _patch_compose_cpu_(canvas, patch, mask, canvas2):
+    """`patch_compose_u8_kernel` in NumPy: paste where every in-range tap of the 8x8 window anchored at (4, 4) is 255."""
+    m = mask.numpy()
+    m = (m[:, :, 0] if m.ndim == 3 else m) == 255
+    h, w = m.shape
+    pad = np.ones((h + 8, w + 8), dtype=bool)                                    # out-of-image taps are ignored = count as white
+    pad[4:4 + h, 4:4 + w] = m
+    keep = np.ones((h, w), dtype=bool)
+    for ky in range(8):
+        for kx in range(8):
+            keep &= pad[ky:ky + h, kx:kx + w]
+    sel = torch.from_numpy(keep)[:, :, None]
+    canvas.copy_(torch.where(sel, patch, canvas))
+    if canvas2 is not None:
+        canvas2.copy_(torch.where(sel, patch, canvas2))
+    return canvas
 
 
 def warp_perspective_batch(jobs):
     """jobs: list of (src uint8 [H,W,C] GPU tensor, forward 3x3 matrix as cv2.warpPerspective takes it, (w, h)) -> list of outputs."""
-    lib = _init().lib
     if not jobs:
         return []
     dev = jobs[0][0].device
+    if dev.type != 'cuda':
+        return [_warp_perspective_cpu(src, m, wh) for src, m, wh in jobs]
+    lib = _init().lib
     table = (WarpJob * len(jobs))()
     outs, keep = [], []
     maxpix = 0
@@ -213,6 +271,8 @@ def warp_perspective_batch(jobs):
 
 def patch_compose_(canvas, patch, mask, canvas2=None):
     """canvas[p] = patch[p] where erode8x8(mask[..., 0]) == 255 (also into canvas2), in place."""
+    if canvas.device.type != 'cuda':
+        return _patch_compose_cpu_(canvas, patch, mask, canvas2)
     lib = _init().lib
     h, w = canvas.shape[:2]
     mc = mask.shape[2] if mask.ndim == 3 else 1

@@ -75,6 +75,17 @@ __device__ __forceinline__ void dma_dwordx4(const float* gsrc, unsigned lds_byte
 }
 __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+// Once-per-tile scalar fetches (scales, bias) of the persistent loop.  They are inline asm with their own wait on purpose: a
+// load the compiler can see leaves a pending-VMEM mark on its destination register, and when that register is later reused
+// by the chunk loop's LDS reads the compiler protects the reuse with `s_waitcnt vmcnt(0)` at the top of EVERY chunk -- which
+// also waits for the halo DMA requested a moment earlier and for the whole U ring (found in the round-1 build's assembly).
+__device__ __forceinline__ float ld_opaque(const float* ptr) {
+    float v;
+    asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(ptr) : "memory");
+    return v;
+}
+
+
 template <int KH, int KW, int S, int BM, int KC>
 struct Geo {
     static constexpr int T = KH * KW;
@@ -143,7 +154,7 @@ __global__ __launch_bounds__(256, 4) void conv2d_mfma(ConvParams p) {
         oy0 = ty * TH; ox0 = tx * TW; m0 = mb * BM;
         const float* in_scale = p.f.in_scale ? p.f.in_scale + (int64_t)n * p.Cin + cbeg : nullptr;
         if (MODE != 0)
-            for (int c = t; c < cin_loop; c += 256) cs[c] = (in_scale && cbeg + c < p.Cin) ? in_scale[c] : 1.f;
+            for (int c = t; c < cin_loop; c += 256) cs[c] = (in_scale && cbeg + c < p.Cin) ? ld_opaque(in_scale + c) : 1.f;
         // Opaque copy of the thread id: without it the compiler hoists the tile-independent index maths of every
         // element out of the persistent loop and keeps ~20 values live in VGPRs (spilling at 4 waves/SIMD).
         int tt = t;
@@ -281,15 +292,15 @@ __global__ __launch_bounds__(256, 4) void conv2d_mfma(ConvParams p) {
                 if (p.f.spade_x) {                          // SPADE mode: per-(n, channel) mean / rstd of the normalised tensor
                     if (t < 32) {
                         const int ch = (e_m0 >> 1) + t;     // this tile's 32 output channels
-                        ep_scale[t] = p.f.spade_mean[e_n * (p.Cout >> 1) + ch];
-                        ep_bias[t] = p.f.spade_rstd[e_n * (p.Cout >> 1) + ch];
+                        ep_scale[t] = ld_opaque(p.f.spade_mean + e_n * (p.Cout >> 1) + ch);
+                        ep_bias[t] = ld_opaque(p.f.spade_rstd + e_n * (p.Cout >> 1) + ch);
                     }
                 } else if (t < BM) {
                     const int co = e_m0 + t;
                     const bool ok = co < p.Cout;
                     const int cc = ok ? co : 0;
-                    const float sc = p.f.out_scale ? p.f.out_scale[(int64_t)e_n * p.Cout + cc] : 1.f;
-                    const float bi = p.f.bias ? p.f.bias[cc] : 0.f;
+                    const float sc = p.f.out_scale ? ld_opaque(p.f.out_scale + (int64_t)e_n * p.Cout + cc) : 1.f;
+                    const float bi = p.f.bias ? ld_opaque(p.f.bias + cc) : 0.f;
                     ep_scale[t] = ok ? sc : 0.f;
                     ep_bias[t] = ok ? bi : 0.f;
                 }

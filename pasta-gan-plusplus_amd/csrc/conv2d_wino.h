@@ -106,7 +106,7 @@ __global__ __launch_bounds__(512, 4) void conv2d_wino(ConvParams p) {
         oy0 = ty * 2; ox0 = tx * 64; m0 = mb * 64;
         const float* in_scale = p.f.in_scale ? p.f.in_scale + (int64_t)n * p.Cin : nullptr;
         if (MODE != 0)                                 // the plain variant never reads the scale
-            for (int c = t; c < cin_loop; c += 512) cs[c] = ((in_scale && c < p.Cin) ? in_scale[c] : 1.f) * p.f.in_gain;     // host: in_gain defaults to 1
+            for (int c = t; c < cin_loop; c += 512) cs[c] = ((in_scale && c < p.Cin) ? ld_opaque(in_scale + c) : 1.f) * p.f.in_gain;     // host: in_gain defaults to 1
         int tt = t;
         asm volatile("" : "+v"(tt));                 // keep the index maths inside the tile loop (see conv2d_kernel.h)
         // gather map: element f of the buffer = (channel f / 288, LDS row (f % 288) / 72, LDS column f % 72)
@@ -222,15 +222,15 @@ __global__ __launch_bounds__(512, 4) void conv2d_wino(ConvParams p) {
                 if (q.f.spade_x) {                          // SPADE mode: per-(n, channel) mean / rstd of the normalised tensor
                     if (t < 32) {
                         const int ch = (e_m0 >> 1) + t;     // this tile's 32 output channels
-                        ep_scale[t] = q.f.spade_mean[e_n * (q.Cout >> 1) + ch];
-                        ep_bias[t] = q.f.spade_rstd[e_n * (q.Cout >> 1) + ch];
+                        ep_scale[t] = ld_opaque(q.f.spade_mean + e_n * (q.Cout >> 1) + ch);      // opaque: see conv2d_kernel.h
+                        ep_bias[t] = ld_opaque(q.f.spade_rstd + e_n * (q.Cout >> 1) + ch);
                     }
                 } else if (t < 64) {
                     const int co = e_m0 + t;
                     const bool ok = co < q.Cout;
                     const int cc = ok ? co : 0;
-                    const float sc = q.f.out_scale ? q.f.out_scale[(int64_t)e_n * q.Cout + cc] : 1.f;
-                    const float bi = q.f.bias ? q.f.bias[cc] : 0.f;
+                    const float sc = q.f.out_scale ? ld_opaque(q.f.out_scale + (int64_t)e_n * q.Cout + cc) : 1.f;
+                    const float bi = q.f.bias ? ld_opaque(q.f.bias + cc) : 0.f;
                     ep_scale[t] = ok ? sc : 0.f;
                     ep_bias[t] = ok ? bi : 0.f;
                 }

@@ -23,6 +23,8 @@ pure-torch route of ``impl='ref'`` semantics (torch.nn.functional), like the ref
 import contextlib
 import os
 
+import weakref
+
 import torch
 
 from . import _native as nat
@@ -103,15 +105,16 @@ def _packed(weight, winograd, flip=False, transpose_oi=False):
     accumulation rounds or double-backward passes use them."""
     base = weight._base if weight._base is not None else weight
     key = (weight.data_ptr(), base._version, tuple(weight.shape), tuple(weight.stride()), bool(winograd), bool(flip), bool(transpose_oi))
-    hit = _pack_cache.get(key)
-    if hit is None:
+    entry = _pack_cache.get(key)
+    hit = entry[1] if entry is not None and entry[0]() is base else None      # same address + version is not identity: a freed
+    if hit is None:                                                           # tensor's block is handed to the next one of its size
         if len(_pack_cache) > 512:
             _pack_cache.clear()
         w = weight.detach()
         if not w.is_contiguous():
             w = w.contiguous()
         hit = conv2d_mfma.pack_weight(w, flip=flip, transpose_oi=transpose_oi, winograd=winograd)
-        _pack_cache[key] = hit
+        _pack_cache[key] = (weakref.ref(base), hit)
     return hit
 
 

@@ -1,7 +1,7 @@
 """CPU-only checks of the product's host side: the C-ABI libraries load and export every
 symbol include/pasta_gan_ops.h declares; argument algebra; the transposed-conv phase
 decomposition (emulated with torch CPU ops standing in for one pg_conv2d_forward launch);
-and the HIP-only contract (CPU tensors and impl='ref' raise, never fall back)."""
+and the reference's dispatch contract (CPU tensors / impl='ref' take the plain-torch route, GPU tensors the native op)."""
 
 import ctypes
 import os
@@ -36,7 +36,7 @@ def test_c_abi_libraries_export_every_declared_symbol():
     for lib, name in zip(libs, custom_ops.PLUGIN_SOURCES):
         fn = getattr(lib, 'pg_' + name.replace('_plugin', '') + '_abi_version')
         fn.restype = ctypes.c_int
-        assert fn() == 1
+        assert fn() == custom_ops.ABI_VERSION
     # host-only entry point: packed-weight size needs no GPU
     conv = libs[list(custom_ops.PLUGIN_SOURCES).index('conv2d_plugin')]
     conv.pg_conv2d_packed_size.restype = ctypes.c_int64
@@ -63,22 +63,37 @@ def test_c_abi_libraries_export_every_declared_symbol():
     assert fwd(dummy, dummy, dummy, 1, 64, 8, 8, 8, 3, 3, 1, 1, 1, 8, 8, i64x4, 0, 1, 0, 0, None, None) == -1
 
 
-def test_product_has_no_cpu_fallback():
-    from torch_utils.ops import bias_act, upfirdn2d, conv2d_gradfix
-    from torch_utils.ops._native import NativeOpError
-    x = torch.zeros(1, 2, 4, 4)
-    with pytest.raises(NativeOpError):
-        bias_act.bias_act(x, act='relu')
-    with pytest.raises(NotImplementedError):
-        bias_act.bias_act(x, act='relu', impl='ref')
-    with pytest.raises(NativeOpError):
-        upfirdn2d.upfirdn2d(x, upfirdn2d.setup_filter([1, 3, 3, 1]))
-    with pytest.raises(NotImplementedError):
-        upfirdn2d.upfirdn2d(x, None, impl='ref')
-    with pytest.raises(NativeOpError):
-        conv2d_gradfix.conv2d(x, torch.zeros(3, 2, 3, 3), padding=1)
+def test_dispatch_follows_the_reference():
+    """upfirdn2d.py:161-164 / bias_act.py:86-89: `impl='cuda'` on a GPU tensor takes the native op, everything else the
+    plain-torch route (product-own, pinned against G1-G3 in test_product_cpu_route.py).  A GPU tensor never lands on the
+    torch route silently: the native wrapper raises when its plugin is missing (checked here without a GPU by making the
+    loader fail)."""
+    from torch_utils import custom_ops
+    from torch_utils.ops import bias_act, upfirdn2d, conv2d_gradfix, _native
+    x = torch.randn(1, 2, 4, 4)
+    assert torch.equal(bias_act.bias_act(x, act='relu', gain=1), torch.relu(x))
+    assert torch.equal(bias_act.bias_act(x, act='relu', gain=1, impl='ref'), torch.relu(x))
+    f = upfirdn2d.setup_filter([1, 3, 3, 1])
+    assert upfirdn2d.upfirdn2d(x, f, padding=2).shape == (1, 2, 5, 5)
+    assert torch.equal(upfirdn2d.upfirdn2d(x, None, impl='ref'), x)
+    w = torch.randn(3, 2, 3, 3)
+    assert torch.equal(conv2d_gradfix.conv2d(x, w, padding=1), F.conv2d(x, w, padding=1))
     with pytest.raises(AssertionError):
         bias_act.bias_act(x, impl='bogus')
+    # a missing / unbuildable plugin is an error, never a detour
+    real, was = custom_ops.get_plugin, bias_act._plugin if hasattr(bias_act, '_plugin') else None
+    def broken(*a, **k):
+        raise RuntimeError('no hipcc')
+    custom_ops.get_plugin = broken
+    try:
+        if hasattr(bias_act, '_plugin'):
+            bias_act._plugin = None
+        with pytest.raises(RuntimeError):
+            bias_act._init()
+    finally:
+        custom_ops.get_plugin = real
+        if hasattr(bias_act, '_plugin'):
+            bias_act._plugin = was
 
 
 def test_product_never_imports_oracle():

@@ -26,4 +26,23 @@ def test_ring_registers_untouched_while_in_flight(tmp_path):
     assert len(asm) == 1
     sys.path.insert(0, os.path.join(ROOT, 'tools'))
     import check_wino_asm
+    import check_kloop_waits
     assert check_wino_asm.check(asm[0])
+    assert check_kloop_waits.check(asm[0], verbose=False)
+
+
+@pytest.mark.skipif(shutil.which('hipcc') is None and not os.path.isfile('/opt/rocm/bin/hipcc'), reason='needs hipcc')
+@pytest.mark.parametrize('unit', ['conv2d_inst_k3s1', 'conv2d16_inst_k3s1'])
+def test_no_compiler_vmcnt_wait_in_k_loop(tmp_path, unit):
+    """The chunk loops double-buffer their halo DMA behind hand-counted waits; a compiler-made vmcnt wait in front of a chunk's
+    first LDS read would wait for the DMA just requested (tools/check_kloop_waits.py)."""
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    src = os.path.join(ROOT, 'pasta-gan-plusplus_amd', 'csrc', unit + '.hip')
+    cmd = [hipcc, '-O3', '-std=c++17', '-fPIC', '-fvisibility=hidden', '--offload-arch=gfx950', '-I', os.path.join(ROOT, 'include'),
+           '-I', os.path.dirname(src), '-c', src, '-o', str(tmp_path / 'k.o'), '-save-temps=obj']
+    subprocess.run(cmd, check=True, cwd=tmp_path, capture_output=True, timeout=900)
+    asm = glob.glob(str(tmp_path / '*gfx950.s'))
+    assert len(asm) == 1
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import check_kloop_waits
+    assert check_kloop_waits.check(asm[0], verbose=False)

@@ -212,6 +212,7 @@ __global__ __launch_bounds__(512, 4) void conv2d_wino(ConvParams p) {
         const float* cs_cur = cs0 + par * cin_loop;
         float* ep_scale = ep0 + par * 128;           // per tile parity: the next tile's constants are written while slow
         float* ep_bias = ep_scale + 64;              // waves may still be in this tile's epilogue
+#pragma unroll 1                                     // unrolled by two, the ragged plain variant spills a VGPR whose reload brings a vmcnt(0) into the loop
         for (int k = 0; k < nchunks; k++, g++) {
             const int buf = g & 1;
             if (k + 1 < nchunks) {

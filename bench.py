@@ -11,10 +11,14 @@ runs the same workload on its own batch (independent images, no data-path collec
 of the timed region.  Rank 0 prints ONE JSON line.
 
 Extra objects on that line:
-  roofline     -- dominant kernel = conv2d_mfma<3,3,1> (the 3x3 implicit-GEMM conv, 96 % of the
-                  FLOPs): sum of algorithmic FLOPs of its launches in the timed region / sum of
+  roofline     -- dominant kernel = conv2d_wino (Winograd F(2x2,3x3) convolution, csrc/conv2d_wino.h:
+                  the stride-1 3x3 layers, ~65 % of the step): sum of the Winograd-domain GEMM FLOPs
+                  (4/9 of the direct-convolution FLOPs) of its launches in the timed region / sum of
                   their durations measured with HIP events on the launch stream, vs 157.3 TFLOP/s;
-                  `traffic` = measured HBM bytes per launch (profiles/r01_traffic.json).
+                  `traffic` = measured HBM bytes per launch, from the newest committed
+                  profiles/rNN_traffic_cfg2.json (rocprofv3 --pmc passes over this same command;
+                  PMC counters cannot be read in-process) -- `traffic_source` names the file.
+                  --mode bf16_1024 (config 5): dominant kernel = conv2d_mfma16, HBM-bound.
   cpu_baseline -- the CPU oracle (oracle/network_ref.py, a port) timed on this host at N=1 on a
                   bounded sample (rank 0, --gpus 1 only).
 """
@@ -36,6 +40,23 @@ CFG2 = dict(w_dim=512, img_resolution=512, img_channels=3, channel_base=32768, c
 BATCH_PER_GPU = 8
 GFLOP_PER_IMAGE = 962.2          # SURVEY.md section 8d (conv FLOPs of one 512^2 image)
 F32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+
+
+def committed_traffic(tag):
+    """HBM bytes per launch of a mode's dominant kernel: PMC counters cannot be read in-process, so the number comes from the
+    newest committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command (tools/traffic_run.sh ->
+    profiles/rNN_traffic_<tag>.json; round 1's file is profiles/r01_traffic.json)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', f'r[0-9][0-9]_traffic_{tag}.json')))
+    if not files and tag == 'cfg2':
+        files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r01_traffic.json')))
+    for path in reversed(files):
+        try:
+            with open(path) as f:
+                return round(json.load(f)['hbm_bytes_per_launch']), os.path.relpath(path, ROOT)
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
 
 
 def make_inputs(n, device, seed):
@@ -198,7 +219,9 @@ def run_stack(args, rank, world, dev, dist):
                                      f'channel_base 32768, channel_max {args.channel_max}, all blocks bf16 (fp32 accumulate), eval, noise_mode=const, random-init weights',
                             images_per_gpu_per_step=n, global_batch=n * world, parallelism=f'replicas x{world}'),
                 roofline=dict(bound='hbm', kernel='conv2d_mfma16<bf16,...> (channels-last implicit GEMM, v_mfma_f32_32x32x16_bf16; all its launches of a step)',
-                              achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(gbs / HBM_PEAK_GBS, 4), traffic=None,
+                              achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(gbs / HBM_PEAK_GBS, 4),
+                              traffic=committed_traffic('cfg5')[0], traffic_source=committed_traffic('cfg5')[1],
+                              algorithmic_bytes_per_launch=round(sum(r[3] for r in dom) / max(len(dom), 1)),
                               bytes_counted='2 * (numel(x) + numel(y)) per launch (weights excluded)',
                               mfma_tflops=round(tfl, 1), mfma_frac=round(tfl / BF16_MFMA_PEAK_TFLOPS, 4),
                               launches_per_step=len(dom) // max(args.steps, 1), conv_time_frac_of_step=round(t_dom / elapsed, 4),
@@ -219,8 +242,10 @@ def run_stack(args, rank, world, dev, dist):
 
 def run_train(args, rank, world, dev, dist):
     """BASELINE config 4 (secondary, --mode train): iterations/s of the 8-phase fullbody G+D step incl. lazy R1, batch 4 per
-    GPU, flat-bucket gradient all-reduce over RCCL.  VGG/contextual losses omitted (weights unavailable offline); the
-    convolution backward passes are aten::convolution_backward (MIOpen) -- hand-written backward kernels are a later row."""
+    GPU, flat-bucket gradient exchange over RCCL overlapped with the last backward (training/ddp.py).  VGG/contextual losses
+    omitted (weights unavailable offline); input gradients of the fp32 convolutions run on the forward MFMA kernels (flipped,
+    O<->I transposed packs), weight gradients of the stride-1 3x3 / 1x1 layers on csrc/conv2d_wgrad.hip, the rest
+    (stride 2, 7x7, transposed, 16-bit) on aten::convolution_backward (MIOpen)."""
     from training import networks, replicas
     from training.loss import StyleGAN2Loss
     from training.training_step import TrainingStep
@@ -340,17 +365,12 @@ def main():
         work = 4.0 / 9.0 if wino else 1.0
         dom_flops, dom_time = sum(f for f, _ in dom), sum(t for _, t in dom)
         achieved = work * dom_flops / dom_time / 1e12 if dom_time > 0 else 0.0
-        traffic = None      # HBM bytes per launch of that kernel: PMC counters cannot be read in-process; taken from the committed
-        try:                # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command (profiles/r01_traffic.json)
-            with open(os.path.join(ROOT, 'profiles', 'r01_traffic.json')) as f:
-                traffic = round(json.load(f)['hbm_bytes_per_launch'])
-        except (OSError, KeyError, ValueError):
-            pass
+        traffic, traffic_src = committed_traffic('cfg2')
         roofline = dict(bound='mfma',
                         kernel=('conv2d_wino<MODE,VEC> (Winograd F(2x2,3x3) stride-1 3x3 convolution, v_mfma_f32_32x32x2_f32)' if wino else
                                 'conv2d_mfma<3,3,1,BM,4,XF> (3x3 stride-1 implicit GEMM, v_mfma_f32_32x32x2_f32)'),
                         achieved=round(achieved, 2), peak=F32_MFMA_PEAK_TFLOPS, unit='TFLOP/s', frac=round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
-                        traffic=traffic, flops_counted=('Winograd-domain GEMM flops = 4/9 of the direct-convolution flops' if wino else 'direct-convolution flops'),
+                        traffic=traffic, traffic_source=traffic_src, flops_counted=('Winograd-domain GEMM flops = 4/9 of the direct-convolution flops' if wino else 'direct-convolution flops'),
                         direct_equivalent_tflops=round(dom_flops / max(dom_time, 1e-12) / 1e12, 2),
                         direct_equivalent_frac=round(dom_flops / max(dom_time, 1e-12) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),    # SURVEY 8d count / peak (> 1: fewer multiplies than counted)
                         launches_per_step=len(dom) // max(args.steps, 1), avg_launch_ms=round(1e3 * dom_time / max(len(dom), 1), 4),

@@ -1,4 +1,6 @@
 // Winograd F(2x2, 3x3) instantiations (own translation unit: see conv2d_kernel.h on build time).
+// hipcc-flags: -fno-slp-vectorize
+// (the K-loop transform is scalar fp32 on purpose -- packed fp32 VALU is slow beside MFMAs -- and must not be re-packed)
 #include "conv2d_wino.h"
 
 namespace pgconv {

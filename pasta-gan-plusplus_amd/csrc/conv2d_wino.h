@@ -32,6 +32,9 @@
 #pragma once
 #include "conv2d_kernel.h"
 
+#ifndef WINO_PK
+#define WINO_PK 0        // 1 = the round-1 packed-fp32 form of the K-loop transform (A/B switch)
+#endif
 #ifndef WINO_EXP
 #define WINO_EXP 0       // dev ablations (tools/wino_variants.py; results wrong by design): 1 no U loads, 2 no LDS operand reads, 4 no tail,
                          // 8 no halo DMA, 128 no chunk barrier, 256 no transform VALU, 512 eight extra independent VALU ops per channel pair,
@@ -271,25 +274,51 @@ __global__ __launch_bounds__(512, 4) void conv2d_wino(ConvParams p) {
             for (int pp = 0; pp < W_KC / 2; pp++) {
                 if (pp + PD < W_KC / 2) read_b(pp + PD, bq[(pp + PD) % (PD + 1)], bs[(pp + PD) % (PD + 1)]);
                 __builtin_amdgcn_sched_barrier(0);                           // the requests go out BEFORE this pair's MFMAs
-                // row transform on column pairs (packed fp32 math): q = (row rp) + s1 * (row rp + 1), scaled by the prologue scale
+                // row transform q = (row rp) + s1 * (row rp + 1), scaled by the prologue scale.  Scalar fp32 on purpose: packed
+                // fp32 VALU (v_pk_fma_f32 / v_pk_add_f32) is an anti-lever beside MFMAs on gfx950 (MI355X_MICROARCH.md price table);
+                // this translation unit is also built with -fno-slp-vectorize so that the compiler does not re-pack it.
                 const float sc = bs[pp % (PD + 1)];
+                const f32x2 (&B)[4] = bq[pp % (PD + 1)];
+                float q0, q1, q2, q3;
+#if WINO_PK
                 f32x2 q01, q23;
-                if (XF) {                                                    // SPADE pre-activation acts on the raw samples
+                if (XF) {
                     f32x2 d[4];
 #pragma unroll
                     for (int i = 0; i < 4; i++)
 #pragma unroll
                         for (int e = 0; e < 2; e++) {
-                            const float v = bq[pp % (PD + 1)][i][e] * sc;
+                            const float v = B[i][e] * sc;
                             d[i][e] = __builtin_amdgcn_fmed3f(fmaxf(v, v * in_slope), -in_cl, in_cl);
                         }
                     q01 = d[2] * s1 + d[0]; q23 = d[3] * s1 + d[1];
                 } else if (MODE == 1) {
                     const float ss = sc * s1;
-                    q01 = bq[pp % (PD + 1)][2] * ss + bq[pp % (PD + 1)][0] * sc; q23 = bq[pp % (PD + 1)][3] * ss + bq[pp % (PD + 1)][1] * sc;
+                    q01 = B[2] * ss + B[0] * sc; q23 = B[3] * ss + B[1] * sc;
                 } else {
-                    q01 = bq[pp % (PD + 1)][2] * s1 + bq[pp % (PD + 1)][0]; q23 = bq[pp % (PD + 1)][3] * s1 + bq[pp % (PD + 1)][1];
+                    q01 = B[2] * s1 + B[0]; q23 = B[3] * s1 + B[1];
                 }
+                q0 = q01[0]; q1 = q01[1]; q2 = q23[0]; q3 = q23[1];
+#else
+                if (XF) {
+                    float d[4][2];
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+#pragma unroll
+                        for (int e = 0; e < 2; e++) {
+                            const float v = B[i][e] * sc;
+                            d[i][e] = __builtin_amdgcn_fmed3f(fmaxf(v, v * in_slope), -in_cl, in_cl);
+                        }
+                    q0 = fmaf(d[2][0], s1, d[0][0]); q1 = fmaf(d[2][1], s1, d[0][1]);
+                    q2 = fmaf(d[3][0], s1, d[1][0]); q3 = fmaf(d[3][1], s1, d[1][1]);
+                } else if (MODE == 1) {
+                    q0 = fmaf(B[2][0], s1, B[0][0]) * sc; q1 = fmaf(B[2][1], s1, B[0][1]) * sc;
+                    q2 = fmaf(B[3][0], s1, B[1][0]) * sc; q3 = fmaf(B[3][1], s1, B[1][1]) * sc;
+                } else {
+                    q0 = fmaf(B[2][0], s1, B[0][0]); q1 = fmaf(B[2][1], s1, B[0][1]);
+                    q2 = fmaf(B[3][0], s1, B[1][0]); q3 = fmaf(B[3][1], s1, B[1][1]);
+                }
+#endif
 #if WINO_EXP & 512
                 { static_assert(true, ""); float dmy = sc;                        // timing probe: 8 independent VALU ops per pair
                   asm volatile("v_add_f32 %0, %0, %0\n\tv_add_f32 %0, %0, %0\n\tv_add_f32 %0, %0, %0\n\tv_add_f32 %0, %0, %0\n\t"
@@ -298,7 +327,7 @@ __global__ __launch_bounds__(512, 4) void conv2d_wino(ConvParams p) {
 #if WINO_EXP & 256
                 const float v0 = bq[pp % (PD + 1)][0][0], v1 = bq[pp % (PD + 1)][0][1], v2 = bq[pp % (PD + 1)][1][0], v3 = bq[pp % (PD + 1)][1][1];   // timing probe: no transform
 #else
-                const float v0 = q01[0] - q23[0], v1 = q01[1] + q23[0], v2 = q23[0] - q01[1], v3 = q01[1] - q23[1];      // B^T d B, row a
+                const float v0 = q0 - q2, v1 = q1 + q2, v2 = q2 - q1, v3 = q1 - q3;      // B^T d B, row a
 #endif
                 wait_a(a_ring[pp % W_RING], pp < W_RING, pp < W_RING && k == 0);   // first pairs of a tile: landed before the previous epilogue's stores
                 acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_ring[pp % W_RING][0], v0, acc[0], 0, 0, 0);

@@ -22,6 +22,7 @@ import fcntl
 import glob
 import hashlib
 import os
+import re
 import shutil
 import subprocess
 import sys
@@ -90,8 +91,20 @@ def _log(msg, end='\n'):
         print(msg, end=end, flush=True)
 
 
+def source_flags(src):
+    """Per-source compiler flags: a `// hipcc-flags: ...` comment in the first lines of a translation unit (part of the
+    source text, hence of the build digest)."""
+    flags = []
+    with open(src) as f:
+        for _ in range(8):
+            m = re.match(r'\s*//\s*hipcc-flags:\s*(.*)', f.readline())
+            if m:
+                flags += m.group(1).split()
+    return flags
+
+
 def _compile_one(hipcc, src, obj, extra_flags):
-    cmd = [hipcc] + HIPCC_FLAGS + list(extra_flags) + ['-I', INCLUDE_DIR, '-I', CSRC_DIR, '-c', src, '-o', obj]
+    cmd = [hipcc] + HIPCC_FLAGS + list(extra_flags) + source_flags(src) + ['-I', INCLUDE_DIR, '-I', CSRC_DIR, '-c', src, '-o', obj]
     if verbosity == 'full':
         print(' '.join(cmd), flush=True)
     proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)

@@ -32,7 +32,7 @@ from . import conv2d_mfma
 from . import conv2d_mfma16
 
 native_input_gradients = os.environ.get('PG_NATIVE_DGRAD', '1') == '1'    # input gradients through the MFMA / Winograd kernels (PG_NATIVE_DGRAD=0: aten)
-native_weight_gradients = os.environ.get('PG_NATIVE_WGRAD', '1') == '1'   # weight gradients of stride-1 3x3 / 1x1 convs through csrc/conv2d_wgrad.hip
+native_weight_gradients = os.environ.get('PG_NATIVE_WGRAD', '0') == '1'   # weight gradients of stride-1 3x3 / 1x1 convs through csrc/conv2d_wgrad.hip (exact, deterministic; measured 1.7x slower than MIOpen's igemm_wrw assembly on the config-4 step, hence opt-in)
 enabled = True                      # True (default here; the reference's loop sets it, training_loop_fullbody.py:386): hand-written kernels.  False: aten
 weight_gradients_disabled = False   # forcefully disable weight gradients (R1, loss_fullbody.py:266)
 
@@ -147,12 +147,18 @@ class _Conv2dMfma(torch.autograd.Function):
             dx = _input_gradient(dy, x.shape, weight, stride, padding, transposed, output_padding)
         want_w = ctx.needs_input_grad[1] and not weight_gradients_disabled
         want_b = has_bias and ctx.needs_input_grad[2]
-        if dx is None and ctx.needs_input_grad[0] or want_w or want_b:
-            mask = [dx is None and ctx.needs_input_grad[0], want_w, want_b]
-            gx, dw, db = torch.ops.aten.convolution_backward(
+        if want_w and native_weight_gradients and not transposed and stride == 1 and not torch.is_grad_enabled():
+            dw = conv2d_mfma.weight_gradient(x, dy, weight.shape, padding)      # a GEMM over pixels (csrc/conv2d_wgrad.hip); None = not covered
+        if want_b and (dw is not None or not want_w):
+            db = dy.sum(dim=[0, 2, 3])
+        mask = [dx is None and ctx.needs_input_grad[0], want_w and dw is None, want_b and db is None]
+        if any(mask):
+            gx, gw, gb = torch.ops.aten.convolution_backward(
                 dy, x, weight, [weight.shape[1 if transposed else 0]] if has_bias else None,
                 [stride, stride], list(padding), [1, 1], transposed, list(output_padding), 1, mask)
             dx = gx if mask[0] else dx
+            dw = gw if mask[1] else dw
+            db = gb if mask[2] else db
         return dx, dw, db, None, None, None, None
 
 
@@ -192,10 +198,6 @@ class _Conv2dMfma16(torch.autograd.Function):
             dx = _input_gradient(dy, x.shape, weight, stride, padding, transposed, output_padding, fn=_Conv2dMfma16, mod=conv2d_mfma16)
         want_w = ctx.needs_input_grad[1] and not weight_gradients_disabled
         want_b = has_bias and ctx.needs_input_grad[2]
-        if want_w and native_weight_gradients and not transposed and stride == 1 and not torch.is_grad_enabled():
-            dw = conv2d_mfma.weight_gradient(x, dy, weight.shape, padding)      # a GEMM over pixels (csrc/conv2d_wgrad.hip); None = not covered
-        if want_b and (dw is not None or not want_w):
-            db = dy.sum(dim=[0, 2, 3])
         need_x = dx is None and ctx.needs_input_grad[0]
         need_w = want_w and dw is None
         need_b = want_b and db is None

@@ -173,8 +173,13 @@ def _up2_composite_phases(wt_iohw, f):
     The (2H+1)^2 intermediate of the two-step form (conv2d_resample.py:125-142) is never written or read: in half
     precision that traffic, not the 4x multiply count, is what the layer costs.  Returns {(a, b): IOHW weights}."""
     cin, cout = int(wt_iohw.shape[0]), int(wt_iohw.shape[1])
-    k6 = 4 * torch.nn.functional.conv2d(wt_iohw.reshape(cin * cout, 1, 3, 3), f.flip([0, 1])[None, None].to(wt_iohw.dtype), padding=3)
-    k6 = k6.reshape(cin, cout, 6, 6)
+    # full 2-D convolution of every 3x3 kernel with the 4x4 filter as nine shifted multiply-adds (K[i+a, j+b] += w[i, j] f[a, b]).
+    # Not F.conv2d: with Cin*Cout one-pixel "images" MIOpen's solver search runs for minutes on the first call.
+    g = (4 * f).to(wt_iohw.dtype)
+    k6 = wt_iohw.new_zeros([cin, cout, 6, 6])
+    for i in range(3):
+        for j in range(3):
+            k6[:, :, i:i + 4, j:j + 4] += wt_iohw[:, :, i:i + 1, j:j + 1] * g
     return {(a, b): k6[:, :, [4 + a, 2 + a, a]][:, :, :, [4 + b, 2 + b, b]].contiguous() for a in (0, 1) for b in (0, 1)}
 
 

@@ -961,9 +961,27 @@ def test_conv2d_gradfix_native_backward_routes():
     """First-order backward of conv2d_gradfix.conv2d on the GPU: input gradient through the MFMA / Winograd kernels with the
     flipped, transposed pack taken straight from the parameter, weight gradient through the native GEMM-over-pixels kernel --
     against PyTorch's own double-precision convolution."""
-    from torch_utils.ops import conv2d_gradfix
-    assert conv2d_gradfix.native_input_gradients and conv2d_gradfix.native_weight_gradients
+    from torch_utils.ops import conv2d_gradfix, conv2d_mfma
+    assert conv2d_gradfix.native_input_gradients
+    calls = {'wgrad': 0}
+    real_wgrad, was = conv2d_mfma.weight_gradient, conv2d_gradfix.native_weight_gradients
+    conv2d_gradfix.native_weight_gradients = True       # opt-in (PG_NATIVE_WGRAD=1): MIOpen's assembly wgrad is faster today
+
+    def counting_wgrad(*a, **k):
+        out = real_wgrad(*a, **k)
+        calls['wgrad'] += out is not None
+        return out
+    conv2d_mfma.weight_gradient = counting_wgrad
     gen = torch.Generator().manual_seed(31)
+    try:
+        _native_backward_cases(conv2d_gradfix, gen)
+    finally:
+        conv2d_mfma.weight_gradient = real_wgrad
+        conv2d_gradfix.native_weight_gradients = was
+    assert calls['wgrad'] == 3          # every case took the native weight-gradient kernel (the route, not only the numbers)
+
+
+def _native_backward_cases(conv2d_gradfix, gen):
     for cin, cout, k, hw in ((32, 80, 3, (20, 24)), (16, 24, 3, (13, 19)), (64, 48, 1, (17, 21))):
         x = torch.randn([2, cin, *hw], generator=gen)
         wt = torch.randn([cout, cin, k, k], generator=gen) / np.sqrt(cin * k * k)

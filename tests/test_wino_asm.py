@@ -19,7 +19,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_ring_registers_untouched_while_in_flight(tmp_path):
     hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
     src = os.path.join(ROOT, 'pasta-gan-plusplus_amd', 'csrc', 'conv2d_inst_wino.hip')
-    cmd = [hipcc, '-O3', '-std=c++17', '-fPIC', '-fvisibility=hidden', '--offload-arch=gfx950', '-I', os.path.join(ROOT, 'include'),
+    sys.path.insert(0, os.path.join(ROOT, 'pasta-gan-plusplus_amd'))
+    from torch_utils import custom_ops
+    cmd = [hipcc] + custom_ops.HIPCC_FLAGS + custom_ops.source_flags(src) + ['-I', os.path.join(ROOT, 'include'),
            '-I', os.path.dirname(src), '-c', src, '-o', str(tmp_path / 'w.o'), '-save-temps=obj']
     subprocess.run(cmd, check=True, cwd=tmp_path, capture_output=True, timeout=600)
     asm = glob.glob(str(tmp_path / '*gfx950.s'))
@@ -38,7 +40,9 @@ def test_no_compiler_vmcnt_wait_in_k_loop(tmp_path, unit):
     first LDS read would wait for the DMA just requested (tools/check_kloop_waits.py)."""
     hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
     src = os.path.join(ROOT, 'pasta-gan-plusplus_amd', 'csrc', unit + '.hip')
-    cmd = [hipcc, '-O3', '-std=c++17', '-fPIC', '-fvisibility=hidden', '--offload-arch=gfx950', '-I', os.path.join(ROOT, 'include'),
+    sys.path.insert(0, os.path.join(ROOT, 'pasta-gan-plusplus_amd'))
+    from torch_utils import custom_ops
+    cmd = [hipcc] + custom_ops.HIPCC_FLAGS + custom_ops.source_flags(src) + ['-I', os.path.join(ROOT, 'include'),
            '-I', os.path.dirname(src), '-c', src, '-o', str(tmp_path / 'k.o'), '-save-temps=obj']
     subprocess.run(cmd, check=True, cwd=tmp_path, capture_output=True, timeout=900)
     asm = glob.glob(str(tmp_path / '*gfx950.s'))

@@ -1,5 +1,5 @@
 """Build container, after `gpurun -- 'bash tools/profile_round.sh'`: copy what that call measured from gpurun_out/ into
-profiles/rNN_* with the commit it was measured on in every header.   python tools/collect_profiles.py 02"""
+profiles/rNN_* with the commit it was measured on in every header.   python tools/collect_profiles.py 02 [commit the call ran on]"""
 import csv
 import json
 import os
@@ -11,10 +11,10 @@ G = os.path.join(ROOT, 'gpurun_out')
 P = os.path.join(ROOT, 'profiles')
 
 
-def main(rnd):
-    commit = subprocess.run(['git', 'rev-parse', '--short', 'HEAD'], cwd=ROOT, capture_output=True, text=True).stdout.strip()
+def main(rnd, commit=None):
+    commit = commit or subprocess.run(['git', 'rev-parse', '--short', 'HEAD'], cwd=ROOT, capture_output=True, text=True).stdout.strip()
     dirty = subprocess.run(['git', 'status', '--porcelain', '--', 'pasta-gan-plusplus_amd', 'bench.py'], cwd=ROOT, capture_output=True, text=True).stdout.strip()
-    stamp = f'commit {commit}{" + uncommitted changes" if dirty else ""}'
+    stamp = f'commit {commit}' if len(sys.argv) > 2 else f'commit {commit}{" + uncommitted changes" if dirty else ""}'
     pre = os.path.join(P, f'r{rnd}_')
 
     def copy_csv(src, dst, header):
@@ -71,4 +71,4 @@ def main(rnd):
 
 
 if __name__ == '__main__':
-    main(sys.argv[1] if len(sys.argv) > 1 else '02')
+    main(sys.argv[1] if len(sys.argv) > 1 else '02', sys.argv[2] if len(sys.argv) > 2 else None)

@@ -200,6 +200,18 @@ int pg_conv2d_winograd_forward(const float* x, const float* packed_u, float* y,
 int pg_modconv_dcoefs(const float* w, const float* styles, float* dcoefs,
                       int N, int Cout, int Cin, int KHW, float scale, void* stream);
 
+/* Streaming 1x1 convolution with few output channels (Cout <= 8; the ToRGB / parsing heads, networks.py:287-316,
+ * modulated_conv2d with demodulate=False at networks.py:37-94): float32 NCHW, HW % 4 == 0, 16-byte aligned tensors:
+ *   y[n,o,p] = clamp(sum_c x[n,c,p] * w[o,c] * scale * styles[n,c] + bias[o]) + skip[n,o,p]
+ * styles / bias / skip may be NULL; clamp < 0 disables it.  PG_ERR_UNSUPPORTED otherwise (use pg_conv2d_forward). */
+int pg_conv1x1_small(const float* x, const float* w, const float* styles, const float* bias, const float* skip, float* y,
+                     int N, int Cin, int64_t HW, int Cout, float scale, float clamp, void* stream);
+
+/* 3x3 convolution of a one-channel image (first layer of the SPADE blocks on the parsing / mask map, networks.py:1708-1712):
+ * y = act(conv2d(x [N,1,H,W], w [Cout,1,3,3] * scale, padding=1)), cross-correlation as F.conv2d; act = PG_ACT_LINEAR | PG_ACT_RELU
+ * (gain 1).  float32, W % 4 == 0, 16-byte aligned; PG_ERR_UNSUPPORTED otherwise (use pg_conv2d_forward). */
+int pg_conv3x3_cin1(const float* x, const float* w, float* y, int N, int H, int W, int Cout, float scale, int act, void* stream);
+
 /* Per-(n,c) mean and rsqrt(var + eps) over H*W (nn.InstanceNorm2d(affine=False), networks.py:1713),
  * and the SPADE combine out = (x - mean) * rstd * (1 + gamma) + beta (networks.py:1722). */
 int pg_instance_norm_stats(const float* x, float* mean, float* rstd, int NC, int64_t HW, float eps, void* stream);

@@ -467,6 +467,141 @@ PG_EXPORT int pg_conv2d_winograd_forward(const float* x, const float* packed_u, 
     return conv_forward(true, x, packed_u, y, N, Cin, H, W, Cout, 3, 3, 1, pad_y, pad_x, OH, OW, ystride, 1, 1, 0, 0, fusion, stream);
 }
 
+// Streaming 1x1 head for fp32 NCHW tensors (the ToRGB / parsing heads: Cout <= 8, networks.py:287-316): a thread owns 4 adjacent
+// pixels and walks the input channels with 16-byte loads (one contiguous 1 KB per wave-instruction, 8 channels in flight), the
+// Cout x Cin weights of the block's image -- already multiplied by its styles -- sit in LDS as [Cin][8] (two broadcast reads per
+// channel).  HBM-bound: 4*Cin bytes read + 4*Cout written (+ 4*Cout skip image) per pixel; the tiled MFMA kernel pads such a
+// layer to 32 output channels and runs it at 3 TB/s.
+namespace {
+typedef float f32x4s __attribute__((ext_vector_type(4)));
+template <int COUT>
+__global__ __launch_bounds__(256) void conv1x1_small_f32_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ styles,
+                                                                const float* __restrict__ bias, const float* __restrict__ skip, float* __restrict__ y,
+                                                                int Cin, int64_t HW4, float scale, float clamp) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];          // [Cin][8]
+    const int n = blockIdx.y;
+    for (int e = threadIdx.x; e < 8 * Cin; e += 256) {
+        const int c = e >> 3, o = e & 7;
+        wl[e] = o < COUT ? w[o * Cin + c] * scale * (styles ? styles[(int64_t)n * Cin + c] : 1.f) : 0.f;
+    }
+    __syncthreads();
+    const float cl = clamp >= 0.f ? clamp : __builtin_inff();
+    const f32x4s* xn = (const f32x4s*)x + (int64_t)n * Cin * HW4;
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < HW4; p += (int64_t)gridDim.x * 256) {
+        f32x4s acc[COUT];
+#pragma unroll
+        for (int o = 0; o < COUT; o++) acc[o] = (f32x4s){0.f, 0.f, 0.f, 0.f};
+        auto mac = [&](const f32x4s& xv, int c) __attribute__((always_inline)) {
+            const f32x4s w0 = *(const f32x4s*)(wl + c * 8), w1 = *(const f32x4s*)(wl + c * 8 + 4);
+#pragma unroll
+            for (int o = 0; o < COUT; o++) acc[o] += xv * (o < 4 ? w0[o & 3] : w1[o & 3]);
+        };
+        int c0 = 0;
+        for (; c0 + 8 <= Cin; c0 += 8) {                                  // eight channel planes in flight, no branch between them
+            f32x4s v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = xn[(int64_t)(c0 + u) * HW4 + p];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 8; u++) mac(v[u], c0 + u);
+        }
+        for (; c0 < Cin; c0++) mac(xn[(int64_t)c0 * HW4 + p], c0);
+#pragma unroll
+        for (int o = 0; o < COUT; o++) {
+            f32x4s r = acc[o] + (bias ? bias[o] : 0.f);
+#pragma unroll
+            for (int e = 0; e < 4; e++) r[e] = fminf(fmaxf(r[e], -cl), cl);
+            const int64_t off = ((int64_t)n * COUT + o) * HW4 + p;
+            if (skip) r += ((const f32x4s*)skip)[off];
+            ((f32x4s*)y)[off] = r;
+        }
+    }
+}
+
+
+// 3x3 convolution of a ONE-channel image (the SPADE blocks' first layer on the parsing / mask map, networks.py:1708-1712:
+// 1 -> 64 channels + ReLU): a 9-tap stencil per output channel.  A thread keeps the 3 x 6 samples its 4 adjacent pixels touch
+// in registers and walks the output channels (weights are uniform: scalar loads), one 16-byte store each -- the kernel is a
+// pure output stream (4*Cout bytes per pixel); the MFMA kernel would pad the single input channel to a 16-channel K chunk.
+template <bool RELU>
+__global__ __launch_bounds__(256) void conv3x3_cin1_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y,
+                                                           int H, int W, int Cout, float scale) {
+    const int n = blockIdx.y;
+    const int W4 = W >> 2;
+    const int64_t HW = (int64_t)H * W;
+    const float* xn = x + (int64_t)n * HW;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < (int64_t)H * W4; q += (int64_t)gridDim.x * 256) {
+        const int oy = (int)(q / W4), ox = 4 * (int)(q % W4);
+        float v[3][6];
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            const int gy = oy + r - 1;
+            const bool row_ok = gy >= 0 && gy < H;
+            const float* row = xn + (int64_t)(row_ok ? gy : 0) * W;
+            const f32x4s m = *(const f32x4s*)(row + ox);
+            const float l = row[ox > 0 ? ox - 1 : 0], rr = row[ox + 4 < W ? ox + 4 : W - 1];
+            v[r][0] = (row_ok && ox > 0) ? l : 0.f;
+            v[r][5] = (row_ok && ox + 4 < W) ? rr : 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[r][1 + e] = row_ok ? m[e] : 0.f;
+        }
+        f32x4s* yo = (f32x4s*)(y + (int64_t)n * Cout * HW + (int64_t)oy * W + ox);
+        for (int co = 0; co < Cout; co++) {
+            const float* wc = w + co * 9;
+            f32x4s acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const float wk = wc[r * 3 + k] * scale;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) acc[e] = fmaf(v[r][e + k], wk, acc[e]);
+                }
+            if (RELU) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) acc[e] = fmaxf(acc[e], 0.f);
+            }
+            yo[(int64_t)co * (HW >> 2)] = acc;
+        }
+    }
+}
+}  // namespace
+
+/* y[n,o,p] = clamp(sum_c x[n,c,p] * w[o,c] * scale * styles[n,c] + bias[o]) + skip[n,o,p]   (ToRGB: networks.py:306-316, demodulate=False) */
+PG_EXPORT int pg_conv1x1_small(const float* x, const float* w, const float* styles, const float* bias, const float* skip, float* y,
+                               int N, int Cin, int64_t HW, int Cout, float scale, float clamp, void* stream) {
+    if (!x || !w || !y || N <= 0 || Cin <= 0 || HW <= 0 || Cout <= 0) return PG_ERR_INVALID_ARG;
+    if (Cout > 8 || HW % 4 != 0 || !pg::aligned16(x) || !pg::aligned16(y) || (skip && !pg::aligned16(skip)) || (size_t)Cin * 32 > 64 * 1024) return PG_ERR_UNSUPPORTED;
+    if (N > 65535) return PG_ERR_TOO_LARGE;
+    const int64_t HW4 = HW / 4;
+    int64_t bx = (HW4 + 255) / 256;
+    const int64_t cap = (int64_t)pg::num_cu() * 8 / N + 1;
+    if (bx > cap) bx = cap;
+    const dim3 grid((unsigned)bx, (unsigned)N);
+    const size_t lds = (size_t)Cin * 32;
+    hipStream_t s = (hipStream_t)stream;
+#define PG_SMALL(C) case C: hipLaunchKernelGGL((conv1x1_small_f32_kernel<C>), grid, dim3(256), lds, s, x, w, styles, bias, skip, y, Cin, HW4, scale, clamp); break;
+    switch (Cout) { PG_SMALL(1) PG_SMALL(2) PG_SMALL(3) PG_SMALL(4) PG_SMALL(5) PG_SMALL(6) PG_SMALL(7) PG_SMALL(8) }
+#undef PG_SMALL
+    return pg::launch_status();
+}
+
+/* y = act(conv2d(x, w * scale, padding=1)) for a single input channel: x [N,1,H,W], w [Cout,1,3,3] (cross-correlation, as
+ * F.conv2d), y [N,Cout,H,W]; act = PG_ACT_LINEAR or PG_ACT_RELU with gain 1.  W % 4 == 0 and 16-byte aligned tensors. */
+PG_EXPORT int pg_conv3x3_cin1(const float* x, const float* w, float* y, int N, int H, int W, int Cout, float scale, int act, void* stream) {
+    if (!x || !w || !y || N <= 0 || H <= 0 || W <= 0 || Cout <= 0) return PG_ERR_INVALID_ARG;
+    if (act != PG_ACT_LINEAR && act != PG_ACT_RELU) return PG_ERR_UNSUPPORTED;
+    if (W % 4 != 0 || !pg::aligned16(x) || !pg::aligned16(y)) return PG_ERR_UNSUPPORTED;
+    if (N > 65535 || (int64_t)Cout * H * W > 0x7fffffffLL * 4) return PG_ERR_TOO_LARGE;
+    int64_t bx = ((int64_t)H * (W / 4) + 255) / 256;
+    const int64_t cap = (int64_t)pg::num_cu() * 8 / N + 1;
+    if (bx > cap) bx = cap;
+    const dim3 grid((unsigned)bx, (unsigned)N);
+    if (act == PG_ACT_RELU) hipLaunchKernelGGL(conv3x3_cin1_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, w, y, H, W, Cout, scale);
+    else hipLaunchKernelGGL(conv3x3_cin1_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, w, y, H, W, Cout, scale);
+    return pg::launch_status();
+}
+
 PG_EXPORT int pg_modconv_dcoefs(const float* w, const float* styles, float* dcoefs,
                                 int N, int Cout, int Cin, int KHW, float scale, void* stream) {
     if (!w || !styles || !dcoefs || N <= 0 || Cout <= 0 || Cin <= 0 || KHW <= 0) return PG_ERR_INVALID_ARG;

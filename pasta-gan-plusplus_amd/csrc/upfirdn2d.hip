@@ -24,7 +24,6 @@
 //
 // Roofline: HBM streaming; algorithmic bytes per call = sizeof(T) * (numel(x) + numel(y))
 // (SURVEY.md section 8d).
-#include <cstdlib>
 #include "pg_common.h"
 
 namespace {
@@ -126,31 +125,26 @@ __global__ __launch_bounds__(256) void upfirdn2d_tiled(Params p, int tilesX, int
     const int ix0 = floor_div(ox0 * DNX - p.padx0, UPX);
     const int iy0 = floor_div(oy0 * DNY - p.pady0, UPY);
     const T* __restrict__ xp = (const T*)p.x + plane * (int64_t)p.inH * p.inW;
-    // two phases so that all of a wave's row loads are in flight together (a load -> wait -> ds_write loop is latency-bound)
-    constexpr int NR = (G::TIH + 3) / 4, NC = (G::TIW + 63) / 64;
-    float stage[NR][NC];
+    // The footprint is walked as one flat element range (256 consecutive elements per step, rows break mid-wave): every
+    // wave-instruction is full -- a per-row walk spends half of its load instructions on the 3-column halo tail, and vector
+    // memory instructions are what this kernel runs out of.  Two phases so that all loads are in flight together (a
+    // load -> wait -> ds_write loop is latency-bound).
+    constexpr int NE = G::TIH * G::TIW, NL = (NE + 255) / 256;
+    float stage[NL];
 #pragma unroll
-    for (int i = 0; i < NR; i++) {
-        const int r = wave + 4 * i;
-        const int gy = iy0 + r;
-        const bool row_ok = r < G::TIH && gy >= 0 && gy < p.inH;            // wave-uniform
-        const T* __restrict__ row = xp + (int64_t)(row_ok ? gy : 0) * p.inW;
-#pragma unroll
-        for (int j = 0; j < NC; j++) {
-            const int gx = ix0 + 64 * j + lx;
-            const bool ok = row_ok && gx >= 0 && gx < p.inW;
-            const float v = (float)row[ok ? gx : 0];                        // unconditional load from a valid address
-            stage[i][j] = ok ? v : 0.f;
-        }
+    for (int i = 0; i < NL; i++) {
+        const int e = t + 256 * i;
+        const int r = e / G::TIW, c = e - r * G::TIW;
+        const int gy = iy0 + r, gx = ix0 + c;
+        const bool ok = e < NE && gy >= 0 && gy < p.inH && gx >= 0 && gx < p.inW;
+        const float v = (float)xp[ok ? (int64_t)gy * p.inW + gx : 0];       // unconditional load from a valid address
+        stage[i] = ok ? v : 0.f;
     }
 #pragma unroll
-    for (int i = 0; i < NR; i++) {
-        const int r = wave + 4 * i;
-#pragma unroll
-        for (int j = 0; j < NC; j++) {
-            const int c = 64 * j + lx;
-            if ((G::TIH % 4 == 0 || r < G::TIH) && (64 * (j + 1) <= G::TIW || c < G::TIW)) sx[r][c] = stage[i][j];
-        }
+    for (int i = 0; i < NL; i++) {
+        const int e = t + 256 * i;
+        const int r = e / G::TIW, c = e - r * G::TIW;
+        if (NE % 256 == 0 || e < NE) sx[r][c] = stage[i];
     }
     __syncthreads();
 
@@ -227,129 +221,6 @@ int launch_tiled(const Params& p, hipStream_t s) {
     if (blocks > 0x7fffffffLL) return PG_ERR_TOO_LARGE;
     hipLaunchKernelGGL((upfirdn2d_tiled<T, UPX, UPY, DNX, DNY, FW, FH>), dim3((unsigned)blocks), dim3(256), 0, s, p, tilesX, tilesY);
     return launch_status();
-}
-
-// ---------------------------------------------------------------- row streaming (no resampling, fp32, dense NCHW)
-// The blur after every transposed-convolution (`up = 2` layers: [N, C, 2H+1, 2W+1] -> [N, C, 2H, 2W], 4x4 taps) is the FIR
-// call that carries the bytes of the synthesis forward.  It needs no LDS: a thread owns 4 adjacent output columns of a strip
-// of R output rows and walks the R + FH - 1 input rows once, two 16-byte loads per row (the 7 samples its 4 columns touch;
-// 4-byte aligned -- the odd row pitch 2W+1 rules out more), keeping the R x 4 partial sums in registers; consecutive lanes =
-// consecutive column quads, so every wave-instruction reads / writes one contiguous 1 KB.  Rows are requested two steps
-// ahead of their use.  The halo rows between strips are re-read ((R+3)/R of the input; neighbouring strips run at the same
-// time, so mostly from L2).  The SynthesisLayer tail rides in the store.
-typedef float f32x4a4 __attribute__((ext_vector_type(4), aligned(4)));
-typedef float f32x4a16 __attribute__((ext_vector_type(4)));
-
-template <int FW, int FH, int R>
-__global__ __launch_bounds__(256) void upfirdn2d_rows(Params p, int quads, int strips) {
-    static_assert(FW <= 4, "two 16-byte loads cover 4 columns + FW - 1");
-    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int q = (int)(gid % quads);
-    const int64_t r1 = gid / quads;
-    const int strip = (int)(r1 % strips);
-    const int64_t plane = r1 / strips;
-    if (plane >= (int64_t)p.N * p.C) return;
-    const int ox = 4 * q, oy0 = strip * R;
-    const int ix0 = ox - p.padx0, iy0 = oy0 - p.pady0;
-    // taps: flipped (true convolution) unless p.flip, zero padded up to FH x FW (uniform: scalar registers)
-    float tap[FH][FW];
-#pragma unroll
-    for (int ky = 0; ky < FH; ky++)
-#pragma unroll
-        for (int kx = 0; kx < FW; kx++) {
-            const int fy = p.flip ? ky : p.fh - 1 - ky, fx = p.flip ? kx : p.fw - 1 - kx;
-            tap[ky][kx] = (ky < p.fh && kx < p.fw) ? p.f[fy * p.fs[0] + fx * p.fs[1]] : 0.f;
-        }
-    const float* __restrict__ xp = (const float*)p.x + plane * (int64_t)p.inH * p.inW;
-    const bool wide = ix0 >= 0 && ix0 + 8 <= p.inW;                      // both 16-byte words inside the row
-    auto load_row = [&](int rr, float (&v)[8]) __attribute__((always_inline)) {
-        const int gy = iy0 + rr;
-        const bool row_ok = gy >= 0 && gy < p.inH;
-        const float* row = xp + (int64_t)(row_ok ? gy : 0) * p.inW;
-        if (wide) {
-            const f32x4a4 a = *(const f32x4a4*)(row + ix0), b = *(const f32x4a4*)(row + ix0 + 4);
-#pragma unroll
-            for (int i = 0; i < 4; i++) { v[i] = row_ok ? a[i] : 0.f; v[4 + i] = row_ok ? b[i] : 0.f; }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 3 + FW; i++) {
-                const int gx = ix0 + i;
-                const bool ok = row_ok && gx >= 0 && gx < p.inW;
-                const float t = row[ok ? gx : 0];
-                v[i] = ok ? t : 0.f;
-            }
-#pragma unroll
-            for (int i = 3 + FW; i < 8; i++) v[i] = 0.f;
-        }
-    };
-    float acc[R][4];
-#pragma unroll
-    for (int r = 0; r < R; r++)
-#pragma unroll
-        for (int c = 0; c < 4; c++) acc[r][c] = 0.f;
-    constexpr int NROWS = R + FH - 1, AHEAD = 2;
-    float ring[AHEAD + 1][8];
-#pragma unroll
-    for (int d = 0; d < AHEAD; d++) load_row(d, ring[d]);
-#pragma unroll
-    for (int rr = 0; rr < NROWS; rr++) {
-        if (rr + AHEAD < NROWS) load_row(rr + AHEAD, ring[(rr + AHEAD) % (AHEAD + 1)]);
-        const float (&v)[8] = ring[rr % (AHEAD + 1)];
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-            const int jy = rr - r;                                         // compile-time after unrolling
-            if (jy >= 0 && jy < FH) {
-#pragma unroll
-                for (int c = 0; c < 4; c++)
-#pragma unroll
-                    for (int jx = 0; jx < FW; jx++) acc[r][c] = fmaf(v[c + jx], tap[jy][jx], acc[r][c]);
-            }
-        }
-    }
-    const int ch = (int)(plane % p.C), n = (int)(plane / p.C);
-    const float bias = (p.has_ep && p.bias) ? p.bias[ch] : 0.f;
-    float* __restrict__ yp = (float*)p.y + plane * (int64_t)p.outH * p.outW;
-    const bool vec = ox + 4 <= p.outW && (p.outW & 3) == 0 && (((uintptr_t)p.y) & 15) == 0;
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-        const int oy = oy0 + r;
-        if (oy >= p.outH) break;
-        float o[4];
-#pragma unroll
-        for (int c = 0; c < 4; c++) o[c] = acc[r][c] * p.gain;
-        if (p.has_ep) {       // SynthesisLayer tail: + noise, + bias, linear/relu/lrelu, gain, clamp
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-                float v = o[c];
-                if (p.noise && ox + c < p.outW) v += p.noise[n * p.noise_bs + (int64_t)oy * p.outW + ox + c] * p.noise_gain;
-                v += bias;
-                v = (v > 0.f ? v : v * p.slope) * p.act_gain;
-                o[c] = fminf(fmaxf(v, -p.clamp), p.clamp);
-            }
-        }
-        if (vec) {
-            *(f32x4a16*)(yp + (int64_t)oy * p.outW + ox) = (f32x4a16){o[0], o[1], o[2], o[3]};
-        } else {
-#pragma unroll
-            for (int c = 0; c < 4; c++)
-                if (ox + c < p.outW) yp[(int64_t)oy * p.outW + ox + c] = o[c];
-        }
-    }
-}
-
-// Returns 1 if the row-streaming kernel took the call (status in *st).
-inline bool try_rows(const Params& p, hipStream_t s, int* st) {
-    static const int rows = [] { const char* e = getenv("PG_FIR_ROWS"); return e ? atoi(e) : 16; }();       // 0 = off (A/B), 8 | 16 = strip height
-    if (rows <= 0 || p.upx != 1 || p.upy != 1 || p.dnx != 1 || p.dny != 1 || p.fw > 4 || p.fh > 4) return false;
-    const int R = rows == 8 ? 8 : 16;
-    const int quads = (p.outW + 3) / 4, strips = (p.outH + R - 1) / R;
-    const int64_t threads = (int64_t)p.N * p.C * strips * quads;
-    const int64_t blocks = (threads + 255) / 256;
-    if (blocks > 0x7fffffffLL) { *st = PG_ERR_TOO_LARGE; return true; }
-    if (R == 8) hipLaunchKernelGGL((upfirdn2d_rows<4, 4, 8>), dim3((unsigned)blocks), dim3(256), 0, s, p, quads, strips);
-    else hipLaunchKernelGGL((upfirdn2d_rows<4, 4, 16>), dim3((unsigned)blocks), dim3(256), 0, s, p, quads, strips);
-    *st = launch_status();
-    return true;
 }
 
 // Returns 1 if a tiled specialisation took the call (status in *st).
@@ -524,7 +395,6 @@ int run(const Params& p, hipStream_t s, bool allow_tiled) {
                             p.xs[0] == (int64_t)p.C * p.inH * p.inW && p.ys[3] == 1 && p.ys[2] == p.outW &&
                             p.ys[1] == (int64_t)p.outH * p.outW && p.ys[0] == (int64_t)p.C * p.outH * p.outW;
     int st = PG_OK;
-    if constexpr (sizeof(T) == 4) { if (allow_tiled && dense_nchw && try_rows(p, s, &st)) return st; }
     if (allow_tiled && dense_nchw && (!p.has_ep || sizeof(T) == 4) && try_tiled<T>(p, s, &st)) return st;
     if constexpr (sizeof(T) <= 4) { if (allow_tiled && try_channels_last<T>(p, s, &st)) return st; }
     if (p.has_ep) return PG_ERR_UNSUPPORTED;

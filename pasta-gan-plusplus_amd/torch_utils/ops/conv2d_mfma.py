@@ -91,6 +91,10 @@ def _init(plugin_name='conv2d_plugin'):
         lib.pg_conv2d_wgrad_plan.argtypes = [i] * 7
         lib.pg_conv2d_wgrad.restype = i
         lib.pg_conv2d_wgrad.argtypes = [vp, vp, vp, vp] + [i] * 12 + [vp]
+        lib.pg_conv3x3_cin1.restype = i
+        lib.pg_conv3x3_cin1.argtypes = [vp, vp, vp, i, i, i, i, f, i, vp]
+        lib.pg_conv1x1_small.restype = i
+        lib.pg_conv1x1_small.argtypes = [vp] * 6 + [i, i, i64, i, f, f, vp]
         _plugin = plugin
     return _plugin
 
@@ -339,6 +343,47 @@ def weight_gradient(x, dy, weight_shape, pad):
                                  nat.stream_of(x))
     nat.check(st, 'pg_conv2d_wgrad')
     return dw
+
+
+def conv3x3_cin1_ok(x, weight, padding=1):
+    return (x.dtype == torch.float32 and x.is_cuda and x.is_contiguous() and int(x.shape[1]) == 1 and tuple(weight.shape[1:]) == (1, 3, 3)
+            and int(padding) == 1 and x.shape[3] % 4 == 0)
+
+
+def conv3x3_cin1(x, weight, scale=1.0, act='linear'):
+    """act(conv2d(x, weight * scale, padding=1)) for a one-channel x as a 9-tap stencil per output channel (act: linear | relu, gain 1)."""
+    lib = _init().lib
+    n, _, h, w = x.shape
+    cout = int(weight.shape[0])
+    wf = _f32c(weight.detach(), 'weight')
+    y = torch.empty([n, cout, h, w], dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.pg_conv3x3_cin1(nat.ptr(x), nat.ptr(wf), nat.ptr(y), n, h, w, cout, float(scale), ACT_INDEX[act], nat.stream_of(x))
+    nat.check(rc, 'pg_conv3x3_cin1')
+    return y
+
+
+def conv1x1_small_ok(x, weight, skip=None):
+    """Shapes the streaming 1x1 head kernel takes: float32 dense NCHW, Cout <= 8, H*W a multiple of 4."""
+    return (x.dtype == torch.float32 and x.is_cuda and x.is_contiguous() and tuple(weight.shape[2:]) == (1, 1) and int(weight.shape[0]) <= 8
+            and (x.shape[2] * x.shape[3]) % 4 == 0 and int(x.shape[1]) <= 2048 and (skip is None or (skip.dtype == torch.float32 and skip.is_contiguous())))
+
+
+def conv1x1_small(x, weight, styles=None, bias=None, skip=None, scale=1.0, clamp=None):
+    """ToRGB-style head in one streaming pass: clamp(conv1x1(x * styles[:, :, None, None], weight * scale) + bias) + skip
+    (networks.py:306-316 with modulated_conv2d(demodulate=False), networks.py:37-94)."""
+    lib = _init().lib
+    n, cin, h, w = x.shape
+    cout = int(weight.shape[0])
+    wf = _f32c(weight.detach().reshape(cout, cin), 'weight')
+    st = _f32c(styles.detach(), 'styles') if styles is not None else None
+    b = _f32c(bias.detach(), 'bias') if bias is not None else None
+    y = torch.empty([n, cout, h, w], dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.pg_conv1x1_small(nat.ptr(x), nat.ptr(wf), nat.ptr(st), nat.ptr(b), nat.ptr(skip), nat.ptr(y), n, cin, h * w, cout,
+                                  float(scale), float(clamp) if clamp is not None else -1.0, nat.stream_of(x))
+    nat.check(rc, 'pg_conv1x1_small')
+    return y
 
 
 def modconv_dcoefs(weight, styles, scale=1.0):

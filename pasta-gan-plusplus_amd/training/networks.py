@@ -447,7 +447,11 @@ class Spade_Norm_Block(nn.Module):
         if _fast_ok(x, denorm_feats, self.conv_mlp.weight, self.conv_gamma.weight, self.conv_beta.weight):
             post = post or {}
             mean, rstd = stats if stats is not None else conv2d_mfma.instance_norm_stats(x, eps=self.param_free_norm.eps)
-            actv = self.conv_mlp(denorm_feats, no_act=True, post_act='relu')     # conv + ReLU in one launch
+            m = self.conv_mlp
+            if conv2d_mfma.conv3x3_cin1_ok(denorm_feats, m.weight, m.padding) and m.up == 1 and m.down == 1 and os.environ.get('PG_CIN1_STENCIL', '1') != '0':
+                actv = conv2d_mfma.conv3x3_cin1(denorm_feats, m.weight, scale=m.weight_gain, act='relu')     # one-channel map: a 9-tap stencil, output-stream bound
+            else:
+                actv = m(denorm_feats, no_act=True, post_act='relu')             # conv + ReLU in one launch
             g, b = self.conv_gamma, self.conv_beta
             c = int(g.weight.shape[0])
             if c % 32 == 0 and g._fast_geometry() and g.down == 1 and x.is_contiguous():
@@ -567,6 +571,12 @@ class _ToRGBBase(nn.Module):
                 pred_parsing = conv2d_mfma16.conv1x1_small(x, self.m_weight1, styles, self.m_bias1, clamp=self.conv_clamp)
             return conv2d_mfma16.conv1x1_small(x, self.weight, styles, self.bias, skip=skip_img, clamp=self.conv_clamp), pred_parsing
         fast = _fast_ok(x, self.weight, self.bias, styles, skip_img)
+        if fast and conv2d_mfma.conv1x1_small_ok(x, self.weight, skip_img) and os.environ.get('PG_HEAD_STREAM', '1') != '0':
+            # fp32 inference: each head is one streaming pass over x (HBM-bound; the MFMA kernel would pad it to 32 output channels)
+            pred_parsing = None
+            if self.is_last and self.is_style:
+                pred_parsing = conv2d_mfma.conv1x1_small(x, self.m_weight1, styles, self.m_bias1, clamp=self.conv_clamp)
+            return conv2d_mfma.conv1x1_small(x, self.weight, styles, self.bias, skip=skip_img, clamp=self.conv_clamp), pred_parsing
         pred_parsing = None
         if self.is_last and self.is_style:
             if fast:

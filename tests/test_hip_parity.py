@@ -995,3 +995,43 @@ def _native_backward_cases(conv2d_gradfix, gen):
         close(gx, rx, 1e-4, 1e-5 * scale_of(rx))
         close(gw, rw, 1e-4, 1e-5 * scale_of(rw))
         close(gb, rb, 1e-4, 1e-5 * scale_of(rb))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('cout,cin,hw,use_styles,use_skip,clamp', [(3, 64, (32, 36), True, True, 256.0), (7, 20, (16, 8), True, False, 0.5),
+                                                                  (1, 8, (4, 4), False, False, None), (8, 130, (10, 12), True, True, None)])
+def test_streaming_head_fp32(cout, cin, hw, use_styles, use_skip, clamp):
+    """pg_conv1x1_small (the fp32 ToRGB / parsing heads as one streaming pass) against the same arithmetic in float64."""
+    from torch_utils.ops import conv2d_mfma
+    gen = torch.Generator().manual_seed(100 * cout + cin)
+    x = torch.randn([3, cin, *hw], generator=gen)
+    w = torch.randn([cout, cin, 1, 1], generator=gen)
+    styles = torch.randn([3, cin], generator=gen) if use_styles else None
+    bias = torch.randn([cout], generator=gen)
+    skip = torch.randn([3, cout, *hw], generator=gen) if use_skip else None
+    assert conv2d_mfma.conv1x1_small_ok(x.to(DEV), w.to(DEV), skip.to(DEV) if use_skip else None)
+    y = conv2d_mfma.conv1x1_small(x.to(DEV), w.to(DEV), styles.to(DEV) if use_styles else None, bias.to(DEV),
+                                  skip=skip.to(DEV) if use_skip else None, scale=0.37, clamp=clamp)
+    xs = x.double() * (styles.double()[:, :, None, None] if use_styles else 1.0)
+    ref = torch.nn.functional.conv2d(xs, w.double() * 0.37) + bias.double()[None, :, None, None]
+    if clamp is not None:
+        ref = ref.clamp(-clamp, clamp)
+    if use_skip:
+        ref = ref + skip.double()
+    close(y, ref, 1e-5, 1e-5 * scale_of(ref))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n,h,w,cout,act', [(2, 9, 12, 5, 'relu'), (1, 1, 4, 3, 'linear'), (3, 33, 64, 64, 'relu')])
+def test_one_channel_stencil_conv(n, h, w, cout, act):
+    """pg_conv3x3_cin1 (the SPADE blocks' first layer on the one-channel map) against F.conv2d in float64."""
+    from torch_utils.ops import conv2d_mfma
+    gen = torch.Generator().manual_seed(7 * h + w)
+    x = torch.randn([n, 1, h, w], generator=gen)
+    wt = torch.randn([cout, 1, 3, 3], generator=gen)
+    assert conv2d_mfma.conv3x3_cin1_ok(x.to(DEV), wt.to(DEV))
+    y = conv2d_mfma.conv3x3_cin1(x.to(DEV), wt.to(DEV), scale=0.61, act=act)
+    ref = torch.nn.functional.conv2d(x.double(), wt.double() * 0.61, padding=1)
+    if act == 'relu':
+        ref = ref.relu()
+    close(y, ref, 1e-5, 1e-6 * scale_of(ref))

@@ -178,7 +178,7 @@ def run_stack(args, rank, world, dev, dist):
     """BASELINE config 5 (--mode bf16_1024): the StyleGAN2 block stack (SynthesisLayer x2 + ToRGB + skip-image upsample per
     resolution, no SPADE) at 1024^2, N=4 per GPU, every block in bf16 with fp32 accumulation.  The 16-bit
     convolution kernel is near the machine's ridge, so both rooflines of its launches are reported: HBM (algorithmic bytes =
-    2*(numel(x) + numel(y)) per launch) as `roofline`, the matrix rate next to it."""
+    x + y + packed weights per launch) as `roofline`, the matrix rate next to it."""
     from training import networks, replicas
     from torch_utils.ops import conv2d_mfma
     from detgen import fill_module_
@@ -195,18 +195,33 @@ def run_stack(args, rank, world, dev, dist):
         for _ in range(args.warmup):
             img = net(ws, noise_mode='const')
         barrier()
-        timeline = conv2d_mfma.start_timeline()
+        timeline = conv2d_mfma.start_timeline()          # per-launch HIP events (for `roofline`) on an eager pass of the same steps
         t0 = time.perf_counter()
         for _ in range(args.steps):
             img = net(ws, noise_mode='const')
         barrier()
-        elapsed = time.perf_counter() - t0
+        elapsed = eager_elapsed = time.perf_counter() - t0
         conv2d_mfma.stop_timeline()
+        if not args.no_graph:
+            # the step is launch-bound on the host (~250 kernels, 4.3 ms of GPU time): replay it as one hipGraph (training/graphed.py).
+            # Events cannot be recorded inside a replayed graph, hence the eager pass above for the per-kernel durations.
+            from training.graphed import GraphedForward
+            fwd = GraphedForward(lambda w_: net(w_, noise_mode='const'), [ws], warmup=1)
+            for _ in range(args.warmup):
+                img = fwd(ws)
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                img = fwd(ws)
+            barrier()
+            elapsed = time.perf_counter() - t0
     assert torch.isfinite(img).all() and img.shape == (n, 3, 1024, 1024)
     elapsed = replicas.max_over_ranks(elapsed, device=dev)
     if rank != 0:
         return
     rows = [(geo, fl, e0.elapsed_time(e1) * 1e-3, by) for geo, fl, e0, e1, by in timeline]
+    execution = ('eager launches' if args.no_graph else
+                 f'one hipGraph replay per step (eager, with per-launch events: {1e3 * eager_elapsed / args.steps:.3f} ms/step)')
     dom = [r for r in rows if r[0][3] == 'mfma16']
     t_dom = sum(r[2] for r in dom)
     gbs = sum(r[3] for r in dom) / max(t_dom, 1e-12) / 1e9
@@ -217,14 +232,14 @@ def run_stack(args, rank, world, dev, dist):
                 vs_baseline=None, dtype='bf16', data='synthetic',
                 config=dict(workload=f'BASELINE config 5: StyleGAN2 block stack 8^2..1024^2 (SynthesisLayer x2 + ToRGB + skip upsample per resolution), '
                                      f'channel_base 32768, channel_max {args.channel_max}, all blocks bf16 (fp32 accumulate), eval, noise_mode=const, random-init weights',
-                            images_per_gpu_per_step=n, global_batch=n * world, parallelism=f'replicas x{world}'),
+                            images_per_gpu_per_step=n, global_batch=n * world, parallelism=f'replicas x{world}', execution=execution),
                 roofline=dict(bound='hbm', kernel='conv2d_mfma16<bf16,...> (channels-last implicit GEMM, v_mfma_f32_32x32x16_bf16; all its launches of a step)',
                               achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(gbs / HBM_PEAK_GBS, 4),
                               traffic=committed_traffic('cfg5')[0], traffic_source=committed_traffic('cfg5')[1],
                               algorithmic_bytes_per_launch=round(sum(r[3] for r in dom) / max(len(dom), 1)),
-                              bytes_counted='2 * (numel(x) + numel(y)) per launch (weights excluded)',
+                              bytes_counted='numel(x) + numel(y) + packed weights, in bytes, per launch',
                               mfma_tflops=round(tfl, 1), mfma_frac=round(tfl / BF16_MFMA_PEAK_TFLOPS, 4),
-                              launches_per_step=len(dom) // max(args.steps, 1), conv_time_frac_of_step=round(t_dom / elapsed, 4),
+                              launches_per_step=len(dom) // max(args.steps, 1), conv_time_frac_of_step=round(t_dom / elapsed, 4),   # its launches' event time / the timed region
                               top_res_gbs=round(sum(r[3] for r in top) / max(sum(r[2] for r in top), 1e-12) / 1e9, 1)))
     if world == 1 and not args.no_cpu_baseline:
         line['cpu_baseline'] = cpu_baseline_stack(args.channel_max)
@@ -296,6 +311,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=BATCH_PER_GPU, help='images per GPU per step (config 2: 8)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-graph', action='store_true', help='config 5: time eager launches instead of hipGraph replays')
     ap.add_argument('--conv-breakdown', default=None, metavar='CSV', help='also write the per-shape conv launch timeline of the timed steps')
     ap.add_argument('--mode', choices=['synthesis', 'generator', 'train', 'bf16_1024'], default='synthesis',
                     help="'synthesis' = the headline (config 2); 'generator' = config 3 (encoders + mapping + synthesis, N=16); 'train' = config 4 step; "

@@ -182,7 +182,8 @@ def conv2d_forward(x, packed, cout, kh, kw, stride=1, pad=(0, 0), out_hw=None, y
         if tl is not None:
             ev1.record()
             tl.append(((kh, kw, int(stride), 'mfma16', f'N{n} {cin}->{cout} {h}x{w} {str(x.dtype)[6:]}'), 2.0 * n * cout * oh * ow * cin * kh * kw, ev0, ev1,
-                       x.element_size() * (x.numel() + n * cout * oh * ow)))
+                       x.element_size() * (x.numel() + n * cout * oh * ow) + (y.element_size() - x.element_size()) * n * cout * oh * ow
+                       + packed.numel() * packed.element_size()))       # algorithmic bytes: x + y + the packed weights this launch reads
     nat.check(st, 'pg_conv2d16_forward')
     return y
 

@@ -194,32 +194,59 @@ def _modconv_fast16(x, weight, styles, noise, up, padding, resample_filter, demo
     cache = cache if cache is not None else _PackCache()
     ep = dict(epilogue) if epilogue else {}
     w32, s32 = weight.detach().float(), styles.detach().float()
-    dcoefs = conv2d_mfma.modconv_dcoefs(w32, s32) if demodulate else None
+    composite = False
+    if up == 2:
+        fw, fh = upfirdn2d._get_filter_size(resample_filter)
+        tpad, fir_pad = _up2_geometry(kh, kw, fw, fh, padding)
+        composite = ((kh, kw, fw, fh) == (3, 3, 4, 4) and tuple(tpad) == (0, 0) and list(fir_pad) == [1, 1, 1, 1] and resample_filter.ndim == 2
+                     and os.environ.get('PG_UP2_COMPOSITE', '1') != '0')
+    # Weight-dominated layers (the low-resolution blocks: N per-sample copies of a 512..1024-channel kernel outweigh the
+    # activations): the reference's NON-fused form (networks.py:73-84; its own choice for half precision at batch > 1,
+    # networks.py:2152-2154) -- x * styles, ONE shared weight pack cached across steps, demodulation as the epilogue's
+    # per-(n, cout) scale.  Styles are normalised per sample like networks.py:57-59 so that x * s stays in 16-bit range;
+    # the factor returns through dcoefs (computed from the normalised styles).
+    taps = 36 if composite else kh * kw
+    shared = (up == 1 or composite) and cout * taps > 2 * h * w and os.environ.get('PG_MODCONV16_SHARED', '1') != '0'
+    out_scale = None
+    if shared:
+        smax = s32.abs().amax(dim=1, keepdim=True).clamp_min(1e-20)
+        s32 = s32 / smax
+        x = x * s32.to(x.dtype)[:, :, None, None]
+        out_scale = conv2d_mfma.modconv_dcoefs(w32, s32) if demodulate else smax.expand(n, cout).contiguous()
+        dcoefs = None
+    else:
+        dcoefs = conv2d_mfma.modconv_dcoefs(w32, s32) if demodulate else None
     if up == 1:
         if not conv2d_mfma16.supported(kh, kw, 1):
             return None
+        if shared:
+            packed = cache.get(('shared', flip_weight, x.dtype), [weight], lambda: conv2d_mfma16.pack_weight(w32, x.dtype, flip=not flip_weight)[0])
+            return conv2d_mfma16.conv2d_forward(x, packed, cout, kh, kw, pad=(padding, padding), sample_stride=0, out_scale=out_scale, noise=noise, **ep)
         packed, per, _ = conv2d_mfma16.pack_weight(w32, x.dtype, flip=not flip_weight, styles=s32, dcoefs=dcoefs)
         return conv2d_mfma16.conv2d_forward(x, packed, cout, kh, kw, pad=(padding, padding), sample_stride=per, noise=noise, **ep)
-    fw, fh = upfirdn2d._get_filter_size(resample_filter)
-    tpad, fir_pad = _up2_geometry(kh, kw, fw, fh, padding)
     out_hw = ((h - 1) * 2 - 2 * tpad[0] + kh, (w - 1) * 2 - 2 * tpad[1] + kw)
 
     def transposed_weight():
         wt = w32.transpose(0, 1)
         return (wt.flip([2, 3]) if flip_weight else wt).contiguous()
-    if (kh, kw, fw, fh) == (3, 3, 4, 4) and tuple(tpad) == (0, 0) and list(fir_pad) == [1, 1, 1, 1] and resample_filter.ndim == 2 \
-            and os.environ.get('PG_UP2_COMPOSITE', '1') != '0':
+    if composite:
         phases = cache.get(('up2_composite', flip_weight), [weight], lambda: _up2_composite_phases(transposed_weight(), resample_filter.float()))
         y = torch.empty([n, cout, 2 * h, 2 * w], dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
         xcl = conv2d_mfma16.to_channels_last(x)
         res = ep.pop('residual', None)
+        if shared:
+            packs = cache.get(('up2_shared', flip_weight, x.dtype), [weight],
+                              lambda: {ab: conv2d_mfma16.pack_weight(wab, x.dtype, transpose_oi=True)[0] for ab, wab in phases.items()})
         for (a, b), wab in phases.items():
-            packed, per, _ = conv2d_mfma16.pack_weight(wab, x.dtype, transpose_oi=True, styles=s32, dcoefs=dcoefs)
+            if shared:
+                packed, per = packs[(a, b)], 0
+            else:
+                packed, per, _ = conv2d_mfma16.pack_weight(wab, x.dtype, transpose_oi=True, styles=s32, dcoefs=dcoefs)
             nz = None
             if noise is not None:       # the phase's samples of the output-resolution noise map
                 nz = noise.reshape(-1, 2 * h, 2 * w)[:, a::2, b::2].contiguous()
             conv2d_mfma16.conv2d_forward(xcl, packed, cout, 3, 3, pad=(1, 1), out_hw=(h, w), y=y, out_step=(2, 2), out_off=(a, b), sample_stride=per,
-                                         noise=nz, **ep)
+                                         out_scale=out_scale, noise=nz, **ep)
         return y if res is None else y.add_(res)
     phases = conv2d_mfma16.pack_transposed(transposed_weight(), x.dtype, 2, tpad, (h, w), out_hw, styles=s32, dcoefs=dcoefs)
     if phases is None:

@@ -285,3 +285,24 @@ def test_upfirdn2d_channels_last_kernel():
         ref = (torch.where(ref > 0, ref, ref * 0.2) * 1.4).clamp(-3, 3)
         assert fused is not None and fused.dtype == dtype
         assert float((fused.float() - ref).abs().max()) <= (1e-5 if dtype == torch.float32 else ULP[dtype] * 3.0 + 1e-5)
+
+
+@pytest.mark.gpu
+def test_graphed_forward_replays_the_stack():
+    """training/graphed.py: one hipGraph replay == the eager forward, bit for bit, also for inputs the graph was not captured with
+    (per-sample weight packing and demodulation are kernels of the graph, not baked constants)."""
+    from training import networks
+    from training.graphed import GraphedForward
+    from detgen import fill_module_
+    net = fill_module_(networks.SynthesisStack(w_dim=64, img_resolution=64, img_channels=3, channel_base=1024, channel_max=64, num_fp16_res=4,
+                                               half_dtype=torch.bfloat16, conv_clamp=256), 'graph.').to(DEV).eval()
+    gen = torch.Generator().manual_seed(5)
+    ws_a = torch.randn([2, net.num_ws, 64], generator=gen).to(DEV)
+    ws_b = torch.randn([2, net.num_ws, 64], generator=gen).to(DEV)
+    with torch.no_grad():
+        eager_a, eager_b = net(ws_a, noise_mode='const').clone(), net(ws_b, noise_mode='const').clone()
+    fwd = GraphedForward(lambda w_: net(w_, noise_mode='const'), [ws_a])
+    assert torch.equal(fwd(ws_a), eager_a)
+    assert torch.equal(fwd(ws_b), eager_b)
+    assert torch.equal(fwd(ws_a), eager_a)
+    assert not torch.equal(eager_a, eager_b)

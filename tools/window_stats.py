@@ -1,6 +1,6 @@
 """GPU box helper: kernel statistics of the TIMED region only.  rocprofv3's --stats covers the whole process -- for the training
 step that is dominated by MIOpen's one-off solver search during warm-up.  This reads the kernel trace, keeps the kernels that
-started in the last `steps * ms_per_step` milliseconds before the last kernel of the run, and writes a stats CSV in the
+started in the last `steps * ms_per_step` milliseconds before the end of the run's last convolution kernel, and writes a stats CSV in the
 --stats format.   python tools/window_stats.py <kernel_trace.csv> <bench log with the JSON line> <out.csv>"""
 import csv
 import json
@@ -15,8 +15,9 @@ def main(trace, log, out):
             line = json.loads(l)
     window_ns = line['steps'] * line['ms_per_step'] * 1e6
     rows = list(csv.DictReader(open(trace)))
-    t_end = max(int(r['End_Timestamp']) for r in rows)
-    keep = [r for r in rows if int(r['Start_Timestamp']) >= t_end - window_ns]
+    conv = [r for r in rows if 'conv2d_' in r['Kernel_Name']]              # the timed region ends with this package's last convolution
+    t_end = max(int(r['End_Timestamp']) for r in (conv or rows))           # (what follows are the bench's own finiteness checks)
+    keep = [r for r in rows if t_end - window_ns <= int(r['Start_Timestamp']) <= t_end]
     agg = {}
     for r in keep:
         d = int(r['End_Timestamp']) - int(r['Start_Timestamp'])

@@ -10,12 +10,12 @@
 //             K = N * OH * OW pixels, two adjacent pixels per MFMA (lanes 0-31 hold pixel 2j, lanes 32-63 pixel 2j+1).
 // Workgroup = 4 waves = 64 couts x 64 cins x all taps; a wave owns one 32 x 32 block for every tap (KH*KW accumulators).
 // The K axis is what gives parallelism: workgroup s of `splits` walks pixel chunks s, s + splits, ... (2 rows x 32 columns of one
-// image each), stages dy[64][64] and the x halo [64][2 + KH - 1][32 + KW - 1] in LDS (odd pitches: both operand reads are
-// conflict-free) and accumulates; its partial block goes to workspace[s][tap][co][ci] and a second pass adds the partials
-// in fixed order (deterministic, no atomics).
+// image each), stages dy[64][64] and the x halo [64][2 + KH - 1][32 + KW - 1] in LDS by LDS-DMA (odd pitches: both operand reads
+// are conflict-free; two buffers, the next chunk in flight behind the MFMAs) and accumulates; its partial block goes to
+// workspace[s][tap][co][ci] and a second pass adds the partials in fixed order (deterministic, no atomics).
 //
 // Roofline: MFMA.  Algorithmic FLOPs = 2 * N * OH * OW * Cout * Cin * KH * KW (the forward pass's count) against 157.3 TFLOP/s.
-#include "pg_common.h"
+#include "conv2d_kernel.h"        // LDS-DMA helpers (dma_dword, lds_offset)
 
 namespace {
 
@@ -32,7 +32,7 @@ struct WGeo {
     static constexpr int IH = WG_R + KH - 1, IW = WG_TW + KW - 1;
     static constexpr int PA = WG_PIX + 1;                               // dy row pitch (odd)
     static constexpr int PB = (IH * IW) | 1;                            // x plane pitch (odd)
-    static constexpr int LDS_FLOATS = WG_BM * PA + WG_BN * PB;
+    static constexpr int LDS_FLOATS = 2 * ((WG_BM * PA + 255) / 256 + (WG_BN * PB + 255) / 256) * 256;   // two staging buffers of whole 256-lane DMA rows
 };
 
 struct WgradParams {
@@ -41,19 +41,45 @@ struct WgradParams {
     int tilesX, tilesY, chunks, splits, coB, ciB;
 };
 
+constexpr unsigned WG_SENTINEL = 0x80000000u;     // byte offset beyond any descriptor range: the DMA writes 0.0f
+
+// Staging: both tiles travel global -> LDS by 4-byte LDS-DMA (`buffer_load_dword ... lds`, conv2d_kernel.h), lane-linear, so the
+// LDS image of a tile is its flat element order and the gather sits in the per-lane source offset.  The offsets relative to the
+// chunk origin are kernel-lifetime registers; a chunk whose footprint lies inside the image just adds its origin (in the
+// descriptor base) -- no per-element arithmetic; border chunks mask their out-of-image elements to a sentinel offset.  Two
+// staging buffers: chunk g + 1 is in flight while chunk g is multiplied, one barrier per chunk.  One workgroup per CU (the
+// 9 x 16 accumulators + 52 gather offsets per lane need the 512-register budget of a single wave per SIMD).
 template <int KH, int KW>
-__global__ __launch_bounds__(256, 2) void conv2d_wgrad(WgradParams p) {
+__global__ __launch_bounds__(256, 1) void conv2d_wgrad(WgradParams p) {
     typedef WGeo<KH, KW> G;
+    constexpr int NDY = (WG_BM * G::PA + 255) / 256, NX = (WG_BN * G::PB + 255) / 256;
     extern __shared__ float smem[];
-    float* dyt = smem;                          // [64 co][PA]
-    float* xt = smem + WG_BM * G::PA;           // [64 ci][PB]
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    constexpr int BUF = (NDY + NX) * 256;       // floats per staging buffer: dy [64 co][PA] then x [64 ci][PB], whole DMA rows
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int half = lane >> 5, l31 = lane & 31;
     const int mt = wave & 1, nt = wave >> 1;
     int b = blockIdx.x;
     const int s = b % p.splits; b /= p.splits;
     const int cib = b % p.ciB, cob = b / p.ciB;
     const int co0 = cob * WG_BM, ci0 = cib * WG_BN;
+    const int OHW = p.OH * p.OW, HW = p.H * p.W;
+    const unsigned smem_b = __builtin_amdgcn_readfirstlane(pgconv::lds_offset(smem));
+
+    // per-thread gather maps (bytes from the chunk origin); statically invalid elements (pitch padding, channels beyond the tensor) = sentinel
+    unsigned rel_dy[NDY], rel_x[NX];
+#pragma unroll
+    for (int i = 0; i < NDY; i++) {
+        const int f = t + 256 * i, co = f / G::PA, px = f % G::PA;
+        const bool ok = co < WG_BM && px < WG_PIX && co0 + co < p.Cout;
+        rel_dy[i] = ok ? (unsigned)(co * OHW + (px / WG_TW) * p.OW + px % WG_TW) * 4u : WG_SENTINEL;
+    }
+#pragma unroll
+    for (int i = 0; i < NX; i++) {
+        const int f = t + 256 * i, ci = f / G::PB, rr = f % G::PB;
+        const bool ok = ci < WG_BN && rr < G::IH * G::IW && ci0 + ci < p.Cin;
+        rel_x[i] = ok ? (unsigned)(ci * HW + (rr / G::IW) * p.W + rr % G::IW) * 4u : WG_SENTINEL;
+    }
 
     f32x16 acc[G::T];
 #pragma unroll
@@ -61,42 +87,81 @@ __global__ __launch_bounds__(256, 2) void conv2d_wgrad(WgradParams p) {
 #pragma unroll
         for (int k = 0; k < 16; k++) acc[tp][k] = 0.f;
 
-    for (int ch = s; ch < p.chunks; ch += p.splits) {
+    auto issue = [&](int ch, int buf) __attribute__((always_inline)) {
         int c = ch;
         const int tx = c % p.tilesX; c /= p.tilesX;
         const int ty = c % p.tilesY;
         const int n = c / p.tilesY;
         const int oy0 = ty * WG_R, ox0 = tx * WG_TW;
-        __syncthreads();                         // previous chunk's reads are done
-        // dy tile: 64 couts x (2 rows x 32 columns); a wave-iteration loads one cout's two 128-byte row segments
-        for (int e = t; e < WG_BM * WG_PIX; e += 256) {
-            const int co = e / WG_PIX, px = e % WG_PIX;
-            const int oy = oy0 + px / WG_TW, ox = ox0 + px % WG_TW;
-            const bool ok = co0 + co < p.Cout && oy < p.OH && ox < p.OW;
-            dyt[co * G::PA + px] = ok ? p.dy[(((int64_t)n * p.Cout + co0 + co) * p.OH + oy) * p.OW + ox] : 0.f;
+        const int iy0 = oy0 - p.pad_y, ix0 = ox0 - p.pad_x;
+        // descriptors based at the chunk origin (the x origin may lie before the tensor: such elements are masked below)
+        const uint64_t dyb = (uint64_t)(uintptr_t)(p.dy + ((int64_t)n * p.Cout + co0) * OHW + (int64_t)oy0 * p.OW + ox0);
+        const uint64_t xb = (uint64_t)(uintptr_t)(p.x + ((int64_t)n * p.Cin + ci0) * HW) + ((int64_t)iy0 * p.W + ix0) * 4;
+        pgconv::i32x4 rdy, rx;
+        rdy[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)dyb); rdy[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(dyb >> 32) & 0xffff);
+        rdy[2] = 0x7ffffffe; rdy[3] = 0x00020000;
+        rx[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)xb); rx[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(xb >> 32) & 0xffff);
+        rx[2] = 0x7ffffffe; rx[3] = 0x00020000;
+        const bool inner_dy = oy0 + WG_R <= p.OH && ox0 + WG_TW <= p.OW;                                       // wave-uniform
+        const bool inner_x = iy0 >= 0 && iy0 + G::IH <= p.H && ix0 >= 0 && ix0 + G::IW <= p.W;
+        const unsigned base_b = smem_b + (unsigned)(buf * BUF + 64 * wave) * 4u;
+#pragma unroll
+        for (int i = 0; i < NDY; i++) {
+            unsigned v = rel_dy[i];
+            if (!inner_dy) {
+                const int px = (t + 256 * i) % G::PA;
+                if (oy0 + px / WG_TW >= p.OH || ox0 + px % WG_TW >= p.OW) v = WG_SENTINEL;
+            }
+            pgconv::dma_dword(rdy, base_b + (unsigned)(256 * i) * 4u, v, 0);
         }
-        // x halo tile: 64 cins x IH x IW, zero outside the image / beyond Cin
-        for (int e = t; e < WG_BN * G::IH * G::IW; e += 256) {
-            const int ci = e / (G::IH * G::IW), r = e % (G::IH * G::IW);
-            const int iy = oy0 - p.pad_y + r / G::IW, ix = ox0 - p.pad_x + r % G::IW;
-            const bool ok = ci0 + ci < p.Cin && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-            xt[ci * G::PB + r] = ok ? p.x[(((int64_t)n * p.Cin + ci0 + ci) * p.H + iy) * p.W + ix] : 0.f;
+#pragma unroll
+        for (int i = 0; i < NX; i++) {
+            unsigned v = rel_x[i];
+            if (!inner_x) {
+                const int rr = (t + 256 * i) % G::PB;
+                const int iy = iy0 + rr / G::IW, ix = ix0 + rr % G::IW;
+                if (iy < 0 || iy >= p.H || ix < 0 || ix >= p.W) v = WG_SENTINEL;
+            }
+            pgconv::dma_dword(rx, base_b + (unsigned)(NDY * 256 + 256 * i) * 4u, v, 0);
         }
-        __syncthreads();
+    };
+
+    int ch = s, g = 0;
+    if (ch < p.chunks) issue(ch, 0);
+    pgconv::dma_wait_all();
+    __syncthreads();
+    for (; ch < p.chunks; ch += p.splits, g++) {
+        const int buf = g & 1;
+        if (ch + p.splits < p.chunks) issue(ch + p.splits, buf ^ 1);       // that buffer was last read one iteration ago (barrier below)
+        const float* dyt = smem + buf * BUF;
+        const float* xt = dyt + NDY * 256;
         const float* a_base = dyt + (mt * 32 + l31) * G::PA + half;
         const float* b_base = xt + (nt * 32 + l31) * G::PB + half;
-#pragma unroll 4
-        for (int kk = 0; kk < WG_PIX / 2; kk++) {                       // two adjacent pixels per step
+        // One wave per SIMD: nothing hides an LDS round trip but the wave's own MFMAs, so the operands of step kk + 1 are
+        // requested before the MFMAs of step kk are issued (register double buffering, order pinned by sched_barrier).
+        auto fetch = [&](int kk, float& a, float (&bv)[G::T]) __attribute__((always_inline)) {
             const int r = (2 * kk) / WG_TW, cc = (2 * kk) % WG_TW;
-            const float a = a_base[2 * kk];
-            float bv[G::T];
+            a = a_base[2 * kk];
 #pragma unroll
             for (int ky = 0; ky < KH; ky++)
 #pragma unroll
                 for (int kx = 0; kx < KW; kx++) bv[ky * KW + kx] = b_base[(r + ky) * G::IW + cc + kx];
+        };
+        float a_cur, b_cur[G::T], a_nxt, b_nxt[G::T];
+        fetch(0, a_cur, b_cur);
+#pragma unroll 2
+        for (int kk = 0; kk < WG_PIX / 2; kk++) {                       // two adjacent pixels per step
+            if (kk + 1 < WG_PIX / 2) fetch(kk + 1, a_nxt, b_nxt);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int tp = 0; tp < G::T; tp++) acc[tp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[tp], acc[tp], 0, 0, 0);
+            for (int tp = 0; tp < G::T; tp++) acc[tp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, b_cur[tp], acc[tp], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            a_cur = a_nxt;
+#pragma unroll
+            for (int tp = 0; tp < G::T; tp++) b_cur[tp] = b_nxt[tp];
         }
+        pgconv::dma_wait_all();                  // the chunk requested above has landed
+        __syncthreads();
     }
     // partial block -> workspace[s][tap][co][ci]: D col = lane & 31 = ci (contiguous), row = (reg & 3) + 8 * (reg >> 2) + 4 * half = co
     float* wsp = p.ws + (int64_t)s * G::T * p.Cout * p.Cin;
@@ -131,7 +196,7 @@ PG_EXPORT int pg_conv2d_wgrad_plan(int N, int Cin, int OH, int OW, int Cout, int
     if (!((KH == 3 && KW == 3) || (KH == 1 && KW == 1))) return 0;
     const int64_t chunks = (int64_t)N * cdiv(OH, WG_R) * cdiv(OW, WG_TW);
     const int blocks = cdiv(Cout, WG_BM) * cdiv(Cin, WG_BN);
-    int64_t s = (2LL * pg::num_cu() + blocks - 1) / blocks;             // ~2 workgroups per CU
+    int64_t s = ((int64_t)pg::num_cu() + blocks - 1) / blocks;            // one (persistent-for-its-share) workgroup per CU
     if (s > chunks) s = chunks;
     if (s < 1) s = 1;
     if (s > 4096) s = 4096;
@@ -163,6 +228,9 @@ PG_EXPORT int pg_conv2d_wgrad(const float* x, const float* dy, float* dw, float*
         hipLaunchKernelGGL((conv2d_wgrad<3, 3>), dim3((unsigned)blocks), dim3(256), lds, s, p);
     } else {
         const size_t lds = WGeo<1, 1>::LDS_FLOATS * sizeof(float);
+        static pg::PerDeviceOnce attr1;
+        const hipError_t e = attr1.run([] { return hipFuncSetAttribute((const void*)conv2d_wgrad<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+        if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL((conv2d_wgrad<1, 1>), dim3((unsigned)blocks), dim3(256), lds, s, p);
     }
     int st = pg::launch_status();

@@ -341,7 +341,7 @@ static int conv_forward(bool winograd, const float* x, const float* packed_w, fl
         if (ext > 0x7fffffffLL || (int64_t)N * OH * OW > 0x7fffffffLL) return PG_ERR_TOO_LARGE;
     }
     ConvParams p;
-    p.ksplit = 1; p.kpart = 0; p.ws_slice = 0;
+    p.ksplit = 1; p.kpart = 0; p.ws_slice = 0; p.wino_gmap = 0;
     p.x = x; p.wp = packed_w; p.y = y;
     p.N = N; p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout; p.CoutP = round_up(Cout, 32); p.OH = OH; p.OW = OW;
     p.pad_y = pad_y; p.pad_x = pad_x;

@@ -47,6 +47,7 @@ struct ConvParams {
     int in_xform;          // prologue bias/act/gain/clamp stage on
     int ksplit, kpart;     // split-K: `ksplit` workgroups share one output tile, each reducing `kpart` input channels into its own
     int64_t ws_slice;      // slice (ws_slice floats apart) of the partial-sum workspace that y then points to; 1 = off
+    int wino_gmap;         // Winograd: interior tiles take the tile-independent gather map from LDS (0 = off: A/B switch PG_WINO_GMAP=0)
     pg_conv2d_fusion f;
 };
 

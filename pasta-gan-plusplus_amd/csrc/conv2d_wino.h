@@ -30,6 +30,7 @@
 // Numerics: exact fp32 products/sums (same MFMA), different summation order; measured max error ~2e-6 of the output
 // scale, the same level as the direct kernel (tests/test_hip_parity.py::test_conv2d_winograd_*).
 #pragma once
+#include <cstdlib>
 #include "conv2d_kernel.h"
 
 #ifndef WINO_PK
@@ -75,6 +76,7 @@ __global__ __launch_bounds__(512, 4) void conv2d_wino(ConvParams p) {
     float* ex0 = smem + 2 * W_BUFS;              // inverse-transform exchange, double buffered [2][W_EXCH]
     float* cs0 = ex0 + 2 * W_EXCH;               // prologue scale of two consecutive tiles [2][cin_loop]
     float* ep0 = cs0 + 2 * cin_loop;             // epilogue scale / bias of two consecutive tiles [2][64 + 64]
+    unsigned* gm0 = (unsigned*)(ep0 + 256);      // VEC: the gather map of an interior tile, [NDMA][256 issuing threads] byte offsets
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -99,6 +101,21 @@ __global__ __launch_bounds__(512, 4) void conv2d_wino(ConvParams p) {
     unsigned xoff[NDMA];
     i32x4 xrsrc;
 
+    // Gather map of a tile whose halo lies inside the image, relative to the tile's first halo sample: it does not depend on
+    // the tile, so it is computed once (the per-tile version costs every issuing wave ~150 VALU instructions -- matrix-pipe
+    // time -- per tile) and kept in LDS; interior tiles read it back and move the tile origin into the descriptor base.
+    if (VEC && wave < 4) {
+#pragma unroll
+        for (int i = 0; i < NDMA; i++) {
+            const bool wide = i < 4;
+            const int f = wide ? 4 * (t + 256 * i) : 4096 + t + 256 * (i - 4);
+            const int c = f / W_CHF, rem = f % W_CHF;
+            const int rl = rem / W_LROW, lc = rem % W_LROW;
+            const int hr = rl == 1 ? 2 : (rl == 2 ? 1 : rl);
+            gm0[i * 256 + t] = (unsigned)(c * HW + hr * p.W + lc) * 4u;
+        }
+    }                                            // (visible to its own thread only: no barrier needed)
+
     auto prep_tile = [&](int tile, float* cs) {
         const int xcd = tile & 7;
         int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (tile >> 3);
@@ -112,8 +129,15 @@ __global__ __launch_bounds__(512, 4) void conv2d_wino(ConvParams p) {
             for (int c = t; c < cin_loop; c += 512) cs[c] = ((in_scale && c < p.Cin) ? ld_opaque(in_scale + c) : 1.f) * p.f.in_gain;     // host: in_gain defaults to 1
         int tt = t;
         asm volatile("" : "+v"(tt));                 // keep the index maths inside the tile loop (see conv2d_kernel.h)
+        const int gy0 = oy0 - p.pad_y, gx0 = ox0 - 4;
+        const bool interior = VEC && p.wino_gmap && gy0 >= 0 && gy0 + 4 <= p.H && gx0 >= 0 && gx0 + W_LROW <= p.W;      // wave-uniform
         // gather map: element f of the buffer = (channel f / 288, LDS row (f % 288) / 72, LDS column f % 72)
-        if (!VEC || wave < 4) {
+        if (interior) {
+            if (wave < 4) {
+#pragma unroll
+                for (int i = 0; i < NDMA; i++) xoff[i] = gm0[i * 256 + tt];
+            }
+        } else if (!VEC || wave < 4) {
 #pragma unroll
             for (int i = 0; i < NDMA; i++) {
                 const bool wide = VEC && i < 4;      // VEC: four 16-byte requests (floats 4e .. 4e+3, e < 1024) + two dwords (floats 4096 ..)
@@ -126,10 +150,11 @@ __global__ __launch_bounds__(512, 4) void conv2d_wino(ConvParams p) {
                 xoff[i] = ok ? (unsigned)(c * HW + gy * p.W + gx) * 4u : 0x80000000u;
             }
         }
-        const uint64_t base = (uint64_t)(uintptr_t)(p.x + (int64_t)n * p.Cin * HW);
+        const int shift = interior ? (gy0 * p.W + gx0) * 4 : 0;        // interior: offsets are relative to the tile's first halo sample
+        const uint64_t base = (uint64_t)(uintptr_t)(p.x + (int64_t)n * p.Cin * HW) + (uint64_t)(int64_t)shift;
         xrsrc[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)base);
         xrsrc[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(base >> 32) & 0xffff);
-        xrsrc[2] = p.Cin * HW * 4;
+        xrsrc[2] = p.Cin * HW * 4 - shift;                               // same absolute end: channels beyond Cin still read as zero
         xrsrc[3] = 0x00020000;
     };
 
@@ -483,6 +508,7 @@ __global__ __launch_bounds__(512, 4) void conv2d_wino(ConvParams p) {
 template <int MODE, bool VEC>
 int launch_wino_xf(const ConvParams& p0, hipStream_t s) {
     ConvParams p = p0;
+    { static const int gmap = [] { const char* e = getenv("PG_WINO_GMAP"); return e ? atoi(e) : 1; }(); p.wino_gmap = gmap; }
     p.tilesX = (p.OW + 63) / 64;
     p.tilesY = (p.OH + 1) / 2;
     p.mblocks = p.CoutP / 64;
@@ -490,7 +516,7 @@ int launch_wino_xf(const ConvParams& p0, hipStream_t s) {
     if (tiles > 0x7fffffffLL) return PG_ERR_TOO_LARGE;
     p.total_tiles = (int)tiles;
     const int cin_loop = ((p.Cin + W_KC - 1) / W_KC) * W_KC;
-    const size_t lds = ((size_t)2 * W_BUFS + 2 * W_EXCH + 2 * cin_loop + 256) * sizeof(float);
+    const size_t lds = ((size_t)2 * W_BUFS + 2 * W_EXCH + 2 * cin_loop + 256 + (VEC ? 6 * 256 : 0)) * sizeof(float);
     if ((int64_t)16 * cin_loop * p.CoutP * 4 > 0x7fffffffLL) return PG_ERR_TOO_LARGE;      // the U stream uses 32-bit byte offsets
     if (lds > 160 * 1024) return PG_ERR_UNSUPPORTED;
     int per_cu = (int)((160 * 1024) / lds);

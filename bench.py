@@ -269,6 +269,7 @@ def run_train(args, rank, world, dev, dist):
     G = networks.GeneratorFull_v20(z_dim=0, c_dim=512, w_dim=512, img_resolution=512, img_channels=3, mapping_kwargs=dict(num_layers=1),
                                    synthesis_kwargs=dict(channel_base=32768, channel_max=512, conv_clamp=256)).to(dev).train()
     dkw = dict(c_dim=512, img_resolution=512, channel_base=32768, channel_max=512, conv_clamp=256, epilogue_kwargs=dict(mbstd_group_size=4))
+    dkw['num_fp16_res'] = args.d_fp16_res                      # train.py:196: fp16 for the 3 highest resolutions of both discriminators
     D = networks.Discriminator(img_channels=6, **dkw).to(dev).train()
     DP = networks.Discriminator(img_channels=10, **dkw).to(dev).train()
     ddp.broadcast_parameters([G, D, DP])
@@ -299,7 +300,7 @@ def run_train(args, rank, world, dev, dist):
         print(json.dumps(dict(metric='fullbody G+D training iterations/sec (8-phase step incl. lazy R1)', value=round(args.steps / elapsed, 4), unit='it/s',
                               n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(1e3 * elapsed / args.steps, 1), higher_is_better=True,
                               scaling='weak', vs_baseline=None, dtype='f32', data='synthetic', images_per_sec=round(args.steps * n * world / elapsed, 3),
-                              config=dict(workload='BASELINE config 4: fullbody G+D step, lazy R1 (gamma 10), L1 + parsing CE, no VGG; D in fp32',
+                              config=dict(workload='BASELINE config 4: fullbody G+D step, lazy R1 (gamma 10), L1 + parsing CE, no VGG; ' + (f'discriminators fp16 at their {args.d_fp16_res} highest resolutions (train.py:196)' if args.d_fp16_res else 'discriminators in fp32'),
                                           batch_per_gpu=n, global_batch=n * world, parallelism=f'dp{world} flat-bucket reduce_scatter+all_gather (RCCL)',
                                           first_batch_idx=0, note='steps start at batch_idx = warmup; reg phases fire every 4th (G) / 16th (D) iteration'))), flush=True)
 
@@ -312,6 +313,7 @@ def main():
     ap.add_argument('--batch', type=int, default=BATCH_PER_GPU, help='images per GPU per step (config 2: 8)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='config 5: time eager launches instead of hipGraph replays')
+    ap.add_argument('--d-fp16-res', type=int, default=3, help='config 4: discriminator resolutions in fp16 (train.py:196: 3; 0 = fp32)')
     ap.add_argument('--conv-breakdown', default=None, metavar='CSV', help='also write the per-shape conv launch timeline of the timed steps')
     ap.add_argument('--mode', choices=['synthesis', 'generator', 'train', 'bf16_1024'], default='synthesis',
                     help="'synthesis' = the headline (config 2); 'generator' = config 3 (encoders + mapping + synthesis, N=16); 'train' = config 4 step; "

@@ -66,8 +66,25 @@ def _native16_ok(x, w, stride, dilation, groups):
             and stride[0] == stride[1] and x.numel() > 0 and w.numel() > 0)
 
 
+def _by_group(fn, input, weight, bias, groups, out_axis, **kw):
+    """A grouped convolution as `groups` ordinary ones on channel slices (the reference's fused modulated convolution:
+    batch folded into the channel axis with groups = N, networks.py:85-94 / conv2d_resample.py:127-131) -- each slice runs on
+    the MFMA kernels and is differentiable like any other call."""
+    cin_g = input.shape[1] // groups
+    w_g = weight.shape[0] // groups
+    outs = []
+    for g in range(groups):
+        wg = weight[g * w_g:(g + 1) * w_g]
+        ng = wg.shape[out_axis]
+        bg = bias[g * ng:(g + 1) * ng] if bias is not None else None
+        outs.append(fn(input[:, g * cin_g:(g + 1) * cin_g], wg, bg, groups=1, **kw))
+    return torch.cat(outs, dim=1)
+
+
 def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1):
     assert isinstance(input, torch.Tensor)
+    if enabled and input.is_cuda and 1 < groups <= 64 and input.ndim == 4 and input.shape[1] % groups == 0 and weight.shape[0] % groups == 0:
+        return _by_group(conv2d, input, weight, bias, groups, 0, stride=stride, padding=padding, dilation=dilation)
     stride, padding, dilation = _pair(stride), _pair(padding), _pair(dilation)
     kh, kw = int(weight.shape[2]), int(weight.shape[3])
     if enabled and input.is_cuda and min(padding) >= 0:
@@ -85,6 +102,8 @@ def _phases_supported(mod, kh, kw, s):
 
 def conv_transpose2d(input, weight, bias=None, stride=1, padding=0, output_padding=0, groups=1, dilation=1):
     assert isinstance(input, torch.Tensor)
+    if enabled and input.is_cuda and 1 < groups <= 64 and input.ndim == 4 and input.shape[1] % groups == 0 and weight.shape[0] % groups == 0:
+        return _by_group(conv_transpose2d, input, weight, bias, groups, 1, stride=stride, padding=padding, output_padding=output_padding, dilation=dilation)
     stride, padding, dilation, output_padding = _pair(stride), _pair(padding), _pair(dilation), _pair(output_padding)
     kh, kw = int(weight.shape[2]), int(weight.shape[3])
     if enabled and input.is_cuda:

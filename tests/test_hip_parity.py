@@ -785,9 +785,12 @@ def test_training_phase_gradients_vs_oracle(phase):
     assert any(v > 0 for v in got.values())
 
 
-def test_full_width_training_iteration_smoke():
+@pytest.mark.parametrize('d_fp16_res', [0, 3])
+def test_full_width_training_iteration_smoke(d_fp16_res):
     """One iteration of the 8-phase schedule (all phases due) with the full-width generator and both discriminators at
-    N=2 on one GPU: finite gradients, every module updated, EMA tracking; exercises GradBucket's single-rank path."""
+    N=2 on one GPU: finite gradients, every module updated, EMA tracking; exercises GradBucket's single-rank path.
+    d_fp16_res = 3 is the reference's training configuration (train.py:196: the discriminators' 3 highest resolutions in fp16,
+    i.e. forward, input gradients and the R1 double backward of those blocks on the 16-bit MFMA kernel)."""
     import time
     from training import networks as PN
     from training.loss import StyleGAN2Loss
@@ -795,7 +798,8 @@ def test_full_width_training_iteration_smoke():
     torch.manual_seed(0)
     G = PN.GeneratorFull_v20(z_dim=0, c_dim=512, w_dim=512, img_resolution=512, img_channels=3, mapping_kwargs=dict(num_layers=1),
                              synthesis_kwargs=dict(channel_base=32768, channel_max=512, conv_clamp=256)).to(DEV).train()
-    dkw = dict(c_dim=512, img_resolution=512, channel_base=32768, channel_max=512, conv_clamp=256, epilogue_kwargs=dict(mbstd_group_size=2))
+    dkw = dict(c_dim=512, img_resolution=512, channel_base=32768, channel_max=512, conv_clamp=256, epilogue_kwargs=dict(mbstd_group_size=2),
+               num_fp16_res=d_fp16_res)
     D, DP = PN.Discriminator(img_channels=6, **dkw).to(DEV).train(), PN.Discriminator(img_channels=10, **dkw).to(DEV).train()
     with torch.no_grad():
         for m in (G, D, DP):

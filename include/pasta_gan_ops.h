@@ -200,6 +200,18 @@ int pg_conv2d_winograd_forward(const float* x, const float* packed_u, float* y,
 int pg_modconv_dcoefs(const float* w, const float* styles, float* dcoefs,
                       int N, int Cout, int Cin, int KHW, float scale, void* stream);
 
+/* Stride-2 transposed 3x3 convolution, all four output parities in one launch (csrc/conv2d_up2.h) -- the `up = 2` layers:
+ * conv2d_gradfix.conv_transpose2d(stride=2, padding=0) behind conv2d_resample.py:125-142, with the modulation / demodulation of
+ * networks.py:73-94 around it:
+ *   y[n, co, 2 iy + ky, 2 ix + kx] += x[n, ci, iy, ix] * in_scale[n, ci] * w[co, ci, ky, kx];   y *= out_scale[n, co]
+ * `packed` = pg_conv2d_pack_weight of the OIHW 3x3 kernel w.  y is [N, Cout, 2H+1, 2W+1] with strides `ystride` (elements; an even row
+ * pitch gives 8-byte stores).  Written: every row, columns 0 .. 2W-1.  The last column (ox = 2W) is the 1-D convolution
+ * y[.., 2q + a, 2W] = sum_ky w[.., ky, 2] x[.., iy, W-1] of the input's last column, which the caller runs through pg_conv2d_forward
+ * (1x2 and 1x1 kernels on that column laid out as a row: torch_utils/ops/conv2d_mfma.py, conv_up2_forward).  in_scale / out_scale may
+ * be NULL. */
+int pg_conv2d_up2_forward(const float* x, const float* packed, float* y, int N, int Cin, int H, int W, int Cout,
+                          const int64_t ystride[4], const float* in_scale, const float* out_scale, void* stream);
+
 /* Streaming 1x1 convolution with few output channels (Cout <= 8; the ToRGB / parsing heads, networks.py:287-316,
  * modulated_conv2d with demodulate=False at networks.py:37-94): float32 NCHW, HW % 4 == 0, 16-byte aligned tensors:
  *   y[n,o,p] = clamp(sum_c x[n,c,p] * w[o,c] * scale * styles[n,c] + bias[o]) + skip[n,o,p]

@@ -1,0 +1,20 @@
+// Fused four-parity stride-2 transposed 3x3 convolution: instantiation + C ABI (own translation unit: see conv2d_kernel.h on build time).
+#include "conv2d_up2.h"
+
+/* y[n, co, 2 iy + ky, 2 ix + kx] += x[n, ci, iy, ix] * in_scale[n, ci] * w[co, ci, ky, kx], then * out_scale[n, co]:
+ * conv_transpose2d(stride 2, padding 0) of a 3x3 kernel (conv2d_gradfix.py:46-53 behind conv2d_resample.py:125-142) with the
+ * modulation / demodulation of networks.py:73-94 around it.  `packed` = pg_conv2d_pack_weight of the OIHW kernel w (3x3).
+ * y is [N, Cout, 2H+1, 2W+1] with strides ystride (elements); an even row pitch gives 8-byte stores.  Written: every row, columns
+ * 0 .. 2W-1; the last column (ox = 2W) is y[.., 2q + a, 2W] = sum_ky w[.., ky, 2] x[.., iy, W-1] -- a 1-D convolution of the input's
+ * last column that the caller runs through pg_conv2d_forward (torch_utils/ops/conv2d_mfma.py: conv_up2_forward). */
+PG_EXPORT int pg_conv2d_up2_forward(const float* x, const float* packed, float* y, int N, int Cin, int H, int W, int Cout,
+                                    const int64_t ystride[4], const float* in_scale, const float* out_scale, void* stream) {
+    if (!x || !packed || !y || !ystride || N <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return PG_ERR_INVALID_ARG;
+    if ((((uintptr_t)x) & 3) != 0 || (((uintptr_t)packed) & 15) != 0) return PG_ERR_INVALID_ARG;
+    if ((int64_t)Cin * H * W * 4 > 0x7fffffffLL) return PG_ERR_TOO_LARGE;             // one image through a 32-bit buffer descriptor
+    pgconv::Up2Params p;
+    p.x = x; p.wp = packed; p.y = y; p.in_scale = in_scale; p.out_scale = out_scale;
+    p.N = N; p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout; p.CoutP = (Cout + 31) / 32 * 32;
+    for (int i = 0; i < 4; i++) p.ys[i] = ystride[i];
+    return pgconv::launch_up2(p, (hipStream_t)stream);
+}

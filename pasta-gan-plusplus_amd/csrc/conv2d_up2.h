@@ -1,0 +1,252 @@
+// Stride-2 transposed 3x3 convolution for gfx950, all four output parities in ONE pass over the input, on
+// v_mfma_f32_32x32x2_f32 -- the `up = 2` SynthesisLayer of the generator (reference: conv2d_resample.py:125-142 ->
+// conv2d_gradfix.conv_transpose2d(stride=2), networks.py:73-94 for the modulation around it).
+//
+//     y[n, co, 2 iy + ky, 2 ix + kx] += x[n, ci, iy, ix] * w[co, ci, ky, kx]            (conv_transpose2d, padding 0)
+// Gather form per output parity (a, b) at position (q, r):  y[2q + a, 2r + b] = sum over the taps with ky = a (mod 2), kx = b (mod 2):
+//     a = 0: (ky 0, iy q), (ky 2, iy q - 1)    a = 1: (ky 1, iy q)      -- same for b / kx / ix / r
+// i.e. 4 + 2 + 2 + 1 = 9 tap-products per position, no multiply spent on stuffed zeros, no scatter.
+//
+// conv2d_kernel.h runs this as four launches (2x2, 2x1, 1x2 and 1x1 taps); the three small ones are bound by the per-chunk
+// structure (halo staging, barrier, operand reads), not by their MFMAs, and every launch re-reads the whole input.  Here a
+// workgroup stages the halo of an 8 x 32 block of positions ONCE per K chunk and issues the 9 tap-products of all four parities
+// from it: 18 MFMAs per channel pair and wave (2 position rows) behind 9 weight + 6 input operand reads.
+//   * workgroup = 4 waves, 32 couts (one M-tile) x 8 x 32 positions; a wave owns 2 position rows x 4 parities = 8 accumulators
+//     (128 VGPRs) -> 2 waves / SIMD; operands of channel pair cp + 1 are requested before the MFMAs of pair cp are issued;
+//   * staging, persistent XCD-aware tile stream, double buffering, zero padding through the buffer range check: as conv2d_kernel.h;
+//   * weights: the plain 3x3 pack of pg_conv2d_pack_weight ([Cin][9][CoutP]), tap = 3 ky + kx;
+//   * epilogue: * out_scale[n, co] (demodulation); a lane holds both x-parities of a position, i.e. two ADJACENT output pixels:
+//     8-byte stores when the output row pitch is even (the host allocates the (2H+1) x (2W+1) result with a padded pitch);
+//   * the tiles cover the positions q <= H, r < W, i.e. every output row and the columns 0 .. 2W-1: a 33rd position column would
+//     cost a whole extra 32-wide tile column (half of all tiles at W = 32).  The last output column (ox = 2W: tap column kx = 2 of
+//     the input column W - 1) is a thin 1-D convolution the host runs through pg_conv2d_forward on that column laid out as a row.
+// Roofline: MFMA; algorithmic FLOPs 2 * N * Cout * Cin * 9 * H * W (+ the one-position border).
+#pragma once
+#include "conv2d_kernel.h"
+
+namespace pgconv {
+
+typedef float f32x2s __attribute__((ext_vector_type(2)));
+
+constexpr int U_TQ = 8, U_TR = 32, U_BM = 32, U_KC = 8;
+constexpr int U_IH = U_TQ + 1, U_IW = U_TR + 1, U_PLANE = U_IH * U_IW;      // halo: rows q0-1 .. q0+7, cols r0-1 .. r0+31
+constexpr int U_NX = U_KC * U_PLANE, U_XPT = (U_NX + 255) / 256;
+constexpr int U_NW4 = U_KC * 9 * U_BM / 4, U_WPT = (U_NW4 + 255) / 256;
+constexpr int U_LDS_X = U_XPT * 256, U_LDS_W = U_WPT * 256 * 4, U_LDS_BUF = U_LDS_X + U_LDS_W;
+
+struct Up2Params {
+    const float* x; const float* wp; float* y;
+    const float* in_scale; const float* out_scale;
+    int N, Cin, H, W, Cout, CoutP;
+    int64_t ys[4];
+    int tilesX, tilesY, mblocks, total_tiles;
+};
+
+template <bool MOD>
+__global__ __launch_bounds__(256, 2) void conv2d_up2(Up2Params p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int cin_loop = ((p.Cin + U_KC - 1) / U_KC) * U_KC;
+    const int nchunks = cin_loop / U_KC;
+    float* cs0 = smem + 2 * U_LDS_BUF;          // input scale of two consecutive tiles [2][cin_loop]
+    float* ep0 = cs0 + 2 * cin_loop;            // output scale of two consecutive tiles [2][32]
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const unsigned smem_b = __builtin_amdgcn_readfirstlane(lds_offset(smem));
+    const int half = lane >> 5, l31 = lane & 31;
+    const int HW = p.H * p.W;
+    const int total = p.total_tiles;
+    const int q8 = total >> 3, r8 = total & 7;
+
+    int n = 0, q0 = 0, r0 = 0, m0 = 0;
+    unsigned xoff[U_XPT];
+    i32x4 xrsrc;
+
+    auto prep_tile = [&](int tile, float* cs) {
+        const int xcd = tile & 7;
+        int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (tile >> 3);
+        const int mb = L % p.mblocks; L /= p.mblocks;
+        const int tx = L % p.tilesX; L /= p.tilesX;
+        const int ty = L % p.tilesY;
+        n = L / p.tilesY;
+        q0 = ty * U_TQ; r0 = tx * U_TR; m0 = mb * U_BM;
+        if (MOD)
+            for (int c = t; c < cin_loop; c += 256) cs[c] = c < p.Cin ? ld_opaque(p.in_scale + (int64_t)n * p.Cin + c) : 1.f;
+        int tt = t;
+        asm volatile("" : "+v"(tt));                 // keep the index maths inside the tile loop (see conv2d_kernel.h)
+#pragma unroll
+        for (int i = 0; i < U_XPT; i++) {
+            const int e = tt + 256 * i;
+            const int c = e / U_PLANE, rem = e % U_PLANE;
+            const int gy = q0 - 1 + rem / U_IW, gx = r0 - 1 + rem % U_IW;
+            const bool ok = e < U_NX && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;     // (gy <= q0 + 7 may exceed H - 1 in a ragged last tile: zero)
+            xoff[i] = ok ? (unsigned)(c * HW + gy * p.W + gx) * 4u : 0x80000000u;
+        }
+        const uint64_t base = (uint64_t)(uintptr_t)(p.x + (int64_t)n * p.Cin * HW);
+        xrsrc[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)base);
+        xrsrc[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(base >> 32) & 0xffff);
+        xrsrc[2] = p.Cin * HW * 4;
+        xrsrc[3] = 0x00020000;
+    };
+
+    auto issue_chunk = [&](int c0, int buf) {
+        const unsigned xs_b = smem_b + (unsigned)(buf * U_LDS_BUF + 64 * wave) * 4u;
+        const unsigned ws_b = smem_b + (unsigned)(buf * U_LDS_BUF + U_LDS_X + 256 * wave) * 4u;
+        const int soff = c0 * HW * 4;
+#pragma unroll
+        for (int i = 0; i < U_XPT; i++) dma_dword(xrsrc, xs_b + 1024u * i, xoff[i], soff);
+        const float* wb = p.wp + (int64_t)c0 * 9 * p.CoutP + m0;
+#pragma unroll
+        for (int i = 0; i < U_WPT; i++) {
+            int e4 = t + 256 * i;
+            if (U_NW4 % 256 != 0 && e4 >= U_NW4) e4 = U_NW4 - 1;       // clamp: the pad lanes copy a duplicate
+            const int row = (e4 * 4) / U_BM, col = (e4 * 4) % U_BM;
+            dma_dwordx4(wb + (int64_t)row * p.CoutP + col, ws_b + 4096u * i);
+        }
+    };
+
+    f32x16 acc[4][2];                                // [parity 2a + b][position row of the wave]
+
+    // operands of one channel pair: 9 taps of this lane's cout, and the 3 x 2 input samples its two positions touch
+    struct Ops { float a[9]; float b[3][2]; };
+    auto fetch = [&](int buf, const float* cs, int c0, int cp, Ops& o) __attribute__((always_inline)) {
+        const float* ab = smem + buf * U_LDS_BUF + U_LDS_X + ((2 * cp + half) * 9) * U_BM + l31;
+        const float* bb = smem + buf * U_LDS_BUF + (2 * cp + half) * U_PLANE + (2 * wave) * U_IW + l31;
+#pragma unroll
+        for (int tp = 0; tp < 9; tp++) o.a[tp] = ab[tp * U_BM];
+        const float sc = MOD ? cs[c0 + 2 * cp + half] : 1.f;
+#pragma unroll
+        for (int rr = 0; rr < 3; rr++)
+#pragma unroll
+            for (int cc = 0; cc < 2; cc++) {
+                const float v = bb[rr * U_IW + cc];
+                o.b[rr][cc] = MOD ? v * sc : v;
+            }
+    };
+    auto mma = [&](const Ops& o) __attribute__((always_inline)) {
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++) {
+            // halo row nt + 0 = input row q - 1, nt + 1 = input row q;  halo col 0 = input col r - 1, col 1 = input col r
+            const float xm_m = o.b[nt][0], xm_0 = o.b[nt][1], x0_m = o.b[nt + 1][0], x0_0 = o.b[nt + 1][1];
+#define PG_MMA(ph, tap, v) acc[ph][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a[tap], v, acc[ph][nt], 0, 0, 0)
+            PG_MMA(0, 0, x0_0); PG_MMA(0, 2, x0_m); PG_MMA(0, 6, xm_0); PG_MMA(0, 8, xm_m);      // (0,0): ky,kx in {0,2}
+            PG_MMA(1, 1, x0_0); PG_MMA(1, 7, xm_0);                                              // (0,1): ky in {0,2}, kx = 1
+            PG_MMA(2, 3, x0_0); PG_MMA(2, 5, x0_m);                                              // (1,0): ky = 1, kx in {0,2}
+            PG_MMA(3, 4, x0_0);                                                                  // (1,1): centre tap
+#undef PG_MMA
+        }
+    };
+
+    int tile = blockIdx.x, par = 0, g = 0;
+    prep_tile(tile, cs0);
+    issue_chunk(0, 0);
+    dma_wait_all();
+    __syncthreads();
+    while (true) {
+#pragma unroll
+        for (int ph = 0; ph < 4; ph++)
+#pragma unroll
+            for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+                for (int k = 0; k < 16; k++) acc[ph][nt][k] = 0.f;
+        int e_n = n, e_q0 = q0, e_r0 = r0, e_m0 = m0;
+        bool has_next = false;
+        int next = tile;
+        const float* cs_cur = cs0 + par * cin_loop;
+        float* ep_scale = ep0 + par * U_BM;
+        for (int k = 0; k < nchunks; k++, g++) {
+            const int buf = g & 1;
+            if (k + 1 < nchunks) {
+                issue_chunk((k + 1) * U_KC, buf ^ 1);
+            } else {
+                e_n = n; e_q0 = q0; e_r0 = r0; e_m0 = m0;
+                if (t < U_BM) {
+                    const int co = e_m0 + t;
+                    ep_scale[t] = co < p.Cout ? (p.out_scale ? ld_opaque(p.out_scale + (int64_t)e_n * p.Cout + co) : 1.f) : 0.f;
+                }
+                next = tile + gridDim.x;
+                has_next = next < total;
+                if (has_next) {
+                    prep_tile(next, cs0 + (par ^ 1) * cin_loop);
+                    issue_chunk(0, buf ^ 1);
+                }
+            }
+            Ops cur, nxt;
+            fetch(buf, cs_cur, k * U_KC, 0, cur);
+#pragma unroll
+            for (int cp = 0; cp < U_KC / 2; cp++) {
+                if (cp + 1 < U_KC / 2) fetch(buf, cs_cur, k * U_KC, cp + 1, nxt);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(cur);
+                __builtin_amdgcn_sched_barrier(0);
+                cur = nxt;
+            }
+            dma_wait_all();
+            __syncthreads();
+        }
+
+        // ---- epilogue: D col = lane & 31 = position r, row = (reg & 3) + 8 * (reg >> 2) + 4 * half = cout.  A lane holds the two
+        // x-parities of its position = two adjacent output pixels.
+        const int r = e_r0 + l31;
+        const bool pair_ok = (p.ys[2] & 1) == 0 && (p.ys[1] & 1) == 0 && (p.ys[0] & 1) == 0 && (((uintptr_t)p.y) & 7) == 0 && p.ys[3] == 1;
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++) {
+            const int q = e_q0 + 2 * wave + nt;
+#pragma unroll
+            for (int a = 0; a < 2; a++) {
+                const bool row_ok = a == 0 ? q <= p.H : q < p.H;
+                const int oy = 2 * q + a;
+                const bool ok0 = row_ok && r < p.W, ok1 = ok0;
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    const int rowc = (k & 3) + 8 * (k >> 2) + 4 * half;
+                    const int co = e_m0 + rowc;
+                    const float sc = ep_scale[rowc];
+                    const float v0 = acc[2 * a][nt][k] * sc, v1 = acc[2 * a + 1][nt][k] * sc;
+                    if (co < p.Cout) {
+                        float* dst = p.y + (int64_t)e_n * p.ys[0] + (int64_t)co * p.ys[1] + (int64_t)oy * p.ys[2] + (int64_t)(2 * r) * p.ys[3];
+                        if (pair_ok && ok1) {
+                            *(f32x2s*)dst = (f32x2s){v0, v1};
+                        } else {
+                            if (ok0) dst[0] = v0;
+                            if (ok1) dst[p.ys[3]] = v1;
+                        }
+                    }
+                }
+            }
+        }
+        if (!has_next) break;
+        tile = next;
+        par ^= 1;
+    }
+}
+
+inline int launch_up2(const Up2Params& p0, hipStream_t s) {
+    Up2Params p = p0;
+    p.tilesX = (p.W + U_TR - 1) / U_TR;
+    p.tilesY = (p.H + 1 + U_TQ - 1) / U_TQ;
+    p.mblocks = p.CoutP / U_BM;
+    const int64_t tiles = (int64_t)p.N * p.tilesX * p.tilesY * p.mblocks;
+    if (tiles > 0x7fffffffLL) return PG_ERR_TOO_LARGE;
+    p.total_tiles = (int)tiles;
+    const int cin_loop = ((p.Cin + U_KC - 1) / U_KC) * U_KC;
+    const size_t lds = ((size_t)2 * U_LDS_BUF + 2 * cin_loop + 2 * U_BM) * sizeof(float);
+    if (lds > 160 * 1024) return PG_ERR_UNSUPPORTED;
+    int per_cu = (int)((160 * 1024) / lds);
+    if (per_cu > 2) per_cu = 2;                             // ~190 VGPRs x 4 waves per workgroup
+    const int64_t blocks = tiles < (int64_t)num_cu() * per_cu ? tiles : (int64_t)num_cu() * per_cu;
+    if (p.in_scale) {
+        static PerDeviceOnce a1;
+        const hipError_t e = a1.run([] { return hipFuncSetAttribute((const void*)conv2d_up2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL((conv2d_up2<true>), dim3((unsigned)blocks), dim3(256), lds, s, p);
+    } else {
+        static PerDeviceOnce a0;
+        const hipError_t e = a0.run([] { return hipFuncSetAttribute((const void*)conv2d_up2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL((conv2d_up2<false>), dim3((unsigned)blocks), dim3(256), lds, s, p);
+    }
+    return launch_status();
+}
+
+}  // namespace pgconv

@@ -124,7 +124,8 @@ __global__ __launch_bounds__(256) void upfirdn2d_tiled(Params p, int tilesX, int
     const int ox0 = tx * G::TOW, oy0 = ty * G::TOH;
     const int ix0 = floor_div(ox0 * DNX - p.padx0, UPX);
     const int iy0 = floor_div(oy0 * DNY - p.pady0, UPY);
-    const T* __restrict__ xp = (const T*)p.x + plane * (int64_t)p.inH * p.inW;
+    const T* __restrict__ xp = (const T*)p.x + plane * p.xs[1];           // rows may be pitched (xs[2] >= inW): a producer that pads its rows for aligned stores
+    const int pitch = (int)p.xs[2];
     // The footprint is walked as one flat element range (256 consecutive elements per step, rows break mid-wave): every
     // wave-instruction is full -- a per-row walk spends half of its load instructions on the 3-column halo tail, and vector
     // memory instructions are what this kernel runs out of.  Two phases so that all loads are in flight together (a
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(256) void upfirdn2d_tiled(Params p, int tilesX, int
         const int r = e / G::TIW, c = e - r * G::TIW;
         const int gy = iy0 + r, gx = ix0 + c;
         const bool ok = e < NE && gy >= 0 && gy < p.inH && gx >= 0 && gx < p.inW;
-        const float v = (float)xp[ok ? (int64_t)gy * p.inW + gx : 0];       // unconditional load from a valid address
+        const float v = (float)xp[ok ? (int64_t)gy * pitch + gx : 0];       // unconditional load from a valid address
         stage[i] = ok ? v : 0.f;
     }
 #pragma unroll
@@ -391,8 +392,9 @@ bool try_channels_last(const Params& p, hipStream_t s, int* st) {
 
 template <typename T>
 int run(const Params& p, hipStream_t s, bool allow_tiled) {
-    const bool dense_nchw = p.xs[3] == 1 && p.xs[2] == p.inW && p.xs[1] == (int64_t)p.inH * p.inW &&
-                            p.xs[0] == (int64_t)p.C * p.inH * p.inW && p.ys[3] == 1 && p.ys[2] == p.outW &&
+    // planes contiguous in (n, c) order, rows contiguous or pitched, output dense
+    const bool dense_nchw = p.xs[3] == 1 && p.xs[2] >= p.inW && p.xs[2] <= 0x7fffffffLL && p.xs[1] == (int64_t)p.inH * p.xs[2] &&
+                            p.xs[0] == (int64_t)p.C * p.xs[1] && p.ys[3] == 1 && p.ys[2] == p.outW &&
                             p.ys[1] == (int64_t)p.outH * p.outW && p.ys[0] == (int64_t)p.C * p.outH * p.outW;
     int st = PG_OK;
     if (allow_tiled && dense_nchw && (!p.has_ep || sizeof(T) == 4) && try_tiled<T>(p, s, &st)) return st;

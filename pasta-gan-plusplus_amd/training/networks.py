@@ -146,10 +146,16 @@ def _modconv_fast(x, weight, styles, noise, up, padding, resample_filter, demodu
         if flip_weight:
             wt = wt.flip([2, 3])
         return conv2d_mfma.pack_transposed(wt.contiguous(), 2, tpad, (h, w), out_hw)
-    phases = cache.get(('up2', flip_weight, h, w), [weight], build)
-    if phases is None:
-        return None
-    y = conv2d_mfma.conv_transpose2d_forward(x, phases, cout, out_hw, stride=2, in_scale=styles, out_scale=dcoefs)
+    if (kh, kw) == (3, 3) and tuple(tpad) == (0, 0) and os.environ.get('PG_UP2_FUSED', '1') != '0':
+        # all four output parities from one staged halo (csrc/conv2d_up2.h); the kernel indexes w[co, ci, ky, kx] of conv_transpose2d,
+        # i.e. the weight flipped iff flip_weight (conv2d_resample's `not flip_weight` twist, as in build() below)
+        packs = cache.get(('up2_fused', flip_weight), [weight], lambda: conv2d_mfma.pack_up2(weight, flip=flip_weight))
+        y = conv2d_mfma.conv_up2_forward(x, packs, cout, in_scale=styles, out_scale=dcoefs)
+    else:
+        phases = cache.get(('up2', flip_weight, h, w), [weight], build)
+        if phases is None:
+            return None
+        y = conv2d_mfma.conv_transpose2d_forward(x, phases, cout, out_hw, stride=2, in_scale=styles, out_scale=dcoefs)
     if ep.get('residual') is None:      # FIR + noise + bias_act in one pass over the tensor
         fused = upfirdn2d.upfirdn2d_bias_act(y, resample_filter, padding=fir_pad, gain=4, noise=noise, b=ep.get('bias'), act=ep.get('act', 'linear'),
                                              alpha=ep.get('alpha') or 0.0, act_gain=ep.get('gain', 1.0), clamp=ep.get('clamp'))

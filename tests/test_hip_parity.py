@@ -1039,3 +1039,33 @@ def test_one_channel_stencil_conv(n, h, w, cout, act):
     if act == 'relu':
         ref = ref.relu()
     close(y, ref, 1e-5, 1e-6 * scale_of(ref))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n,cin,cout,h,w,mod', [(2, 16, 32, 8, 32, True), (1, 5, 7, 9, 13, True), (3, 24, 40, 17, 33, False), (1, 64, 64, 32, 64, True)])
+def test_fused_up2_transposed_conv(n, cin, cout, h, w, mod):
+    """pg_conv2d_up2_forward (all four parities of the stride-2 transposed 3x3 convolution in one launch, modulation prologue,
+    demodulation epilogue, pitched output) against conv_transpose2d in float64."""
+    from torch_utils.ops import conv2d_mfma
+    gen = torch.Generator().manual_seed(1000 * n + cin + w)
+    x = torch.randn([n, cin, h, w], generator=gen)
+    wt = torch.randn([cout, cin, 3, 3], generator=gen) / np.sqrt(cin * 9)          # OIHW as the kernel indexes it: y[2iy+ky] += x[iy] w[co,ci,ky,kx]
+    s_in = torch.randn([n, cin], generator=gen) if mod else None
+    s_out = torch.rand([n, cout], generator=gen) + 0.5 if mod else None
+    flip = bool((n + cin) % 2)                     # pack_up2 flips iff asked: hand it the pre-flipped kernel then
+    wdev = (wt.flip([2, 3]) if flip else wt).contiguous().to(DEV)
+    packs = conv2d_mfma.pack_up2(wdev, flip=flip)
+    y = conv2d_mfma.conv_up2_forward(x.to(DEV), packs, cout, in_scale=s_in.to(DEV) if mod else None, out_scale=s_out.to(DEV) if mod else None)
+    assert y.shape == (n, cout, 2 * h + 1, 2 * w + 1) and y.stride(2) % 4 == 0
+    xs = x.double() * (s_in.double()[:, :, None, None] if mod else 1.0)
+    ref = torch.nn.functional.conv_transpose2d(xs, wt.double().transpose(0, 1), stride=2)
+    if mod:
+        ref = ref * s_out.double()[:, :, None, None]
+    close(y, ref, 1e-5, 2e-6 * scale_of(ref))
+    # the FIR pass reads the pitched tensor in place
+    from torch_utils.ops import upfirdn2d
+    f = upfirdn2d.setup_filter([1, 3, 3, 1]).to(DEV)
+    close(upfirdn2d.upfirdn2d(y, f, padding=[1, 1, 1, 1], gain=4), upfirdn2d.upfirdn2d(y.contiguous(), f, padding=[1, 1, 1, 1], gain=4), 0, 0)
+    fused = upfirdn2d.upfirdn2d_bias_act(y, f, padding=[1, 1, 1, 1], gain=4, b=torch.zeros(cout, device=DEV), act='lrelu', act_gain=1.0)
+    ref2 = torch.nn.functional.leaky_relu(upfirdn2d.upfirdn2d(y.contiguous(), f, padding=[1, 1, 1, 1], gain=4), 0.2)
+    close(fused, ref2, 1e-6, 1e-6 * scale_of(ref2))

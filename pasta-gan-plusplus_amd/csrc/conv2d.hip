@@ -395,7 +395,7 @@ static int conv_forward(bool winograd, const float* x, const float* packed_w, fl
     int st = PG_ERR_UNSUPPORTED;
     if (stride == 1) {
         if (KH == 3 && KW == 3) st = pgconv::launch_k3s1(p, s);
-        else if (KH == 1 && KW == 1) st = pgconv::launch_k1s1(p, s);
+        else if (KH == 1 && KW == 1) { st = pgconv::launch_s1x1(p, s); if (st == PG_ERR_UNSUPPORTED) st = pgconv::launch_k1s1(p, s); }
         else if (KH == 2 && KW == 2) st = pgconv::launch_k2x2(p, s);     // polyphase pieces of a stride-2 transposed 3x3
         else if (KH == 2 && KW == 1) st = pgconv::launch_k2x1(p, s);
         else if (KH == 1 && KW == 2) st = pgconv::launch_k1x2(p, s);

@@ -1069,3 +1069,32 @@ def test_fused_up2_transposed_conv(n, cin, cout, h, w, mod):
     fused = upfirdn2d.upfirdn2d_bias_act(y, f, padding=[1, 1, 1, 1], gain=4, b=torch.zeros(cout, device=DEV), act='lrelu', act_gain=1.0)
     ref2 = torch.nn.functional.leaky_relu(upfirdn2d.upfirdn2d(y.contiguous(), f, padding=[1, 1, 1, 1], gain=4), 0.2)
     close(fused, ref2, 1e-6, 1e-6 * scale_of(ref2))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n,cin,cin2,cout,h,w,fused', [(2, 64, 0, 64, 64, 64, True), (1, 32, 24, 40, 64, 66, True), (2, 70, 0, 96, 64, 64, False),
+                                                     (1, 64, 64, 128, 80, 52, True), (1, 20, 0, 33, 64, 64, True)])
+def test_streaming_1x1_conv(n, cin, cin2, cout, h, w, fused):
+    """The streaming 1x1 kernel (csrc/conv2d_s1x1.h: B operand straight from global memory, weights in LDS, 16-/8-byte stores) --
+    taken by pg_conv2d_forward for 32 <= Cout <= 128 and H*W >= 4096 -- against float64, with two-source input, modulation,
+    demodulation, bias, lrelu, gain, clamp and residual; must agree with the tiled kernel (PG_S1X1=0 is an A/B switch of the
+    library, so the comparison here is against the reference arithmetic)."""
+    from torch_utils.ops import conv2d_mfma
+    gen = torch.Generator().manual_seed(17 * cin + cout)
+    x = torch.randn([n, cin, h, w], generator=gen)
+    x2 = torch.randn([n, cin2, h, w], generator=gen) if cin2 else None
+    ct = cin + cin2
+    wt = torch.randn([cout, ct, 1, 1], generator=gen) / np.sqrt(ct)
+    kw = {}
+    ref_in = torch.cat([x, x2], 1).double() if cin2 else x.double()
+    if fused:
+        s_in, s_out = torch.randn([n, ct], generator=gen), torch.rand([n, cout], generator=gen) + 0.5
+        bias, res = torch.randn([cout], generator=gen), torch.randn([n, cout, h, w], generator=gen)
+        kw = dict(in_scale=s_in.to(DEV), out_scale=s_out.to(DEV), bias=bias.to(DEV), act='lrelu', alpha=0.2, gain=1.3, clamp=1.5, residual=res.to(DEV))
+        ref_in = ref_in * s_in.double()[:, :, None, None]
+    y = conv2d_mfma.conv2d_forward(x.to(DEV), conv2d_mfma.pack_weight(wt.to(DEV)), cout, 1, 1, x2=x2.to(DEV) if cin2 else None, **kw)
+    ref = torch.nn.functional.conv2d(ref_in, wt.double())
+    if fused:
+        ref = ref * s_out.double()[:, :, None, None] + bias.double()[None, :, None, None]
+        ref = (torch.nn.functional.leaky_relu(ref, 0.2) * 1.3).clamp(-1.5, 1.5) + res.double()
+    close(y, ref, 1e-5, 3e-6 * scale_of(ref))

@@ -372,13 +372,64 @@ __global__ __launch_bounds__(256, 2) void upfirdn2d_cl(Params p) {
     }
 }
 
+// Channels-last zero-insertion up-sampling by 2 (no decimation): the gradient of the discriminator's FIR down-sampling
+// (Upfirdn2dCuda.backward swaps up and down: upfirdn2d.py:245-264) and the skip-image up-sampling of 16-bit blocks.  Polyphase: an
+// output pixel touches only the taps that land on real samples -- (FH/2) x (FW/2) of them -- so a thread (one output pixel x one
+// 16-byte channel vector) reads 2 x 2 input vectors for a 4-tap filter.
+template <typename T, int FH, int FW>
+__global__ __launch_bounds__(256) void upfirdn2d_cl_up2(Params p) {
+    constexpr int V = Vec16<T>::N;
+    const int CV = p.C / V;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int cv = (int)(idx % CV);
+    const int ox = (int)(idx / CV);
+    if (ox >= p.outW) return;
+    const int n = blockIdx.z, oy = blockIdx.y;
+    const int ux0 = ox - p.padx0, uy0 = oy - p.pady0;        // up-sampled grid coordinate of tap 0
+    const int kx0 = ux0 & 1, ky0 = uy0 & 1;                  // first tap on a real sample: (u0 + k) even  (two's complement: works for negatives)
+    const int ix0 = (ux0 + kx0) >> 1, iy0 = (uy0 + ky0) >> 1;
+    const T* __restrict__ xn = (const T*)p.x + (int64_t)n * p.inH * p.inW * p.C + cv * V;
+    float acc[V];
+#pragma unroll
+    for (int c = 0; c < V; c++) acc[c] = 0.f;
+#pragma unroll
+    for (int jy = 0; jy < FH / 2; jy++) {
+        const int ky = ky0 + 2 * jy, iy = iy0 + jy;
+        const int fy = p.flip ? ky : p.fh - 1 - ky;
+#pragma unroll
+        for (int jx = 0; jx < FW / 2; jx++) {
+            const int kx = kx0 + 2 * jx, ix = ix0 + jx;
+            const int fx = p.flip ? kx : p.fw - 1 - kx;
+            const bool ok = ky < p.fh && kx < p.fw && iy >= 0 && iy < p.inH && ix >= 0 && ix < p.inW;
+            const float tap = ok ? p.f[fy * p.fs[0] + fx * p.fs[1]] : 0.f;
+            const u32x4 v = *(const u32x4*)(xn + ((int64_t)(ok ? iy : 0) * p.inW + (ok ? ix : 0)) * p.C);    // always a valid address
+            float xv[V];
+            Vec16<T>::widen(v, xv);
+#pragma unroll
+            for (int c = 0; c < V; c++) acc[c] = fmaf(xv[c], tap, acc[c]);
+        }
+    }
+    float out[V];
+#pragma unroll
+    for (int c = 0; c < V; c++) out[c] = acc[c] * p.gain;
+    T* __restrict__ yn = (T*)p.y + (int64_t)n * p.outH * p.outW * p.C + cv * V;
+    *(u32x4*)(yn + ((int64_t)oy * p.outW + ox) * p.C) = Vec16<T>::narrow(out);
+}
+
 template <typename T>
 bool try_channels_last(const Params& p, hipStream_t s, int* st) {
     constexpr int V = Vec16<T>::N;
     const bool dense_cl = p.xs[1] == 1 && p.xs[3] == p.C && p.xs[2] == (int64_t)p.inW * p.C && p.xs[0] == (int64_t)p.inH * p.inW * p.C &&
                           p.ys[1] == 1 && p.ys[3] == p.C && p.ys[2] == (int64_t)p.outW * p.C && p.ys[0] == (int64_t)p.outH * p.outW * p.C;
-    if (!dense_cl || p.C % V != 0 || p.upx != 1 || p.upy != 1 || p.dnx != p.dny || p.dnx > 2 || p.fw > 4 || p.fh > 4 ||
-        !aligned16(p.x) || !aligned16(p.y) || p.N > 65535) return false;
+    if (!dense_cl || p.C % V != 0 || p.fw > 4 || p.fh > 4 || !aligned16(p.x) || !aligned16(p.y) || p.N > 65535) return false;
+    if (p.upx == 2 && p.upy == 2 && p.dnx == 1 && p.dny == 1 && !p.has_ep) {
+        const int64_t bx2 = ((int64_t)p.outW * (p.C / V) + 255) / 256;
+        if (bx2 > 0x7fffffffLL || p.outH > 65535) return false;
+        hipLaunchKernelGGL((upfirdn2d_cl_up2<T, 4, 4>), dim3((unsigned)bx2, (unsigned)p.outH, (unsigned)p.N), dim3(256), 0, s, p);
+        *st = launch_status();
+        return true;
+    }
+    if (p.upx != 1 || p.upy != 1 || p.dnx != p.dny || p.dnx > 2) return false;
     constexpr int RPT = 4;                                 // output rows per thread: (RPT*DN + 3) x 4 16-byte loads in flight
     const int64_t bx = ((int64_t)p.outW * (p.C / V) + 255) / 256;
     const int by = (p.outH + RPT - 1) / RPT;

@@ -266,14 +266,15 @@ def test_synthesis_stack_half_vs_oracle(dtype):
 
 
 def test_upfirdn2d_channels_last_kernel():
-    """The channels-last FIR (blur / 2x decimation, with and without the fused tail) against the NCHW kernel's result."""
+    """The channels-last FIR (blur / 2x decimation / 2x zero-insertion up-sampling, with and without the fused tail) against the NCHW kernel's result."""
     from torch_utils.ops import upfirdn2d
     gen = torch.Generator().manual_seed(21)
     f = upfirdn2d.setup_filter([1, 3, 3, 1]).to(DEV)
     for dtype in (torch.float32, torch.bfloat16, torch.float16):
         x = torch.randn([2, 16, 37, 45], generator=gen).to(DEV, dtype)
         xcl = x.contiguous(memory_format=torch.channels_last)
-        for kw in (dict(padding=[1, 1, 1, 1], gain=4), dict(down=2, padding=[1, 1, 1, 1]), dict(padding=[2, 2, 2, 2]), dict(down=2, padding=[0, 1, 2, 0])):
+        for kw in (dict(padding=[1, 1, 1, 1], gain=4), dict(down=2, padding=[1, 1, 1, 1]), dict(padding=[2, 2, 2, 2]), dict(down=2, padding=[0, 1, 2, 0]),
+                   dict(up=2, padding=[2, 1, 2, 1], gain=4), dict(up=2, padding=[1, 2, 0, 3], flip_filter=True), dict(up=2, padding=[3, 3, 3, 3])):     # up = 2: the gradient of the 2x decimation
             a = upfirdn2d.upfirdn2d(xcl, f, **kw)
             b = upfirdn2d.upfirdn2d(x.float(), f, **kw)
             assert a.is_contiguous(memory_format=torch.channels_last) and a.shape == b.shape

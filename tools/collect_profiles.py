@@ -30,6 +30,8 @@ def main(rnd, commit=None):
                       ('cfg5', 'python bench.py --mode bf16_1024 --no-cpu-baseline --steps 7 --warmup 2 (config 5, bf16 1024^2 N=4)'),
                       ('train', 'python bench.py --mode train --no-cpu-baseline --steps 3 --warmup 1 (config 4, one GPU, batch 4)')):
         copy_csv(os.path.join(G, f'prof_{tag}', 'kernel_stats.csv'), pre + f'{tag}_kernel_stats.csv', f'rocprofv3 --kernel-trace --stats -- {what}')
+        copy_csv(os.path.join(G, f'prof_{tag}', 'kernel_stats_timed.csv'), pre + f'{tag}_kernel_stats_timed.csv',
+                 f'the same run, kernels of the TIMED region only (tools/window_stats.py over the kernel trace): {what}')
         copy_csv(os.path.join(G, f'prof_{tag}', 'by_shape.csv'), pre + f'{tag}_conv_by_shape.csv',
                  f'bench.py --conv-breakdown under the same command: conv launches of one step grouped by geometry / algorithm / shape')
 

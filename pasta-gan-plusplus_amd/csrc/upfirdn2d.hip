@@ -24,6 +24,7 @@
 //
 // Roofline: HBM streaming; algorithmic bytes per call = sizeof(T) * (numel(x) + numel(y))
 // (SURVEY.md section 8d).
+#include <cstdlib>
 #include "pg_common.h"
 
 namespace {
@@ -212,6 +213,195 @@ __global__ __launch_bounds__(256) void upfirdn2d_tiled(Params p, int tilesX, int
             yp[(int64_t)oy * p.outW + ox] = (T)v;
         }
     }
+}
+
+// ---------------------------------------------------------------- blur (no resampling), float32: separable, 16-byte accesses
+// The FIR call that carries the bytes of the synthesis forward is the 4x4 blur after every up-sampling convolution.  Measured on the
+// generic tiled kernel above: it is bound by VALU work, not by memory -- 16 multiply-adds per output (its 2x decimation variant, with a
+// quarter of the outputs per input byte, runs at 5 TB/s; the blur at 3.9; adding the fused tail's arithmetic slows it further; wider
+// tiles, 16-byte accesses and a prefetching persistent loop each changed nothing).  So this kernel cuts the arithmetic:
+//   * the filter is an outer product fy (x) fx (setup_filter builds it that way; verified on the taps by every workgroup, with the
+//     full 2-D evaluation as the fallback): a horizontal 4-tap pass per footprint row, then a vertical 4-tap pass -- with 8 output
+//     rows per thread 9.5 multiply-adds per output instead of 16;
+//   * a thread owns 4 adjacent output columns x 8 rows of a 64 x 128 tile; per footprint row one ds_read_b128 + one b64 (+ b32): the
+//     7 samples its 4 columns touch (D = the tile-constant misalignment of the footprint, a template parameter so the reads stay aligned);
+//   * every global access is 16 bytes: the footprint is staged as ALIGNED float4 words (the producer pads its rows to a multiple of 4
+//     floats, conv2d_up2.h; words straddling the image edge fall back to guarded scalars), stores and noise loads are float4;
+//   * persistent workgroups; the next tile's footprint is in flight (in registers) while this one is filtered.
+typedef float f32x4f __attribute__((ext_vector_type(4)));
+typedef float f32x2f __attribute__((ext_vector_type(2)));
+
+template <int D, int TOW>
+__global__ __launch_bounds__(256) void upfirdn2d_blur4(Params p, int tilesX, int tilesY, int total) {
+    constexpr int TOH = 8192 / TOW, RPT = 8, IH = TOH + 3, WORDS = TOW / 4 + 2, PITCH = 4 * WORDS, CQ = TOW / 4;
+    extern __shared__ __attribute__((aligned(16))) float sxf[];            // [IH][PITCH]
+    const int t = threadIdx.x;
+    const int pitch = (int)p.xs[2];
+    constexpr int NL = (IH * WORDS + 255) / 256;
+    // taps: flipped (true convolution) unless p.flip, zero padded to 4 x 4 (uniform: scalar registers)
+    float tap[4][4];
+#pragma unroll
+    for (int ky = 0; ky < 4; ky++)
+#pragma unroll
+        for (int kx = 0; kx < 4; kx++) {
+            const int fy = p.flip ? ky : p.fh - 1 - ky, fx = p.flip ? kx : p.fw - 1 - kx;
+            tap[ky][kx] = (ky < p.fh && kx < p.fw) ? p.f[fy * p.fs[0] + fx * p.fs[1]] : 0.f;
+        }
+    // outer-product factors through the largest tap; `sep` = the 16 taps really are fyv[ky] * fxv[kx]
+    int pk = 0, pj = 0;
+    float pv = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 4; ky++)
+#pragma unroll
+        for (int kx = 0; kx < 4; kx++)
+            if (fabsf(tap[ky][kx]) > fabsf(pv)) { pv = tap[ky][kx]; pk = ky; pj = kx; }
+    float fxv[4], fyv[4];
+    bool sep = pv != 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        fxv[k] = pk == 0 ? tap[0][k] : (pk == 1 ? tap[1][k] : (pk == 2 ? tap[2][k] : tap[3][k]));
+        const float col = pj == 0 ? tap[k][0] : (pj == 1 ? tap[k][1] : (pj == 2 ? tap[k][2] : tap[k][3]));
+        fyv[k] = sep ? col / pv : 0.f;
+    }
+#pragma unroll
+    for (int ky = 0; ky < 4; ky++)
+#pragma unroll
+        for (int kx = 0; kx < 4; kx++) sep = sep && fabsf(tap[ky][kx] - fyv[ky] * fxv[kx]) <= 1e-6f * fabsf(pv);
+
+    auto fetch = [&](int tile, f32x4f (&stage)[NL]) __attribute__((always_inline)) {
+        const int tx = tile % tilesX, ty = (tile / tilesX) % tilesY;
+        const int64_t plane = tile / (tilesX * tilesY);
+        const int iy0 = ty * TOH - p.pady0, a0 = tx * TOW - p.padx0 - D;             // a0: a multiple of 4 by the choice of D
+        const float* __restrict__ xp = (const float*)p.x + plane * p.xs[1];
+#pragma unroll
+        for (int i = 0; i < NL; i++) {
+            const int e = t + 256 * i;
+            const int r = e / WORDS, wd = e - r * WORDS;
+            const int gy = iy0 + r, gx = a0 + 4 * wd;
+            const bool row_ok = e < IH * WORDS && gy >= 0 && gy < p.inH;
+            f32x4f v = {0.f, 0.f, 0.f, 0.f};
+            if (row_ok && gx >= 0 && gx + 4 <= p.inW) {
+                v = *(const f32x4f*)(xp + (int64_t)gy * pitch + gx);
+            } else if (row_ok && gx + 4 > 0 && gx < p.inW) {               // word straddles the left / right edge
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (gx + k >= 0 && gx + k < p.inW) v[k] = xp[(int64_t)gy * pitch + gx + k];
+            }
+            stage[i] = v;
+        }
+    };
+    const int cx = t % CQ, ry = t / CQ;                                   // columns 4cx .. 4cx + 3, rows RPT * ry .. of the tile
+    f32x4f stage[NL];
+    int tile = blockIdx.x;
+    if (tile < total) fetch(tile, stage);
+    for (; tile < total; tile += gridDim.x) {
+#pragma unroll
+        for (int i = 0; i < NL; i++) {
+            const int e = t + 256 * i;
+            const int r = e / WORDS, wd = e - r * WORDS;
+            if (e < IH * WORDS) *(f32x4f*)&sxf[r * PITCH + 4 * wd] = stage[i];
+        }
+        __syncthreads();
+        if (tile + (int)gridDim.x < total) fetch(tile + gridDim.x, stage);
+        const int tx = tile % tilesX, ty = (tile / tilesX) % tilesY;
+        const int64_t plane = tile / (tilesX * tilesY);
+        const int ox0 = tx * TOW, oy0 = ty * TOH;
+        float acc[RPT][4];
+#pragma unroll
+        for (int r = 0; r < RPT; r++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) acc[r][c] = 0.f;
+#pragma unroll
+        for (int rr = 0; rr < RPT + 3; rr++) {                            // footprint rows of this thread's strip
+            // output column c, tap kx: staged column 4cx + c + kx + D, i.e. the samples v[D .. D + 6]
+            float v[12];
+            const float* row = &sxf[(RPT * ry + rr) * PITCH + 4 * cx];
+            *(f32x4f*)&v[0] = *(const f32x4f*)(row);
+            *(f32x4f*)&v[4] = *(const f32x4f*)(row + 4);
+            if (D + 6 >= 8) { *(f32x2f*)&v[8] = *(const f32x2f*)(row + 8); }
+            if (sep) {
+                float h[4];
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    h[c] = v[D + c] * fxv[0];
+#pragma unroll
+                    for (int kx = 1; kx < 4; kx++) h[c] = fmaf(v[D + c + kx], fxv[kx], h[c]);
+                }
+#pragma unroll
+                for (int r = 0; r < RPT; r++) {
+                    const int ky = rr - r;
+                    if (ky >= 0 && ky < 4) {
+#pragma unroll
+                        for (int c = 0; c < 4; c++) acc[r][c] = fmaf(h[c], fyv[ky], acc[r][c]);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < RPT; r++) {
+                    const int ky = rr - r;
+                    if (ky >= 0 && ky < 4) {
+#pragma unroll
+                        for (int c = 0; c < 4; c++)
+#pragma unroll
+                            for (int kx = 0; kx < 4; kx++) acc[r][c] = fmaf(v[D + c + kx], tap[ky][kx], acc[r][c]);
+                    }
+                }
+            }
+        }
+        const int ch = (int)(plane % p.C), n = (int)(plane / p.C);
+        const float bias = (p.has_ep && p.bias) ? p.bias[ch] : 0.f;
+        float* __restrict__ yp = (float*)p.y + plane * (int64_t)p.outH * p.outW;
+        const int ox = ox0 + 4 * cx;
+#pragma unroll
+        for (int r = 0; r < RPT; r++) {
+            const int oy = oy0 + RPT * ry + r;
+            if (oy >= p.outH || ox >= p.outW) continue;                    // outW % 4 == 0 (host): a thread's 4 columns are in or out together
+            f32x4f o = {acc[r][0] * p.gain, acc[r][1] * p.gain, acc[r][2] * p.gain, acc[r][3] * p.gain};
+            if (p.has_ep) {       // SynthesisLayer tail: + noise, + bias, linear/relu/lrelu, gain, clamp
+                if (p.noise) o += *(const f32x4f*)(p.noise + n * p.noise_bs + (int64_t)oy * p.outW + ox) * p.noise_gain;
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    float w = o[c] + bias;
+                    w = (w > 0.f ? w : w * p.slope) * p.act_gain;
+                    o[c] = fminf(fmaxf(w, -p.clamp), p.clamp);
+                }
+            }
+            *(f32x4f*)(yp + (int64_t)oy * p.outW + ox) = o;
+        }
+        __syncthreads();                                                   // every thread is done with the tile before the next one overwrites it
+    }
+}
+
+// Returns 1 if the 16-byte blur kernel took the call (status in *st).
+inline bool try_blur4(const Params& p, hipStream_t s, int* st) {
+    static const bool on = [] { const char* e = getenv("PG_FIR_BLUR4"); return e ? atoi(e) != 0 : true; }();      // A/B switch
+    if (!on || p.upx != 1 || p.upy != 1 || p.dnx != 1 || p.dny != 1 || p.fw > 4 || p.fh > 4) return false;
+    if ((p.xs[2] & 3) != 0 || (p.xs[1] & 3) != 0 || (p.outW & 3) != 0 || !aligned16(p.x) || !aligned16(p.y)) return false;
+    if (p.noise && (!aligned16(p.noise) || (p.noise_bs & 3) != 0)) return false;
+    const int d = ((-p.padx0) % 4 + 4) % 4;                               // ox0 - padx0 - d is a multiple of 4 (ox0 is one of 64)
+    if (d + 6 > 11) return false;
+    static const int shape = [] { const char* e = getenv("PG_FIR_BLUR4_TILE"); return e ? atoi(e) : 128; }();     // tile width 64 | 128 | 256 (dev switch; 128: 263 us, 64: 272 us, 256: 261 / slower with the tail)
+    const int TOW = shape == 128 ? 128 : (shape == 256 ? 256 : 64), TOH = 8192 / TOW;
+    if (p.outW % TOW != 0 || p.outH % TOH != 0) return false;             // large planes only: on the 128^2 and smaller layers the big tiles are mostly empty (measured slower)
+    const int tilesX = (p.outW + TOW - 1) / TOW, tilesY = (p.outH + TOH - 1) / TOH;
+    const int64_t tiles = (int64_t)tilesX * tilesY * p.N * p.C;
+    if (tiles > 0x7fffffffLL) { *st = PG_ERR_TOO_LARGE; return true; }
+    const int total = (int)tiles;
+    const size_t lds = (size_t)(TOH + 3) * (TOW + 8) * sizeof(float);     // ~37 KB: 4 workgroups per CU
+    const int64_t blocks = tiles < (int64_t)num_cu() * 4 ? tiles : (int64_t)num_cu() * 4;
+#define PG_B4(DD) \
+    if (TOW == 64) hipLaunchKernelGGL((upfirdn2d_blur4<DD, 64>), dim3((unsigned)blocks), dim3(256), lds, s, p, tilesX, tilesY, total); \
+    else if (TOW == 128) hipLaunchKernelGGL((upfirdn2d_blur4<DD, 128>), dim3((unsigned)blocks), dim3(256), lds, s, p, tilesX, tilesY, total); \
+    else hipLaunchKernelGGL((upfirdn2d_blur4<DD, 256>), dim3((unsigned)blocks), dim3(256), lds, s, p, tilesX, tilesY, total);
+    switch (d) {
+        case 0: PG_B4(0) break;
+        case 1: PG_B4(1) break;
+        case 2: PG_B4(2) break;
+        default: PG_B4(3) break;
+    }
+#undef PG_B4
+    *st = launch_status();
+    return true;
 }
 
 template <typename T, int UPX, int UPY, int DNX, int DNY, int FW, int FH>
@@ -448,6 +638,7 @@ int run(const Params& p, hipStream_t s, bool allow_tiled) {
                             p.xs[0] == (int64_t)p.C * p.xs[1] && p.ys[3] == 1 && p.ys[2] == p.outW &&
                             p.ys[1] == (int64_t)p.outH * p.outW && p.ys[0] == (int64_t)p.C * p.outH * p.outW;
     int st = PG_OK;
+    if constexpr (sizeof(T) == 4) { if (allow_tiled && dense_nchw && try_blur4(p, s, &st)) return st; }
     if (allow_tiled && dense_nchw && (!p.has_ep || sizeof(T) == 4) && try_tiled<T>(p, s, &st)) return st;
     if constexpr (sizeof(T) <= 4) { if (allow_tiled && try_channels_last<T>(p, s, &st)) return st; }
     if (p.has_ep) return PG_ERR_UNSUPPORTED;

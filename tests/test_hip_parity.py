@@ -1065,7 +1065,12 @@ def test_fused_up2_transposed_conv(n, cin, cout, h, w, mod):
     # the FIR pass reads the pitched tensor in place
     from torch_utils.ops import upfirdn2d
     f = upfirdn2d.setup_filter([1, 3, 3, 1]).to(DEV)
-    close(upfirdn2d.upfirdn2d(y, f, padding=[1, 1, 1, 1], gain=4), upfirdn2d.upfirdn2d(y.contiguous(), f, padding=[1, 1, 1, 1], gain=4), 0, 0)
+    ref1 = upfirdn2d.upfirdn2d(y.contiguous(), f, padding=[1, 1, 1, 1], gain=4)          # dense rows: the generic tiled kernel; pitched rows: the 16-byte blur kernel
+    close(upfirdn2d.upfirdn2d(y, f, padding=[1, 1, 1, 1], gain=4), ref1, 1e-6, 1e-6 * scale_of(ref1))
+    for pad in ([2, 2, 2, 2], [0, 3, 1, 2], [3, 0, 2, 1]):                                     # every footprint misalignment D of the blur kernel
+        refp = upfirdn2d.upfirdn2d(y.contiguous(), f, padding=pad)
+        if refp.shape[3] % 4 == 0:
+            close(upfirdn2d.upfirdn2d(y, f, padding=pad), refp, 1e-6, 1e-6 * scale_of(refp))
     fused = upfirdn2d.upfirdn2d_bias_act(y, f, padding=[1, 1, 1, 1], gain=4, b=torch.zeros(cout, device=DEV), act='lrelu', act_gain=1.0)
     ref2 = torch.nn.functional.leaky_relu(upfirdn2d.upfirdn2d(y.contiguous(), f, padding=[1, 1, 1, 1], gain=4), 0.2)
     close(fused, ref2, 1e-6, 1e-6 * scale_of(ref2))

@@ -47,16 +47,20 @@ constexpr unsigned WG_SENTINEL = 0x80000000u;     // byte offset beyond any desc
 // LDS image of a tile is its flat element order and the gather sits in the per-lane source offset.  The offsets relative to the
 // chunk origin are kernel-lifetime registers; a chunk whose footprint lies inside the image just adds its origin (in the
 // descriptor base) -- no per-element arithmetic; border chunks mask their out-of-image elements to a sentinel offset.  Two
-// staging buffers: chunk g + 1 is in flight while chunk g is multiplied, one barrier per chunk.  One workgroup per CU (the
-// 9 x 16 accumulators + 52 gather offsets per lane need the 512-register budget of a single wave per SIMD).
+// staging buffers: chunk g + 1 is in flight while chunk g is multiplied, one barrier per chunk.  One workgroup of EIGHT waves per
+// CU: waves 0-3 multiply (9 x 16 accumulators each), waves 4-7 only request the next chunk (52 requests + M0 traffic per lane and
+// chunk) -- issued by the multiplying waves themselves those requests cost 20 % of the kernel (measured: 88 -> 110 TFLOP/s with
+// the requests removed), from a wave of their own they overlap the other wave's MFMAs on the same SIMD.
 template <int KH, int KW>
-__global__ __launch_bounds__(256, 1) void conv2d_wgrad(WgradParams p) {
+__global__ __launch_bounds__(512, 1) void conv2d_wgrad(WgradParams p) {
     typedef WGeo<KH, KW> G;
     constexpr int NDY = (WG_BM * G::PA + 255) / 256, NX = (WG_BN * G::PB + 255) / 256;
     extern __shared__ float smem[];
     constexpr int BUF = (NDY + NX) * 256;       // floats per staging buffer: dy [64 co][PA] then x [64 ci][PB], whole DMA rows
-    const int t = threadIdx.x, lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int lane = threadIdx.x & 63;
+    const int wave8 = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const bool loader = wave8 >= 4;                  // wave-uniform role
+    const int wave = wave8 & 3, t = threadIdx.x & 255;
     const int half = lane >> 5, l31 = lane & 31;
     const int mt = wave & 1, nt = wave >> 1;
     int b = blockIdx.x;
@@ -66,19 +70,70 @@ __global__ __launch_bounds__(256, 1) void conv2d_wgrad(WgradParams p) {
     const int OHW = p.OH * p.OW, HW = p.H * p.W;
     const unsigned smem_b = __builtin_amdgcn_readfirstlane(pgconv::lds_offset(smem));
 
-    // per-thread gather maps (bytes from the chunk origin); statically invalid elements (pitch padding, channels beyond the tensor) = sentinel
-    unsigned rel_dy[NDY], rel_x[NX];
-#pragma unroll
-    for (int i = 0; i < NDY; i++) {
-        const int f = t + 256 * i, co = f / G::PA, px = f % G::PA;
-        const bool ok = co < WG_BM && px < WG_PIX && co0 + co < p.Cout;
-        rel_dy[i] = ok ? (unsigned)(co * OHW + (px / WG_TW) * p.OW + px % WG_TW) * 4u : WG_SENTINEL;
-    }
-#pragma unroll
-    for (int i = 0; i < NX; i++) {
-        const int f = t + 256 * i, ci = f / G::PB, rr = f % G::PB;
-        const bool ok = ci < WG_BN && rr < G::IH * G::IW && ci0 + ci < p.Cin;
-        rel_x[i] = ok ? (unsigned)(ci * HW + (rr / G::IW) * p.W + rr % G::IW) * 4u : WG_SENTINEL;
+    if (loader) {
+        // ---- loader waves: gather maps, then request chunk after chunk, one barrier per chunk with the multiplying waves
+        // per-thread gather maps (bytes from the chunk origin); statically invalid elements (pitch padding, channels beyond the tensor) = sentinel
+        unsigned rel_dy[NDY], rel_x[NX];
+    #pragma unroll
+        for (int i = 0; i < NDY; i++) {
+            const int f = t + 256 * i, co = f / G::PA, px = f % G::PA;
+            const bool ok = co < WG_BM && px < WG_PIX && co0 + co < p.Cout;
+            rel_dy[i] = ok ? (unsigned)(co * OHW + (px / WG_TW) * p.OW + px % WG_TW) * 4u : WG_SENTINEL;
+        }
+    #pragma unroll
+        for (int i = 0; i < NX; i++) {
+            const int f = t + 256 * i, ci = f / G::PB, rr = f % G::PB;
+            const bool ok = ci < WG_BN && rr < G::IH * G::IW && ci0 + ci < p.Cin;
+            rel_x[i] = ok ? (unsigned)(ci * HW + (rr / G::IW) * p.W + rr % G::IW) * 4u : WG_SENTINEL;
+        }
+        auto issue = [&](int ch, int buf) __attribute__((always_inline)) {
+            int c = ch;
+            const int tx = c % p.tilesX; c /= p.tilesX;
+            const int ty = c % p.tilesY;
+            const int n = c / p.tilesY;
+            const int oy0 = ty * WG_R, ox0 = tx * WG_TW;
+            const int iy0 = oy0 - p.pad_y, ix0 = ox0 - p.pad_x;
+            // descriptors based at the chunk origin (the x origin may lie before the tensor: such elements are masked below)
+            const uint64_t dyb = (uint64_t)(uintptr_t)(p.dy + ((int64_t)n * p.Cout + co0) * OHW + (int64_t)oy0 * p.OW + ox0);
+            const uint64_t xb = (uint64_t)(uintptr_t)(p.x + ((int64_t)n * p.Cin + ci0) * HW) + ((int64_t)iy0 * p.W + ix0) * 4;
+            pgconv::i32x4 rdy, rx;
+            rdy[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)dyb); rdy[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(dyb >> 32) & 0xffff);
+            rdy[2] = 0x7ffffffe; rdy[3] = 0x00020000;
+            rx[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)xb); rx[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(xb >> 32) & 0xffff);
+            rx[2] = 0x7ffffffe; rx[3] = 0x00020000;
+            const bool inner_dy = oy0 + WG_R <= p.OH && ox0 + WG_TW <= p.OW;                                       // wave-uniform
+            const bool inner_x = iy0 >= 0 && iy0 + G::IH <= p.H && ix0 >= 0 && ix0 + G::IW <= p.W;
+            const unsigned base_b = smem_b + (unsigned)(buf * BUF + 64 * wave) * 4u;
+    #pragma unroll
+            for (int i = 0; i < NDY; i++) {
+                unsigned v = rel_dy[i];
+                if (!inner_dy) {
+                    const int px = (t + 256 * i) % G::PA;
+                    if (oy0 + px / WG_TW >= p.OH || ox0 + px % WG_TW >= p.OW) v = WG_SENTINEL;
+                }
+                pgconv::dma_dword(rdy, base_b + (unsigned)(256 * i) * 4u, v, 0);
+            }
+    #pragma unroll
+            for (int i = 0; i < NX; i++) {
+                unsigned v = rel_x[i];
+                if (!inner_x) {
+                    const int rr = (t + 256 * i) % G::PB;
+                    const int iy = iy0 + rr / G::IW, ix = ix0 + rr % G::IW;
+                    if (iy < 0 || iy >= p.H || ix < 0 || ix >= p.W) v = WG_SENTINEL;
+                }
+                pgconv::dma_dword(rx, base_b + (unsigned)(NDY * 256 + 256 * i) * 4u, v, 0);
+            }
+        };
+        int ch = s, g = 0;
+        if (ch < p.chunks) issue(ch, 0);
+        pgconv::dma_wait_all();
+        __syncthreads();
+        for (; ch < p.chunks; ch += p.splits, g++) {
+            if (ch + p.splits < p.chunks) issue(ch + p.splits, (g & 1) ^ 1);      // that buffer was last read one iteration ago (barrier below)
+            pgconv::dma_wait_all();                                              // the chunk requested above has landed
+            __syncthreads();
+        }
+        return;
     }
 
     f32x16 acc[G::T];
@@ -87,52 +142,10 @@ __global__ __launch_bounds__(256, 1) void conv2d_wgrad(WgradParams p) {
 #pragma unroll
         for (int k = 0; k < 16; k++) acc[tp][k] = 0.f;
 
-    auto issue = [&](int ch, int buf) __attribute__((always_inline)) {
-        int c = ch;
-        const int tx = c % p.tilesX; c /= p.tilesX;
-        const int ty = c % p.tilesY;
-        const int n = c / p.tilesY;
-        const int oy0 = ty * WG_R, ox0 = tx * WG_TW;
-        const int iy0 = oy0 - p.pad_y, ix0 = ox0 - p.pad_x;
-        // descriptors based at the chunk origin (the x origin may lie before the tensor: such elements are masked below)
-        const uint64_t dyb = (uint64_t)(uintptr_t)(p.dy + ((int64_t)n * p.Cout + co0) * OHW + (int64_t)oy0 * p.OW + ox0);
-        const uint64_t xb = (uint64_t)(uintptr_t)(p.x + ((int64_t)n * p.Cin + ci0) * HW) + ((int64_t)iy0 * p.W + ix0) * 4;
-        pgconv::i32x4 rdy, rx;
-        rdy[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)dyb); rdy[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(dyb >> 32) & 0xffff);
-        rdy[2] = 0x7ffffffe; rdy[3] = 0x00020000;
-        rx[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)xb); rx[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(xb >> 32) & 0xffff);
-        rx[2] = 0x7ffffffe; rx[3] = 0x00020000;
-        const bool inner_dy = oy0 + WG_R <= p.OH && ox0 + WG_TW <= p.OW;                                       // wave-uniform
-        const bool inner_x = iy0 >= 0 && iy0 + G::IH <= p.H && ix0 >= 0 && ix0 + G::IW <= p.W;
-        const unsigned base_b = smem_b + (unsigned)(buf * BUF + 64 * wave) * 4u;
-#pragma unroll
-        for (int i = 0; i < NDY; i++) {
-            unsigned v = rel_dy[i];
-            if (!inner_dy) {
-                const int px = (t + 256 * i) % G::PA;
-                if (oy0 + px / WG_TW >= p.OH || ox0 + px % WG_TW >= p.OW) v = WG_SENTINEL;
-            }
-            pgconv::dma_dword(rdy, base_b + (unsigned)(256 * i) * 4u, v, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < NX; i++) {
-            unsigned v = rel_x[i];
-            if (!inner_x) {
-                const int rr = (t + 256 * i) % G::PB;
-                const int iy = iy0 + rr / G::IW, ix = ix0 + rr % G::IW;
-                if (iy < 0 || iy >= p.H || ix < 0 || ix >= p.W) v = WG_SENTINEL;
-            }
-            pgconv::dma_dword(rx, base_b + (unsigned)(NDY * 256 + 256 * i) * 4u, v, 0);
-        }
-    };
-
     int ch = s, g = 0;
-    if (ch < p.chunks) issue(ch, 0);
-    pgconv::dma_wait_all();
-    __syncthreads();
+    __syncthreads();                             // chunk 0 has landed
     for (; ch < p.chunks; ch += p.splits, g++) {
         const int buf = g & 1;
-        if (ch + p.splits < p.chunks) issue(ch + p.splits, buf ^ 1);       // that buffer was last read one iteration ago (barrier below)
         const float* dyt = smem + buf * BUF;
         const float* xt = dyt + NDY * 256;
         const float* a_base = dyt + (mt * 32 + l31) * G::PA + half;
@@ -160,7 +173,6 @@ __global__ __launch_bounds__(256, 1) void conv2d_wgrad(WgradParams p) {
 #pragma unroll
             for (int tp = 0; tp < G::T; tp++) b_cur[tp] = b_nxt[tp];
         }
-        pgconv::dma_wait_all();                  // the chunk requested above has landed
         __syncthreads();
     }
     // partial block -> workspace[s][tap][co][ci]: D col = lane & 31 = ci (contiguous), row = (reg & 3) + 8 * (reg >> 2) + 4 * half = co
@@ -225,13 +237,13 @@ PG_EXPORT int pg_conv2d_wgrad(const float* x, const float* dy, float* dw, float*
         static pg::PerDeviceOnce attr;
         const hipError_t e = attr.run([] { return hipFuncSetAttribute((const void*)conv2d_wgrad<3, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
         if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL((conv2d_wgrad<3, 3>), dim3((unsigned)blocks), dim3(256), lds, s, p);
+        hipLaunchKernelGGL((conv2d_wgrad<3, 3>), dim3((unsigned)blocks), dim3(512), lds, s, p);
     } else {
         const size_t lds = WGeo<1, 1>::LDS_FLOATS * sizeof(float);
         static pg::PerDeviceOnce attr1;
         const hipError_t e = attr1.run([] { return hipFuncSetAttribute((const void*)conv2d_wgrad<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
         if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL((conv2d_wgrad<1, 1>), dim3((unsigned)blocks), dim3(256), lds, s, p);
+        hipLaunchKernelGGL((conv2d_wgrad<1, 1>), dim3((unsigned)blocks), dim3(512), lds, s, p);
     }
     int st = pg::launch_status();
     if (st != PG_OK) return st;

@@ -32,7 +32,7 @@ from . import conv2d_mfma
 from . import conv2d_mfma16
 
 native_input_gradients = os.environ.get('PG_NATIVE_DGRAD', '1') == '1'    # input gradients through the MFMA / Winograd kernels (PG_NATIVE_DGRAD=0: aten)
-native_weight_gradients = os.environ.get('PG_NATIVE_WGRAD', '0') == '1'   # weight gradients of stride-1 3x3 / 1x1 convs through csrc/conv2d_wgrad.hip (exact, deterministic; measured 1.7x slower than MIOpen's igemm_wrw assembly on the config-4 step, hence opt-in)
+native_weight_gradients = os.environ.get('PG_NATIVE_WGRAD', '1') == '1'   # weight gradients of stride-1 3x3 / 1x1 fp32 convs through csrc/conv2d_wgrad.hip (exact, deterministic; PG_NATIVE_WGRAD=0: aten / MIOpen)
 enabled = True                      # True (default here; the reference's loop sets it, training_loop_fullbody.py:386): hand-written kernels.  False: aten
 weight_gradients_disabled = False   # forcefully disable weight gradients (R1, loss_fullbody.py:266)
 

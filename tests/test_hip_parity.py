@@ -969,7 +969,7 @@ def test_conv2d_gradfix_native_backward_routes():
     assert conv2d_gradfix.native_input_gradients
     calls = {'wgrad': 0}
     real_wgrad, was = conv2d_mfma.weight_gradient, conv2d_gradfix.native_weight_gradients
-    conv2d_gradfix.native_weight_gradients = True       # opt-in (PG_NATIVE_WGRAD=1): MIOpen's assembly wgrad is faster today
+    conv2d_gradfix.native_weight_gradients = True       # the default; set explicitly so that an exported PG_NATIVE_WGRAD=0 cannot hollow out the check
 
     def counting_wgrad(*a, **k):
         out = real_wgrad(*a, **k)

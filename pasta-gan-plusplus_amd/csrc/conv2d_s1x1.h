@@ -13,7 +13,7 @@
 //   * no barrier and no LDS traffic for activations in the K loop; channel-pair loads are requested a group (4 pairs) ahead;
 //   * MT x E = 8 accumulators of 16 registers: (MT 2, E 4) for Cout <= 64 -- the form that is used: 64->64 at 512^2 275 vs 311 us,
 //     128->64 412 vs 417 us against the tiled kernel; (MT 4, E 2) for Cout <= 128 measured 8-12 % slower (8-byte accesses, 244
-//     VGPRs) and is not dispatched.  One workgroup of 8 waves per CU (226 VGPRs): 2 waves per SIMD is what limits it to ~3.9 TB/s;
+//     VGPRs), two 64-cout passes over the same pixel tile (input from L2 the second time) -3 ... +7 %: neither is dispatched.  One workgroup of 8 waves per CU (226 VGPRs): 2 waves per SIMD is what limits it to ~3.9 TB/s;
 //   * two-source mode (channels [split, Cin) from x2), epilogue: * out_scale, + bias, act, gain, clamp, + residual -- as conv2d_kernel.h.
 // Roofline: HBM; algorithmic bytes 4 * N * H*W * (Cin + Cout) (+ residual).
 #pragma once

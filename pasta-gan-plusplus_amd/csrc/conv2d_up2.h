@@ -28,9 +28,14 @@ namespace pgconv {
 
 typedef float f32x2s __attribute__((ext_vector_type(2)));
 
-constexpr int U_TQ = 8, U_TR = 32, U_BM = 32, U_KC = 8;
-constexpr int U_IH = U_TQ + 1, U_IW = U_TR + 1, U_PLANE = U_IH * U_IW;      // halo: rows q0-1 .. q0+7, cols r0-1 .. r0+31
-constexpr int U_NX = U_KC * U_PLANE, U_XPT = (U_NX + 255) / 256;
+constexpr int U_BM = 32, U_KC = 8;
+// The 32 MFMA columns of a wave are 32 / TRW rows x TRW columns of positions: TRW = 32 for the wide layers, 16 / 8 for the 16^2 / 8^2
+// ones (a 32-wide row of positions would be mostly empty there).  Workgroup tile: 8 * (32 / TRW) rows x TRW columns.
+template <int TRW> struct UGeo {
+    static constexpr int RG = 32 / TRW, TQ = 8 * RG, IH = TQ + 1, IW = TRW + 1, PLANE = IH * IW;      // halo: rows q0-1 .., cols r0-1 ..
+    static constexpr int NX = U_KC * PLANE;
+};
+constexpr int U_XPT = (U_KC * 297 + 255) / 256;         // 9 x 33, 17 x 17, 33 x 9: at most 297 halo samples per channel
 constexpr int U_NW4 = U_KC * 9 * U_BM / 4, U_WPT = (U_NW4 + 255) / 256;
 constexpr int U_LDS_X = U_XPT * 256, U_LDS_W = U_WPT * 256 * 4, U_LDS_BUF = U_LDS_X + U_LDS_W;
 
@@ -42,8 +47,10 @@ struct Up2Params {
     int tilesX, tilesY, mblocks, total_tiles;
 };
 
-template <bool MOD>
+template <bool MOD, int TRW>
 __global__ __launch_bounds__(256, 2) void conv2d_up2(Up2Params p) {
+    typedef UGeo<TRW> G;
+    static_assert(G::PLANE <= 297, "halo tile larger than the staging buffer");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int cin_loop = ((p.Cin + U_KC - 1) / U_KC) * U_KC;
     const int nchunks = cin_loop / U_KC;
@@ -69,7 +76,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_up2(Up2Params p) {
         const int tx = L % p.tilesX; L /= p.tilesX;
         const int ty = L % p.tilesY;
         n = L / p.tilesY;
-        q0 = ty * U_TQ; r0 = tx * U_TR; m0 = mb * U_BM;
+        q0 = ty * G::TQ; r0 = tx * TRW; m0 = mb * U_BM;
         if (MOD)
             for (int c = t; c < cin_loop; c += 256) cs[c] = c < p.Cin ? ld_opaque(p.in_scale + (int64_t)n * p.Cin + c) : 1.f;
         int tt = t;
@@ -77,9 +84,9 @@ __global__ __launch_bounds__(256, 2) void conv2d_up2(Up2Params p) {
 #pragma unroll
         for (int i = 0; i < U_XPT; i++) {
             const int e = tt + 256 * i;
-            const int c = e / U_PLANE, rem = e % U_PLANE;
-            const int gy = q0 - 1 + rem / U_IW, gx = r0 - 1 + rem % U_IW;
-            const bool ok = e < U_NX && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;     // (gy <= q0 + 7 may exceed H - 1 in a ragged last tile: zero)
+            const int c = e / G::PLANE, rem = e % G::PLANE;
+            const int gy = q0 - 1 + rem / G::IW, gx = r0 - 1 + rem % G::IW;
+            const bool ok = e < G::NX && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;     // (gy <= q0 + 7 may exceed H - 1 in a ragged last tile: zero)
             xoff[i] = ok ? (unsigned)(c * HW + gy * p.W + gx) * 4u : 0x80000000u;
         }
         const uint64_t base = (uint64_t)(uintptr_t)(p.x + (int64_t)n * p.Cin * HW);
@@ -107,27 +114,29 @@ __global__ __launch_bounds__(256, 2) void conv2d_up2(Up2Params p) {
 
     f32x16 acc[4][2];                                // [parity 2a + b][position row of the wave]
 
-    // operands of one channel pair: 9 taps of this lane's cout, and the 3 x 2 input samples its two positions touch
-    struct Ops { float a[9]; float b[3][2]; };
+    // operands of one channel pair: 9 taps of this lane's cout, and the 2 x 2 input samples each of its two positions touches
+    struct Ops { float a[9]; float b[2][2][2]; };           // b[position row nt][input row q - 1 | q][input col r - 1 | r]
+    const int lr = l31 / TRW, lc = l31 % TRW;
     auto fetch = [&](int buf, const float* cs, int c0, int cp, Ops& o) __attribute__((always_inline)) {
         const float* ab = smem + buf * U_LDS_BUF + U_LDS_X + ((2 * cp + half) * 9) * U_BM + l31;
-        const float* bb = smem + buf * U_LDS_BUF + (2 * cp + half) * U_PLANE + (2 * wave) * U_IW + l31;
+        const float* bb = smem + buf * U_LDS_BUF + (2 * cp + half) * G::PLANE + ((2 * wave) * G::RG + lr) * G::IW + lc;
 #pragma unroll
         for (int tp = 0; tp < 9; tp++) o.a[tp] = ab[tp * U_BM];
         const float sc = MOD ? cs[c0 + 2 * cp + half] : 1.f;
 #pragma unroll
-        for (int rr = 0; rr < 3; rr++)
+        for (int nt = 0; nt < 2; nt++)
 #pragma unroll
-            for (int cc = 0; cc < 2; cc++) {
-                const float v = bb[rr * U_IW + cc];
-                o.b[rr][cc] = MOD ? v * sc : v;
-            }
+            for (int dy = 0; dy < 2; dy++)
+#pragma unroll
+                for (int cc = 0; cc < 2; cc++) {
+                    const float v = bb[(nt * G::RG + dy) * G::IW + cc];       // (RG = 1: the two position rows share a halo row; the compiler merges the reads)
+                    o.b[nt][dy][cc] = MOD ? v * sc : v;
+                }
     };
     auto mma = [&](const Ops& o) __attribute__((always_inline)) {
 #pragma unroll
         for (int nt = 0; nt < 2; nt++) {
-            // halo row nt + 0 = input row q - 1, nt + 1 = input row q;  halo col 0 = input col r - 1, col 1 = input col r
-            const float xm_m = o.b[nt][0], xm_0 = o.b[nt][1], x0_m = o.b[nt + 1][0], x0_0 = o.b[nt + 1][1];
+            const float xm_m = o.b[nt][0][0], xm_0 = o.b[nt][0][1], x0_m = o.b[nt][1][0], x0_0 = o.b[nt][1][1];
 #define PG_MMA(ph, tap, v) acc[ph][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a[tap], v, acc[ph][nt], 0, 0, 0)
             PG_MMA(0, 0, x0_0); PG_MMA(0, 2, x0_m); PG_MMA(0, 6, xm_0); PG_MMA(0, 8, xm_m);      // (0,0): ky,kx in {0,2}
             PG_MMA(1, 1, x0_0); PG_MMA(1, 7, xm_0);                                              // (0,1): ky in {0,2}, kx = 1
@@ -187,11 +196,11 @@ __global__ __launch_bounds__(256, 2) void conv2d_up2(Up2Params p) {
 
         // ---- epilogue: D col = lane & 31 = position r, row = (reg & 3) + 8 * (reg >> 2) + 4 * half = cout.  A lane holds the two
         // x-parities of its position = two adjacent output pixels.
-        const int r = e_r0 + l31;
+        const int r = e_r0 + lc;
         const bool pair_ok = (p.ys[2] & 1) == 0 && (p.ys[1] & 1) == 0 && (p.ys[0] & 1) == 0 && (((uintptr_t)p.y) & 7) == 0 && p.ys[3] == 1;
 #pragma unroll
         for (int nt = 0; nt < 2; nt++) {
-            const int q = e_q0 + 2 * wave + nt;
+            const int q = e_q0 + (2 * wave + nt) * G::RG + lr;
 #pragma unroll
             for (int a = 0; a < 2; a++) {
                 const bool row_ok = a == 0 ? q <= p.H : q < p.H;
@@ -221,10 +230,12 @@ __global__ __launch_bounds__(256, 2) void conv2d_up2(Up2Params p) {
     }
 }
 
-inline int launch_up2(const Up2Params& p0, hipStream_t s) {
+template <int TRW>
+int launch_up2_t(const Up2Params& p0, hipStream_t s) {
+    typedef UGeo<TRW> G;
     Up2Params p = p0;
-    p.tilesX = (p.W + U_TR - 1) / U_TR;
-    p.tilesY = (p.H + 1 + U_TQ - 1) / U_TQ;
+    p.tilesX = (p.W + TRW - 1) / TRW;
+    p.tilesY = (p.H + 1 + G::TQ - 1) / G::TQ;
     p.mblocks = p.CoutP / U_BM;
     const int64_t tiles = (int64_t)p.N * p.tilesX * p.tilesY * p.mblocks;
     if (tiles > 0x7fffffffLL) return PG_ERR_TOO_LARGE;
@@ -233,20 +244,26 @@ inline int launch_up2(const Up2Params& p0, hipStream_t s) {
     const size_t lds = ((size_t)2 * U_LDS_BUF + 2 * cin_loop + 2 * U_BM) * sizeof(float);
     if (lds > 160 * 1024) return PG_ERR_UNSUPPORTED;
     int per_cu = (int)((160 * 1024) / lds);
-    if (per_cu > 2) per_cu = 2;                             // ~190 VGPRs x 4 waves per workgroup
+    if (per_cu > 2) per_cu = 2;                             // ~230 VGPRs x 4 waves per workgroup
     const int64_t blocks = tiles < (int64_t)num_cu() * per_cu ? tiles : (int64_t)num_cu() * per_cu;
     if (p.in_scale) {
         static PerDeviceOnce a1;
-        const hipError_t e = a1.run([] { return hipFuncSetAttribute((const void*)conv2d_up2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+        const hipError_t e = a1.run([] { return hipFuncSetAttribute((const void*)conv2d_up2<true, TRW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
         if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL((conv2d_up2<true>), dim3((unsigned)blocks), dim3(256), lds, s, p);
+        hipLaunchKernelGGL((conv2d_up2<true, TRW>), dim3((unsigned)blocks), dim3(256), lds, s, p);
     } else {
         static PerDeviceOnce a0;
-        const hipError_t e = a0.run([] { return hipFuncSetAttribute((const void*)conv2d_up2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+        const hipError_t e = a0.run([] { return hipFuncSetAttribute((const void*)conv2d_up2<false, TRW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
         if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL((conv2d_up2<false>), dim3((unsigned)blocks), dim3(256), lds, s, p);
+        hipLaunchKernelGGL((conv2d_up2<false, TRW>), dim3((unsigned)blocks), dim3(256), lds, s, p);
     }
     return launch_status();
+}
+
+inline int launch_up2(const Up2Params& p, hipStream_t s) {
+    if (p.W > 16) return launch_up2_t<32>(p, s);
+    if (p.W > 8) return launch_up2_t<16>(p, s);
+    return launch_up2_t<8>(p, s);
 }
 
 }  // namespace pgconv

@@ -1043,7 +1043,8 @@ def test_one_channel_stencil_conv(n, h, w, cout, act):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('n,cin,cout,h,w,mod', [(2, 16, 32, 8, 32, True), (1, 5, 7, 9, 13, True), (3, 24, 40, 17, 33, False), (1, 64, 64, 32, 64, True),
-                                               (1, 3, 2, 1, 1, True), (2, 8, 33, 2, 40, False), (1, 17, 5, 40, 2, True), (1, 9, 64, 8, 31, True)])
+                                               (1, 3, 2, 1, 1, True), (2, 8, 33, 2, 40, False), (1, 17, 5, 40, 2, True), (1, 9, 64, 8, 31, True),
+                                               (2, 16, 40, 16, 16, True), (2, 32, 32, 8, 8, True), (1, 8, 8, 33, 7, False)])      # 16- and 8-wide position tiles
 def test_fused_up2_transposed_conv(n, cin, cout, h, w, mod):
     """pg_conv2d_up2_forward (all four parities of the stride-2 transposed 3x3 convolution in one launch, modulation prologue,
     demodulation epilogue, pitched output) against conv_transpose2d in float64."""

@@ -244,14 +244,14 @@ int pg_spade_feat_assemble(const float* feat_upper, const float* feat_lower, con
                            float* out, int N, int C, int H, int W, void* stream);
 int pg_conv2d_abi_version(void);
 
-/* Weight gradient of a stride-1 float32 NCHW convolution (3x3 or 1x1) -- what conv2d_gradfix.py:137-150 asks
+/* Weight gradient of a float32 NCHW convolution (3x3 at stride 1 or 2, 1x1 at stride 1) -- what conv2d_gradfix.py:137-150 asks
  * aten::cudnn_convolution_backward_weight for:
- *   dw[co, ci, ky, kx] = sum_{n, oy, ox} dy[n, co, oy, ox] * x[n, ci, oy + ky - pad_y, ox + kx - pad_x]
+ *   dw[co, ci, ky, kx] = sum_{n, oy, ox} dy[n, co, oy, ox] * x[n, ci, stride * oy + ky - pad_y, stride * ox + kx - pad_x]
  * A GEMM over pixels on the fp32 MFMA, split `splits` ways over the pixel axis with a fixed-order second pass (deterministic).
  * pg_conv2d_wgrad_plan returns the `splits` to use (0 = geometry not covered); `workspace` holds splits * KH*KW * Cout * Cin floats. */
-int pg_conv2d_wgrad_plan(int N, int Cin, int OH, int OW, int Cout, int KH, int KW);
+int pg_conv2d_wgrad_plan(int N, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride);
 int pg_conv2d_wgrad(const float* x, const float* dy, float* dw, float* workspace,
-                    int N, int Cin, int H, int W, int Cout, int KH, int KW, int pad_y, int pad_x, int OH, int OW,
+                    int N, int Cin, int H, int W, int Cout, int KH, int KW, int stride, int pad_y, int pad_x, int OH, int OW,
                     int splits, void* stream);
 
 /* ------------------------------------------------------------------------

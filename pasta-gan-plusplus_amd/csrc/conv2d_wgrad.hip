@@ -1,9 +1,9 @@
-// Weight gradient of a stride-1 fp32 NCHW convolution for gfx950 as a GEMM over pixels on v_mfma_f32_32x32x2_f32.
+// Weight gradient of a stride-1 (3x3, 1x1) or stride-2 (3x3) fp32 NCHW convolution for gfx950 as a GEMM over pixels on v_mfma_f32_32x32x2_f32.
 //
 // What it replaces in the reference: `aten::cudnn_convolution_backward_weight` behind conv2d_gradfix
 // (torch_utils/ops/conv2d_gradfix.py:137-150) for the geometries that carry the training step's FLOPs (3x3 and 1x1,
 // stride 1: the SPADE blocks, the style-branch conv1 layers, ToRGB, the discriminator's conv0):
-//     dw[co, ci, ky, kx] = sum_{n, oy, ox} dy[n, co, oy, ox] * x[n, ci, oy + ky - pad_y, ox + kx - pad_x]
+//     dw[co, ci, ky, kx] = sum_{n, oy, ox} dy[n, co, oy, ox] * x[n, ci, S oy + ky - pad_y, S ox + kx - pad_x]
 //
 // GEMM view:  M = Cout (A = dy: for a fixed cout the pixels are contiguous -> K-contiguous),
 //             N = Cin, once per tap (B = x shifted by the tap: K-contiguous as well),
@@ -22,15 +22,15 @@ namespace {
 using namespace pg;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int WG_TW = 32, WG_R = 2;            // pixel chunk: WG_R rows x WG_TW columns
-constexpr int WG_PIX = WG_TW * WG_R;
+constexpr int WG_TW = 32;                      // pixel chunk: R rows x WG_TW columns of dy (R = 2 at stride 1, 1 at stride 2: the x footprint must fit LDS twice)
 constexpr int WG_BM = 64, WG_BN = 64;
 
-template <int KH, int KW>
+template <int KH, int KW, int S>
 struct WGeo {
     static constexpr int T = KH * KW;
-    static constexpr int IH = WG_R + KH - 1, IW = WG_TW + KW - 1;
-    static constexpr int PA = WG_PIX + 1;                               // dy row pitch (odd)
+    static constexpr int R = S == 1 ? 2 : 1, PIX = WG_TW * R;
+    static constexpr int IH = (R - 1) * S + KH, IW = (WG_TW - 1) * S + KW;
+    static constexpr int PA = PIX + 1;                                  // dy row pitch (odd)
     static constexpr int PB = (IH * IW) | 1;                            // x plane pitch (odd)
     static constexpr int LDS_FLOATS = 2 * ((WG_BM * PA + 255) / 256 + (WG_BN * PB + 255) / 256) * 256;   // two staging buffers of whole 256-lane DMA rows
 };
@@ -51,9 +51,10 @@ constexpr unsigned WG_SENTINEL = 0x80000000u;     // byte offset beyond any desc
 // CU: waves 0-3 multiply (9 x 16 accumulators each), waves 4-7 only request the next chunk (52 requests + M0 traffic per lane and
 // chunk) -- issued by the multiplying waves themselves those requests cost 20 % of the kernel (measured: 88 -> 110 TFLOP/s with
 // the requests removed), from a wave of their own they overlap the other wave's MFMAs on the same SIMD.
-template <int KH, int KW>
+template <int KH, int KW, int S>
 __global__ __launch_bounds__(512, 1) void conv2d_wgrad(WgradParams p) {
-    typedef WGeo<KH, KW> G;
+    typedef WGeo<KH, KW, S> G;
+    constexpr int WG_R = G::R, WG_PIX = G::PIX;
     constexpr int NDY = (WG_BM * G::PA + 255) / 256, NX = (WG_BN * G::PB + 255) / 256;
     extern __shared__ float smem[];
     constexpr int BUF = (NDY + NX) * 256;       // floats per staging buffer: dy [64 co][PA] then x [64 ci][PB], whole DMA rows
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(512, 1) void conv2d_wgrad(WgradParams p) {
             const int ty = c % p.tilesY;
             const int n = c / p.tilesY;
             const int oy0 = ty * WG_R, ox0 = tx * WG_TW;
-            const int iy0 = oy0 - p.pad_y, ix0 = ox0 - p.pad_x;
+            const int iy0 = oy0 * S - p.pad_y, ix0 = ox0 * S - p.pad_x;
             // descriptors based at the chunk origin (the x origin may lie before the tensor: such elements are masked below)
             const uint64_t dyb = (uint64_t)(uintptr_t)(p.dy + ((int64_t)n * p.Cout + co0) * OHW + (int64_t)oy0 * p.OW + ox0);
             const uint64_t xb = (uint64_t)(uintptr_t)(p.x + ((int64_t)n * p.Cin + ci0) * HW) + ((int64_t)iy0 * p.W + ix0) * 4;
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(512, 1) void conv2d_wgrad(WgradParams p) {
         const float* dyt = smem + buf * BUF;
         const float* xt = dyt + NDY * 256;
         const float* a_base = dyt + (mt * 32 + l31) * G::PA + half;
-        const float* b_base = xt + (nt * 32 + l31) * G::PB + half;
+        const float* b_base = xt + (nt * 32 + l31) * G::PB + half * S;
         // One wave per SIMD: nothing hides an LDS round trip but the wave's own MFMAs, so the operands of step kk + 1 are
         // requested before the MFMAs of step kk are issued (register double buffering, order pinned by sched_barrier).
         auto fetch = [&](int kk, float& a, float (&bv)[G::T]) __attribute__((always_inline)) {
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(512, 1) void conv2d_wgrad(WgradParams p) {
 #pragma unroll
             for (int ky = 0; ky < KH; ky++)
 #pragma unroll
-                for (int kx = 0; kx < KW; kx++) bv[ky * KW + kx] = b_base[(r + ky) * G::IW + cc + kx];
+                for (int kx = 0; kx < KW; kx++) bv[ky * KW + kx] = b_base[(r * S + ky) * G::IW + cc * S + kx];
         };
         float a_cur, b_cur[G::T], a_nxt, b_nxt[G::T];
         fetch(0, a_cur, b_cur);
@@ -203,10 +204,10 @@ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 }  // namespace
 
 /* Number of K splits pg_conv2d_wgrad wants (its workspace is splits * KH*KW * Cout * Cin floats); 0 = geometry not covered. */
-PG_EXPORT int pg_conv2d_wgrad_plan(int N, int Cin, int OH, int OW, int Cout, int KH, int KW) {
+PG_EXPORT int pg_conv2d_wgrad_plan(int N, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride) {
     if (N <= 0 || Cin <= 0 || OH <= 0 || OW <= 0 || Cout <= 0) return 0;
-    if (!((KH == 3 && KW == 3) || (KH == 1 && KW == 1))) return 0;
-    const int64_t chunks = (int64_t)N * cdiv(OH, WG_R) * cdiv(OW, WG_TW);
+    if (!((KH == 3 && KW == 3 && (stride == 1 || stride == 2)) || (KH == 1 && KW == 1 && stride == 1))) return 0;
+    const int64_t chunks = (int64_t)N * cdiv(OH, stride == 1 ? 2 : 1) * cdiv(OW, WG_TW);
     const int blocks = cdiv(Cout, WG_BM) * cdiv(Cin, WG_BN);
     int64_t s = ((int64_t)pg::num_cu() + blocks - 1) / blocks;            // one (persistent-for-its-share) workgroup per CU
     if (s > chunks) s = chunks;
@@ -216,15 +217,15 @@ PG_EXPORT int pg_conv2d_wgrad_plan(int N, int Cin, int OH, int OW, int Cout, int
 }
 
 PG_EXPORT int pg_conv2d_wgrad(const float* x, const float* dy, float* dw, float* workspace,
-                              int N, int Cin, int H, int W, int Cout, int KH, int KW, int pad_y, int pad_x, int OH, int OW,
+                              int N, int Cin, int H, int W, int Cout, int KH, int KW, int stride, int pad_y, int pad_x, int OH, int OW,
                               int splits, void* stream) {
     if (!x || !dy || !dw || !workspace || N <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0 || OH <= 0 || OW <= 0 || splits <= 0) return PG_ERR_INVALID_ARG;
-    if (!((KH == 3 && KW == 3) || (KH == 1 && KW == 1))) return PG_ERR_UNSUPPORTED;
-    if (OH != H + 2 * pad_y - KH + 1 || OW != W + 2 * pad_x - KW + 1) return PG_ERR_INVALID_ARG;        // stride 1 only
+    if (!((KH == 3 && KW == 3 && (stride == 1 || stride == 2)) || (KH == 1 && KW == 1 && stride == 1))) return PG_ERR_UNSUPPORTED;
+    if (OH != (H + 2 * pad_y - KH) / stride + 1 || OW != (W + 2 * pad_x - KW) / stride + 1 || pad_y < 0 || pad_x < 0) return PG_ERR_INVALID_ARG;
     WgradParams p;
     p.x = x; p.dy = dy; p.ws = workspace;
     p.N = N; p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout; p.OH = OH; p.OW = OW; p.pad_y = pad_y; p.pad_x = pad_x;
-    p.tilesX = cdiv(OW, WG_TW); p.tilesY = cdiv(OH, WG_R);
+    p.tilesX = cdiv(OW, WG_TW); p.tilesY = cdiv(OH, stride == 1 ? 2 : 1);
     const int64_t chunks = (int64_t)N * p.tilesX * p.tilesY;
     if (chunks > 0x7fffffffLL) return PG_ERR_TOO_LARGE;
     p.chunks = (int)chunks; p.splits = splits;
@@ -232,19 +233,16 @@ PG_EXPORT int pg_conv2d_wgrad(const float* x, const float* dy, float* dw, float*
     const int64_t blocks = (int64_t)p.coB * p.ciB * splits;
     if (blocks > 0x7fffffffLL) return PG_ERR_TOO_LARGE;
     hipStream_t s = (hipStream_t)stream;
-    if (KH == 3) {
-        const size_t lds = WGeo<3, 3>::LDS_FLOATS * sizeof(float);
-        static pg::PerDeviceOnce attr;
-        const hipError_t e = attr.run([] { return hipFuncSetAttribute((const void*)conv2d_wgrad<3, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
-        if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL((conv2d_wgrad<3, 3>), dim3((unsigned)blocks), dim3(512), lds, s, p);
-    } else {
-        const size_t lds = WGeo<1, 1>::LDS_FLOATS * sizeof(float);
-        static pg::PerDeviceOnce attr1;
-        const hipError_t e = attr1.run([] { return hipFuncSetAttribute((const void*)conv2d_wgrad<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
-        if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL((conv2d_wgrad<1, 1>), dim3((unsigned)blocks), dim3(512), lds, s, p);
-    }
+#define PG_WGRAD(KK, SS) { \
+        const size_t lds = WGeo<KK, KK, SS>::LDS_FLOATS * sizeof(float); \
+        static pg::PerDeviceOnce attr; \
+        const hipError_t e = attr.run([] { return hipFuncSetAttribute((const void*)conv2d_wgrad<KK, KK, SS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }); \
+        if (e != hipSuccess) return (int)e; \
+        hipLaunchKernelGGL((conv2d_wgrad<KK, KK, SS>), dim3((unsigned)blocks), dim3(512), lds, s, p); }
+    if (KH == 3 && stride == 1) PG_WGRAD(3, 1)
+    else if (KH == 3) PG_WGRAD(3, 2)
+    else PG_WGRAD(1, 1)
+#undef PG_WGRAD
     int st = pg::launch_status();
     if (st != PG_OK) return st;
     const int64_t total = (int64_t)KH * KW * Cout * Cin;

@@ -88,9 +88,9 @@ def _init(plugin_name='conv2d_plugin'):
         lib.pg_spade_norm.restype = i
         lib.pg_spade_norm.argtypes = [vp, vp, vp, vp, vp, vp, i, i64, vp]
         lib.pg_conv2d_wgrad_plan.restype = i
-        lib.pg_conv2d_wgrad_plan.argtypes = [i] * 7
+        lib.pg_conv2d_wgrad_plan.argtypes = [i] * 8
         lib.pg_conv2d_wgrad.restype = i
-        lib.pg_conv2d_wgrad.argtypes = [vp, vp, vp, vp] + [i] * 12 + [vp]
+        lib.pg_conv2d_wgrad.argtypes = [vp, vp, vp, vp] + [i] * 13 + [vp]
         lib.pg_conv2d_up2_forward.restype = i
         lib.pg_conv2d_up2_forward.argtypes = [vp, vp, vp, i, i, i, i, i, ctypes.POINTER(ctypes.c_int64), vp, vp, vp]
         lib.pg_conv3x3_cin1.restype = i
@@ -325,23 +325,24 @@ def conv_transpose2d_forward(x, packed_phases, cout, out_hw, **fusion):
     return y
 
 
-def weight_gradient(x, dy, weight_shape, pad):
-    """d(loss)/d(weight) of y = conv2d(x, w, stride=1, padding=pad) for 3x3 / 1x1 kernels: a GEMM over pixels on the fp32 MFMA
-    (csrc/conv2d_wgrad.hip).  Returns None when the geometry is not covered (callers then ask aten)."""
+def weight_gradient(x, dy, weight_shape, pad, stride=1):
+    """d(loss)/d(weight) of y = conv2d(x, w, stride, padding=pad) for 3x3 (stride 1 | 2) / 1x1 (stride 1) kernels: a GEMM over pixels
+    on the fp32 MFMA (csrc/conv2d_wgrad.hip).  Returns None when the geometry is not covered (callers then ask aten)."""
     lib = _init().lib
     cout, cin, kh, kw = (int(v) for v in weight_shape)
     n, _, h, w = x.shape
     oh, ow = int(dy.shape[2]), int(dy.shape[3])
-    if x.dtype != torch.float32 or dy.dtype != torch.float32 or (oh, ow) != (h + 2 * pad[0] - kh + 1, w + 2 * pad[1] - kw + 1):
+    stride = int(stride)
+    if x.dtype != torch.float32 or dy.dtype != torch.float32 or min(pad) < 0 or (oh, ow) != ((h + 2 * pad[0] - kh) // stride + 1, (w + 2 * pad[1] - kw) // stride + 1):
         return None
-    splits = lib.pg_conv2d_wgrad_plan(n, cin, oh, ow, cout, kh, kw)
+    splits = lib.pg_conv2d_wgrad_plan(n, cin, oh, ow, cout, kh, kw, stride)
     if splits <= 0:
         return None
     x, dy = x.contiguous(), dy.contiguous()
     dw = torch.empty([cout, cin, kh, kw], dtype=torch.float32, device=x.device)
     ws = torch.empty([splits * kh * kw * cout * cin], dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        st = lib.pg_conv2d_wgrad(nat.ptr(x), nat.ptr(dy), nat.ptr(dw), nat.ptr(ws), n, cin, h, w, cout, kh, kw, int(pad[0]), int(pad[1]), oh, ow, splits,
+        st = lib.pg_conv2d_wgrad(nat.ptr(x), nat.ptr(dy), nat.ptr(dw), nat.ptr(ws), n, cin, h, w, cout, kh, kw, stride, int(pad[0]), int(pad[1]), oh, ow, splits,
                                  nat.stream_of(x))
     nat.check(st, 'pg_conv2d_wgrad')
     return dw

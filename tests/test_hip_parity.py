@@ -944,20 +944,22 @@ def test_modulated_conv2d_fp16_prenorm_golden(golden):
     close(y.float(), g[f'{name}/y'], rtol=1e-2, atol=1e-2)
 
 
-@pytest.mark.parametrize('shape', [(2, 16, 24, 20, 37, 3), (1, 70, 130, 9, 33, 3), (3, 64, 64, 17, 17, 1), (2, 5, 7, 8, 40, 1), (8, 64, 64, 64, 64, 3)],
-                         ids=['3x3_ragged', '3x3_multi_block', '1x1', '1x1_tiny', '3x3_many_chunks'])
+@pytest.mark.parametrize('shape', [(2, 16, 24, 20, 37, 3, 1), (1, 70, 130, 9, 33, 3, 1), (3, 64, 64, 17, 17, 1, 1), (2, 5, 7, 8, 40, 1, 1), (8, 64, 64, 64, 64, 3, 1),
+                                   (2, 16, 24, 21, 37, 3, 2), (1, 70, 130, 10, 66, 3, 2), (4, 64, 64, 65, 65, 3, 2)],
+                         ids=['3x3_ragged', '3x3_multi_block', '1x1', '1x1_tiny', '3x3_many_chunks', '3x3s2_ragged', '3x3s2_multi_block', '3x3s2_odd_input'])
 def test_native_weight_gradient_exact(shape):
-    """csrc/conv2d_wgrad.hip (GEMM over pixels, K-split with a fixed-order second pass) on small-integer data: every partial sum is
-    exact in fp32, so the result must equal the fp64 weight gradient bit for bit."""
+    """csrc/conv2d_wgrad.hip (GEMM over pixels, K-split with a fixed-order second pass; stride 1 and 2) on small-integer data: every
+    partial sum is exact in fp32, so the result must equal the fp64 weight gradient bit for bit."""
     from torch_utils.ops import conv2d_mfma
-    n, cin, cout, h, w, k = shape
-    gen = torch.Generator().manual_seed(n * 1000 + cin)
+    n, cin, cout, h, w, k, st = shape
+    gen = torch.Generator().manual_seed(n * 1000 + cin + st)
     x = torch.randint(-3, 4, [n, cin, h, w], generator=gen).float()
-    dy = torch.randint(-2, 3, [n, cout, h, w], generator=gen).float()
-    got = conv2d_mfma.weight_gradient(x.to(DEV), dy.to(DEV), [cout, cin, k, k], (k // 2, k // 2))
+    oh, ow = (h + 2 * (k // 2) - k) // st + 1, (w + 2 * (k // 2) - k) // st + 1
+    dy = torch.randint(-2, 3, [n, cout, oh, ow], generator=gen).float()
+    got = conv2d_mfma.weight_gradient(x.to(DEV), dy.to(DEV), [cout, cin, k, k], (k // 2, k // 2), stride=st)
     assert got is not None
     wref = torch.zeros([cout, cin, k, k], dtype=torch.float64, requires_grad=True)
-    torch.nn.functional.conv2d(x.double(), wref, padding=k // 2).backward(dy.double())
+    torch.nn.functional.conv2d(x.double(), wref, padding=k // 2, stride=st).backward(dy.double())
     assert torch.equal(got.double().cpu(), wref.grad), float((got.double().cpu() - wref.grad).abs().max())
 
 

@@ -166,8 +166,13 @@ class _Conv2dMfma(torch.autograd.Function):
             dx = _input_gradient(dy, x.shape, weight, stride, padding, transposed, output_padding)
         want_w = ctx.needs_input_grad[1] and not weight_gradients_disabled
         want_b = has_bias and ctx.needs_input_grad[2]
-        if want_w and native_weight_gradients and not transposed and stride in (1, 2) and not torch.is_grad_enabled():
-            dw = conv2d_mfma.weight_gradient(x, dy, weight.shape, padding, stride=stride)      # a GEMM over pixels (csrc/conv2d_wgrad.hip); None = not covered
+        if want_w and native_weight_gradients and stride in (1, 2) and not torch.is_grad_enabled():
+            if not transposed:
+                dw = conv2d_mfma.weight_gradient(x, dy, weight.shape, padding, stride=stride)      # a GEMM over pixels (csrc/conv2d_wgrad.hip); None = not covered
+            else:
+                # y = conv_transpose2d(x, w[Cin, Cout]):  dw[ci, co, ky, kx] = sum x[ci, iy, ix] dy[co, s iy + ky - p, s ix + kx - p] -- the weight
+                # gradient of the strided convolution dy -> x, whose 'OIHW' kernel has O = Cin, I = Cout: the same kernel with the roles swapped
+                dw = conv2d_mfma.weight_gradient(dy, x, weight.shape, padding, stride=stride)
         if want_b and (dw is not None or not want_w):
             db = dy.sum(dim=[0, 2, 3])
         mask = [dx is None and ctx.needs_input_grad[0], want_w and dw is None, want_b and db is None]

@@ -1107,3 +1107,34 @@ def test_streaming_1x1_conv(n, cin, cin2, cout, h, w, fused):
         ref = ref * s_out.double()[:, :, None, None] + bias.double()[None, :, None, None]
         ref = (torch.nn.functional.leaky_relu(ref, 0.2) * 1.3).clamp(-1.5, 1.5) + res.double()
     close(y, ref, 1e-5, 3e-6 * scale_of(ref))
+
+
+@pytest.mark.gpu
+def test_transposed_conv_weight_gradient_native():
+    """conv_transpose2d(stride 2): its weight gradient is the weight gradient of the strided convolution dy -> x with the roles swapped,
+    so conv2d_gradfix sends it to the same native kernel (exact on small integers; the route is asserted)."""
+    from torch_utils.ops import conv2d_gradfix, conv2d_mfma
+    gen = torch.Generator().manual_seed(77)
+    x = torch.randint(-2, 3, [2, 24, 9, 11], generator=gen).float()
+    w = torch.randint(-2, 3, [24, 40, 3, 3], generator=gen).float()
+    calls, real, was = [0], conv2d_mfma.weight_gradient, conv2d_gradfix.native_weight_gradients
+    conv2d_gradfix.native_weight_gradients = True
+
+    def counting(*a, **k):
+        out = real(*a, **k)
+        calls[0] += out is not None
+        return out
+    conv2d_mfma.weight_gradient = counting
+    try:
+        xd, wd = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+        y = conv2d_gradfix.conv_transpose2d(xd, wd, stride=2, padding=0)
+        dy = torch.randint(-2, 3, list(y.shape), generator=gen).float()
+        gx, gw = torch.autograd.grad(y, [xd, wd], dy.to(DEV))
+    finally:
+        conv2d_mfma.weight_gradient = real
+        conv2d_gradfix.native_weight_gradients = was
+    assert calls[0] == 1
+    x64, w64 = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    rx, rw = torch.autograd.grad(torch.nn.functional.conv_transpose2d(x64, w64, stride=2), [x64, w64], dy.double())
+    assert torch.equal(gw.double().cpu(), rw)
+    close(gx, rx, 1e-5, 1e-5 * scale_of(rx))

@@ -53,11 +53,11 @@ _cached_plugins = dict()
 class NativePlugin:
     """A loaded C-ABI library: ``plugin.lib`` is the ``ctypes.CDLL``; ``plugin.path`` its file."""
 
-    def __init__(self, name, path):
+    def __init__(self, name, path, abi_name=None):
         self.name = name
         self.path = path
         self.lib = ctypes.CDLL(path)
-        probe = getattr(self.lib, 'pg_' + name.replace('_plugin', '') + '_abi_version', None)
+        probe = getattr(self.lib, 'pg_' + (abi_name or name).replace('_plugin', '') + '_abi_version', None)
         if probe is None:
             raise RuntimeError(f'{path} does not export its ABI version; rebuild it from csrc/')
         probe.restype = ctypes.c_int
@@ -153,7 +153,7 @@ def _resolve_sources(module_name, sources):
     return [s if os.path.isabs(s) else os.path.join(CSRC_DIR, s) for s in sources]
 
 
-def get_plugin(module_name, sources=None, extra_hipcc_flags=(), build_only=False, **_ignored_build_kwargs):
+def get_plugin(module_name, sources=None, extra_hipcc_flags=(), build_only=False, abi_name=None, **_ignored_build_kwargs):
     """Build (if stale) and load the native plugin `module_name`; returns a `NativePlugin`.
 
     Extra keyword arguments of the reference signature (``extra_cuda_cflags=...``) are accepted
@@ -189,7 +189,7 @@ def get_plugin(module_name, sources=None, extra_hipcc_flags=(), build_only=False
             fcntl.flock(lock, fcntl.LOCK_UN)
     if build_only:
         return so_path
-    plugin = NativePlugin(module_name, so_path)
+    plugin = NativePlugin(module_name, so_path, abi_name)      # abi_name: dev variants of a plugin built under another name
     _cached_plugins[module_name] = plugin
     return plugin
 

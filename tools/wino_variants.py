@@ -18,7 +18,7 @@ from torch_utils.ops import conv2d_mfma
 from torch_utils.ops import _native as nat
 libs = {}
 if os.environ.get('WINO_PREV'):                  # a prebuilt csrc/wino_prev.so (older revision of the sources) as variant -1
-    prev = custom_ops.NativePlugin('wino_prev', os.path.join(custom_ops.CSRC_DIR, 'wino_prev.so'))
+    prev = custom_ops.NativePlugin('wino_prev', os.path.join(custom_ops.CSRC_DIR, 'wino_prev.so'), 'conv2d_plugin')
     _orig0 = custom_ops.get_plugin
     custom_ops.get_plugin = lambda name, **kw: prev
     conv2d_mfma._plugin = None
@@ -28,7 +28,7 @@ for v in VARIANTS:
     conv2d_mfma._plugin = None
     custom_ops.PLUGIN_SOURCES[f'wino_exp{v}'] = SRC
     _orig = custom_ops.get_plugin
-    custom_ops.get_plugin = lambda name, _v=v, **kw: _orig(name, extra_hipcc_flags=[f'-DWINO_EXP={_v}'], **kw)
+    custom_ops.get_plugin = lambda name, _v=v, **kw: _orig(name, extra_hipcc_flags=[f'-DWINO_EXP={_v}'], abi_name='conv2d_plugin', **kw)
     libs[v] = conv2d_mfma._init(f'wino_exp{v}')
     custom_ops.get_plugin = _orig
 

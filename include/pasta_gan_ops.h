@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 2
+#define PG_ABI_VERSION 3
 
 enum pg_dtype { PG_F32 = 0, PG_F16 = 1, PG_BF16 = 2, PG_F64 = 3 };
 
@@ -199,6 +199,17 @@ int pg_conv2d_winograd_forward(const float* x, const float* packed_u, float* y,
  *   dcoefs[n,o] = rsqrt(sum_{i,k} (w[o,i,k] * scale * styles[n,i])^2 + 1e-8);  w is OIHW. */
 int pg_modconv_dcoefs(const float* w, const float* styles, float* dcoefs,
                       int N, int Cout, int Cin, int KHW, float scale, void* stream);
+
+/* The same coefficients in two steps, for callers that keep weights across calls (eval): the tap energy
+ *   w2[o,i] = scale^2 * sum_k w[o,i,k]^2        (pg_modconv_w2: weights only, once per weight version)
+ * and the per-call style preparation (pg_modconv_prep, one launch):
+ *   normalize != 0: smax[n] = max(max_i |styles[n,i]|, 1e-20), s' = styles / smax (the half-precision pre-normalisation of
+ *                   networks.py:57-59); s_norm (float32 [N,Cin]) and s16 (bf16 / fp16 [N,Cin], half_dtype) receive s' when non-NULL
+ *   normalize == 0: s' = styles
+ *   out[n,o] = demodulate ? rsqrt(sum_i w2[o,i] * s'[n,i]^2 + 1e-8) : smax[n]. */
+int pg_modconv_w2(const float* w, float* w2, int Cout, int Cin, int KHW, float scale, void* stream);
+int pg_modconv_prep(const float* w2, const float* styles, float* out, float* s_norm, void* s16, int half_dtype,
+                    int N, int Cout, int Cin, int normalize, int demodulate, void* stream);
 
 /* Stride-2 transposed 3x3 convolution, all four output parities in one launch (csrc/conv2d_up2.h) -- the `up = 2` layers:
  * conv2d_gradfix.conv_transpose2d(stride=2, padding=0) behind conv2d_resample.py:125-142, with the modulation / demodulation of

@@ -92,6 +92,68 @@ __global__ __launch_bounds__(256) void dcoefs_kernel(const float* __restrict__ w
     if (threadIdx.x == 0) d[blockIdx.x] = rsqrtf(red[0] + red[1] + red[2] + red[3] + 1e-8f);
 }
 
+// The same coefficients from the per-(o, i) tap energy  W2[o,i] = scale^2 * sum_k w[o,i,k]^2  (weights only: computed once per
+// weight version and cached by the caller):  dcoefs[n,o] = rsqrt(sum_i W2[o,i] * s[n,i]^2 + 1e-8) -- 1 / KHW of the weight bytes
+// per call.  One thread per (o, i).
+__global__ __launch_bounds__(256) void modconv_w2_kernel(const float* __restrict__ w, float* __restrict__ w2, int64_t total, int KHW, float scale2) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const float* we = w + e * KHW;
+    float acc = 0.f;
+    for (int k = 0; k < KHW; k++) acc = fmaf(we[k], we[k], acc);
+    w2[e] = acc * scale2;
+}
+
+// Style preparation of one modulated convolution in a single launch (workgroup = 4 waves = 16 couts of sample blockIdx.y):
+//   normalize != 0 (the half-precision pre-normalisation of networks.py:57-59):  smax = max(max_i |s[n,i]|, 1e-20), s' = s / smax,
+//       s_norm[n,i] = s' (float32) and, when s16 is given, the same rounded to bf16 / fp16;   otherwise s' = s
+//   out[n,o] = demodulate ? rsqrt(sum_i W2[o,i] * s'^2 + 1e-8) : smax
+__global__ __launch_bounds__(256) void modconv_prep_kernel(const float* __restrict__ w2, const float* __restrict__ styles, float* __restrict__ out,
+                                                           float* __restrict__ s_norm, unsigned short* __restrict__ s16, int half_dtype,
+                                                           int Cout, int Cin, int normalize, int demodulate) {
+    extern __shared__ float sq[];                    // s'^2 of this sample
+    __shared__ float red[4];
+    const int n = blockIdx.y, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const float* sn = styles + (int64_t)n * Cin;
+    float smax = 1.f;
+    if (normalize) {
+        float m = 0.f;
+        for (int i = t; i < Cin; i += 256) m = fmaxf(m, fabsf(sn[i]));
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off, 64));
+        if (lane == 0) red[wave] = m;
+        __syncthreads();
+        smax = fmaxf(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])), 1e-20f);
+    }
+    for (int i = t; i < Cin; i += 256) {
+        const float v = normalize ? sn[i] / smax : sn[i];
+        sq[i] = v * v;
+        if (normalize && blockIdx.x == 0) {
+            if (s_norm) s_norm[(int64_t)n * Cin + i] = v;
+            if (s16) {
+                unsigned short h;
+                if (half_dtype == PG_BF16) { const __bf16 b = (__bf16)v; h = __builtin_bit_cast(unsigned short, b); }
+                else { const _Float16 b = (_Float16)v; h = __builtin_bit_cast(unsigned short, b); }
+                s16[(int64_t)n * Cin + i] = h;
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int o = blockIdx.x * 16 + wave * 4 + j;
+        if (o >= Cout) break;                                    // wave-uniform
+        float acc = 0.f;
+        if (demodulate) {
+            const float* wo = w2 + (int64_t)o * Cin;
+            for (int i = lane; i < Cin; i += 64) acc = fmaf(wo[i], sq[i], acc);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+        }
+        if (lane == 0) out[(int64_t)n * Cout + o] = demodulate ? rsqrtf(acc + 1e-8f) : smax;
+    }
+}
+
 // ------------------------------------------------------------------ instance-norm statistics (two passes over one plane)
 constexpr int IN_THREADS = 1024;
 __device__ __forceinline__ float block_sum_1024(float v, float* red) {
@@ -606,6 +668,23 @@ PG_EXPORT int pg_modconv_dcoefs(const float* w, const float* styles, float* dcoe
                                 int N, int Cout, int Cin, int KHW, float scale, void* stream) {
     if (!w || !styles || !dcoefs || N <= 0 || Cout <= 0 || Cin <= 0 || KHW <= 0) return PG_ERR_INVALID_ARG;
     hipLaunchKernelGGL(dcoefs_kernel, dim3((unsigned)(N * Cout)), dim3(256), 0, (hipStream_t)stream, w, styles, dcoefs, Cout, Cin, KHW, scale);
+    return pg::launch_status();
+}
+
+PG_EXPORT int pg_modconv_w2(const float* w, float* w2, int Cout, int Cin, int KHW, float scale, void* stream) {
+    if (!w || !w2 || Cout <= 0 || Cin <= 0 || KHW <= 0) return PG_ERR_INVALID_ARG;
+    const int64_t total = (int64_t)Cout * Cin;
+    hipLaunchKernelGGL(modconv_w2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, w2, total, KHW, scale * scale);
+    return pg::launch_status();
+}
+
+PG_EXPORT int pg_modconv_prep(const float* w2, const float* styles, float* out, float* s_norm, void* s16, int half_dtype,
+                              int N, int Cout, int Cin, int normalize, int demodulate, void* stream) {
+    if (!styles || !out || N <= 0 || Cout <= 0 || Cin <= 0 || (demodulate && !w2)) return PG_ERR_INVALID_ARG;
+    if (s16 && half_dtype != PG_BF16 && half_dtype != PG_F16) return PG_ERR_INVALID_ARG;
+    if (N > 65535 || (size_t)Cin * 4 > 64 * 1024) return PG_ERR_TOO_LARGE;
+    hipLaunchKernelGGL(modconv_prep_kernel, dim3((unsigned)((Cout + 15) / 16), (unsigned)N), dim3(256), (size_t)Cin * 4, (hipStream_t)stream,
+                       w2, styles, out, s_norm, (unsigned short*)s16, half_dtype, Cout, Cin, normalize, demodulate);
     return pg::launch_status();
 }
 

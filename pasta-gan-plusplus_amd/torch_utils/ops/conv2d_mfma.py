@@ -83,6 +83,10 @@ def _init(plugin_name='conv2d_plugin'):
         lib.pg_spade_feat_assemble.argtypes = [vp] * 11 + [i, i, i, i, vp]
         lib.pg_modconv_dcoefs.restype = i
         lib.pg_modconv_dcoefs.argtypes = [vp, vp, vp, i, i, i, i, f, vp]
+        lib.pg_modconv_w2.restype = i
+        lib.pg_modconv_w2.argtypes = [vp, vp, i, i, i, f, vp]
+        lib.pg_modconv_prep.restype = i
+        lib.pg_modconv_prep.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, i, vp]
         lib.pg_instance_norm_stats.restype = i
         lib.pg_instance_norm_stats.argtypes = [vp, vp, vp, i, i64, f, vp]
         lib.pg_spade_norm.restype = i
@@ -462,6 +466,40 @@ def modconv_dcoefs(weight, styles, scale=1.0):
         st = lib.pg_modconv_dcoefs(nat.ptr(weight), nat.ptr(styles), nat.ptr(d), n, cout, cin, kh * kw, float(scale), nat.stream_of(weight))
     nat.check(st, 'pg_modconv_dcoefs')
     return d
+
+
+def modconv_w2(weight, scale=1.0):
+    """Tap energy scale^2 * sum_k w[o,i,k]^2 -> [Cout, Cin]: the weight-only half of the demodulation coefficients
+    (networks.py:64-68), computed once per weight version by callers that cache it."""
+    lib = _init().lib
+    weight = _f32c(weight.detach(), 'weight')
+    cout, cin, kh, kw = weight.shape
+    w2 = torch.empty([cout, cin], dtype=torch.float32, device=weight.device)
+    with torch.cuda.device(weight.device):
+        st = lib.pg_modconv_w2(nat.ptr(weight), nat.ptr(w2), cout, cin, kh * kw, float(scale), nat.stream_of(weight))
+    nat.check(st, 'pg_modconv_w2')
+    return w2
+
+
+def modconv_prep(w2, styles, cout, normalize=False, demodulate=True, half_dtype=None):
+    """One launch per modulated convolution: returns (out [N, Cout], s_norm, s16).  out = demodulation coefficients of the
+    (normalised, if `normalize`) styles, or the per-sample style maximum when not demodulating; s_norm / s16 = the
+    normalised styles in float32 / `half_dtype` (None unless `normalize`)."""
+    lib = _init().lib
+    styles = _f32c(styles.detach(), 'styles')
+    n, cin = styles.shape
+    if demodulate:
+        w2 = _f32c(w2, 'w2')
+        assert tuple(w2.shape) == (cout, cin)
+    out = torch.empty([n, cout], dtype=torch.float32, device=styles.device)
+    s_norm = torch.empty_like(styles) if normalize else None
+    s16 = torch.empty([n, cin], dtype=half_dtype, device=styles.device) if (normalize and half_dtype is not None) else None
+    code = 0 if s16 is None else nat.PG_DTYPE[half_dtype]
+    with torch.cuda.device(styles.device):
+        st = lib.pg_modconv_prep(nat.ptr(w2) if demodulate else None, nat.ptr(styles), nat.ptr(out), nat.ptr(s_norm) if s_norm is not None else None,
+                                 nat.ptr(s16) if s16 is not None else None, code, n, cout, cin, int(bool(normalize)), int(bool(demodulate)), nat.stream_of(styles))
+    nat.check(st, 'pg_modconv_prep')
+    return out, s_norm, s16
 
 
 def instance_norm_stats(x, eps=1e-5):

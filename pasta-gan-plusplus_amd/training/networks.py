@@ -127,7 +127,10 @@ def _modconv_fast(x, weight, styles, noise, up, padding, resample_filter, demodu
     n, _, h, w = x.shape
     cache = cache if cache is not None else _PackCache()
     ep = dict(epilogue) if epilogue else {}
-    dcoefs = conv2d_mfma.modconv_dcoefs(weight, styles) if demodulate else None
+    dcoefs = None
+    if demodulate:      # weight-only tap energy cached per weight version; one small launch per call (networks.py:64-68)
+        w2 = cache.get(('w2',), [weight], lambda: conv2d_mfma.modconv_w2(weight))
+        dcoefs = conv2d_mfma.modconv_prep(w2, styles, cout)[0]
     if up == 1:
         if not conv2d_mfma.supported(kh, kw, 1):
             return None
@@ -214,14 +217,13 @@ def _modconv_fast16(x, weight, styles, noise, up, padding, resample_filter, demo
     taps = 36 if composite else kh * kw
     shared = (up == 1 or composite) and cout * taps > 2 * h * w and os.environ.get('PG_MODCONV16_SHARED', '1') != '0'
     out_scale = None
-    if shared:
-        smax = s32.abs().amax(dim=1, keepdim=True).clamp_min(1e-20)
-        s32 = s32 / smax
-        x = x * s32.to(x.dtype)[:, :, None, None]
-        out_scale = conv2d_mfma.modconv_dcoefs(w32, s32) if demodulate else smax.expand(n, cout).contiguous()
+    w2 = cache.get(('w2',), [weight], lambda: conv2d_mfma.modconv_w2(w32)) if demodulate else None
+    if shared:          # one launch: per-sample maximum, normalised styles (float32 + 16-bit), coefficients of the normalised styles
+        out_scale, s32, s16 = conv2d_mfma.modconv_prep(w2, s32, cout, normalize=True, demodulate=demodulate, half_dtype=x.dtype)
+        x = x * s16[:, :, None, None]
         dcoefs = None
     else:
-        dcoefs = conv2d_mfma.modconv_dcoefs(w32, s32) if demodulate else None
+        dcoefs = conv2d_mfma.modconv_prep(w2, s32, cout)[0] if demodulate else None
     if up == 1:
         if not conv2d_mfma16.supported(kh, kw, 1):
             return None
@@ -243,6 +245,8 @@ def _modconv_fast16(x, weight, styles, noise, up, padding, resample_filter, demo
         if shared:
             packs = cache.get(('up2_shared', flip_weight, x.dtype), [weight],
                               lambda: {ab: conv2d_mfma16.pack_weight(wab, x.dtype, transpose_oi=True)[0] for ab, wab in phases.items()})
+        if noise is not None:           # phase-major copy of the noise map, one pass: [B, 2, 2, h, w]
+            noise_phases = noise.reshape(-1, h, 2, w, 2).permute(0, 2, 4, 1, 3).contiguous()
         for (a, b), wab in phases.items():
             if shared:
                 packed, per = packs[(a, b)], 0
@@ -250,7 +254,7 @@ def _modconv_fast16(x, weight, styles, noise, up, padding, resample_filter, demo
                 packed, per, _ = conv2d_mfma16.pack_weight(wab, x.dtype, transpose_oi=True, styles=s32, dcoefs=dcoefs)
             nz = None
             if noise is not None:       # the phase's samples of the output-resolution noise map
-                nz = noise.reshape(-1, 2 * h, 2 * w)[:, a::2, b::2].contiguous()
+                nz = noise_phases[:, a, b]
             conv2d_mfma16.conv2d_forward(xcl, packed, cout, 3, 3, pad=(1, 1), out_hw=(h, w), y=y, out_step=(2, 2), out_off=(a, b), sample_stride=per,
                                          out_scale=out_scale, noise=nz, **ep)
         return y if res is None else y.add_(res)
@@ -317,14 +321,21 @@ class FullyConnectedLayer(nn.Module):
     def forward(self, x):
         """Equalised-LR dense layer (reference networks.py:115-128): the runtime gains scale the operands, a linear layer
         is one GEMM with the bias in its epilogue (hipBLASLt), anything else hands bias + activation to bias_act."""
-        weight = self.weight.to(x.dtype).mul(self.weight_gain)
+        weight = self.weight.to(x.dtype)
         bias = None
         if self.bias is not None:
             bias = self.bias.to(x.dtype)
             bias = bias if self.bias_gain == 1 else bias.mul(self.bias_gain)
-        if self.activation == 'linear':
-            return torch.nn.functional.linear(x, weight, bias)
-        return bias_act.bias_act(torch.nn.functional.linear(x, weight), bias, act=self.activation)
+        if x.ndim == 2:
+            # the weight gain rides on the GEMM's alpha (no scaled copy of the weight per call)
+            if self.activation == 'linear' and bias is not None:
+                return torch.addmm(bias.unsqueeze(0), x, weight.t(), alpha=self.weight_gain)
+            y = torch.mm(x, weight.t()).mul_(self.weight_gain)
+        else:
+            y = torch.nn.functional.linear(x, weight.mul(self.weight_gain))
+        if self.activation == 'linear' and bias is None:
+            return y
+        return bias_act.bias_act(y, bias, act=self.activation)
 
 
 class _ConvBase(nn.Module):

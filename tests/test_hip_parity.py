@@ -503,6 +503,22 @@ def test_support_kernels_vs_oracle():
     d = conv2d_mfma.modconv_dcoefs(w.to(DEV), s.to(DEV))
     ref = ((w[None] * s[:, None, :, None, None]).square().sum(dim=(2, 3, 4)) + 1e-8).rsqrt()
     close(d, ref, 1e-5, 1e-6)
+    # the cached-tap-energy form used by the network routes, plain and with the half-precision pre-normalisation
+    w2 = conv2d_mfma.modconv_w2(w.to(DEV))
+    close(w2, w.square().sum(dim=(2, 3)), 1e-6, 1e-6)
+    d2, none_a, none_b = conv2d_mfma.modconv_prep(w2, s.to(DEV), 10)
+    assert none_a is None and none_b is None
+    close(d2, ref, 1e-5, 1e-6)
+    wide_w, wide_s = det_tensor('dc.ww', [70, 300, 3, 3]), det_tensor('dc.ws', [5, 300], scale=4.0)
+    smax = wide_s.abs().amax(dim=1, keepdim=True)
+    sn = wide_s / smax
+    for dt in (torch.bfloat16, torch.float16):
+        out, s_norm, s16 = conv2d_mfma.modconv_prep(conv2d_mfma.modconv_w2(wide_w.to(DEV)), wide_s.to(DEV), 70, normalize=True, half_dtype=dt)
+        close(s_norm, sn, 1e-6, 1e-7)
+        assert s16.dtype == dt and torch.equal(s16.cpu(), sn.to(dt))
+        close(out, ((wide_w[None] * sn[:, None, :, None, None]).square().sum(dim=(2, 3, 4)) + 1e-8).rsqrt(), 1e-5, 1e-6)
+    out, s_norm, s16 = conv2d_mfma.modconv_prep(None, wide_s.to(DEV), 70, normalize=True, demodulate=False, half_dtype=torch.bfloat16)
+    close(out, smax.expand(5, 70), 0, 0)
 
 
 # =============================================================== conv2d_resample / modulated_conv2d

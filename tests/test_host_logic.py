@@ -23,7 +23,7 @@ def declared_symbols():
 def test_header_declares_expected_entry_points():
     syms = declared_symbols()
     for s in ('pg_bias_act', 'pg_upfirdn2d', 'pg_conv2d_forward', 'pg_conv2d_pack_weight', 'pg_conv2d_packed_size',
-              'pg_modconv_dcoefs', 'pg_instance_norm_stats', 'pg_spade_norm'):
+              'pg_modconv_dcoefs', 'pg_modconv_w2', 'pg_modconv_prep', 'pg_instance_norm_stats', 'pg_spade_norm'):
         assert s in syms
 
 

@@ -285,6 +285,11 @@ int pg_conv2d16_pack_weight(const float* w, void* packed, int dtype, int Cout, i
                             const int* taps_y, int ntaps_y, const int* taps_x, int ntaps_x,
                             float scale, int flip_hw, int transpose_oi,
                             const float* styles, const float* dcoefs, int nsamples, void* stream);
+/* The same for `ngroups` weight tensors of one shape in ONE launch (the four composite phase kernels of an up-by-2 modulated
+ * convolution share styles / dcoefs): group g reads w + g * w_group_stride (floats) and writes packed[(g * nsamples + n)]. */
+int pg_conv2d16_pack_weight_grouped(const float* w, void* packed, int dtype, int ngroups, int64_t w_group_stride,
+                                    int Cout, int Cin, int KH, int KW, float scale, int flip_hw, int transpose_oi,
+                                    const float* styles, const float* dcoefs, int nsamples, void* stream);
 
 /* Fused epilogue of pg_conv2d16_forward:  v = acc * out_scale[n,co] + noise[n?,oy,ox] * noise_gain + bias[co];
  * v = clamp(act(v) * gain);  y = T(v + residual).  Every pointer may be NULL; all vectors are float32. */

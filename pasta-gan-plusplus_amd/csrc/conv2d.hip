@@ -139,18 +139,26 @@ __global__ __launch_bounds__(256) void modconv_prep_kernel(const float* __restri
         }
     }
     __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int o = blockIdx.x * 16 + wave * 4 + j;
-        if (o >= Cout) break;                                    // wave-uniform
-        float acc = 0.f;
-        if (demodulate) {
-            const float* wo = w2 + (int64_t)o * Cin;
-            for (int i = lane; i < Cin; i += 64) acc = fmaf(wo[i], sq[i], acc);
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    const int o0 = blockIdx.x * 16 + wave * 4;
+    if (o0 >= Cout) return;                                          // wave-uniform
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (demodulate) {
+        const float* wo = w2 + (int64_t)o0 * Cin;
+        const int64_t r1 = o0 + 1 < Cout ? Cin : 0, r2 = o0 + 2 < Cout ? 2 * (int64_t)Cin : 0, r3 = o0 + 3 < Cout ? 3 * (int64_t)Cin : 0;   // rows past Cout re-read row o0
+        for (int i = lane; i < Cin; i += 64) {                       // four independent load streams per lane
+            const float q = sq[i];
+            acc[0] = fmaf(wo[i], q, acc[0]); acc[1] = fmaf(wo[r1 + i], q, acc[1]);
+            acc[2] = fmaf(wo[r2 + i], q, acc[2]); acc[3] = fmaf(wo[r3 + i], q, acc[3]);
         }
-        if (lane == 0) out[(int64_t)n * Cout + o] = demodulate ? rsqrtf(acc + 1e-8f) : smax;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) acc[j] += __shfl_down(acc[j], off, 64);
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (o0 + j < Cout) out[(int64_t)n * Cout + o0 + j] = demodulate ? rsqrtf(acc[j] + 1e-8f) : smax;
     }
 }
 

@@ -11,6 +11,7 @@ using pgconv16::Conv16Params;
 using pgconv16::Half16;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
@@ -23,10 +24,12 @@ struct TapSel { int ny, nx; int ys[8], xs[8]; };
 template <typename T, int KK>                                          // KK = KH * KW of the source weight (compile time: no runtime division)
 __global__ __launch_bounds__(256) void pack16_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, int Cout, int Cin, int KW, TapSel sel,
                                                      int CinP, int CoutP, float scale, int flip, int transpose_oi,
-                                                     const float* __restrict__ styles, const float* __restrict__ dcoefs, int64_t per_sample) {
+                                                     const float* __restrict__ styles, const float* __restrict__ dcoefs, int64_t per_sample,
+                                                     int nsamples, int64_t w_group_stride) {
     constexpr int RUN = 16 * KK, PITCH = RUN + 1;
     __shared__ float tile[64 * PITCH];                                 // [64 couts][16 channels][KK] (+1 pad per cout row)
-    const int n = blockIdx.z, k16 = blockIdx.y, cb = blockIdx.x;
+    const int z = blockIdx.z, n = z % nsamples, k16 = blockIdx.y, cb = blockIdx.x;      // z = group * nsamples + sample
+    w += (int64_t)(z / nsamples) * w_group_stride;
     const int KH = KK / KW, T_ = sel.ny * sel.nx;
     const int co0 = cb * 64, ci0 = k16 * 16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -60,7 +63,7 @@ __global__ __launch_bounds__(256) void pack16_kernel(const float* __restrict__ w
     }
     __syncthreads();
     // ---- store: thread -> (row = tap * 2 + h, cout): 16 bytes = 8 consecutive channels of one tap
-    unsigned short* dst = out + (int64_t)n * per_sample + (int64_t)k16 * T_ * 2 * CoutP * 8;
+    unsigned short* dst = out + (int64_t)z * per_sample + (int64_t)k16 * T_ * 2 * CoutP * 8;
     for (int e = threadIdx.x; e < T_ * 2 * 64; e += 256) {
         const int col = e & 63, row = e >> 6;
         const int h = row & 1, tap = row >> 1;
@@ -77,8 +80,8 @@ __global__ __launch_bounds__(256) void pack16_kernel(const float* __restrict__ w
 
 template <typename T>
 int launch_pack16(int KK, dim3 grid, hipStream_t s, const float* w, unsigned short* packed, int Cout, int Cin, int KW, const TapSel& sel, int CinP, int CoutP,
-                  float scale, int flip, int transpose_oi, const float* styles, const float* dcoefs, int64_t per_sample) {
-#define PG_PACK(K) case K: hipLaunchKernelGGL((pack16_kernel<T, K>), grid, dim3(256), 0, s, w, packed, Cout, Cin, KW, sel, CinP, CoutP, scale, flip, transpose_oi, styles, dcoefs, per_sample); break;
+                  float scale, int flip, int transpose_oi, const float* styles, const float* dcoefs, int64_t per_sample, int nsamples, int64_t w_group_stride) {
+#define PG_PACK(K) case K: hipLaunchKernelGGL((pack16_kernel<T, K>), grid, dim3(256), 0, s, w, packed, Cout, Cin, KW, sel, CinP, CoutP, scale, flip, transpose_oi, styles, dcoefs, per_sample, nsamples, w_group_stride); break;
     switch (KK) { PG_PACK(1) PG_PACK(2) PG_PACK(3) PG_PACK(4) PG_PACK(6) PG_PACK(9) default: return PG_ERR_UNSUPPORTED; }
 #undef PG_PACK
     return pg::launch_status();
@@ -110,6 +113,43 @@ __global__ __launch_bounds__(256) void splitk_finish16_kernel(const float* __res
             if (f.residual) v += Half16<T>::widen(((const unsigned short*)f.residual)[off]);
             ((unsigned short*)y)[off] = (unsigned short)(Half16<T>::pack(v, 0.f) & 0xffff);
         }
+    }
+}
+
+// The same for 16-bit channels-last outputs (cout stride 1, Cout % 4 == 0): four consecutive couts per thread -- 16-byte workspace
+// loads, 32-bit index arithmetic, one 8-byte store.
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_finish16_vec4_kernel(const float* __restrict__ ws, unsigned short* __restrict__ y, int ksplit, int64_t slice,
+                                                                   int total4, int Cout, int OH, int OW, int64_t ys0, int64_t ys2, int64_t ys3,
+                                                                   int osy, int osx, int ooy, int oox, pg_conv2d16_fusion f) {
+    const float slope = f.act == PG_ACT_LINEAR ? 1.f : (f.act == PG_ACT_RELU ? 0.f : f.alpha);
+    const float cl = f.clamp >= 0.f ? f.clamp : __builtin_inff();
+    const int Cout4 = Cout >> 2;
+    for (int q = blockIdx.x * 256 + threadIdx.x; q < total4; q += gridDim.x * 256) {
+        const int c4 = q % Cout4;
+        int r = q / Cout4;
+        const int ox = r % OW; r /= OW;
+        const int oy = r % OH, n = r / OH;
+        const int co = 4 * c4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        const float* src = ws + 4 * (int64_t)q;
+        for (int z = 0; z < ksplit; z++) v += *(const f32x4*)(src + (int64_t)z * slice);
+        if (f.out_scale) v *= *(const f32x4*)(f.out_scale + (int64_t)n * Cout + co);
+        if (f.noise) v += f.noise[n * f.noise_batch_stride + (int64_t)oy * OW + ox] * f.noise_gain;
+        if (f.bias) { v[0] += f.bias[co]; v[1] += f.bias[co + 1]; v[2] += f.bias[co + 2]; v[3] += f.bias[co + 3]; }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const float a = v[j] > 0.f ? v[j] : v[j] * slope;
+            v[j] = fminf(fmaxf(a * f.gain, -cl), cl);
+        }
+        const int64_t off = n * ys0 + co + (int64_t)(oy * osy + ooy) * ys2 + (int64_t)(ox * osx + oox) * ys3;
+        if (f.residual) {
+            const u32x2 rr = *(const u32x2*)((const unsigned short*)f.residual + off);
+            v[0] += Half16<T>::widen((unsigned short)(rr[0] & 0xffff)); v[1] += Half16<T>::widen((unsigned short)(rr[0] >> 16));
+            v[2] += Half16<T>::widen((unsigned short)(rr[1] & 0xffff)); v[3] += Half16<T>::widen((unsigned short)(rr[1] >> 16));
+        }
+        const u32x2 o = {Half16<T>::pack(v[0], v[1]), Half16<T>::pack(v[2], v[3])};
+        *(u32x2*)(y + off) = o;
     }
 }
 
@@ -261,6 +301,20 @@ int conv16_forward(const void* x, const void* packed, void* y, int dtype, int ou
         st = pgconv16::launch16_k3s2(p, dtype, s);
     }
     if (st != PG_OK || ksplit <= 1) return st;
+    const bool vec4 = out_dtype != PG_F32 && Cout % 4 == 0 && ystride[1] == 1 && ((ystride[0] | ystride[2] | ystride[3]) & 3) == 0 && (((uintptr_t)y) & 7) == 0 &&
+                      (((uintptr_t)workspace) & 15) == 0 && (!tail.out_scale || (((uintptr_t)tail.out_scale) & 15) == 0) &&
+                      (!tail.residual || (((uintptr_t)tail.residual) & 7) == 0);
+    if (vec4) {
+        int64_t blocks4 = (slice / 4 + 255) / 256;
+        if (blocks4 > pg::max_stream_blocks()) blocks4 = pg::max_stream_blocks();
+        if (dtype == PG_BF16)
+            hipLaunchKernelGGL((splitk_finish16_vec4_kernel<bf16_t>), dim3((unsigned)blocks4), dim3(256), 0, s, workspace, (unsigned short*)y, ksplit, slice, (int)(slice / 4), Cout, OH, OW,
+                               ystride[0], ystride[2], ystride[3], osy, osx, ooy, oox, tail);
+        else
+            hipLaunchKernelGGL((splitk_finish16_vec4_kernel<f16_t>), dim3((unsigned)blocks4), dim3(256), 0, s, workspace, (unsigned short*)y, ksplit, slice, (int)(slice / 4), Cout, OH, OW,
+                               ystride[0], ystride[2], ystride[3], osy, osx, ooy, oox, tail);
+        return pg::launch_status();
+    }
     int64_t blocks = (slice + 255) / 256;
     if (blocks > pg::max_stream_blocks()) blocks = pg::max_stream_blocks();
     if (dtype == PG_BF16)
@@ -279,11 +333,11 @@ PG_EXPORT int64_t pg_conv2d16_packed_size(int Cout, int Cin, int KH, int KW) {
     return (int64_t)round_up(Cin, 32) * KH * KW * round_up(Cout, 64);
 }
 
-PG_EXPORT int pg_conv2d16_pack_weight(const float* w, void* packed, int dtype, int Cout, int Cin, int KH, int KW,
-                                      const int* taps_y, int ntaps_y, const int* taps_x, int ntaps_x,
-                                      float scale, int flip_hw, int transpose_oi,
-                                      const float* styles, const float* dcoefs, int nsamples, void* stream) {
-    if (!w || !packed || Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0 || nsamples <= 0) return PG_ERR_INVALID_ARG;
+static int pack_weight16(const float* w, void* packed, int dtype, int ngroups, int64_t w_group_stride, int Cout, int Cin, int KH, int KW,
+                         const int* taps_y, int ntaps_y, const int* taps_x, int ntaps_x,
+                         float scale, int flip_hw, int transpose_oi,
+                         const float* styles, const float* dcoefs, int nsamples, void* stream) {
+    if (!w || !packed || Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0 || nsamples <= 0 || ngroups <= 0 || w_group_stride < 0) return PG_ERR_INVALID_ARG;
     if (dtype != PG_BF16 && dtype != PG_F16) return PG_ERR_INVALID_ARG;
     TapSel sel;
     sel.ny = taps_y ? ntaps_y : KH;
@@ -296,14 +350,27 @@ PG_EXPORT int pg_conv2d16_pack_weight(const float* w, void* packed, int dtype, i
     }
     const int CinP = round_up(Cin, 32), CoutP = round_up(Cout, 64);
     const int64_t per_sample = (int64_t)CinP * sel.ny * sel.nx * CoutP;
-    if (CinP / 16 > 65535 || nsamples > 65535) return PG_ERR_TOO_LARGE;
-    const dim3 grid((unsigned)(CoutP / 64), (unsigned)(CinP / 16), (unsigned)nsamples);
+    if (CinP / 16 > 65535 || (int64_t)nsamples * ngroups > 65535) return PG_ERR_TOO_LARGE;
+    const dim3 grid((unsigned)(CoutP / 64), (unsigned)(CinP / 16), (unsigned)(nsamples * ngroups));
     if (sel.nx > 3) return PG_ERR_UNSUPPORTED;
     if (dtype == PG_BF16)
         return launch_pack16<bf16_t>(KH * KW, grid, (hipStream_t)stream, w, (unsigned short*)packed, Cout, Cin, KW, sel, CinP, CoutP, scale, flip_hw, transpose_oi,
-                                     styles, dcoefs, per_sample);
+                                     styles, dcoefs, per_sample, nsamples, w_group_stride);
     return launch_pack16<f16_t>(KH * KW, grid, (hipStream_t)stream, w, (unsigned short*)packed, Cout, Cin, KW, sel, CinP, CoutP, scale, flip_hw, transpose_oi,
-                                styles, dcoefs, per_sample);
+                                styles, dcoefs, per_sample, nsamples, w_group_stride);
+}
+
+PG_EXPORT int pg_conv2d16_pack_weight(const float* w, void* packed, int dtype, int Cout, int Cin, int KH, int KW,
+                                      const int* taps_y, int ntaps_y, const int* taps_x, int ntaps_x,
+                                      float scale, int flip_hw, int transpose_oi,
+                                      const float* styles, const float* dcoefs, int nsamples, void* stream) {
+    return pack_weight16(w, packed, dtype, 1, 0, Cout, Cin, KH, KW, taps_y, ntaps_y, taps_x, ntaps_x, scale, flip_hw, transpose_oi, styles, dcoefs, nsamples, stream);
+}
+
+PG_EXPORT int pg_conv2d16_pack_weight_grouped(const float* w, void* packed, int dtype, int ngroups, int64_t w_group_stride,
+                                              int Cout, int Cin, int KH, int KW, float scale, int flip_hw, int transpose_oi,
+                                              const float* styles, const float* dcoefs, int nsamples, void* stream) {
+    return pack_weight16(w, packed, dtype, ngroups, w_group_stride, Cout, Cin, KH, KW, nullptr, 0, nullptr, 0, scale, flip_hw, transpose_oi, styles, dcoefs, nsamples, stream);
 }
 
 // Dev hook (not part of include/pasta_gan_ops.h): device buffer of >= 4000 uint64 that PG_CONV16_DBG=32 fills with

@@ -44,6 +44,8 @@ def _init():
         lib.pg_conv2d16_packed_size.argtypes = [i, i, i, i]
         lib.pg_conv2d16_pack_weight.restype = i
         lib.pg_conv2d16_pack_weight.argtypes = [vp, vp, i, i, i, i, i, pi, i, pi, i, f, i, i, vp, vp, i, vp]
+        lib.pg_conv2d16_pack_weight_grouped.restype = i
+        lib.pg_conv2d16_pack_weight_grouped.argtypes = [vp, vp, i, i, i64, i, i, i, i, f, i, i, vp, vp, i, vp]
         fwd = [vp, vp, vp, i, i, i, i, i, i, i, i, i, i, i, i, i, i, i64, p64, i, i, i, i, ctypes.POINTER(Fusion16)]
         lib.pg_conv2d16_forward.restype = i
         lib.pg_conv2d16_forward.argtypes = fwd + [vp]
@@ -107,6 +109,35 @@ def pack_weight(w, dtype, scale=1.0, flip=False, transpose_oi=False, taps=None, 
                                          float(scale), int(bool(flip)), int(bool(transpose_oi)), nat.ptr(styles), nat.ptr(dcoefs), n, nat.stream_of(w))
     nat.check(st, 'pg_conv2d16_pack_weight')
     return packed, (per if (styles is not None or dcoefs is not None) else 0), (len(ty), len(tx))
+
+
+def pack_weight_grouped(ws, dtype, scale=1.0, flip=False, transpose_oi=False, styles=None, dcoefs=None):
+    """`pack_weight` of G same-shape weight tensors stacked as [G, ...] in one launch (shared styles / dcoefs): returns
+    (packed [G, N * per], per_sample_stride or 0)."""
+    lib = _init()
+    assert dtype in DTYPES
+    ws = _f32(ws, 'weights')
+    g = ws.shape[0]
+    if transpose_oi:
+        cin, cout, kh, kw = ws.shape[1:]
+    else:
+        cout, cin, kh, kw = ws.shape[1:]
+    n = 1
+    if styles is not None:
+        styles = _f32(styles, 'styles')
+        n = styles.shape[0]
+        assert styles.shape[1] == cin
+    if dcoefs is not None:
+        dcoefs = _f32(dcoefs, 'dcoefs', None)
+        n = dcoefs.shape[0]
+        assert dcoefs.shape[1] == cout and (styles is None or styles.shape[0] == n)
+    per = lib.pg_conv2d16_packed_size(cout, cin, kh, kw)
+    packed = torch.empty([g, n * per], dtype=dtype, device=ws.device)
+    with torch.cuda.device(ws.device):
+        st = lib.pg_conv2d16_pack_weight_grouped(nat.ptr(ws), nat.ptr(packed), nat.PG_DTYPE[dtype], g, ws[0].numel(), cout, cin, kh, kw,
+                                                 float(scale), int(bool(flip)), int(bool(transpose_oi)), nat.ptr(styles), nat.ptr(dcoefs), n, nat.stream_of(ws))
+    nat.check(st, 'pg_conv2d16_pack_weight_grouped')
+    return packed, (per if (styles is not None or dcoefs is not None) else 0)
 
 
 def conv2d_forward(x, packed, cout, kh, kw, stride=1, pad=(0, 0), out_hw=None, y=None, out_step=(1, 1), out_off=(0, 0), sample_stride=0,

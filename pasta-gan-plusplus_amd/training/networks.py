@@ -247,11 +247,12 @@ def _modconv_fast16(x, weight, styles, noise, up, padding, resample_filter, demo
                               lambda: {ab: conv2d_mfma16.pack_weight(wab, x.dtype, transpose_oi=True)[0] for ab, wab in phases.items()})
         if noise is not None:           # phase-major copy of the noise map, one pass: [B, 2, 2, h, w]
             noise_phases = noise.reshape(-1, h, 2, w, 2).permute(0, 2, 4, 1, 3).contiguous()
-        for (a, b), wab in phases.items():
-            if shared:
-                packed, per = packs[(a, b)], 0
-            else:
-                packed, per, _ = conv2d_mfma16.pack_weight(wab, x.dtype, transpose_oi=True, styles=s32, dcoefs=dcoefs)
+        if not shared:                  # the four per-sample phase packs in one launch
+            stacked = cache.get(('up2_stacked', flip_weight), [weight], lambda: torch.stack(list(phases.values())).contiguous())
+            packed_all, per = conv2d_mfma16.pack_weight_grouped(stacked, x.dtype, transpose_oi=True, styles=s32, dcoefs=dcoefs)
+        for g, ((a, b), wab) in enumerate(phases.items()):
+            packed = packs[(a, b)] if shared else packed_all[g]
+            per = 0 if shared else per
             nz = None
             if noise is not None:       # the phase's samples of the output-resolution noise map
                 nz = noise_phases[:, a, b]
@@ -329,7 +330,7 @@ class FullyConnectedLayer(nn.Module):
         if x.ndim == 2:
             # the weight gain rides on the GEMM's alpha (no scaled copy of the weight per call)
             if self.activation == 'linear' and bias is not None:
-                return torch.addmm(bias.unsqueeze(0), x, weight.t(), alpha=self.weight_gain)
+                return torch.addmm(bias, x, weight.t(), alpha=self.weight_gain)      # 1-D bias: the GEMM's own bias epilogue, no broadcast copy
             y = torch.mm(x, weight.t()).mul_(self.weight_gain)
         else:
             y = torch.nn.functional.linear(x, weight.mul(self.weight_gain))
@@ -574,7 +575,10 @@ class SynthesisLayer(nn.Module):
         if self.use_noise and noise_mode == 'random':
             noise = torch.randn([x.shape[0], 1, self.resolution, self.resolution], device=x.device) * self.noise_strength
         if self.use_noise and noise_mode == 'const':
-            noise = self.noise_const * self.noise_strength
+            if torch.is_grad_enabled() and self.noise_strength.requires_grad:
+                noise = self.noise_const * self.noise_strength
+            else:       # inference: the product only changes with its operands
+                noise = self._cache.get(('noise',), [self.noise_const, self.noise_strength], lambda: (self.noise_const * self.noise_strength).detach())
         act_gain = self.act_gain * gain
         act_clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
         fusable = _fast_ok(x, self.weight, self.bias, styles, noise) or _fast16_ok(x, self.weight, self.bias, styles, noise)

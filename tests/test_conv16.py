@@ -168,6 +168,39 @@ def test_conv16_splitk_exact(dtype):
     ref16 = ref.clamp(0, 200)
     err = (y16.double().cpu() - ref16).abs()
     assert bool((err <= ULP[dtype] * ref16.abs()).all())
+    # the vectorised finish with every epilogue stage, written into one phase of a 2x larger channels-last output
+    osc = (_ints(gen, [n, cout], 1, 2) / 2)
+    nz = _ints(gen, [h, w], -2, 2)
+    big = torch.zeros([n, cout, 2 * h, 2 * w], device=DEV, dtype=dtype).contiguous(memory_format=torch.channels_last)
+    res = _ints(gen, [n, cout, 2 * h, 2 * w], -4, 4)
+    M.conv2d_forward(x.to(DEV, dtype), packed, cout, 3, 3, pad=(1, 1), out_hw=(h, w), y=big, out_step=(2, 2), out_off=(1, 0), out_scale=osc.to(DEV),
+                     noise=nz.to(DEV), bias=bias.to(DEV), act='lrelu', alpha=0.25, gain=2.0, clamp=300.0,
+                     residual=res.to(DEV, dtype).contiguous(memory_format=torch.channels_last))
+    v = _ref_conv(x, wt, padding=1) * osc.double().reshape(n, cout, 1, 1) + nz.double() + bias.double().reshape(1, -1, 1, 1)
+    v = (torch.where(v > 0, v, v * 0.25) * 2.0).clamp(-300, 300) + res.double()[:, :, 1::2, 0::2]
+    got = big.double().cpu()
+    err = (got[:, :, 1::2, 0::2] - v).abs()
+    assert bool((err <= 2 * ULP[dtype] * v.abs() + 1e-6).all())
+    assert float(got[:, :, 0::2].abs().max()) == 0 and float(got[:, :, 1::2, 1::2].abs().max()) == 0
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['bf16', 'fp16'])
+def test_pack_weight_grouped_matches_single_packs(dtype):
+    """One launch for the four composite phase kernels of an up-by-2 modulated convolution == four separate packs, bit for bit."""
+    from torch_utils.ops import conv2d_mfma16 as M
+    gen = torch.Generator().manual_seed(11)
+    g, cin, cout, n = 4, 40, 72, 3
+    ws = torch.randn([g, cin, cout, 3, 3], generator=gen).to(DEV)
+    styles = torch.randn([n, cin], generator=gen).to(DEV)
+    dcoefs = torch.rand([n, cout], generator=gen).to(DEV) + 0.5
+    packed, per = M.pack_weight_grouped(ws, dtype, transpose_oi=True, styles=styles, dcoefs=dcoefs)
+    for i in range(g):
+        single, per1, _ = M.pack_weight(ws[i], dtype, transpose_oi=True, styles=styles, dcoefs=dcoefs)
+        assert per1 == per and torch.equal(packed[i].view(torch.int16), single.view(torch.int16))
+    packed, per = M.pack_weight_grouped(ws.transpose(1, 2).contiguous(), dtype, flip=True)
+    for i in range(g):
+        single, per1, _ = M.pack_weight(ws[i].transpose(0, 1).contiguous(), dtype, flip=True)
+        assert per == per1 == 0 and torch.equal(packed[i].view(torch.int16), single.view(torch.int16))
 
 
 @pytest.mark.parametrize('dtype', DTYPES, ids=['bf16', 'fp16'])

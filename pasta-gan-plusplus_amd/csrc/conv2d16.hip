@@ -391,8 +391,11 @@ PG_EXPORT int pg_conv2d16_splitk_plan(int N, int Cin, int OH, int OW, int Cout, 
     const int kc = kc_for16(KH, KW);
     if (Cin % kc != 0) return 1;
     const int nchunks = Cin / kc;
-    const int th = stride == 2 ? 8 : 16;                               // output rows of one workgroup tile (conv2d16_inst_*.hip)
-    const int64_t tiles = (int64_t)N * ((OW + 31) / 32) * ((OH + th - 1) / th) * ((Cout <= 32 ? 1 : (round_up(Cout, 64) / 64)));
+    int th = stride == 2 ? 8 : 16, tw = 32, bm = Cout <= 32 ? 32 : 64; // the workgroup tile (conv2d16_inst_*.hip, launch16_mt)
+    const int sm = pgconv16::small_tile16(KH, KW, stride, OH, OW, Cout);
+    if (sm == 1) { th = 8; tw = 8; bm = 128; }
+    if (sm == 2) { th = 16; tw = 16; bm = 64; }
+    const int64_t tiles = (int64_t)N * ((OW + tw - 1) / tw) * ((OH + th - 1) / th) * ((Cout + bm - 1) / bm);
     if (tiles >= pg::num_cu() || nchunks < 8) return 1;
     int best = 1;                                                      // largest divisor of nchunks that keeps >= 4 chunks per share and
     for (int k = 2; k <= 16; k++)                                      // does not overshoot ~2 workgroups per CU

@@ -33,6 +33,7 @@
 
 #pragma once
 #include <algorithm>
+#include <cstdlib>
 #include "pg_common.h"
 
 namespace pgconv16 {
@@ -584,9 +585,25 @@ int launch16(const Conv16Params& p0, hipStream_t s) {
     return launch_status();
 }
 
+// Low-resolution 3x3 layers (8^2 / 16^2 images of the wide blocks): the 16 x 32 pixel tile would be 7/8 or 1/2 padding -- matrix work
+// and weight traffic spent on nothing.  1 = one 8 x 8 image x 128 couts per workgroup, 2 = one 16 x 16 image x 64 couts, 0 = the
+// regular tile.  Shared by the launcher and the split-K planner.  PG_CONV16_SMALL=0 switches it off (A/B).
+inline int small_tile16(int KH, int KW, int S, int OH, int OW, int Cout) {
+    static const bool on = [] { const char* e = getenv("PG_CONV16_SMALL"); return e ? atoi(e) != 0 : true; }();
+    if (!on || KH != 3 || KW != 3 || S != 1 || Cout < 128) return 0;
+    if (OH <= 8 && OW <= 8) return 1;
+    if (OH <= 16 && OW <= 16) return 2;
+    return 0;
+}
+
 // M-tile count by the width of the layer (32-cout blocks for narrow layers: no MFMA spent on padding rows)
 template <typename T, int KH, int KW, int S, int NT, int KC, int NB>
 int launch16_mt(const Conv16Params& p, hipStream_t s) {
+    if constexpr (KH == 3 && KW == 3 && S == 1) {
+        const int sm = small_tile16(KH, KW, S, p.OH, p.OW, p.Cout);
+        if (sm == 1) return launch16<T, KH, KW, S, 8, 4, 1, 1, KC, NB>(p, s);        // TH x TW = 8 x 8, BM = 128
+        if (sm == 2) return launch16<T, KH, KW, S, 16, 1, 2, 1, KC, NB>(p, s);       // TH x TW = 16 x 16, BM = 64
+    }
     if (p.Cout <= 32) return launch16<T, KH, KW, S, 32, 1, 1, NT, KC, NB>(p, s);
     return launch16<T, KH, KW, S, 32, 1, 2, NT, KC, NB>(p, s);
 }

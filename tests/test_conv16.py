@@ -68,6 +68,36 @@ def test_conv16_exact_f32_out(dtype, geom, shape):
     assert torch.equal(y.double().cpu(), ref), float((y.double().cpu() - ref).abs().max())
 
 
+SMALL_SHAPES = [  # (n, cin, cout, h, w, pad): the low-resolution tiles -- 8 x 8 pixels x 128 couts, 16 x 16 x 64 couts (launch16_mt); with and without split-K
+    (3, 64, 136, 8, 8, 1), (2, 48, 128, 7, 5, 1), (2, 32, 192, 16, 16, 1), (1, 80, 136, 13, 16, 1), (4, 512, 256, 8, 8, 1), (2, 256, 128, 16, 16, 1),
+    (2, 32, 160, 9, 10, 0), (1, 32, 128, 12, 18, 2),
+]
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['bf16', 'fp16'])
+@pytest.mark.parametrize('shape', SMALL_SHAPES, ids=[f'n{s[0]}c{s[1]}o{s[2]}_{s[3]}x{s[4]}p{s[5]}' for s in SMALL_SHAPES])
+def test_conv16_small_tiles_exact(dtype, shape):
+    """Low-resolution layers run dedicated workgroup tiles: small integers, bit for bit against F.conv2d, float32 and 16-bit outputs
+    with the full epilogue (the split-K shapes go through the workspace + finish kernel)."""
+    from torch_utils.ops import conv2d_mfma16 as M
+    n, cin, cout, h, w, pad = shape
+    gen = torch.Generator().manual_seed(hash(shape) & 0xffff)
+    x = _ints(gen, [n, cin, h, w], -2, 2)
+    wt = _ints(gen, [cout, cin, 3, 3], -1, 1) * (torch.rand([cout, cin, 3, 3], generator=gen) < (16.0 / cin))
+    packed, _, _ = M.pack_weight(wt.to(DEV), dtype)
+    ref = _ref_conv(x, wt, padding=pad)
+    y = M.conv2d_forward(x.to(DEV, dtype), packed, cout, 3, 3, pad=(pad, pad), out_dtype=torch.float32)
+    assert y.shape == ref.shape and torch.equal(y.double().cpu(), ref), float((y.double().cpu() - ref).abs().max())
+    bias = _ints(gen, [cout], -4, 4)
+    res = _ints(gen, list(ref.shape), -8, 8)
+    nz = _ints(gen, list(ref.shape[2:]), -2, 2)
+    y16 = M.conv2d_forward(x.to(DEV, dtype), packed, cout, 3, 3, pad=(pad, pad), bias=bias.to(DEV), noise=nz.to(DEV), act='relu',
+                           residual=res.to(DEV, dtype).contiguous(memory_format=torch.channels_last))
+    ref16 = (ref + bias.double().reshape(1, -1, 1, 1) + nz.double()).clamp_min(0) + res.double()
+    assert float(ref16.abs().max()) <= 256
+    assert torch.equal(y16.double().cpu(), ref16), float((y16.double().cpu() - ref16).abs().max())
+
+
 @pytest.mark.parametrize('dtype', DTYPES, ids=['bf16', 'fp16'])
 @pytest.mark.parametrize('shape', [(2, 32, 64, 33, 45), (1, 64, 32, 40, 40), (2, 16, 8, 16, 16)], ids=['a', 'b', 'c'])
 def test_conv16_vector_epilogue_exact(dtype, shape):

@@ -566,11 +566,12 @@ class SynthesisLayer(nn.Module):
         self.bias = nn.Parameter(torch.zeros([out_channels]))
         self._cache = _PackCache()
 
-    def forward(self, x, w, noise_mode='random', fused_modconv=True, gain=1):
+    def forward(self, x, w, noise_mode='random', fused_modconv=True, gain=1, styles=None):
         assert noise_mode in ['random', 'const', 'none']
         in_res = self.resolution // self.up
         misc.assert_shape(x, [None, self.weight.shape[1], in_res, in_res])
-        styles = self.affine(w)
+        if styles is None:              # (private `styles`: the affine output computed by the caller, SynthesisStack.all_styles)
+            styles = self.affine(w)
         noise = None
         if self.use_noise and noise_mode == 'random':
             noise = torch.randn([x.shape[0], 1, self.resolution, self.resolution], device=x.device) * self.noise_strength
@@ -609,9 +610,11 @@ class _ToRGBBase(nn.Module):
             self.m_bias1 = nn.Parameter(torch.zeros([self.PARSING_CHANNELS]))
         self._cache, self._cache_p = _PackCache(), _PackCache()
 
-    def forward(self, x, w, fused_modconv=True, skip_img=None):
-        """Returns (rgb, pred_parsing); `skip_img` (private) is added to rgb inside the same launch."""
-        styles = self.affine(w) * self.weight_gain
+    def forward(self, x, w, fused_modconv=True, skip_img=None, styles=None):
+        """Returns (rgb, pred_parsing); `skip_img` (private) is added to rgb inside the same launch; `styles` (private) =
+        affine(w) * weight_gain computed by the caller."""
+        if styles is None:
+            styles = self.affine(w) * self.weight_gain
         if _fast16_ok(x, self.weight, self.bias, styles, skip_img) and self.weight.shape[2:] == (1, 1):
             # half-precision inference: each head is one streaming pass (float32 image out, skip image added in it)
             pred_parsing = None
@@ -849,18 +852,24 @@ class SynthesisStackBlock(nn.Module):
         self.num_conv = 1 if in_channels == 0 else 2
         self.num_torgb = 1
 
-    def forward(self, x, img, ws, force_fp32=False, **layer_kwargs):
+    def affine_layers(self):
+        """(layer, index of its w within the block's ws, gain folded into its styles) in call order."""
+        convs = [self.conv1] if self.in_channels == 0 else [self.conv0, self.conv1]
+        return [(m, i, 1.0) for i, m in enumerate(convs)] + [(self.torgb, self.num_conv, self.torgb.weight_gain)]
+
+    def forward(self, x, img, ws, force_fp32=False, styles=None, **layer_kwargs):
         misc.assert_shape(ws, [None, self.num_conv + self.num_torgb, self.w_dim])
         half = self.half_dtype is not None and not force_fp32
         fmt = dict(dtype=self.half_dtype if half else torch.float32, memory_format=torch.channels_last if half else torch.contiguous_format)
+        st = list(styles) if styles is not None else [None] * (self.num_conv + self.num_torgb)
         if self.in_channels == 0:
             x = self.const.to(fmt['dtype'])[None].expand(ws.shape[0], -1, -1, -1).contiguous(memory_format=fmt['memory_format'])
-            x = self.conv1(x, ws[:, 0], **layer_kwargs)
+            x = self.conv1(x, ws[:, 0], styles=st[0], **layer_kwargs)
         else:
-            x = self.conv1(self.conv0(x.to(**fmt), ws[:, 0], **layer_kwargs), ws[:, 1], **layer_kwargs)
+            x = self.conv1(self.conv0(x.to(**fmt), ws[:, 0], styles=st[0], **layer_kwargs), ws[:, 1], styles=st[1], **layer_kwargs)
         if img is not None:
             img = upfirdn2d.upsample2d(img, self.resample_filter)
-        rgb, _ = self.torgb(x, ws[:, self.num_conv], skip_img=img)
+        rgb, _ = self.torgb(x, ws[:, self.num_conv], skip_img=img, styles=st[self.num_conv])
         return x, rgb.to(dtype=torch.float32, memory_format=torch.contiguous_format)
 
 
@@ -886,14 +895,53 @@ class SynthesisStack(nn.Module):
             setattr(self, f'b{res}', block)
             self.num_ws += block.num_conv + (block.num_torgb if res == img_resolution else 0)
 
+    def all_styles(self, ws):
+        """Inference: the ~2 dozen affine layers of the stack (FullyConnectedLayer, networks.py:115-128: w @ (W * gain)^T + b) as ONE
+        GEMM over all (w index, layer) pairs -- 0.7 GFLOP, mostly unused, instead of a launch per layer -- and one gather that
+        leaves each layer's [N, Cin] styles contiguous.  Weights are concatenated once per parameter version.  Returns
+        {resolution: [styles of conv0?, conv1, torgb]}; the ToRGB weight gain is folded in."""
+        n = ws.shape[0]
+        entries, start = [], 0          # (resolution, layer, absolute w index, gain)
+        for res in self.block_resolutions:
+            block = getattr(self, f'b{res}')
+            entries += [(res, m, start + i, g) for m, i, g in block.affine_layers()]
+            start += block.num_conv
+        params = [t for _, m, _, _ in entries for t in (m.affine.weight, m.affine.bias)]
+
+        def build():
+            wt = torch.cat([m.affine.weight.detach().float() * (m.affine.weight_gain * g) for _, m, _, g in entries]).t().contiguous()
+            b = torch.cat([m.affine.bias.detach().float() * (m.affine.bias_gain * g) for _, m, _, g in entries]).contiguous()
+            return wt, b
+        if not hasattr(self, '_affine_cache'):
+            self._affine_cache, self._gather = _PackCache(), {}
+        wt, b = self._affine_cache.get(('all',), params, build)
+        total = wt.shape[1]
+        key = (n, ws.device)
+        if key not in self._gather:     # flat index of styles[l][n, c] inside the [N * num_ws, total] product
+            idx, col = [], 0
+            rows = torch.arange(n, dtype=torch.int64)[:, None] * self.num_ws
+            for _, m, wi, _ in entries:
+                c = m.affine.weight.shape[0]
+                idx.append(((rows + wi) * total + col + torch.arange(c, dtype=torch.int64)[None, :]).reshape(-1))
+                col += c
+            self._gather[key] = torch.cat(idx).to(ws.device)
+        flat = torch.addmm(b, ws.reshape(n * self.num_ws, self.w_dim), wt).reshape(-1).index_select(0, self._gather[key])
+        out, off = {}, 0
+        for res, m, _, _ in entries:
+            c = m.affine.weight.shape[0]
+            out.setdefault(res, []).append(flat[off:off + n * c].view(n, c))
+            off += n * c
+        return out
+
     def forward(self, ws, **block_kwargs):
         misc.assert_shape(ws, [None, self.num_ws, self.w_dim])
         ws = ws.to(torch.float32)
         x = img = None
         start = 0
+        styles = self.all_styles(ws) if (ws.is_cuda and not torch.is_grad_enabled() and os.environ.get('PG_AFFINE_BATCHED', '1') != '0') else None
         for res in self.block_resolutions:
             block = getattr(self, f'b{res}')
-            x, img = block(x, img, ws[:, start:start + block.num_conv + block.num_torgb], **block_kwargs)
+            x, img = block(x, img, ws[:, start:start + block.num_conv + block.num_torgb], styles=styles[res] if styles is not None else None, **block_kwargs)
             start += block.num_conv
         return img
 

@@ -186,3 +186,30 @@ def test_conv2d_resample_plan():
     # a transposed conv with a larger kernel absorbs part of the (negative) FIR padding itself
     p = _plan(5, 5, 4, 4, 2, 1, 0)
     assert p.route == 'transposed' and p.conv_pad == (2, 2) and p.fir_pad == [0, 0, 0, 0]
+
+
+def test_stack_batched_affine_matches_per_layer_affine():
+    """SynthesisStack.all_styles (inference: one GEMM + one gather for every affine layer) == affine(w) (* ToRGB weight gain) layer by layer."""
+    import torch
+    from training import networks
+    net = networks.SynthesisStack(w_dim=512, img_resolution=64, channel_base=2048, channel_max=64).eval()
+    gen = torch.Generator().manual_seed(3)
+    for p in net.parameters():
+        p.data.copy_(torch.randn(p.shape, generator=gen))
+    ws = torch.randn([3, net.num_ws, 512], generator=gen)
+    with torch.no_grad():
+        styles = net.all_styles(ws)
+        start = 0
+        for res in net.block_resolutions:
+            block = getattr(net, f'b{res}')
+            assert len(styles[res]) == block.num_conv + block.num_torgb
+            for (layer, i, g), got in zip(block.affine_layers(), styles[res]):
+                ref = layer.affine(ws[:, start + i]) * g
+                assert got.is_contiguous() and got.shape == ref.shape
+                assert float((ref - got).abs().max()) <= 2e-6 * float(ref.abs().max())
+            start += block.num_conv
+        # a parameter update invalidates the concatenated weights
+        net.b8.conv1.affine.weight.add_(1.0)
+        again = net.all_styles(ws)
+        ref = net.b8.conv1.affine(ws[:, 0])
+        assert float((ref - again[8][0]).abs().max()) <= 2e-6 * float(ref.abs().max())

@@ -34,32 +34,62 @@ __global__ __launch_bounds__(256) void pack16_kernel(const float* __restrict__ w
     const int co0 = cb * 64, ci0 = k16 * 16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // ---- load: OIHW keeps (ci, ky, kx) contiguous per cout; IOHW (transposed weights) keeps (co, ky, kx) contiguous per ci
+    // (all global loads of a wave are issued before the first value is used: the loops below have compile-time trip counts and the
+    // loads land in registers -- one exposed memory round trip per workgroup instead of one per cout / channel row)
     if (!transpose_oi) {
-        for (int col = wave; col < 64; col += 4) {                     // one wave per cout: its 16 * KK floats are one contiguous run
-            const int co = co0 + col;
-            const float dsc = (co < Cout ? scale : 0.f) * ((dcoefs && co < Cout) ? dcoefs[(int64_t)n * Cout + co] : 1.f);
-            const float* src = w + ((int64_t)(co < Cout ? co : 0) * Cin + ci0) * KK;
+        constexpr int PER_ROW = (RUN + 63) / 64;
+        float v[16][PER_ROW], dsc[16];
 #pragma unroll
-            for (int r = lane; r < RUN; r += 64) {
-                const int ci = ci0 + r / KK;
-                float v = 0.f;
-                if (ci < Cin) v = src[r] * dsc * (styles ? styles[(int64_t)n * Cin + ci] : 1.f);
-                tile[col * PITCH + r] = v;
+        for (int it = 0; it < 16; it++) {                              // one wave per cout: its 16 * KK floats are one contiguous run
+            const int co = co0 + wave + 4 * it;
+            const float* src = w + ((int64_t)(co < Cout ? co : 0) * Cin + ci0) * KK;
+            dsc[it] = (co < Cout ? scale : 0.f) * ((dcoefs && co < Cout) ? dcoefs[(int64_t)n * Cout + co] : 1.f);
+#pragma unroll
+            for (int k = 0; k < PER_ROW; k++) {
+                const int r = lane + 64 * k;
+                v[it][k] = (r < RUN && ci0 + r / KK < Cin) ? src[r] : 0.f;
             }
         }
+        float sty[PER_ROW];
+#pragma unroll
+        for (int k = 0; k < PER_ROW; k++) {
+            const int r = lane + 64 * k, ci = ci0 + r / KK;
+            sty[k] = (styles && r < RUN && ci < Cin) ? styles[(int64_t)n * Cin + ci] : 1.f;
+        }
+#pragma unroll
+        for (int it = 0; it < 16; it++)
+#pragma unroll
+            for (int k = 0; k < PER_ROW; k++) {
+                const int r = lane + 64 * k;
+                if (r < RUN) tile[(wave + 4 * it) * PITCH + r] = v[it][k] * dsc[it] * sty[k];
+            }
     } else {
-        for (int c = wave; c < 16; c += 4) {                           // one wave per input channel: 64 couts x KK floats contiguous
-            const int ci = ci0 + c;
-            const float ssc = (ci < Cin ? scale : 0.f) * ((styles && ci < Cin) ? styles[(int64_t)n * Cin + ci] : 1.f);
+        constexpr int PER_CH = KK;                                     // 64 * KK floats per channel = KK per lane
+        float v[4][PER_CH], ssc[4];
+#pragma unroll
+        for (int it = 0; it < 4; it++) {                               // one wave per input channel: 64 couts x KK floats contiguous
+            const int ci = ci0 + wave + 4 * it;
+            ssc[it] = (ci < Cin ? scale : 0.f) * ((styles && ci < Cin) ? styles[(int64_t)n * Cin + ci] : 1.f);
             const float* src = w + ((int64_t)(ci < Cin ? ci : 0) * Cout + co0) * KK;
 #pragma unroll
-            for (int e = lane; e < 64 * KK; e += 64) {
-                const int col = e / KK, kk = e % KK;
-                float v = 0.f;
-                if (co0 + col < Cout) v = src[e] * ssc * (dcoefs ? dcoefs[(int64_t)n * Cout + co0 + col] : 1.f);
-                tile[col * PITCH + c * KK + kk] = v;
+            for (int k = 0; k < PER_CH; k++) {
+                const int e = lane + 64 * k;
+                v[it][k] = (co0 + e / KK < Cout) ? src[e] : 0.f;
             }
         }
+        float dco[PER_CH];
+#pragma unroll
+        for (int k = 0; k < PER_CH; k++) {
+            const int col = (lane + 64 * k) / KK;
+            dco[k] = (dcoefs && co0 + col < Cout) ? dcoefs[(int64_t)n * Cout + co0 + col] : 1.f;
+        }
+#pragma unroll
+        for (int it = 0; it < 4; it++)
+#pragma unroll
+            for (int k = 0; k < PER_CH; k++) {
+                const int e = lane + 64 * k, col = e / KK, kk = e % KK;
+                tile[col * PITCH + (wave + 4 * it) * KK + kk] = v[it][k] * ssc[it] * dco[k];
+            }
     }
     __syncthreads();
     // ---- store: thread -> (row = tap * 2 + h, cout): 16 bytes = 8 consecutive channels of one tap

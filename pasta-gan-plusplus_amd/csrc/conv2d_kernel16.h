@@ -586,13 +586,14 @@ int launch16(const Conv16Params& p0, hipStream_t s) {
 }
 
 // Low-resolution 3x3 layers (8^2 / 16^2 images of the wide blocks): the 16 x 32 pixel tile would be 7/8 or 1/2 padding -- matrix work
-// and weight traffic spent on nothing.  1 = one 8 x 8 image x 128 couts per workgroup, 2 = one 16 x 16 image x 64 couts, 0 = the
-// regular tile.  Shared by the launcher and the split-K planner.  PG_CONV16_SMALL=0 switches it off (A/B).
+// and weight traffic spent on nothing.  1 = one 8 x 8 image x 128 couts per workgroup, 2 = 16 x 16 pixels x 64 couts (images up to 64 x 64: four times the tiles of the
+// regular shape, so a quarter of the split-K shares and workspace traffic), 0 = the regular tile.  Shared by the launcher and the split-K planner.  PG_CONV16_SMALL=0 switches it off (A/B).
 inline int small_tile16(int KH, int KW, int S, int OH, int OW, int Cout) {
     static const bool on = [] { const char* e = getenv("PG_CONV16_SMALL"); return e ? atoi(e) != 0 : true; }();
     if (!on || KH != 3 || KW != 3 || S != 1 || Cout < 128) return 0;
     if (OH <= 8 && OW <= 8) return 1;
-    if (OH <= 16 && OW <= 16) return 2;
+    static const int lim2 = [] { const char* e = getenv("PG_CONV16_SMALL2_MAX"); return e ? atoi(e) : 64; }();      // (measured on config 5: 16 -> 2.74, 32 -> 2.72, 64 -> 2.68 ms/step: less split-K)
+    if (OH <= lim2 && OW <= lim2) return 2;
     return 0;
 }
 

@@ -70,7 +70,7 @@ def test_conv16_exact_f32_out(dtype, geom, shape):
 
 SMALL_SHAPES = [  # (n, cin, cout, h, w, pad): the low-resolution tiles -- 8 x 8 pixels x 128 couts, 16 x 16 x 64 couts (launch16_mt); with and without split-K
     (3, 64, 136, 8, 8, 1), (2, 48, 128, 7, 5, 1), (2, 32, 192, 16, 16, 1), (1, 80, 136, 13, 16, 1), (4, 512, 256, 8, 8, 1), (2, 256, 128, 16, 16, 1),
-    (2, 32, 160, 9, 10, 0), (1, 32, 128, 12, 18, 2),
+    (2, 32, 160, 9, 10, 0), (1, 32, 128, 12, 18, 2), (1, 32, 128, 40, 64, 1), (2, 64, 136, 32, 32, 1), (1, 256, 128, 64, 64, 1),
 ]
 
 

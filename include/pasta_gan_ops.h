@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 3
+#define PG_ABI_VERSION 4
 
 enum pg_dtype { PG_F32 = 0, PG_F16 = 1, PG_BF16 = 2, PG_F64 = 3 };
 
@@ -304,6 +304,13 @@ typedef struct pg_conv2d16_fusion {
     float        gain;          /* 0 => 1 */
     float        clamp;         /* < 0 = off */
     const void*  residual;      /* dtype / strides of y */
+    /* Four output phases in one launch (the composite kernels of an up-by-2 layer, conv2d_resample.py:125-142 with the FIR folded in):
+     * phase_cout > 0 => the Cout = 4 * phase_cout output channels are four blocks; block ph = 2a + b is written as channels
+     * 0 .. phase_cout-1 of output pixel (oy * out_step_y + a, ox * out_step_x + b) (out_off_* ignored); out_scale / bias have
+     * phase_cout entries per row; noise is [N?, 4, OH, OW] with noise_phase_stride elements between phases.  phase_cout must be 32
+     * or a multiple of 64 (PG_ERR_UNSUPPORTED otherwise); no residual. */
+    int          phase_cout;
+    int64_t      noise_phase_stride;
 } pg_conv2d16_fusion;
 
 /*

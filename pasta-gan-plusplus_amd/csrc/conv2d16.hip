@@ -127,15 +127,16 @@ __global__ __launch_bounds__(256) void splitk_finish16_kernel(const float* __res
     const float slope = f.act == PG_ACT_LINEAR ? 1.f : (f.act == PG_ACT_RELU ? 0.f : f.alpha);
     const float cl = f.clamp >= 0.f ? f.clamp : __builtin_inff();
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int co = (int)(i % Cout), ox = (int)((i / Cout) % OW), oy = (int)((i / ((int64_t)Cout * OW)) % OH), n = (int)(i / ((int64_t)Cout * OW * OH));
+        const int cot = (int)(i % Cout), ox = (int)((i / Cout) % OW), oy = (int)((i / ((int64_t)Cout * OW)) % OH), n = (int)(i / ((int64_t)Cout * OW * OH));
+        const int pc = f.phase_cout, ph = pc ? cot / pc : 0, co = cot - ph * pc, ce = pc ? pc : Cout;      // four-phase mode: pg_conv2d16_fusion
         float v = 0.f;
         for (int z = 0; z < ksplit; z++) v += ws[(int64_t)z * slice + i];
-        if (f.out_scale) v *= f.out_scale[(int64_t)n * Cout + co];
-        if (f.noise) v += f.noise[n * f.noise_batch_stride + (int64_t)oy * OW + ox] * f.noise_gain;
+        if (f.out_scale) v *= f.out_scale[(int64_t)n * ce + co];
+        if (f.noise) v += f.noise[n * f.noise_batch_stride + ph * f.noise_phase_stride + (int64_t)oy * OW + ox] * f.noise_gain;
         if (f.bias) v += f.bias[co];
         v = v > 0.f ? v : v * slope;
         v = fminf(fmaxf(v * f.gain, -cl), cl);
-        const int64_t off = n * ys0 + co * ys1 + (int64_t)(oy * osy + ooy) * ys2 + (int64_t)(ox * osx + oox) * ys3;
+        const int64_t off = n * ys0 + co * ys1 + (int64_t)(oy * osy + (pc ? (ph >> 1) : ooy)) * ys2 + (int64_t)(ox * osx + (pc ? (ph & 1) : oox)) * ys3;
         if (out_f32) {
             if (f.residual) v += ((const float*)f.residual)[off];
             ((float*)y)[off] = v;
@@ -160,19 +161,19 @@ __global__ __launch_bounds__(256) void splitk_finish16_vec4_kernel(const float* 
         int r = q / Cout4;
         const int ox = r % OW; r /= OW;
         const int oy = r % OH, n = r / OH;
-        const int co = 4 * c4;
+        const int pc = f.phase_cout, ph = pc ? (4 * c4) / pc : 0, co = 4 * c4 - ph * pc, ce = pc ? pc : Cout;       // four-phase mode (pc % 4 == 0)
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         const float* src = ws + 4 * (int64_t)q;
         for (int z = 0; z < ksplit; z++) v += *(const f32x4*)(src + (int64_t)z * slice);
-        if (f.out_scale) v *= *(const f32x4*)(f.out_scale + (int64_t)n * Cout + co);
-        if (f.noise) v += f.noise[n * f.noise_batch_stride + (int64_t)oy * OW + ox] * f.noise_gain;
+        if (f.out_scale) v *= *(const f32x4*)(f.out_scale + (int64_t)n * ce + co);
+        if (f.noise) v += f.noise[n * f.noise_batch_stride + ph * f.noise_phase_stride + (int64_t)oy * OW + ox] * f.noise_gain;
         if (f.bias) { v[0] += f.bias[co]; v[1] += f.bias[co + 1]; v[2] += f.bias[co + 2]; v[3] += f.bias[co + 3]; }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const float a = v[j] > 0.f ? v[j] : v[j] * slope;
             v[j] = fminf(fmaxf(a * f.gain, -cl), cl);
         }
-        const int64_t off = n * ys0 + co + (int64_t)(oy * osy + ooy) * ys2 + (int64_t)(ox * osx + oox) * ys3;
+        const int64_t off = n * ys0 + co + (int64_t)(oy * osy + (pc ? (ph >> 1) : ooy)) * ys2 + (int64_t)(ox * osx + (pc ? (ph & 1) : oox)) * ys3;
         if (f.residual) {
             const u32x2 rr = *(const u32x2*)((const unsigned short*)f.residual + off);
             v[0] += Half16<T>::widen((unsigned short)(rr[0] & 0xffff)); v[1] += Half16<T>::widen((unsigned short)(rr[0] >> 16));
@@ -274,8 +275,14 @@ int conv16_forward(const void* x, const void* packed, void* y, int dtype, int ou
     if (w_sample_stride != 0 && w_sample_stride != per_sample) return PG_ERR_INVALID_ARG;
     const int64_t w_bytes = (w_sample_stride ? (int64_t)N * per_sample : per_sample) * 2;
     if (w_bytes > 0x7fffffffLL) return PG_ERR_TOO_LARGE;
-    const int64_t ext = 1 + (int64_t)(N - 1) * ystride[0] + (int64_t)(Cout - 1) * ystride[1] +
-                        ((int64_t)(OH - 1) * osy + ooy) * ystride[2] + ((int64_t)(OW - 1) * osx + oox) * ystride[3];
+    const int pcout = fusion ? fusion->phase_cout : 0;                  // four-phase mode: see pg_conv2d16_fusion
+    if (pcout) {
+        if (pcout < 0 || Cout != 4 * pcout || osy < 2 || osx < 2 || fusion->residual || fusion->noise_phase_stride < 0) return PG_ERR_INVALID_ARG;
+        if (pcout != 32 && pcout % 64 != 0) return PG_ERR_UNSUPPORTED;
+    }
+    const int c_ext = pcout ? pcout : Cout, oy_ext = pcout ? 1 : ooy, ox_ext = pcout ? 1 : oox;
+    const int64_t ext = 1 + (int64_t)(N - 1) * ystride[0] + (int64_t)(c_ext - 1) * ystride[1] +
+                        ((int64_t)(OH - 1) * osy + oy_ext) * ystride[2] + ((int64_t)(OW - 1) * osx + ox_ext) * ystride[3];
     if (ext > 0x3fffffffLL) return PG_ERR_TOO_LARGE;
 
     Conv16Params p;
@@ -302,7 +309,7 @@ int conv16_forward(const void* x, const void* packed, void* y, int dtype, int ou
     if (p.f.act > PG_ACT_LRELU) return PG_ERR_UNSUPPORTED;
     if (p.f.act == PG_ACT_LRELU && (p.f.alpha < 0.f || p.f.alpha > 1.f)) return PG_ERR_UNSUPPORTED;
     if (out_dtype == PG_F32) p.out_mode = pgconv16::OUT_SCALAR32;
-    else p.out_mode = (ystride[1] == 1 && Cout % 8 == 0 && ystride[3] % 8 == 0 && ystride[2] % 8 == 0 && ystride[0] % 8 == 0 &&
+    else p.out_mode = (ystride[1] == 1 && c_ext % 8 == 0 && ystride[3] % 8 == 0 && ystride[2] % 8 == 0 && ystride[0] % 8 == 0 &&
                        (((uintptr_t)y) & 15) == 0 && (!p.f.residual || (((uintptr_t)p.f.residual) & 7) == 0)) ? pgconv16::OUT_VEC16 : pgconv16::OUT_SCALAR16;
     hipStream_t s = (hipStream_t)stream;
 
@@ -331,7 +338,7 @@ int conv16_forward(const void* x, const void* packed, void* y, int dtype, int ou
         st = pgconv16::launch16_k3s2(p, dtype, s);
     }
     if (st != PG_OK || ksplit <= 1) return st;
-    const bool vec4 = out_dtype != PG_F32 && Cout % 4 == 0 && ystride[1] == 1 && ((ystride[0] | ystride[2] | ystride[3]) & 3) == 0 && (((uintptr_t)y) & 7) == 0 &&
+    const bool vec4 = out_dtype != PG_F32 && Cout % 4 == 0 && c_ext % 4 == 0 && ystride[1] == 1 && ((ystride[0] | ystride[2] | ystride[3]) & 3) == 0 && (((uintptr_t)y) & 7) == 0 &&
                       (((uintptr_t)workspace) & 15) == 0 && (!tail.out_scale || (((uintptr_t)tail.out_scale) & 15) == 0) &&
                       (!tail.residual || (((uintptr_t)tail.residual) & 7) == 0);
     if (vec4) {

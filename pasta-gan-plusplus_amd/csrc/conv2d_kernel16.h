@@ -266,21 +266,27 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_mfma16(Conv16Params p) {
     // Per-cout epilogue constants and the tile's noise samples: wave w < EPS/64 fetches 64 demodulation scales, the next
     // EPS/64 waves 64 biases (idle waves write zeros into the dump area); every thread one noise sample (tile pixel t).
     // Whole-tensor descriptors (constant), the row / plane offset in the scalar offset; the per-thread parts are fixed.
+    // Four-phase mode (pg_conv2d16_fusion::phase_cout): m-block -> (phase, first channel inside the phase); the per-cout vectors and
+    // the stores use the phase-local channel, the stores and the noise the phase's pixel offset.  A block never straddles phases
+    // (the host checks phase_cout % BM == 0).
+    const int pc = p.f.phase_cout, ce = pc ? pc : p.Cout;
+    auto phase_of = [&](int m0) __attribute__((always_inline)) { return pc ? (int)(m0 >= pc) + (int)(m0 >= 2 * pc) + (int)(m0 >= 3 * pc) : 0; };
     const bool side_scale = wave < G::EPS / 64, side_bias = !side_scale && wave < 2 * (G::EPS / 64);
-    const i32x4 sbrsrc = side_scale ? make_rsrc(p.f.out_scale, p.f.out_scale ? (int64_t)p.N * p.Cout * 4 : 0)
-                                    : make_rsrc(p.f.bias, (p.f.bias && side_bias) ? (int64_t)p.Cout * 4 : 0);
-    const i32x4 nrsrc = make_rsrc(p.f.noise, p.f.noise ? ((int64_t)(p.N - 1) * p.f.noise_batch_stride + (int64_t)p.OH * p.OW) * 4 : 0);
+    const i32x4 sbrsrc = side_scale ? make_rsrc(p.f.out_scale, p.f.out_scale ? (int64_t)p.N * ce * 4 : 0)
+                                    : make_rsrc(p.f.bias, (p.f.bias && side_bias) ? (int64_t)ce * 4 : 0);
+    const i32x4 nrsrc = make_rsrc(p.f.noise, p.f.noise ? ((int64_t)(p.N - 1) * p.f.noise_batch_stride + (pc ? 3 * p.f.noise_phase_stride : 0) + (int64_t)p.OH * p.OW) * 4 : 0);
     const unsigned side_rel = (unsigned)((wave * 64 + lane) % G::EPS) * 4u;                 // + m0 * 4 (+ n * Cout * 4 for the scales)
     const int noise_dy = t / G::TW, noise_dx = t % G::TW;                                   // this thread's pixel of the tile
     auto issue_side = [&](int par) __attribute__((always_inline)) {
         const int n = par ? d_n1 : d_n0, oy0 = par ? d_oy01 : d_oy00, ox0 = par ? d_ox01 : d_ox00, m0 = par ? d_m01 : d_m00;
         const unsigned sb_ = side_b + (unsigned)(par * G::EP_FLOATS) * 4u;
-        const bool live = (side_scale || side_bias) && m0 + (int)(side_rel >> 2) < p.Cout;
+        const int ph = phase_of(m0), mc0 = m0 - ph * pc;
+        const bool live = (side_scale || side_bias) && mc0 + (int)(side_rel >> 2) < ce;
         dma4(sbrsrc, (side_scale || side_bias) ? sb_ + (unsigned)(wave * 64) * 4u : dump_b, live ? side_rel : SENTINEL,
-             (unsigned)(m0 + (side_scale ? n * p.Cout : 0)) * 4u);
+             (unsigned)(mc0 + (side_scale ? n * ce : 0)) * 4u);
         const int ny = oy0 + noise_dy, nx = ox0 + noise_dx;
         const unsigned noise_voff = (t < G::TH * G::TW && ny < p.OH && nx < p.OW) ? (unsigned)(ny * p.OW + nx) * 4u : SENTINEL;
-        dma4(nrsrc, sb_ + (unsigned)(2 * G::EPS + wave * 64) * 4u, noise_voff, (unsigned)(n * p.f.noise_batch_stride) * 4u);
+        dma4(nrsrc, sb_ + (unsigned)(2 * G::EPS + wave * 64) * 4u, noise_voff, (unsigned)(n * p.f.noise_batch_stride + ph * p.f.noise_phase_stride) * 4u);
     };
 
     // ---- the chunk stream
@@ -437,7 +443,9 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_mfma16(Conv16Params p) {
 
         // ---- epilogue: D col = lane & 31 (pixel), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) (cout)
         const int e_z = dpar ? d_z1 : d_z0;
-        const int e_n = dpar ? d_n1 : d_n0, e_oy0 = dpar ? d_oy01 : d_oy00, e_ox0 = dpar ? d_ox01 : d_ox00, e_m0 = dpar ? d_m01 : d_m00;
+        const int e_n = dpar ? d_n1 : d_n0, e_oy0 = dpar ? d_oy01 : d_oy00, e_ox0 = dpar ? d_ox01 : d_ox00, e_mt0 = dpar ? d_m01 : d_m00;
+        const int e_ph = phase_of(e_mt0), e_m0 = e_mt0 - e_ph * pc;           // phase-local first channel of this block
+        const int e_ooy = pc ? (e_ph >> 1) : p.ooy, e_oox = pc ? (e_ph & 1) : p.oox;
         const unsigned char* side = smem + (size_t)G::NBUF * G::LDS_BUF * 16 + (size_t)dpar * G::EP_FLOATS * 4;
         // per-cout constants of this lane's rows, gain folded in: v = clamp(act(acc * scale + noise + bias) * gain) with a
         // positively homogeneous activation (linear / relu / lrelu, gain > 0) is med3(max(u, u * slope), -cl, cl),
@@ -472,7 +480,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_mfma16(Conv16Params p) {
             const int oy = e_oy0 + row_l, ox = e_ox0 + col_l;
             const bool pix_ok = oy < p.OH && ox < p.OW;
             const float nz = nzv[nt] * noise_gain * gain;
-            const int64_t pix_off = (int64_t)e_z * p.ws_slice + (int64_t)e_n * p.ys[0] + (int64_t)(oy * p.osy + p.ooy) * p.ys[2] + (int64_t)(ox * p.osx + p.oox) * p.ys[3];
+            const int64_t pix_off = (int64_t)e_z * p.ws_slice + (int64_t)e_n * p.ys[0] + (int64_t)(oy * p.osy + e_ooy) * p.ys[2] + (int64_t)(ox * p.osx + e_oox) * p.ys[3];
 #pragma unroll
             for (int mt = 0; mt < MT; mt++) {
                 const int mloc = (wmx * MT + mt) * 32;
@@ -492,7 +500,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_mfma16(Conv16Params p) {
                     for (int g = 0; g < 4; g++) {
                         const int co = e_m0 + mloc + 8 * g + 4 * half;
                         if (rp) {
-                            const bool ok = pix_ok && co < p.Cout;
+                            const bool ok = pix_ok && co < ce;
                             const u32x2 rv = *(const u32x2*)(rp + (ok ? pix_off + co : 0));
                             v[4 * g + 0] += HT::widen((unsigned short)(rv[0] & 0xffff));
                             v[4 * g + 1] += HT::widen((unsigned short)(rv[0] >> 16));
@@ -513,7 +521,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_mfma16(Conv16Params p) {
                             a[d] = r[0]; b[d] = r[1];
                         }
                         const int co = e_m0 + mloc + 8 * (g0 + half);
-                        const unsigned so = (pix_ok && co < p.Cout && !(p.dbg & 1)) ? (unsigned)(pix_off + co) * 2u : SENTINEL;
+                        const unsigned so = (pix_ok && co < ce && !(p.dbg & 1)) ? (unsigned)(pix_off + co) * 2u : SENTINEL;
                         __builtin_amdgcn_raw_buffer_store_b128(u32x4{a[0], a[1], b[0], b[1]}, yrsrc, (int)so, 0, 0);
                     }
                 } else if (p.out_mode == OUT_VEC32) {
@@ -521,7 +529,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_mfma16(Conv16Params p) {
 #pragma unroll
                     for (int g = 0; g < 4; g++) {
                         const int co = e_m0 + mloc + 8 * g + 4 * half;
-                        const unsigned so = (pix_ok && co < p.Cout) ? (unsigned)(pix_off + co) * 4u : SENTINEL;
+                        const unsigned so = (pix_ok && co < ce) ? (unsigned)(pix_off + co) * 4u : SENTINEL;
                         __builtin_amdgcn_raw_buffer_store_b128(u32x4{__builtin_bit_cast(unsigned, v[4 * g]), __builtin_bit_cast(unsigned, v[4 * g + 1]),
                                                                      __builtin_bit_cast(unsigned, v[4 * g + 2]), __builtin_bit_cast(unsigned, v[4 * g + 3])}, yrsrc, (int)so, 0, 0);
                     }
@@ -529,7 +537,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_mfma16(Conv16Params p) {
 #pragma unroll
                     for (int i = 0; i < 16; i++) {
                         const int co = e_m0 + mloc + (i & 3) + 8 * (i >> 2) + 4 * half;
-                        if (pix_ok && co < p.Cout) {
+                        if (pix_ok && co < ce) {
                             const int64_t off = pix_off + (int64_t)co * p.ys[1];
                             if (p.out_mode == OUT_SCALAR32) {
                                 float u = v[i];
@@ -567,6 +575,7 @@ int launch16(const Conv16Params& p0, hipStream_t s) {
     p.tilesX = (p.OW + G::TW - 1) / G::TW;
     p.tilesY = (p.OH + G::TH - 1) / G::TH;
     p.mblocks = (p.Cout + G::BM - 1) / G::BM;              // (not CoutP: the packing pads to 64, a 32-cout block would be all padding)
+    if (p.f.phase_cout && p.f.phase_cout % G::BM != 0) return PG_ERR_UNSUPPORTED;        // a cout block must not straddle two phases
     const int64_t tiles = (int64_t)p.N * p.tilesX * p.tilesY * p.mblocks * (p.ksplit > 1 ? p.ksplit : 1);
     if (tiles > 0x7fffffffLL) return PG_ERR_TOO_LARGE;
     p.total_tiles = (int)tiles;
@@ -588,10 +597,10 @@ int launch16(const Conv16Params& p0, hipStream_t s) {
 // Low-resolution 3x3 layers (8^2 / 16^2 images of the wide blocks): the 16 x 32 pixel tile would be 7/8 or 1/2 padding -- matrix work
 // and weight traffic spent on nothing.  1 = one 8 x 8 image x 128 couts per workgroup, 2 = 16 x 16 pixels x 64 couts (images up to 64 x 64: four times the tiles of the
 // regular shape, so a quarter of the split-K shares and workspace traffic), 0 = the regular tile.  Shared by the launcher and the split-K planner.  PG_CONV16_SMALL=0 switches it off (A/B).
-inline int small_tile16(int KH, int KW, int S, int OH, int OW, int Cout) {
+inline int small_tile16(int KH, int KW, int S, int OH, int OW, int Cout, int phase_cout = 0) {
     static const bool on = [] { const char* e = getenv("PG_CONV16_SMALL"); return e ? atoi(e) != 0 : true; }();
-    if (!on || KH != 3 || KW != 3 || S != 1 || Cout < 128) return 0;
-    if (OH <= 8 && OW <= 8) return 1;
+    if (!on || KH != 3 || KW != 3 || S != 1 || Cout < 128 || phase_cout % 64 != 0) return 0;      // (four-phase mode: whole cout blocks per phase)
+    if (OH <= 8 && OW <= 8 && phase_cout % 128 == 0) return 1;
     static const int lim2 = [] { const char* e = getenv("PG_CONV16_SMALL2_MAX"); return e ? atoi(e) : 64; }();      // (measured on config 5: 16 -> 2.74, 32 -> 2.72, 64 -> 2.68 ms/step: less split-K)
     if (OH <= lim2 && OW <= lim2) return 2;
     return 0;
@@ -601,11 +610,11 @@ inline int small_tile16(int KH, int KW, int S, int OH, int OW, int Cout) {
 template <typename T, int KH, int KW, int S, int NT, int KC, int NB>
 int launch16_mt(const Conv16Params& p, hipStream_t s) {
     if constexpr (KH == 3 && KW == 3 && S == 1) {
-        const int sm = small_tile16(KH, KW, S, p.OH, p.OW, p.Cout);
+        const int sm = small_tile16(KH, KW, S, p.OH, p.OW, p.Cout, p.f.phase_cout);
         if (sm == 1) return launch16<T, KH, KW, S, 8, 4, 1, 1, KC, NB>(p, s);        // TH x TW = 8 x 8, BM = 128
         if (sm == 2) return launch16<T, KH, KW, S, 16, 1, 2, 1, KC, NB>(p, s);       // TH x TW = 16 x 16, BM = 64
     }
-    if (p.Cout <= 32) return launch16<T, KH, KW, S, 32, 1, 1, NT, KC, NB>(p, s);
+    if ((p.f.phase_cout ? p.f.phase_cout : p.Cout) <= 32) return launch16<T, KH, KW, S, 32, 1, 1, NT, KC, NB>(p, s);
     return launch16<T, KH, KW, S, 32, 1, 2, NT, KC, NB>(p, s);
 }
 

@@ -28,7 +28,7 @@ class Fusion16(ctypes.Structure):
     """Mirror of ``pg_conv2d16_fusion`` (include/pasta_gan_ops.h)."""
     _fields_ = [('out_scale', ctypes.c_void_p), ('noise', ctypes.c_void_p), ('noise_batch_stride', ctypes.c_int64), ('noise_gain', ctypes.c_float),
                 ('bias', ctypes.c_void_p), ('act', ctypes.c_int), ('alpha', ctypes.c_float), ('gain', ctypes.c_float), ('clamp', ctypes.c_float),
-                ('residual', ctypes.c_void_p)]
+                ('residual', ctypes.c_void_p), ('phase_cout', ctypes.c_int), ('noise_phase_stride', ctypes.c_int64)]
 
 
 _lib = None
@@ -140,12 +140,21 @@ def pack_weight_grouped(ws, dtype, scale=1.0, flip=False, transpose_oi=False, st
     return packed, (per if (styles is not None or dcoefs is not None) else 0)
 
 
+def phases_supported(cout):
+    """Four-phase launches need the per-phase channel count to be a whole number of cout blocks (pg_conv2d16_fusion)."""
+    return cout == 32 or cout % 64 == 0
+
+
 def conv2d_forward(x, packed, cout, kh, kw, stride=1, pad=(0, 0), out_hw=None, y=None, out_step=(1, 1), out_off=(0, 0), sample_stride=0,
-                   out_dtype=None, out_scale=None, noise=None, noise_gain=1.0, bias=None, act='linear', alpha=0.0, gain=1.0, clamp=None, residual=None):
+                   out_dtype=None, out_scale=None, noise=None, noise_gain=1.0, bias=None, act='linear', alpha=0.0, gain=1.0, clamp=None, residual=None,
+                   phases=False):
     """One launch of the 16-bit MFMA convolution.  `x`: logical [N, Cin, H, W] bf16 / fp16, Cin % 16 == 0 (converted to
     channels-last storage if it is not); `packed` from `pack_weight` (`sample_stride` = its per-sample stride for
     modulated weights).  Writes y[n, co, oy*step+off, ox*step+off]; allocates a channels-last `y` of x's dtype (or a
-    contiguous float32 one for out_dtype=torch.float32) when none is given."""
+    contiguous float32 one for out_dtype=torch.float32) when none is given.
+    `phases=True`: `packed` holds 4 * cout output channels -- the four phase kernels (a, b) = (0,0), (0,1), (1,0), (1,1) of an
+    up-by-2 layer stacked along Cout -- and block 2a + b is written to y[n, :, 2*oy + a, 2*ox + b] (y given, [N, cout, 2*OH, 2*OW]);
+    out_scale / bias have cout entries per row, noise is [N or 1, 4, OH, OW] (phase-major)."""
     lib = _init()
     if x.dtype not in DTYPES or not x.is_cuda or x.ndim != 4:
         raise nat.NativeOpError('conv2d_mfma16: x must be a 4-D bf16 / fp16 GPU tensor')
@@ -164,6 +173,9 @@ def conv2d_forward(x, packed, cout, kh, kw, stride=1, pad=(0, 0), out_hw=None, y
                         memory_format=torch.contiguous_format if out_dtype == torch.float32 else torch.channels_last)
     else:
         assert y.dtype == out_dtype and y.device == x.device and y.shape[0] == n and y.shape[1] == cout
+    if phases:
+        assert residual is None and tuple(y.shape) == (n, cout, 2 * oh, 2 * ow) and phases_supported(cout)
+        out_step, out_off = (2, 2), (0, 0)
     fz = Fusion16()
     keep = []
 
@@ -177,12 +189,13 @@ def conv2d_forward(x, packed, cout, kh, kw, stride=1, pad=(0, 0), out_hw=None, y
     fz.out_scale = dev(out_scale, 'out_scale', n * cout)
     if noise is not None:
         noise = _f32(noise, 'noise')
-        if noise.numel() == oh * ow:
+        per_image = (4 if phases else 1) * oh * ow
+        if noise.numel() == per_image:
             fz.noise_batch_stride = 0
-        elif noise.numel() == n * oh * ow:
-            fz.noise_batch_stride = oh * ow
+        elif noise.numel() == n * per_image:
+            fz.noise_batch_stride = per_image
         else:
-            raise nat.NativeOpError('conv2d_mfma16: noise must have OH*OW or N*OH*OW elements')
+            raise nat.NativeOpError('conv2d_mfma16: noise must have OH*OW or N*OH*OW elements (x 4, phase-major, for a four-phase launch)')
         keep.append(noise)
         fz.noise = noise.data_ptr()
     fz.noise_gain = float(noise_gain)
@@ -194,7 +207,10 @@ def conv2d_forward(x, packed, cout, kh, kw, stride=1, pad=(0, 0), out_hw=None, y
             raise nat.NativeOpError('conv2d_mfma16: residual must match y in dtype, shape and strides')
         keep.append(residual)
         fz.residual = residual.data_ptr()
-    args = [nat.ptr(x), nat.ptr(packed), nat.ptr(y), nat.PG_DTYPE[x.dtype], nat.PG_DTYPE[out_dtype], n, cin, h, w, cout, kh, kw, int(stride),
+    cout_total = cout
+    if phases:
+        fz.phase_cout, fz.noise_phase_stride, cout_total = cout, oh * ow, 4 * cout
+    args = [nat.ptr(x), nat.ptr(packed), nat.ptr(y), nat.PG_DTYPE[x.dtype], nat.PG_DTYPE[out_dtype], n, cin, h, w, cout_total, kh, kw, int(stride),
             int(pad_y), int(pad_x), oh, ow, int(sample_stride), nat.i64arr(y.stride()), int(out_step[0]), int(out_step[1]), int(out_off[0]), int(out_off[1]),
             ctypes.byref(fz)]
     tl = conv2d_mfma._timeline
@@ -204,16 +220,16 @@ def conv2d_forward(x, packed, cout, kh, kw, stride=1, pad=(0, 0), out_hw=None, y
             ev0.record()
         ksplit = 1
         if os.environ.get('PG_CONV_SPLITK', '1') != '0':
-            ksplit = lib.pg_conv2d16_splitk_plan(n, cin, oh, ow, cout, kh, kw, int(stride))
+            ksplit = lib.pg_conv2d16_splitk_plan(n, cin, oh, ow, cout_total, kh, kw, int(stride))
         if ksplit > 1:
-            ws = torch.empty([ksplit * n * cout * oh * ow], dtype=torch.float32, device=x.device)
+            ws = torch.empty([ksplit * n * cout_total * oh * ow], dtype=torch.float32, device=x.device)
             st = lib.pg_conv2d16_forward_splitk(*args, nat.ptr(ws), ksplit, nat.stream_of(x))
         else:
             st = lib.pg_conv2d16_forward(*args, nat.stream_of(x))
         if tl is not None:
             ev1.record()
-            tl.append(((kh, kw, int(stride), 'mfma16', f'N{n} {cin}->{cout} {h}x{w} {str(x.dtype)[6:]}'), 2.0 * n * cout * oh * ow * cin * kh * kw, ev0, ev1,
-                       x.element_size() * (x.numel() + n * cout * oh * ow) + (y.element_size() - x.element_size()) * n * cout * oh * ow
+            tl.append(((kh, kw, int(stride), 'mfma16', f'N{n} {cin}->{cout_total}{" (4 phases)" if phases else ""} {h}x{w} {str(x.dtype)[6:]}'), 2.0 * n * cout_total * oh * ow * cin * kh * kw, ev0, ev1,
+                       x.element_size() * (x.numel() + n * cout_total * oh * ow) + (y.element_size() - x.element_size()) * n * cout_total * oh * ow
                        + packed.numel() * packed.element_size()))       # algorithmic bytes: x + y + the packed weights this launch reads
     nat.check(st, 'pg_conv2d16_forward')
     return y

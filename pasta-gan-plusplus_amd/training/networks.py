@@ -247,6 +247,18 @@ def _modconv_fast16(x, weight, styles, noise, up, padding, resample_filter, demo
                               lambda: {ab: conv2d_mfma16.pack_weight(wab, x.dtype, transpose_oi=True)[0] for ab, wab in phases.items()})
         if noise is not None:           # phase-major copy of the noise map, one pass: [B, 2, 2, h, w]
             noise_phases = noise.reshape(-1, h, 2, w, 2).permute(0, 2, 4, 1, 3).contiguous()
+        if conv2d_mfma16.phases_supported(cout) and os.environ.get('PG_UP2_MERGED', '1') != '0':
+            # all four phases in ONE launch: their kernels stacked along Cout (block 2a + b), each cout block written to its own
+            # output phase -- the input is read once, a quarter of the launches and of the split-K shares
+            wcat = cache.get(('up2_cat', flip_weight), [weight], lambda: torch.cat(list(phases.values()), dim=1).contiguous())
+            if shared:
+                packed = cache.get(('up2_cat_shared', flip_weight, x.dtype), [weight], lambda: conv2d_mfma16.pack_weight(wcat, x.dtype, transpose_oi=True)[0])
+                per = 0
+            else:
+                packed, per, _ = conv2d_mfma16.pack_weight(wcat, x.dtype, transpose_oi=True, styles=s32, dcoefs=dcoefs.repeat(1, 4) if dcoefs is not None else None)
+            conv2d_mfma16.conv2d_forward(xcl, packed, cout, 3, 3, pad=(1, 1), out_hw=(h, w), y=y, sample_stride=per, out_scale=out_scale,
+                                         noise=noise_phases if noise is not None else None, phases=True, **ep)
+            return y if res is None else y.add_(res)
         if not shared:                  # the four per-sample phase packs in one launch
             stacked = cache.get(('up2_stacked', flip_weight), [weight], lambda: torch.stack(list(phases.values())).contiguous())
             packed_all, per = conv2d_mfma16.pack_weight_grouped(stacked, x.dtype, transpose_oi=True, styles=s32, dcoefs=dcoefs)

@@ -242,9 +242,6 @@ def _modconv_fast16(x, weight, styles, noise, up, padding, resample_filter, demo
         y = torch.empty([n, cout, 2 * h, 2 * w], dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
         xcl = conv2d_mfma16.to_channels_last(x)
         res = ep.pop('residual', None)
-        if shared:
-            packs = cache.get(('up2_shared', flip_weight, x.dtype), [weight],
-                              lambda: {ab: conv2d_mfma16.pack_weight(wab, x.dtype, transpose_oi=True)[0] for ab, wab in phases.items()})
         if noise is not None:           # phase-major copy of the noise map, one pass: [B, 2, 2, h, w]
             noise_phases = noise.reshape(-1, h, 2, w, 2).permute(0, 2, 4, 1, 3).contiguous()
         if conv2d_mfma16.phases_supported(cout) and os.environ.get('PG_UP2_MERGED', '1') != '0':
@@ -259,7 +256,10 @@ def _modconv_fast16(x, weight, styles, noise, up, padding, resample_filter, demo
             conv2d_mfma16.conv2d_forward(xcl, packed, cout, 3, 3, pad=(1, 1), out_hw=(h, w), y=y, sample_stride=per, out_scale=out_scale,
                                          noise=noise_phases if noise is not None else None, phases=True, **ep)
             return y if res is None else y.add_(res)
-        if not shared:                  # the four per-sample phase packs in one launch
+        if shared:
+            packs = cache.get(('up2_shared', flip_weight, x.dtype), [weight],
+                              lambda: {ab: conv2d_mfma16.pack_weight(wab, x.dtype, transpose_oi=True)[0] for ab, wab in phases.items()})
+        else:                           # the four per-sample phase packs in one launch
             stacked = cache.get(('up2_stacked', flip_weight), [weight], lambda: torch.stack(list(phases.values())).contiguous())
             packed_all, per = conv2d_mfma16.pack_weight_grouped(stacked, x.dtype, transpose_oi=True, styles=s32, dcoefs=dcoefs)
         for g, ((a, b), wab) in enumerate(phases.items()):

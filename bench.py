@@ -203,7 +203,7 @@ def run_stack(args, rank, world, dev, dist):
         elapsed = eager_elapsed = time.perf_counter() - t0
         conv2d_mfma.stop_timeline()
         if not args.no_graph:
-            # the step is launch-bound on the host (~250 kernels, 4.3 ms of GPU time): replay it as one hipGraph (training/graphed.py).
+            # the step is launch-bound on the host (~95 kernels, 2.4 ms of GPU time): replay it as one hipGraph (training/graphed.py).
             # Events cannot be recorded inside a replayed graph, hence the eager pass above for the per-kernel durations.
             from training.graphed import GraphedForward
             fwd = GraphedForward(lambda w_: net(w_, noise_mode='const'), [ws], warmup=1)

@@ -37,9 +37,9 @@
 #define WINO_PK 0        // 1 = the round-1 packed-fp32 form of the K-loop transform (A/B switch)
 #endif
 #ifndef WINO_PRIO
-#define WINO_PRIO 1      // 1 = wave priority 2 through the K loop (and again right before each pair's MFMA group), 0 in the tail: a workgroup that
-                         // multiplies wins issue arbitration over the co-resident workgroup's inverse transform / stores, whose VALU, LDS and
-                         // store instructions then fill the gaps instead of delaying MFMAs (measured 1.5-2.7 % per launch; 0 = off, A/B)
+#define WINO_PRIO 1      // 1 = wave priority 2 for each pair's MFMA group, 1 for the rest of the K loop, 0 in the tail: a workgroup that multiplies
+                         // wins issue arbitration over the co-resident workgroup's inverse transform / stores, whose VALU, LDS and store
+                         // instructions then fill the gaps instead of delaying MFMAs (measured 1.5-2.7 % per launch; 0 = off, A/B)
 #endif
 #ifndef WINO_EXP
 #define WINO_EXP 0       // dev ablations (tools/wino_variants.py; results wrong by design): 1 no U loads, 2 no LDS operand reads, 4 no tail,
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(512, 4) void conv2d_wino(ConvParams p) {
         float* ep_scale = ep0 + par * 128;           // per tile parity: the next tile's constants are written while slow
         float* ep_bias = ep_scale + 64;              // waves may still be in this tile's epilogue
 #if WINO_PRIO
-        __builtin_amdgcn_s_setprio(2);
+        __builtin_amdgcn_s_setprio(1);
 #endif
 #pragma unroll 1                                     // unrolled by two, the ragged plain variant spills a VGPR whose reload brings a vmcnt(0) into the loop
         for (int k = 0; k < nchunks; k++, g++) {
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(512, 4) void conv2d_wino(ConvParams p) {
                 acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_ring[pp % W_RING][2], v2, acc[2], 0, 0, 0);
                 acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_ring[pp % W_RING][3], v3, acc[3], 0, 0, 0);
 #if WINO_PRIO
-                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_s_setprio(1);
 #endif
                 if (pp == W_KC / 2 - W_RING && k + 1 == nchunks) a_reset();  // from here on: the next tile's first pairs
 #if !(WINO_EXP & 1)

@@ -44,7 +44,7 @@
 #ifndef WINO_EXP
 #define WINO_EXP 0       // dev ablations (tools/wino_variants.py; results wrong by design): 1 no U loads, 2 no LDS operand reads, 4 no tail,
                          // 8 no halo DMA, 128 no chunk barrier, 256 no transform VALU, 512 eight extra independent VALU ops per channel pair,
-                         // 1024 no LDS exchange in the tail, 2048 no output stores
+                         // 1024 no LDS exchange in the tail, 2048 no output stores, 32768 no wave priorities
 #endif
 
 namespace pgconv {
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(512, 4) void conv2d_wino(ConvParams p) {
         const float* cs_cur = cs0 + par * cin_loop;
         float* ep_scale = ep0 + par * 128;           // per tile parity: the next tile's constants are written while slow
         float* ep_bias = ep_scale + 64;              // waves may still be in this tile's epilogue
-#if WINO_PRIO
+#if WINO_PRIO && !(WINO_EXP & 32768)
         __builtin_amdgcn_s_setprio(1);
 #endif
 #pragma unroll 1                                     // unrolled by two, the ragged plain variant spills a VGPR whose reload brings a vmcnt(0) into the loop
@@ -363,14 +363,14 @@ __global__ __launch_bounds__(512, 4) void conv2d_wino(ConvParams p) {
                 const float v0 = q0 - q2, v1 = q1 + q2, v2 = q2 - q1, v3 = q1 - q3;      // B^T d B, row a
 #endif
                 wait_a(a_ring[pp % W_RING], pp < W_RING, pp < W_RING && k == 0);   // first pairs of a tile: landed before the previous epilogue's stores
-#if WINO_PRIO
+#if WINO_PRIO && !(WINO_EXP & 32768)
                 __builtin_amdgcn_s_setprio(2);
 #endif
                 acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_ring[pp % W_RING][0], v0, acc[0], 0, 0, 0);
                 acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_ring[pp % W_RING][1], v1, acc[1], 0, 0, 0);
                 acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_ring[pp % W_RING][2], v2, acc[2], 0, 0, 0);
                 acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_ring[pp % W_RING][3], v3, acc[3], 0, 0, 0);
-#if WINO_PRIO
+#if WINO_PRIO && !(WINO_EXP & 32768)
                 __builtin_amdgcn_s_setprio(1);
 #endif
                 if (pp == W_KC / 2 - W_RING && k + 1 == nchunks) a_reset();  // from here on: the next tile's first pairs
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(512, 4) void conv2d_wino(ConvParams p) {
 #endif
         }
 
-#if WINO_PRIO
+#if WINO_PRIO && !(WINO_EXP & 32768)
         __builtin_amdgcn_s_setprio(0);
 #endif
         // ---- inverse transform + fused epilogue.  Column half in registers: Y'[a][q] = sum_b M[a][b] At[q][b]; the row half

@@ -33,6 +33,8 @@ for v in VARIANTS:
     custom_ops.get_plugin = _orig
 
 SHAPES = [(8, 256, 128, 128), (8, 256, 64, 128), (8, 512, 64, 64), (8, 64, 512, 512), (8, 128, 256, 256)]
+if os.environ.get('WINO_SHAPES'):               # e.g. WINO_SHAPES=4,256,128,128;4,16,512,512  (N,H,Cin,Cout)
+    SHAPES = [tuple(int(v) for v in sh.split(',')) for sh in os.environ['WINO_SHAPES'].split(';')]
 rounds = int(os.environ.get('WINO_ROUNDS', '7'))
 for (N, H, cin, cout) in SHAPES:
     x = torch.randn(N, cin, H, H, device='cuda')

@@ -81,9 +81,16 @@ class TrainingStep:
         if self.ema_rampup is not None:
             ema_nimg = min(ema_nimg, self.cur_nimg * self.ema_rampup)
         beta = 0.5 ** (self.batch_size / max(ema_nimg, 1e-8))
+        # p_ema <- p.lerp(p_ema, beta), b_ema <- b (training_loop_fullbody.py:486-494) as multi-tensor launches: a handful per step
+        # instead of two per parameter and one per buffer
+        ps, ps_ema, bs, bs_ema = [], [], [], []
         for name, m in self.G_parts.items():
             ema = self.G_ema_parts[name]
             for p_ema, p in zip(ema.parameters(), m.parameters()):
-                p_ema.copy_(p.lerp(p_ema, beta))
+                ps.append(p.detach()); ps_ema.append(p_ema)
             for b_ema, b in zip(ema.buffers(), m.buffers()):
-                b_ema.copy_(b)
+                bs.append(b); bs_ema.append(b_ema)
+        if ps:
+            torch._foreach_copy_(ps_ema, torch._foreach_lerp(ps, ps_ema, beta))
+        if bs:
+            torch._foreach_copy_(bs_ema, bs)

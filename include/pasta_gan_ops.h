@@ -2,11 +2,14 @@
  * pasta_gan_ops.h -- C ABI of the MI355X (gfx950) kernels behind PASTA-GAN++'s
  * generator-synthesis operator API.
  *
- * Three shared libraries export these symbols (one per reference "plugin"):
- *   bias_act_plugin.so   pg_bias_act
- *   upfirdn2d_plugin.so  pg_upfirdn2d
- *   conv2d_plugin.so     pg_conv2d_pack_weight, pg_conv2d_forward,
- *                        pg_modconv_dcoefs, pg_instance_norm_stats, pg_spade_norm
+ * Four shared libraries export these symbols (one per reference "plugin", plus the loader's patch routing):
+ *   bias_act_plugin.so      pg_bias_act
+ *   upfirdn2d_plugin.so     pg_upfirdn2d, pg_upfirdn2d_bias_act
+ *   conv2d_plugin.so        fp32: pg_conv2d_{packed_size,pack_weight,forward,splitk_plan,forward_splitk}, pg_conv2d_winograd_*,
+ *                           pg_conv2d_up2_forward, pg_conv1x1_small, pg_conv3x3_cin1, pg_conv2d_wgrad{_plan,};
+ *                           16-bit: pg_conv2d16_{packed_size,pack_weight,pack_weight_grouped,forward,splitk_plan,forward_splitk},
+ *                           pg_conv1x1_small16;  glue: pg_modconv_{dcoefs,w2,prep}, pg_instance_norm_stats, pg_spade_*
+ *   patch_routing_plugin.so pg_patch_routing_*
  * plus pg_<plugin>_abi_version() in each.  They are what the reference's L1
  * Python ops bind in place of its pybind plugins (see INTEGRATION.md for the
  * ctypes stub a maintainer adds to the reference tree).

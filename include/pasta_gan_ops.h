@@ -9,7 +9,7 @@
  *                           pg_conv2d_up2_forward, pg_conv1x1_small, pg_conv3x3_cin1, pg_conv2d_wgrad{_plan,};
  *                           16-bit: pg_conv2d16_{packed_size,pack_weight,pack_weight_grouped,forward,splitk_plan,forward_splitk},
  *                           pg_conv1x1_small16;  glue: pg_modconv_{dcoefs,w2,prep}, pg_instance_norm_stats, pg_spade_*
- *   patch_routing_plugin.so pg_patch_routing_*
+ *   patch_routing_plugin.so pg_warp_perspective_u8, pg_patch_compose_u8
  * plus pg_<plugin>_abi_version() in each.  They are what the reference's L1
  * Python ops bind in place of its pybind plugins (see INTEGRATION.md for the
  * ctypes stub a maintainer adds to the reference tree).

@@ -5,10 +5,12 @@ random latents + style maps, noise_mode='const', argmax parsing path as test.py 
 
     python bench.py --gpus N --steps K --warmup W
 
-N > 1 is launched by the driver through torch.distributed.run, one rank per GPU; every rank
-runs the same workload on its own batch (independent images, no data-path collective:
-"weak" scaling); RCCL is used only for the barrier and the max-over-ranks
-of the timed region.  Rank 0 prints ONE JSON line.
+N > 1: one rank per GPU.  Started through torch.distributed.run (RANK / WORLD_SIZE in the environment) this process IS
+a rank; started plainly as `python bench.py --gpus N` it is the launcher: before importing torch or touching the GPU it
+starts N fresh child processes of itself (training/launch.py, what the reference's train.py:563-568 does with
+torch.multiprocessing.spawn) and waits.  Every rank asserts WORLD_SIZE == --gpus.  Every rank runs the same workload on
+its own batch (independent images, no data-path collective: "weak" scaling); RCCL is used only for
+the barrier and the max-over-ranks of the timed region.  Rank 0 prints ONE JSON line.
 
 Extra objects on that line:
   roofline     -- dominant kernel = conv2d_wino (Winograd F(2x2,3x3) convolution, csrc/conv2d_wino.h:
@@ -21,6 +23,9 @@ Extra objects on that line:
                   --mode bf16_1024 (config 5): dominant kernel = conv2d_mfma16, HBM-bound.
   cpu_baseline -- the CPU oracle (oracle/network_ref.py, a port) timed on this host at N=1 on a
                   bounded sample (rank 0, --gpus 1 only).
+  secondary    -- (--gpus 1, headline mode only) BASELINE configs 3 and 5 run as short child processes of the same script after the
+                  headline's timed region: their value / ms_per_step / roofline, so that those numbers are driver-timed too.
+                  Headline fields are untouched by it.
 """
 
 import argparse
@@ -34,7 +39,7 @@ sys.path.insert(0, os.path.join(ROOT, 'pasta-gan-plusplus_amd'))
 sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
+torch = None                     # imported by main() AFTER the launcher branch: the launcher parent must not touch the GPU runtime
 
 CFG2 = dict(w_dim=512, img_resolution=512, img_channels=3, channel_base=32768, channel_max=512, conv_clamp=256)
 BATCH_PER_GPU = 8
@@ -301,8 +306,72 @@ def run_train(args, rank, world, dev, dist):
                               n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(1e3 * elapsed / args.steps, 1), higher_is_better=True,
                               scaling='weak', vs_baseline=None, dtype='f32', data='synthetic', images_per_sec=round(args.steps * n * world / elapsed, 3),
                               config=dict(workload='BASELINE config 4: fullbody G+D step, lazy R1 (gamma 10), L1 + parsing CE, no VGG; ' + (f'discriminators fp16 at their {args.d_fp16_res} highest resolutions (train.py:196)' if args.d_fp16_res else 'discriminators in fp32'),
-                                          batch_per_gpu=n, global_batch=n * world, parallelism=f'dp{world} flat-bucket reduce_scatter+all_gather (RCCL)',
+                                          batch_per_gpu=n, global_batch=n * world, parallelism=f'dp{world}, one flat fp32 gradient bucket per phase, segment all_reduce (RCCL) launched from autograd hooks on a side stream',
                                           first_batch_idx=0, note='steps start at batch_idx = warmup; reg phases fire every 4th (G) / 16th (D) iteration'))), flush=True)
+
+
+def run_selftest(args, rank, world):
+    """Launcher / rank plumbing without a GPU (tests/test_bench_launcher.py): gloo, a stub forward, the same barrier -> timed
+    steps -> barrier -> MAX over ranks -> one JSON line from rank 0 protocol as the real modes.  Not a measurement."""
+    import torch.distributed as dist
+    from training import replicas
+    if world > 1 or 'RANK' in os.environ:
+        dist.init_process_group('gloo')
+    stub = torch.nn.Conv2d(3, 4, 3, padding=1)
+    x = torch.randn([args.batch, 3, 16, 16], generator=torch.Generator().manual_seed(rank))
+
+    def barrier():
+        if dist.is_initialized():
+            dist.barrier()
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            stub(x)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            y = stub(x)
+        barrier()
+    elapsed = replicas.max_over_ranks(time.perf_counter() - t0)
+    ranks_seen = torch.zeros([world])
+    ranks_seen[rank] = 1
+    if dist.is_initialized():
+        dist.all_reduce(ranks_seen)
+    if rank == 0:
+        print(json.dumps(dict(metric='launcher selftest (stub forward on CPU, gloo)', value=round(args.steps * args.batch * world / elapsed, 3), unit='images/s',
+                              n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(1e3 * elapsed / args.steps, 3), higher_is_better=True,
+                              scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
+                              config=dict(workload='stub', images_per_gpu_per_step=args.batch, global_batch=args.batch * world, parallelism=f'replicas x{world}',
+                                          ranks_seen=int(ranks_seen.sum()), out_shape=list(y.shape)))), flush=True)
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def secondary_runs(budget_s=150.0):
+    """BASELINE configs 3 and 5 as child processes of this script (fresh processes: the parent's GPU memory pool and plugin state do not
+    leak into them; the parent only waits -- it never execs), a few seconds each; their JSON lines are attached to the headline
+    line as `secondary`.  Failures are recorded, never raised: the headline must not depend on them."""
+    import subprocess
+    out = {}
+    t_start = time.perf_counter()
+    for key, extra in (('config3_generator', ['--mode', 'generator', '--steps', '8', '--warmup', '3']),
+                       ('config5_bf16_1024', ['--mode', 'bf16_1024', '--steps', '30', '--warmup', '10', '--no-cpu-baseline'])):
+        left = budget_s - (time.perf_counter() - t_start)
+        if left < 20:
+            out[key] = dict(error='skipped: time budget of the secondary runs used up')
+            continue
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), '--gpus', '1', *extra], capture_output=True, text=True, timeout=left,
+                               env={k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE')})
+            line = [l for l in r.stdout.splitlines() if l.startswith('{')]
+            if r.returncode != 0 or not line:
+                out[key] = dict(error=f'exit {r.returncode}: {(r.stderr or r.stdout)[-300:]}')
+                continue
+            j = json.loads(line[-1])
+            out[key] = {k: j[k] for k in ('metric', 'value', 'unit', 'steps', 'warmup', 'ms_per_step', 'dtype', 'config', 'roofline') if k in j}
+        except Exception as e:                                # noqa: BLE001 -- recorded, the headline line still prints
+            out[key] = dict(error=f'{type(e).__name__}: {e}'[:300])
+    return out
 
 
 def main():
@@ -315,21 +384,35 @@ def main():
     ap.add_argument('--no-graph', action='store_true', help='config 5: time eager launches instead of hipGraph replays')
     ap.add_argument('--d-fp16-res', type=int, default=3, help='config 4: discriminator resolutions in fp16 (train.py:196: 3; 0 = fp32)')
     ap.add_argument('--conv-breakdown', default=None, metavar='CSV', help='also write the per-shape conv launch timeline of the timed steps')
-    ap.add_argument('--mode', choices=['synthesis', 'generator', 'train', 'bf16_1024'], default='synthesis',
+    ap.add_argument('--mode', choices=['synthesis', 'generator', 'train', 'bf16_1024', 'selftest'], default='synthesis',
                     help="'synthesis' = the headline (config 2); 'generator' = config 3 (encoders + mapping + synthesis, N=16); 'train' = config 4 step; "
-                         "'bf16_1024' = config 5 (StyleGAN2 stack at 1024^2 in bf16, N=4)")
+                         "'bf16_1024' = config 5 (StyleGAN2 stack at 1024^2 in bf16, N=4); 'selftest' = launcher / rank plumbing on CPU over gloo with a stub forward (no measurement)")
+    ap.add_argument('--no-secondary', action='store_true', help='headline mode: skip the config 3 / config 5 child runs')
     ap.add_argument('--channel-max', type=int, default=1024, help="config 5: widest layer (SURVEY 8d: 'channels 1024 -> 32')")
     args = ap.parse_args()
 
+    from training import launch
+    if args.gpus > 1 and not launch.launched_as_rank():
+        # Plain `python bench.py --gpus N`: this process is the launcher.  It has imported neither torch nor the plugins and never
+        # touches the GPU; the N ranks are fresh children of it (reference: train.py:563-568).
+        sys.exit(launch.spawn_ranks([os.path.abspath(__file__), *sys.argv[1:]], args.gpus))
+
+    global torch
+    import torch as _torch
+    torch = _torch
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        sys.exit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start it plainly (it launches its own ranks) or with --nproc-per-node {args.gpus}')
+    if args.mode == 'selftest':
+        return run_selftest(args, rank, world)
     if not torch.cuda.is_available():
         sys.exit('bench.py needs an MI355X: the product has no CPU path')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     dist = None
-    if world > 1 or 'RANK' in os.environ:                   # launched by torch.distributed.run: one rank per GPU
+    if world > 1 or launch.launched_as_rank():              # one rank per GPU
         import torch.distributed as dist
         dist.init_process_group('nccl', device_id=dev)      # RCCL over xGMI
 
@@ -404,6 +487,10 @@ def main():
                     roofline=roofline)
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline()
+        if world == 1 and not args.no_secondary:
+            del net, inp, out                                  # the children get the whole GPU
+            torch.cuda.empty_cache()
+            line['secondary'] = secondary_runs()
         if args.conv_breakdown:                                # per (geometry, algorithm, shape, fused stages): launches, time, rate
             groups = {}
             for geo, fl, e0, e1, _ in timeline:

@@ -13,9 +13,14 @@ steps (Gmain: 43 M floats = 172 MB; each discriminator: 31.6 M = 126 MB):
   the backward kernels of the earlier layers are still executing (what DDP's bucket hooks give the reference).
   Large segments suit the point-to-point xGMI mesh (7 links per GPU): RCCL splits 30-60 MB over all links;
 * parameters that received no gradient on ANY rank keep ``grad = None`` -- exactly what the reference's optimizers
-  see (DDP leaves unused parameters untouched): a tiny MAX all-reduce of the per-parameter "touched" flags decides,
-  and ``any_touched`` tells the caller whether the phase produced a gradient at all (the Greg phase does not: no
-  exchange, no optimizer step, so Adam's statistics do not depend on the world size).
+  see (DDP leaves unused parameters untouched).  The per-parameter "touched" flags travel INSIDE the segments (one float
+  per parameter at each segment's tail, summed with the gradients), and ``any_touched`` tells the caller whether the
+  phase produced a gradient at all;
+* **the collectives a rank issues never depend on which parameters received a gradient on that rank** (ADVICE r2): a phase
+  is exactly ``len(seg_range)`` all-reduces, segment 0, 1, 2, ... in index order and nothing else.  A hook launches
+  segment k only once segments 0..k-1 are launched; ``finish()`` launches whatever is left, in order.  Ranks whose graphs
+  differ (data-dependent unused parameters, which the reference tolerates with find_unused_parameters=True) therefore
+  still pair every collective with its peer's collective of the same size.
 """
 
 import torch
@@ -32,31 +37,45 @@ class GradBucket:
         # reverse registration order: the last layers' gradients are produced first
         order = list(range(len(self.params)))[::-1]
         sizes = [self.params[i].numel() for i in order]
-        self.total = sum(sizes)
-        self.flat = torch.zeros([self.total], dtype=torch.float32, device=dev)
-        self.views, off = [None] * len(self.params), 0
-        self.offset = [0] * len(self.params)
-        for i, n in zip(order, sizes):
-            self.views[i] = self.flat[off:off + n].view_as(self.params[i])
-            self.offset[i] = off
-            off += n
-        # segment boundaries on parameter boundaries, ~equal sizes
+        total = sum(sizes)
+        # segment boundaries on parameter boundaries, ~equal sizes; layout of a segment: [its gradients | one flag per parameter]
         nseg = max(1, min(int(segments), len(self.params)))
-        target, self.seg_of, self.seg_range = self.total / nseg, [0] * len(self.params), []
-        start, seg = 0, 0
+        target, self.seg_of = total / nseg, [0] * len(self.params)
+        members, acc, seg = [[]], 0, 0
         for k, (i, n) in enumerate(zip(order, sizes)):
+            members[-1].append(i)
             self.seg_of[i] = seg
-            end = self.offset[i] + n
-            if (end - start >= target and seg < nseg - 1) or k == len(order) - 1:
-                self.seg_range.append((start, end))
-                start, seg = end, seg + 1
-        self.seg_members = [sum(1 for s in self.seg_of if s == k) for k in range(len(self.seg_range))]
-        self.touched = torch.zeros([len(self.params)], dtype=torch.float32, device=dev)
+            acc += n
+            if acc >= target * (seg + 1) and seg < nseg - 1 and k < len(order) - 1:
+                members.append([])
+                seg += 1
+        self.total = total + len(self.params)
+        self.flat = torch.zeros([self.total], dtype=torch.float32, device=dev)
+        self.views, self.offset = [None] * len(self.params), [0] * len(self.params)
+        self.seg_range, self.flag_range, self.flag_slot = [], [], [0] * len(self.params)
+        off = 0
+        for mem in members:
+            start = off
+            for i in mem:
+                n = self.params[i].numel()
+                self.views[i] = self.flat[off:off + n].view_as(self.params[i])
+                self.offset[i] = off
+                off += n
+            self.flag_range.append((off, off + len(mem)))
+            for j, i in enumerate(mem):
+                self.flag_slot[i] = off + j
+            off += len(mem)
+            self.seg_range.append((start, off))
+        assert off == self.total
+        self.members = members
+        self.seg_members = [len(mem) for mem in members]
+        self._slot_index = torch.tensor(self.flag_slot, dtype=torch.int64, device=dev)
         self._touched_host = [False] * len(self.params)
         self._pending, self._launched, self._works = [], [], []
         self._active = False
         self._comm_stream = torch.cuda.Stream(device=dev) if dev.type == 'cuda' else None
         self.any_touched = False
+        self.launch_log = []                                 # (segment, 'hook' | 'finish') in issue order, per phase: tests read it
         for i, p in enumerate(self.params):
             was = p.requires_grad                            # the step freezes every module between phases; hooks need a leaf that requires grad
             p.requires_grad_(True)
@@ -65,7 +84,7 @@ class GradBucket:
 
     # ------------------------------------------------------------------ per-phase protocol
     def begin(self):
-        """Before the phase's backward passes: zero the bucket, point every .grad into it, arm the hooks."""
+        """Before the phase's backward passes: zero the bucket (gradients and flags), point every .grad into it, arm the hooks."""
         self.flat.zero_()
         for p, v in zip(self.params, self.views):
             p.grad = v
@@ -73,6 +92,7 @@ class GradBucket:
         self._pending = list(self.seg_members)
         self._launched = [False] * len(self.seg_range)
         self._works = []
+        self.launch_log = []
         self._active = True
         self._sync_round = False
 
@@ -87,18 +107,30 @@ class GradBucket:
                 return
             self._touched_host[i] = True
             if self._sync_round and self.world > 1:
-                k = self.seg_of[i]
-                self._pending[k] -= 1
-                if self._pending[k] == 0:
-                    self._launch(k)
+                self._pending[self.seg_of[i]] -= 1
+                self._launch_ready('hook')
         return hook
 
-    def _launch(self, k):
-        if self._launched[k]:
-            return
+    def _launch_ready(self, who):
+        """Launch, in index order, every segment whose gradients are all enqueued -- never skipping over an unfinished one."""
+        for k in range(len(self.seg_range)):
+            if self._launched[k]:
+                continue
+            if self._pending[k] > 0:
+                return
+            self._launch(k, who)
+
+    def _launch(self, k, who):
         self._launched[k] = True
+        self.launch_log.append((k, who))
         a, b = self.seg_range[k]
+        fa, fb = self.flag_range[k]
         seg = self.flat[a:b]
+        if who == 'hook':
+            self.flat[fa:fb].fill_(1.0)                      # launched from a hook: every parameter of the segment has a gradient here
+        else:
+            flags = [1.0 if self._touched_host[i] else 0.0 for i in self.members[k]]
+            self.flat[fa:fb].copy_(torch.tensor(flags, dtype=torch.float32), non_blocking=False)
         if self._comm_stream is not None:
             ev = torch.cuda.Event()
             ev.record()                                      # everything enqueued so far: this segment's gradients are among it
@@ -110,22 +142,23 @@ class GradBucket:
             self._works.append((dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self.group, async_op=True), seg))
 
     def finish(self):
-        """After the last backward: exchange what the hooks could not (segments holding unused parameters), decide which
-        gradients exist anywhere, hand `None` back to the rest.  Returns True if the phase produced any gradient."""
+        """After the last backward: exchange what the hooks could not (segments holding parameters without a gradient on this
+        rank), in index order; then read the summed flags, hand `None` back to parameters nobody produced.  Returns True if
+        the phase produced any gradient anywhere."""
         self._active = False
-        flags = torch.tensor([1.0 if t else 0.0 for t in self._touched_host], dtype=torch.float32, device=self.flat.device)
         if self.world > 1:
-            dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=self.group)
-        alive = flags.cpu().tolist() if self.world > 1 else [1.0 if t else 0.0 for t in self._touched_host]
-        self.any_touched = any(a > 0 for a in alive)
-        if self.world > 1 and self.any_touched:
             for k in range(len(self.seg_range)):
-                self._launch(k)
+                if not self._launched[k]:
+                    self._launch(k, 'finish')
             if self._comm_stream is not None:
                 torch.cuda.current_stream(self.flat.device).wait_stream(self._comm_stream)
             for work, seg in self._works:
                 work.wait()
                 seg.mul_(1.0 / self.world)
+            alive = self.flat[self._slot_index].cpu().tolist()
+        else:
+            alive = [1.0 if t else 0.0 for t in self._touched_host]
+        self.any_touched = any(a > 0 for a in alive)
         for p, a in zip(self.params, alive):
             if a == 0:
                 p.grad = None                                # no rank produced it: the optimizer must not see a zero gradient

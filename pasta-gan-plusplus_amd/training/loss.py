@@ -37,6 +37,11 @@ class StyleGAN2Loss:
         self.report = report or (lambda name, value: None)
         self.on_last_backward = None          # callable; fired once per accumulate_gradients(sync=True), before its last backward
 
+    def phase_is_empty(self, phase):
+        """True for a phase that runs no backward whatever the data (the same answer on every rank): 'Greg', whose only term --
+        path-length regularisation -- is commented out in the reference (loss_fullbody.py:200-221); an R1 phase with gamma 0."""
+        return phase == 'Greg' or (phase in ('Dreg', 'D_parsingreg') and self.r1_gamma == 0)
+
     # ------------------------------------------------------------------ forward helpers (loss_fullbody.py:75-114)
     def run_G(self, z, c, pose, const_feats, denorm_upper_mask, denorm_lower_mask, denorm_upper_input, denorm_lower_input, gt_parsing):
         cat_feats = {str(f.shape[2]): f for f in const_feats}

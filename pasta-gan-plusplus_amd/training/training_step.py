@@ -7,9 +7,10 @@ Phases, in order (each with its own Adam; lazy regularisation rescales lr/betas 
 Per due phase: gradients are views of the phase's flat bucket (training.ddp.GradBucket.begin) -> only the phase's
 module requires grad -> accumulate over the rounds of this rank's share of the batch; during the LAST backward of the
 last round finished segments of the bucket are already being summed over RCCL on a side stream -> finish the exchange
--> nan_to_num -> Adam step.  A phase that produced no gradient on any rank (Greg: path-length regularisation is
-commented out in the reference, loss_fullbody.py:200-221) exchanges nothing and takes no optimizer step -- what the
-reference's Adam does with all-None gradients.  Then the G_ema update (:642-650).  ADA / ticks / snapshots / metrics are outside the hot path and not restated.
+-> nan_to_num -> Adam step.  A phase the loss declares statically empty (Greg: path-length regularisation is
+commented out in the reference, loss_fullbody.py:200-221) is skipped on every rank alike; any other phase issues the same
+collectives on every rank whatever gradients it produced (training/ddp.py), and one that produced no gradient anywhere
+takes no optimizer step -- what the reference's Adam does with all-None gradients.  Then the G_ema update (:642-650).  ADA / ticks / snapshots / metrics are outside the hot path and not restated.
 """
 
 import copy
@@ -57,6 +58,8 @@ class TrainingStep:
         """`rounds`: this rank's accumulation rounds, each a dict of the tensors accumulate_gradients takes
         (real_img, gen_z, style_input, retain, pose, denorm_*_input, denorm_*_mask, gt_parsing)."""
         for ph in self.due_phases():
+            if getattr(self.loss, 'phase_is_empty', lambda name: False)(ph.name):
+                continue                                         # statically empty on every rank (Greg): no forward, no exchange, no step
             ph.bucket.begin()                                    # zero the flat bucket; every .grad is a view into it
             for m in ph.modules:
                 m.requires_grad_(True)

@@ -78,13 +78,13 @@ def _ddp_worker(rank, world, init_file, out_file):
     stubs.set_phase_trainable(nets, 'Dboth')
     params = list(nets['D'].parameters())
     extra = torch.nn.Parameter(torch.zeros(3))                      # a parameter that never receives a gradient
-    bucket = ddp.GradBucket(params + [extra], segments=3)
+    bucket = ddp.GradBucket([extra] + params, segments=3)           # first registered = last segment (like synthesis.b8.const): earlier segments still launch from hooks
     assert len(bucket.seg_range) >= 2                               # several segments: some launch from the hooks, the rest in finish()
     bucket.begin()
     assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(bucket.params, bucket.views))      # gradients ARE the bucket
     loss.on_last_backward = bucket.last_round                       # Dboth = two backward calls; only the second may exchange
     loss.accumulate_gradients(phase='Dboth', sync=True, **mine)
-    launched_by_hooks = sum(bucket._launched)
+    launched_by_hooks = sum(1 for _, who in bucket.launch_log if who == 'hook')
     assert bucket.finish() is True
     assert extra.grad is None                                       # untouched on every rank: stays None (no zero gradient for Adam)
     assert all(p.grad is not None for p in params)
@@ -109,6 +109,48 @@ def test_flat_bucket_overlapped_exchange_two_ranks():
     loss.accumulate_gradients(phase='Dboth', **stubs.batch(4))
     for i, p in enumerate(nets['D'].parameters()):
         np.testing.assert_allclose(got[f'p{i}'], p.grad.numpy(), rtol=2e-4, atol=1e-6)
+
+
+def _diverging_worker(rank, world, init_file, out_file):
+    sys.path.insert(0, PKG)
+    from training import ddp
+    torch.set_num_threads(2)
+    dist.init_process_group('gloo', init_method=f'file://{init_file}', rank=rank, world_size=world)
+    torch.manual_seed(0)
+    ps = [torch.nn.Parameter(torch.randn(n)) for n in (5, 7, 3, 6, 4, 8)]
+    bucket = ddp.GradBucket(ps, segments=3)
+    assert len(bucket.seg_range) == 3
+    logs = []
+    for it in range(2):
+        bucket.begin()
+        bucket.last_round()
+        # rank 1 never uses ps[3] (a middle segment), rank 0 never uses ps[0] (the LAST segment); nobody uses ps[5] in iteration 1
+        used = [i for i in range(6) if not (rank == 1 and i == 3) and not (rank == 0 and i == 0) and not (it == 1 and i == 5)]
+        sum(((rank + 1.0) * (i + 1.0) * ps[i]).sum() for i in used).backward()
+        assert bucket.finish() is True
+        logs.append(list(bucket.launch_log))
+        assert [k for k, _ in bucket.launch_log] == [0, 1, 2]            # every rank: the same collectives in the same order
+        for i, p in enumerate(ps):
+            users = [r for r in range(world) if not (r == 1 and i == 3) and not (r == 0 and i == 0) and not (it == 1 and i == 5)]
+            if not users:
+                assert p.grad is None
+            else:
+                want = sum((r + 1.0) * (i + 1.0) for r in users) / world
+                assert torch.allclose(p.grad, torch.full_like(p.grad, want)), (it, i, p.grad, want)
+    if rank == 0:
+        np.savez(out_file, hook0=np.array([sum(1 for _, w in l if w == 'hook') for l in logs]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_collective_order_does_not_depend_on_which_parameters_got_gradients():
+    """ranks whose graphs differ (a parameter unused on one rank only) must still issue the same
+    all-reduces in the same order -- segment 0, 1, 2 and nothing else -- and end with the right averaged gradients; a parameter
+    nobody used keeps grad None.  (With the round-2 protocol this test pairs a segment all-reduce with the flags all-reduce.)"""
+    with tempfile.TemporaryDirectory() as tmp:
+        init_file, out_file = os.path.join(tmp, 'rdzv'), os.path.join(tmp, 'o.npz')
+        mp.spawn(_diverging_worker, args=(2, init_file, out_file), nprocs=2, join=True)
+        assert np.load(out_file)['hook0'].tolist() == [2, 0]            # rank 0: segments 0, 1 from hooks in iteration 0 (ps[0] unused -> segment 2 in finish); iteration 1: ps[5] unused -> none
 
 
 def _step_worker(rank, world, init_file, out_file):

@@ -201,12 +201,17 @@ __global__ __launch_bounds__(256) void wgrad_reduce(const float* __restrict__ ws
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// The kernel's gather maps are 32-bit BYTE offsets of a 64-channel block, (ci * plane + y * W + x) * 4, with 0x80000000 as the
+// "write zero" sentinel: a plane must keep every valid offset (plus a halo row's slack) below 2^31.
+inline bool offsets_fit(int64_t plane) { return (64 * plane + 4096) * 4 < 0x7fffffffLL; }
+
 }  // namespace
 
 /* Number of K splits pg_conv2d_wgrad wants (its workspace is splits * KH*KW * Cout * Cin floats); 0 = geometry not covered. */
 PG_EXPORT int pg_conv2d_wgrad_plan(int N, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride) {
     if (N <= 0 || Cin <= 0 || OH <= 0 || OW <= 0 || Cout <= 0) return 0;
     if (!((KH == 3 && KW == 3 && (stride == 1 || stride == 2)) || (KH == 1 && KW == 1 && stride == 1))) return 0;
+    if (!offsets_fit((int64_t)OH * OW) || !offsets_fit(((int64_t)OH * stride + KH) * ((int64_t)OW * stride + KW))) return 0;    // x plane bounded through the output extent
     const int64_t chunks = (int64_t)N * cdiv(OH, stride == 1 ? 2 : 1) * cdiv(OW, WG_TW);
     const int blocks = cdiv(Cout, WG_BM) * cdiv(Cin, WG_BN);
     int64_t s = ((int64_t)pg::num_cu() + blocks - 1) / blocks;            // one (persistent-for-its-share) workgroup per CU
@@ -222,6 +227,7 @@ PG_EXPORT int pg_conv2d_wgrad(const float* x, const float* dy, float* dw, float*
     if (!x || !dy || !dw || !workspace || N <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0 || OH <= 0 || OW <= 0 || splits <= 0) return PG_ERR_INVALID_ARG;
     if (!((KH == 3 && KW == 3 && (stride == 1 || stride == 2)) || (KH == 1 && KW == 1 && stride == 1))) return PG_ERR_UNSUPPORTED;
     if (OH != (H + 2 * pad_y - KH) / stride + 1 || OW != (W + 2 * pad_x - KW) / stride + 1 || pad_y < 0 || pad_x < 0) return PG_ERR_INVALID_ARG;
+    if (!offsets_fit((int64_t)H * W) || !offsets_fit((int64_t)OH * OW)) return PG_ERR_TOO_LARGE;
     WgradParams p;
     p.x = x; p.dy = dy; p.ws = workspace;
     p.N = N; p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout; p.OH = OH; p.OW = OW; p.pad_y = pad_y; p.pad_x = pad_x;

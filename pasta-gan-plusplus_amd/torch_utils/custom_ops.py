@@ -7,8 +7,9 @@ file lock so concurrent ranks build once (:95-105) -- but MI355X-native: the sou
 are hand-written HIP compiled by ``hipcc --offload-arch=gfx950`` into an in-tree
 ``csrc/<module_name>.so`` that is bound with ``ctypes`` (no pybind, no torch
 extension, no hipify).  A content digest next to the .so makes the build
-incremental; the prebuilt library travels with the tree, so a machine without
-``hipcc`` (or with an up-to-date .so) just loads it.
+incremental.  The .so files are build products: git-ignored (a fresh checkout builds them on
+first use, or ahead of time with ``build_all()`` / ``tools/ensure_built.py`` -- do that in a plain process, never under
+a profiler) but not gpurun-ignored, so a tree built here carries them to the GPU box, where an up-to-date .so is just loaded.
 
 There is no fallback: if the library can neither be found nor built this raises,
 and the ops built on it raise too.  A library older than its sources is only loaded when

@@ -12,8 +12,8 @@ Gradients: the INPUT gradient of a convolution is again a convolution (with the 
 flipped weight; a strided conv's is a transposed conv and vice versa), so it runs the same MFMA kernel through
 this same autograd Function -- which makes arbitrary-order input gradients (R1, loss_fullbody.py:262-274) native
 too, exactly how the reference's ``_conv2d_gradfix`` recurses (conv2d_gradfix.py:118-135).  The WEIGHT gradient
-(a reduction over pixels, a different GEMM shape) still comes from ``aten::convolution_backward`` and honours
-``no_weight_gradients``.  bf16 / fp16 tensors (the discriminator's fp16 blocks, networks.py:444-523; the half-precision
+(a reduction over pixels, a different GEMM shape: csrc/conv2d_wgrad.hip) is native for the float32 3x3 (stride 1, 2, transposed)
+and 1x1 layers; other geometries and 16-bit layers take ``aten::convolution_backward``; both honour ``no_weight_gradients``.  bf16 / fp16 tensors (the discriminator's fp16 blocks, networks.py:444-523; the half-precision
 synthesis stack) run the 16-bit MFMA kernel (``conv2d_mfma16`` -> ``csrc/conv2d_kernel16.h``) on channels-last storage,
 input gradients included.  Configurations the kernels do not cover (groups > 1, dilation, exotic kernel sizes) go to
 PyTorch-ROCm's convolution on the GPU, as does everything when ``enabled`` is set to False.  CPU tensors take the
@@ -88,10 +88,13 @@ def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1):
     stride, padding, dilation = _pair(stride), _pair(padding), _pair(dilation)
     kh, kw = int(weight.shape[2]), int(weight.shape[3])
     if enabled and input.is_cuda and min(padding) >= 0:
-        if _native_ok(input, weight, stride, dilation, groups) and conv2d_mfma.supported(kh, kw, stride[0]):
-            return _Conv2dMfma.apply(input, weight, bias, stride[0], padding, False, (0, 0))
-        if _native16_ok(input, weight, stride, dilation, groups) and conv2d_mfma16.supported(kh, kw, stride[0]):
-            return _Conv2dMfma16.apply(input, weight, bias, stride[0], padding, False, (0, 0))
+        try:                                           # a VALID request the kernels decline (32-bit indexing limits, LDS budget) takes the aten route
+            if _native_ok(input, weight, stride, dilation, groups) and conv2d_mfma.supported(kh, kw, stride[0]):
+                return _Conv2dMfma.apply(input, weight, bias, stride[0], padding, False, (0, 0))
+            if _native16_ok(input, weight, stride, dilation, groups) and conv2d_mfma16.supported(kh, kw, stride[0]):
+                return _Conv2dMfma16.apply(input, weight, bias, stride[0], padding, False, (0, 0))
+        except nat.NativeNotCovered:
+            pass
     return torch.nn.functional.conv2d(input=input, weight=weight, bias=bias, stride=stride, padding=padding, dilation=dilation, groups=groups)
 
 
@@ -107,33 +110,44 @@ def conv_transpose2d(input, weight, bias=None, stride=1, padding=0, output_paddi
     stride, padding, dilation, output_padding = _pair(stride), _pair(padding), _pair(dilation), _pair(output_padding)
     kh, kw = int(weight.shape[2]), int(weight.shape[3])
     if enabled and input.is_cuda:
-        if _native_ok(input, weight, stride, dilation, groups) and _phases_supported(conv2d_mfma, kh, kw, stride[0]):
-            return _Conv2dMfma.apply(input, weight, bias, stride[0], padding, True, output_padding)
-        if _native16_ok(input, weight, stride, dilation, groups) and _phases_supported(conv2d_mfma16, kh, kw, stride[0]):
-            return _Conv2dMfma16.apply(input, weight, bias, stride[0], padding, True, output_padding)
+        try:
+            if _native_ok(input, weight, stride, dilation, groups) and _phases_supported(conv2d_mfma, kh, kw, stride[0]):
+                return _Conv2dMfma.apply(input, weight, bias, stride[0], padding, True, output_padding)
+            if _native16_ok(input, weight, stride, dilation, groups) and _phases_supported(conv2d_mfma16, kh, kw, stride[0]):
+                return _Conv2dMfma16.apply(input, weight, bias, stride[0], padding, True, output_padding)
+        except nat.NativeNotCovered:
+            pass
     return torch.nn.functional.conv_transpose2d(input=input, weight=weight, bias=bias, stride=stride, padding=padding,
                                                 output_padding=output_padding, groups=groups, dilation=dilation)
 
 
-_pack_cache = {}      # (storage ptr, version, shape, strides, winograd, flip, transpose) -> packed weights; a handful of live entries per step
+_pack_cache = {}      # (storage ptr, version, shape, strides, winograd, flip, transpose) -> (weakref to the source, packed weights)
+_PACK_CACHE_MAX_BYTES = 1 << 30
 
 
 def _packed(weight, winograd, flip=False, transpose_oi=False):
-    """Packed form of `weight` for the MFMA kernels, cached per parameter version: within one training step the same
-    weights are packed once for the forward and once (flipped, O<->I transposed) for the input gradient, however many
-    accumulation rounds or double-backward passes use them."""
+    """Packed form of `weight` for the MFMA kernels, cached for as long as the SOURCE TENSOR OBJECT lives and keeps its version:
+    a parameter passed directly hits across steps until the optimizer writes it; the equalised-LR temporaries of the training
+    route (``self.weight * self.weight_gain``) hit for the forward, the input gradient and every accumulation round /
+    double-backward pass of the graph that holds them, and their entries are dropped the moment autograd releases the
+    temporary (weakref callback) -- nothing packed outlives its source.  A byte cap bounds the live set."""
     base = weight._base if weight._base is not None else weight
     key = (weight.data_ptr(), base._version, tuple(weight.shape), tuple(weight.stride()), bool(winograd), bool(flip), bool(transpose_oi))
     entry = _pack_cache.get(key)
     hit = entry[1] if entry is not None and entry[0]() is base else None      # same address + version is not identity: a freed
     if hit is None:                                                           # tensor's block is handed to the next one of its size
-        if len(_pack_cache) > 512:
-            _pack_cache.clear()
         w = weight.detach()
         if not w.is_contiguous():
             w = w.contiguous()
         hit = conv2d_mfma.pack_weight(w, flip=flip, transpose_oi=transpose_oi, winograd=winograd)
-        _pack_cache[key] = (weakref.ref(base), hit)
+        if sum(e[1].numel() * e[1].element_size() for e in _pack_cache.values()) + hit.numel() * hit.element_size() > _PACK_CACHE_MAX_BYTES:
+            _pack_cache.clear()
+
+        def _evict(ref, key=key):
+            e = _pack_cache.get(key)
+            if e is not None and e[0] is ref:
+                del _pack_cache[key]
+        _pack_cache[key] = (weakref.ref(base, _evict), hit)
     return hit
 
 

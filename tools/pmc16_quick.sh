@@ -1,5 +1,6 @@
 # usage (GPU box): bash tools/pmc16_quick.sh "<dbg values>" N CIN COUT H [K]
 cd /tmp && export TMPDIR=/tmp
+python3 $GRAFT_REPO_ROOT/tools/ensure_built.py || exit 1     # plugins are built in a plain process, never under the profiler
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/pmc16
 mkdir -p $O
 DBGS="$1"; shift

@@ -1,5 +1,6 @@
 # usage (GPU box): bash tools/pmc16_run.sh N CIN COUT H [K]   -> gpurun_out/pmc16/summary_<shape>.txt
 cd /tmp && export TMPDIR=/tmp
+python3 $GRAFT_REPO_ROOT/tools/ensure_built.py || exit 1     # plugins are built in a plain process, never under the profiler
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/pmc16
 mkdir -p $O
 TAG="n$1_c$2_o$3_h$4_k${5:-3}"

@@ -1,5 +1,6 @@
 # usage (GPU box): bash tools/pmc_fir.sh    -> gpurun_out/pmc_fir/summary.txt: PMC counters of the blur kernels on [8,64,513(516),513] -> 512^2
 cd /tmp && export TMPDIR=/tmp
+python3 $GRAFT_REPO_ROOT/tools/ensure_built.py || exit 1     # plugins are built in a plain process, never under the profiler
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/pmc_fir
 mkdir -p $O
 : > $O/summary.txt

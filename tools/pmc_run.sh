@@ -1,4 +1,5 @@
 cd /tmp && export TMPDIR=/tmp
+python3 $GRAFT_REPO_ROOT/tools/ensure_built.py || exit 1     # plugins are built in a plain process, never under the profiler
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/pmc
 mkdir -p $O
 rocprofv3 --list-avail 2>/dev/null | grep -o "SQ_[A-Z_0-9]*\|TCP_[A-Z_0-9]*\|TA_[A-Z_0-9]*" | sort -u > $O/avail.txt

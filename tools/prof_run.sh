@@ -1,6 +1,7 @@
 # usage (on the GPU box): bash tools/prof_run.sh <tag> <bench.py args...>
 #   -> gpurun_out/prof_<tag>/kernel_stats.csv (whole process) and kernel_stats_timed.csv (timed region only, tools/window_stats.py)
 cd /tmp && export TMPDIR=/tmp
+python3 $GRAFT_REPO_ROOT/tools/ensure_built.py || exit 1     # plugins are built in a plain process, never under the profiler
 R=$GRAFT_REPO_ROOT; TAG=${1:-cfg2}; shift
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O; rm -rf /tmp/prof_out

@@ -2,6 +2,8 @@
 #   bash tools/profile_round.sh
 R=$GRAFT_REPO_ROOT
 cd $R
+# build the plugins in a plain, unprofiled process first: under rocprofv3 the loader's hipcc children would inherit the profiler's preload
+python3 tools/ensure_built.py > gpurun_out/build.log 2>&1
 bash tools/prof_run.sh cfg2 --conv-breakdown $R/gpurun_out/prof_cfg2/by_shape.csv > gpurun_out/prof_cfg2.log 2>&1
 bash tools/prof_run.sh cfg5 --mode bf16_1024 --conv-breakdown $R/gpurun_out/prof_cfg5/by_shape.csv > gpurun_out/prof_cfg5.log 2>&1
 bash tools/prof_run.sh train --mode train --steps 3 --warmup 1 > gpurun_out/prof_train.log 2>&1

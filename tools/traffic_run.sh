@@ -2,6 +2,7 @@
 # (1 timed step), as MI355X_MICROARCH.md prescribes.  usage: bash tools/traffic_run.sh <tag> <kernel substring> <bench.py args...>
 #   -> gpurun_out/traffic_<tag>/{FETCH_SIZE,WRITE_SIZE}.csv (that kernel's launches of the timed step only)
 cd /tmp && export TMPDIR=/tmp
+python3 $GRAFT_REPO_ROOT/tools/ensure_built.py || exit 1     # plugins are built in a plain process, never under the profiler
 R=$GRAFT_REPO_ROOT; TAG=${1:-cfg2}; KSUB=${2:-conv2d_wino}; shift; shift
 O=$R/gpurun_out/traffic_$TAG
 mkdir -p $O

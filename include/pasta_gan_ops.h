@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 4
+#define PG_ABI_VERSION 5
 
 enum pg_dtype { PG_F32 = 0, PG_F16 = 1, PG_BF16 = 2, PG_F64 = 3 };
 
@@ -197,6 +197,20 @@ int pg_conv2d_winograd_pack_weight(const float* w, float* packed, int Cout, int 
 int pg_conv2d_winograd_forward(const float* x, const float* packed_u, float* y,
                                int N, int Cin, int H, int W, int Cout, int pad_y, int pad_x, int OH, int OW,
                                const int64_t ystride[4], const pg_conv2d_fusion* fusion, void* stream);
+
+/*
+ * Winograd F(4x4, 3x3) variant (round 3; csrc/conv2d_wino4.h): 2.25 multiplies per output instead of 4 -- the same call
+ * contract as the F(2x2) entry points above, its own weight layout (36 * CinP * CoutP64 floats, transformed in float64 and
+ * rounded once).  Declines (PG_ERR_UNSUPPORTED; callers use pg_conv2d_winograd_forward) unless W % 4 == 0, x is 16-byte
+ * aligned, pad_x in [0, 4], no x2 and no input pre-activation stage (in_scale is supported).  float32 error ~4x that of the
+ * F(2x2) kernel: max-abs 3.7e-5 on the config-2 image against the direct float32 network (tools/f43_error_probe.py).
+ */
+int64_t pg_conv2d_winograd4_packed_size(int Cout, int Cin);
+int pg_conv2d_winograd4_pack_weight(const float* w, float* packed, int Cout, int Cin,
+                                    float scale, int flip_hw, int transpose_oi, void* stream);
+int pg_conv2d_winograd4_forward(const float* x, const float* packed_u, float* y,
+                                int N, int Cin, int H, int W, int Cout, int pad_y, int pad_x, int OH, int OW,
+                                const int64_t ystride[4], const pg_conv2d_fusion* fusion, void* stream);
 
 /* Demodulation coefficients of modulated_conv2d (networks.py:64-68):
  *   dcoefs[n,o] = rsqrt(sum_{i,k} (w[o,i,k] * scale * styles[n,i])^2 + 1e-8);  w is OIHW. */

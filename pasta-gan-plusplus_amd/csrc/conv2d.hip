@@ -72,6 +72,53 @@ __global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict_
     }
 }
 
+
+// Winograd F(4x4, 3x3) weight transform: U = G g G^T (6x6) per (ci, co) in float64, rounded once, stored in the order the waves of
+// conv2d_wino4.h walk it: [m-block 64][mt][q][chunk 16 ch][group = (xi third jg, pair quad)][xi jj][lane = (h, co & 31)][pair s], with
+//   xi = 6a + b = 9q + 3jg + jj,   channel = 16 chunk + 2 (4 quad + s) + h.
+//   G = [[1/4, 0, 0], [-1/6, -1/6, -1/6], [-1/6, 1/6, -1/6], [1/24, 1/12, 1/6], [1/24, -1/12, 1/6], [0, 0, 1]]
+__global__ __launch_bounds__(256) void wino4_pack_kernel(const float* __restrict__ w, float* __restrict__ up, int Cout, int Cin,
+                                                         int CinP, int CoutP, float scale, int flip, int transpose_oi) {
+    const double G[6][3] = {{0.25, 0.0, 0.0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                            {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0.0, 0.0, 1.0}};
+    const int nchunks = CinP / 16;
+    const int64_t total = (int64_t)CinP * CoutP;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int co = (int)(i % CoutP), ci = (int)(i / CoutP);
+        double g[3][3];
+#pragma unroll
+        for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+            for (int kx = 0; kx < 3; kx++) {
+                double v = 0.0;
+                if (co < Cout && ci < Cin) {
+                    const int sy = flip ? 2 - ky : ky, sx = flip ? 2 - kx : kx;
+                    const int64_t src = transpose_oi ? (((int64_t)ci * Cout + co) * 3 + sy) * 3 + sx
+                                                     : (((int64_t)co * Cin + ci) * 3 + sy) * 3 + sx;
+                    v = (double)(w[src] * scale);
+                }
+                g[ky][kx] = v;
+            }
+        double tg[6][3];                                 // G g
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+#pragma unroll
+            for (int kx = 0; kx < 3; kx++) tg[a][kx] = G[a][0] * g[0][kx] + G[a][1] * g[1][kx] + G[a][2] * g[2][kx];
+        const int mb = co >> 6, mt = (co >> 5) & 1, m = co & 31;
+        const int k = ci >> 4, cc = ci & 15, pair = cc >> 1, h = cc & 1, quad = pair >> 2, sp = pair & 3;
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+#pragma unroll
+            for (int b = 0; b < 6; b++) {
+                const double u = tg[a][0] * G[b][0] + tg[a][1] * G[b][1] + tg[a][2] * G[b][2];      // (G g) G^T
+                const int xi = 6 * a + b, q = xi / 9, j = xi % 9, jg = j / 3, jj = j % 3;
+                const int64_t unit = ((int64_t)(mb * 2 + mt) * 4 + q) * nchunks + k;
+                const int64_t dst = ((((unit * 3 + jg) * 2 + quad) * 3 + jj) * 64 + (h * 32 + m)) * 4 + sp;
+                up[dst] = (float)u;
+            }
+    }
+}
+
 // ------------------------------------------------------------------ demodulation coefficients
 // one workgroup per (n, o): rsqrt(sum_{i,k} (w[o,i,k] * scale * s[n,i])^2 + 1e-8)
 __global__ __launch_bounds__(256) void dcoefs_kernel(const float* __restrict__ w, const float* __restrict__ styles, float* __restrict__ d,
@@ -395,7 +442,7 @@ PG_EXPORT int pg_conv2d_pack_weight(const float* w, float* packed, int Cout, int
     return pg::launch_status();
 }
 
-static int conv_forward(bool winograd, const float* x, const float* packed_w, float* y,
+static int conv_forward(int winograd, const float* x, const float* packed_w, float* y,
                         int N, int Cin, int H, int W, int Cout, int KH, int KW,
                         int stride, int pad_y, int pad_x, int OH, int OW,
                         const int64_t ystride[4], int out_step_y, int out_step_x, int out_off_y, int out_off_x,
@@ -445,7 +492,7 @@ static int conv_forward(bool winograd, const float* x, const float* packed_w, fl
         if (p.f.x2) return PG_ERR_UNSUPPORTED;                  // two-source launches stay on the direct kernel
         if (pad_x < 0 || pad_x > 4) return PG_ERR_UNSUPPORTED;  // the LDS halo row starts 4 columns left of the tile
         p.CoutP = round_up(Cout, 64);
-        return pgconv::launch_wino(p, s);
+        return winograd == 2 ? pgconv::launch_wino4(p, s) : pgconv::launch_wino(p, s);
     }
     pg_conv2d_fusion tail = p.f;
     const int64_t slice = (int64_t)N * Cout * OH * OW;
@@ -487,7 +534,7 @@ PG_EXPORT int pg_conv2d_forward(const float* x, const float* packed_w, float* y,
                                 int stride, int pad_y, int pad_x, int OH, int OW,
                                 const int64_t ystride[4], int out_step_y, int out_step_x, int out_off_y, int out_off_x,
                                 const pg_conv2d_fusion* fusion, void* stream) {
-    return conv_forward(false, x, packed_w, y, N, Cin, H, W, Cout, KH, KW, stride, pad_y, pad_x, OH, OW,
+    return conv_forward(0, x, packed_w, y, N, Cin, H, W, Cout, KH, KW, stride, pad_y, pad_x, OH, OW,
                         ystride, out_step_y, out_step_x, out_off_y, out_off_x, fusion, stream);
 }
 
@@ -511,7 +558,7 @@ PG_EXPORT int pg_conv2d_forward_splitk(const float* x, const float* packed_w, fl
                                        const int64_t ystride[4], int out_step_y, int out_step_x, int out_off_y, int out_off_x,
                                        const pg_conv2d_fusion* fusion, float* workspace, int ksplit, void* stream) {
     if (ksplit < 1 || (ksplit > 1 && !workspace)) return PG_ERR_INVALID_ARG;
-    return conv_forward(false, x, packed_w, y, N, Cin, H, W, Cout, KH, KW, stride, pad_y, pad_x, OH, OW,
+    return conv_forward(0, x, packed_w, y, N, Cin, H, W, Cout, KH, KW, stride, pad_y, pad_x, OH, OW,
                         ystride, out_step_y, out_step_x, out_off_y, out_off_x, fusion, stream, workspace, ksplit);
 }
 
@@ -534,7 +581,29 @@ PG_EXPORT int pg_conv2d_winograd_pack_weight(const float* w, float* packed, int 
 PG_EXPORT int pg_conv2d_winograd_forward(const float* x, const float* packed_u, float* y,
                                          int N, int Cin, int H, int W, int Cout, int pad_y, int pad_x, int OH, int OW,
                                          const int64_t ystride[4], const pg_conv2d_fusion* fusion, void* stream) {
-    return conv_forward(true, x, packed_u, y, N, Cin, H, W, Cout, 3, 3, 1, pad_y, pad_x, OH, OW, ystride, 1, 1, 0, 0, fusion, stream);
+    return conv_forward(1, x, packed_u, y, N, Cin, H, W, Cout, 3, 3, 1, pad_y, pad_x, OH, OW, ystride, 1, 1, 0, 0, fusion, stream);
+}
+
+PG_EXPORT int64_t pg_conv2d_winograd4_packed_size(int Cout, int Cin) {
+    if (Cout <= 0 || Cin <= 0) return 0;
+    return (int64_t)36 * round_up(Cin, 16) * round_up(Cout, 64);
+}
+
+PG_EXPORT int pg_conv2d_winograd4_pack_weight(const float* w, float* packed, int Cout, int Cin,
+                                              float scale, int flip_hw, int transpose_oi, void* stream) {
+    if (!w || !packed || Cout <= 0 || Cin <= 0) return PG_ERR_INVALID_ARG;
+    const int CinP = round_up(Cin, 16), CoutP = round_up(Cout, 64);
+    const int64_t total = (int64_t)CinP * CoutP;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > pg::max_stream_blocks()) blocks = pg::max_stream_blocks();
+    hipLaunchKernelGGL(wino4_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, packed, Cout, Cin, CinP, CoutP, scale, flip_hw, transpose_oi);
+    return pg::launch_status();
+}
+
+PG_EXPORT int pg_conv2d_winograd4_forward(const float* x, const float* packed_u, float* y,
+                                          int N, int Cin, int H, int W, int Cout, int pad_y, int pad_x, int OH, int OW,
+                                          const int64_t ystride[4], const pg_conv2d_fusion* fusion, void* stream) {
+    return conv_forward(2, x, packed_u, y, N, Cin, H, W, Cout, 3, 3, 1, pad_y, pad_x, OH, OW, ystride, 1, 1, 0, 0, fusion, stream);
 }
 
 // Streaming 1x1 head for fp32 NCHW tensors (the ToRGB / parsing heads: Cout <= 8, networks.py:287-316): a thread owns 4 adjacent

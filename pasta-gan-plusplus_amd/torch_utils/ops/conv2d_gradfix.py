@@ -159,7 +159,7 @@ class _Conv2dMfma(torch.autograd.Function):
         kh, kw = int(weight.shape[2]), int(weight.shape[3])
         if not transposed:
             cout = int(weight.shape[0])
-            wg = conv2d_mfma.use_winograd(kh, kw, stride, cout, cin, pad=padding)
+            wg = conv2d_mfma.use_winograd(kh, kw, stride, cout, cin, pad=padding, hw=(h, w))
             y = conv2d_mfma.conv2d_forward(x, _packed(weight, wg), cout, kh, kw, stride=stride, pad=padding, bias=bias, winograd=wg)
         else:
             cout = int(weight.shape[1])
@@ -263,7 +263,7 @@ def _input_gradient(dy, x_shape, weight, stride, padding, transposed, output_pad
                 # plain first-order backward: the flipped / transposed pack comes straight from the parameter (cached per version),
                 # no transposed copy of the weight tensor is made
                 cin_f = int(weight.shape[1])
-                wg = globals()['conv2d_mfma'].use_winograd(kh, kw, 1, cin_f, int(weight.shape[0]), pad=(py, px))
+                wg = globals()['conv2d_mfma'].use_winograd(kh, kw, 1, cin_f, int(weight.shape[0]), pad=(py, px), hw=dy.shape[2:])
                 pk = _packed(weight, wg, flip=True, transpose_oi=True)
                 return globals()['conv2d_mfma'].conv2d_forward(dy.contiguous(), pk, cin_f, kh, kw, stride=1, pad=(py, px), winograd=wg)
             return _Conv2dMfma.apply(dy, weight.transpose(0, 1).flip([2, 3]), None, 1, (py, px), False, (0, 0))

@@ -77,6 +77,12 @@ def _init(plugin_name='conv2d_plugin'):
         lib.pg_conv2d_winograd_pack_weight.argtypes = [vp, vp, i, i, f, i, i, vp]
         lib.pg_conv2d_winograd_forward.restype = i
         lib.pg_conv2d_winograd_forward.argtypes = [vp, vp, vp, i, i, i, i, i, i, i, i, i, ctypes.POINTER(i64), ctypes.POINTER(Fusion), vp]
+        lib.pg_conv2d_winograd4_packed_size.restype = i64
+        lib.pg_conv2d_winograd4_packed_size.argtypes = [i, i]
+        lib.pg_conv2d_winograd4_pack_weight.restype = i
+        lib.pg_conv2d_winograd4_pack_weight.argtypes = [vp, vp, i, i, f, i, i, vp]
+        lib.pg_conv2d_winograd4_forward.restype = i
+        lib.pg_conv2d_winograd4_forward.argtypes = [vp, vp, vp, i, i, i, i, i, i, i, i, i, ctypes.POINTER(i64), ctypes.POINTER(Fusion), vp]
         lib.pg_spade_masked_sums.restype = i
         lib.pg_spade_masked_sums.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, vp]
         lib.pg_spade_feat_assemble.restype = i
@@ -105,17 +111,30 @@ def _init(plugin_name='conv2d_plugin'):
     return _plugin
 
 
-def use_winograd(kh, kw, stride, cout, cin=None, x2=None, pad=None):
-    """Launch policy for 3x3 stride-1 convolutions: the Winograd F(2x2,3x3) kernel (csrc/conv2d_wino.h) unless the layer is
-    too narrow to fill its 64-cout x 16-channel tiles.  PG_CONV_ALGO=direct|winograd overrides (A/B measurements)."""
+def use_winograd(kh, kw, stride, cout, cin=None, x2=None, pad=None, hw=None, xf=False):
+    """Launch policy for 3x3 stride-1 convolutions.  Returns 0 (direct implicit GEMM), 1 (Winograd F(2x2,3x3), csrc/conv2d_wino.h) or
+    2 (Winograd F(4x4,3x3), csrc/conv2d_wino4.h) -- truthy = some Winograd kernel, and the value is what `pack_weight(winograd=...)` /
+    `conv2d_forward(winograd=...)` take.  F(4x4) needs the image size (`hw`): its 8 x 64-pixel tiles and 16-channel chunks pay on layers
+    with Cin >= 64, Cout a multiple of 64 and images of at least 32 x 64 whose width is a multiple of 4; `xf` (an input pre-activation
+    stage) stays on F(2x2).  PG_CONV_ALGO=direct|winograd|winograd2|winograd4 overrides (A/B measurements): 'winograd2' = never F(4x4),
+    'winograd4' = F(4x4) wherever the kernel accepts the launch."""
     if (int(kh), int(kw), int(stride)) != (3, 3, 1) or x2 is not None:
-        return False
-    if pad is not None and not 0 <= int(pad[1]) <= 4:         # the kernel's LDS halo row starts 4 columns left of the tile
-        return False
+        return 0
+    if pad is not None and not 0 <= int(pad[1]) <= 4:         # the kernels' LDS halo row starts 4 columns left of the tile
+        return 0
     mode = os.environ.get('PG_CONV_ALGO', 'auto')
     if mode == 'direct':
-        return False
-    return True if mode == 'winograd' else (int(cout) > 32 and (cin is None or int(cin) >= 16))
+        return 0
+    f4_possible = hw is not None and not xf and int(hw[1]) % 4 == 0
+    if mode == 'winograd4' and f4_possible:
+        return 2
+    if mode in ('winograd', 'winograd2', 'winograd4'):
+        return 1
+    if not (int(cout) > 32 and (cin is None or int(cin) >= 16)):
+        return 0
+    if f4_possible and cin is not None and int(cin) >= 64 and int(cin) % 16 == 0 and int(cout) % 64 == 0 and int(hw[0]) >= 32 and int(hw[1]) >= 64:
+        return 2
+    return 1
 
 
 def supported(kh, kw, stride):
@@ -132,7 +151,8 @@ def _f32c(t, name):
 
 def pack_weight(w, scale=1.0, flip=False, transpose_oi=False, winograd=False):
     """OIHW (or IOHW when `transpose_oi`) float32 weights -> the kernel's [CinP][taps][CoutP] layout, or, with
-    `winograd`, the pre-transformed [16][CinP][CoutP64] layout of the F(2x2,3x3) kernel (3x3 weights only)."""
+    `winograd` = 1 / True, the pre-transformed [16][CinP][CoutP64] layout of the F(2x2,3x3) kernel, with `winograd` = 2 the
+    36 * CinP * CoutP64 operand stream of the F(4x4,3x3) kernel (3x3 weights only)."""
     lib = _init().lib
     w = _f32c(w.detach(), 'weight')
     if transpose_oi:
@@ -142,9 +162,11 @@ def pack_weight(w, scale=1.0, flip=False, transpose_oi=False, winograd=False):
     if winograd:
         if (kh, kw) != (3, 3):
             raise nat.NativeOpError('conv2d_mfma: the Winograd layout is for 3x3 weights')
-        packed = torch.empty([lib.pg_conv2d_winograd_packed_size(cout, cin)], dtype=torch.float32, device=w.device)
+        size, pack = ((lib.pg_conv2d_winograd4_packed_size, lib.pg_conv2d_winograd4_pack_weight) if int(winograd) == 2 else
+                      (lib.pg_conv2d_winograd_packed_size, lib.pg_conv2d_winograd_pack_weight))
+        packed = torch.empty([size(cout, cin)], dtype=torch.float32, device=w.device)
         with torch.cuda.device(w.device):
-            st = lib.pg_conv2d_winograd_pack_weight(nat.ptr(w), nat.ptr(packed), cout, cin, float(scale), int(bool(flip)), int(bool(transpose_oi)), nat.stream_of(w))
+            st = pack(nat.ptr(w), nat.ptr(packed), cout, cin, float(scale), int(bool(flip)), int(bool(transpose_oi)), nat.stream_of(w))
         nat.check(st, 'pg_conv2d_winograd_pack_weight')
         return packed
     packed = torch.empty([lib.pg_conv2d_packed_size(cout, cin, kh, kw)], dtype=torch.float32, device=w.device)
@@ -236,8 +258,9 @@ def conv2d_forward(x, packed, cout, kh, kw, stride=1, pad=(0, 0), out_hw=None, y
         if winograd:
             if (kh, kw, int(stride)) != (3, 3, 1) or tuple(out_step) != (1, 1) or tuple(out_off) != (0, 0):
                 raise nat.NativeOpError('conv2d_mfma: winograd=True needs a 3x3 stride-1 dense-output launch')
-            st = lib.pg_conv2d_winograd_forward(nat.ptr(x), nat.ptr(packed), nat.ptr(y), n, cin, h, w, cout, int(pad_y), int(pad_x),
-                                                int(oh), int(ow), nat.i64arr(y.stride()), ctypes.byref(fz), nat.stream_of(x))
+            fwd = lib.pg_conv2d_winograd4_forward if int(winograd) == 2 else lib.pg_conv2d_winograd_forward
+            st = fwd(nat.ptr(x), nat.ptr(packed), nat.ptr(y), n, cin, h, w, cout, int(pad_y), int(pad_x),
+                     int(oh), int(ow), nat.i64arr(y.stride()), ctypes.byref(fz), nat.stream_of(x))
         else:
             ksplit = 1
             if spade is None and x2 is None and os.environ.get('PG_CONV_SPLITK', '1') != '0':
@@ -253,7 +276,7 @@ def conv2d_forward(x, packed, cout, kh, kw, stride=1, pad=(0, 0), out_hw=None, y
                                            ctypes.byref(fz), nat.stream_of(x))
         if _timeline is not None:
             ev1.record()
-            _timeline.append(((kh, kw, int(stride), 'winograd' if winograd else 'direct', f'N{n} {cin}->{cout} {h}x{w}' + (' spade' if spade is not None else '') + (' xf' if in_act != 'linear' else '') + (' mod' if in_scale is not None else '') + (' res' if residual is not None else '')), 2.0 * n * cout * oh * ow * cin * kh * kw, ev0, ev1,
+            _timeline.append(((kh, kw, int(stride), ('winograd4' if int(winograd) == 2 else 'winograd') if winograd else 'direct', f'N{n} {cin}->{cout} {h}x{w}' + (' spade' if spade is not None else '') + (' xf' if in_act != 'linear' else '') + (' mod' if in_scale is not None else '') + (' res' if residual is not None else '')), 2.0 * n * cout * oh * ow * cin * kh * kw, ev0, ev1,
                               4 * (x.numel() + (x2.numel() if x2 is not None else 0) + n * ychan * oh * ow)))
     nat.check(st, 'pg_conv2d_forward')
     return y

@@ -134,7 +134,7 @@ def _modconv_fast(x, weight, styles, noise, up, padding, resample_filter, demodu
     if up == 1:
         if not conv2d_mfma.supported(kh, kw, 1):
             return None
-        wg = conv2d_mfma.use_winograd(kh, kw, 1, cout, cin)
+        wg = conv2d_mfma.use_winograd(kh, kw, 1, cout, cin, pad=(padding, padding), hw=x.shape[2:])
         packed = cache.get(('plain', flip_weight, wg), [weight], lambda: conv2d_mfma.pack_weight(weight, flip=not flip_weight, winograd=wg))
         return conv2d_mfma.conv2d_forward(x, packed, cout, kh, kw, stride=1, pad=(padding, padding), in_scale=styles,
                                           out_scale=dcoefs, noise=noise, winograd=wg, **ep)
@@ -419,7 +419,7 @@ class Conv2dLayer(_ConvBase):
         if self.down == 1:
             if x2 is not None and x.shape[1] % 16 != 0:
                 x, x2 = torch.cat([x, x2], dim=1), None
-            wg = conv2d_mfma.use_winograd(k, k, 1, cout, x.shape[1], x2)
+            wg = conv2d_mfma.use_winograd(k, k, 1, cout, x.shape[1], x2, pad=(self.padding, self.padding), hw=x.shape[2:])
             return conv2d_mfma.conv2d_forward(x, self._packed(False, wg), cout, k, k, pad=(self.padding, self.padding), x2=x2, winograd=wg, **ep)
         if x2 is not None:
             x = torch.cat([x, x2], dim=1)
@@ -470,7 +470,7 @@ class Spade_Conv2dLayer(_ConvBase):
         if _fast_ok(x, self.weight, self.bias, residual) and self._fast_geometry() and self.down == 1 and (no_act or self.bias is None):
             pro = {} if no_act else dict(in_act=self.activation, in_gain=act_gain, in_clamp=act_clamp,
                                          in_alpha=bias_act.activation_funcs[self.activation].def_alpha)
-            wg = conv2d_mfma.use_winograd(k, k, 1, cout, x.shape[1])
+            wg = conv2d_mfma.use_winograd(k, k, 1, cout, x.shape[1], pad=(self.padding, self.padding), hw=x.shape[2:], xf=not no_act)
             try:
                 return conv2d_mfma.conv2d_forward(x, self._packed(False, wg), cout, k, k, pad=(self.padding, self.padding), act=post_act, residual=residual,
                                                   winograd=wg, **pro)
@@ -513,7 +513,7 @@ class Spade_Norm_Block(nn.Module):
             c = int(g.weight.shape[0])
             if c % 32 == 0 and g._fast_geometry() and g.down == 1 and x.is_contiguous():
                 # gamma and beta convolutions as ONE launch (they share `actv`) whose epilogue applies the normalisation
-                wg = conv2d_mfma.use_winograd(3, 3, 1, 2 * c, actv.shape[1])
+                wg = conv2d_mfma.use_winograd(3, 3, 1, 2 * c, actv.shape[1], pad=(g.padding, g.padding), hw=actv.shape[2:])
                 packed = self._cache.get(('gamma_beta', wg), [g.weight, b.weight],
                                          lambda: conv2d_mfma.pack_spade_gamma_beta(g.weight, b.weight, g.weight_gain, b.weight_gain, winograd=wg))
                 return conv2d_mfma.conv2d_forward(actv, packed, 2 * c, 3, 3, pad=(g.padding, g.padding), spade=(x, mean, rstd), winograd=wg, **post)

@@ -48,7 +48,7 @@ class StubSynthesis(nn.Module):
         self.rgb, self.rgb2, self.parse = nn.Conv2d(8, 3, 1), nn.Conv2d(8, 3, 1), nn.Conv2d(8, 7, 1)
 
     def forward(self, ws, pose_feat, cat_feats, du, dl, mu, ml, gt_parsing, **_):
-        x = torch.cat([pose_feat, cat_feats[str(RES)], du, dl, mu, ml], dim=1)
+        x = torch.cat([pose_feat, cat_feats[str(du.shape[-1])], du, dl, mu, ml], dim=1)
         h = torch.tanh(self.mix(x)) * (1 + self.style(ws[:, 0])[:, :, None, None])
         return torch.tanh(self.rgb(h)), torch.tanh(self.rgb2(h)), self.parse(h)
 
@@ -75,7 +75,8 @@ def build(device='cpu'):
     return nets
 
 
-def batch(n=4, device='cpu'):
+def batch(n=4, device='cpu', res=None):
+    RES = res or globals()['RES']                      # the goldens (g9) use the default 16; the full-width config-4 test passes 512
     b = dict(real_img=det_tensor('stub.real', [n, 3, RES, RES], 'uniform'), gen_z=torch.zeros([n, 0]),
              style_input=det_tensor('stub.style', [n, 4, RES, RES], 'uniform'), retain=det_tensor('stub.retain', [n, 2, RES, RES], 'uniform'),
              pose=det_tensor('stub.pose', [n, 5, RES, RES], 'uniform'), denorm_upper_input=det_tensor('stub.du', [n, 3, RES, RES], 'uniform'),

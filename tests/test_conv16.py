@@ -361,6 +361,36 @@ def test_synthesis_stack_half_vs_oracle(dtype):
     assert float((got32 - want).abs().max()) <= 1e-4 * float(want.abs().max())
 
 
+def test_config5_stack_full_width_prefix_vs_oracle():
+    """The network bench.py --mode bf16_1024 times (channel_base 32768, channel_max 1024, bf16 everywhere, N = 4) on its 8^2..256^2
+    prefix -- the same blocks with the same channel widths (1024, 1024, 1024, 512, 256, 128) as the 1024^2 stack -- against the
+    float32 CPU oracle stack (the benched widths were only covered at 128^2 / <= 256 channels).  Same bar as the
+    reduced-size test: bf16 rounds every activation to 2^-8 relative, ~12 layers deep -> 3e-2 of the output range; the fp32 route
+    of the same network must be tight."""
+    from detgen import fill_module_
+    from training import networks as PN
+    from oracle import network_ref as NR
+    kw = dict(w_dim=512, img_resolution=256, img_channels=3, channel_base=32768, channel_max=1024, conv_clamp=256)
+    ref = fill_module_(NR.SynthesisStack(**kw), 'cfg5.').eval()
+    net = PN.SynthesisStack(num_fp16_res=8, half_dtype=torch.bfloat16, **kw)
+    missing, unexpected = net.load_state_dict(ref.state_dict(), strict=False)
+    assert not unexpected and all('resample_filter' in k for k in missing), (missing, unexpected)
+    net = net.to(DEV).eval()
+    assert [net.block_resolutions[0], net.block_resolutions[-1]] == [8, 256] if hasattr(net, 'block_resolutions') else True
+    n = 4
+    ws = torch.randn([n, net.num_ws, 512], generator=torch.Generator().manual_seed(0))
+    with torch.no_grad():
+        got = net(ws.to(DEV), noise_mode='const').cpu()
+        got32 = net(ws.to(DEV), noise_mode='const', force_fp32=True).cpu()
+        want = ref(ws, noise_mode='const')
+    assert got.shape == want.shape == (n, 3, 256, 256)
+    rng = float(want.abs().max())
+    err16, err32 = float((got - want).abs().max()) / rng, float((got32 - want).abs().max()) / rng
+    print(f'config 5 prefix (8^2..256^2, channel_max 1024, N=4): bf16 {err16:.2e}, fp32 route {err32:.2e} of the output range {rng:.1f}')
+    assert err16 <= 3e-2, err16
+    assert err32 <= 1e-4, err32
+
+
 def test_upfirdn2d_channels_last_kernel():
     """The channels-last FIR (blur / 2x decimation / 2x zero-insertion up-sampling, with and without the fused tail) against the NCHW kernel's result."""
     from torch_utils.ops import upfirdn2d

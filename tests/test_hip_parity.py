@@ -368,6 +368,61 @@ def test_conv2d_winograd_rejects_what_it_cannot_do():
     close(y5, F.conv2d(x.double().cpu(), w3.double().cpu(), padding=5), 1e-4, 1e-5)
 
 
+@pytest.mark.parametrize('n,cin,cout,h,w,pad', [(1, 16, 64, 8, 64, 1), (2, 64, 64, 16, 128, 1), (2, 32, 128, 24, 64, 1), (1, 48, 70, 9, 72, 1), (2, 20, 40, 13, 100, 0),
+                                                (1, 128, 128, 40, 192, 1), (3, 64, 64, 64, 64, 2), (2, 16, 64, 7, 8, 1), (1, 80, 64, 32, 64, 4)])
+def test_conv2d_winograd4_kernel(n, cin, cout, h, w, pad):
+    """csrc/conv2d_wino4.h (Winograd F(4x4,3x3), round 3) on full, edge and ragged tiles (heights that are no multiple of 8, widths
+    no multiple of 64, couts no multiple of 64, channel counts no multiple of 16, paddings 0..4): plain against the fp64 convolution;
+    every fused stage, per-sample noise and SPADE mode against the direct MFMA kernel running the same launch.  Tolerance: F(4x4)'s
+    transforms cost ~4x the rounding of the direct kernel (tools/f43_error_probe.py): 1e-4 of the output scale."""
+    from torch_utils.ops import conv2d_mfma
+    import torch.nn.functional as F
+    x = det_tensor(f'w4.x.{cin}.{h}.{w}', [n, cin, h, w]).to(DEV)
+    wt = det_tensor(f'w4.w.{cin}.{cout}', [cout, cin, 3, 3], scale=1 / (3 * math.sqrt(cin))).to(DEV)
+
+    def run(algo, **kw):
+        return conv2d_mfma.conv2d_forward(x, conv2d_mfma.pack_weight(wt, winograd=algo), cout, 3, 3, pad=(pad, pad), winograd=algo, **kw)
+    ref = F.conv2d(x.double().cpu(), wt.double().cpu(), padding=pad)
+    close(run(2), ref, 0, 1e-4 * scale_of(ref))
+    oh, ow = ref.shape[2:]
+    kw = dict(in_scale=det_tensor('w4.s', [n, cin]).to(DEV) + 1.5, out_scale=det_tensor('w4.d', [n, cout]).abs().to(DEV) + 0.5, noise=det_tensor('w4.nz', [oh, ow]).to(DEV),
+              noise_gain=0.3, bias=det_tensor('w4.b', [cout]).to(DEV), act='lrelu', alpha=0.2, gain=1.4, clamp=2.0, residual=det_tensor('w4.r', [n, cout, oh, ow]).to(DEV))
+    a, b = run(0, **kw), run(2, **kw)
+    close(b, a, 0, 2e-4 * scale_of(ref) * 3)
+    kw = dict(noise=det_tensor('w4.nzb', [n, oh, ow]).to(DEV), bias=det_tensor('w4.b', [cout]).to(DEV), act='relu')
+    close(run(2, **kw), run(0, **kw), 0, 2e-4 * scale_of(ref))
+    if cout % 64 == 0:
+        c = cout // 2
+        sx, mean, rstd = det_tensor('w4.sx', [n, c, oh, ow]).to(DEV), det_tensor('w4.mu', [n, c]).to(DEV), det_tensor('w4.rs', [n, c]).abs().to(DEV) + 0.5
+        outs = []
+        for algo in (0, 2):
+            pk = conv2d_mfma.pack_spade_gamma_beta(wt[:c].contiguous(), wt[c:].contiguous(), winograd=algo)
+            outs.append(conv2d_mfma.conv2d_forward(x, pk, cout, 3, 3, pad=(pad, pad), spade=(sx, mean, rstd), winograd=algo, act='lrelu', alpha=0.2, gain=1.4, clamp=3.0))
+        close(outs[1], outs[0], 0, 2e-4 * scale_of(outs[0]))
+    # flipped / O<->I transposed packs (the input-gradient route): dx of y = conv(x, w) is conv(dy, w^T flipped)
+    dy = det_tensor(f'w4.dy.{cout}.{oh}', [n, cout, oh, ow]).to(DEV)
+    if 0 <= 2 - pad <= 4:
+        pk = conv2d_mfma.pack_weight(wt, flip=True, transpose_oi=True, winograd=2)
+        dx = conv2d_mfma.conv2d_forward(dy, pk, cin, 3, 3, pad=(2 - pad, 2 - pad), winograd=2)
+        want = torch.nn.grad.conv2d_input(x.shape, wt.double().cpu(), dy.double().cpu(), padding=pad)
+        close(dx, want, 0, 1e-4 * scale_of(want))
+
+
+def test_conv2d_winograd4_policy_and_declines():
+    from torch_utils.ops import conv2d_mfma
+    from torch_utils.ops._native import NativeNotCovered
+    assert conv2d_mfma.use_winograd(3, 3, 1, 128, 128, pad=(1, 1), hw=(256, 256)) == 2
+    assert conv2d_mfma.use_winograd(3, 3, 1, 128, 128, pad=(1, 1)) == 1                          # no image size: F(2x2)
+    assert conv2d_mfma.use_winograd(3, 3, 1, 128, 128, pad=(1, 1), hw=(256, 254)) == 1          # width no multiple of 4
+    assert conv2d_mfma.use_winograd(3, 3, 1, 128, 128, pad=(1, 1), hw=(256, 256), xf=True) == 1  # input pre-activation: F(2x2) has the prologue
+    assert conv2d_mfma.use_winograd(3, 3, 1, 96, 128, pad=(1, 1), hw=(256, 256)) == 1 and conv2d_mfma.use_winograd(3, 3, 1, 128, 32, pad=(1, 1), hw=(256, 256)) == 1
+    assert conv2d_mfma.use_winograd(3, 3, 1, 512, 512, pad=(1, 1), hw=(16, 16)) == 1 and conv2d_mfma.use_winograd(3, 3, 1, 16, 16, hw=(256, 256)) == 0
+    x = det_tensor('w4d.x', [1, 16, 8, 66]).to(DEV)
+    wt = det_tensor('w4d.w', [64, 16, 3, 3]).to(DEV)
+    with pytest.raises(NativeNotCovered):
+        conv2d_mfma.conv2d_forward(x, conv2d_mfma.pack_weight(wt, winograd=2), 64, 3, 3, pad=(1, 1), winograd=2)        # W % 4 != 0
+
+
 @pytest.mark.parametrize('n,cin,cout,h,w,kh,kw,pad,step', [(8, 512, 512, 8, 8, 2, 2, 1, 2), (4, 512, 96, 16, 16, 1, 1, 0, 1), (2, 256, 512, 32, 32, 3, 3, 1, 1),
                                                           (8, 512, 3, 16, 16, 1, 1, 0, 1), (3, 144, 40, 9, 13, 1, 2, 0, 2)])
 def test_conv2d_split_k_matches_single_pass(n, cin, cout, h, w, kh, kw, pad, step, monkeypatch):
@@ -665,6 +720,14 @@ def test_synthesis_reduced_golden(golden, variant, labels):
         np.testing.assert_allclose(float(t.double().abs().sum()), float(g[f'{variant}/{nm}_abssum']), rtol=1e-4)
 
 
+def _pixel_bar(nm, a, b, what=''):
+    """north_star: <= 1e-3 max-abs delta vs the reference ops, ABSOLUTE (the random-weight outputs span 15-115, so a bar
+    relative to the range was ~100x looser than stated).  Returns the measured delta."""
+    delta = float((a.detach().cpu().double() - b.detach().cpu().double()).abs().max())
+    assert delta <= 1e-3, f'{what}{nm}: max-abs delta {delta:.3e} > 1e-3 (output range {scale_of(b):.3e})'
+    return delta
+
+
 def test_synthesis_full_width_vs_oracle():
     """BASELINE config 2's network (channel_base 32768, 27.6 M parameters), N=1, against the CPU oracle."""
     from training import networks as PN
@@ -681,9 +744,7 @@ def test_synthesis_full_width_vs_oracle():
         out = net(*args(lambda t: t.to(DEV)), noise_mode='const')
         ref = ref_net(*args(lambda t: t), noise_mode='const')
     for nm, a, b in zip(('img', 'finetune_img', 'pred_parsing'), out, ref):
-        s = scale_of(b)
-        delta = float((a.cpu().double() - b.double()).abs().max())
-        assert delta <= 1e-3 * s, f'{nm}: max-abs delta {delta:.3e} vs output range {s:.3e}'
+        print(f'config 2 N=1 {nm}: max-abs delta {_pixel_bar(nm, a, b):.2e} (range {scale_of(b):.1f})')
 
 
 # =============================================================== "next" row f1: encoders, mapping, full generator
@@ -734,9 +795,7 @@ def test_full_generator_vs_oracle():
         out = call(net, lambda t: t.to(DEV))
         want = call(ref, lambda t: t)
     for nm, a, b in zip(('img', 'finetune_img', 'pred_parsing'), out, want):
-        s = scale_of(b)
-        delta = float((a.cpu().double() - b.double()).abs().max())
-        assert delta <= 1e-3 * s, f'{nm}: max-abs delta {delta:.3e} vs output range {s:.3e}'
+        print(f'config 3 N=1 {nm}: max-abs delta {_pixel_bar(nm, a, b):.2e} (range {scale_of(b):.1f})')
 
 
 def test_discriminator_with_r1_double_backward_golden(golden):
@@ -799,6 +858,44 @@ def test_training_phase_gradients_vs_oracle(phase):
     for k in want:
         assert abs(got[k] - want[k]) <= 3e-3 * abs(want[k]) + 1e-6, (k, got[k], want[k])
     assert any(v > 0 for v in got.values())
+
+
+@pytest.mark.parametrize('phase', ['Dboth', 'Gmain'])
+def test_config4_discriminators_at_real_shape_vs_oracle(phase):
+    """BASELINE config 4's discriminators at their REAL shape and per-rank batch (train.py:174, 196-198: 512^2, channel_base 32768,
+    conv_clamp 256, minibatch-std groups of 4, batch_gpu 4) inside the product loss on the GPU against the oracle discriminators in
+    the same loss on the CPU: `Dboth` = both backward passes of the D phase incl. the R1 double backward (weight gradients of every
+    layer, native wgrad kernels included); `Gmain` = the generator phase, i.e. the discriminators' INPUT gradients flowing into the
+    (plain-torch stub) generator at 512^2.  fp32 on both sides; per-parameter sum|grad| within 3e-3."""
+    import stubs
+    from training import networks as PN
+    from training.loss import StyleGAN2Loss
+    from oracle import network_ref as NR
+    res, n = 512, 4
+    d_kw = lambda ch: dict(c_dim=stubs.CDIM, img_resolution=res, img_channels=ch, channel_base=32768, channel_max=512, conv_clamp=256,
+                           mapping_kwargs=dict(num_layers=1), epilogue_kwargs=dict(mbstd_group_size=4))
+
+    def run(device, D_cls):
+        nets = stubs.build(device)
+        for name, ch in (('D', 6), ('D_parsing', 10)):
+            ref = fill_module_(NR.Discriminator(**d_kw(ch)), f'c4.{name}.')
+            d = D_cls(**d_kw(ch))
+            d.load_state_dict(ref.state_dict(), strict=False)
+            nets[name] = d.to(device).train()
+        loss = StyleGAN2Loss(device=torch.device(device), **nets, style_mixing_prob=0, r1_gamma=10, l1_weight=50, mask_weight=1.0)
+        stubs.zero_grads(nets)
+        stubs.set_phase_trainable(nets, phase)
+        loss.accumulate_gradients(phase=phase, gain=1, **stubs.batch(n, device, res=res))
+        return stubs.grad_signature(nets)
+
+    torch.set_num_threads(min(16, len(__import__('os').sched_getaffinity(0))))
+    got, want = run(DEV, PN.Discriminator), run('cpu', NR.Discriminator)
+    assert got.keys() == want.keys()
+    worst = max((abs(got[k] - want[k]) / (abs(want[k]) + 1e-12), k) for k in want if want[k] > 0)
+    print(f'config 4 {phase} at 512^2, N=4: {sum(1 for v in want.values() if v > 0)} parameters with gradients, worst signature mismatch {worst[0]:.2e} ({worst[1]})')
+    for k in want:
+        assert abs(got[k] - want[k]) <= 3e-3 * abs(want[k]) + 1e-6, (k, got[k], want[k])
+    assert sum(1 for k, v in got.items() if v > 0 and k.startswith('D.' if phase == 'Dboth' else 'G_')) >= 4
 
 
 @pytest.mark.parametrize('d_fp16_res', [0, 3])
@@ -864,9 +961,36 @@ def test_synthesis_full_width_batch8_vs_oracle():
         for i in (0, 3, 7):
             ref = ref_net(*args(lambda t: t[i:i + 1]), noise_mode='const')
             for nm, a, b in zip(('img', 'finetune_img', 'pred_parsing'), out, ref):
-                s = scale_of(b)
-                delta = float((a[i:i + 1].double() - b.double()).abs().max())
-                assert delta <= 1e-3 * s, f'image {i} {nm}: max-abs delta {delta:.3e} vs output range {s:.3e}'
+                _pixel_bar(nm, a[i:i + 1], b, f'image {i} ')
+
+
+def test_bench_workload_argmax_path_batch8_vs_oracle():
+    """The EXACT workload bench.py times (its make_inputs / run_net: gt_parsing=None, i.e. the argmax parsing path of test.py) at
+    N=8 against the CPU oracle on images 0, 3 and 7.  `img` and `pred_parsing` are upstream of the argmax and must meet the bar
+    outright; `finetune_img` is downstream of it -- a near-tie in the parsing logits may legitimately flip a label -- so it is
+    compared where both sides took the same labels: everywhere if the label maps agree (expected), otherwise the disagreeing
+    fraction must be tiny and the comparison is skipped for that image with a message."""
+    import bench
+    from training import networks as PN
+    from oracle import network_ref as NR
+    bench.torch = torch
+    ref_net = bench.init_weights(NR.SynthesisNetworkFull_v18(**bench.CFG2)).eval()
+    net = _load(PN.SynthesisNetworkFull_v18(**bench.CFG2), ref_net)
+    dev_inp, cpu_inp = bench.make_inputs(8, DEV, seed=0), bench.make_inputs(8, 'cpu', seed=0)
+    take = lambda d, i: {k: ({kk: vv[i:i + 1] for kk, vv in v.items()} if isinstance(v, dict) else v[i:i + 1]) for k, v in d.items()}
+    with torch.no_grad():
+        out = [o.cpu() for o in bench.run_net(net, dev_inp)]
+        for i in (0, 3, 7):
+            ref = bench.run_net(ref_net, take(cpu_inp, i))
+            d_img = _pixel_bar('img', out[0][i:i + 1], ref[0], f'image {i} ')
+            d_pp = _pixel_bar('pred_parsing', out[2][i:i + 1], ref[2], f'image {i} ')
+            flips = float((out[2][i:i + 1].argmax(dim=1) != ref[2].argmax(dim=1)).float().mean())
+            if flips == 0:
+                d_fi = _pixel_bar('finetune_img', out[1][i:i + 1], ref[1], f'image {i} ')
+                print(f'bench workload image {i}: img {d_img:.2e}, pred_parsing {d_pp:.2e}, finetune_img {d_fi:.2e} (labels identical)')
+            else:
+                assert flips < 1e-4, f'image {i}: {flips:.2e} of the argmax labels differ'
+                print(f'bench workload image {i}: img {d_img:.2e}, pred_parsing {d_pp:.2e}; {flips:.2e} of the labels flipped on near-ties, finetune_img not compared')
 
 
 def test_config3_chain_patch_routing_into_generator_n16():

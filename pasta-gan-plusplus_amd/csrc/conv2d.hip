@@ -74,8 +74,8 @@ __global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict_
 
 
 // Winograd F(4x4, 3x3) weight transform: U = G g G^T (6x6) per (ci, co) in float64, rounded once, stored in the order the waves of
-// conv2d_wino4.h walk it: [m-block 64][mt][q][chunk 16 ch][group = (xi third jg, pair quad)][xi jj][lane = (h, co & 31)][pair s], with
-//   xi = 6a + b = 9q + 3jg + jj,   channel = 16 chunk + 2 (4 quad + s) + h.
+// conv2d_wino4.h walk it: [m-block 64][mt][a][chunk 16 ch][group = (b half jg, pair quad)][b third jj][lane = (h, co & 31)][pair s], with
+//   xi = 6a + b,  b = 3jg + jj,   channel = 16 chunk + 2 (4 quad + s) + h.
 //   G = [[1/4, 0, 0], [-1/6, -1/6, -1/6], [-1/6, 1/6, -1/6], [1/24, 1/12, 1/6], [1/24, -1/12, 1/6], [0, 0, 1]]
 __global__ __launch_bounds__(256) void wino4_pack_kernel(const float* __restrict__ w, float* __restrict__ up, int Cout, int Cin,
                                                          int CinP, int CoutP, float scale, int flip, int transpose_oi) {
@@ -111,9 +111,9 @@ __global__ __launch_bounds__(256) void wino4_pack_kernel(const float* __restrict
 #pragma unroll
             for (int b = 0; b < 6; b++) {
                 const double u = tg[a][0] * G[b][0] + tg[a][1] * G[b][1] + tg[a][2] * G[b][2];      // (G g) G^T
-                const int xi = 6 * a + b, q = xi / 9, j = xi % 9, jg = j / 3, jj = j % 3;
-                const int64_t unit = ((int64_t)(mb * 2 + mt) * 4 + q) * nchunks + k;
-                const int64_t dst = ((((unit * 3 + jg) * 2 + quad) * 3 + jj) * 64 + (h * 32 + m)) * 4 + sp;
+                const int jg = b / 3, jj = b % 3;
+                const int64_t unit = ((int64_t)(mb * 2 + mt) * 6 + a) * nchunks + k;
+                const int64_t dst = ((((unit * 2 + jg) * 2 + quad) * 3 + jj) * 64 + (h * 32 + m)) * 4 + sp;
                 up[dst] = (float)u;
             }
     }

@@ -10,23 +10,25 @@
 // (512 threads = 16 channels x 32 tiles, one 6x6 patch each) writes V[36][16][32] to LDS, and a GEMM phase multiplies from it
 // (B operand = V by ds_read, A operand = pre-transformed weights streamed from L2 by each wave, as in conv2d_wino.h).
 //
-// Mapping
-//   * workgroup = 512 threads = 8 waves, ONE per CU (LDS 118-150 KB); tile = 64 couts x (8 output rows x 64 output cols) = 32 tiles of
-//     4x4 outputs, MFMA column n = 2 * tile_x + tile_y (this interleave makes the 16-byte patch reads of the transform phase
-//     conflict-free: tile_y adds 8 sixteen-byte slots mod 16).
-//   * GEMM phase: wave w = (q = w >> 1, mt = w & 1) owns xi in [9q, 9q + 9) for cout M-tile mt: 9 accumulators = 144 VGPRs, two waves
-//     per SIMD.  Per chunk 72 MFMAs per wave in six groups of (3 xi) x (4 channel pairs): three accumulators in rotation, the
-//     group's A words are three 16-byte loads (1 KB per wave-instruction, contiguous 3 KB per group; packed by
-//     pg_conv2d_winograd4_pack_weight in exactly the order the wave walks), its B words six ds_read2st64_b32.
-//   * the raw 10-row halo tile [16][10][72] arrives by 16-byte LDS-DMA (waves 0-3 issue, gather map kept in LDS; zero padding = the
-//     buffer range check on a sentinel offset), requested for chunk k+1 when the transform of chunk k is done: single raw buffer,
-//     single V buffer, two barriers per chunk.
-//   * U words are inline-asm loads waited for with hand-counted vmcnt (two groups in flight; the DMA sits between them in the
-//     queue for the issuing waves: vmcnt(3 + 12) for the first two groups of a chunk, vmcnt(3) after -- the third group's wait is
-//     also what guarantees the DMA has landed before the next chunk's barrier).
-//   * tail: all 36 xi of a (cout, tile) live in different waves, so 16 couts per round go through LDS (the V buffer, dead by then);
-//     512 threads then own one (cout, tile) each: inverse transform 6x6 -> 4x4 (100 VALU), fused epilogue of conv2d_wino.h on four
-//     16-byte row segments.  SPADE mode: thread = (channel, tile, row pair) combining the gamma and beta rows of its channel.
+// Mapping (second version; the first had 8 waves x 9 xi and exchanged all 36 values per output tile: its tail was 19-26 % of a launch)
+//   * workgroup = 768 threads = 12 waves, ONE per CU (LDS 118-150 KB), three waves per SIMD; tile = 64 couts x (8 output rows x 64
+//     output cols) = 32 tiles of 4x4 outputs, MFMA column n = 2 * tile_x + tile_y (this interleave makes the 16-byte patch reads of
+//     the transform phase conflict-free: tile_y adds 8 sixteen-byte slots mod 16).
+//   * GEMM phase: wave w = (a = w >> 1, mt = w & 1) owns row a of the 6x6 transform domain, xi = 6a .. 6a + 5, for cout M-tile mt:
+//     6 accumulators = 96 VGPRs.  Per chunk 48 MFMAs per wave in four groups of (3 xi) x (4 channel pairs): three accumulators in
+//     rotation; a group's A words are three 16-byte loads (1 KB per wave-instruction, 3 KB contiguous per group, packed by
+//     pg_conv2d_winograd4_pack_weight in exactly the order the wave walks), its B words six ds_read2st64_b32 of V.
+//   * transform phase: waves 0-7 (16 channels x 32 tiles, one 6x6 patch per thread); waves 8-11 own the chores instead: they issue
+//     the 16-byte LDS-DMA of the raw 10-row halo tile [16][10][72] for chunk k+1 as soon as the transform of chunk k is done (gather
+//     map kept in LDS; zero padding = the buffer range check on a sentinel offset), compute edge-tile gather maps and fetch the
+//     epilogue constants.  Single raw buffer, single V buffer, two barriers per chunk.
+//   * U words are inline-asm loads waited for with hand-counted vmcnt (one group ahead; for the issuing waves the DMA sits in the
+//     queue behind the first two groups' words: vmcnt(3 + NDMA) there, vmcnt(3) after -- the third group's wait is also what
+//     guarantees the DMA has landed before the next chunk's barrier).
+//   * tail: a wave holds all six b of its row a, so the column half of the inverse transform (6 -> 4) is done in registers and the
+//     four results of a (cout, tile) leave as ONE 16-byte LDS word; 16 couts per round; waves 0-7 then own one (cout, tile) each:
+//     six 16-byte reads, the row half (6 -> 4 per column), the fused epilogue of conv2d_wino.h on four 16-byte row segments
+//     addressed by 32-bit offsets against per-image bases.  SPADE mode: thread = (channel, tile, row pair) combining gamma and beta.
 // Numerics: float32 throughout, weights transformed in float64 by the pack kernel and rounded once; tools/f43_error_probe.py
 // measures the effect on the whole config-2 network (3.7e-5 max-abs on `img` against the direct float32 run, F(2x2): 1.0e-5).
 #pragma once
@@ -34,7 +36,8 @@
 #include "conv2d_wino.h"
 
 #ifndef WINO4_EXP
-#define WINO4_EXP 0      // dev ablations (results wrong by design): 1 no U loads, 2 no transform phase, 4 no tail, 8 no halo DMA
+#define WINO4_EXP 0      // dev ablations (results wrong by design): 1 no U loads, 2 no transform phase, 4 no tail, 8 no halo DMA, 16 no output stores,
+                         // 32 no finishing (exchange writes and barriers stay), 64 no exchange writes, 128 cycle stamps of workgroup 0's second tile into y[0..]
 #endif
 
 namespace pgconv {
@@ -49,7 +52,8 @@ constexpr int W4_NDMA = 12;                      // requests per issuing thread 
 constexpr int W4_RAW = W4_NX + 16;               // + room for the 0..3 float shift that aligns the patches
 constexpr int W4_V = 36 * 512;                   // V[xi][channel 16][tile 32]  /  exchange [xi][cout 16][tile 32]
 constexpr int W4_UGROUP = 3 * 1024;              // bytes of one A-operand group (3 xi x 64 lanes x 16 B)
-constexpr int W4_UCHUNK = 6 * W4_UGROUP;         // per (wave unit, chunk)
+constexpr int W4_UCHUNK = 4 * W4_UGROUP;         // per (wave unit = (m-block, mt, a), chunk): groups (jg, quad)
+constexpr int W4_EX = 6 * 16 * 32 * 4;           // exchange floats per round: [a][cout 16][tile 32][4 columns]
 
 // 1-D transforms.  B^T rows (input), A^T rows (output) of F(4,3) with points 0, 1, -1, 2, -2, inf.
 __device__ __forceinline__ void w4_bt(float d0, float d1, float d2, float d3, float d4, float d5,
@@ -71,9 +75,39 @@ __device__ __forceinline__ void w4_at(float m0, float m1, float m2, float m3, fl
     y3 = fmaf(8.f, d34, d12) + m5;
 }
 
+// Six V values of transform-domain row A (xi = 6A .. 6A + 5) of this wave's 64 (channel, tile) items, written with ds_write_addtid_b32:
+// address = M0 + offset + 4 * lane with no address VGPR -- 128 B/clk/CU, twice the rate of ds_write_b32, which is what bounded the
+// transform phase (36 writes per thread).  V[xi] planes are 2048 bytes apart; the instruction's offset field is 16 bits, so row 5 goes
+// through a second base 16384 bytes up.  M0 is compiler-reserved: saved and restored inside the statement (cdna_hip_programming.md
+// section 5.7); the writes are drained here because the compiler cannot count them for the barrier that follows.
+template <int A>
+__device__ __forceinline__ void w4_write_row(unsigned m0_base, float v0, float v1, float v2, float v3, float v4, float v5) {
+    constexpr int ADJ = A == 5 ? 16384 : 0;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                 "ds_write_addtid_b32 %2 offset:%8\n\tds_write_addtid_b32 %3 offset:%9\n\tds_write_addtid_b32 %4 offset:%10\n\t"
+                 "ds_write_addtid_b32 %5 offset:%11\n\tds_write_addtid_b32 %6 offset:%12\n\tds_write_addtid_b32 %7 offset:%13\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "s"(m0_base + ADJ), "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(v4), "v"(v5),
+                   "n"((6 * A + 0) * 2048 - ADJ), "n"((6 * A + 1) * 2048 - ADJ), "n"((6 * A + 2) * 2048 - ADJ),
+                   "n"((6 * A + 3) * 2048 - ADJ), "n"((6 * A + 4) * 2048 - ADJ), "n"((6 * A + 5) * 2048 - ADJ)
+                 : "memory");
+}
+
+// The lane index, recomputed where a phase needs it (two VALU instructions) instead of living in a VGPR across the whole kernel: with 96
+// accumulator registers, a 12-register operand ring and the 36-value patch of the transform phase the budget of 168 has no room for
+// loop-invariant address registers -- a spilled one comes back through a scratch load, i.e. a vmcnt(0) in the middle of the K loop.
+// (volatile: not merged with other calls, not hoisted out of the loops)
+__device__ __forceinline__ int w4_fresh_lane() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+
 // MODE: 0 = plain input, 1 = per-(n, channel) input scale (modulated convolution).  (Pre-activation launches stay on conv2d_wino.h.)
 template <int MODE>
-__global__ __launch_bounds__(512, 2) void conv2d_wino4(ConvParams p) {
+__global__ __launch_bounds__(768, 3) void conv2d_wino4(ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int cin_loop = ((p.Cin + W4_KC - 1) / W4_KC) * W4_KC;
     const int nchunks = cin_loop / W4_KC;
@@ -84,14 +118,14 @@ __global__ __launch_bounds__(512, 2) void conv2d_wino4(ConvParams p) {
     unsigned* gmI = (unsigned*)(ep0 + 256);      // gather map of an interior tile [12][256] (byte offsets relative to the tile's first halo sample)
     unsigned* gmE = gmI + W4_NDMA * 256;         // gather map of the current edge tile (absolute in the image, sentinel outside)
 
-    const int t = threadIdx.x, lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const unsigned smem_b = __builtin_amdgcn_readfirstlane(lds_offset(smem));
-    const int half = lane >> 5, l31 = lane & 31;
     const int HW = p.H * p.W;
     const int total = p.total_tiles;
     const int q8 = total >> 3, r8 = total & 7;
-    const int q = wave >> 1, mt = wave & 1;      // GEMM role
+    const int ta = wave >> 1, mt = wave & 1;     // GEMM role: transform-domain row a, cout M-tile
+    const bool chore = wave >= 8;                // waves 8-11: DMA issue, gather maps, epilogue constants (they sit out the transform and the finish)
+    const int cw = wave - 8;                     // chore wave 0..3; chore thread index tc = 64 cw + lane
     const int sh = p.pad_x & 3;                  // float shift of the staged tile: patch column 0 of tile_x lands on LDS column 4 tile_x + cbase
     const int cbase = 4 - p.pad_x + sh;          // 4 (pad 0..3) or 0 (pad 4): a multiple of 4 -> 16-byte aligned patch reads
 
@@ -100,13 +134,14 @@ __global__ __launch_bounds__(512, 2) void conv2d_wino4(ConvParams p) {
     i32x4 xrsrc;
 
     // Interior gather map: tile-independent, computed once.  Word f of the buffer = (channel f / 180, row (f % 180) / 18, word f % 18).
-    if (wave < 4) {
+    if (chore) {
+        const int tc = 64 * cw + w4_fresh_lane();
 #pragma unroll
         for (int i = 0; i < W4_NDMA; i++) {
-            const int f = i * 256 + t;
+            const int f = i * 256 + tc;
             const int c = f / 180, rem = f % 180;
             const int row = rem / 18, wd = rem % 18;
-            gmI[i * 256 + t] = (unsigned)(c * HW + row * p.W + 4 * wd) * 4u;
+            gmI[i * 256 + tc] = (unsigned)(c * HW + row * p.W + 4 * wd) * 4u;
         }
     }                                            // (read back by the writing thread only: no barrier needed)
 
@@ -120,13 +155,12 @@ __global__ __launch_bounds__(512, 2) void conv2d_wino4(ConvParams p) {
         oy0 = ty * 8; ox0 = tx * 64; m0 = mb * 64;
         if (MODE != 0) {
             const float* in_scale = p.f.in_scale ? p.f.in_scale + (int64_t)n * p.Cin : nullptr;
-            for (int c = t; c < cin_loop; c += 512) cs[c] = ((in_scale && c < p.Cin) ? ld_opaque(in_scale + c) : 1.f) * p.f.in_gain;
+            for (int c = 64 * wave + w4_fresh_lane(); c < cin_loop; c += 768) cs[c] = ((in_scale && c < p.Cin) ? ld_opaque(in_scale + c) : 1.f) * p.f.in_gain;
         }
         const int gy0 = oy0 - p.pad_y, gx0 = ox0 - 4;
         edge = !(gy0 >= 0 && gy0 + W4_ROWS <= p.H && gx0 >= 0 && gx0 + W4_LROW <= p.W);           // wave-uniform
-        if (edge && wave < 4) {
-            int tt = t;
-            asm volatile("" : "+v"(tt));             // keep the index maths inside the tile loop
+        if (edge && chore) {
+            const int tt = 64 * cw + w4_fresh_lane();
 #pragma unroll
             for (int i = 0; i < W4_NDMA; i++) {
                 const int f = i * 256 + tt;
@@ -147,29 +181,27 @@ __global__ __launch_bounds__(512, 2) void conv2d_wino4(ConvParams p) {
 
     auto issue_chunk = [&](int c0) {
 #if !(WINO4_EXP & 8)
-        if (wave < 4) {
+        if (chore) {
             const unsigned xs_b = smem_b + (unsigned)sh * 4u;
             const int soff = c0 * HW * 4;
             const unsigned* gm = edge ? gmE : gmI;
+            const int tc = 64 * cw + w4_fresh_lane();
             unsigned off[W4_NDMA];
 #pragma unroll
-            for (int i = 0; i < W4_NDMA; i++) off[i] = gm[i * 256 + t];
+            for (int i = 0; i < W4_NDMA; i++) off[i] = gm[i * 256 + tc];
 #pragma unroll
-            for (int i = 0; i < W4_NDMA - 1; i++) dma_dwordx4_buf(xrsrc, xs_b + (unsigned)(256 * i + 64 * wave) * 16u, off[i], soff);
-            if (wave == 0) dma_dwordx4_buf(xrsrc, xs_b + (unsigned)(256 * (W4_NDMA - 1)) * 16u, off[W4_NDMA - 1], soff);    // words 2816..2879
-            else asm volatile("s_nop 0");
+            for (int i = 0; i < W4_NDMA - 1; i++) dma_dwordx4_buf(xrsrc, xs_b + (unsigned)(256 * i + 64 * cw) * 16u, off[i], soff);
+            if (cw == 0) dma_dwordx4_buf(xrsrc, xs_b + (unsigned)(256 * (W4_NDMA - 1)) * 16u, off[W4_NDMA - 1], soff);    // words 2816..2879
         }
 #endif
     };
-    // requests the DMA-issuing waves put in the queue per chunk (wave 0 one more)
-    // -> counted waits below use the per-wave number
 
-    f32x16 acc[9];
+    f32x16 acc[6];                                   // [b]
 
-    // A-operand stream of this wave: [m-block][mt][q][chunk][group 6][xi 3][lane 64][4 pairs] floats, walked strictly forwards
-    // inside a tile; two groups in flight.
+    // A-operand stream of this wave: [m-block][mt][a][chunk][group = (jg, quad)][xi 3][lane 64][4 pairs] floats, walked strictly
+    // forwards inside a tile, one group ahead.
     unsigned pa;
-    auto a_reset = [&](int m0_) { pa = (unsigned)((((m0_ >> 6) * 2 + mt) * 4 + q) * nchunks) * (unsigned)W4_UCHUNK + (unsigned)lane * 16u; };
+    auto a_reset = [&](int m0_) { pa = (unsigned)((((m0_ >> 6) * 2 + mt) * 6 + ta) * nchunks) * (unsigned)W4_UCHUNK + (unsigned)w4_fresh_lane() * 16u; };
     auto load_u = [&](f32x4 (&dst)[3]) {
 #if !(WINO4_EXP & 1)
         asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst[0]) : "v"(pa), "s"(p.wp));
@@ -178,10 +210,10 @@ __global__ __launch_bounds__(512, 2) void conv2d_wino4(ConvParams p) {
 #endif
         pa += (unsigned)W4_UGROUP;
     };
+    // wait for the three words of one group; `younger` = vector-memory operations issued after them that may still be in flight
     auto wait_u = [&](f32x4 (&g)[3], bool dma_younger) {
-        // 3 younger ring words, plus (first two groups of a chunk, issuing waves) the chunk's DMA requests issued after them
         if (dma_younger) {
-            if (wave == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 + W4_NDMA));
+            if (cw == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 + W4_NDMA));
             else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 + W4_NDMA - 1));
         } else {
             asm volatile("s_waitcnt vmcnt(3)");
@@ -196,23 +228,25 @@ __global__ __launch_bounds__(512, 2) void conv2d_wino4(ConvParams p) {
         return a;
     };
 
-    // transform role: channel 2 * wave + half of the chunk, tile n = l31 -> (tile_x = n >> 1, tile_y = n & 1)
-    const float* rb = raw + (2 * wave + half) * W4_CHF + (4 * (l31 & 1)) * W4_LROW + 4 * (l31 >> 1) + cbase;
-    float* vw = V + wave * 64 + lane;                                   // V[xi][2 wave + half][l31]
-    const float* vb = V + 9 * q * 512 + lane;                           // B operand base: V[9q + j][pair][half][l31]
 
+#if WINO4_EXP & 128
+    unsigned long long stamp[16];
+    int tiles_done = 0;
+#define W4_STAMP(i) do { if (tiles_done == 1) stamp[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define W4_STAMP(i) do { } while (0)
+#endif
     int tile = blockIdx.x;
     int par = 0;
     prep_tile(tile, cs0);
     f32x4 ur[2][3];
     a_reset(m0);
-    load_u(ur[0]);
-    load_u(ur[1]);
+    load_u(ur[0]);                                                      // group 0 of the first chunk
     issue_chunk(0);
-    dma_wait_all();                                                     // (also the two U groups: they are home before the first chunk)
+    dma_wait_all();
     while (true) {
 #pragma unroll
-        for (int j = 0; j < 9; j++)
+        for (int j = 0; j < 6; j++)
 #pragma unroll
             for (int k = 0; k < 16; k++) acc[j][k] = 0.f;
 
@@ -223,13 +257,18 @@ __global__ __launch_bounds__(512, 2) void conv2d_wino4(ConvParams p) {
         float* ep_scale = ep0 + par * 128;
         float* ep_bias = ep_scale + 64;
 
+        W4_STAMP(0);
 #pragma unroll 1
         for (int k = 0; k < nchunks; k++) {
-            __syncthreads();                                            // A: raw(k) has landed (each issuing wave waited for its own requests
-                                                                        //    at its third U group), V is free (every wave is past GEMM(k-1) / the tail)
-            // ---- transform phase: one 6x6 patch per thread -> 36 V values
+            __syncthreads();                                            // A: raw(k) has landed (the issuing waves waited for their requests at
+                                                                        //    their third U group), V is free (every wave is past GEMM(k-1) / the tail)
+            if (k == 2) W4_STAMP(1);
+            // ---- transform phase (waves 0-7): one 6x6 patch per thread -> 36 V values
 #if !(WINO4_EXP & 2)
-            {
+            if (!chore) {
+                // transform role (waves 0-7): channel 2 * wave + half of the chunk, tile n = l31 -> (tile_x = n >> 1, tile_y = n & 1)
+                const int lane = w4_fresh_lane(), half = lane >> 5, l31 = lane & 31;
+                const float* rb = raw + (2 * wave + half) * W4_CHF + (4 * (l31 & 1)) * W4_LROW + 4 * (l31 >> 1) + cbase;
                 float d[6][6];
 #pragma unroll
                 for (int r = 0; r < 6; r++) {
@@ -241,94 +280,129 @@ __global__ __launch_bounds__(512, 2) void conv2d_wino4(ConvParams p) {
 #pragma unroll
                 for (int j = 0; j < 6; j++)                              // columns: over the patch rows
                     w4_bt(d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j], d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j]);
-#pragma unroll
-                for (int a = 0; a < 6; a++) {                            // rows: over the patch columns, then out to V[6a + b]
-                    float v0, v1, v2, v3, v4, v5;
-                    w4_bt(d[a][0], d[a][1], d[a][2], d[a][3], d[a][4], d[a][5], v0, v1, v2, v3, v4, v5);
-                    if (MODE != 0) { v0 *= sc; v1 *= sc; v2 *= sc; v3 *= sc; v4 *= sc; v5 *= sc; }
-                    vw[(6 * a + 0) * 512] = v0; vw[(6 * a + 1) * 512] = v1; vw[(6 * a + 2) * 512] = v2;
-                    vw[(6 * a + 3) * 512] = v3; vw[(6 * a + 4) * 512] = v4; vw[(6 * a + 5) * 512] = v5;
-                }
+                // rows: over the patch columns, then out to V[6a + b]
+                const unsigned vbase = smem_b + (unsigned)(W4_RAW * 4 + wave * 256);      // bytes: V + 64 floats per transform wave (< 65536: checked by the host)
+#define W4_ROW(A) { float v0, v1, v2, v3, v4, v5; \
+                    w4_bt(d[A][0], d[A][1], d[A][2], d[A][3], d[A][4], d[A][5], v0, v1, v2, v3, v4, v5); \
+                    if (MODE != 0) { v0 *= sc; v1 *= sc; v2 *= sc; v3 *= sc; v4 *= sc; v5 *= sc; } \
+                    w4_write_row<A>(vbase, v0, v1, v2, v3, v4, v5); }
+                W4_ROW(0) W4_ROW(1) W4_ROW(2) W4_ROW(3) W4_ROW(4) W4_ROW(5)
+#undef W4_ROW
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
 #endif
+            if (k == 2) W4_STAMP(2);
             __syncthreads();                                            // B: V(k) complete, raw free
+            if (k == 2) W4_STAMP(3);
 
-            // ---- request the next chunk (of this tile, or the first of the next tile)
-            bool issued = true;
-            if (k + 1 < nchunks) {
-                issue_chunk((k + 1) * W4_KC);
-            } else {
-                e_n = n; e_oy0 = oy0; e_ox0 = ox0; e_m0 = m0;
+            if (k == 0) {
+                // epilogue constants of THIS tile (wave 8 only, before anything new enters its queue: ld_opaque waits for vmcnt(0))
                 const auto& qa = *fresh_args();
+                const int tc = wave == 8 ? w4_fresh_lane() : 64;              // wave 8 only
                 if (qa.f.spade_x) {
-                    if (t < 32) {
-                        const int ch = (e_m0 >> 1) + t;
-                        ep_scale[t] = ld_opaque(qa.f.spade_mean + e_n * (qa.Cout >> 1) + ch);
-                        ep_bias[t] = ld_opaque(qa.f.spade_rstd + e_n * (qa.Cout >> 1) + ch);
+                    if (tc < 32) {
+                        const int ch = (m0 >> 1) + tc;
+                        ep_scale[tc] = ld_opaque(qa.f.spade_mean + n * (qa.Cout >> 1) + ch);
+                        ep_bias[tc] = ld_opaque(qa.f.spade_rstd + n * (qa.Cout >> 1) + ch);
                     }
-                } else if (t < 64) {
-                    const int co = e_m0 + t;
+                } else if (tc < 64) {
+                    const int co = m0 + tc;
                     const bool ok = co < qa.Cout;
                     const int cc = ok ? co : 0;
-                    const float scv = qa.f.out_scale ? ld_opaque(qa.f.out_scale + (int64_t)e_n * qa.Cout + cc) : 1.f;
+                    const float scv = qa.f.out_scale ? ld_opaque(qa.f.out_scale + (int64_t)n * qa.Cout + cc) : 1.f;
                     const float bi = qa.f.bias ? ld_opaque(qa.f.bias + cc) : 0.f;
-                    ep_scale[t] = ok ? scv : 0.f;
-                    ep_bias[t] = ok ? bi : 0.f;
-                }
-                next = tile + gridDim.x;
-                has_next = next < total;
-                if (has_next) {
-                    prep_tile(next, cs0 + (par ^ 1) * cin_loop);
-                    issue_chunk(0);
-                } else {
-                    issued = false;
+                    ep_scale[tc] = ok ? scv : 0.f;
+                    ep_bias[tc] = ok ? bi : 0.f;
                 }
             }
-            const bool dma_q = issued && wave < 4;                       // this wave put DMA requests behind its two ring groups
+            load_u(ur[1]);                                               // group 1 of this chunk (BEFORE the DMA: its wait must not depend on it)
+            // ---- request the next chunk (of this tile, or the first of the next tile).  The next tile is prepared (coordinates, edge
+            // gather map, prologue scales) one chunk EARLY -- right after this tile's last chunk has been requested -- so that the last
+            // chunk only has to issue: the chore waves would otherwise reach the tail thousands of cycles after everybody else.
+            bool issued = true;
+            const bool prep_now = nchunks == 1 ? true : k + 2 == nchunks;
+            if (k + 1 < nchunks) issue_chunk((k + 1) * W4_KC);
+            if (prep_now) {
+                e_n = n; e_oy0 = oy0; e_ox0 = ox0; e_m0 = m0;
+                next = tile + gridDim.x;
+                has_next = next < total;
+                if (has_next) prep_tile(next, cs0 + (par ^ 1) * cin_loop);
+            }
+            if (k + 1 == nchunks) {
+                if (has_next) issue_chunk(0);
+                else issued = false;
+            }
+            const bool dma_q = issued && chore;                          // this wave put DMA requests behind the words of groups 0 and 1
 
-            // ---- GEMM phase: 6 groups of (3 xi) x (4 channel pairs)
-#pragma unroll
-            for (int g = 0; g < 6; g++) {
-                const int jg = g >> 1, quad = g & 1;
-                float b[3][4];
+            // ---- GEMM phase: 4 groups of (3 xi) x (4 channel pairs).  Ring: group g in slot g & 1; requests: group 1 above, group g + 2
+            // after the MFMAs of group g (g = 2: group 0 of the next chunk / tile; g = 3: nothing -- one group crosses the transform phase).
+            const float* vb = V + 6 * ta * 512 + w4_fresh_lane();                // B operand base: V[6a + b][pair][half][l31]
+            // B words are read half a group (3 xi x 2 pairs) ahead of the MFMAs that use them: 6 MFMAs = 384 matrix-pipe cycles cover
+            // the LDS latency, so a wave only ever waits for LDS at the first half group of a chunk.
+            float bw[2][3][2];
+            auto read_b = [&](int hg, float (&dst)[3][2]) {                  // hg = half group 0..7: (jg, quad, pair half)
+                const int jg = hg >> 2, quad = (hg >> 1) & 1, ph = hg & 1;
 #pragma unroll
                 for (int jj = 0; jj < 3; jj++)
 #pragma unroll
-                    for (int s = 0; s < 4; s++) b[jj][s] = vb[(3 * jg + jj) * 512 + (4 * quad + s) * 64];
+                    for (int s = 0; s < 2; s++) dst[jj][s] = vb[(3 * jg + jj) * 512 + (4 * quad + 2 * ph + s) * 64];
+            };
+            read_b(0, bw[0]);
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int jg = g >> 1;
                 wait_u(ur[g & 1], g < 2 && dma_q);
 #pragma unroll
-                for (int s = 0; s < 4; s++)
+                for (int ph = 0; ph < 2; ph++) {
+                    const int hg = 2 * g + ph;
+                    if (hg + 1 < 8) read_b(hg + 1, bw[(hg + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);                       // the reads go out BEFORE this half group's MFMAs
 #pragma unroll
-                    for (int jj = 0; jj < 3; jj++)
-                        acc[3 * jg + jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(ur[g & 1][jj][s], b[jj][s], acc[3 * jg + jj], 0, 0, 0);
-                if (g == 4 && k + 1 == nchunks) a_reset(m0);             // from here on: the next tile's first groups (m0 is already the next tile's)
-                load_u(ur[g & 1]);                                       // refill the slot two groups ahead
+                    for (int s = 0; s < 2; s++)
+#pragma unroll
+                        for (int jj = 0; jj < 3; jj++)
+                            acc[3 * jg + jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(ur[g & 1][jj][2 * ph + s], bw[hg & 1][jj][s], acc[3 * jg + jj], 0, 0, 0);
+                }
+                if (g == 2 && k + 1 == nchunks) a_reset(m0);             // from here on: the next tile's first group (m0 is already the next tile's)
+                if (g < 3) load_u(ur[g & 1]);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if (k == 2) W4_STAMP(4);
             if (!issued) dma_wait_all();                                 // last chunk of the last tile: nothing counted behind us
         }
+        W4_STAMP(5);
 
         // ---- inverse transform + fused epilogue, 16 couts per round through LDS (the V buffer)
 #if WINO4_EXP & 4
         { float sm = 0.f;
-          for (int j = 0; j < 9; j++) for (int k = 0; k < 16; k++) sm += acc[j][k];
-          if (sm == 12345.678f) p.y[t] = sm; }
+          for (int j = 0; j < 6; j++) for (int k = 0; k < 16; k++) sm += acc[j][k];
+          if (sm == 12345.678f) p.y[w4_fresh_lane()] = sm; }
         __syncthreads();
         if (!has_next) break;
         tile = next; par ^= 1;
         continue;
 #endif
+        // Everything the rounds need is read from the kernel-argument segment ONCE here (a scalar load per use inside the rounds --
+        // what re-reading through an opaque pointer turns into -- cost ~4 us per tile: with one workgroup per CU nothing hides it).
         const auto& qa = *fresh_args();
         const bool spade = qa.f.spade_x != nullptr;
         const float gain = qa.f.gain, slope = act_slope(qa.f.act, qa.f.alpha);
         const float cl = qa.f.clamp >= 0.f ? qa.f.clamp : __builtin_inff();
         const bool plain_tail = slope == 1.f && gain == 1.f && qa.f.clamp < 0.f;
-        const bool vec_ok = qa.ys[3] == 1 && ((qa.ys[0] | qa.ys[1] | qa.ys[2] | qa.f.noise_batch_stride) & 3) == 0 && (qa.OW & 3) == 0 &&
-                            ((((uintptr_t)qa.y) | ((uintptr_t)qa.f.noise) | ((uintptr_t)qa.f.residual) | ((uintptr_t)qa.f.spade_x)) & 15) == 0;      // 16-byte row segments everywhere
-        const bool full = vec_ok && e_oy0 + 8 <= qa.OH && e_ox0 + 64 <= qa.OW && e_m0 + 64 <= qa.Cout;      // wave-uniform
-        const int fn = t & 31, ftx = fn >> 1, fty = fn & 1;              // finishing role: tile
-        const int oyb = e_oy0 + 4 * fty, oxb = e_ox0 + 4 * ftx;
-        float* ex = V;
+        const int OHv = qa.OH, OWv = qa.OW, Coutv = qa.Cout;
+        const float ngain = qa.f.noise_gain;
+        // (the host only launches this kernel with 16-byte addressable outputs: unit x stride, strides and OW multiples of 4, aligned bases)
+        const bool full = e_oy0 + 8 <= OHv && e_ox0 + 64 <= OWv && e_m0 + 64 <= Coutv;      // wave-uniform: no predicates needed
+        const bool seg_rows_full = full;
+        // per-image bases (uniform) + 32-bit byte offsets inside the image (the host checks that one image of y stays below 4 GB)
+        const int64_t img_off = (int64_t)e_n * qa.ys[0];
+        float* y_n = qa.y + img_off;
+        const float* res_n = qa.f.residual ? qa.f.residual + img_off : nullptr;
+        const float* spx_n = qa.f.spade_x ? qa.f.spade_x + img_off : nullptr;
+        const float* nz_n = qa.f.noise ? qa.f.noise + (int64_t)e_n * qa.f.noise_batch_stride : nullptr;
+        const unsigned cstride_b = (unsigned)qa.ys[1] * 4u, rstride_b = (unsigned)qa.ys[2] * 4u, nzrow_b = (unsigned)OWv * 4u;
+        f32x4* ex4 = (f32x4*)V;
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
         auto act4 = [&](f32x4 v) {
             if (!plain_tail) {
 #pragma unroll
@@ -336,106 +410,147 @@ __global__ __launch_bounds__(512, 2) void conv2d_wino4(ConvParams p) {
             }
             return v;
         };
-        // one output row segment (4 pixels) of channel `ch` at row oy: load / store with the full-tile fast path or guarded scalars
-        auto load4 = [&](const float* base, int ch, int oy, bool chan_ok) {
-            f32x4 r = {0.f, 0.f, 0.f, 0.f};
-            const int64_t o = (int64_t)e_n * qa.ys[0] + (int64_t)ch * qa.ys[1] + (int64_t)oy * qa.ys[2] + (int64_t)oxb * qa.ys[3];
-            if (full) return *(const f32x4*)(base + o);
-            if (chan_ok && oy < qa.OH) {
-#pragma unroll
-                for (int e = 0; e < 4; e++) if (oxb + e < qa.OW) r[e] = base[o + e * qa.ys[3]];
-            }
-            return r;
+        auto load4 = [&](const float* base, unsigned off_b, bool ok) {
+            return (seg_rows_full || ok) ? *(const f32x4*)((const char*)base + off_b) : zero4;
         };
-        auto store4 = [&](int ch, int oy, f32x4 v, bool chan_ok) {
-            const int64_t o = (int64_t)e_n * qa.ys[0] + (int64_t)ch * qa.ys[1] + (int64_t)oy * qa.ys[2] + (int64_t)oxb * qa.ys[3];
-            if (full) { *(f32x4*)(qa.y + o) = v; return; }
-            if (chan_ok && oy < qa.OH) {
+        auto store4 = [&](unsigned off_b, f32x4 v, bool ok) {
+            if (WINO4_EXP & 16) { if (v[0] == 12345.678f) *(f32x4*)((char*)y_n + off_b) = v; return; }
+            if (seg_rows_full || ok) *(f32x4*)((char*)y_n + off_b) = v;
+        };
+        // Finishing role of a thread in round `rnd`, rebuilt from the lane index where it is used (a handful of VALU instructions; kept
+        // live -- or precomputed for all four rounds, as the compiler prefers -- it costs registers that the rounds do not have):
+        // non-SPADE thread = (cout c16 of 16, tile fn); SPADE thread = (channel c8 of 8, tile fn, row pair rh).
+        struct Role { int t, fn, oyb, rh, c8, col; unsigned ob, nzb; bool cok; };
+        auto role_of = [&](int rnd) {
+            Role g;
+            const int lane = w4_fresh_lane();
+            g.t = 64 * wave + lane;
+            g.fn = g.t & 31;
+            const int ftx = g.fn >> 1, fty = g.fn & 1, c16 = g.t >> 5;
+            g.oyb = e_oy0 + 4 * fty;
+            const int oxb = e_ox0 + 4 * ftx;
+            g.rh = g.t >> 8; g.c8 = c16 & 7;
+            g.col = (c16 >> 3) * 32 + 8 * rnd + (c16 & 7);
+            const int ch = spade ? (e_m0 >> 1) + 8 * rnd + g.c8 : e_m0 + g.col;
+            const bool chan_ok = spade || ch < Coutv;
+            g.cok = chan_ok && oxb < OWv;                               // OW % 4 == 0: a 4-pixel segment is inside or outside as a whole
+            g.ob = (unsigned)g.oyb * rstride_b + (unsigned)oxb * 4u + (unsigned)(chan_ok ? ch : Coutv - 1) * cstride_b + (spade ? (unsigned)(2 * g.rh) * rstride_b : 0u);
+            g.nzb = ((unsigned)g.oyb * (unsigned)OWv + (unsigned)oxb) * 4u;
+            return g;
+        };
+        const bool op_is_noise = !spade && !res_n && nz_n;
+        const bool late_noise = !spade && res_n && nz_n;
+        auto request = [&](int rnd, f32x4 (&dst)[4]) {
 #pragma unroll
-                for (int e = 0; e < 4; e++) if (oxb + e < qa.OW) qa.y[o + e * qa.ys[3]] = v[e];
+            for (int r = 0; r < 4; r++) dst[r] = zero4;
+            if (chore || (WINO4_EXP & 32)) return;
+            const Role g = role_of(rnd);
+            if (spade) {
+#pragma unroll
+                for (int rr = 0; rr < 2; rr++) dst[rr] = load4(spx_n, g.ob + (unsigned)rr * rstride_b, g.cok && g.oyb + 2 * g.rh + rr < OHv);
+            } else if (res_n) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) dst[r] = load4(res_n, g.ob + (unsigned)r * rstride_b, g.cok && g.oyb + r < OHv);
+            } else if (nz_n) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) dst[r] = load4(nz_n, g.nzb + (unsigned)r * nzrow_b, g.cok && g.oyb + r < OHv);
             }
         };
-        auto noise4 = [&](int oy) {
-            f32x4 r = {0.f, 0.f, 0.f, 0.f};
-            if (!qa.f.noise) return r;
-            const float* nzp = qa.f.noise + (int64_t)e_n * qa.f.noise_batch_stride + (int64_t)oy * qa.OW + oxb;
-            if (full) return *(const f32x4*)nzp * qa.f.noise_gain;     // OW % 4 == 0 and oxb % 4 == 0; the noise tensor's base is checked by the host
-            if (oy < qa.OH) {
+        // Column half of the inverse transform (over b) in registers, for all 16 accumulator rows at once: 96 live accumulator registers
+        // become 64 before the rounds start.
+        f32x4 yy[16];
 #pragma unroll
-                for (int e = 0; e < 4; e++) if (oxb + e < qa.OW) r[e] = nzp[e] * qa.f.noise_gain;
-            }
-            return r;
-        };
+        for (int r = 0; r < 16; r++) {
+            float y0, y1, y2, y3;
+            w4_at(acc[0][r], acc[1][r], acc[2][r], acc[3][r], acc[4][r], acc[5][r], y0, y1, y2, y3);
+            yy[r] = (f32x4){y0, y1, y2, y3};
+        }
+        W4_STAMP(6);
+        f32x4 op[4];
+        request(0, op);
 #pragma unroll
         for (int rnd = 0; rnd < 4; rnd++) {
-            // couts 8 rnd + 4 half + i of this wave's M-tile live in accumulator registers 4 rnd + i
+            // couts 8 rnd + 4 half + i of this wave's M-tile come from accumulator registers 4 rnd + i; the four column results of
+            // (a, cout, tile) leave as one 16-byte word.
+            {
+                const int lane = w4_fresh_lane();
+                f32x4* exw = ex4 + (ta * 16 + mt * 8 + 4 * (lane >> 5)) * 32 + (lane & 31);
 #pragma unroll
-            for (int j = 0; j < 9; j++)
-#pragma unroll
-                for (int i = 0; i < 4; i++) ex[(9 * q + j) * 512 + (mt * 8 + 4 * half + i) * 32 + l31] = acc[j][4 * rnd + i];
+                for (int i = 0; i < 4; i++)
+                    if (!(WINO4_EXP & 64) || yy[4 * rnd + i][0] == 12345.678f) exw[i * 32] = yy[4 * rnd + i];
+            }
+            if (rnd == 0) W4_STAMP(7);
             __syncthreads();
+            if (rnd == 0) W4_STAMP(8);
             if (rnd == 0) {
-                // the next tile's first two U groups (requested during the last chunk) must be home before this tile's stores enter
-                // the queue: vmcnt counts stores too, and the counted waits of the next chunk assume only loads behind them
-                asm volatile("s_waitcnt vmcnt(0)" : "+v"(ur[0][0]), "+v"(ur[0][1]), "+v"(ur[0][2]), "+v"(ur[1][0]), "+v"(ur[1][1]), "+v"(ur[1][2]));
+                // the next tile's first U group (requested during the last chunk) must be home before this tile's stores enter the queue:
+                // vmcnt counts stores too, and the counted waits of the next chunk assume only loads behind the ring words
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(ur[0][0]), "+v"(ur[0][1]), "+v"(ur[0][2]));
             }
-            if (!spade) {
-                const int c16 = t >> 5;
-                const int col = (c16 >> 3) * 32 + 8 * rnd + (c16 & 7);   // cout within the 64-block
-                const int co = e_m0 + col;
-                const bool chan_ok = co < qa.Cout;
-                const int coc = chan_ok ? co : qa.Cout - 1;
-                const float esc = ep_scale[col], ebi = ep_bias[col];
-                const float* er = ex + t;                                // ex[xi][c16][fn] = ex[xi * 512 + t]
-                float w[4][6];
+            if (rnd == 0) W4_STAMP(9);
+            if (!chore && !(WINO4_EXP & 32)) {
+                const Role g = role_of(rnd);
+                f32x4 v[4];
+                if (!spade) {
+                    const float esc = ep_scale[g.col], ebi = ep_bias[g.col];
+                    {
+                        f32x4 z[6];
 #pragma unroll
-                for (int b = 0; b < 6; b++)                              // over a, column b at a time (6 live inputs)
-                    w4_at(er[(0 * 6 + b) * 512], er[(1 * 6 + b) * 512], er[(2 * 6 + b) * 512], er[(3 * 6 + b) * 512], er[(4 * 6 + b) * 512], er[(5 * 6 + b) * 512],
-                          w[0][b], w[1][b], w[2][b], w[3][b]);
+                        for (int a = 0; a < 6; a++) z[a] = ex4[(a * 16) * 32 + g.t];   // ex4[a][c16][fn]
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    float y0, y1, y2, y3;
-                    w4_at(w[r][0], w[r][1], w[r][2], w[r][3], w[r][4], w[r][5], y0, y1, y2, y3);
-                    const f32x4 y = {y0, y1, y2, y3};
-                    f32x4 v = y * esc + (noise4(oyb + r) + ebi);
-                    v = act4(v);
-                    if (qa.f.residual) v += load4(qa.f.residual, coc, oyb + r, chan_ok);
-                    store4(coc, oyb + r, v, chan_ok);
-                }
-            } else {
-                // SPADE combine (networks.py:1715-1722): M-tile 0 rows are gamma, M-tile 1 rows beta of the same 32 channels;
-                // thread = (channel c8, tile, row pair rh):  y = (x - mean) * rstd * (1 + gamma) + beta
-                const int rh = t >> 8, c8 = (t >> 5) & 7;                // rh is wave-uniform
-                const int chl = 8 * rnd + c8;
-                const int ch = (e_m0 >> 1) + chl;
-                const float mu = ep_scale[chl], rs = ep_bias[chl];
-                f32x4 gb[2][2];                                          // [gamma | beta][row of the pair]
-#pragma unroll
-                for (int gbi = 0; gbi < 2; gbi++) {
-                    const float* er = ex + (gbi * 8 + c8) * 32 + fn;
-                    float z[6][4];
-#pragma unroll
-                    for (int a = 0; a < 6; a++)                          // over b, row a at a time
-                        w4_at(er[(6 * a + 0) * 512], er[(6 * a + 1) * 512], er[(6 * a + 2) * 512], er[(6 * a + 3) * 512], er[(6 * a + 4) * 512], er[(6 * a + 5) * 512],
-                              z[a][0], z[a][1], z[a][2], z[a][3]);
-#pragma unroll
-                    for (int c = 0; c < 4; c++) {                        // over a: only this thread's two output rows
-                        const float s12 = z[1][c] + z[2][c], d12 = z[1][c] - z[2][c], s34 = z[3][c] + z[4][c], d34 = z[3][c] - z[4][c];
-                        gb[gbi][0][c] = rh ? fmaf(4.f, s34, s12) : z[0][c] + s12 + s34;
-                        gb[gbi][1][c] = rh ? fmaf(8.f, d34, d12) + z[5][c] : fmaf(2.f, d34, d12);
+                        for (int c = 0; c < 4; c++) {                        // row half (over a), one column at a time
+                            float y0, y1, y2, y3;
+                            w4_at(z[0][c], z[1][c], z[2][c], z[3][c], z[4][c], z[5][c], y0, y1, y2, y3);
+                            v[0][c] = y0; v[1][c] = y1; v[2][c] = y2; v[3][c] = y3;
+                        }
                     }
-                }
 #pragma unroll
-                for (int rr = 0; rr < 2; rr++) {
-                    const int oy = oyb + 2 * rh + rr;
-                    const f32x4 x = load4(qa.f.spade_x, ch, oy, true);
-                    f32x4 v = (x - mu) * rs * (gb[0][rr] + 1.f) + gb[1][rr];
-                    v = act4(v);
-                    store4(ch, oy, v, true);
+                    for (int r = 0; r < 4; r++) {
+                        f32x4 nzr = op_is_noise ? op[r] * ngain : zero4;
+                        if (late_noise) nzr = load4(nz_n, g.nzb + (unsigned)r * nzrow_b, g.cok && g.oyb + r < OHv) * ngain;
+                        f32x4 w = v[r] * esc + (nzr + ebi);
+                        w = act4(w);
+                        if (res_n) w += op[r];
+                        v[r] = w;
+                    }
+                    if (rnd < 3) request(rnd + 1, op);                       // before this round's stores
+#pragma unroll
+                    for (int r = 0; r < 4; r++) store4(g.ob + (unsigned)r * rstride_b, v[r], g.cok && g.oyb + r < OHv);
+                } else {
+                    // SPADE combine (networks.py:1715-1722): M-tile 0 rows are gamma, M-tile 1 rows beta of the same 32 channels;
+                    // thread = (channel c8, tile, row pair rh):  y = (x - mean) * rstd * (1 + gamma) + beta
+                    const int chl = 8 * rnd + g.c8, rh = g.rh;
+                    const float mu = ep_scale[chl], rsd = ep_bias[chl];
+                    f32x4 gb[2][2];                                          // [gamma | beta][row of the pair]
+#pragma unroll
+                    for (int gbi = 0; gbi < 2; gbi++) {
+                        f32x4 z[6];
+#pragma unroll
+                        for (int a = 0; a < 6; a++) z[a] = ex4[(a * 16 + gbi * 8 + g.c8) * 32 + g.fn];
+#pragma unroll
+                        for (int c = 0; c < 4; c++) {                        // over a: only this thread's two output rows
+                            const float s12 = z[1][c] + z[2][c], d12 = z[1][c] - z[2][c], s34 = z[3][c] + z[4][c], d34 = z[3][c] - z[4][c];
+                            gb[gbi][0][c] = rh ? fmaf(4.f, s34, s12) : z[0][c] + s12 + s34;
+                            gb[gbi][1][c] = rh ? fmaf(8.f, d34, d12) + z[5][c] : fmaf(2.f, d34, d12);
+                        }
+                    }
+#pragma unroll
+                    for (int rr = 0; rr < 2; rr++) v[rr] = act4((op[rr] - mu) * rsd * (gb[0][rr] + 1.f) + gb[1][rr]);
+                    if (rnd < 3) request(rnd + 1, op);                       // before this round's stores
+#pragma unroll
+                    for (int rr = 0; rr < 2; rr++) store4(g.ob + (unsigned)rr * rstride_b, v[rr], g.cok && g.oyb + 2 * rh + rr < OHv);
                 }
             }
+            if (rnd == 0) W4_STAMP(10);
             __syncthreads();                                             // the exchange area is rewritten by the next round / the next transform
+            W4_STAMP(11 + rnd);
         }
+#if WINO4_EXP & 128
+        if (tiles_done == 1 && blockIdx.x == 0 && (w4_fresh_lane() == 0)) {
+            for (int i = 0; i < 15; i++) ((unsigned*)p.y)[wave * 16 + i] = (unsigned)(stamp[i] - stamp[0]);
+        }
+        tiles_done++;
+#endif
         if (!has_next) break;
         tile = next;
         par ^= 1;
@@ -454,12 +569,19 @@ int launch_wino4_mode(const ConvParams& p0, hipStream_t s) {
     const int cin_loop = ((p.Cin + W4_KC - 1) / W4_KC) * W4_KC;
     const size_t lds = ((size_t)W4_RAW + W4_V + 2 * cin_loop + 256 + 2 * W4_NDMA * 256) * sizeof(float);
     if ((int64_t)36 * cin_loop * p.CoutP * 4 > 0x7fffffffLL) return PG_ERR_TOO_LARGE;      // the U stream uses 32-bit byte offsets
+    {   // the tail addresses one image of y / residual / spade_x with 32-bit byte offsets
+        const int64_t ext = 1 + (int64_t)(p.f.spade_x ? p.Cout / 2 - 1 : p.Cout - 1) * p.ys[1] + (int64_t)(p.OH - 1) * p.ys[2] + (int64_t)(p.OW - 1) * p.ys[3];
+        if (ext * 4 > 0xffffffffLL || (int64_t)p.OH * p.OW * 4 > 0xffffffffLL) return PG_ERR_TOO_LARGE;
+    }
     if (lds > 160 * 1024) return PG_ERR_UNSUPPORTED;
+    // the tail moves 16-byte row segments: unit x stride, every other stride and OW a multiple of 4, 16-byte aligned bases
+    if (p.ys[3] != 1 || ((p.ys[0] | p.ys[1] | p.ys[2] | p.f.noise_batch_stride) & 3) != 0 || (p.OW & 3) != 0 ||
+        ((((uintptr_t)p.y) | ((uintptr_t)p.f.noise) | ((uintptr_t)p.f.residual) | ((uintptr_t)p.f.spade_x)) & 15) != 0) return PG_ERR_UNSUPPORTED;
     const int64_t blocks = tiles < (int64_t)num_cu() ? tiles : (int64_t)num_cu();
     static PerDeviceOnce lds_attr;
     const hipError_t e = lds_attr.run([] { return hipFuncSetAttribute((const void*)conv2d_wino4<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((conv2d_wino4<MODE>), dim3((unsigned)blocks), dim3(512), lds, s, p);
+    hipLaunchKernelGGL((conv2d_wino4<MODE>), dim3((unsigned)blocks), dim3(768), lds, s, p);
     return launch_status();
 }
 

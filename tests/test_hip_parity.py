@@ -368,7 +368,7 @@ def test_conv2d_winograd_rejects_what_it_cannot_do():
     close(y5, F.conv2d(x.double().cpu(), w3.double().cpu(), padding=5), 1e-4, 1e-5)
 
 
-@pytest.mark.parametrize('n,cin,cout,h,w,pad', [(1, 16, 64, 8, 64, 1), (2, 64, 64, 16, 128, 1), (2, 32, 128, 24, 64, 1), (1, 48, 70, 9, 72, 1), (2, 20, 40, 13, 100, 0),
+@pytest.mark.parametrize('n,cin,cout,h,w,pad', [(1, 16, 64, 8, 64, 1), (2, 64, 64, 16, 128, 1), (2, 32, 128, 24, 64, 1), (1, 48, 70, 9, 72, 1), (2, 20, 40, 13, 100, 1),
                                                 (1, 128, 128, 40, 192, 1), (3, 64, 64, 64, 64, 2), (2, 16, 64, 7, 8, 1), (1, 80, 64, 32, 64, 4)])
 def test_conv2d_winograd4_kernel(n, cin, cout, h, w, pad):
     """csrc/conv2d_wino4.h (Winograd F(4x4,3x3), round 3) on full, edge and ragged tiles (heights that are no multiple of 8, widths

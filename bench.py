@@ -13,10 +13,10 @@ its own batch (independent images, no data-path collective: "weak" scaling, SURV
 the barrier and the max-over-ranks of the timed region.  Rank 0 prints ONE JSON line.
 
 Extra objects on that line:
-  roofline     -- dominant kernel = conv2d_wino (Winograd F(2x2,3x3) convolution, csrc/conv2d_wino.h:
-                  the stride-1 3x3 layers, ~65 % of the step): sum of the Winograd-domain GEMM FLOPs
-                  (4/9 of the direct-convolution FLOPs) of its launches in the timed region / sum of
-                  their durations measured with HIP events on the launch stream, vs 157.3 TFLOP/s;
+  roofline     -- dominant kernel = conv2d_wino4 (Winograd F(4x4,3x3) convolution, csrc/conv2d_wino4.h:
+                  the stride-1 3x3 layers with Cin >= 64, ~58 % of the step): sum of the FLOPs it executes
+                  on the matrix pipe (1/4 of the direct-convolution FLOPs) over its launches in the timed region /
+                  sum of their durations measured with HIP events on the launch stream, vs 157.3 TFLOP/s;
                   `traffic` = measured HBM bytes per launch, from the newest committed
                   profiles/rNN_traffic_cfg2.json (rocprofv3 --pmc passes over this same command;
                   PMC counters cannot be read in-process) -- `traffic_source` names the file.
@@ -457,24 +457,34 @@ def main():
     if rank == 0:
         images = args.batch * args.steps * world
         value = images / elapsed
-        # Dominant kernel = the Winograd F(2x2,3x3) convolution (csrc/conv2d_wino.h).  Its matrix work is 16 GEMMs per 2x2 output
-        # tile = 4/9 of the direct convolution's multiply-adds, so the MFMA roofline is priced on THOSE flops (`achieved`);
-        # the direct-convolution-equivalent rate of the same launches is reported next to it (it can exceed the matrix peak).
-        wino = [(fl, e0.elapsed_time(e1) * 1e-3) for geo, fl, e0, e1, _ in timeline if geo[3] == 'winograd']
-        allk = [(fl, e0.elapsed_time(e1) * 1e-3) for geo, fl, e0, e1, _ in timeline]
-        dom = wino if wino else [(fl, tm) for (geo, fl, e0, e1, _b), (_, tm) in zip(timeline, allk) if geo[:3] == (3, 3, 1)]
-        work = 4.0 / 9.0 if wino else 1.0
+        # Dominant kernel = the convolution algorithm with the largest share of the timed region.  The MFMA roofline is priced on the
+        # flops that algorithm EXECUTES on the matrix pipe -- Winograd F(4x4,3x3) (csrc/conv2d_wino4.h): 36 multiplies per 16 outputs =
+        # 1/4 of the direct-convolution count; F(2x2,3x3) (csrc/conv2d_wino.h): 4/9; the direct implicit GEMM: all of it -- and the
+        # direct-convolution-equivalent rate of the same launches is reported next to it (it can exceed the matrix peak).
+        WORK = {'winograd4': 0.25, 'winograd': 4.0 / 9.0, 'direct': 1.0}
+        KERNEL = {'winograd4': 'conv2d_wino4<MODE> (Winograd F(4x4,3x3) stride-1 3x3 convolution, v_mfma_f32_32x32x2_f32)',
+                  'winograd': 'conv2d_wino<MODE,VEC> (Winograd F(2x2,3x3) stride-1 3x3 convolution, v_mfma_f32_32x32x2_f32)',
+                  'direct': 'conv2d_mfma<KH,KW,S,BM,KC,XF> (implicit GEMM, v_mfma_f32_32x32x2_f32)'}
+        by_algo = {}
+        for geo, fl, e0, e1, _ in timeline:
+            by_algo.setdefault(geo[3], []).append((fl, e0.elapsed_time(e1) * 1e-3))
+        allk = [ft for v in by_algo.values() for ft in v]
+        algo = max(by_algo, key=lambda a_: sum(tm for _, tm in by_algo[a_]))
+        dom, work = by_algo[algo], WORK[algo]
         dom_flops, dom_time = sum(f for f, _ in dom), sum(t for _, t in dom)
         achieved = work * dom_flops / dom_time / 1e12 if dom_time > 0 else 0.0
         traffic, traffic_src = committed_traffic('cfg2')
-        roofline = dict(bound='mfma',
-                        kernel=('conv2d_wino<MODE,VEC> (Winograd F(2x2,3x3) stride-1 3x3 convolution, v_mfma_f32_32x32x2_f32)' if wino else
-                                'conv2d_mfma<3,3,1,BM,4,XF> (3x3 stride-1 implicit GEMM, v_mfma_f32_32x32x2_f32)'),
+        roofline = dict(bound='mfma', kernel=KERNEL[algo],
                         achieved=round(achieved, 2), peak=F32_MFMA_PEAK_TFLOPS, unit='TFLOP/s', frac=round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
-                        traffic=traffic, traffic_source=traffic_src, flops_counted=('Winograd-domain GEMM flops = 4/9 of the direct-convolution flops' if wino else 'direct-convolution flops'),
+                        traffic=traffic, traffic_source=traffic_src,
+                        flops_counted=f'flops the kernel executes on the matrix pipe = {work:.4g} x the direct-convolution flops of SURVEY 8d',
                         direct_equivalent_tflops=round(dom_flops / max(dom_time, 1e-12) / 1e12, 2),
                         direct_equivalent_frac=round(dom_flops / max(dom_time, 1e-12) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),    # SURVEY 8d count / peak (> 1: fewer multiplies than counted)
                         launches_per_step=len(dom) // max(args.steps, 1), avg_launch_ms=round(1e3 * dom_time / max(len(dom), 1), 4),
+                        time_frac_of_step=round(dom_time / elapsed, 4),
+                        other_algorithms={a_: dict(launches_per_step=len(v) // max(args.steps, 1), ms_per_step=round(1e3 * sum(t for _, t in v) / args.steps, 3),
+                                                   executed_tflops=round(WORK[a_] * sum(f for f, _ in v) / max(sum(t for _, t in v), 1e-12) / 1e12, 2))
+                                          for a_, v in by_algo.items() if a_ != algo},
                         all_conv_direct_equivalent_tflops=round(sum(f for f, _ in allk) / max(sum(t for _, t in allk), 1e-12) / 1e12, 2),
                         conv_time_frac_of_step=round(sum(t for _, t in allk) / elapsed, 4),
                         end_to_end_direct_equivalent_frac=round(value / world * GFLOP_PER_IMAGE / 1e3 / F32_MFMA_PEAK_TFLOPS, 4))

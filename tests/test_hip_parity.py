@@ -369,7 +369,7 @@ def test_conv2d_winograd_rejects_what_it_cannot_do():
 
 
 @pytest.mark.parametrize('n,cin,cout,h,w,pad', [(1, 16, 64, 8, 64, 1), (2, 64, 64, 16, 128, 1), (2, 32, 128, 24, 64, 1), (1, 48, 70, 9, 72, 1), (2, 20, 40, 13, 100, 1),
-                                                (1, 128, 128, 40, 192, 1), (3, 64, 64, 64, 64, 2), (2, 16, 64, 7, 8, 1), (1, 80, 64, 32, 64, 4)])
+                                                (1, 128, 128, 40, 192, 1), (3, 64, 64, 64, 64, 2), (3, 64, 64, 40, 64, 3), (2, 16, 64, 7, 8, 1), (1, 80, 64, 32, 64, 3), (2, 16, 64, 12, 62, 2)])
 def test_conv2d_winograd4_kernel(n, cin, cout, h, w, pad):
     """csrc/conv2d_wino4.h (Winograd F(4x4,3x3), round 3) on full, edge and ragged tiles (heights that are no multiple of 8, widths
     no multiple of 64, couts no multiple of 64, channel counts no multiple of 16, paddings 0..4): plain against the fp64 convolution;
@@ -383,8 +383,13 @@ def test_conv2d_winograd4_kernel(n, cin, cout, h, w, pad):
     def run(algo, **kw):
         return conv2d_mfma.conv2d_forward(x, conv2d_mfma.pack_weight(wt, winograd=algo), cout, 3, 3, pad=(pad, pad), winograd=algo, **kw)
     ref = F.conv2d(x.double().cpu(), wt.double().cpu(), padding=pad)
-    close(run(2), ref, 0, 1e-4 * scale_of(ref))
     oh, ow = ref.shape[2:]
+    if ow % 4 != 0:                       # the tail moves 16-byte row segments: such a launch is declined (the policy never asks for it)
+        from torch_utils.ops._native import NativeNotCovered
+        with pytest.raises(NativeNotCovered):
+            run(2)
+        return
+    close(run(2), ref, 0, 1e-4 * scale_of(ref))
     kw = dict(in_scale=det_tensor('w4.s', [n, cin]).to(DEV) + 1.5, out_scale=det_tensor('w4.d', [n, cout]).abs().to(DEV) + 0.5, noise=det_tensor('w4.nz', [oh, ow]).to(DEV),
               noise_gain=0.3, bias=det_tensor('w4.b', [cout]).to(DEV), act='lrelu', alpha=0.2, gain=1.4, clamp=2.0, residual=det_tensor('w4.r', [n, cout, oh, ow]).to(DEV))
     a, b = run(0, **kw), run(2, **kw)
@@ -414,6 +419,7 @@ def test_conv2d_winograd4_policy_and_declines():
     assert conv2d_mfma.use_winograd(3, 3, 1, 128, 128, pad=(1, 1), hw=(256, 256)) == 2
     assert conv2d_mfma.use_winograd(3, 3, 1, 128, 128, pad=(1, 1)) == 1                          # no image size: F(2x2)
     assert conv2d_mfma.use_winograd(3, 3, 1, 128, 128, pad=(1, 1), hw=(256, 254)) == 1          # width no multiple of 4
+    assert conv2d_mfma.use_winograd(3, 3, 1, 128, 128, pad=(2, 2), hw=(256, 256)) == 1          # output width 258: no 16-byte row segments
     assert conv2d_mfma.use_winograd(3, 3, 1, 128, 128, pad=(1, 1), hw=(256, 256), xf=True) == 1  # input pre-activation: F(2x2) has the prologue
     assert conv2d_mfma.use_winograd(3, 3, 1, 96, 128, pad=(1, 1), hw=(256, 256)) == 1 and conv2d_mfma.use_winograd(3, 3, 1, 128, 32, pad=(1, 1), hw=(256, 256)) == 1
     assert conv2d_mfma.use_winograd(3, 3, 1, 512, 512, pad=(1, 1), hw=(16, 16)) == 1 and conv2d_mfma.use_winograd(3, 3, 1, 16, 16, hw=(256, 256)) == 0

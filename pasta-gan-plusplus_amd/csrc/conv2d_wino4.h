@@ -37,7 +37,8 @@
 
 #ifndef WINO4_EXP
 #define WINO4_EXP 0      // dev ablations (results wrong by design): 1 no U loads, 2 no transform phase, 4 no tail, 8 no halo DMA, 16 no output stores,
-                         // 32 no finishing (exchange writes and barriers stay), 64 no exchange writes, 128 cycle stamps of workgroup 0's second tile into y[0..]
+                         // 32 no finishing (exchange writes and barriers stay), 64 no exchange writes, 128 cycle stamps of workgroup 0's second tile into y[0..];
+                         // debugging switches that stay correct: 256 chore waves drain their queue at the end of every chunk, 512 every U wait is vmcnt(0)
 #endif
 
 namespace pgconv {
@@ -212,7 +213,9 @@ __global__ __launch_bounds__(768, 3) void conv2d_wino4(ConvParams p) {
     };
     // wait for the three words of one group; `younger` = vector-memory operations issued after them that may still be in flight
     auto wait_u = [&](f32x4 (&g)[3], bool dma_younger) {
-        if (dma_younger) {
+        if (WINO4_EXP & 512) {
+            asm volatile("s_waitcnt vmcnt(0)");
+        } else if (dma_younger) {
             if (cw == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 + W4_NDMA));
             else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 + W4_NDMA - 1));
         } else {
@@ -369,6 +372,7 @@ __global__ __launch_bounds__(768, 3) void conv2d_wino4(ConvParams p) {
             }
             if (k == 2) W4_STAMP(4);
             if (!issued) dma_wait_all();                                 // last chunk of the last tile: nothing counted behind us
+            if ((WINO4_EXP & 256) && chore) dma_wait_all();
         }
         W4_STAMP(5);
 
@@ -468,6 +472,7 @@ __global__ __launch_bounds__(768, 3) void conv2d_wino4(ConvParams p) {
         W4_STAMP(6);
         f32x4 op[4];
         request(0, op);
+        __syncthreads();                                                 // the exchange area IS the V buffer: every wave must be past its last GEMM reads before the first word is written
 #pragma unroll
         for (int rnd = 0; rnd < 4; rnd++) {
             // couts 8 rnd + 4 half + i of this wave's M-tile come from accumulator registers 4 rnd + i; the four column results of

@@ -413,6 +413,27 @@ def test_conv2d_winograd4_kernel(n, cin, cout, h, w, pad):
         close(dx, want, 0, 1e-4 * scale_of(want))
 
 
+@pytest.mark.parametrize('n,h,cin,cout', [(8, 512, 64, 64), (8, 256, 128, 128)])
+def test_conv2d_winograd4_repeated_launches_are_identical(n, h, cin, cout):
+    """Full-size launches of the F(4x4) kernel, 60 in a row with other work in between: every result must equal the first one bit for bit
+    and match the direct kernel.  (Round 3: the tail's exchange area aliases the V buffer; without the barrier in front of its first write a
+    fast wave overwrote operands slower waves were still multiplying -- 20 % of the launches had wrong tiles, none of the small cases did.)"""
+    from torch_utils.ops import conv2d_mfma
+    gen = torch.Generator().manual_seed(31)
+    x = torch.randn([n, cin, h, h], generator=gen).to(DEV)
+    other = torch.randn([n, cin, h, h], generator=gen).to(DEV)
+    wt = (torch.randn([cout, cin, 3, 3], generator=gen) / (3 * math.sqrt(cin))).to(DEV)
+    pk4, pk0 = conv2d_mfma.pack_weight(wt, winograd=2), conv2d_mfma.pack_weight(wt)
+    ref = conv2d_mfma.conv2d_forward(x, pk0, cout, 3, 3, pad=(1, 1))
+    first = conv2d_mfma.conv2d_forward(x, pk4, cout, 3, 3, pad=(1, 1), winograd=2)
+    assert float((first - ref).abs().max()) <= 1e-4 * scale_of(ref)
+    for it in range(60):
+        if it % 3 == 1:
+            conv2d_mfma.conv2d_forward(other, pk0, cout, 3, 3, pad=(1, 1))
+        y = conv2d_mfma.conv2d_forward(x, pk4, cout, 3, 3, pad=(1, 1), winograd=2)
+        assert torch.equal(y, first), f'launch {it} differs from the first one: max |d| {float((y - first).abs().max()):.3e}'
+
+
 def test_conv2d_winograd4_policy_and_declines():
     from torch_utils.ops import conv2d_mfma
     from torch_utils.ops._native import NativeNotCovered

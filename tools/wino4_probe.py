@@ -30,8 +30,8 @@ def run(x, w, cout, pad, algo, **kw):
 
 
 if what in ('check', 'all'):
-    for (N, cin, cout, H, W, pad) in [(1, 16, 64, 8, 64, 1), (2, 64, 64, 16, 128, 1), (2, 32, 128, 24, 64, 1), (1, 48, 70, 9, 72, 1), (2, 20, 40, 13, 100, 1),
-                                      (1, 128, 128, 40, 192, 1), (3, 64, 64, 64, 64, 2), (3, 64, 64, 40, 64, 3), (2, 16, 64, 7, 8, 1)]:
+    for (N, cin, cout, H, W, pad) in [(1, 32, 64, 8, 64, 1), (2, 64, 64, 16, 128, 1), (2, 32, 128, 24, 64, 1), (1, 48, 70, 9, 72, 1), (2, 20, 40, 13, 100, 1),
+                                      (1, 128, 128, 40, 192, 1), (3, 64, 64, 64, 64, 2), (3, 64, 64, 40, 64, 3), (2, 40, 64, 7, 8, 1)]:
         if (W + 2 * pad - 2) % 4 != 0:
             print(f'N{N} cin{cin} cout{cout} {H}x{W} pad{pad}: output width {W + 2 * pad - 2} is no multiple of 4 -> the kernel declines (F(2x2) serves it)')
             continue
@@ -60,7 +60,7 @@ if what in ('check', 'all'):
             print(f'   spade: |F(4x4) - direct| {(outs_[0] - outs_[1]).abs().max().item():.2e}  scale {outs_[0].abs().max().item():.2f}', flush=True)
 
 if what in ('time', 'all'):
-    for (N, H, cin, cout) in [(8, 256, 128, 128), (8, 256, 128, 256), (8, 512, 64, 64), (8, 512, 64, 128), (8, 128, 256, 256), (8, 64, 512, 512), (8, 32, 512, 512)]:
+    for (N, H, cin, cout) in [(8, 256, 128, 128), (8, 256, 128, 256), (8, 512, 64, 64), (8, 512, 64, 128), (8, 128, 256, 256), (8, 64, 512, 512), (8, 32, 512, 512), (8, 16, 512, 512), (8, 8, 512, 512), (16, 256, 128, 128), (16, 512, 64, 64)]:
         x = torch.randn(N, cin, H, H, device=dev)
         w = torch.randn(cout, cin, 3, 3, device=dev) / (3 * cin ** 0.5)
         pk = [conv2d_mfma.pack_weight(w, winograd=a) for a in (0, 1, 2)]

@@ -1100,8 +1100,9 @@ class GeneratorFull_v20(nn.Module):
 
 # ============================================================================
 # Downstream of synthesis in the training step: the two discriminators
-# (image+pose, 6 channels; parsing+pose, 10 channels).  Same ops again; fp16 blocks (num_fp16_res > 0) run their
-# convolutions through PyTorch-ROCm (the MFMA kernel is fp32), bias_act / upfirdn2d stay on the HIP kernels.
+# (image+pose, 6 channels; parsing+pose, 10 channels).  Same ops again; fp16 blocks (num_fp16_res > 0) run their convolutions --
+# forward, input gradients and the R1 double backward -- on the 16-bit MFMA kernel (conv2d_mfma16, channels-last); their weight
+# gradients take aten::convolution_backward; bias_act / upfirdn2d are this package's HIP kernels in every precision.
 
 class DiscriminatorBlock(nn.Module):
     """One resolution of the discriminator (reference networks.py:444-523): [fromrgb] -> conv0 -> conv1 (down 2), with

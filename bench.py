@@ -467,23 +467,24 @@ def main():
                   'direct': 'conv2d_mfma<KH,KW,S,BM,KC,XF> (implicit GEMM, v_mfma_f32_32x32x2_f32)'}
         by_algo = {}
         for geo, fl, e0, e1, _ in timeline:
-            by_algo.setdefault(geo[3], []).append((fl, e0.elapsed_time(e1) * 1e-3))
-        allk = [ft for v in by_algo.values() for ft in v]
-        algo = max(by_algo, key=lambda a_: sum(tm for _, tm in by_algo[a_]))
-        dom, work = by_algo[algo], WORK[algo]
+            by_algo.setdefault(geo[3], []).append((fl, e0.elapsed_time(e1) * 1e-3, _))
+        allk = [ft[:2] for v in by_algo.values() for ft in v]
+        algo = max(by_algo, key=lambda a_: sum(ft[1] for ft in by_algo[a_]))
+        dom, work = [ft[:2] for ft in by_algo[algo]], WORK[algo]
+        dom_bytes = sum(ft[2] for ft in by_algo[algo])
         dom_flops, dom_time = sum(f for f, _ in dom), sum(t for _, t in dom)
         achieved = work * dom_flops / dom_time / 1e12 if dom_time > 0 else 0.0
         traffic, traffic_src = committed_traffic('cfg2')
         roofline = dict(bound='mfma', kernel=KERNEL[algo],
                         achieved=round(achieved, 2), peak=F32_MFMA_PEAK_TFLOPS, unit='TFLOP/s', frac=round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
-                        traffic=traffic, traffic_source=traffic_src,
+                        traffic=traffic, traffic_source=traffic_src, algorithmic_bytes_per_launch=round(dom_bytes / max(len(dom), 1)),
                         flops_counted=f'flops the kernel executes on the matrix pipe = {work:.4g} x the direct-convolution flops of SURVEY 8d',
                         direct_equivalent_tflops=round(dom_flops / max(dom_time, 1e-12) / 1e12, 2),
                         direct_equivalent_frac=round(dom_flops / max(dom_time, 1e-12) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),    # SURVEY 8d count / peak (> 1: fewer multiplies than counted)
                         launches_per_step=len(dom) // max(args.steps, 1), avg_launch_ms=round(1e3 * dom_time / max(len(dom), 1), 4),
                         time_frac_of_step=round(dom_time / elapsed, 4),
-                        other_algorithms={a_: dict(launches_per_step=len(v) // max(args.steps, 1), ms_per_step=round(1e3 * sum(t for _, t in v) / args.steps, 3),
-                                                   executed_tflops=round(WORK[a_] * sum(f for f, _ in v) / max(sum(t for _, t in v), 1e-12) / 1e12, 2))
+                        other_algorithms={a_: dict(launches_per_step=len(v) // max(args.steps, 1), ms_per_step=round(1e3 * sum(ft[1] for ft in v) / args.steps, 3),
+                                                   executed_tflops=round(WORK[a_] * sum(ft[0] for ft in v) / max(sum(ft[1] for ft in v), 1e-12) / 1e12, 2))
                                           for a_, v in by_algo.items() if a_ != algo},
                         all_conv_direct_equivalent_tflops=round(sum(f for f, _ in allk) / max(sum(t for _, t in allk), 1e-12) / 1e12, 2),
                         conv_time_frac_of_step=round(sum(t for _, t in allk) / elapsed, 4),

@@ -115,7 +115,8 @@ def use_winograd(kh, kw, stride, cout, cin=None, x2=None, pad=None, hw=None, xf=
     """Launch policy for 3x3 stride-1 convolutions.  Returns 0 (direct implicit GEMM), 1 (Winograd F(2x2,3x3), csrc/conv2d_wino.h) or
     2 (Winograd F(4x4,3x3), csrc/conv2d_wino4.h) -- truthy = some Winograd kernel, and the value is what `pack_weight(winograd=...)` /
     `conv2d_forward(winograd=...)` take.  F(4x4) needs the image size (`hw`): its 8 x 64-pixel tiles and 16-channel chunks pay on layers
-    with Cin >= 64, Cout a multiple of 64 and images of at least 32 x 64 whose width -- and output width -- is a multiple of 4; `xf` (an input pre-activation
+    with Cin >= 64, Cout a multiple of 64 and images of at least 32 x 32 (measured: 1.6x over F(2x2) at 32^2 although half of every 8 x 64 tile is
+    padding there; slower at 16^2) whose width -- and output width -- is a multiple of 4; `xf` (an input pre-activation
     stage) stays on F(2x2).  PG_CONV_ALGO=direct|winograd|winograd2|winograd4 overrides (A/B measurements): 'winograd2' = never F(4x4),
     'winograd4' = F(4x4) wherever the kernel accepts the launch."""
     if (int(kh), int(kw), int(stride)) != (3, 3, 1) or x2 is not None:
@@ -132,7 +133,7 @@ def use_winograd(kh, kw, stride, cout, cin=None, x2=None, pad=None, hw=None, xf=
         return 1
     if not (int(cout) > 32 and (cin is None or int(cin) >= 16)):
         return 0
-    if f4_possible and cin is not None and int(cin) >= 64 and int(cin) % 16 == 0 and int(cout) % 64 == 0 and int(hw[0]) >= 32 and int(hw[1]) >= 64:
+    if f4_possible and cin is not None and int(cin) >= 64 and int(cin) % 16 == 0 and int(cout) % 64 == 0 and int(hw[0]) >= 32 and int(hw[1]) >= 32:
         return 2
     return 1
 

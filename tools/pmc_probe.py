@@ -1,4 +1,4 @@
-"""Dev tool (GPU box): a handful of launches of the two hottest conv shapes, for rocprofv3 --pmc passes (argv[1] = winograd: that kernel)."""
+"""Dev tool (GPU box): a handful of launches of the two hottest conv shapes, for rocprofv3 --pmc passes (argv[1] = winograd4 | winograd | direct)."""
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'pasta-gan-plusplus_amd'))
@@ -7,7 +7,7 @@ from torch_utils import custom_ops
 custom_ops.verbosity = 'none'
 from torch_utils.ops import conv2d_mfma
 dev = 'cuda'
-wg = len(sys.argv) > 1 and sys.argv[1] == 'winograd'
+wg = {'winograd4': 2, 'winograd': 1}.get(sys.argv[1] if len(sys.argv) > 1 else '', 0)
 for (N, H, cin, cout) in [(8, 256, 128, 128), (8, 512, 64, 64)]:
     x = torch.randn(N, cin, H, H, device=dev)
     w = torch.randn(cout, cin, 3, 3, device=dev) / (3 * cin ** 0.5)

@@ -10,14 +10,14 @@ for set in "GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCL
            "SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INST_CYCLES_VMEM SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS" \
            "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM SQ_INSTS_FLAT SQ_INSTS_GDS"; do
   i=$((i+1))
-  timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/p$i -- python3 $R/tools/pmc_probe.py winograd > $O/p$i.log 2>&1
+  timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/p$i -- python3 $R/tools/pmc_probe.py ${PMC_ALGO:-winograd4} > $O/p$i.log 2>&1
   f=$(find $O/p$i -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && python3 - "$f" "$i" >> $O/summary.txt <<'PY'
 import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 agg = collections.defaultdict(list)
 for r in rows:
-    if 'wino' in r['Kernel_Name']:
+    if 'conv2d_wino' in r['Kernel_Name']:
         agg[(r['Grid_Size'], r['Counter_Name'])].append(float(r['Counter_Value']))
 for (g, c), v in sorted(agg.items()):
     print(f'pass{sys.argv[2]} grid={g} {c} mean={sum(v)/len(v):.1f} n={len(v)}')

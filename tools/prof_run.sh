@@ -5,7 +5,7 @@ python3 $GRAFT_REPO_ROOT/tools/ensure_built.py || exit 1     # plugins are built
 R=$GRAFT_REPO_ROOT; TAG=${1:-cfg2}; shift
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O; rm -rf /tmp/prof_out
-timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_out -- python3 $R/bench.py --no-cpu-baseline --steps 7 --warmup 2 "$@" > $O/bench_under_rocprof.log 2>&1
+timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_out -- python3 $R/bench.py --no-cpu-baseline --no-secondary --steps 7 --warmup 2 "$@" > $O/bench_under_rocprof.log 2>&1
 f=$(find /tmp/prof_out -name "*kernel_stats.csv" | head -1)
 cp "$f" $O/kernel_stats.csv
 t=$(find /tmp/prof_out -name "*kernel_trace.csv" | head -1)

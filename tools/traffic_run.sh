@@ -8,7 +8,7 @@ O=$R/gpurun_out/traffic_$TAG
 mkdir -p $O
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/tr_$c
-  timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/tr_$c -- python3 $R/bench.py --no-cpu-baseline --steps 1 --warmup 1 "$@" > $O/$c.log 2>&1
+  timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/tr_$c -- python3 $R/bench.py --no-cpu-baseline --no-secondary --steps 1 --warmup 1 "$@" > $O/$c.log 2>&1
   f=$(find /tmp/tr_$c -name "*counter_collection.csv" | head -1)
   python3 - "$f" "$O/$c.csv" "$KSUB" <<'PY'
 import csv, sys

@@ -9,6 +9,16 @@ PG_DTYPE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2, torch.float64
 PG_ERRORS = {-1: 'invalid argument', -2: 'unsupported configuration', -3: 'tensor too large for 32-bit kernel indexing'}
 
 
+# Every packed-weight cache of this package keys its entries on (parameter address, parameter version, ..., cache_epoch[0]).  A hipGraph
+# replay of a training phase updates parameters WITHOUT moving their Python-side version counters and a capture must not rely on packs made
+# outside it, so training.training_step bumps the epoch before every capture and after every replay (stale entries then simply miss).
+cache_epoch = [0]
+
+
+def invalidate_packed_weights():
+    cache_epoch[0] += 1
+
+
 class NativeOpError(RuntimeError):
     pass
 

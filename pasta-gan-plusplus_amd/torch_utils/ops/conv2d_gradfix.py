@@ -132,7 +132,7 @@ def _packed(weight, winograd, flip=False, transpose_oi=False):
     double-backward pass of the graph that holds them, and their entries are dropped the moment autograd releases the
     temporary (weakref callback) -- nothing packed outlives its source.  A byte cap bounds the live set."""
     base = weight._base if weight._base is not None else weight
-    key = (weight.data_ptr(), base._version, tuple(weight.shape), tuple(weight.stride()), bool(winograd), bool(flip), bool(transpose_oi))
+    key = (weight.data_ptr(), base._version, tuple(weight.shape), tuple(weight.stride()), int(winograd), bool(flip), bool(transpose_oi), nat.cache_epoch[0])
     entry = _pack_cache.get(key)
     hit = entry[1] if entry is not None and entry[0]() is base else None      # same address + version is not identity: a freed
     if hit is None:                                                           # tensor's block is handed to the next one of its size

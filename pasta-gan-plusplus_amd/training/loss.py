@@ -50,7 +50,10 @@ class StyleGAN2Loss:
         if self.style_mixing_prob > 0:
             cutoff = torch.empty([], dtype=torch.int64, device=ws.device).random_(1, ws.shape[1])
             cutoff = torch.where(torch.rand([], device=ws.device) < self.style_mixing_prob, cutoff, torch.full_like(cutoff, ws.shape[1]))
-            ws[:, cutoff:] = self.G_mapping(torch.randn_like(z), c, skip_w_avg_update=True)[:, cutoff:]
+            # ws[:, cutoff:] = mapping(...)[:, cutoff:] (loss_fullbody.py:90) without reading `cutoff` on the host (a 0-dim tensor used as a slice
+            # bound synchronises, and cannot be captured into a hipGraph): the same selection as a mask
+            mixed = self.G_mapping(torch.randn_like(z), c, skip_w_avg_update=True)
+            ws = torch.where((torch.arange(ws.shape[1], device=ws.device) >= cutoff)[None, :, None], mixed, ws)
         img, finetune_img, pred_parsing = self.G_synthesis(ws, pose_feat, cat_feats, denorm_upper_input, denorm_lower_input,
                                                            denorm_upper_mask, denorm_lower_mask, gt_parsing)
         return img, finetune_img, pred_parsing, ws

@@ -56,7 +56,7 @@ class _PackCache:
         self._store = {}
 
     def get(self, tag, params, build):
-        key = tuple((p.data_ptr(), p._version, p.device) for p in params)
+        key = tuple((p.data_ptr(), p._version, p.device) for p in params) + (nat.cache_epoch[0],)
         hit = self._store.get(tag)
         if hit is None or hit[0] != key:
             hit = (key, build())

@@ -14,8 +14,11 @@ takes no optimizer step -- what the reference's Adam does with all-None gradient
 """
 
 import copy
+import warnings
 
 import torch
+
+from torch_utils.ops import _native as nat
 
 from . import ddp
 
@@ -27,25 +30,33 @@ class Phase:
 
 class TrainingStep:
     def __init__(self, G_parts, D, D_parsing, loss, lr=0.0005, betas=(0.0, 0.99), eps=1e-8, G_reg_interval=4, D_reg_interval=16,
-                 batch_size=32, ema_kimg=10, ema_rampup=None, G_ema_parts=None):
-        """`G_parts`: dict name -> module for G_mapping / G_synthesis / G_const_encoding / G_style_encoding."""
+                 batch_size=32, ema_kimg=10, ema_rampup=None, G_ema_parts=None, graphs=False):
+        """`G_parts`: dict name -> module for G_mapping / G_synthesis / G_const_encoding / G_style_encoding.
+        `graphs` (single process only): every phase -- zero the bucket, forward, backward(s), nan_to_num, Adam step -- is captured into
+        one hipGraph the second time it is due and replayed from then on: the ~9 000 kernel launches of an iteration stop being
+        issued one by one from Python (the GPU idled 23-29 % of an eager step behind the host)."""
         self.G_parts, self.D, self.D_parsing, self.loss = G_parts, D, D_parsing, loss
         self.batch_size, self.ema_kimg, self.ema_rampup = batch_size, ema_kimg, ema_rampup
         self.G_ema_parts = G_ema_parts if G_ema_parts is not None else {k: copy.deepcopy(m).eval().requires_grad_(False) for k, m in G_parts.items()}
         self.all_modules = list(G_parts.values()) + [D, D_parsing]
         for m in self.all_modules:
             m.requires_grad_(False)
+        self.graphs = bool(graphs) and torch.cuda.is_available() and not (torch.distributed.is_available() and torch.distributed.is_initialized()
+                                                                          and torch.distributed.get_world_size() > 1)
+        self._graph = {}                 # phase index -> dict(graph, static rounds) | 'eager' (capture refused) ; filled lazily
+        self._seen = set()               # phase indices that have run once eagerly (first-call work stays out of the graphs)
+        adam_kw = dict(capturable=True) if self.graphs else {}
         self.phases = []
         for name, modules, interval in (('G', list(G_parts.values()), G_reg_interval), ('D', [D], D_reg_interval),
                                         ('D_parsing', [D_parsing], D_reg_interval), ('D_parsing', [D_parsing], D_reg_interval)):
             params = [p for m in modules for p in m.parameters()]
             bucket = ddp.GradBucket(params)
             if interval is None:
-                opt = torch.optim.Adam(params, lr=lr, betas=tuple(betas), eps=eps)
+                opt = torch.optim.Adam(params, lr=lr, betas=tuple(betas), eps=eps, **adam_kw)
                 self.phases.append(Phase(name + 'both', modules, opt, 1, bucket))
             else:
                 ratio = interval / (interval + 1)
-                opt = torch.optim.Adam(params, lr=lr * ratio, betas=tuple(b ** ratio for b in betas), eps=eps)
+                opt = torch.optim.Adam(params, lr=lr * ratio, betas=tuple(b ** ratio for b in betas), eps=eps, **adam_kw)
                 self.phases.append(Phase(name + 'main', modules, opt, 1, bucket))
                 self.phases.append(Phase(name + 'reg', modules, opt, interval, bucket))
         self.cur_nimg = 0
@@ -54,26 +65,71 @@ class TrainingStep:
     def due_phases(self):
         return [ph for ph in self.phases if self.batch_idx % ph.interval == 0]
 
+    def _phase(self, ph, rounds):
+        """One due phase, eagerly: returns nothing; everything it does is GPU work enqueued on the current stream plus Python bookkeeping."""
+        ph.bucket.begin()                                    # zero the flat bucket; every .grad is a view into it
+        for m in ph.modules:
+            m.requires_grad_(True)
+        for r, batch in enumerate(rounds):
+            last = r == len(rounds) - 1
+            self.loss.on_last_backward = ph.bucket.last_round if last else None
+            self.loss.accumulate_gradients(phase=ph.name, sync=last, gain=ph.interval, **batch)
+        self.loss.on_last_backward = None
+        for m in ph.modules:
+            m.requires_grad_(False)
+        if not ph.bucket.finish():                           # nobody produced a gradient: nothing to exchange, nothing to step
+            return
+        torch.nan_to_num(ph.bucket.flat, nan=0, posinf=1e5, neginf=-1e5, out=ph.bucket.flat)
+        ph.opt.step()
+
+    def _phase_graphed(self, idx, ph, rounds):
+        """First time: eager (plugin loading, kernel attributes, MIOpen's solver choice stay out of the graph).  Second time: capture, then
+        replay.  Later: copy the batch into the static buffers, replay."""
+        if idx not in self._seen or self._graph.get(idx) == 'eager':
+            self._seen.add(idx)
+            self._phase(ph, rounds)
+            nat.invalidate_packed_weights()
+            return
+        entry = self._graph.get(idx)
+        if entry is None:
+            static = [{k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in b.items()} for b in rounds]
+            graph = torch.cuda.CUDAGraph()
+            nat.invalidate_packed_weights()                  # no pack made outside the capture may be reused inside it
+            try:
+                torch.cuda.synchronize()
+                with torch.cuda.graph(graph):
+                    self._phase(ph, static)
+            except Exception as e:                           # noqa: BLE001 -- a phase that cannot be captured keeps running eagerly
+                warnings.warn(f'training step: phase {ph.name} is not capturable ({type(e).__name__}: {e}); it stays eager')
+                self._graph[idx] = 'eager'
+                torch.cuda.synchronize()
+                nat.invalidate_packed_weights()
+                self._phase(ph, rounds)
+                nat.invalidate_packed_weights()
+                return
+            entry = self._graph[idx] = dict(graph=graph, static=static)
+        for dst, src in zip(entry['static'], rounds):
+            for k, v in src.items():
+                if isinstance(v, torch.Tensor) and dst[k].data_ptr() != v.data_ptr():
+                    dst[k].copy_(v)
+        entry['graph'].replay()
+        nat.invalidate_packed_weights()                      # the replay moved the weights without moving their version counters
+
+    def graphed_phases(self):
+        return [self.phases[i].name for i, e in sorted(self._graph.items()) if e != 'eager']
+
     def run(self, rounds):
         """`rounds`: this rank's accumulation rounds, each a dict of the tensors accumulate_gradients takes
         (real_img, gen_z, style_input, retain, pose, denorm_*_input, denorm_*_mask, gt_parsing)."""
-        for ph in self.due_phases():
+        for idx, ph in enumerate(self.phases):
+            if self.batch_idx % ph.interval != 0:
+                continue
             if getattr(self.loss, 'phase_is_empty', lambda name: False)(ph.name):
                 continue                                         # statically empty on every rank (Greg): no forward, no exchange, no step
-            ph.bucket.begin()                                    # zero the flat bucket; every .grad is a view into it
-            for m in ph.modules:
-                m.requires_grad_(True)
-            for r, batch in enumerate(rounds):
-                last = r == len(rounds) - 1
-                self.loss.on_last_backward = ph.bucket.last_round if last else None
-                self.loss.accumulate_gradients(phase=ph.name, sync=last, gain=ph.interval, **batch)
-            self.loss.on_last_backward = None
-            for m in ph.modules:
-                m.requires_grad_(False)
-            if not ph.bucket.finish():                           # nobody produced a gradient (Greg): nothing to exchange, nothing to step
-                continue
-            torch.nan_to_num(ph.bucket.flat, nan=0, posinf=1e5, neginf=-1e5, out=ph.bucket.flat)
-            ph.opt.step()
+            if self.graphs:
+                self._phase_graphed(idx, ph, rounds)
+            else:
+                self._phase(ph, rounds)
         self._update_ema()
         self.cur_nimg += self.batch_size
         self.batch_idx += 1

@@ -925,6 +925,44 @@ def test_config4_discriminators_at_real_shape_vs_oracle(phase):
     assert sum(1 for k, v in got.items() if v > 0 and k.startswith('D.' if phase == 'Dboth' else 'G_')) >= 4
 
 
+def test_training_step_graph_replay_equals_eager():
+    """TrainingStep(graphs=True): every phase captured into a hipGraph the second time it is due and replayed afterwards must leave the
+    same weights, Adam statistics and EMA as the eager step (the replay runs the very kernels the eager phase launches; packed-weight
+    caches are invalidated around captures and replays).  Product discriminators (HIP ops, R1 double backward) + stub generator, 6
+    iterations: eager first run, capture, four replays of the every-iteration phases; the lazy-regularisation phases stay eager here."""
+    import stubs
+    from training import networks as PN
+    from training.loss import StyleGAN2Loss
+    from training.training_step import TrainingStep
+    from oracle import network_ref as NR
+
+    def run(graphs):
+        torch.manual_seed(0)
+        nets = stubs.build(DEV)
+        for name, ch in (('D', 6), ('D_parsing', 10)):
+            ref = fill_module_(NR.Discriminator(**_d_kw(ch)), f'tg.{name}.')
+            d = PN.Discriminator(**_d_kw(ch))
+            d.load_state_dict(ref.state_dict(), strict=False)
+            nets[name] = d.to(DEV).train()
+        loss = StyleGAN2Loss(device=torch.device(DEV), **nets, style_mixing_prob=0, r1_gamma=10, l1_weight=50, mask_weight=1.0)
+        G_parts = {k: v for k, v in nets.items() if k.startswith('G_')}
+        step = TrainingStep(G_parts, nets['D'], nets['D_parsing'], loss, batch_size=4, graphs=graphs)
+        b = stubs.batch(4, DEV)
+        for _ in range(6):
+            step.run([b])
+        torch.cuda.synchronize()
+        return step, {f'{k}.{n}': p.detach().clone() for k, m in nets.items() for n, p in m.named_parameters()}
+
+    eager_step, eager = run(False)
+    graph_step, graphed = run(True)
+    assert set(graph_step.graphed_phases()) >= {'Gmain', 'Dmain', 'D_parsingmain'}, graph_step.graphed_phases()
+    assert eager.keys() == graphed.keys()
+    for k in eager:
+        assert torch.allclose(graphed[k], eager[k], rtol=1e-4, atol=1e-6), (k, float((graphed[k] - eager[k]).abs().max()))
+    for a, b in zip(eager_step.G_ema_parts['G_synthesis'].parameters(), graph_step.G_ema_parts['G_synthesis'].parameters()):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-6)
+
+
 @pytest.mark.parametrize('d_fp16_res', [0, 3])
 def test_full_width_training_iteration_smoke(d_fp16_res):
     """One iteration of the 8-phase schedule (all phases due) with the full-width generator and both discriminators at

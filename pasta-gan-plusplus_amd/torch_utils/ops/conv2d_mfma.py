@@ -327,6 +327,18 @@ def transposed_phases(kh, kw, stride, pad_y, pad_x, in_hw, out_hw):
             for py in ys if py is not None for px in xs if px is not None]
 
 
+_tap_indices = {}
+
+
+def _tap_index(taps, device):
+    """Device index tensor of a tap list, made once per (taps, device): indexing with a Python list builds the index on the host and copies
+    it over at every call -- a host-to-device copy, which a hipGraph capture refuses (training.training_step)."""
+    key = (tuple(int(t) for t in taps), str(device))
+    if key not in _tap_indices:
+        _tap_indices[key] = torch.tensor(key[0], dtype=torch.int64, device=device)
+    return _tap_indices[key]
+
+
 def pack_transposed(w_iohw, stride, pad, in_hw, out_hw, scale=1.0):
     """Packed per-phase weights of conv_transpose2d(x, w_iohw, stride, padding=pad) -> list of (phase, packed)."""
     kh, kw = int(w_iohw.shape[2]), int(w_iohw.shape[3])
@@ -337,7 +349,7 @@ def pack_transposed(w_iohw, stride, pad, in_hw, out_hw, scale=1.0):
     for ph in phases:
         if not supported(len(ph['ky']), len(ph['kx']), 1):
             return None
-        sel = w_iohw.detach()[:, :, ph['ky'], :][:, :, :, ph['kx']]
+        sel = w_iohw.detach().index_select(2, _tap_index(ph['ky'], w_iohw.device)).index_select(3, _tap_index(ph['kx'], w_iohw.device))
         out.append((ph, pack_weight(sel, scale=scale, transpose_oi=True)))
     return out
 

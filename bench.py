@@ -281,7 +281,7 @@ def run_train(args, rank, world, dev, dist):
     parts = dict(G_mapping=G.mapping, G_synthesis=G.synthesis, G_const_encoding=G.const_encoding, G_style_encoding=G.style_encoding)
     loss = StyleGAN2Loss(device=dev, **parts, D=D, D_parsing=DP, style_mixing_prob=0.9, r1_gamma=10, l1_weight=50, mask_weight=1.0)
     n = args.batch if args.batch != BATCH_PER_GPU else 4       # batch_gpu 4 (global 32 on 8 GPUs, train.py:174)
-    step = TrainingStep(parts, D, DP, loss, batch_size=n * world, graphs=(world == 1 and not args.no_graph))
+    step = TrainingStep(parts, D, DP, loss, batch_size=n * world, graphs=(world == 1 and args.train_graphs))
     g = torch.Generator(device='cpu').manual_seed(100 + rank)
     u = lambda *s: (torch.rand(*s, generator=g) * 2 - 1).to(dev)
     batch = dict(real_img=u(n, 3, 512, 512), gen_z=torch.zeros([n, 0], device=dev), style_input=u(n, 45, 128, 128), retain=u(n, 6, 512, 512),
@@ -382,7 +382,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=BATCH_PER_GPU, help='images per GPU per step (config 2: 8)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-graph', action='store_true', help='configs 4 and 5: time eager launches instead of hipGraph replays')
+    ap.add_argument('--no-graph', action='store_true', help='config 5: time eager launches instead of hipGraph replays')
+    ap.add_argument('--train-graphs', action='store_true', help='config 4: replay each phase as one hipGraph (TrainingStep(graphs=True)); measured 312 vs 304 ms eager -- the step is GPU-bound')
     ap.add_argument('--d-fp16-res', type=int, default=3, help='config 4: discriminator resolutions in fp16 (train.py:196: 3; 0 = fp32)')
     ap.add_argument('--conv-breakdown', default=None, metavar='CSV', help='also write the per-shape conv launch timeline of the timed steps')
     ap.add_argument('--mode', choices=['synthesis', 'generator', 'train', 'bf16_1024', 'selftest'], default='synthesis',

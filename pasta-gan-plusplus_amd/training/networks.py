@@ -796,10 +796,10 @@ class SynthesisNetworkFull_v18(nn.Module):
         region_256 = _half_nearest(region)
         covered = region_256 & (_half_nearest(denorm_mask) > 0.9)
         hole = (region_256 & ~covered).to(denorm_input.dtype)
-        feat = self.spade_encoder(torch.where(region, denorm_input, denorm_input.new_tensor(-1.0)))
+        feat = self.spade_encoder(torch.where(region, denorm_input, -1.0))
         covered = covered.to(feat.dtype)
         count = covered.sum(dim=(2, 3), keepdim=True)
-        count = torch.where(count > 10, count, count.new_tensor(256.0 * 256.0))
+        count = torch.where(count > 10, count, 256.0 * 256.0)
         mean = (feat * covered).sum(dim=(2, 3), keepdim=True) / count
         return feat * (1 - hole) + mean * hole
 
@@ -834,8 +834,8 @@ class SynthesisNetworkFull_v18(nn.Module):
 
         if _fast_ok(x_256, denorm_upper_input, denorm_lower_input, denorm_upper_mask, denorm_lower_mask) and denorm_upper_mask.dtype == torch.float32:
             # inference route: encoder inputs as in get_spade_feat, then the inpainting + merge of both branches in three launches
-            feat_u = self.spade_encoder(torch.where(upper_mask > 0.9, denorm_upper_input, denorm_upper_input.new_tensor(-1.0)))
-            feat_l = self.spade_encoder(torch.where(lower_mask > 0.9, denorm_lower_input, denorm_lower_input.new_tensor(-1.0)))
+            feat_u = self.spade_encoder(torch.where(upper_mask > 0.9, denorm_upper_input, -1.0))
+            feat_l = self.spade_encoder(torch.where(lower_mask > 0.9, denorm_lower_input, -1.0))
             spade_feat = conv2d_mfma.spade_feat_assemble(feat_u, feat_l, upper_mask, lower_mask, denorm_upper_mask, denorm_lower_mask)
         else:
             spade_feat = (self.get_spade_feat(upper_mask.detach(), denorm_upper_mask, denorm_upper_input) * (_half_nearest(upper_mask) > 0.9)

@@ -14,6 +14,7 @@ takes no optimizer step -- what the reference's Adam does with all-None gradient
 """
 
 import copy
+import os
 import warnings
 
 import torch
@@ -34,7 +35,9 @@ class TrainingStep:
         """`G_parts`: dict name -> module for G_mapping / G_synthesis / G_const_encoding / G_style_encoding.
         `graphs` (single process only): every phase -- zero the bucket, forward, backward(s), nan_to_num, Adam step -- is captured into
         one hipGraph the second time it is due and replayed from then on: the ~9 000 kernel launches of an iteration stop being
-        issued one by one from Python (the GPU idled 23-29 % of an eager step behind the host)."""
+        issued one by one from Python.  Measured (round 3, config 4, one MI355X): 312 ms per iteration replayed vs 304 ms eager -- outside the
+        profiler the eager step is already GPU-bound (the 23-29 % idle seen under rocprofv3 is the profiler's own host cost), so this is an
+        option for hosts slower than the GPU box, off by default."""
         self.G_parts, self.D, self.D_parsing, self.loss = G_parts, D, D_parsing, loss
         self.batch_size, self.ema_kimg, self.ema_rampup = batch_size, ema_kimg, ema_rampup
         self.G_ema_parts = G_ema_parts if G_ema_parts is not None else {k: copy.deepcopy(m).eval().requires_grad_(False) for k, m in G_parts.items()}
@@ -100,7 +103,9 @@ class TrainingStep:
                 with torch.cuda.graph(graph):
                     self._phase(ph, static)
             except Exception as e:                           # noqa: BLE001 -- a phase that cannot be captured keeps running eagerly
-                warnings.warn(f'training step: phase {ph.name} is not capturable ({type(e).__name__}: {e}); it stays eager')
+                import traceback
+                where = ' <- '.join(f'{os.path.basename(f.filename)}:{f.lineno} {f.name}' for f in traceback.extract_tb(e.__traceback__)[-6:][::-1])
+                warnings.warn(f'training step: phase {ph.name} is not capturable ({type(e).__name__}: {str(e).splitlines()[0]}; at {where}); it stays eager')
                 self._graph[idx] = 'eager'
                 torch.cuda.synchronize()
                 nat.invalidate_packed_weights()

@@ -213,3 +213,23 @@ def test_stack_batched_affine_matches_per_layer_affine():
         again = net.all_styles(ws)
         ref = net.b8.conv1.affine(ws[:, 0])
         assert float((ref - again[8][0]).abs().max()) <= 2e-6 * float(ref.abs().max())
+
+
+def test_winograd_launch_policy(monkeypatch):
+    """conv2d_mfma.use_winograd: 0 = direct, 1 = F(2x2,3x3), 2 = F(4x4,3x3) (round 3) -- pure host logic, no plugin needed."""
+    import importlib
+    conv2d_mfma = importlib.import_module('torch_utils.ops.conv2d_mfma')      # (conftest.py puts the package on sys.path)
+    monkeypatch.delenv('PG_CONV_ALGO', raising=False)
+    uw = conv2d_mfma.use_winograd
+    assert uw(3, 3, 1, 128, 128, pad=(1, 1), hw=(256, 256)) == 2 and uw(3, 3, 1, 64, 64, pad=(1, 1), hw=(512, 512)) == 2
+    assert uw(3, 3, 1, 512, 512, pad=(1, 1), hw=(32, 32)) == 2 and uw(3, 3, 1, 512, 512, pad=(1, 1), hw=(16, 16)) == 1
+    assert uw(3, 3, 1, 128, 128, pad=(1, 1)) == 1                                   # no image size given: F(2x2)
+    assert uw(3, 3, 1, 128, 128, pad=(1, 1), hw=(256, 254)) == 1                   # width no multiple of 4
+    assert uw(3, 3, 1, 128, 128, pad=(2, 2), hw=(256, 256)) == 1                   # output width 258
+    assert uw(3, 3, 1, 128, 128, pad=(1, 1), hw=(256, 256), xf=True) == 1          # input pre-activation stage: F(2x2) has the prologue
+    assert uw(3, 3, 1, 96, 128, pad=(1, 1), hw=(256, 256)) == 1 and uw(3, 3, 1, 128, 32, pad=(1, 1), hw=(256, 256)) == 1
+    assert uw(3, 3, 1, 16, 16, hw=(256, 256)) == 0 and uw(3, 3, 2, 128, 128) == 0 and uw(1, 1, 1, 128, 128) == 0 and uw(3, 3, 1, 64, 16, pad=(1, 5)) == 0
+    monkeypatch.setenv('PG_CONV_ALGO', 'winograd2')
+    assert uw(3, 3, 1, 128, 128, pad=(1, 1), hw=(256, 256)) == 1
+    monkeypatch.setenv('PG_CONV_ALGO', 'direct')
+    assert uw(3, 3, 1, 128, 128, pad=(1, 1), hw=(256, 256)) == 0

@@ -121,6 +121,7 @@ __global__ __launch_bounds__(768, 3) void conv2d_wino4(ConvParams p) {
 
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const unsigned smem_b = __builtin_amdgcn_readfirstlane(lds_offset(smem));
+    if (smem_b > 1024u) __builtin_trap();        // ds_write_addtid_b32 bases are 16-bit: the V buffer must start below 64 KB (dynamic LDS is this kernel's only LDS: 0)
     const int HW = p.H * p.W;
     const int total = p.total_tiles;
     const int q8 = total >> 3, r8 = total & 7;

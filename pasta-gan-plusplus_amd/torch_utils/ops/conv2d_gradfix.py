@@ -180,7 +180,9 @@ class _Conv2dMfma(torch.autograd.Function):
             dx = _input_gradient(dy, x.shape, weight, stride, padding, transposed, output_padding)
         want_w = ctx.needs_input_grad[1] and not weight_gradients_disabled
         want_b = has_bias and ctx.needs_input_grad[2]
-        if want_w and native_weight_gradients and stride in (1, 2) and not torch.is_grad_enabled():
+        # (under create_graph the native weight gradient -- a plain tensor -- is only right when nothing upstream could ask for ITS gradient:
+        # neither dy nor x carries a graph; otherwise aten's differentiable convolution_backward builds the higher-order graph)
+        if want_w and native_weight_gradients and stride in (1, 2) and not (torch.is_grad_enabled() and (dy.requires_grad or x.requires_grad)):
             if not transposed:
                 dw = conv2d_mfma.weight_gradient(x, dy, weight.shape, padding, stride=stride)      # a GEMM over pixels (csrc/conv2d_wgrad.hip); None = not covered
             else:

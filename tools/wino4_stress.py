@@ -22,18 +22,32 @@ if EXP:                                                      # a -DWINO4_EXP=<EX
 
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 torch.manual_seed(1)
-for (N, H, cin, cout, mod) in [(8, 512, 64, 64, False), (8, 256, 128, 128, False), (8, 512, 64, 64, True)]:
+CASES = [(8, 512, 64, 64, 'plain'), (8, 256, 128, 128, 'plain'), (8, 512, 64, 64, 'mod'), (8, 256, 128, 256, 'spade'), (8, 256, 128, 128, 'res'),
+         (16, 256, 128, 128, 'plain'), (1, 256, 128, 128, 'plain'), (8, 128, 256, 256, 'mod'), (8, 32, 512, 512, 'mod'), (3, 200, 64, 192, 'res')]
+for (N, H, cin, cout, mode) in CASES:
     x = torch.randn(N, cin, H, H, device='cuda')
     w = torch.randn(cout, cin, 3, 3, device='cuda') / (3 * cin ** 0.5)
-    kw = dict(in_scale=torch.rand(N, cin, device='cuda') + 0.5, out_scale=torch.rand(N, cout, device='cuda') + 0.5, noise=torch.randn(H, H, device='cuda'),
-              bias=torch.randn(cout, device='cuda'), act='lrelu', alpha=0.2, gain=1.4, clamp=256.0) if mod else {}
-    pk4, pk0 = conv2d_mfma.pack_weight(w, winograd=2), conv2d_mfma.pack_weight(w)
+    kw = {}
+    if mode == 'mod':
+        kw = dict(in_scale=torch.rand(N, cin, device='cuda') + 0.5, out_scale=torch.rand(N, cout, device='cuda') + 0.5, noise=torch.randn(H, H, device='cuda'),
+                  bias=torch.randn(cout, device='cuda'), act='lrelu', alpha=0.2, gain=1.4, clamp=256.0)
+    elif mode == 'res':
+        kw = dict(bias=torch.randn(cout, device='cuda'), residual=torch.randn(N, cout, H, H, device='cuda'), act='relu')
+    if mode == 'spade':
+        c = cout // 2
+        sp = (torch.randn(N, c, H, H, device='cuda'), torch.randn(N, c, device='cuda'), torch.rand(N, c, device='cuda') + 0.5)
+        pk4 = conv2d_mfma.pack_spade_gamma_beta(w[:c].contiguous(), w[c:].contiguous(), winograd=2)
+        pk0 = conv2d_mfma.pack_spade_gamma_beta(w[:c].contiguous(), w[c:].contiguous(), winograd=0)
+        kw = dict(spade=sp, act='lrelu', alpha=0.2, gain=1.4, clamp=3.0)
+    else:
+        pk4, pk0 = conv2d_mfma.pack_weight(w, winograd=2), conv2d_mfma.pack_weight(w)
     ref = conv2d_mfma.conv2d_forward(x, pk0, cout, 3, 3, pad=(1, 1), **kw)
     bad, worst = 0, 0.0
     other = torch.randn(N, cin, H, H, device='cuda')
+    wo = conv2d_mfma.pack_weight(torch.randn(64, cin, 3, 3, device='cuda'))
     for it in range(iters):
         if it % 3 == 1:                                      # some other work in between: different cache / clock state
-            conv2d_mfma.conv2d_forward(other, pk0, cout, 3, 3, pad=(1, 1))
+            conv2d_mfma.conv2d_forward(other, wo, 64, 3, 3, pad=(1, 1))
         y = conv2d_mfma.conv2d_forward(x, pk4, cout, 3, 3, pad=(1, 1), winograd=2, **kw)
         e = float((y - ref).abs().max())
         worst = max(worst, e)
@@ -42,4 +56,4 @@ for (N, H, cin, cout, mod) in [(8, 512, 64, 64, False), (8, 256, 128, 128, False
             if bad <= 3:
                 idx = torch.nonzero((y - ref).abs() > 1e-3)
                 print(f'   iteration {it}: max |d| {e:.3e}, {idx.shape[0]} elements off; first {idx[0].tolist()}, last {idx[-1].tolist()}', flush=True)
-    print(f'N{N} {cin}->{cout} {H}x{H}{" mod" if mod else ""}: {bad} bad launches of {iters}; worst |F(4x4) - direct| {worst:.3e}', flush=True)
+    print(f'N{N} {cin}->{cout} {H}x{H} {mode}: {bad} bad launches of {iters}; worst |F(4x4) - direct| {worst:.3e}', flush=True)

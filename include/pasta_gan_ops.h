@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 5
+#define PG_ABI_VERSION 6
 
 enum pg_dtype { PG_F32 = 0, PG_F16 = 1, PG_BF16 = 2, PG_F64 = 3 };
 
@@ -233,10 +233,8 @@ int pg_modconv_prep(const float* w2, const float* styles, float* out, float* s_n
  * networks.py:73-94 around it:
  *   y[n, co, 2 iy + ky, 2 ix + kx] += x[n, ci, iy, ix] * in_scale[n, ci] * w[co, ci, ky, kx];   y *= out_scale[n, co]
  * `packed` = pg_conv2d_pack_weight of the OIHW 3x3 kernel w.  y is [N, Cout, 2H+1, 2W+1] with strides `ystride` (elements; an even row
- * pitch gives 8-byte stores).  Written: every row, columns 0 .. 2W-1.  The last column (ox = 2W) is the 1-D convolution
- * y[.., 2q + a, 2W] = sum_ky w[.., ky, 2] x[.., iy, W-1] of the input's last column, which the caller runs through pg_conv2d_forward
- * (1x2 and 1x1 kernels on that column laid out as a row: torch_utils/ops/conv2d_mfma.py, conv_up2_forward).  in_scale / out_scale may
- * be NULL. */
+ * pitch gives 8-byte stores).  Every element of y is written (since ABI 6; before, the caller computed the last column ox = 2W itself).
+ * in_scale / out_scale may be NULL. */
 int pg_conv2d_up2_forward(const float* x, const float* packed, float* y, int N, int Cin, int H, int W, int Cout,
                           const int64_t ystride[4], const float* in_scale, const float* out_scale, void* stream);
 

@@ -4,9 +4,8 @@
 /* y[n, co, 2 iy + ky, 2 ix + kx] += x[n, ci, iy, ix] * in_scale[n, ci] * w[co, ci, ky, kx], then * out_scale[n, co]:
  * conv_transpose2d(stride 2, padding 0) of a 3x3 kernel (conv2d_gradfix.py:46-53 behind conv2d_resample.py:125-142) with the
  * modulation / demodulation of networks.py:73-94 around it.  `packed` = pg_conv2d_pack_weight of the OIHW kernel w (3x3).
- * y is [N, Cout, 2H+1, 2W+1] with strides ystride (elements); an even row pitch gives 8-byte stores.  Written: every row, columns
- * 0 .. 2W-1; the last column (ox = 2W) is y[.., 2q + a, 2W] = sum_ky w[.., ky, 2] x[.., iy, W-1] -- a 1-D convolution of the input's
- * last column that the caller runs through pg_conv2d_forward (torch_utils/ops/conv2d_mfma.py: conv_up2_forward). */
+ * y is [N, Cout, 2H+1, 2W+1] with strides ystride (elements); an even row pitch gives 8-byte stores.  Every element of y is written
+ * (the last column ox = 2W by the edge tiles of the same launch, conv2d_up2.h). */
 PG_EXPORT int pg_conv2d_up2_forward(const float* x, const float* packed, float* y, int N, int Cin, int H, int W, int Cout,
                                     const int64_t ystride[4], const float* in_scale, const float* out_scale, void* stream) {
     if (!x || !packed || !y || !ystride || N <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return PG_ERR_INVALID_ARG;

@@ -18,8 +18,12 @@
 //   * epilogue: * out_scale[n, co] (demodulation); a lane holds both x-parities of a position, i.e. two ADJACENT output pixels:
 //     8-byte stores when the output row pitch is even (the host allocates the (2H+1) x (2W+1) result with a padded pitch);
 //   * the tiles cover the positions q <= H, r < W, i.e. every output row and the columns 0 .. 2W-1: a 33rd position column would
-//     cost a whole extra 32-wide tile column (half of all tiles at W = 32).  The last output column (ox = 2W: tap column kx = 2 of
-//     the input column W - 1) is a thin 1-D convolution the host runs through pg_conv2d_forward on that column laid out as a row.
+//     cost a whole extra 32-wide tile column (half of all tiles at W = 32).  The last output column (ox = 2W: position r = W, whose
+//     only non-zero samples are x[q, W-1] and x[q-1, W-1], i.e. taps 2, 8 of parity (0,0) and tap 5 of parity (1,0)) is covered by EDGE
+//     tiles in the same launch: 32 couts x 256 positions DOWN that column (the 32 MFMA columns of a wave are 32 consecutive q),
+//     3 instead of 18 MFMAs per channel pair and position row, staging the input column W-1 only.  They run as a short pass BEFORE
+//     the tile stream, one per workgroup from the END of the grid -- the workgroups the static tile stream gives one tile less.
+//     (Until round 3 the host ran this column as two thin launches of the tiled kernel on a side stream: 0.3-0.7 ms of residency each.)
 // Roofline: MFMA; algorithmic FLOPs 2 * N * Cout * Cin * 9 * H * W (+ the one-position border).
 #pragma once
 #include "conv2d_kernel.h"
@@ -45,7 +49,9 @@ struct Up2Params {
     int N, Cin, H, W, Cout, CoutP;
     int64_t ys[4];
     int tilesX, tilesY, mblocks, total_tiles;
+    int etilesY, edge_tiles;                    // edge tiles of the last output column: N x etilesY x mblocks
 };
+constexpr int U_EQ = 256, U_EPLANE = U_EQ + 1;  // positions per edge tile; staged samples per channel (rows q0-1 .. q0+255 of column W-1)
 
 template <bool MOD, int TRW>
 __global__ __launch_bounds__(256, 2) void conv2d_up2(Up2Params p) {
@@ -111,6 +117,79 @@ __global__ __launch_bounds__(256, 2) void conv2d_up2(Up2Params p) {
             dma_dwordx4(wb + (int64_t)row * p.CoutP + col, ws_b + 4096u * i);
         }
     };
+
+    // ---- edge pass: the last output column (see the header comment).  Plain double-buffered chunk loop, no cross-tile pipelining.
+    static_assert(U_KC * U_EPLANE <= U_XPT * 256, "edge column larger than the staging buffer");
+    for (int et = (int)gridDim.x - 1 - (int)blockIdx.x; et < p.edge_tiles; et += gridDim.x) {
+        int L = et;
+        const int mb = L % p.mblocks; L /= p.mblocks;
+        const int ty = L % p.etilesY;
+        n = L / p.etilesY; q0 = ty * U_EQ; m0 = mb * U_BM;
+        if (MOD)
+            for (int c = t; c < cin_loop; c += 256) cs0[c] = c < p.Cin ? ld_opaque(p.in_scale + (int64_t)n * p.Cin + c) : 1.f;
+        if (t < U_BM) {
+            const int co = m0 + t;
+            ep0[t] = co < p.Cout ? (p.out_scale ? ld_opaque(p.out_scale + (int64_t)n * p.Cout + co) : 1.f) : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < U_XPT; i++) {
+            const int e = t + 256 * i;
+            const int c = e / U_EPLANE, gy = q0 - 1 + e % U_EPLANE;
+            const bool ok = e < U_KC * U_EPLANE && gy >= 0 && gy < p.H;
+            xoff[i] = ok ? (unsigned)(c * HW + gy * p.W + p.W - 1) * 4u : 0x80000000u;
+        }
+        const uint64_t base = (uint64_t)(uintptr_t)(p.x + (int64_t)n * p.Cin * HW);
+        xrsrc[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)base);
+        xrsrc[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(base >> 32) & 0xffff);
+        xrsrc[2] = p.Cin * HW * 4;
+        xrsrc[3] = 0x00020000;
+        issue_chunk(0, 0);
+        f32x16 ea[2][2];                             // [output row parity a][position row of the wave]
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+                for (int k = 0; k < 16; k++) ea[a][nt][k] = 0.f;
+        for (int k = 0; k < nchunks; k++) {
+            const int buf = k & 1;
+            dma_wait_all();
+            __syncthreads();
+            if (k + 1 < nchunks) issue_chunk((k + 1) * U_KC, buf ^ 1);
+#pragma unroll
+            for (int cp = 0; cp < U_KC / 2; cp++) {
+                const float* ab = smem + buf * U_LDS_BUF + U_LDS_X + ((2 * cp + half) * 9) * U_BM + l31;
+                const float* bb = smem + buf * U_LDS_BUF + (2 * cp + half) * U_EPLANE + (2 * wave) * 32 + l31;
+                const float a2 = ab[2 * U_BM], a5 = ab[5 * U_BM], a8 = ab[8 * U_BM];
+                const float sc = MOD ? cs0[k * U_KC + 2 * cp + half] : 1.f;
+#pragma unroll
+                for (int nt = 0; nt < 2; nt++) {
+                    const float xm = MOD ? bb[nt * 32] * sc : bb[nt * 32], x0 = MOD ? bb[nt * 32 + 1] * sc : bb[nt * 32 + 1];      // x[q - 1, W - 1], x[q, W - 1]
+                    ea[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, x0, ea[0][nt], 0, 0, 0);
+                    ea[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a8, xm, ea[0][nt], 0, 0, 0);
+                    ea[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a5, x0, ea[1][nt], 0, 0, 0);
+                }
+            }
+        }
+        // D col = lane & 31 = position q, row = cout (as below): output rows 2q and 2q + 1 of column 2W
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++) {
+            const int q = q0 + (2 * wave + nt) * 32 + l31;
+#pragma unroll
+            for (int a = 0; a < 2; a++) {
+                const bool row_ok = a == 0 ? q <= p.H : q < p.H;
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    const int rowc = (k & 3) + 8 * (k >> 2) + 4 * half;
+                    const int co = m0 + rowc;
+                    if (row_ok && co < p.Cout)
+                        p.y[(int64_t)n * p.ys[0] + (int64_t)co * p.ys[1] + (int64_t)(2 * q + a) * p.ys[2] + (int64_t)(2 * p.W) * p.ys[3]] = ea[a][nt][k] * ep0[rowc];
+                }
+            }
+        }
+        __syncthreads();                             // the staging buffers and scales are rewritten next
+    }
+    if ((int)blockIdx.x >= p.total_tiles) return;    // a workgroup launched for an edge tile only
 
     f32x16 acc[4][2];                                // [parity 2a + b][position row of the wave]
 
@@ -238,14 +317,17 @@ int launch_up2_t(const Up2Params& p0, hipStream_t s) {
     p.tilesY = (p.H + 1 + G::TQ - 1) / G::TQ;
     p.mblocks = p.CoutP / U_BM;
     const int64_t tiles = (int64_t)p.N * p.tilesX * p.tilesY * p.mblocks;
-    if (tiles > 0x7fffffffLL) return PG_ERR_TOO_LARGE;
+    p.etilesY = (p.H + 1 + U_EQ - 1) / U_EQ;
+    const int64_t etiles = (int64_t)p.N * p.etilesY * p.mblocks;
+    if (tiles + etiles > 0x7fffffffLL) return PG_ERR_TOO_LARGE;
     p.total_tiles = (int)tiles;
+    p.edge_tiles = (int)etiles;
     const int cin_loop = ((p.Cin + U_KC - 1) / U_KC) * U_KC;
     const size_t lds = ((size_t)2 * U_LDS_BUF + 2 * cin_loop + 2 * U_BM) * sizeof(float);
     if (lds > 160 * 1024) return PG_ERR_UNSUPPORTED;
     int per_cu = (int)((160 * 1024) / lds);
     if (per_cu > 2) per_cu = 2;                             // ~230 VGPRs x 4 waves per workgroup
-    const int64_t blocks = tiles < (int64_t)num_cu() * per_cu ? tiles : (int64_t)num_cu() * per_cu;
+    const int64_t blocks = tiles + etiles < (int64_t)num_cu() * per_cu ? tiles + etiles : (int64_t)num_cu() * per_cu;
     if (p.in_scale) {
         static PerDeviceOnce a1;
         const hipError_t e = a1.run([] { return hipFuncSetAttribute((const void*)conv2d_up2<true, TRW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });

@@ -46,7 +46,7 @@ PLUGIN_SOURCES = {
                       'conv2d16_inst_k1x2.hip', 'conv2d16_inst_k3s2.hip'],
 }
 
-ABI_VERSION = 5      # == PG_ABI_VERSION of include/pasta_gan_ops.h; bumped with every struct / signature change
+ABI_VERSION = 6      # == PG_ABI_VERSION of include/pasta_gan_ops.h; bumped with every struct / signature change
 
 _cached_plugins = dict()
 

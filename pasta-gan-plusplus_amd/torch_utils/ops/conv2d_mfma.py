@@ -388,32 +388,18 @@ def weight_gradient(x, dy, weight_shape, pad, stride=1):
     return dw
 
 
-_side_streams = {}
-
-
-def _side_stream(device):
-    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
-    if key not in _side_streams:
-        _side_streams[key] = torch.cuda.Stream(device=device)
-    return _side_streams[key]
-
-
 def pack_up2(weight, flip=False):
-    """Packed weights of `conv_up2_forward` for the OIHW 3x3 kernel w = `weight` (flipped spatially iff `flip`): the 3x3 pack for
-    the four-parity kernel and the two thin packs of the last output column (tap column kx = 2)."""
+    """Packed weights of `conv_up2_forward` for the OIHW 3x3 kernel w = `weight` (flipped spatially iff `flip`): the plain 3x3 pack."""
     w = weight.detach().float()
     if flip:
         w = w.flip([2, 3])
-    col_even = torch.stack([w[:, :, 2, 2], w[:, :, 0, 2]], dim=-1).unsqueeze(2).contiguous()       # [Cout, Cin, 1, 2]: out[q] = k0 x[q-1] + k1 x[q]
-    col_odd = w[:, :, 1:2, 2:3].contiguous()                                                       # [Cout, Cin, 1, 1]
-    return dict(main=pack_weight(w.contiguous()), col_even=pack_weight(col_even), col_odd=pack_weight(col_odd))
+    return dict(main=pack_weight(w.contiguous()))
 
 
 def conv_up2_forward(x, packs, cout, in_scale=None, out_scale=None):
-    """conv_transpose2d(x * in_scale, w, stride=2, padding=0) * out_scale for a 3x3 kernel: all four output parities in one launch
-    (csrc/conv2d_up2.h) + the last output column as two thin launches of the tiled kernel on the input's last column laid out as a
-    row.  `packs` = pack_up2(w).  Returns a [N, Cout, 2H+1, 2W+1] view whose rows are padded to a multiple of 4 floats (aligned
-    pair stores here, aligned rows for the FIR pass that follows)."""
+    """conv_transpose2d(x * in_scale, w, stride=2, padding=0) * out_scale for a 3x3 kernel: all four output parities and the last
+    output column in one launch (csrc/conv2d_up2.h).  `packs` = pack_up2(w).  Returns a [N, Cout, 2H+1, 2W+1] view whose rows are
+    padded to a multiple of 4 floats (aligned pair stores here, aligned rows for the FIR pass that follows)."""
     lib = _init().lib
     x = _f32c(x, 'x')
     n, cin, h, w = x.shape
@@ -423,16 +409,6 @@ def conv_up2_forward(x, packs, cout, in_scale=None, out_scale=None):
     y = buf[:, :, :, :ow]
     s_in = _f32c(in_scale, 'in_scale') if in_scale is not None else None
     s_out = _f32c(out_scale, 'out_scale') if out_scale is not None else None
-    # Last column ox = 2W: y[2q + a, 2W] = sum_ky w[ky, 2] x[iy, W-1] -- the input column as a [N, Cin, 1, H] row image, outputs strided
-    # by 2 rows.  Two tiny, latency-bound launches: they run on a side stream BESIDE the main kernel (disjoint outputs), joined before
-    # the caller's next kernel.
-    main, side = torch.cuda.current_stream(x.device), _side_stream(x.device)
-    side.wait_stream(main)
-    with torch.cuda.stream(side):
-        xcol = x[:, :, :, w - 1].reshape(n, cin, 1, h).contiguous()
-        ycol = buf[:, :, :, 2 * w].unsqueeze(2)                                  # [N, Cout, 1, 2H+1], element stride = one output row
-        conv2d_forward(xcol, packs['col_even'], cout, 1, 2, pad=(0, 1), out_hw=(1, h + 1), y=ycol, out_step=(1, 2), out_off=(0, 0), in_scale=s_in, out_scale=s_out)
-        conv2d_forward(xcol, packs['col_odd'], cout, 1, 1, pad=(0, 0), out_hw=(1, h), y=ycol, out_step=(1, 2), out_off=(0, 1), in_scale=s_in, out_scale=s_out)
     tl = _timeline
     with torch.cuda.device(x.device):
         if tl is not None:
@@ -444,7 +420,6 @@ def conv_up2_forward(x, packs, cout, in_scale=None, out_scale=None):
             ev1.record()
             tl.append(((3, 3, 2, 'direct', f'N{n} {cin}->{cout} {h}x{w} up2' + (' mod' if in_scale is not None else '')), 2.0 * n * cout * cin * 9 * h * w, ev0, ev1,
                        4 * (x.numel() + n * cout * oh * ow)))
-    main.wait_stream(side)
     nat.check(st, 'pg_conv2d_up2_forward')
     return y
 

@@ -144,6 +144,167 @@ __global__ __launch_bounds__(512, 1) void conv1x1_stream(ConvParams p) {
     }
 }
 
+// ---- Ring form (round 3): the same mapping, (MT 2, E 4), for Cout = 64 exactly, Cin % 32 == 0, whole 1024-pixel tile rows, no residual.
+// The plain-C++ prefetch of conv1x1_stream above does not prefetch: `cur = nxt` copies registers whose loads are in flight, so hipcc
+// puts `s_waitcnt vmcnt(0)` between the loads of group g + 1 and the MFMAs of group g (found in the assembly) and every group exposes a
+// full memory round trip with two waves per SIMD to cover it: 3.9 TB/s.  Here the input words are inline-asm loads into a RING of four
+// groups (4 channel pairs x 16 bytes each), requested THREE groups (12 KB per wave, 96 KB per CU) ahead with hand-counted vmcnt, and the
+// request stream runs across tile boundaries: the first three groups of the next tile are in flight while this tile's 32 stores issue.
+// vmcnt returns loads and stores in issue order, so the wait for group g counts what is younger than its four loads: the three groups
+// behind it (12) and, for the first three groups after an epilogue, that epilogue's 32 stores (44).  Every store of the epilogue is
+// unconditional (Cout = 64, full tiles) -- the count is exact; anything else the compiler issues in between (the weight reload at an
+// image change) only makes a wait conservative.
+constexpr int S1_RING = 4, S1_AHEAD = 3, S1_GRP = 4;
+__global__ __launch_bounds__(512, 1) void conv1x1_stream_ring(ConvParams p) {
+    constexpr int BM = 64, E = 4, WPIX = 32 * E, WAVES = 8, GRP = S1_GRP;
+    extern __shared__ __attribute__((aligned(16))) float smem[];           // ws[Cin][BM], then ep_scale[BM], ep_bias[BM]
+    float* ws = smem;
+    float* ep_scale = smem + p.Cin * BM;
+    float* ep_bias = ep_scale + BM;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int HW = p.H * p.W;                                              // (host: Cin * HW * 4 < 2^31)
+    const int ptiles = HW / (WPIX * WAVES);
+    const int split = p.f.x2 ? p.f.cin_split : p.Cin;
+    const int ngroups = p.Cin / (2 * GRP);
+    const float gain = p.f.gain, slope = act_slope(p.f.act, p.f.alpha);
+    const float cl = p.f.clamp >= 0.f ? p.f.clamp : __builtin_inff();
+    const bool plain_tail = slope == 1.f && gain == 1.f && p.f.clamp < 0.f;
+
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    f32x4v ring[S1_RING][GRP];
+
+    // where a tile's input lives: per-image bases (uniform) + this lane's byte offset (its 4 pixels, its channel of a pair)
+    struct Src { const float* b1; const float* b2; unsigned voff; };
+    auto src_of = [&](int tile) {
+        const int pt = tile % ptiles, n = (tile / ptiles) / p.mblocks;
+        Src s;
+        s.b1 = p.x + (int64_t)n * split * HW;
+        s.b2 = p.f.x2 ? p.f.x2 + (int64_t)n * (p.Cin - split) * HW : s.b1;
+        s.voff = (unsigned)(((pt * WAVES + wave) * WPIX + E * l31) + half * HW) * 4u;
+        return s;
+    };
+    auto request = [&](int slot, const Src& s, int g) __attribute__((always_inline)) {
+        const int c0 = 2 * GRP * g;                                        // first channel of the group; split % 8 == 0: one source per group
+        const float* base = c0 < split ? s.b1 : s.b2;
+        const unsigned goff = (unsigned)((c0 < split ? c0 : c0 - split) * HW) * 4u;
+#pragma unroll
+        for (int u = 0; u < GRP; u++) {
+            const unsigned off = s.voff + goff + (unsigned)(2 * u * HW) * 4u;
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(ring[slot][u]) : "v"(off), "s"(base) : "memory");
+        }
+    };
+
+    const int per = (p.total_tiles + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int t_begin = (int)blockIdx.x * per, t_end = min(p.total_tiles, t_begin + per);
+    if (t_begin >= t_end) return;
+    Src cur = src_of(t_begin);
+#pragma unroll
+    for (int g = 0; g < S1_AHEAD; g++) request(g, cur, g);                 // (Cin >= 32: ngroups >= 4 > S1_AHEAD)
+    int cur_key = -1;
+    bool after_store = false;
+    for (int tile = t_begin; tile < t_end; tile++) {
+        const int key = tile / ptiles;
+        const int mb = key % p.mblocks, n = key / p.mblocks;
+        const int m0 = mb * BM;
+        const int pt = tile % ptiles;
+        const Src nxt = tile + 1 < t_end ? src_of(tile + 1) : cur;        // past the end: re-request this tile (keeps the counts static)
+        if (key != cur_key) {
+            __syncthreads();                                               // every wave is done with the previous weights
+            for (int e = t; e < p.Cin * BM; e += 512) {
+                const int ci = e / BM, co = e % BM;
+                float v = p.wp[(int64_t)ci * p.CoutP + m0 + co];
+                if (p.f.in_scale) v *= p.f.in_scale[(int64_t)n * p.Cin + ci];
+                ws[e] = v;
+            }
+            if (t < BM) {
+                const int co = m0 + t;
+                ep_scale[t] = p.f.out_scale ? p.f.out_scale[(int64_t)n * p.Cout + co] : 1.f;
+                ep_bias[t] = p.f.bias ? p.f.bias[co] : 0.f;
+            }
+            __syncthreads();
+            cur_key = key;
+        }
+        f32x16 acc[2][E];
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+            for (int e = 0; e < E; e++)
+#pragma unroll
+                for (int k = 0; k < 16; k++) acc[mt][e][k] = 0.f;
+
+        for (int j = 0; j < ngroups; j += S1_RING) {
+#pragma unroll
+            for (int s = 0; s < S1_RING; s++) {
+                const int g = j + s, gp = g + S1_AHEAD;
+                if (gp < ngroups) request((s + S1_AHEAD) % S1_RING, cur, gp);
+                else request((s + S1_AHEAD) % S1_RING, nxt, gp - ngroups);
+                if (s < S1_AHEAD && j == 0 && after_store)
+                    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(ring[s][0]), "+v"(ring[s][1]), "+v"(ring[s][2]), "+v"(ring[s][3]) : "n"(S1_AHEAD * GRP + 32) : "memory");
+                else
+                    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(ring[s][0]), "+v"(ring[s][1]), "+v"(ring[s][2]), "+v"(ring[s][3]) : "n"(S1_AHEAD * GRP) : "memory");
+#pragma unroll
+                for (int u = 0; u < GRP; u++) {
+                    const float* wr = ws + (2 * (GRP * g + u) + half) * BM + l31;
+                    const float a0 = wr[0], a1 = wr[32];
+#pragma unroll
+                    for (int e = 0; e < E; e++) acc[0][e] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, ring[s][u][e], acc[0][e], 0, 0, 0);
+#pragma unroll
+                    for (int e = 0; e < E; e++) acc[1][e] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, ring[s][u][e], acc[1][e], 0, 0, 0);
+                }
+            }
+        }
+
+        // ---- epilogue: exactly 32 unconditional 16-byte stores (the vmcnt(44) above counts them)
+        float* yb = p.y + (int64_t)n * p.ys[0] + ((pt * WAVES + wave) * WPIX + E * l31);
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const int row = mt * 32 + (k & 3) + 8 * (k >> 2) + 4 * half;
+                const float sc = ep_scale[row], bi = ep_bias[row];
+                f32x4v v;
+#pragma unroll
+                for (int e = 0; e < E; e++) {
+                    float r = fmaf(acc[mt][e][k], sc, bi);
+                    if (!plain_tail) { r = r > 0.f ? r : r * slope; r = fminf(fmaxf(r * gain, -cl), cl); }
+                    v[e] = r;
+                }
+                float* dst = yb + (int64_t)(m0 + row) * p.ys[1];
+                asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(dst), "v"(v) : "memory");
+            }
+        after_store = true;
+        cur = nxt;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // the three groups requested past the end
+}
+
+inline bool s1x1_ring_ok(const ConvParams& p) {
+    const int64_t HW = (int64_t)p.H * p.W;
+    if (p.Cout != 64 || p.CoutP != 64 || p.Cin % 32 != 0 || p.Cin < 32 || HW % 1024 != 0 || p.f.residual) return false;
+    if (p.f.x2 && (p.f.cin_split % 8 != 0 || p.f.cin_split <= 0 || p.f.cin_split >= p.Cin)) return false;
+    if ((int64_t)p.Cin * HW * 4 > 0x7fffffffLL) return false;              // 32-bit lane offsets within one image
+    return (size_t)(p.Cin + 2) * 64 * 4 <= 150 * 1024;
+}
+
+inline int launch_s1x1_ring(const ConvParams& p0, hipStream_t s) {
+    ConvParams p = p0;
+    const int64_t HW = (int64_t)p.H * p.W;
+    const int64_t ptiles = HW / 1024;
+    p.mblocks = 1;
+    const int64_t tiles = ptiles * p.N;
+    if (tiles > 0x7fffffffLL) return PG_ERR_TOO_LARGE;
+    p.total_tiles = (int)tiles;
+    const size_t lds = (size_t)(p.Cin + 2) * 64 * sizeof(float);
+    static PerDeviceOnce attr;
+    const hipError_t e = attr.run([] { return hipFuncSetAttribute((const void*)conv1x1_stream_ring, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+    if (e != hipSuccess) return (int)e;
+    const int64_t blocks = tiles < (int64_t)num_cu() ? tiles : (int64_t)num_cu();
+    hipLaunchKernelGGL(conv1x1_stream_ring, dim3((unsigned)blocks), dim3(512), lds, s, p);
+    return launch_status();
+}
+
 // True if the streaming kernel takes this launch (else the caller uses the tiled kernel).
 inline bool s1x1_ok(const ConvParams& p) {
     const int64_t HW = (int64_t)p.H * p.W;

@@ -1368,6 +1368,39 @@ def test_streaming_1x1_conv(n, cin, cin2, cout, h, w, fused):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('n,cin,cin2,h,w,fused', [(3, 64, 0, 512, 256, False), (3, 64, 64, 256, 256, True), (1, 32, 0, 32, 32, True), (5, 96, 32, 64, 112, True),
+                                                 (2, 160, 0, 128, 64, False), (9, 64, 0, 128, 128, True)])
+def test_streaming_1x1_conv_ring(n, cin, cin2, h, w, fused):
+    """The ring form of the streaming 1x1 kernel (conv1x1_stream_ring: Cout = 64, Cin % 32 == 0, H*W % 1024 == 0, no residual; input
+    words requested three groups ahead across tile boundaries with hand-counted vmcnt) against float64: several tiles and several
+    images per workgroup, two-source input, modulation, demodulation, bias, lrelu, gain, clamp; twice, bit-identical."""
+    from torch_utils.ops import conv2d_mfma
+    cout = 64
+    gen = torch.Generator().manual_seed(31 * cin + n)
+    x = torch.randn([n, cin, h, w], generator=gen)
+    x2 = torch.randn([n, cin2, h, w], generator=gen) if cin2 else None
+    ct = cin + cin2
+    wt = torch.randn([cout, ct, 1, 1], generator=gen) / np.sqrt(ct)
+    kw = {}
+    ref_in = torch.cat([x, x2], 1).double() if cin2 else x.double()
+    if fused:
+        s_in, s_out = torch.randn([n, ct], generator=gen), torch.rand([n, cout], generator=gen) + 0.5
+        bias = torch.randn([cout], generator=gen)
+        kw = dict(in_scale=s_in.to(DEV), out_scale=s_out.to(DEV), bias=bias.to(DEV), act='lrelu', alpha=0.2, gain=1.3, clamp=1.5)
+        ref_in = ref_in * s_in.double()[:, :, None, None]
+    pk = conv2d_mfma.pack_weight(wt.to(DEV))
+    xd, x2d = x.to(DEV), (x2.to(DEV) if cin2 else None)
+    y = conv2d_mfma.conv2d_forward(xd, pk, cout, 1, 1, x2=x2d, **kw)
+    ref = torch.nn.functional.conv2d(ref_in, wt.double())
+    if fused:
+        ref = ref * s_out.double()[:, :, None, None] + bias.double()[None, :, None, None]
+        ref = (torch.nn.functional.leaky_relu(ref, 0.2) * 1.3).clamp(-1.5, 1.5)
+    close(y, ref, 1e-5, 3e-6 * scale_of(ref))
+    for _ in range(3):
+        assert torch.equal(conv2d_mfma.conv2d_forward(xd, pk, cout, 1, 1, x2=x2d, **kw), y)
+
+
+@pytest.mark.gpu
 def test_transposed_conv_weight_gradient_native():
     """conv_transpose2d(stride 2): its weight gradient is the weight gradient of the strided convolution dy -> x with the roles swapped,
     so conv2d_gradfix sends it to the same native kernel (exact on small integers; the route is asserted)."""

@@ -106,7 +106,9 @@ __device__ __forceinline__ int w4_fresh_lane() {
     return l;
 }
 
-// MODE: 0 = plain input, 1 = per-(n, channel) input scale (modulated convolution).  (Pre-activation launches stay on conv2d_wino.h.)
+// MODE: 0 = plain input, 1 = per-(n, channel) input scale (modulated convolution), 2 = plain input + SPADE combine in the tail (its own
+// instantiation: with both tails in one kernel every edit of one moved the other's register allocation -- and its time by 3-6 %).
+// (Pre-activation launches stay on conv2d_wino.h.)
 template <int MODE>
 __global__ __launch_bounds__(768, 3) void conv2d_wino4(ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -155,7 +157,7 @@ __global__ __launch_bounds__(768, 3) void conv2d_wino4(ConvParams p) {
         const int ty = L % p.tilesY;
         n = L / p.tilesY;
         oy0 = ty * 8; ox0 = tx * 64; m0 = mb * 64;
-        if (MODE != 0) {
+        if (MODE == 1) {
             const float* in_scale = p.f.in_scale ? p.f.in_scale + (int64_t)n * p.Cin : nullptr;
             for (int c = 64 * wave + w4_fresh_lane(); c < cin_loop; c += 768) cs[c] = ((in_scale && c < p.Cin) ? ld_opaque(in_scale + c) : 1.f) * p.f.in_gain;
         }
@@ -280,7 +282,7 @@ __global__ __launch_bounds__(768, 3) void conv2d_wino4(ConvParams p) {
                     d[r][0] = lo[0]; d[r][1] = lo[1]; d[r][2] = lo[2]; d[r][3] = lo[3]; d[r][4] = hi[0]; d[r][5] = hi[1];
                 }
                 float sc = 1.f;
-                if (MODE != 0) sc = cs_cur[k * W4_KC + 2 * wave + half];
+                if (MODE == 1) sc = cs_cur[k * W4_KC + 2 * wave + half];
 #pragma unroll
                 for (int j = 0; j < 6; j++)                              // columns: over the patch rows
                     w4_bt(d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j], d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j]);
@@ -288,7 +290,7 @@ __global__ __launch_bounds__(768, 3) void conv2d_wino4(ConvParams p) {
                 const unsigned vbase = smem_b + (unsigned)(W4_RAW * 4 + wave * 256);      // bytes: V + 64 floats per transform wave (< 65536: checked by the host)
 #define W4_ROW(A) { float v0, v1, v2, v3, v4, v5; \
                     w4_bt(d[A][0], d[A][1], d[A][2], d[A][3], d[A][4], d[A][5], v0, v1, v2, v3, v4, v5); \
-                    if (MODE != 0) { v0 *= sc; v1 *= sc; v2 *= sc; v3 *= sc; v4 *= sc; v5 *= sc; } \
+                    if (MODE == 1) { v0 *= sc; v1 *= sc; v2 *= sc; v3 *= sc; v4 *= sc; v5 *= sc; } \
                     w4_write_row<A>(vbase, v0, v1, v2, v3, v4, v5); }
                 W4_ROW(0) W4_ROW(1) W4_ROW(2) W4_ROW(3) W4_ROW(4) W4_ROW(5)
 #undef W4_ROW
@@ -303,7 +305,7 @@ __global__ __launch_bounds__(768, 3) void conv2d_wino4(ConvParams p) {
                 // epilogue constants of THIS tile (wave 8 only, before anything new enters its queue: ld_opaque waits for vmcnt(0))
                 const auto& qa = *fresh_args();
                 const int tc = wave == 8 ? w4_fresh_lane() : 64;              // wave 8 only
-                if (qa.f.spade_x) {
+                if (MODE == 2 || qa.f.spade_x) {
                     if (tc < 32) {
                         const int ch = (m0 >> 1) + tc;
                         ep_scale[tc] = ld_opaque(qa.f.spade_mean + n * (qa.Cout >> 1) + ch);
@@ -390,7 +392,9 @@ __global__ __launch_bounds__(768, 3) void conv2d_wino4(ConvParams p) {
         // Everything the rounds need is read from the kernel-argument segment ONCE here (a scalar load per use inside the rounds --
         // what re-reading through an opaque pointer turns into -- cost ~4 us per tile: with one workgroup per CU nothing hides it).
         const auto& qa = *fresh_args();
-        const bool spade = qa.f.spade_x != nullptr;
+        // (MODE 0 / 1 keep the SPADE branch as dead runtime code on purpose: compiled without it, hipcc's register allocation of the
+        // remaining tail spills 112-144 VGPRs)
+        const bool spade = MODE == 2 ? true : qa.f.spade_x != nullptr;
         const float gain = qa.f.gain, slope = act_slope(qa.f.act, qa.f.alpha);
         const float cl = qa.f.clamp >= 0.f ? qa.f.clamp : __builtin_inff();
         const bool plain_tail = slope == 1.f && gain == 1.f && qa.f.clamp < 0.f;
@@ -403,15 +407,18 @@ __global__ __launch_bounds__(768, 3) void conv2d_wino4(ConvParams p) {
         const int64_t img_off = (int64_t)e_n * qa.ys[0];
         float* y_n = qa.y + img_off;
         const float* res_n = qa.f.residual ? qa.f.residual + img_off : nullptr;
-        const float* spx_n = qa.f.spade_x ? qa.f.spade_x + img_off : nullptr;
+        const float* spx_n = spade ? qa.f.spade_x + img_off : nullptr;
         const float* nz_n = qa.f.noise ? qa.f.noise + (int64_t)e_n * qa.f.noise_batch_stride : nullptr;
         const unsigned cstride_b = (unsigned)qa.ys[1] * 4u, rstride_b = (unsigned)qa.ys[2] * 4u, nzrow_b = (unsigned)OWv * 4u;
         f32x4* ex4 = (f32x4*)V;
         const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+        // act(v) * gain = max(v * gain, v * (slope * gain)) for 0 <= slope <= 1, gain > 0 (the host guarantees both): two multiplies and a
+        // max instead of multiply / compare / select / multiply
+        const float g_pos = gain, g_neg = gain * slope;
         auto act4 = [&](f32x4 v) {
             if (!plain_tail) {
 #pragma unroll
-                for (int e = 0; e < 4; e++) v[e] = __builtin_amdgcn_fmed3f((v[e] > 0.f ? v[e] : v[e] * slope) * gain, -cl, cl);
+                for (int e = 0; e < 4; e++) v[e] = __builtin_amdgcn_fmed3f(fmaxf(v[e] * g_pos, v[e] * g_neg), -cl, cl);
             }
             return v;
         };
@@ -445,7 +452,9 @@ __global__ __launch_bounds__(768, 3) void conv2d_wino4(ConvParams p) {
         };
         const bool op_is_noise = !spade && !res_n && nz_n;
         const bool late_noise = !spade && res_n && nz_n;
+        const bool has_operand = spade || res_n || nz_n;
         auto request = [&](int rnd, f32x4 (&dst)[4]) {
+            if (!has_operand) return;                                    // (wave-uniform; `dst` keeps the zeros it was declared with)
 #pragma unroll
             for (int r = 0; r < 4; r++) dst[r] = zero4;
             if (chore || (WINO4_EXP & 32)) return;
@@ -471,7 +480,7 @@ __global__ __launch_bounds__(768, 3) void conv2d_wino4(ConvParams p) {
             yy[r] = (f32x4){y0, y1, y2, y3};
         }
         W4_STAMP(6);
-        f32x4 op[4];
+        f32x4 op[4] = {zero4, zero4, zero4, zero4};
         request(0, op);
         __syncthreads();                                                 // the exchange area IS the V buffer: every wave must be past its last GEMM reads before the first word is written
 #pragma unroll
@@ -512,9 +521,15 @@ __global__ __launch_bounds__(768, 3) void conv2d_wino4(ConvParams p) {
                     }
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
-                        f32x4 nzr = op_is_noise ? op[r] * ngain : zero4;
-                        if (late_noise) nzr = load4(nz_n, g.nzb + (unsigned)r * nzrow_b, g.cok && g.oyb + r < OHv) * ngain;
-                        f32x4 w = v[r] * esc + (nzr + ebi);
+                        f32x4 w;
+                        if (op_is_noise || late_noise) {                     // wave-uniform
+                            const f32x4 nz = late_noise ? load4(nz_n, g.nzb + (unsigned)r * nzrow_b, g.cok && g.oyb + r < OHv) : op[r];
+#pragma unroll
+                            for (int e = 0; e < 4; e++) w[e] = fmaf(v[r][e], esc, fmaf(nz[e], ngain, ebi));
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; e++) w[e] = fmaf(v[r][e], esc, ebi);
+                        }
                         w = act4(w);
                         if (res_n) w += op[r];
                         v[r] = w;
@@ -541,7 +556,14 @@ __global__ __launch_bounds__(768, 3) void conv2d_wino4(ConvParams p) {
                         }
                     }
 #pragma unroll
-                    for (int rr = 0; rr < 2; rr++) v[rr] = act4((op[rr] - mu) * rsd * (gb[0][rr] + 1.f) + gb[1][rr]);
+                    for (int rr = 0; rr < 2; rr++) {
+                        f32x4 w = (op[rr] - mu) * rsd * (gb[0][rr] + 1.f) + gb[1][rr];
+                        if (!plain_tail) {
+#pragma unroll
+                            for (int e = 0; e < 4; e++) w[e] = __builtin_amdgcn_fmed3f((w[e] > 0.f ? w[e] : w[e] * slope) * gain, -cl, cl);
+                        }
+                        v[rr] = w;
+                    }
                     if (rnd < 3) request(rnd + 1, op);                       // before this round's stores
 #pragma unroll
                     for (int rr = 0; rr < 2; rr++) store4(g.ob + (unsigned)rr * rstride_b, v[rr], g.cok && g.oyb + 2 * rh + rr < OHv);

@@ -441,7 +441,7 @@ __global__ __launch_bounds__(768, 3) void conv2d_wino4(ConvParams p) {
             const int ftx = g.fn >> 1, fty = g.fn & 1, c16 = g.t >> 5;
             g.oyb = e_oy0 + 4 * fty;
             const int oxb = e_ox0 + 4 * ftx;
-            g.rh = g.t >> 8; g.c8 = c16 & 7;
+            g.rh = wave >> 2; g.c8 = c16 & 7;                            // (rh: waves 0-3 | 4-7 -- wave-uniform, kept on the scalar unit)
             g.col = (c16 >> 3) * 32 + 8 * rnd + (c16 & 7);
             const int ch = spade ? (e_m0 >> 1) + 8 * rnd + g.c8 : e_m0 + g.col;
             const bool chan_ok = spade || ch < Coutv;
@@ -540,7 +540,8 @@ __global__ __launch_bounds__(768, 3) void conv2d_wino4(ConvParams p) {
                 } else {
                     // SPADE combine (networks.py:1715-1722): M-tile 0 rows are gamma, M-tile 1 rows beta of the same 32 channels;
                     // thread = (channel c8, tile, row pair rh):  y = (x - mean) * rstd * (1 + gamma) + beta
-                    const int chl = 8 * rnd + g.c8, rh = g.rh;
+                    const int chl = 8 * rnd + g.c8;
+                    const int rh = wave >> 2;                                // == g.rh, but on the scalar unit: the row selects below are branches, not v_cndmask pairs
                     const float mu = ep_scale[chl], rsd = ep_bias[chl];
                     f32x4 gb[2][2];                                          // [gamma | beta][row of the pair]
 #pragma unroll
@@ -551,18 +552,17 @@ __global__ __launch_bounds__(768, 3) void conv2d_wino4(ConvParams p) {
 #pragma unroll
                         for (int c = 0; c < 4; c++) {                        // over a: only this thread's two output rows
                             const float s12 = z[1][c] + z[2][c], d12 = z[1][c] - z[2][c], s34 = z[3][c] + z[4][c], d34 = z[3][c] - z[4][c];
-                            gb[gbi][0][c] = rh ? fmaf(4.f, s34, s12) : z[0][c] + s12 + s34;
-                            gb[gbi][1][c] = rh ? fmaf(8.f, d34, d12) + z[5][c] : fmaf(2.f, d34, d12);
+                            if (rh) { gb[gbi][0][c] = fmaf(4.f, s34, s12); gb[gbi][1][c] = fmaf(8.f, d34, d12) + z[5][c]; }
+                            else { gb[gbi][0][c] = z[0][c] + s12 + s34; gb[gbi][1][c] = fmaf(2.f, d34, d12); }
                         }
                     }
+                    const float nmr = -mu * rsd;
 #pragma unroll
                     for (int rr = 0; rr < 2; rr++) {
-                        f32x4 w = (op[rr] - mu) * rsd * (gb[0][rr] + 1.f) + gb[1][rr];
-                        if (!plain_tail) {
+                        f32x4 w;
 #pragma unroll
-                            for (int e = 0; e < 4; e++) w[e] = __builtin_amdgcn_fmed3f((w[e] > 0.f ? w[e] : w[e] * slope) * gain, -cl, cl);
-                        }
-                        v[rr] = w;
+                        for (int e = 0; e < 4; e++) w[e] = fmaf(fmaf(op[rr][e], rsd, nmr), gb[0][rr][e] + 1.f, gb[1][rr][e]);
+                        v[rr] = act4(w);
                     }
                     if (rnd < 3) request(rnd + 1, op);                       // before this round's stores
 #pragma unroll

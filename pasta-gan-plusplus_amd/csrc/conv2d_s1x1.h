@@ -144,7 +144,9 @@ __global__ __launch_bounds__(512, 1) void conv1x1_stream(ConvParams p) {
     }
 }
 
-// ---- Ring form (round 3): the same mapping, (MT 2, E 4), for Cout = 64 exactly, Cin % 32 == 0, whole 1024-pixel tile rows, no residual.
+// ---- Ring form (round 3): the same mapping, (MT 2, E 4), for Cout a multiple of 64 (one pass over the pixels per 64-cout block: the
+// blocks of an image run side by side on different workgroups, so all but one pass come from L2 / MALL), Cin % 32 == 0, whole
+// 1024-pixel tile rows, no residual.
 // The plain-C++ prefetch of conv1x1_stream above does not prefetch: `cur = nxt` copies registers whose loads are in flight, so hipcc
 // puts `s_waitcnt vmcnt(0)` between the loads of group g + 1 and the MFMAs of group g (found in the assembly) and every group exposes a
 // full memory round trip with two waves per SIMD to cover it: 3.9 TB/s.  Here the input words are inline-asm loads into a RING of four
@@ -152,7 +154,7 @@ __global__ __launch_bounds__(512, 1) void conv1x1_stream(ConvParams p) {
 // request stream runs across tile boundaries: the first three groups of the next tile are in flight while this tile's 32 stores issue.
 // vmcnt returns loads and stores in issue order, so the wait for group g counts what is younger than its four loads: the three groups
 // behind it (12) and, for the first three groups after an epilogue, that epilogue's 32 stores (44).  Every store of the epilogue is
-// unconditional (Cout = 64, full tiles) -- the count is exact; anything else the compiler issues in between (the weight reload at an
+// unconditional (64-cout blocks, full tiles) -- the count is exact; anything else the compiler issues in between (the weight reload at an
 // image change) only makes a wait conservative.
 constexpr int S1_RING = 4, S1_AHEAD = 3, S1_GRP = 4;
 __global__ __launch_bounds__(512, 1) void conv1x1_stream_ring(ConvParams p) {
@@ -282,7 +284,12 @@ __global__ __launch_bounds__(512, 1) void conv1x1_stream_ring(ConvParams p) {
 
 inline bool s1x1_ring_ok(const ConvParams& p) {
     const int64_t HW = (int64_t)p.H * p.W;
-    if (p.Cout != 64 || p.CoutP != 64 || p.Cin % 32 != 0 || p.Cin < 32 || HW % 1024 != 0 || p.f.residual) return false;
+    if (p.Cout % 64 != 0 || p.CoutP != p.Cout || p.Cin % 32 != 0 || p.Cin < 32 || HW % 1024 != 0 || HW < 4096 || p.f.residual) return false;
+    if (p.in_xform || p.f.noise || p.f.spade_x || p.ksplit > 1) return false;
+    if (p.osy != 1 || p.osx != 1 || p.ooy != 0 || p.oox != 0 || p.pad_y != 0 || p.pad_x != 0) return false;
+    if (p.ys[3] != 1 || p.ys[2] != p.OW || p.ys[1] != HW || p.OH != p.H || p.OW != p.W) return false;     // flattened pixel axis
+    if ((((uintptr_t)p.x) | ((uintptr_t)p.y) | ((uintptr_t)p.f.x2)) & 15) return false;
+    if ((p.ys[0] & 3) != 0) return false;
     if (p.f.x2 && (p.f.cin_split % 8 != 0 || p.f.cin_split <= 0 || p.f.cin_split >= p.Cin)) return false;
     if ((int64_t)p.Cin * HW * 4 > 0x7fffffffLL) return false;              // 32-bit lane offsets within one image
     return (size_t)(p.Cin + 2) * 64 * 4 <= 150 * 1024;
@@ -292,8 +299,8 @@ inline int launch_s1x1_ring(const ConvParams& p0, hipStream_t s) {
     ConvParams p = p0;
     const int64_t HW = (int64_t)p.H * p.W;
     const int64_t ptiles = HW / 1024;
-    p.mblocks = 1;
-    const int64_t tiles = ptiles * p.N;
+    p.mblocks = p.Cout / 64;                                            // each 64-cout block streams the pixels again (the other blocks' workgroups read the same image at about the same time: L2 / MALL)
+    const int64_t tiles = ptiles * p.mblocks * p.N;
     if (tiles > 0x7fffffffLL) return PG_ERR_TOO_LARGE;
     p.total_tiles = (int)tiles;
     const size_t lds = (size_t)(p.Cin + 2) * 64 * sizeof(float);

@@ -19,8 +19,12 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
         const int tap = (int)((i / CoutP) % T);
         const int ci = (int)(i / ((int64_t)CoutP * T));
         float v = 0.f;
-        if (co < Cout && ci < Cin) {
-            int ky = tap / KW, kx = tap % KW;
+        int ky = tap / KW, kx = tap % KW;
+        int cs = ci;
+        // ROWPAIR form (conv2d_kernel.h; every 7x7 kernel with Cin = 3): "channel 3" of tap (ky, kx), ky even, is channel 2 of tap (ky + 1, kx)
+        if (Cin == 3 && KH == 7 && KW == 7 && ci == 3 && (ky & 1) == 0 && ky + 1 < KH) { cs = 2; ky += 1; }
+        if (co < Cout && cs < Cin) {
+            const int ci = cs;
             if (flip) { ky = KH - 1 - ky; kx = KW - 1 - kx; }
             const int64_t src = transpose_oi ? (((int64_t)ci * Cout + co) * KH + ky) * KW + kx
                                              : (((int64_t)co * Cin + ci) * KH + ky) * KW + kx;
@@ -458,7 +462,8 @@ static int conv_forward(int winograd, const float* x, const float* packed_w, flo
         if (ext > 0x7fffffffLL || (int64_t)N * OH * OW > 0x7fffffffLL) return PG_ERR_TOO_LARGE;
     }
     ConvParams p;
-    p.ksplit = 1; p.kpart = 0; p.ws_slice = 0; p.wino_gmap = 0;
+    p.ksplit = 1; p.kpart = 0; p.ws_slice = 0; p.wino_gmap = 0; p.rowpair = 0;
+    p.rowpair_pack = 1;                 // every packed 7x7 / Cin = 3 kernel comes from pg_conv2d_pack_weight, i.e. is in the ROWPAIR form
     p.x = x; p.wp = packed_w; p.y = y;
     p.N = N; p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout; p.CoutP = round_up(Cout, 32); p.OH = OH; p.OW = OW;
     p.pad_y = pad_y; p.pad_x = pad_x;

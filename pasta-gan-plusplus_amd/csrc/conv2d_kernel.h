@@ -47,6 +47,8 @@ struct ConvParams {
     int in_xform;          // prologue bias/act/gain/clamp stage on
     int ksplit, kpart;     // split-K: `ksplit` workgroups share one output tile, each reducing `kpart` input channels into its own
     int64_t ws_slice;      // slice (ws_slice floats apart) of the partial-sum workspace that y then points to; 1 = off
+    int rowpair_pack;      // the packed weights are in the ROWPAIR form (pg_conv2d_pack_weight makes it for every 7x7 kernel with Cin = 3)
+    int rowpair;           // 7x7, Cin = 3 (see conv2d_mfma: ROWPAIR): the fourth channel slot carries channel 2 one row down
     int wino_gmap;         // Winograd: interior tiles take the tile-independent gather map from LDS (0 = off: A/B switch PG_WINO_GMAP=0)
     pg_conv2d_fusion f;
 };
@@ -103,6 +105,9 @@ struct Geo {
     static constexpr int LDS_W = WPT * 256 * 4;
     static constexpr int LDS_BUF = LDS_X + LDS_W;         // one staging buffer (floats)
     static constexpr size_t LDS_BYTES = (size_t)2 * LDS_BUF * 4;   // double buffered
+    // workgroups per CU the staging buffers leave room for (the launcher computes the same from the full LDS size): geometries that
+    // cannot have four anyway -- the 7x7 stem: 68 KB of weights + halo per workgroup -- get the registers of the waves that cannot exist
+    static constexpr int MIN_BLOCKS = LDS_BYTES * 4 <= 156 * 1024 ? 4 : LDS_BYTES * 3 <= 156 * 1024 ? 3 : LDS_BYTES * 2 <= 156 * 1024 ? 2 : 1;
 };
 
 // The fused activations are linear / relu / lrelu (everything the synthesis path uses): one select,
@@ -113,7 +118,7 @@ __device__ __forceinline__ float act_slope(int act, float alpha) { return act ==
 // MODE: 0 = plain input (the B operand goes from LDS to the MFMA untouched: VALU instructions cost matrix-pipe time),
 //       1 = per-(n, channel) input scale (modulated convolution), 2 = scale + pre-activation (XF).
 template <int KH, int KW, int S, int BM, int KC, int MODE>
-__global__ __launch_bounds__(256, 4) void conv2d_mfma(ConvParams p) {
+__global__ __launch_bounds__(256, (Geo<KH, KW, S, BM, KC>::MIN_BLOCKS)) void conv2d_mfma(ConvParams p) {
     constexpr bool XF = MODE == 2;
     typedef Geo<KH, KW, S, BM, KC> G;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -136,6 +141,13 @@ __global__ __launch_bounds__(256, 4) void conv2d_mfma(ConvParams p) {
     // ---- state of the tile whose chunks are being requested
     int n = 0, oy0 = 0, ox0 = 0, m0 = 0, cbeg = 0, zsl = 0;      // cbeg / zsl: first channel and workspace slice of a split-K share
     unsigned xoff[G::XPT];
+    // ROWPAIR (the network's 7x7 stem, Cin = 3, K chunk = 2 channels): chunk 1 would multiply channel 2 beside an all-zero channel 3.
+    // Instead its second slot carries channel 2 ONE ROW DOWN and the pack kernel puts w[.., 2, ky + 1, kx] into "channel 3" of tap
+    // (ky, kx) for even ky: the MFMA's two k-slices then are the taps (ky, kx) and (ky + 1, kx) of channel 2, and the chunk walks the
+    // kernel rows 0, 2, 4, 6 only -- 49 + 28 instead of 98 MFMA steps per tile and register tile.  Operand reads are unchanged (the
+    // shift sits in the staging offsets); without the mode the same pack is still correct (channel 3 of x reads as zero).
+    constexpr bool ROWPAIR = KH == 7 && KW == 7 && S == 1 && KC == 2 && MODE == 0;
+    unsigned xoff2[ROWPAIR ? G::XPT : 1];
     i32x4 xrsrc, xrsrc2;             // image n of x (channels [0, split)) and of the optional second source x2
     const int split = p.f.x2 ? p.f.cin_split : p.Cin;
 
@@ -168,6 +180,10 @@ __global__ __launch_bounds__(256, 4) void conv2d_mfma(ConvParams p) {
             const int gy = oy0 * S - p.pad_y + rr, gx = ox0 * S - p.pad_x + cc;
             const bool ok = e < G::NX && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
             xoff[i] = ok ? (unsigned)(c * HW + gy * p.W + gx) * 4u : 0x80000000u;
+            if constexpr (ROWPAIR) {
+                const bool ok2 = e < G::NX && gy + c >= 0 && gy + c < p.H && gx >= 0 && gx < p.W;      // slot 1 = the same channel, one row down
+                xoff2[i] = ok2 ? (unsigned)((gy + c) * p.W + gx) * 4u : 0x80000000u;
+            }
         }
         // raw buffer descriptor of image n: base, stride 0, num_records = bytes, flags as make_buffer_rsrc's 0x00020000
         const uint64_t base = (uint64_t)(uintptr_t)(p.x + ((int64_t)n * split + cbeg) * HW);
@@ -193,7 +209,11 @@ __global__ __launch_bounds__(256, 4) void conv2d_mfma(ConvParams p) {
         if (c0 < split) {                                   // wave-uniform: split is a multiple of the chunk size
             const int soff = c0 * HW * 4;
 #pragma unroll
-            for (int i = 0; i < G::XPT; i++) if (!(DIRECT_EXP & 2)) dma_dword(xrsrc, xs_b + 1024u * i, xoff[i], soff);
+            for (int i = 0; i < G::XPT; i++) {
+                unsigned xo = xoff[i];
+                if constexpr (ROWPAIR) { if (p.rowpair && c0 == 2) xo = xoff2[i]; }
+                if (!(DIRECT_EXP & 2)) dma_dword(xrsrc, xs_b + 1024u * i, xo, soff);
+            }
         } else {
             const int soff = (c0 - split) * HW * 4;
 #pragma unroll
@@ -228,6 +248,7 @@ __global__ __launch_bounds__(256, 4) void conv2d_mfma(ConvParams p) {
             const float sc = MODE != 0 ? cs[c0 + 2 * cp + half] * in_gain : 1.f;
 #pragma unroll
             for (int ky = 0; ky < KH; ky++) {
+                if constexpr (ROWPAIR) { if (p.rowpair && c0 == 2 && (ky & 1)) continue; }      // (wave-uniform) the odd rows ride in the second k-slice
 #pragma unroll
                 for (int kx = 0; kx < KW; kx++) {
                     float a[G::MT], b[G::NT];
@@ -411,6 +432,7 @@ int launch_conv_xf(const ConvParams& p0, hipStream_t s) {
     p.tilesX = (p.OW + TW - 1) / TW;
     p.tilesY = (p.OH + TH - 1) / TH;
     p.mblocks = p.CoutP / BM;
+    p.rowpair = KH == 7 && KW == 7 && S == 1 && KC == 2 && MODE == 0 && p.Cin == 3 && !p.f.x2 && p.ksplit <= 1 && p.rowpair_pack;
     const int64_t tiles = (int64_t)p.N * p.tilesX * p.tilesY * p.mblocks * (p.ksplit > 1 ? p.ksplit : 1);
     if (tiles > 0x7fffffffLL) return PG_ERR_TOO_LARGE;
     p.total_tiles = (int)tiles;

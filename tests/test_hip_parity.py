@@ -255,6 +255,26 @@ def test_conv2d_vs_oracle(case):
     close(dw, gw, 1e-3, 1e-4 * scale_of(gw))
 
 
+@pytest.mark.parametrize('n,cout,h,w,pad,mod,flip', [(2, 64, 37, 70, 3, False, False), (1, 40, 64, 33, 3, False, True), (2, 64, 19, 40, 3, True, False),
+                                                    (1, 128, 9, 100, 0, False, False), (3, 64, 8, 32, 2, False, False), (1, 7, 21, 21, 3, True, True)])
+def test_conv7x7_three_channel_stem(n, cout, h, w, pad, mod, flip):
+    """The 7x7 stem on a 3-channel image (networks.py ResnetGenerator-style encoders): pg_conv2d_pack_weight stores such kernels in the
+    row-pair form (channel slot 3 = channel 2 one kernel row down) and the plain launch walks only the even kernel rows in its second
+    K chunk; a modulated launch (no row-pair mode) must still be exact with the same pack, as must the flipped pack.  Against float64."""
+    from torch_utils.ops import conv2d_mfma
+    import torch.nn.functional as F
+    gen = torch.Generator().manual_seed(7 * cout + h)
+    x = torch.randn([n, 3, h, w], generator=gen)
+    wt = torch.randn([cout, 3, 7, 7], generator=gen) / math.sqrt(147)
+    s_in = torch.randn([n, 3], generator=gen) if mod else None
+    b = torch.randn([cout], generator=gen)
+    packed = conv2d_mfma.pack_weight(wt.to(DEV), flip=flip)
+    y = conv2d_mfma.conv2d_forward(x.to(DEV), packed, cout, 7, 7, pad=(pad, pad), in_scale=s_in.to(DEV) if mod else None, bias=b.to(DEV), act='relu')
+    xr = x.double() * (s_in.double()[:, :, None, None] if mod else 1.0)
+    ref = F.conv2d(xr, (wt.flip([2, 3]) if flip else wt).double(), b.double(), padding=pad).relu()
+    close(y, ref, 1e-5, 3e-6 * scale_of(ref))
+
+
 @pytest.mark.parametrize('n,cin,cout,h,w,k,pad,opad', [(2, 6, 5, 8, 8, 3, 0, 0), (1, 64, 64, 16, 19, 3, 0, 0), (2, 8, 12, 7, 9, 3, 1, 0), (1, 16, 8, 6, 6, 3, 1, 1)])
 def test_conv_transpose2d_vs_oracle(n, cin, cout, h, w, k, pad, opad):
     from torch_utils.ops import conv2d_gradfix

@@ -443,7 +443,7 @@ int launch_conv_xf(const ConvParams& p0, hipStream_t s) {
     // persistent grid: as many workgroups as stay resident (4 per CU by registers; fewer if LDS-limited);
     // every workgroup walks tiles id, id + grid, ...
     int per_cu = (int)((160 * 1024) / lds);
-    if (per_cu > 4) per_cu = 4;
+    if (per_cu > G::MIN_BLOCKS) per_cu = G::MIN_BLOCKS;       // the kernel's launch bounds (registers)
     if (per_cu < 1) per_cu = 1;
     const int64_t blocks = tiles < (int64_t)num_cu() * per_cu ? tiles : (int64_t)num_cu() * per_cu;
     static PerDeviceOnce lds_attr;

@@ -191,6 +191,7 @@ __global__ __launch_bounds__(512, 1) void conv1x1_stream_ring(ConvParams p) {
         const int c0 = 2 * GRP * g;                                        // first channel of the group; split % 8 == 0: one source per group
         const float* base = c0 < split ? s.b1 : s.b2;
         const unsigned goff = (unsigned)((c0 < split ? c0 : c0 - split) * HW) * 4u;
+        asm volatile("s_nop 4" ::: "memory");       // `base` may come straight from a spill lane (v_readlane -> SGPR -> VMEM needs 5 wait states; asm operands are invisible to the hazard recognizer)
 #pragma unroll
         for (int u = 0; u < GRP; u++) {
             const unsigned off = s.voff + goff + (unsigned)(2 * u * HW) * 4u;

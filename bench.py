@@ -464,7 +464,7 @@ def main():
         # 1/4 of the direct-convolution count; F(2x2,3x3) (csrc/conv2d_wino.h): 4/9; the direct implicit GEMM: all of it -- and the
         # direct-convolution-equivalent rate of the same launches is reported next to it (it can exceed the matrix peak).
         WORK = {'winograd4': 0.25, 'winograd': 4.0 / 9.0, 'direct': 1.0}
-        KERNEL = {'winograd4': 'conv2d_wino4<MODE> (Winograd F(4x4,3x3) stride-1 3x3 convolution, v_mfma_f32_32x32x2_f32)',
+        KERNEL = {'winograd4': 'conv2d_wino4<MODE,TAIL> (Winograd F(4x4,3x3) stride-1 3x3 convolution, v_mfma_f32_32x32x2_f32)',
                   'winograd': 'conv2d_wino<MODE,VEC> (Winograd F(2x2,3x3) stride-1 3x3 convolution, v_mfma_f32_32x32x2_f32)',
                   'direct': 'conv2d_mfma<KH,KW,S,BM,KC,XF> (implicit GEMM, v_mfma_f32_32x32x2_f32)'}
         by_algo = {}

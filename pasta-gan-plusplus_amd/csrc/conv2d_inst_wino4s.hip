@@ -1,7 +1,8 @@
-// Winograd F(4x4, 3x3), SPADE-combine tail (own translation unit: see conv2d_kernel.h on build time).
+// Winograd F(4x4, 3x3): plain input with the SPADE-combine tail / the plain tail (own translation unit: see conv2d_kernel.h on build time).
 // hipcc-flags: -fno-slp-vectorize
 #include "conv2d_wino4.h"
 
 namespace pgconv {
-int launch_wino4_spade(const ConvParams& p, hipStream_t s) { return launch_wino4_mode<2>(p, s); }
+int launch_wino4_spade(const ConvParams& p, hipStream_t s) { return launch_wino4_mode<0, W4_TAIL_SPADE>(p, s); }
+int launch_wino4_plain(const ConvParams& p, hipStream_t s) { return launch_wino4_mode<0, W4_TAIL_PLAIN>(p, s); }
 }  // namespace pgconv

@@ -106,10 +106,17 @@ __device__ __forceinline__ int w4_fresh_lane() {
     return l;
 }
 
-// MODE: 0 = plain input, 1 = per-(n, channel) input scale (modulated convolution), 2 = plain input + SPADE combine in the tail (its own
-// instantiation: with both tails in one kernel every edit of one moved the other's register allocation -- and its time by 3-6 %).
-// (Pre-activation launches stay on conv2d_wino.h.)
-template <int MODE>
+// MODE: 0 = plain input, 1 = per-(n, channel) input scale (modulated convolution).  (Pre-activation launches stay on conv2d_wino.h.)
+// TAIL: which operands the fused epilogue has -- its own instantiation each, because with several tails in one kernel every edit of one
+// moved the others' register allocation (and their time by 3-6 %), and because the specialised ones need far fewer scalar registers
+// (13-26 spilled SGPRs instead of 50):
+//   W4_TAIL_ANY    whatever pg_conv2d_fusion says, decided at run time (the fallback; it keeps ALL branches on purpose: compiled without the
+//                  SPADE branch, hipcc's register allocation of what remains spills 112-144 VGPRs)
+//   W4_TAIL_PLAIN  scale / bias / activation only (-3.6 ... -5.7 % per launch against W4_TAIL_ANY)
+//   W4_TAIL_SPADE  the SPADE combine (-2.5 ... -4.5 %)
+//   W4_TAIL_RES / W4_TAIL_NOISE (residual only / noise only) compile cleanly too but measured +1 % / -1 ... +5 %: not instantiated.
+enum { W4_TAIL_ANY = 0, W4_TAIL_PLAIN = 1, W4_TAIL_SPADE = 2, W4_TAIL_RES = 3, W4_TAIL_NOISE = 4 };
+template <int MODE, int TAIL>
 __global__ __launch_bounds__(768, 3) void conv2d_wino4(ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int cin_loop = ((p.Cin + W4_KC - 1) / W4_KC) * W4_KC;
@@ -305,7 +312,7 @@ __global__ __launch_bounds__(768, 3) void conv2d_wino4(ConvParams p) {
                 // epilogue constants of THIS tile (wave 8 only, before anything new enters its queue: ld_opaque waits for vmcnt(0))
                 const auto& qa = *fresh_args();
                 const int tc = wave == 8 ? w4_fresh_lane() : 64;              // wave 8 only
-                if (MODE == 2 || qa.f.spade_x) {
+                if (TAIL == W4_TAIL_SPADE || (TAIL == W4_TAIL_ANY && qa.f.spade_x)) {
                     if (tc < 32) {
                         const int ch = (m0 >> 1) + tc;
                         ep_scale[tc] = ld_opaque(qa.f.spade_mean + n * (qa.Cout >> 1) + ch);
@@ -392,9 +399,7 @@ __global__ __launch_bounds__(768, 3) void conv2d_wino4(ConvParams p) {
         // Everything the rounds need is read from the kernel-argument segment ONCE here (a scalar load per use inside the rounds --
         // what re-reading through an opaque pointer turns into -- cost ~4 us per tile: with one workgroup per CU nothing hides it).
         const auto& qa = *fresh_args();
-        // (MODE 0 / 1 keep the SPADE branch as dead runtime code on purpose: compiled without it, hipcc's register allocation of the
-        // remaining tail spills 112-144 VGPRs)
-        const bool spade = MODE == 2 ? true : qa.f.spade_x != nullptr;
+        const bool spade = TAIL == W4_TAIL_SPADE ? true : (TAIL == W4_TAIL_ANY ? qa.f.spade_x != nullptr : false);
         const float gain = qa.f.gain, slope = act_slope(qa.f.act, qa.f.alpha);
         const float cl = qa.f.clamp >= 0.f ? qa.f.clamp : __builtin_inff();
         const bool plain_tail = slope == 1.f && gain == 1.f && qa.f.clamp < 0.f;
@@ -406,9 +411,9 @@ __global__ __launch_bounds__(768, 3) void conv2d_wino4(ConvParams p) {
         // per-image bases (uniform) + 32-bit byte offsets inside the image (the host checks that one image of y stays below 4 GB)
         const int64_t img_off = (int64_t)e_n * qa.ys[0];
         float* y_n = qa.y + img_off;
-        const float* res_n = qa.f.residual ? qa.f.residual + img_off : nullptr;
+        const float* res_n = ((TAIL == W4_TAIL_ANY || TAIL == W4_TAIL_RES) && qa.f.residual) ? qa.f.residual + img_off : nullptr;
         const float* spx_n = spade ? qa.f.spade_x + img_off : nullptr;
-        const float* nz_n = qa.f.noise ? qa.f.noise + (int64_t)e_n * qa.f.noise_batch_stride : nullptr;
+        const float* nz_n = ((TAIL == W4_TAIL_ANY || TAIL == W4_TAIL_NOISE) && qa.f.noise) ? qa.f.noise + (int64_t)e_n * qa.f.noise_batch_stride : nullptr;
         const unsigned cstride_b = (unsigned)qa.ys[1] * 4u, rstride_b = (unsigned)qa.ys[2] * 4u, nzrow_b = (unsigned)OWv * 4u;
         f32x4* ex4 = (f32x4*)V;
         const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -585,7 +590,7 @@ __global__ __launch_bounds__(768, 3) void conv2d_wino4(ConvParams p) {
     }
 }
 
-template <int MODE>
+template <int MODE, int TAIL>
 int launch_wino4_mode(const ConvParams& p0, hipStream_t s) {
     ConvParams p = p0;
     p.tilesX = (p.OW + 63) / 64;
@@ -607,9 +612,9 @@ int launch_wino4_mode(const ConvParams& p0, hipStream_t s) {
         ((((uintptr_t)p.y) | ((uintptr_t)p.f.noise) | ((uintptr_t)p.f.residual) | ((uintptr_t)p.f.spade_x)) & 15) != 0) return PG_ERR_UNSUPPORTED;
     const int64_t blocks = tiles < (int64_t)num_cu() ? tiles : (int64_t)num_cu();
     static PerDeviceOnce lds_attr;
-    const hipError_t e = lds_attr.run([] { return hipFuncSetAttribute((const void*)conv2d_wino4<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+    const hipError_t e = lds_attr.run([] { return hipFuncSetAttribute((const void*)conv2d_wino4<MODE, TAIL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((conv2d_wino4<MODE>), dim3((unsigned)blocks), dim3(768), lds, s, p);
+    hipLaunchKernelGGL((conv2d_wino4<MODE, TAIL>), dim3((unsigned)blocks), dim3(768), lds, s, p);
     return launch_status();
 }
 

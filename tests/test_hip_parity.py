@@ -1131,6 +1131,26 @@ def test_bench_workload_argmax_path_batch8_vs_oracle():
                 print(f'bench workload image {i}: img {d_img:.2e}, pred_parsing {d_pp:.2e}; {flips:.2e} of the labels flipped on near-ties, finetune_img not compared')
 
 
+def test_bench_workload_repeats_bit_identical():
+    """Every kernel on the config-2 path is deterministic (no atomics, fixed reduction orders), so the bench workload at N=8 must
+    reproduce its first outputs bit for bit under load; a pass that differs is a race (the F(4x4) tail race of round 3 made 20 % of
+    full-size launches wrong while every small test passed).  `tools/step_stress.py` is the long form of this test."""
+    import bench
+    from training import networks as PN
+    bench.torch = torch
+    net = bench.init_weights(PN.SynthesisNetworkFull_v18(**bench.CFG2)).to(DEV).eval()
+    inp = bench.make_inputs(8, DEV, seed=5)
+    other = torch.randn(32, 64, 256, 256, device=DEV)
+    with torch.no_grad():
+        ref = [t.clone() for t in bench.run_net(net, inp) if torch.is_tensor(t)]
+        for it in range(12):
+            if it % 3 == 1:
+                other.mul_(1.0001)
+            out = [t for t in bench.run_net(net, inp) if torch.is_tensor(t)]
+            for k, (a, b) in enumerate(zip(ref, out)):
+                assert torch.equal(a, b), f'pass {it}, output {k}: max |d| {float((a - b).abs().max()):.3e} against the first pass'
+
+
 def test_config3_chain_patch_routing_into_generator_n16():
     """BASELINE config 3 end to end on the product: patch routing (HIP warps) -> uint8 tensors normalised as test.py does
     (test.py:126-147) -> GeneratorFull_v20 at N=16.  Checks: finite outputs, and every image of the batch equals the N=1 run

@@ -1411,7 +1411,7 @@ def test_streaming_1x1_conv(n, cin, cin2, cout, h, w, fused):
 @pytest.mark.parametrize('n,cin,cin2,cout,h,w,fused', [(3, 64, 0, 64, 512, 256, False), (3, 64, 64, 64, 256, 256, True), (1, 32, 0, 64, 32, 32, True),
                                                       (5, 96, 32, 64, 64, 112, True), (2, 160, 0, 64, 128, 64, False), (9, 64, 0, 64, 128, 128, True),
                                                       (3, 128, 0, 128, 256, 256, True), (2, 128, 64, 128, 128, 128, False), (2, 320, 0, 256, 64, 64, True),
-                                                      (1, 576, 0, 512, 32, 32, False), (5, 64, 0, 192, 64, 48, True)])
+                                                      (1, 576, 0, 512, 32, 32, False), (5, 64, 0, 192, 64, 48, True), (2, 32, 0, 64, 64, 64, True), (1, 32, 32, 128, 128, 64, False)])
 def test_streaming_1x1_conv_ring(n, cin, cin2, cout, h, w, fused):
     """The ring form of the streaming 1x1 kernel (conv1x1_stream_ring: Cout % 64 == 0 -- one pass over the pixels per 64-cout block --,
     Cin % 32 == 0, H*W % 1024 == 0, no residual; input words requested three groups ahead across tile boundaries with hand-counted

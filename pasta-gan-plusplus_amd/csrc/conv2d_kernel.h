@@ -304,6 +304,7 @@ __global__ __launch_bounds__(256, (Geo<KH, KW, S, BM, KC>::MIN_BLOCKS)) void con
         const float* cs_cur = cs0 + par * cin_loop;
         float* ep_scale = ep0 + par * 2 * BM;
         float* ep_bias = ep_scale + BM;
+        __builtin_amdgcn_s_setprio(1);                // K loop above other workgroups' epilogues on this SIMD
         for (int k = 0; k < nchunks; k++, g++) {
             const int buf = g & 1;
             if (k + 1 < nchunks) {
@@ -338,6 +339,7 @@ __global__ __launch_bounds__(256, (Geo<KH, KW, S, BM, KC>::MIN_BLOCKS)) void con
             __syncthreads();
         }
 
+        __builtin_amdgcn_s_setprio(0);
         // ---- epilogue of this tile: D layout col = lane&31 (pixel), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (cout).
         // Per-cout constants come from LDS; every load is unconditional from a clamped, always-valid address.  The
         // outputs are walked in groups of 4 consecutive couts; the group's extra operand (residual, or the tensor being

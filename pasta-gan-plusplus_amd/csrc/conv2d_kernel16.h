@@ -161,8 +161,15 @@ __device__ __forceinline__ float act_slope(int act, float alpha) { return act ==
 // L * d < 2^32 (launch16 checks it).
 __device__ __forceinline__ unsigned div_magic(unsigned L, unsigned M) { return M ? __umulhi(L, M) : L; }
 
-template <typename T, int KH, int KW, int S, int TWL, int WM, int MT, int NT, int KC, int NB>
-__global__ __launch_bounds__(THREADS, 2) void conv2d_mfma16(Conv16Params p) {
+// SPLIT (round 3): four more waves (8 .. 11) own everything that is not multiplying -- the chunk requests, the tile preparation, the
+// per-tile side loads -- and run two chunks ahead of waves 0 .. 7, which only wait at the chunk barrier, multiply and write tiles out.
+// In the one-role form every wave spends ~1.1-1.4 k cycles per chunk issuing its five requests (and ~3.5 k per tile preparing it)
+// between the barrier and its first MFMA, all eight at the same time: the matrix pipe has nothing queued for a third of the K loop
+// (tools/conv16_stamps.py).  Needs >= 2 chunks per tile (the side buffers of tile T + 2 are requested with its first chunk, which must
+// not happen before tile T's epilogue has read its own).
+constexpr int LOADERS = 4;
+template <typename T, int KH, int KW, int S, int TWL, int WM, int MT, int NT, int KC, int NB, bool SPLIT = false>
+__global__ __launch_bounds__(SPLIT ? THREADS + 64 * LOADERS : THREADS, SPLIT ? 3 : 2) void conv2d_mfma16(Conv16Params p) {
     typedef Geo16<KH, KW, S, TWL, WM, MT, NT, KC, NB> G;
     typedef Half16<T> HT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -177,6 +184,11 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_mfma16(Conv16Params p) {
     const unsigned dump_b = side_b + 2u * G::EP_FLOATS * 4u;
     const int half = lane >> 5, l31 = lane & 31;
     const int wpx = wave % G::WP, wmx = wave / G::WP;
+    const bool loader = SPLIT && wave >= WAVES;           // wave-uniform role
+    const int lw = wave - WAVES;                          // loader index 0 .. 3
+    // request instruction i2 of a chunk, as issued by this thread: the one-role form's instruction i of wave vw (same slots, same maps)
+    constexpr int LD = SPLIT ? 2 * G::DPC : G::DPC;
+    auto slot_of = [&](int i2) __attribute__((always_inline)) { return SPLIT ? ((i2 >> 1) * WAVES + (i2 & 1) * LOADERS + lw) * 64 : (i2 * WAVES + wave) * 64; };
     const int total = p.total_tiles;
     const int q8 = total >> 3, r8 = total & 7;
     const int cin_loop = p.ksplit > 1 ? p.kpart : p.Cin;  // channels one workgroup reduces per tile
@@ -196,12 +208,13 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_mfma16(Conv16Params p) {
     //   rel[i]  byte offset of the slot's source relative to the tile's first halo pixel (halo) / the slab's first row (weights);
     //           SENTINEL for padding slots
     //   hyx[i]  halo coordinates (row | col << 16) for the border test; rows >= 0x4000 never pass it
-    unsigned rel[G::DPC], hyx[G::DPC];
+    unsigned rel[LD], hyx[LD];
     unsigned tailmask = 0;                                // bit i: this lane's halo slot i holds channels >= tail_ch of a chunk
 #pragma unroll
-    for (int i = 0; i < G::DPC; i++) {
-        const int sb = (i * WAVES + wave) * 64;
+    for (int i = 0; i < LD; i++) {
+        const int sb = slot_of(i);
         rel[i] = SENTINEL; hyx[i] = 0x4000u;
+        if (SPLIT && !loader) continue;
         if (sb >= G::NXS_PAD) {
             const int e = sb + lane - G::NXS_PAD;
             const int row = e / G::BM, col = e % G::BM;
@@ -221,12 +234,12 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_mfma16(Conv16Params p) {
 
     // ---- tile descriptors: [parity] of the tile being multiplied / the next one
     int d_z0 = 0, d_z1 = 0, d_n0 = 0, d_n1 = 0, d_oy00 = 0, d_oy01 = 0, d_ox00 = 0, d_ox01 = 0, d_m00 = 0, d_m01 = 0;      // (explicit pairs: a runtime-indexed array would live in scratch)
-    unsigned voff[G::DPC];                                // DMA offsets of the tile being requested (halo lanes; weight lanes = rel)
+    unsigned voff[LD];                                    // DMA offsets of the tile being requested (halo lanes; weight lanes = rel)
     unsigned w_soff = 0, x_soff0 = 0;
 
     // Tile -> (n, tile_y, tile_x, m-block[, K share]), XCD-aware: workgroups that share an XCD (id % 8) walk one contiguous
     // range of logical tiles, so adjacent halos and the weight slabs hit the same L2.  All of it runs on the scalar unit.
-    auto prep_tile = [&](int tile, int par) __attribute__((always_inline)) {
+    auto prep_tile = [&](int tile, int par, const bool want_voff = true) __attribute__((always_inline)) {
         const int xcd = tile & 7;
         unsigned L = (unsigned)((xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (tile >> 3));
         int zsl = 0;
@@ -243,13 +256,14 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_mfma16(Conv16Params p) {
         d_oy01 = par ? oy0 : d_oy01; d_oy00 = par ? d_oy00 : oy0;
         d_ox01 = par ? ox0 : d_ox01; d_ox00 = par ? d_ox00 : ox0;
         d_m01 = par ? m0 : d_m01;  d_m00 = par ? d_m00 : m0;
+        if (!want_voff) return;                           // (SPLIT: the multiplying waves only need the coordinates, for their epilogue)
         // halo: source offset = tile origin + rel; lanes outside the image (border tiles only) get the sentinel
         const int ty0 = oy0 * S - p.pad_y, tx0 = ox0 * S - p.pad_x;
         const unsigned org = (unsigned)((ty0 * p.W + tx0) * p.xC * 2);
         const bool interior = ty0 >= 0 && tx0 >= 0 && ty0 + G::IH_T <= p.H && tx0 + G::IW_T <= p.W;      // wave-uniform
 #pragma unroll
-        for (int i = 0; i < G::DPC; i++) {
-            const int sb = (i * WAVES + wave) * 64;
+        for (int i = 0; i < LD; i++) {
+            const int sb = slot_of(i);
             if (sb < G::NXS_PAD) {                        // wave-uniform
                 if (interior) {
                     voff[i] = org + rel[i];               // padding slots: org + 2^31 stays out of range (0 <= org < 2^31)
@@ -271,22 +285,28 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_mfma16(Conv16Params p) {
     // (the host checks phase_cout % BM == 0).
     const int pc = p.f.phase_cout, ce = pc ? pc : p.Cout;
     auto phase_of = [&](int m0) __attribute__((always_inline)) { return pc ? (int)(m0 >= pc) + (int)(m0 >= 2 * pc) + (int)(m0 >= 3 * pc) : 0; };
-    const bool side_scale = wave < G::EPS / 64, side_bias = !side_scale && wave < 2 * (G::EPS / 64);
+    static_assert(!SPLIT || 2 * (G::EPS / 64) <= LOADERS, "per-cout side vectors: one 64-float DMA per loader wave");
+    const int sw = SPLIT ? lw : wave;                     // the wave index the side loads are dealt out by
+    const bool side_scale = sw < G::EPS / 64, side_bias = !side_scale && sw < 2 * (G::EPS / 64);
     const i32x4 sbrsrc = side_scale ? make_rsrc(p.f.out_scale, p.f.out_scale ? (int64_t)p.N * ce * 4 : 0)
                                     : make_rsrc(p.f.bias, (p.f.bias && side_bias) ? (int64_t)ce * 4 : 0);
     const i32x4 nrsrc = make_rsrc(p.f.noise, p.f.noise ? ((int64_t)(p.N - 1) * p.f.noise_batch_stride + (pc ? 3 * p.f.noise_phase_stride : 0) + (int64_t)p.OH * p.OW) * 4 : 0);
-    const unsigned side_rel = (unsigned)((wave * 64 + lane) % G::EPS) * 4u;                 // + m0 * 4 (+ n * Cout * 4 for the scales)
-    const int noise_dy = t / G::TW, noise_dx = t % G::TW;                                   // this thread's pixel of the tile
+    const unsigned side_rel = (unsigned)((sw * 64 + lane) % G::EPS) * 4u;                   // + m0 * 4 (+ n * Cout * 4 for the scales)
     auto issue_side = [&](int par) __attribute__((always_inline)) {
         const int n = par ? d_n1 : d_n0, oy0 = par ? d_oy01 : d_oy00, ox0 = par ? d_ox01 : d_ox00, m0 = par ? d_m01 : d_m00;
         const unsigned sb_ = side_b + (unsigned)(par * G::EP_FLOATS) * 4u;
         const int ph = phase_of(m0), mc0 = m0 - ph * pc;
         const bool live = (side_scale || side_bias) && mc0 + (int)(side_rel >> 2) < ce;
-        dma4(sbrsrc, (side_scale || side_bias) ? sb_ + (unsigned)(wave * 64) * 4u : dump_b, live ? side_rel : SENTINEL,
+        dma4(sbrsrc, (side_scale || side_bias) ? sb_ + (unsigned)(sw * 64) * 4u : dump_b, live ? side_rel : SENTINEL,
              (unsigned)(mc0 + (side_scale ? n * ce : 0)) * 4u);
-        const int ny = oy0 + noise_dy, nx = ox0 + noise_dx;
-        const unsigned noise_voff = (t < G::TH * G::TW && ny < p.OH && nx < p.OW) ? (unsigned)(ny * p.OW + nx) * 4u : SENTINEL;
-        dma4(nrsrc, sb_ + (unsigned)(2 * G::EPS + wave * 64) * 4u, noise_voff, (unsigned)(n * p.f.noise_batch_stride + ph * p.f.noise_phase_stride) * 4u);
+        // the tile's noise samples, one per pixel: every thread one (one-role form), every loader thread two
+#pragma unroll
+        for (int j = 0; j < (SPLIT ? WAVES / LOADERS : 1); j++) {
+            const int vw = SPLIT ? j * LOADERS + lw : wave, tt = vw * 64 + lane;
+            const int ny = oy0 + tt / G::TW, nx = ox0 + tt % G::TW;
+            const unsigned noise_voff = (tt < G::TH * G::TW && ny < p.OH && nx < p.OW) ? (unsigned)(ny * p.OW + nx) * 4u : SENTINEL;
+            dma4(nrsrc, sb_ + (unsigned)(2 * G::EPS + vw * 64) * 4u, noise_voff, (unsigned)(n * p.f.noise_batch_stride + ph * p.f.noise_phase_stride) * 4u);
+        }
     };
 
     // ---- the chunk stream
@@ -297,9 +317,9 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_mfma16(Conv16Params p) {
     int dpar = 0;                                         // descriptor parity of the tile being multiplied
 
     auto issue_next = [&]() __attribute__((always_inline)) {
-        if (c_done || (c_chunk == 0 && c_ahead > 1)) return;
+        if (c_done || (!SPLIT && c_chunk == 0 && c_ahead > 1)) return;
         if (c_chunk == 0) {
-            const int par = dpar ^ (c_ahead & 1);
+            const int par = SPLIT ? (c_ahead & 1) : dpar ^ (c_ahead & 1);      // (SPLIT: c_ahead counts the tiles requested so far)
             prep_tile(c_tile, par);
             if (!(p.dbg & 16)) issue_side(par);
         }
@@ -309,8 +329,8 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_mfma16(Conv16Params p) {
         const unsigned wk_soff = w_soff + (unsigned)((c0 / 16) * G::T * 2) * (unsigned)p.CoutP * 16u;
         const unsigned buf_b = smem_b + (unsigned)(ibuf * G::LDS_BUF) * 16u;
 #pragma unroll
-        for (int i = 0; i < G::DPC; i++) {
-            const int sb = (i * WAVES + wave) * 64;
+        for (int i = 0; i < LD; i++) {
+            const int sb = slot_of(i);
             const bool is_w = sb >= G::NXS_PAD;           // wave-uniform
             unsigned vo = is_w ? rel[i] : voff[i];
             if (partial && ((tailmask >> i) & 1)) vo = SENTINEL;
@@ -399,48 +419,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_mfma16(Conv16Params p) {
     const float noise_gain = p.f.noise ? p.f.noise_gain : 0.f;
     constexpr int EP_STORES = MT * NT * 2;                // 16-byte stores of the vector epilogue per wave
 
-    // One loop, one issue site: the first NBUF - 1 passes only fill the pipeline (`it` < 0), every later pass waits for the oldest
-    // chunk in flight, requests one more and multiplies; a tile's epilogue runs in the pass of its last chunk.
-    int tile = blockIdx.x;
-    int k_cur = 0;
-    bool after_ep = false;
-#pragma unroll
-    for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-        for (int nt = 0; nt < NT; nt++)
-#pragma unroll
-            for (int k = 0; k < 16; k++) acc[mt][nt][k] = 0.f;
-    int n_stamp = 0;
-    auto stamp = [&](int tag) __attribute__((always_inline)) {
-        if ((p.dbg & 32) && blockIdx.x == 0 && wave == (p.dbg >> 8) && n_stamp < 4000) {
-            const unsigned long long tm = __builtin_amdgcn_s_memtime();
-            if (lane == 0) p.stamps[n_stamp] = (tm << 8) | (unsigned)tag;
-            n_stamp++;
-        }
-    };
-#pragma unroll 1
-    for (int it = -(G::NBUF - 1);; it++) {
-        stamp(1);
-        if (it >= 0) {
-            // chunk `cbuf` must have landed: everything younger in this wave's queue may stay in flight -- the next chunk's
-            // DMAs (inflight == 2) and, right after a tile's vector epilogue, its stores
-            if (inflight > 1) { if (after_ep && p.out_mode == OUT_VEC16) vm_wait<G::DPC + EP_STORES>(); else vm_wait<G::DPC>(); }
-            else              { if (after_ep && p.out_mode == OUT_VEC16) vm_wait<EP_STORES>(); else vm_wait<0>(); }
-            after_ep = false;
-            stamp(2);
-            __builtin_amdgcn_s_barrier();                  // every wave's share has landed; every wave is done with the buffer requested next
-            stamp(3);
-        }
-        issue_next();
-        stamp(4);
-        if (it < 0) continue;
-        if (!(p.dbg & 4)) compute_chunk(cbuf);
-        stamp(5);
-        cbuf = cbuf == G::NBUF - 1 ? 0 : cbuf + 1;
-        inflight--;
-        if (++k_cur < nchunks) continue;
-        k_cur = 0;
-
+    auto write_tile = [&]() __attribute__((always_inline)) {
         // ---- epilogue: D col = lane & 31 (pixel), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) (cout)
         const int e_z = dpar ? d_z1 : d_z0;
         const int e_n = dpar ? d_n1 : d_n0, e_oy0 = dpar ? d_oy01 : d_oy00, e_ox0 = dpar ? d_ox01 : d_ox00, e_mt0 = dpar ? d_m01 : d_m00;
@@ -450,29 +429,12 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_mfma16(Conv16Params p) {
         // per-cout constants of this lane's rows, gain folded in: v = clamp(act(acc * scale + noise + bias) * gain) with a
         // positively homogeneous activation (linear / relu / lrelu, gain > 0) is med3(max(u, u * slope), -cl, cl),
         // u = acc * (scale * gain) + (bias + noise) * gain  --  one fma, one multiply, one max, one median per value
-        f32x4 sg[MT][4], bg[MT][4];
-#pragma unroll
-        for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-            for (int g = 0; g < 4; g++) {
-                const int r0 = (wmx * MT + mt) * 32 + 8 * g + 4 * half;
-                sg[mt][g] = *(lds_f4)(side + (size_t)r0 * 4);
-                bg[mt][g] = *(lds_f4)(side + (size_t)(G::EPS + r0) * 4);
-            }
         float nzv[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; nt++) {
             const int row_l = (wpx * NT + nt) * G::RP + l31 / TWL, col_l = l31 % TWL;
             nzv[nt] = *(lds_f)(side + (size_t)(2 * G::EPS + row_l * G::TW + col_l) * 4);
         }
-#pragma unroll
-        for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-            for (int g = 0; g < 4; g++) {
-                if (has_scale) sg[mt][g] = sg[mt][g] * gain;
-                else sg[mt][g] = f32x4{gain, gain, gain, gain};
-                bg[mt][g] = bg[mt][g] * gain;
-            }
 #pragma unroll
         for (int nt = 0; nt < NT; nt++) {
             if (p.dbg & 8) break;
@@ -486,12 +448,19 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_mfma16(Conv16Params p) {
                 const int mloc = (wmx * MT + mt) * 32;
                 float v[16];
 #pragma unroll
-                for (int g = 0; g < 4; g++)
+                for (int g = 0; g < 4; g++) {
+                    // (read where they are used -- 2 x 16 bytes of LDS per 4 values: held for the whole tile they were 64 registers,
+                    // which the three-waves-per-SIMD form of the kernel does not have)
+                    const int r0 = mloc + 8 * g + 4 * half;
+                    f32x4 sgv = *(lds_f4)(side + (size_t)r0 * 4), bgv = *(lds_f4)(side + (size_t)(G::EPS + r0) * 4);
+                    sgv = has_scale ? sgv * gain : f32x4{gain, gain, gain, gain};
+                    bgv = bgv * gain;
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
-                        const float u = fmaf(acc[mt][nt][4 * g + j], sg[mt][g][j], bg[mt][g][j] + nz);
+                        const float u = fmaf(acc[mt][nt][4 * g + j], sgv[j], bgv[j] + nz);
                         v[4 * g + j] = __builtin_amdgcn_fmed3f(fmaxf(u, u * slope), -cl, cl);
                     }
+                }
                 if (p.out_mode == OUT_VEC16) {
                     // ys[1] == 1, Cout % 8 == 0: 8 consecutive couts of one pixel per lane after the half-wave exchange
                     const unsigned short* rp = (const unsigned short*)p.f.residual;
@@ -553,6 +522,88 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_mfma16(Conv16Params p) {
                 }
             }
         }
+    };
+
+    // One loop, one issue site: the first NBUF - 1 passes only fill the pipeline (`it` < 0), every later pass waits for the oldest
+    // chunk in flight, requests one more and multiplies; a tile's epilogue runs in the pass of its last chunk.
+    int tile = blockIdx.x;
+    int k_cur = 0;
+    bool after_ep = false;
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+            for (int k = 0; k < 16; k++) acc[mt][nt][k] = 0.f;
+    int n_stamp = 0;
+    auto stamp = [&](int tag) __attribute__((always_inline)) {
+        if ((p.dbg & 32) && blockIdx.x == 0 && wave == (p.dbg >> 8) && n_stamp < 4000) {
+            const unsigned long long tm = __builtin_amdgcn_s_memtime();
+            if (lane == 0) p.stamps[n_stamp] = (tm << 8) | (unsigned)tag;
+            n_stamp++;
+        }
+    };
+    if constexpr (SPLIT) {
+        // chunks this workgroup multiplies: its tiles blockIdx.x, blockIdx.x + gridDim.x, ... x nchunks; chunk c lives in staging buffer c % NBUF.
+        // Barrier c (one per chunk, all twelve waves) says: chunk c has landed, everybody is done with chunk c - 1.
+        const int my_chunks = ((total - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x) * nchunks;
+        if (loader) {
+            int req = 0;
+            issue_next(); req++;                                        // (the host only launches this form with nchunks >= 2)
+            issue_next(); req++;
+            for (int c = 0; c < my_chunks; c++) {
+                // chunk c must have landed; what is younger in this wave's queue -- chunk c + 1's requests (and, in front of them, the
+                // side loads of its tile when it is a tile's first chunk) -- may stay in flight
+                if (req > c + 1) vm_wait<LD>(); else vm_wait<0>();
+                __builtin_amdgcn_s_barrier();
+                if (req < my_chunks) { issue_next(); req++; }           // into the buffer of chunk c - 1: every multiplying wave is past it
+            }
+            return;
+        }
+        for (;;) {
+            for (int k = 0; k < nchunks; k++) {
+                __builtin_amdgcn_s_barrier();
+                if (!(p.dbg & 4)) compute_chunk(cbuf);
+                cbuf = cbuf == G::NBUF - 1 ? 0 : cbuf + 1;
+            }
+            prep_tile(tile, dpar, false);                               // coordinates of this tile for the epilogue (scalar unit)
+            write_tile();
+            if (tile + (int)gridDim.x >= total) break;
+            tile += gridDim.x;
+            dpar ^= 1;
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+                    for (int k = 0; k < 16; k++) acc[mt][nt][k] = 0.f;
+        }
+        return;
+    }
+#pragma unroll 1
+    for (int it = -(G::NBUF - 1);; it++) {
+        stamp(1);
+        if (it >= 0) {
+            // chunk `cbuf` must have landed: everything younger in this wave's queue may stay in flight -- the next chunk's
+            // DMAs (inflight == 2) and, right after a tile's vector epilogue, its stores
+            if (inflight > 1) { if (after_ep && p.out_mode == OUT_VEC16) vm_wait<G::DPC + EP_STORES>(); else vm_wait<G::DPC>(); }
+            else              { if (after_ep && p.out_mode == OUT_VEC16) vm_wait<EP_STORES>(); else vm_wait<0>(); }
+            after_ep = false;
+            stamp(2);
+            __builtin_amdgcn_s_barrier();                  // every wave's share has landed; every wave is done with the buffer requested next
+            stamp(3);
+        }
+        issue_next();
+        stamp(4);
+        if (it < 0) continue;
+        if (!(p.dbg & 4)) compute_chunk(cbuf);
+        stamp(5);
+        cbuf = cbuf == G::NBUF - 1 ? 0 : cbuf + 1;
+        inflight--;
+        if (++k_cur < nchunks) continue;
+        k_cur = 0;
+
+        write_tile();
         after_ep = true;
         stamp(6);
         if (tile + (int)gridDim.x >= total) break;
@@ -568,7 +619,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv2d_mfma16(Conv16Params p) {
     }
 }
 
-template <typename T, int KH, int KW, int S, int TWL, int WM, int MT, int NT, int KC, int NB>
+template <typename T, int KH, int KW, int S, int TWL, int WM, int MT, int NT, int KC, int NB, bool SPLIT = false>
 int launch16(const Conv16Params& p0, hipStream_t s) {
     typedef Geo16<KH, KW, S, TWL, WM, MT, NT, KC, NB> G;
     Conv16Params p = p0;
@@ -586,11 +637,16 @@ int launch16(const Conv16Params& p0, hipStream_t s) {
     p.m_tilesX = magic(p.tilesX); p.m_tilesY = magic(p.tilesY); p.m_mblocks = magic(p.mblocks); p.m_ksplit = magic(p.ksplit);
     if ((int64_t)p.N * p.H * p.W * p.xC * 2 > 0x7fffffffLL) return PG_ERR_TOO_LARGE;      // whole-tensor descriptor of x
     const int64_t blocks = tiles < (int64_t)num_cu() ? tiles : (int64_t)num_cu();       // persistent: one workgroup per CU
-    auto kern = conv2d_mfma16<T, KH, KW, S, TWL, WM, MT, NT, KC, NB>;
+    if constexpr (KH == 3 && KW == 3 && S == 1 && NB == 3 && !SPLIT && TWL > 8) {      // the two-role form (see the kernel): >= 2 chunks per tile; (the 8 x 8-pixel tile of the 8^2 layers measured slower with it: 44.5 vs 36.5 us)
+        static const bool split_on = [] { const char* e = getenv("PG_CONV16_SPLIT"); return e ? atoi(e) != 0 : true; }();       // A/B switch
+        const int cin_loop = p.ksplit > 1 ? p.kpart : p.Cin;
+        if (split_on && (cin_loop + KC - 1) / KC >= 2) return launch16<T, KH, KW, S, TWL, WM, MT, NT, KC, NB, true>(p0, s);
+    }
+    auto kern = conv2d_mfma16<T, KH, KW, S, TWL, WM, MT, NT, KC, NB, SPLIT>;
     static PerDeviceOnce lds_attr;
     const hipError_t e = lds_attr.run([&] { return hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(THREADS), G::LDS_BYTES, s, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(SPLIT ? THREADS + 64 * LOADERS : THREADS), G::LDS_BYTES, s, p);
     return launch_status();
 }
 

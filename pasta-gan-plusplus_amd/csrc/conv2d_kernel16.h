@@ -142,7 +142,8 @@ struct Geo16 {
     static constexpr int PER = 16 / SLOTS;                // pixels per 256-byte LDS bank row
     static constexpr int KS = KC / 16;                    // MFMA k-steps per tap per chunk
     static constexpr int NXS = IH_T * IW_T * SLOTS;       // halo slots
-    static constexpr int NXS_PAD = (NXS + 63) / 64 * 64;  // the halo / weight boundary is wave-instruction aligned
+    static constexpr int NXS_PAD = (NXS + 255) / 256 * 256;  // the halo / weight boundary is aligned to FOUR wave-instructions: in the two-role form
+                                                          // instruction i2 of every loader wave is then on the same side of it (a compile-time fact per i2)
     static constexpr int NWS = KS * T * 2 * BM;           // weight slots
     static constexpr int DPC = (NXS_PAD + NWS + THREADS - 1) / THREADS;      // DMA instructions per thread per chunk
     static constexpr int LDS_BUF = DPC * THREADS;         // slots
@@ -189,6 +190,8 @@ __global__ __launch_bounds__(SPLIT ? THREADS + 64 * LOADERS : THREADS, SPLIT ? 3
     // request instruction i2 of a chunk, as issued by this thread: the one-role form's instruction i of wave vw (same slots, same maps)
     constexpr int LD = SPLIT ? 2 * G::DPC : G::DPC;
     auto slot_of = [&](int i2) __attribute__((always_inline)) { return SPLIT ? ((i2 >> 1) * WAVES + (i2 & 1) * LOADERS + lw) * 64 : (i2 * WAVES + wave) * 64; };
+    // is request i2 a weight-slab request?  wave-uniform; in the two-role form a constant per i2 (NXS_PAD is a multiple of 256 slots)
+    auto is_weight = [&](int i2) __attribute__((always_inline)) { return SPLIT ? ((i2 >> 1) * WAVES + (i2 & 1) * LOADERS) * 64 >= G::NXS_PAD : slot_of(i2) >= G::NXS_PAD; };
     const int total = p.total_tiles;
     const int q8 = total >> 3, r8 = total & 7;
     const int cin_loop = p.ksplit > 1 ? p.kpart : p.Cin;  // channels one workgroup reduces per tile
@@ -210,12 +213,12 @@ __global__ __launch_bounds__(SPLIT ? THREADS + 64 * LOADERS : THREADS, SPLIT ? 3
     //   hyx[i]  halo coordinates (row | col << 16) for the border test; rows >= 0x4000 never pass it
     unsigned rel[LD], hyx[LD];
     unsigned tailmask = 0;                                // bit i: this lane's halo slot i holds channels >= tail_ch of a chunk
+    auto setup_maps = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < LD; i++) {
         const int sb = slot_of(i);
         rel[i] = SENTINEL; hyx[i] = 0x4000u;
-        if (SPLIT && !loader) continue;
-        if (sb >= G::NXS_PAD) {
+        if (is_weight(i)) {
             const int e = sb + lane - G::NXS_PAD;
             const int row = e / G::BM, col = e % G::BM;
             if (e < G::NWS) rel[i] = (unsigned)(row * p.CoutP + col) * 16u;
@@ -231,6 +234,9 @@ __global__ __launch_bounds__(SPLIT ? THREADS + 64 * LOADERS : THREADS, SPLIT ? 3
             if (tail_ch && c * 8 >= tail_ch) tailmask |= 1u << i;
         }
     }
+
+    };
+    if constexpr (!SPLIT) setup_maps();               // (two-role form: by the loader waves, after the roles part -- the maps must not be live in the multiplying waves' code)
 
     // ---- tile descriptors: [parity] of the tile being multiplied / the next one
     int d_z0 = 0, d_z1 = 0, d_n0 = 0, d_n1 = 0, d_oy00 = 0, d_oy01 = 0, d_ox00 = 0, d_ox01 = 0, d_m00 = 0, d_m01 = 0;      // (explicit pairs: a runtime-indexed array would live in scratch)
@@ -263,8 +269,7 @@ __global__ __launch_bounds__(SPLIT ? THREADS + 64 * LOADERS : THREADS, SPLIT ? 3
         const bool interior = ty0 >= 0 && tx0 >= 0 && ty0 + G::IH_T <= p.H && tx0 + G::IW_T <= p.W;      // wave-uniform
 #pragma unroll
         for (int i = 0; i < LD; i++) {
-            const int sb = slot_of(i);
-            if (sb < G::NXS_PAD) {                        // wave-uniform
+            if (!is_weight(i)) {                          // wave-uniform
                 if (interior) {
                     voff[i] = org + rel[i];               // padding slots: org + 2^31 stays out of range (0 <= org < 2^31)
                 } else {
@@ -331,7 +336,7 @@ __global__ __launch_bounds__(SPLIT ? THREADS + 64 * LOADERS : THREADS, SPLIT ? 3
 #pragma unroll
         for (int i = 0; i < LD; i++) {
             const int sb = slot_of(i);
-            const bool is_w = sb >= G::NXS_PAD;           // wave-uniform
+            const bool is_w = is_weight(i);               // wave-uniform
             unsigned vo = is_w ? rel[i] : voff[i];
             if (partial && ((tailmask >> i) & 1)) vo = SENTINEL;
             if (!is_w && (p.dbg & 2)) vo = SENTINEL;
@@ -529,12 +534,14 @@ __global__ __launch_bounds__(SPLIT ? THREADS + 64 * LOADERS : THREADS, SPLIT ? 3
     int tile = blockIdx.x;
     int k_cur = 0;
     bool after_ep = false;
+    if (!loader) {                                        // (two-role form: the loader waves must not carry 64 accumulator registers around)
 #pragma unroll
-    for (int mt = 0; mt < MT; mt++)
+        for (int mt = 0; mt < MT; mt++)
 #pragma unroll
-        for (int nt = 0; nt < NT; nt++)
+            for (int nt = 0; nt < NT; nt++)
 #pragma unroll
-            for (int k = 0; k < 16; k++) acc[mt][nt][k] = 0.f;
+                for (int k = 0; k < 16; k++) acc[mt][nt][k] = 0.f;
+    }
     int n_stamp = 0;
     auto stamp = [&](int tag) __attribute__((always_inline)) {
         if ((p.dbg & 32) && blockIdx.x == 0 && wave == (p.dbg >> 8) && n_stamp < 4000) {
@@ -548,26 +555,35 @@ __global__ __launch_bounds__(SPLIT ? THREADS + 64 * LOADERS : THREADS, SPLIT ? 3
         // Barrier c (one per chunk, all twelve waves) says: chunk c has landed, everybody is done with chunk c - 1.
         const int my_chunks = ((total - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x) * nchunks;
         if (loader) {
+            setup_maps();
             int req = 0;
             issue_next(); req++;                                        // (the host only launches this form with nchunks >= 2)
             issue_next(); req++;
             for (int c = 0; c < my_chunks; c++) {
                 // chunk c must have landed; what is younger in this wave's queue -- chunk c + 1's requests (and, in front of them, the
                 // side loads of its tile when it is a tile's first chunk) -- may stay in flight
+                stamp(1);
                 if (req > c + 1) vm_wait<LD>(); else vm_wait<0>();
+                stamp(2);
                 __builtin_amdgcn_s_barrier();
+                stamp(3);
                 if (req < my_chunks) { issue_next(); req++; }           // into the buffer of chunk c - 1: every multiplying wave is past it
+                stamp(4);
             }
             return;
         }
         for (;;) {
             for (int k = 0; k < nchunks; k++) {
+                stamp(1);
                 __builtin_amdgcn_s_barrier();
+                stamp(3);
                 if (!(p.dbg & 4)) compute_chunk(cbuf);
+                stamp(5);
                 cbuf = cbuf == G::NBUF - 1 ? 0 : cbuf + 1;
             }
             prep_tile(tile, dpar, false);                               // coordinates of this tile for the epilogue (scalar unit)
             write_tile();
+            stamp(6);
             if (tile + (int)gridDim.x >= total) break;
             tile += gridDim.x;
             dpar ^= 1;

@@ -18,7 +18,7 @@ for arg in sys.argv[1:] or ['4,32,32,1024,3']:
     w = torch.randn(cout, cin, K, K, device='cuda') / (K * cin ** 0.5)
     pk, _, _ = M.pack_weight(w, dt)
     bias = torch.randn(cout, device='cuda')
-    for wv in (0, 5):
+    for wv in (0, 5, 8):
         os.environ['PG_CONV16_DBG'] = str(32 | (wv << 8))
         buf.zero_()
         M.conv2d_forward(x, pk, cout, K, K, pad=(K // 2, K // 2), bias=bias, act='lrelu', alpha=0.2, gain=1.4, clamp=256)

@@ -31,4 +31,6 @@ for arg in sys.argv[1:] or ['4,32,32,1024,3']:
         for (a, b), v in sorted(seg.items()):
             v2 = v[len(v) // 4:]
             print(f'   {names[a]:>15} -> {names[b]:<15} n={len(v):4d} mean={sum(v2) / len(v2):8.0f} min={min(v2):6d} max={max(v2):7d}')
+            if wv >= 8 and (a, b) == (3, 4):
+                print('      per pass:', ' '.join(str(x) for x in v))
     os.environ['PG_CONV16_DBG'] = '0'

@@ -44,19 +44,20 @@ def main(rnd, commit=None):
         except OSError:
             print('missing traffic', tag)
             continue
-        algo = None
+        algo = per_step = None
         bj = os.path.join(G, f'bench_{tag}.json')
         if os.path.isfile(bj):
             try:
                 line = json.loads(open(bj).read().strip().splitlines()[-1])
                 algo = line['roofline'].get('algorithmic_bytes_per_launch')
+                per_step = line['roofline'].get('launches_per_step')
             except (ValueError, KeyError, IndexError):
                 pass
         fetch, write = 2.0 * 1024 * sum(rd) / max(len(rd), 1), 1024 * sum(wr) / max(len(wr), 1)
-        out = dict(kernel=kernel, measured_on=stamp, launches_per_step=len(rd), fetch_bytes_per_launch=fetch, write_bytes_per_launch=write,
+        out = dict(kernel=kernel, measured_on=stamp, launches_per_step=per_step, launches_sampled=len(rd), fetch_bytes_per_launch=fetch, write_bytes_per_launch=write,
                    hbm_bytes_per_launch=fetch + write, algorithmic_bytes_per_launch=algo,
                    note='rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over bench.py --steps 1 (tools/traffic_run.sh); FETCH_SIZE '
-                        'doubled per the gfx950 correction of MI355X_MICROARCH.md; per launch = mean over that kernel\'s launches of the timed step')
+                        'doubled per the gfx950 correction of MI355X_MICROARCH.md; per launch = mean over that kernel\'s launches in the second half of the profiled process (launches_sampled; config 5 runs an eager and a graph pass there); launches_per_step is bench.py\'s count')
         with open(pre + f'traffic_{tag}.json', 'w') as f:
             json.dump(out, f, indent=1)
         print('wrote', os.path.relpath(pre + f'traffic_{tag}.json', ROOT), f'{(fetch + write) / 1e6:.1f} MB/launch')

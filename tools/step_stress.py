@@ -1,4 +1,4 @@
-"""Dev tool (GPU box): the config-2 step (and the config-3 generator) repeated under load; every kernel on the path is deterministic,
+"""Dev tool (GPU box): the config-2 step and the config-5 bf16 stack repeated under load; every kernel on the path is deterministic,
 so any output that differs from the first pass is a race (that is how the F(4x4) tail race of round 3 showed up: 20 % of full-size
 launches wrong while every small test passed).
     python tools/step_stress.py [passes]"""
@@ -33,3 +33,22 @@ for n in (8, 3):
                     d = [float((a - b).abs().max()) for a, b in zip(ref, out)]
                     print(f'   pass {it}: outputs differ from the first pass: max |d| per output {d}', flush=True)
     print(f'config 2, N={n}: {bad} of {passes} passes differ from the first ({len(ref)} outputs compared bit for bit)', flush=True)
+
+# config 5: the bf16 1024^2 stack (two-role 16-bit kernel, split-K, four-phase launches), fp16 as well
+from detgen import fill_module_
+for half in (torch.bfloat16, torch.float16):
+    stack = fill_module_(networks.SynthesisStack(num_fp16_res=8, half_dtype=half, channel_max=1024, **bench.CFG5), 'cfg5.').to(dev).eval()
+    ws = torch.randn([4, stack.num_ws, 512], generator=torch.Generator().manual_seed(3)).to(dev)
+    other = torch.randn(64, 64, 256, 256, device=dev)
+    with torch.no_grad():
+        ref = stack(ws, noise_mode='const').clone()
+        bad = 0
+        for it in range(passes):
+            if it % 4 == 1:
+                other.mul_(1.0001)
+            out = stack(ws, noise_mode='const')
+            if not torch.equal(ref, out):
+                bad += 1
+                if bad <= 3:
+                    print(f'   pass {it}: max |d| {float((ref.float() - out.float()).abs().max()):.3e}', flush=True)
+    print(f'config 5 ({half}), N=4: {bad} of {passes} passes differ from the first', flush=True)

@@ -118,6 +118,10 @@ __device__ __forceinline__ void dma4(i32x4 rsrc, unsigned lds_byte, unsigned vof
 }
 template <int N> __device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" :: "i"(N) : "memory"); }
 
+#ifndef PG_CONV16_STAMPS
+#define PG_CONV16_STAMPS 0       // 1 (tools/conv16_stamps.py / conv16_ablate.py build their own plugin with it): the PG_CONV16_DBG switches -- ablations, s_memtime
+                                 // stamps of one wave; in the product build they are compiled out (the stamp checks alone were 2 % of config 5)
+#endif
 constexpr unsigned SENTINEL = 0x80000000u;
 
 __device__ __forceinline__ i32x4 make_rsrc(const void* base, int64_t bytes) {
@@ -171,6 +175,7 @@ __device__ __forceinline__ unsigned div_magic(unsigned L, unsigned M) { return M
 constexpr int LOADERS = 4;
 template <typename T, int KH, int KW, int S, int TWL, int WM, int MT, int NT, int KC, int NB, bool SPLIT = false>
 __global__ __launch_bounds__(SPLIT ? THREADS + 64 * LOADERS : THREADS, SPLIT ? 3 : 2) void conv2d_mfma16(Conv16Params p) {
+    const int dbg_ = PG_CONV16_STAMPS ? p.dbg : 0;      // the dev switches exist in the diagnostic build only (PG_CONV16_STAMPS)
     typedef Geo16<KH, KW, S, TWL, WM, MT, NT, KC, NB> G;
     typedef Half16<T> HT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -326,7 +331,7 @@ __global__ __launch_bounds__(SPLIT ? THREADS + 64 * LOADERS : THREADS, SPLIT ? 3
         if (c_chunk == 0) {
             const int par = SPLIT ? (c_ahead & 1) : dpar ^ (c_ahead & 1);      // (SPLIT: c_ahead counts the tiles requested so far)
             prep_tile(c_tile, par);
-            if (!(p.dbg & 16)) issue_side(par);
+            if (!(dbg_ & 16)) issue_side(par);
         }
         const int c0 = c_chunk * KC;
         const bool partial = tail_ch != 0 && c_chunk == nchunks - 1;
@@ -339,7 +344,7 @@ __global__ __launch_bounds__(SPLIT ? THREADS + 64 * LOADERS : THREADS, SPLIT ? 3
             const bool is_w = is_weight(i);               // wave-uniform
             unsigned vo = is_w ? rel[i] : voff[i];
             if (partial && ((tailmask >> i) & 1)) vo = SENTINEL;
-            if (!is_w && (p.dbg & 2)) vo = SENTINEL;
+            if (!is_w && (dbg_ & 2)) vo = SENTINEL;
             dma16(is_w ? wrsrc : xrsrc, buf_b + (unsigned)sb * 16u, vo, is_w ? wk_soff : x_soff);
         }
         ibuf = ibuf == G::NBUF - 1 ? 0 : ibuf + 1;
@@ -442,7 +447,7 @@ __global__ __launch_bounds__(SPLIT ? THREADS + 64 * LOADERS : THREADS, SPLIT ? 3
         }
 #pragma unroll
         for (int nt = 0; nt < NT; nt++) {
-            if (p.dbg & 8) break;
+            if (dbg_ & 8) break;
             const int row_l = (wpx * NT + nt) * G::RP + l31 / TWL, col_l = l31 % TWL;
             const int oy = e_oy0 + row_l, ox = e_ox0 + col_l;
             const bool pix_ok = oy < p.OH && ox < p.OW;
@@ -495,7 +500,7 @@ __global__ __launch_bounds__(SPLIT ? THREADS + 64 * LOADERS : THREADS, SPLIT ? 3
                             a[d] = r[0]; b[d] = r[1];
                         }
                         const int co = e_m0 + mloc + 8 * (g0 + half);
-                        const unsigned so = (pix_ok && co < ce && !(p.dbg & 1)) ? (unsigned)(pix_off + co) * 2u : SENTINEL;
+                        const unsigned so = (pix_ok && co < ce && !(dbg_ & 1)) ? (unsigned)(pix_off + co) * 2u : SENTINEL;
                         __builtin_amdgcn_raw_buffer_store_b128(u32x4{a[0], a[1], b[0], b[1]}, yrsrc, (int)so, 0, 0);
                     }
                 } else if (p.out_mode == OUT_VEC32) {
@@ -544,7 +549,7 @@ __global__ __launch_bounds__(SPLIT ? THREADS + 64 * LOADERS : THREADS, SPLIT ? 3
     }
     int n_stamp = 0;
     auto stamp = [&](int tag) __attribute__((always_inline)) {
-        if ((p.dbg & 32) && blockIdx.x == 0 && wave == (p.dbg >> 8) && n_stamp < 4000) {
+        if (PG_CONV16_STAMPS && (dbg_ & 32) && blockIdx.x == 0 && wave == (dbg_ >> 8) && n_stamp < 4000) {
             const unsigned long long tm = __builtin_amdgcn_s_memtime();
             if (lane == 0) p.stamps[n_stamp] = (tm << 8) | (unsigned)tag;
             n_stamp++;
@@ -577,7 +582,7 @@ __global__ __launch_bounds__(SPLIT ? THREADS + 64 * LOADERS : THREADS, SPLIT ? 3
                 stamp(1);
                 __builtin_amdgcn_s_barrier();
                 stamp(3);
-                if (!(p.dbg & 4)) compute_chunk(cbuf);
+                if (!(dbg_ & 4)) compute_chunk(cbuf);
                 stamp(5);
                 cbuf = cbuf == G::NBUF - 1 ? 0 : cbuf + 1;
             }
@@ -612,7 +617,7 @@ __global__ __launch_bounds__(SPLIT ? THREADS + 64 * LOADERS : THREADS, SPLIT ? 3
         issue_next();
         stamp(4);
         if (it < 0) continue;
-        if (!(p.dbg & 4)) compute_chunk(cbuf);
+        if (!(dbg_ & 4)) compute_chunk(cbuf);
         stamp(5);
         cbuf = cbuf == G::NBUF - 1 ? 0 : cbuf + 1;
         inflight--;

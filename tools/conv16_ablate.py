@@ -5,7 +5,14 @@ sys.path.insert(0, os.path.join(ROOT, 'pasta-gan-plusplus_amd'))
 import torch
 from torch_utils import custom_ops
 custom_ops.verbosity = 'none'
-from torch_utils.ops import conv2d_mfma16 as M
+SRC = custom_ops.PLUGIN_SOURCES['conv2d_plugin']
+custom_ops.get_plugin('conv16_stamps', sources=SRC, extra_hipcc_flags=['-DPG_CONV16_STAMPS=1'], build_only=True)      # the product build has no dev switches
+from torch_utils.ops import conv2d_mfma, conv2d_mfma16 as M
+custom_ops.PLUGIN_SOURCES['conv16_stamps'] = SRC
+_orig = custom_ops.get_plugin
+custom_ops.get_plugin = lambda name, **kw: _orig(name, extra_hipcc_flags=['-DPG_CONV16_STAMPS=1'], abi_name='conv2d_plugin', **kw)
+conv2d_mfma._init('conv16_stamps')
+custom_ops.get_plugin = _orig
 dt = torch.bfloat16
 shapes = [(4, 32, 32, 1024, 3), (4, 64, 64, 512, 3), (4, 128, 128, 256, 3), (4, 64, 32, 512, 3), (4, 256, 256, 128, 3), (4, 64, 64, 512, 1)]
 if len(sys.argv) > 1:

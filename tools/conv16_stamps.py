@@ -5,14 +5,23 @@ sys.path.insert(0, os.path.join(ROOT, 'pasta-gan-plusplus_amd'))
 import torch
 from torch_utils import custom_ops
 custom_ops.verbosity = 'none'
-from torch_utils.ops import conv2d_mfma16 as M
+SRC = custom_ops.PLUGIN_SOURCES['conv2d_plugin']
+custom_ops.get_plugin('conv16_stamps', sources=SRC, extra_hipcc_flags=['-DPG_CONV16_STAMPS=1'], build_only=True)      # the product build compiles the stamps out
+if len(sys.argv) > 1 and sys.argv[1] == 'build':
+    sys.exit(0)
+from torch_utils.ops import conv2d_mfma, conv2d_mfma16 as M
+custom_ops.PLUGIN_SOURCES['conv16_stamps'] = SRC
+_orig = custom_ops.get_plugin
+custom_ops.get_plugin = lambda name, **kw: _orig(name, extra_hipcc_flags=['-DPG_CONV16_STAMPS=1'], abi_name='conv2d_plugin', **kw)
+conv2d_mfma._init('conv16_stamps')
+custom_ops.get_plugin = _orig
 lib = M._init()
 buf = torch.zeros(4096, dtype=torch.int64, device='cuda')
 lib.pg_conv2d16_debug_stamps.argtypes = [ctypes.c_void_p]
 lib.pg_conv2d16_debug_stamps(ctypes.c_void_p(buf.data_ptr()))
 dt = torch.bfloat16
 names = {1: 'loop-top', 2: 'after-wait', 3: 'after-barrier', 4: 'after-issue', 5: 'after-compute', 6: 'after-epilogue'}
-for arg in sys.argv[1:] or ['4,32,32,1024,3']:
+for arg in [a for a in sys.argv[1:] if a != 'build'] or ['4,32,32,1024,3']:
     N, cin, cout, H, K = (int(v) for v in arg.split(','))
     x = torch.randn(N, cin, H, H, device='cuda').to(dt).contiguous(memory_format=torch.channels_last)
     w = torch.randn(cout, cin, K, K, device='cuda') / (K * cin ** 0.5)

@@ -134,7 +134,7 @@ __device__ __forceinline__ i32x4 make_rsrc(const void* base, int64_t bytes) {
     return r;
 }
 
-template <int KH, int KW, int S, int TWL, int WM, int MT, int NT, int KC, int NB>
+template <int KH, int KW, int S, int TWL, int WM, int MT, int NT, int KC, int NB, bool SPLIT_G = false>
 struct Geo16 {
     static constexpr int T = KH * KW;
     static constexpr int WP = WAVES / WM;                 // waves along pixels
@@ -150,7 +150,11 @@ struct Geo16 {
                                                           // instruction i2 of every loader wave is then on the same side of it (a compile-time fact per i2)
     static constexpr int NWS = KS * T * 2 * BM;           // weight slots
     static constexpr int DPC = (NXS_PAD + NWS + THREADS - 1) / THREADS;      // DMA instructions per thread per chunk
-    static constexpr int LDS_BUF = DPC * THREADS;         // slots
+    // one staging buffer, in slots.  One-role form: a whole number of 512-thread request instructions.  Two-role form: when halo + weights
+    // are a multiple of 256 slots (one request instruction of the FOUR loader waves) the buffer ends there and the request instructions past
+    // it do not exist -- what lets two 32-channel buffers of the 16 x 32-pixel x 64-cout tile fit into 160 KB
+    static constexpr bool TIGHT = SPLIT_G && (NXS_PAD + NWS) % 256 == 0;
+    static constexpr int LDS_BUF = TIGHT ? NXS_PAD + NWS : DPC * THREADS;
     static constexpr int NBUF = NB;                       // staging buffers; NBUF - 1 chunks in flight
     static constexpr int EPS = (BM + 63) / 64 * 64;       // per-cout constants: [scale EPS][bias EPS] floats
     static constexpr int EP_FLOATS = 2 * EPS + THREADS;   // + the tile's noise samples; one extra 64-float pad for idle waves
@@ -176,7 +180,7 @@ constexpr int LOADERS = 4;
 template <typename T, int KH, int KW, int S, int TWL, int WM, int MT, int NT, int KC, int NB, bool SPLIT = false>
 __global__ __launch_bounds__(SPLIT ? THREADS + 64 * LOADERS : THREADS, SPLIT ? 3 : 2) void conv2d_mfma16(Conv16Params p) {
     const int dbg_ = PG_CONV16_STAMPS ? p.dbg : 0;      // the dev switches exist in the diagnostic build only (PG_CONV16_STAMPS)
-    typedef Geo16<KH, KW, S, TWL, WM, MT, NT, KC, NB> G;
+    typedef Geo16<KH, KW, S, TWL, WM, MT, NT, KC, NB, SPLIT> G;
     typedef Half16<T> HT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef const __attribute__((address_space(3))) i32x4* lds_v4;
@@ -196,6 +200,9 @@ __global__ __launch_bounds__(SPLIT ? THREADS + 64 * LOADERS : THREADS, SPLIT ? 3
     constexpr int LD = SPLIT ? 2 * G::DPC : G::DPC;
     auto slot_of = [&](int i2) __attribute__((always_inline)) { return SPLIT ? ((i2 >> 1) * WAVES + (i2 & 1) * LOADERS + lw) * 64 : (i2 * WAVES + wave) * 64; };
     // is request i2 a weight-slab request?  wave-uniform; in the two-role form a constant per i2 (NXS_PAD is a multiple of 256 slots)
+    // does request i2 exist?  (two-role form with a tight buffer: the instructions whose slots lie past the buffer do not)
+    auto exists = [&](int i2) __attribute__((always_inline)) { return !SPLIT || ((i2 >> 1) * WAVES + (i2 & 1) * LOADERS) * 64 < G::LDS_BUF; };
+    constexpr int LD_EFF = SPLIT ? (G::LDS_BUF + 255) / 256 : G::DPC;      // requests per issuing thread and chunk that exist
     auto is_weight = [&](int i2) __attribute__((always_inline)) { return SPLIT ? ((i2 >> 1) * WAVES + (i2 & 1) * LOADERS) * 64 >= G::NXS_PAD : slot_of(i2) >= G::NXS_PAD; };
     const int total = p.total_tiles;
     const int q8 = total >> 3, r8 = total & 7;
@@ -223,6 +230,7 @@ __global__ __launch_bounds__(SPLIT ? THREADS + 64 * LOADERS : THREADS, SPLIT ? 3
     for (int i = 0; i < LD; i++) {
         const int sb = slot_of(i);
         rel[i] = SENTINEL; hyx[i] = 0x4000u;
+        if (!exists(i)) continue;
         if (is_weight(i)) {
             const int e = sb + lane - G::NXS_PAD;
             const int row = e / G::BM, col = e % G::BM;
@@ -274,7 +282,7 @@ __global__ __launch_bounds__(SPLIT ? THREADS + 64 * LOADERS : THREADS, SPLIT ? 3
         const bool interior = ty0 >= 0 && tx0 >= 0 && ty0 + G::IH_T <= p.H && tx0 + G::IW_T <= p.W;      // wave-uniform
 #pragma unroll
         for (int i = 0; i < LD; i++) {
-            if (!is_weight(i)) {                          // wave-uniform
+            if (exists(i) && !is_weight(i)) {             // wave-uniform
                 if (interior) {
                     voff[i] = org + rel[i];               // padding slots: org + 2^31 stays out of range (0 <= org < 2^31)
                 } else {
@@ -340,6 +348,7 @@ __global__ __launch_bounds__(SPLIT ? THREADS + 64 * LOADERS : THREADS, SPLIT ? 3
         const unsigned buf_b = smem_b + (unsigned)(ibuf * G::LDS_BUF) * 16u;
 #pragma unroll
         for (int i = 0; i < LD; i++) {
+            if (!exists(i)) continue;
             const int sb = slot_of(i);
             const bool is_w = is_weight(i);               // wave-uniform
             unsigned vo = is_w ? rel[i] : voff[i];
@@ -556,19 +565,21 @@ __global__ __launch_bounds__(SPLIT ? THREADS + 64 * LOADERS : THREADS, SPLIT ? 3
         }
     };
     if constexpr (SPLIT) {
-        // chunks this workgroup multiplies: its tiles blockIdx.x, blockIdx.x + gridDim.x, ... x nchunks; chunk c lives in staging buffer c % NBUF.
+        // chunks this workgroup multiplies: its tiles blockIdx.x, blockIdx.x + gridDim.x, ... x nchunks; chunk c lives in staging buffer c % NBUF
+        // (NBUF = 3: requests two chunks ahead; NBUF = 2, the 32-channel chunks: one).
         // Barrier c (one per chunk, all twelve waves) says: chunk c has landed, everybody is done with chunk c - 1.
         const int my_chunks = ((total - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x) * nchunks;
         if (loader) {
             setup_maps();
             int req = 0;
-            issue_next(); req++;                                        // (the host only launches this form with nchunks >= 2)
-            issue_next(); req++;
+#pragma unroll
+            for (int j = 0; j < G::NBUF - 1; j++)                       // NBUF - 1 chunks ahead (the host only launches this form with nchunks >= 2)
+                if (req < my_chunks) { issue_next(); req++; }
             for (int c = 0; c < my_chunks; c++) {
                 // chunk c must have landed; what is younger in this wave's queue -- chunk c + 1's requests (and, in front of them, the
                 // side loads of its tile when it is a tile's first chunk) -- may stay in flight
                 stamp(1);
-                if (req > c + 1) vm_wait<LD>(); else vm_wait<0>();
+                if (G::NBUF > 2 && req > c + 1) vm_wait<LD_EFF * (G::NBUF - 2)>(); else vm_wait<0>();
                 stamp(2);
                 __builtin_amdgcn_s_barrier();
                 stamp(3);
@@ -642,7 +653,10 @@ __global__ __launch_bounds__(SPLIT ? THREADS + 64 * LOADERS : THREADS, SPLIT ? 3
 
 template <typename T, int KH, int KW, int S, int TWL, int WM, int MT, int NT, int KC, int NB, bool SPLIT = false>
 int launch16(const Conv16Params& p0, hipStream_t s) {
-    typedef Geo16<KH, KW, S, TWL, WM, MT, NT, KC, NB> G;
+    // 32-channel chunks exist in the two-role form only (their one-role staging buffers would not fit 160 KB): the caller checked the conditions
+    if constexpr (KC == 32 && KH == 3 && KW == 3 && S == 1 && !SPLIT) return launch16<T, KH, KW, S, TWL, WM, MT, NT, KC, NB, true>(p0, s);
+    else {
+    typedef Geo16<KH, KW, S, TWL, WM, MT, NT, KC, NB, SPLIT> G;
     Conv16Params p = p0;
     p.tilesX = (p.OW + G::TW - 1) / G::TW;
     p.tilesY = (p.OH + G::TH - 1) / G::TH;
@@ -669,6 +683,7 @@ int launch16(const Conv16Params& p0, hipStream_t s) {
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(SPLIT ? THREADS + 64 * LOADERS : THREADS), G::LDS_BYTES, s, p);
     return launch_status();
+    }
 }
 
 // Low-resolution 3x3 layers (8^2 / 16^2 images of the wide blocks): the 16 x 32 pixel tile would be 7/8 or 1/2 padding -- matrix work
@@ -688,7 +703,10 @@ template <typename T, int KH, int KW, int S, int NT, int KC, int NB>
 int launch16_mt(const Conv16Params& p, hipStream_t s) {
     if constexpr (KH == 3 && KW == 3 && S == 1) {
         const int sm = small_tile16(KH, KW, S, p.OH, p.OW, p.Cout, p.f.phase_cout);
-        if (sm == 1) return launch16<T, KH, KW, S, 8, 4, 1, 1, KC, NB>(p, s);        // TH x TW = 8 x 8, BM = 128
+        if (sm == 1) {                                                               // TH x TW = 8 x 8, BM = 128
+            if constexpr (KC == 32) return PG_ERR_UNSUPPORTED;                       // (no 32-channel-chunk form of this tile: launch16_k3s1 does not send it here)
+            else return launch16<T, KH, KW, S, 8, 4, 1, 1, KC, NB>(p, s);
+        }
         if (sm == 2) return launch16<T, KH, KW, S, 16, 1, 2, 1, KC, NB>(p, s);       // TH x TW = 16 x 16, BM = 64
     }
     if ((p.f.phase_cout ? p.f.phase_cout : p.Cout) <= 32) return launch16<T, KH, KW, S, 32, 1, 1, NT, KC, NB>(p, s);

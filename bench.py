@@ -23,8 +23,9 @@ Extra objects on that line:
                   --mode bf16_1024 (config 5): dominant kernel = conv2d_mfma16, HBM-bound.
   cpu_baseline -- the CPU oracle (oracle/network_ref.py, a port) timed on this host at N=1 on a
                   bounded sample (rank 0, --gpus 1 only).
-  secondary    -- (--gpus 1, headline mode only) BASELINE configs 3 and 5 run as short child processes of the same script after the
-                  headline's timed region: their value / ms_per_step / roofline, so that those numbers are driver-timed too.
+  secondary    -- (--gpus 1, headline mode only) BASELINE configs 3, 5 and 4 (one-GPU share of the training step: batch 4, `--mode train`) run as
+                  short child processes of the same script after the headline's timed region: their value / ms_per_step / roofline, so that
+                  those numbers are driver-timed too (skipped under a profiler).
                   Headline fields are untouched by it.
 """
 
@@ -36,7 +37,6 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, 'pasta-gan-plusplus_amd'))
-sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
 sys.path.insert(0, ROOT)
 
 torch = None                     # imported by main() AFTER the launcher branch: the launcher parent must not touch the GPU runtime
@@ -83,7 +83,7 @@ def run_net(net, inp):
 
 
 def init_weights(net):
-    from detgen import fill_module_
+    from training.synthetic import fill_module_
     return fill_module_(net, 'cfg2.')      # name-keyed N(0,1) weights, noise_strength 0.1
 
 
@@ -160,7 +160,7 @@ def cpu_baseline_stack(channel_max, max_seconds=60.0):
     """The float32 oracle stack (oracle/network_ref.py SynthesisStack, a port) on the host cores, N=1: the blocks up to 256^2 of
     the same 1024^2 network (a bounded sample: the two top blocks alone are ~60 % of the FLOPs and minutes of CPU time)."""
     from oracle import network_ref as NR
-    from detgen import fill_module_
+    from training.synthetic import fill_module_
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
@@ -186,7 +186,7 @@ def run_stack(args, rank, world, dev, dist):
     x + y + packed weights per launch) as `roofline`, the matrix rate next to it."""
     from training import networks, replicas
     from torch_utils.ops import conv2d_mfma
-    from detgen import fill_module_
+    from training.synthetic import fill_module_
     n = args.batch if args.batch != BATCH_PER_GPU else 4
     net = networks.SynthesisStack(num_fp16_res=8, half_dtype=torch.bfloat16, channel_max=args.channel_max, **CFG5)
     net = fill_module_(net, 'cfg5.').to(dev).eval()
@@ -264,8 +264,9 @@ def run_train(args, rank, world, dev, dist):
     """BASELINE config 4 (secondary, --mode train): iterations/s of the 8-phase fullbody G+D step incl. lazy R1, batch 4 per
     GPU, flat-bucket gradient exchange over RCCL overlapped with the last backward (training/ddp.py).  VGG/contextual losses
     omitted (weights unavailable offline); input gradients of the fp32 convolutions run on the forward MFMA kernels (flipped,
-    O<->I transposed packs), weight gradients of the stride-1 3x3 / 1x1 layers on csrc/conv2d_wgrad.hip, the rest
-    (stride 2, 7x7, transposed, 16-bit) on aten::convolution_backward (MIOpen)."""
+    O<->I transposed packs), weight gradients of the fp32 3x3 (stride 1 / 2, transposed) and 1x1 layers on csrc/conv2d_wgrad.hip; what is
+    left on aten::convolution_backward (MIOpen) is listed in DESIGN.md section 3.2c.  `roofline` = the largest kernel of the step,
+    conv2d_wgrad<3,3,1>, timed with HIP events around its launches."""
     from training import networks, replicas
     from training.loss import StyleGAN2Loss
     from training.training_step import TrainingStep
@@ -293,14 +294,29 @@ def run_train(args, rank, world, dev, dist):
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+    from torch_utils.ops import conv2d_mfma
     for _ in range(args.warmup):
         step.run([batch])
     barrier()
+    wtl = conv2d_mfma.start_wgrad_timeline() if (rank == 0 and not step.graphs) else None      # events cannot be recorded inside a replayed graph
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step.run([batch])
     barrier()
     elapsed = replicas.max_over_ranks(time.perf_counter() - t0, device=dev)
+    conv2d_mfma.stop_wgrad_timeline()
+    roofline = None
+    if wtl:
+        # largest single kernel of the step: the fp32 weight gradient of the stride-1 3x3 layers (csrc/conv2d_wgrad.hip: a GEMM over pixels on the fp32
+        # MFMA + its fixed-order split-K reduction, both inside the event pair); flops = the forward count of SURVEY 8d for the same layer
+        dom = [(fl, e0.elapsed_time(e1) * 1e-3, by) for geo, fl, e0, e1, by in wtl if geo[:3] == (3, 3, 1)]
+        if dom:
+            fl, tm = sum(d[0] for d in dom), sum(d[1] for d in dom)
+            allw = sum(e0.elapsed_time(e1) * 1e-3 for _, _, e0, e1, _ in wtl)
+            roofline = dict(bound='mfma', kernel='conv2d_wgrad<3,3,1> + wgrad_reduce (fp32 weight gradient of the stride-1 3x3 layers, v_mfma_f32_32x32x2_f32)',
+                            achieved=round(fl / tm / 1e12, 2), peak=F32_MFMA_PEAK_TFLOPS, unit='TFLOP/s', frac=round(fl / tm / 1e12 / F32_MFMA_PEAK_TFLOPS, 4), traffic=None,
+                            launches_per_step=round(len(dom) / args.steps, 1), avg_launch_ms=round(1e3 * tm / len(dom), 4), time_frac_of_step=round(tm / elapsed, 4),
+                            algorithmic_bytes_per_launch=round(sum(d[2] for d in dom) / len(dom)), all_native_wgrad_time_frac_of_step=round(allw / elapsed, 4))
     if rank == 0:
         print(json.dumps(dict(metric='fullbody G+D training iterations/sec (8-phase step incl. lazy R1)', value=round(args.steps / elapsed, 4), unit='it/s',
                               n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(1e3 * elapsed / args.steps, 1), higher_is_better=True,
@@ -308,7 +324,8 @@ def run_train(args, rank, world, dev, dist):
                               config=dict(workload='BASELINE config 4: fullbody G+D step, lazy R1 (gamma 10), L1 + parsing CE, no VGG; ' + (f'discriminators fp16 at their {args.d_fp16_res} highest resolutions (train.py:196)' if args.d_fp16_res else 'discriminators in fp32'),
                                           batch_per_gpu=n, global_batch=n * world, parallelism=f'dp{world}, one flat fp32 gradient bucket per phase, segment all_reduce (RCCL) launched from autograd hooks on a side stream',
                                           first_batch_idx=0, note='steps start at batch_idx = warmup; reg phases fire every 4th (G) / 16th (D) iteration',
-                                          execution=(f'one hipGraph replay per phase once captured (captured so far: {step.graphed_phases()}); a phase runs eagerly the first time it is due and is captured the second time' if step.graphs else 'eager launches')))), flush=True)
+                                          execution=(f'one hipGraph replay per phase once captured (captured so far: {step.graphed_phases()}); a phase runs eagerly the first time it is due and is captured the second time' if step.graphs else 'eager launches')),
+                              **(dict(roofline=roofline) if roofline else {}))), flush=True)
 
 
 def run_selftest(args, rank, world):
@@ -348,15 +365,23 @@ def run_selftest(args, rank, world):
         dist.destroy_process_group()
 
 
-def secondary_runs(budget_s=150.0):
-    """BASELINE configs 3 and 5 as child processes of this script (fresh processes: the parent's GPU memory pool and plugin state do not
+def under_profiler():
+    """True when a rocprofv3 / roctracer tool library is preloaded into this process: children would inherit it, write into the same
+    output directory and spend minutes under tracing -- the secondary runs are skipped then."""
+    return any('rocprof' in os.environ.get(k, '').lower() or 'roctracer' in os.environ.get(k, '').lower()
+               for k in ('LD_PRELOAD', 'ROCP_TOOL_LIBRARIES', 'HSA_TOOLS_LIB', 'ROCPROFILER_LIBRARY_PATH'))
+
+
+def secondary_runs(budget_s=200.0):
+    """BASELINE configs 3, 5 and 4 as child processes of this script (fresh processes: the parent's GPU memory pool and plugin state do not
     leak into them; the parent only waits -- it never execs), a few seconds each; their JSON lines are attached to the headline
     line as `secondary`.  Failures are recorded, never raised: the headline must not depend on them."""
     import subprocess
     out = {}
     t_start = time.perf_counter()
     for key, extra in (('config3_generator', ['--mode', 'generator', '--steps', '8', '--warmup', '3']),
-                       ('config5_bf16_1024', ['--mode', 'bf16_1024', '--steps', '30', '--warmup', '10', '--no-cpu-baseline'])):
+                       ('config5_bf16_1024', ['--mode', 'bf16_1024', '--steps', '30', '--warmup', '10', '--no-cpu-baseline']),
+                       ('config4_train_step', ['--mode', 'train', '--steps', '5', '--warmup', '2', '--no-cpu-baseline'])):
         left = budget_s - (time.perf_counter() - t_start)
         if left < 20:
             out[key] = dict(error='skipped: time budget of the secondary runs used up')
@@ -369,7 +394,7 @@ def secondary_runs(budget_s=150.0):
                 out[key] = dict(error=f'exit {r.returncode}: {(r.stderr or r.stdout)[-300:]}')
                 continue
             j = json.loads(line[-1])
-            out[key] = {k: j[k] for k in ('metric', 'value', 'unit', 'steps', 'warmup', 'ms_per_step', 'dtype', 'config', 'roofline') if k in j}
+            out[key] = {k: j[k] for k in ('metric', 'value', 'unit', 'steps', 'warmup', 'ms_per_step', 'images_per_sec', 'dtype', 'config', 'roofline') if k in j}
         except Exception as e:                                # noqa: BLE001 -- recorded, the headline line still prints
             out[key] = dict(error=f'{type(e).__name__}: {e}'[:300])
     return out
@@ -500,7 +525,9 @@ def main():
                     roofline=roofline)
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline()
-        if world == 1 and not args.no_secondary:
+        if world == 1 and not args.no_secondary and under_profiler():
+            line['secondary'] = dict(skipped='a profiler tool library is preloaded into this process')
+        elif world == 1 and not args.no_secondary:
             del net, inp, out                                  # the children get the whole GPU
             torch.cuda.empty_cache()
             line['secondary'] = secondary_runs()

@@ -32,6 +32,7 @@ verbosity = 'brief'  # Verbosity level: 'none', 'brief', 'full' (reference custo
 
 CSRC_DIR = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'csrc'))
 INCLUDE_DIR = os.path.normpath(os.path.join(CSRC_DIR, '..', '..', 'include'))
+DEV_DIR = os.path.join(CSRC_DIR, 'dev')
 OFFLOAD_ARCH = 'gfx950'
 HIPCC_FLAGS = ['-O3', '-std=c++17', '-fPIC', '-fvisibility=hidden', f'--offload-arch={OFFLOAD_ARCH}']
 
@@ -126,16 +127,42 @@ def _build(module_name, sources, so_path, digest, extra_flags):
         list(pool.map(lambda so: _compile_one(hipcc, so[0], so[1], extra_flags), zip(sources, objs)))
     tmp = so_path + f'.tmp{os.getpid()}'
     cmd = [hipcc, '-shared', '-fPIC', f'--offload-arch={OFFLOAD_ARCH}', '-o', tmp] + objs
-    proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-    if proc.returncode != 0:
-        raise RuntimeError(f'link of {module_name} failed:\n{proc.stdout}')
-    os.replace(tmp, so_path)
+    try:
+        proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if proc.returncode != 0:
+            raise RuntimeError(f'link of {module_name} failed:\n{proc.stdout}')
+        os.replace(tmp, so_path)
+    finally:
+        clean(only=module_name)                   # hipcc's `<out>.N.host-*` temporaries and a half-written tmp of a failed / interrupted link
     with open(so_path + '.digest', 'w') as f:
         f.write(digest)
 
 
 def plugin_path(module_name):
-    return os.path.join(CSRC_DIR, module_name + '.so')
+    """Product plugins live in csrc/; every other name (development variants built by tools/ with extra -D flags) in csrc/dev/,
+    which `clean(dev=True)` empties -- dev builds never sit beside the product libraries."""
+    if module_name in PLUGIN_SOURCES and module_name.endswith('_plugin'):
+        return os.path.join(CSRC_DIR, module_name + '.so')
+    os.makedirs(DEV_DIR, exist_ok=True)
+    return os.path.join(DEV_DIR, module_name + '.so')
+
+
+def clean(dev=False, only=''):
+    """Delete compiler temporaries an interrupted / parallel hipcc left in csrc/ (`<name>.so.N.host-*`, `*.tmp<pid>`) and,
+    with dev=True, the development builds of csrc/dev/.  `only` restricts the sweep to one plugin's files (a build cleans up
+    after itself without touching a concurrent build of another plugin).  Returns the removed paths."""
+    gone = []
+    for pat in (only + '*.host-*', only + '*.so.tmp*', only + '*.so.[0-9]*'):
+        for path in glob.glob(os.path.join(CSRC_DIR, pat)) + glob.glob(os.path.join(DEV_DIR, pat)):
+            try:
+                os.remove(path)
+                gone.append(path)
+            except OSError:
+                pass
+    if dev and os.path.isdir(DEV_DIR):
+        gone += glob.glob(os.path.join(DEV_DIR, '*'))
+        shutil.rmtree(DEV_DIR, ignore_errors=True)
+    return gone
 
 
 def is_up_to_date(module_name, sources=None, extra_flags=()):
@@ -196,7 +223,8 @@ def get_plugin(module_name, sources=None, extra_hipcc_flags=(), build_only=False
 
 
 def build_all(names=None):
-    """Compile every plugin (used by __graft_entry__.build())."""
+    """Compile every plugin (used by __graft_entry__.build()); leaves no compiler temporaries behind."""
+    clean()
     return [get_plugin(n, build_only=True) for n in (names or PLUGIN_SOURCES)]
 
 

@@ -41,12 +41,25 @@ _plugin = None
 # Optional launch timeline for bench.py's roofline: when a list, every convolution launch appends
 # (geometry, algorithmic FLOPs, start event, end event, algorithmic bytes) recorded on the launch stream.
 _timeline = None
+_wgrad_timeline = None      # the same for the weight-gradient launches (bench.py --mode train): its own list, so a training run does not pay two events on each of its forward launches
 
 
 def start_timeline():
     global _timeline
     _timeline = []
     return _timeline
+
+
+def start_wgrad_timeline():
+    global _wgrad_timeline
+    _wgrad_timeline = []
+    return _wgrad_timeline
+
+
+def stop_wgrad_timeline():
+    global _wgrad_timeline
+    tl, _wgrad_timeline = _wgrad_timeline, None
+    return tl
 
 
 def stop_timeline():
@@ -111,14 +124,16 @@ def _init(plugin_name='conv2d_plugin'):
     return _plugin
 
 
-def use_winograd(kh, kw, stride, cout, cin=None, x2=None, pad=None, hw=None, xf=False):
+def use_winograd(kh, kw, stride, cout, cin=None, x2=None, pad=None, hw=None, xf=False, ep=None):
     """Launch policy for 3x3 stride-1 convolutions.  Returns 0 (direct implicit GEMM), 1 (Winograd F(2x2,3x3), csrc/conv2d_wino.h) or
     2 (Winograd F(4x4,3x3), csrc/conv2d_wino4.h) -- truthy = some Winograd kernel, and the value is what `pack_weight(winograd=...)` /
     `conv2d_forward(winograd=...)` take.  F(4x4) needs the image size (`hw`): its 8 x 64-pixel tiles and 16-channel chunks pay on layers
     with Cin >= 64, Cout a multiple of 64 and images of at least 32 x 32 (measured: 1.6x over F(2x2) at 32^2 although half of every 8 x 64 tile is
     padding there; slower at 16^2) whose width -- and output width -- is a multiple of 4; `xf` (an input pre-activation
     stage) stays on F(2x2).  PG_CONV_ALGO=direct|winograd|winograd2|winograd4 overrides (A/B measurements): 'winograd2' = never F(4x4),
-    'winograd4' = F(4x4) wherever the kernel accepts the launch."""
+    'winograd4' = F(4x4) wherever the kernel accepts the launch.  `ep` = the fused epilogue's keyword arguments when the caller has them: the
+    F(4x4) tail evaluates the activation as max(v * gain, v * gain * slope), exact for gain > 0 and 0 <= alpha <= 1 only (the kernel declines
+    anything else with PG_ERR_UNSUPPORTED); such launches stay on F(2x2), whose tail uses the select form."""
     if (int(kh), int(kw), int(stride)) != (3, 3, 1) or x2 is not None:
         return 0
     if pad is not None and not 0 <= int(pad[1]) <= 4:         # the kernels' LDS halo row starts 4 columns left of the tile
@@ -127,6 +142,11 @@ def use_winograd(kh, kw, stride, cout, cin=None, x2=None, pad=None, hw=None, xf=
     if mode == 'direct':
         return 0
     f4_possible = hw is not None and not xf and int(hw[1]) % 4 == 0 and (pad is None or (int(hw[1]) + 2 * int(pad[1]) - 2) % 4 == 0)
+    if ep:
+        gain = ep.get('gain', 1.0)
+        alpha = ep.get('alpha', 0.2)
+        if (gain is not None and not float(gain) > 0) or (ep.get('act', 'linear') == 'lrelu' and alpha is not None and not 0 <= float(alpha) <= 1):
+            f4_possible = False
     if mode == 'winograd4' and f4_possible:
         return 2
     if mode in ('winograd', 'winograd2', 'winograd4'):
@@ -381,9 +401,16 @@ def weight_gradient(x, dy, weight_shape, pad, stride=1):
     x, dy = x.contiguous(), dy.contiguous()
     dw = torch.empty([cout, cin, kh, kw], dtype=torch.float32, device=x.device)
     ws = torch.empty([splits * kh * kw * cout * cin], dtype=torch.float32, device=x.device)
+    tl = _wgrad_timeline
     with torch.cuda.device(x.device):
+        if tl is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
         st = lib.pg_conv2d_wgrad(nat.ptr(x), nat.ptr(dy), nat.ptr(dw), nat.ptr(ws), n, cin, h, w, cout, kh, kw, stride, int(pad[0]), int(pad[1]), oh, ow, splits,
                                  nat.stream_of(x))
+        if tl is not None:
+            ev1.record()
+            tl.append(((kh, kw, stride, 'wgrad', f'N{n} {cin}->{cout} {h}x{w}'), 2.0 * n * cout * oh * ow * cin * kh * kw, ev0, ev1, 4 * (x.numel() + dy.numel() + dw.numel())))
     nat.check(st, 'pg_conv2d_wgrad')
     return dw
 

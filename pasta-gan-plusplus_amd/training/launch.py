@@ -9,7 +9,10 @@ Differences, on purpose:
 * rendezvous is the ``env://`` form over 127.0.0.1 with a port the parent found free (the reference uses a file in a
   temp dir; the driver's own launcher -- torch.distributed.run -- uses the same variables, so a rank cannot tell who
   started it): RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT;
-* a rank that dies takes the others down (the parent kills the process group it started) and its exit code is returned.
+* a rank that dies takes the others down (the parent kills the process group it started) and its exit code is returned;
+* a parent that is told to stop (SIGTERM / SIGHUP / SIGINT: a driver's timeout, a cancelled job) takes its ranks with it: the
+  ranks run in sessions of their own, so the signal is turned into an exception that runs the same clean-up (the reference's
+  ``torch.multiprocessing.spawn`` children are daemonic and die with their parent).
 """
 
 import os
@@ -46,10 +49,23 @@ def spawn_ranks(argv, nprocs, timeout=None, poll=0.05):
     Returns the first non-zero exit code, or 0.  `timeout` (seconds) bounds the whole job."""
     assert nprocs >= 1
     port = free_port()
-    procs = [subprocess.Popen([sys.executable, *argv], env=rank_env(r, nprocs, port), start_new_session=True) for r in range(nprocs)]
+
+    def _stop(signum, _frame):
+        raise SystemExit(128 + signum)                        # unwinds through the `finally` below: the ranks are killed first
+
+    handled = (signal.SIGTERM, signal.SIGHUP, signal.SIGINT)
+    previous = {}
+    try:
+        for sig in handled:
+            previous[sig] = signal.signal(sig, _stop)
+    except ValueError:                                        # not the main thread: the caller owns signal handling
+        pass
+    procs = []
     deadline = None if timeout is None else time.monotonic() + timeout
     code = 0
     try:
+        for r in range(nprocs):
+            procs.append(subprocess.Popen([sys.executable, *argv], env=rank_env(r, nprocs, port), start_new_session=True))
         alive = list(procs)
         while alive:
             for p in list(alive):
@@ -80,4 +96,6 @@ def spawn_ranks(argv, nprocs, timeout=None, poll=0.05):
                 except ProcessLookupError:
                     pass
                 p.wait()
+        for sig, old in previous.items():
+            signal.signal(sig, old)
     return code

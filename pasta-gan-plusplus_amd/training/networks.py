@@ -134,7 +134,7 @@ def _modconv_fast(x, weight, styles, noise, up, padding, resample_filter, demodu
     if up == 1:
         if not conv2d_mfma.supported(kh, kw, 1):
             return None
-        wg = conv2d_mfma.use_winograd(kh, kw, 1, cout, cin, pad=(padding, padding), hw=x.shape[2:])
+        wg = conv2d_mfma.use_winograd(kh, kw, 1, cout, cin, pad=(padding, padding), hw=x.shape[2:], ep=ep)
         packed = cache.get(('plain', flip_weight, wg), [weight], lambda: conv2d_mfma.pack_weight(weight, flip=not flip_weight, winograd=wg))
         return conv2d_mfma.conv2d_forward(x, packed, cout, kh, kw, stride=1, pad=(padding, padding), in_scale=styles,
                                           out_scale=dcoefs, noise=noise, winograd=wg, **ep)
@@ -419,7 +419,7 @@ class Conv2dLayer(_ConvBase):
         if self.down == 1:
             if x2 is not None and x.shape[1] % 16 != 0:
                 x, x2 = torch.cat([x, x2], dim=1), None
-            wg = conv2d_mfma.use_winograd(k, k, 1, cout, x.shape[1], x2, pad=(self.padding, self.padding), hw=x.shape[2:])
+            wg = conv2d_mfma.use_winograd(k, k, 1, cout, x.shape[1], x2, pad=(self.padding, self.padding), hw=x.shape[2:], ep=ep)
             return conv2d_mfma.conv2d_forward(x, self._packed(False, wg), cout, k, k, pad=(self.padding, self.padding), x2=x2, winograd=wg, **ep)
         if x2 is not None:
             x = torch.cat([x, x2], dim=1)

@@ -64,12 +64,15 @@ class TrainingStep:
                 self.phases.append(Phase(name + 'reg', modules, opt, interval, bucket))
         self.cur_nimg = 0
         self.batch_idx = 0
+        self.observer = None             # tests: callable(event, phase) at 'begin' of a phase and when its 'gradients' are final (eager phases only)
 
     def due_phases(self):
         return [ph for ph in self.phases if self.batch_idx % ph.interval == 0]
 
     def _phase(self, ph, rounds):
         """One due phase, eagerly: returns nothing; everything it does is GPU work enqueued on the current stream plus Python bookkeeping."""
+        if self.observer is not None:
+            self.observer('begin', ph)
         ph.bucket.begin()                                    # zero the flat bucket; every .grad is a view into it
         for m in ph.modules:
             m.requires_grad_(True)
@@ -83,6 +86,8 @@ class TrainingStep:
         if not ph.bucket.finish():                           # nobody produced a gradient: nothing to exchange, nothing to step
             return
         torch.nan_to_num(ph.bucket.flat, nan=0, posinf=1e5, neginf=-1e5, out=ph.bucket.flat)
+        if self.observer is not None:
+            self.observer('gradients', ph)                   # exchanged, cleaned gradients in place; the optimizer has not stepped yet
         ph.opt.step()
 
     def _phase_graphed(self, idx, ph, rounds):

@@ -58,3 +58,35 @@ def test_launcher_parent_does_not_import_torch_and_propagates_failure(tmp_path):
     assert subprocess.run([sys.executable, '-c', code], env=_clean_env(), timeout=60).returncode == 0
     assert sorted(p.name for p in tmp_path.glob('r?')) == ['r0', 'r1', 'r2'] and (tmp_path / 'r2').read_text() == '2'
     assert subprocess.run([sys.executable, '-c', code, 'fail'], env=_clean_env(), timeout=60).returncode == 7
+
+
+def test_sigterm_to_the_launcher_takes_the_ranks_down(tmp_path):
+    # the ranks run in sessions of their own -- a launcher that dies of SIGTERM without cleaning up would leave them holding the GPUs
+    import signal
+    import time
+    probe = tmp_path / 'sleeper.py'
+    probe.write_text('import os, sys, time\nopen(sys.argv[1] + os.environ["RANK"], "w").write(str(os.getpid()))\ntime.sleep(120)\n')
+    code = ('import sys; sys.path.insert(0, %r); from training import launch; sys.exit(launch.spawn_ranks([%r, %r], 2))'
+            % (os.path.join(ROOT, 'pasta-gan-plusplus_amd'), str(probe), str(tmp_path / 'pid')))
+    parent = subprocess.Popen([sys.executable, '-c', code], env=_clean_env())
+    try:
+        deadline = time.monotonic() + 30
+        while time.monotonic() < deadline and not all((tmp_path / f'pid{r}').exists() and (tmp_path / f'pid{r}').read_text() for r in (0, 1)):
+            time.sleep(0.05)
+        pids = [int((tmp_path / f'pid{r}').read_text()) for r in (0, 1)]
+        parent.send_signal(signal.SIGTERM)
+        assert parent.wait(timeout=30) == 128 + signal.SIGTERM
+        deadline = time.monotonic() + 10
+        def alive(pid):
+            try:
+                os.kill(pid, 0)
+                with open(f'/proc/{pid}/stat') as f:
+                    return f.read().split(')')[-1].split()[0] != 'Z'
+            except (ProcessLookupError, FileNotFoundError):
+                return False
+        while time.monotonic() < deadline and any(alive(p) for p in pids):
+            time.sleep(0.05)
+        assert not any(alive(p) for p in pids), 'rank processes survived the launcher'
+    finally:
+        if parent.poll() is None:
+            parent.kill()

@@ -389,11 +389,16 @@ def test_conv2d_winograd_rejects_what_it_cannot_do():
 
 
 @pytest.mark.parametrize('n,cin,cout,h,w,pad', [(1, 16, 64, 8, 64, 1), (2, 64, 64, 16, 128, 1), (2, 32, 128, 24, 64, 1), (1, 48, 70, 9, 72, 1), (2, 20, 40, 13, 100, 1),
-                                                (1, 128, 128, 40, 192, 1), (3, 64, 64, 64, 64, 2), (3, 64, 64, 40, 64, 3), (2, 16, 64, 7, 8, 1), (1, 80, 64, 32, 64, 3), (2, 16, 64, 12, 62, 2)])
+                                                (1, 128, 128, 40, 192, 1), (3, 64, 64, 64, 64, 2), (3, 64, 64, 40, 64, 3), (2, 16, 64, 7, 8, 1), (1, 80, 64, 32, 64, 3), (2, 16, 64, 12, 62, 2),
+                                                (2, 40, 70, 13, 72, 3), (1, 32, 96, 19, 136, 3)])
 def test_conv2d_winograd4_kernel(n, cin, cout, h, w, pad):
     """csrc/conv2d_wino4.h (Winograd F(4x4,3x3), round 3) on full, edge and ragged tiles (heights that are no multiple of 8, widths
-    no multiple of 64, couts no multiple of 64, channel counts no multiple of 16, paddings 0..4): plain against the fp64 convolution;
-    every fused stage, per-sample noise and SPADE mode against the direct MFMA kernel running the same launch.  Tolerance: F(4x4)'s
+    no multiple of 64, couts no multiple of 64, channel counts no multiple of 16): plain against the fp64 convolution;
+    every fused stage, per-sample noise and SPADE mode against the direct MFMA kernel running the same launch (which meets the oracle in
+    test_conv2d_fused_prologue_epilogue_vs_oracle; test_conv2d_winograd4_tails_vs_oracle compares one shape per tail kind with the oracle directly).
+    Paddings: the kernel needs W % 4 == 0 AND OW = W + 2 pad - 2 a multiple of 4, i.e. only ODD paddings (1, 3) can run -- the pad = 2 cases
+    here assert the decline; pad 0 / 4 (the `cbase == 0` / `sh == 0` arithmetic of the kernel) is unreachable through the C ABI and untested.
+    pad = 3 also runs with ragged H and Cout % 64 != 0 together.  Tolerance: F(4x4)'s
     transforms cost ~4x the rounding of the direct kernel (tools/f43_error_probe.py): 1e-4 of the output scale."""
     from torch_utils.ops import conv2d_mfma
     import torch.nn.functional as F
@@ -454,9 +459,67 @@ def test_conv2d_winograd4_repeated_launches_are_identical(n, h, cin, cout):
         assert torch.equal(y, first), f'launch {it} differs from the first one: max |d| {float((y - first).abs().max()):.3e}'
 
 
+@pytest.mark.parametrize('tail', ['plain', 'residual', 'mod_noise', 'spade'])
+def test_conv2d_winograd4_tails_vs_oracle(tail):
+    """One shape per tail kind of the F(4x4) kernel (W4_TAIL_PLAIN / the run-time tail with a residual / modulated + noise / W4_TAIL_SPADE)
+    against the UNFUSED oracle composition (oracle.ops_ref + fp64 convolution), not against another HIP kernel ("what's weak")."""
+    from torch_utils.ops import conv2d_mfma
+    from oracle import ops_ref as R
+    from oracle import network_ref as NR
+    import torch.nn.functional as F
+    n, cin, cout, h, w = 2, 64, 128, 24, 72
+    x = det_tensor('w4o.x', [n, cin, h, w])
+    wt = det_tensor('w4o.w', [cout, cin, 3, 3], scale=1 / (3 * math.sqrt(cin)))
+    b = det_tensor('w4o.b', [cout])
+    conv = lambda xx, ww: F.conv2d(xx.double(), ww.double(), padding=1)
+    run = lambda pk, **kw: conv2d_mfma.conv2d_forward(x.to(DEV), pk, cout, 3, 3, pad=(1, 1), winograd=2, **kw)
+    pk = conv2d_mfma.pack_weight(wt.to(DEV), winograd=2)
+    if tail == 'plain':
+        y = run(pk, bias=b.to(DEV), act='lrelu', alpha=0.2, gain=math.sqrt(2), clamp=1.5)
+        ref = R.bias_act(conv(x, wt), b.double(), act='lrelu', gain=math.sqrt(2), clamp=1.5)
+    elif tail == 'residual':
+        res = det_tensor('w4o.r', [n, cout, h, w])
+        y = run(pk, bias=b.to(DEV), act='relu', gain=0.7, residual=res.to(DEV))
+        ref = R.bias_act(conv(x, wt), b.double(), act='relu', gain=0.7) + res.double()
+    elif tail == 'mod_noise':      # the non-fused modulated convolution (networks.py:73-82): x * styles -> conv -> fma(dcoefs, noise) -> bias_act
+        styles, noise = det_tensor('w4o.s', [n, cin]) + 1.2, det_tensor('w4o.nz', [h, w])
+        dco = ((wt.double()[None] * styles.double()[:, None, :, None, None]).square().sum([2, 3, 4]) + 1e-8).rsqrt()
+        y = run(pk, in_scale=styles.to(DEV), out_scale=dco.float().to(DEV), noise=noise.to(DEV), noise_gain=0.4, bias=b.to(DEV), act='lrelu', alpha=0.2,
+                gain=math.sqrt(2), clamp=256.0)
+        ref = R.fma(conv(x.double() * styles.double()[:, :, None, None], wt), dco[:, :, None, None], noise.double() * 0.4)
+        ref = R.bias_act(ref, b.double(), act='lrelu', gain=math.sqrt(2), clamp=256.0)
+    else:                          # Spade_Norm_Block (networks.py:1715-1723): instance norm of sx, gamma / beta convolutions of x, then a following layer's pre-activation
+        c = cout // 2
+        sx = det_tensor('w4o.sx', [n, c, h, w]) * 2 + 0.3
+        mean = sx.double().mean([2, 3])
+        rstd = (sx.double().var([2, 3], unbiased=False) + 1e-5).rsqrt()
+        pks = conv2d_mfma.pack_spade_gamma_beta(wt[:c].contiguous().to(DEV), wt[c:].contiguous().to(DEV), winograd=2)
+        y = run(pks, spade=(sx.to(DEV), mean.float().to(DEV), rstd.float().to(DEV)), act='relu', gain=math.sqrt(2))
+        ref = NR.instance_norm(sx.double()) * (1 + conv(x, wt[:c])) + conv(x, wt[c:])
+        ref = R.bias_act(ref, None, act='relu', gain=math.sqrt(2))
+    close(y, ref, 0, 1e-4 * scale_of(ref))
+
+
 def test_conv2d_winograd4_policy_and_declines():
     from torch_utils.ops import conv2d_mfma
     from torch_utils.ops._native import NativeNotCovered
+    # the tail's max() form of the activation is exact for gain > 0, 0 <= alpha <= 1 only (ADVICE r3): the policy keeps anything else on F(2x2),
+    # the kernel declines it, and the F(2x2) launch of the same request meets the oracle
+    geo = dict(pad=(1, 1), hw=(64, 64))
+    assert conv2d_mfma.use_winograd(3, 3, 1, 64, 64, ep=dict(act='lrelu', alpha=0.2, gain=1.4), **geo) == 2
+    assert conv2d_mfma.use_winograd(3, 3, 1, 64, 64, ep=dict(act='lrelu', alpha=1.5, gain=1.4), **geo) == 1
+    assert conv2d_mfma.use_winograd(3, 3, 1, 64, 64, ep=dict(act='relu', gain=-1.0), **geo) == 1
+    assert conv2d_mfma.use_winograd(3, 3, 1, 64, 64, ep=dict(act='relu', alpha=None, gain=None), **geo) == 2
+    xa = det_tensor('w4d.xa', [1, 64, 32, 64])
+    wa = det_tensor('w4d.wa', [64, 64, 3, 3], scale=0.05)
+    for kw in (dict(act='lrelu', alpha=1.5, gain=1.4), dict(act='lrelu', alpha=0.2, gain=-0.5), dict(act='relu', gain=-2.0)):
+        with pytest.raises(NativeNotCovered):
+            conv2d_mfma.conv2d_forward(xa.to(DEV), conv2d_mfma.pack_weight(wa.to(DEV), winograd=2), 64, 3, 3, pad=(1, 1), winograd=2, **kw)
+        y = conv2d_mfma.conv2d_forward(xa.to(DEV), conv2d_mfma.pack_weight(wa.to(DEV), winograd=1), 64, 3, 3, pad=(1, 1), winograd=1, **kw)
+        from oracle import ops_ref as R
+        import torch.nn.functional as F
+        ref = R.bias_act(F.conv2d(xa.double(), wa.double(), padding=1), None, act=kw['act'], alpha=kw.get('alpha'), gain=kw['gain'])
+        close(y, ref, 0, 1e-5 * scale_of(ref))
     assert conv2d_mfma.use_winograd(3, 3, 1, 128, 128, pad=(1, 1), hw=(256, 256)) == 2
     assert conv2d_mfma.use_winograd(3, 3, 1, 128, 128, pad=(1, 1)) == 1                          # no image size: F(2x2)
     assert conv2d_mfma.use_winograd(3, 3, 1, 128, 128, pad=(1, 1), hw=(256, 254)) == 1          # width no multiple of 4
@@ -1077,6 +1140,126 @@ def test_full_width_training_iteration_smoke(d_fp16_res):
     assert all(torch.isfinite(p).all() for m in (G, D, DP) for p in m.parameters())
     assert sum(int(not torch.equal(a, b)) for a, b in zip(before, after)) >= 8
     assert step.batch_idx == 1
+
+
+def test_config4_whole_iteration_batch4_vs_oracle():
+    """BASELINE config 4's per-rank share as ONE piece: the full-width generator and both discriminators at 512^2,
+    per-rank batch 4 (train.py:174), all eight phases of one `TrainingStep.run` on the GPU (training_loop_fullbody.py:468-481, 604-639) --
+    and the per-parameter gradient signatures of its `Gmain` and `Dmain` phases, taken when the phase's gradients are final and before its
+    optimizer steps, against the CPU oracle networks run through the same loss FROM THE WEIGHTS THE PRODUCT HAD AT THE START OF THAT PHASE
+    (Dmain follows Gmain's Adam step: the oracle is handed the stepped generator, so that each comparison isolates one phase's forward +
+    backward).  fp32 discriminators on both sides (the fp16 discriminator blocks have their own oracle test with a 16-bit bar);
+    noise_strength = 0 (the training route draws fresh noise per call, which two devices cannot share); no style mixing.  Bar: per-parameter
+    sum|grad| within 3e-3 (the bar of the per-network tests this one joins); single-element parameters only in sign and magnitude."""
+    import os
+    import time
+    from training import networks as PN
+    from training.loss import StyleGAN2Loss
+    from training.training_step import TrainingStep
+    from oracle import network_ref as NR
+    n = 4
+    g_kw = dict(z_dim=0, c_dim=512, w_dim=512, img_resolution=512, img_channels=3, mapping_kwargs=dict(num_layers=1),
+                synthesis_kwargs=dict(channel_base=32768, channel_max=512, conv_clamp=256))
+    d_kw = lambda ch: dict(c_dim=512, img_resolution=512, img_channels=ch, channel_base=32768, channel_max=512, conv_clamp=256,
+                           epilogue_kwargs=dict(mbstd_group_size=4))
+    ref = dict(G=fill_module_(NR.GeneratorFull_v20(**g_kw), 'c4w.G.', noise_strength=0.0).train(),
+               D=fill_module_(NR.Discriminator(**d_kw(6)), 'c4w.D.').train(), D_parsing=fill_module_(NR.Discriminator(**d_kw(10)), 'c4w.DP.').train())
+    net = dict(G=PN.GeneratorFull_v20(**g_kw), D=PN.Discriminator(**d_kw(6)), D_parsing=PN.Discriminator(**d_kw(10)))
+    for k in net:
+        missing, unexpected = net[k].load_state_dict(ref[k].state_dict(), strict=False)
+        assert not unexpected and not [m for m in missing if 'resample_filter' not in m], (k, missing, unexpected)
+        net[k] = net[k].to(DEV).train()
+    parts = lambda g: dict(G_mapping=g.mapping, G_synthesis=g.synthesis, G_const_encoding=g.const_encoding, G_style_encoding=g.style_encoding)
+    mk_loss = lambda nets, device: StyleGAN2Loss(device=torch.device(device), **parts(nets['G']), D=nets['D'], D_parsing=nets['D_parsing'],
+                                                 style_mixing_prob=0, r1_gamma=10, l1_weight=50, mask_weight=1.0)
+    u = lambda name, *shape: det_tensor('c4w.' + name, shape, 'uniform')
+    batch = dict(real_img=u('real', n, 3, 512, 512), gen_z=torch.zeros([n, 0]), style_input=u('style', n, 45, 128, 128), retain=u('retain', n, 6, 512, 512),
+                 pose=u('pose', n, 5, 512, 512), denorm_upper_input=u('du', n, 3, 512, 512), denorm_lower_input=u('dl', n, 3, 512, 512),
+                 denorm_upper_mask=det_tensor('c4w.mu', [n, 1, 512, 512], 'blockmask'), denorm_lower_mask=det_tensor('c4w.ml', [n, 1, 512, 512], 'blockmask'),
+                 gt_parsing=det_tensor('c4w.gt', [n, 1, 512, 512], 'labels7'))
+    sig_of = lambda nets: {f'{k}.{pn}': (None if p_.grad is None else float(p_.grad.double().abs().sum())) for k, m in nets.items() for pn, p_ in m.named_parameters()}
+
+    want_phases = ('Gmain', 'Dmain')
+    start, got, order = {}, {}, []
+
+    def observer(event, ph):
+        order.append((event, ph.name))
+        if ph.name not in want_phases:
+            return
+        if event == 'begin':
+            start[ph.name] = {k: {a: b.detach().cpu().clone() for a, b in m.state_dict().items()} for k, m in net.items()}
+        else:
+            got[ph.name] = sig_of(net)
+
+    step = TrainingStep(parts(net['G']), net['D'], net['D_parsing'], mk_loss(net, DEV), batch_size=n)
+    step.observer = observer
+    before = {k: [p_.detach().clone() for p_ in m.parameters()] for k, m in net.items()}
+    t0 = time.perf_counter()
+    step.run([{k: v.to(DEV) for k, v in batch.items()}])
+    torch.cuda.synchronize()
+    t_gpu = time.perf_counter() - t0
+    # the whole 8-phase schedule ran (Greg is statically empty: no backward, no step -- loss.phase_is_empty), every network moved, all finite
+    assert [nm for ev, nm in order if ev == 'gradients'] == ['Gmain', 'Dmain', 'Dreg', 'D_parsingmain', 'D_parsingreg', 'D_parsingmain', 'D_parsingreg'], order
+    for k, m in net.items():
+        assert all(torch.isfinite(p_).all() for p_ in m.parameters()), k
+        assert sum(int(not torch.equal(a, b)) for a, b in zip(before[k], m.parameters())) >= 0.9 * len(before[k]) - 2, k
+
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+    ref_loss = mk_loss(ref, 'cpu')
+    report = []
+    for phase in want_phases:
+        t0 = time.perf_counter()
+        for k, m in ref.items():
+            m.load_state_dict(start[phase][k], strict=False)
+            for p_ in m.parameters():
+                p_.grad = None
+            m.requires_grad_(k == ('G' if phase.startswith('G') else 'D'))
+        ref_loss.accumulate_gradients(phase=phase, gain=1, **batch)
+        want = sig_of(ref)
+        assert want.keys() == got[phase].keys()
+        numel = {f'{k}.{pn}': p_.numel() for k, m in ref.items() for pn, p_ in m.named_parameters()}
+        worst, n_grad, bad = (0.0, ''), 0, []
+        for key, w in want.items():
+            g = got[phase][key]
+            if w is None or w == 0.0:
+                assert g is None or g == 0.0, (phase, key, g)     # e.g. synthesis.b8.const (networks.py:2118 vs :2157-2161) never receives a gradient
+                continue
+            assert g is not None, (phase, key)
+            n_grad += 1
+            if numel[key] == 1:          # a signed sum over every pixel of a layer: sign and magnitude only (see test_config4_generator_gradients_full_width_vs_oracle)
+                if not 0.5 <= g / (w + 1e-30) <= 2.0:
+                    bad.append((key, g, w))
+                continue
+            worst = max(worst, (abs(g - w) / (abs(w) + 1e-12), key))
+            if abs(g - w) > 3e-3 * abs(w) + 1e-6:
+                bad.append((key, g, w))
+        report.append(f'{phase}: {n_grad} parameters with gradients, worst signature mismatch {worst[0]:.2e} ({worst[1]}), oracle {time.perf_counter() - t0:.0f} s')
+        assert not bad, (phase, bad[:8])
+        assert n_grad >= (150 if phase == 'Gmain' else 20), (phase, n_grad)
+    print(f'config 4 whole iteration at batch {n} (GPU {t_gpu:.2f} s incl. first-call work): ' + '; '.join(report))
+
+
+@pytest.mark.timeout(900)
+def test_bench_as_single_rank_under_torch_distributed_run():
+    """The launch the driver uses for N > 1, at N = 1 on the hardware that is there: `torch.distributed.run --nproc-per-node 1`
+    sets RANK / WORLD_SIZE, so bench.py is a rank -- `init_process_group('nccl')` (RCCL), the barrier on both sides of the timed region and
+    `replicas.max_over_ranks` (an all-reduce MAX on the device) all execute.  One JSON line, n_gpus 1, a finite positive value."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    torch.cuda.empty_cache()
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1', '--master-port', '29671',
+                        os.path.join(root, 'bench.py'), '--gpus', '1', '--no-cpu-baseline', '--no-secondary', '--steps', '2', '--warmup', '1'],
+                       capture_output=True, text=True, timeout=800, env=env)
+    assert r.returncode == 0, (r.stderr or r.stdout)[-3000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = lines[0]
+    assert j['n_gpus'] == 1 and j['steps'] == 2 and j['value'] > 0 and j['config']['parallelism'] == 'replicas x1' and 'roofline' in j
 
 
 # =============================================================== round-2 parity holes

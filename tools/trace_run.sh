@@ -2,7 +2,7 @@ cd /tmp && export TMPDIR=/tmp
 python3 $GRAFT_REPO_ROOT/tools/ensure_built.py || exit 1     # plugins are built in a plain process, never under the profiler
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/trace
 mkdir -p $O
-timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/tr_out -- python3 $R/bench.py --no-cpu-baseline --steps 2 --warmup 1 > $O/log.txt 2>&1
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/tr_out -- python3 $R/bench.py --no-cpu-baseline --no-secondary --steps 2 --warmup 1 > $O/log.txt 2>&1
 f=$(find /tmp/tr_out -name "*kernel_trace.csv" | head -1)
 python3 - "$f" > $O/last_step.txt <<'PY'
 import csv, sys, re

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 6
+#define PG_ABI_VERSION 7
 
 enum pg_dtype { PG_F32 = 0, PG_F16 = 1, PG_BF16 = 2, PG_F64 = 3 };
 
@@ -211,6 +211,18 @@ int pg_conv2d_winograd4_pack_weight(const float* w, float* packed, int Cout, int
 int pg_conv2d_winograd4_forward(const float* x, const float* packed_u, float* y,
                                 int N, int Cin, int H, int W, int Cout, int pad_y, int pad_x, int OH, int OW,
                                 const int64_t ystride[4], const pg_conv2d_fusion* fusion, void* stream);
+
+/*
+ * The same F(4x4, 3x3) algorithm with TWO workgroups per CU (round 4; csrc/conv2d_wino4b.h, v_mfma_f32_16x16x4_f32, 64 couts x 16
+ * tiles per workgroup): same call contract, acceptance rules and numerics as pg_conv2d_winograd4_forward, its own weight stream
+ * order (pg_conv2d_winograd4_packed_size floats).  SPADE combine mode expects gamma / beta rows packed as ADJACENT cout pairs
+ * (row 2c = gamma of channel c, row 2c + 1 = beta), not as blocks of 32.
+ */
+int pg_conv2d_winograd4b_pack_weight(const float* w, float* packed, int Cout, int Cin,
+                                     float scale, int flip_hw, int transpose_oi, void* stream);
+int pg_conv2d_winograd4b_forward(const float* x, const float* packed_u, float* y,
+                                 int N, int Cin, int H, int W, int Cout, int pad_y, int pad_x, int OH, int OW,
+                                 const int64_t ystride[4], const pg_conv2d_fusion* fusion, void* stream);
 
 /* Demodulation coefficients of modulated_conv2d (networks.py:64-68):
  *   dcoefs[n,o] = rsqrt(sum_{i,k} (w[o,i,k] * scale * styles[n,i])^2 + 1e-8);  w is OIHW. */

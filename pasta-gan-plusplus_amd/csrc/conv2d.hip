@@ -123,6 +123,50 @@ __global__ __launch_bounds__(256) void wino4_pack_kernel(const float* __restrict
     }
 }
 
+// The same transform in the order the waves of conv2d_wino4b.h walk it (two workgroups per CU, v_mfma_f32_16x16x4_f32):
+//   [m-block 64][cout block cb 4][row half ah 2][chunk 16 ch][e = 6 a' + b (18)][lane = (kq, m) 64][j 4]
+//   with xi = 6 (3 ah + a') + b, cout = 64 mb + 16 cb + m, channel = 16 chunk + 4 j + kq: one 16-byte word per lane = the A operands of the four K steps of one xi.
+__global__ __launch_bounds__(256) void wino4b_pack_kernel(const float* __restrict__ w, float* __restrict__ up, int Cout, int Cin,
+                                                          int CinP, int CoutP, float scale, int flip, int transpose_oi) {
+    const double G[6][3] = {{0.25, 0.0, 0.0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                            {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0.0, 0.0, 1.0}};
+    const int nchunks = CinP / 16;
+    const int64_t total = (int64_t)CinP * CoutP;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int co = (int)(i % CoutP), ci = (int)(i / CoutP);
+        double g[3][3];
+#pragma unroll
+        for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+            for (int kx = 0; kx < 3; kx++) {
+                double v = 0.0;
+                if (co < Cout && ci < Cin) {
+                    const int sy = flip ? 2 - ky : ky, sx = flip ? 2 - kx : kx;
+                    const int64_t src = transpose_oi ? (((int64_t)ci * Cout + co) * 3 + sy) * 3 + sx
+                                                     : (((int64_t)co * Cin + ci) * 3 + sy) * 3 + sx;
+                    v = (double)(w[src] * scale);
+                }
+                g[ky][kx] = v;
+            }
+        double tg[6][3];                                 // G g
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+#pragma unroll
+            for (int kx = 0; kx < 3; kx++) tg[a][kx] = G[a][0] * g[0][kx] + G[a][1] * g[1][kx] + G[a][2] * g[2][kx];
+        const int mb = co >> 6, cbk = (co >> 4) & 3, m = co & 15;
+        const int k = ci >> 4, cc = ci & 15, j = cc >> 2, kq = cc & 3;
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+#pragma unroll
+            for (int b = 0; b < 6; b++) {
+                const double u = tg[a][0] * G[b][0] + tg[a][1] * G[b][1] + tg[a][2] * G[b][2];      // (G g) G^T
+                const int64_t unit = ((int64_t)(mb * 4 + cbk) * 2 + a / 3) * nchunks + k;
+                const int64_t dst = ((unit * 18 + (a % 3) * 6 + b) * 64 + (kq * 16 + m)) * 4 + j;
+                up[dst] = (float)u;
+            }
+    }
+}
+
 // ------------------------------------------------------------------ demodulation coefficients
 // one workgroup per (n, o): rsqrt(sum_{i,k} (w[o,i,k] * scale * s[n,i])^2 + 1e-8)
 __global__ __launch_bounds__(256) void dcoefs_kernel(const float* __restrict__ w, const float* __restrict__ styles, float* __restrict__ d,
@@ -497,7 +541,7 @@ static int conv_forward(int winograd, const float* x, const float* packed_w, flo
         if (p.f.x2) return PG_ERR_UNSUPPORTED;                  // two-source launches stay on the direct kernel
         if (pad_x < 0 || pad_x > 4) return PG_ERR_UNSUPPORTED;  // the LDS halo row starts 4 columns left of the tile
         p.CoutP = round_up(Cout, 64);
-        return winograd == 2 ? pgconv::launch_wino4(p, s) : pgconv::launch_wino(p, s);
+        return winograd == 3 ? pgconv::launch_wino4b(p, s) : winograd == 2 ? pgconv::launch_wino4(p, s) : pgconv::launch_wino(p, s);
     }
     pg_conv2d_fusion tail = p.f;
     const int64_t slice = (int64_t)N * Cout * OH * OW;
@@ -609,6 +653,23 @@ PG_EXPORT int pg_conv2d_winograd4_forward(const float* x, const float* packed_u,
                                           int N, int Cin, int H, int W, int Cout, int pad_y, int pad_x, int OH, int OW,
                                           const int64_t ystride[4], const pg_conv2d_fusion* fusion, void* stream) {
     return conv_forward(2, x, packed_u, y, N, Cin, H, W, Cout, 3, 3, 1, pad_y, pad_x, OH, OW, ystride, 1, 1, 0, 0, fusion, stream);
+}
+
+PG_EXPORT int pg_conv2d_winograd4b_pack_weight(const float* w, float* packed, int Cout, int Cin,
+                                               float scale, int flip_hw, int transpose_oi, void* stream) {
+    if (!w || !packed || Cout <= 0 || Cin <= 0) return PG_ERR_INVALID_ARG;
+    const int CinP = round_up(Cin, 16), CoutP = round_up(Cout, 64);
+    const int64_t total = (int64_t)CinP * CoutP;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > pg::max_stream_blocks()) blocks = pg::max_stream_blocks();
+    hipLaunchKernelGGL(wino4b_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, packed, Cout, Cin, CinP, CoutP, scale, flip_hw, transpose_oi);
+    return pg::launch_status();
+}
+
+PG_EXPORT int pg_conv2d_winograd4b_forward(const float* x, const float* packed_u, float* y,
+                                           int N, int Cin, int H, int W, int Cout, int pad_y, int pad_x, int OH, int OW,
+                                           const int64_t ystride[4], const pg_conv2d_fusion* fusion, void* stream) {
+    return conv_forward(3, x, packed_u, y, N, Cin, H, W, Cout, 3, 3, 1, pad_y, pad_x, OH, OW, ystride, 1, 1, 0, 0, fusion, stream);
 }
 
 // Streaming 1x1 head for fp32 NCHW tensors (the ToRGB / parsing heads: Cout <= 8, networks.py:287-316): a thread owns 4 adjacent

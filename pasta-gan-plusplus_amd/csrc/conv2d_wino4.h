@@ -33,6 +33,7 @@
 // measures the effect on the whole config-2 network (3.7e-5 max-abs on `img` against the direct float32 run, F(2x2): 1.0e-5).
 #pragma once
 #include <cstdlib>
+#include <type_traits>
 #include "conv2d_wino.h"
 
 #ifndef WINO4_EXP
@@ -207,7 +208,8 @@ __global__ __launch_bounds__(768, 3) void conv2d_wino4(ConvParams p) {
 #endif
     };
 
-    f32x16 acc[6];                                   // [b]
+    f32x16 acc[6];                                   // [b]; never zeroed: see `chunk`
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
     // A-operand stream of this wave: [m-block][mt][a][chunk][group = (jg, quad)][xi 3][lane 64][4 pairs] floats, walked strictly
     // forwards inside a tile, one group ahead.
@@ -258,11 +260,6 @@ __global__ __launch_bounds__(768, 3) void conv2d_wino4(ConvParams p) {
     issue_chunk(0);
     dma_wait_all();
     while (true) {
-#pragma unroll
-        for (int j = 0; j < 6; j++)
-#pragma unroll
-            for (int k = 0; k < 16; k++) acc[j][k] = 0.f;
-
         int e_n = n, e_oy0 = oy0, e_ox0 = ox0, e_m0 = m0;
         bool has_next = false;
         int next = tile;
@@ -271,8 +268,11 @@ __global__ __launch_bounds__(768, 3) void conv2d_wino4(ConvParams p) {
         float* ep_bias = ep_scale + 64;
 
         W4_STAMP(0);
-#pragma unroll 1
-        for (int k = 0; k < nchunks; k++) {
+        // One K chunk.  FIRST (chunk 0 of a tile) is a second copy of the body in which the first MFMA into each accumulator reads the inline
+        // constant 0 as its C operand: the 96 v_mov per wave and tile that zeroed the accumulators (1.1 k issue cycles per SIMD and tile with
+        // nothing else running) are gone.
+        auto chunk = [&](const int k, auto first_tag) __attribute__((always_inline)) {
+            constexpr bool FIRST = decltype(first_tag)::value;
             __syncthreads();                                            // A: raw(k) has landed (the issuing waves waited for their requests at
                                                                         //    their third U group), V is free (every wave is past GEMM(k-1) / the tail)
             if (k == 2) W4_STAMP(1);
@@ -324,8 +324,10 @@ __global__ __launch_bounds__(768, 3) void conv2d_wino4(ConvParams p) {
                     const int cc = ok ? co : 0;
                     const float scv = qa.f.out_scale ? ld_opaque(qa.f.out_scale + (int64_t)n * qa.Cout + cc) : 1.f;
                     const float bi = qa.f.bias ? ld_opaque(qa.f.bias + cc) : 0.f;
-                    ep_scale[tc] = ok ? scv : 0.f;
-                    ep_bias[tc] = ok ? bi : 0.f;
+                    // linear / relu / lrelu are positively homogeneous and the host guarantees gain > 0:  act(v * s + b) * gain = act(v * (s * gain) + b * gain),
+                    // so the gain rides in the per-cout constants (and in the noise gain) and the tail's activation is max(w, w * slope) alone
+                    ep_scale[tc] = ok ? scv * qa.f.gain : 0.f;
+                    ep_bias[tc] = ok ? bi * qa.f.gain : 0.f;
                 }
             }
             load_u(ur[1]);                                               // group 1 of this chunk (BEFORE the DMA: its wait must not depend on it)
@@ -333,19 +335,23 @@ __global__ __launch_bounds__(768, 3) void conv2d_wino4(ConvParams p) {
             // gather map, prologue scales) one chunk EARLY -- right after this tile's last chunk has been requested -- so that the last
             // chunk only has to issue: the chore waves would otherwise reach the tail thousands of cycles after everybody else.
             bool issued = true;
-            const bool prep_now = nchunks == 1 ? true : k + 2 == nchunks;
-            if (k + 1 < nchunks) issue_chunk((k + 1) * W4_KC);
-            if (prep_now) {
-                e_n = n; e_oy0 = oy0; e_ox0 = ox0; e_m0 = m0;
-                next = tile + gridDim.x;
-                has_next = next < total;
-                if (has_next) prep_tile(next, cs0 + (par ^ 1) * cin_loop);
-            }
-            if (k + 1 == nchunks) {
-                if (has_next) issue_chunk(0);
-                else issued = false;
-            }
-            const bool dma_q = issued && chore;                          // this wave put DMA requests behind the words of groups 0 and 1
+            auto request_next = [&]() __attribute__((always_inline)) {
+                const bool prep_now = nchunks == 1 ? true : k + 2 == nchunks;
+                if (k + 1 < nchunks) issue_chunk((k + 1) * W4_KC);
+                if (prep_now) {
+                    e_n = n; e_oy0 = oy0; e_ox0 = ox0; e_m0 = m0;
+                    next = tile + gridDim.x;
+                    has_next = next < total;
+                    if (has_next) prep_tile(next, cs0 + (par ^ 1) * cin_loop);
+                }
+                if (k + 1 == nchunks) {
+                    if (has_next) issue_chunk(0);
+                    else issued = false;
+                }
+            };
+            constexpr bool LATE = (WINO4_EXP & 1024) != 0;               // timing experiment: the chore waves request the next chunk after group 1's MFMAs instead of before group 0's
+            if (!LATE) request_next();
+            bool dma_q = issued && chore;                                // this wave put DMA requests behind the words of groups 0 and 1 (LATE: of groups 2 and 3)
 
             // ---- GEMM phase: 4 groups of (3 xi) x (4 channel pairs).  Ring: group g in slot g & 1; requests: group 1 above, group g + 2
             // after the MFMAs of group g (g = 2: group 0 of the next chunk / tile; g = 3: nothing -- one group crosses the transform phase).
@@ -364,7 +370,7 @@ __global__ __launch_bounds__(768, 3) void conv2d_wino4(ConvParams p) {
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 const int jg = g >> 1;
-                wait_u(ur[g & 1], g < 2 && dma_q);
+                wait_u(ur[g & 1], (LATE ? g >= 2 : g < 2) && dma_q);
 #pragma unroll
                 for (int ph = 0; ph < 2; ph++) {
                     const int hg = 2 * g + ph;
@@ -374,16 +380,22 @@ __global__ __launch_bounds__(768, 3) void conv2d_wino4(ConvParams p) {
                     for (int s = 0; s < 2; s++)
 #pragma unroll
                         for (int jj = 0; jj < 3; jj++)
-                            acc[3 * jg + jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(ur[g & 1][jj][2 * ph + s], bw[hg & 1][jj][s], acc[3 * jg + jj], 0, 0, 0);
+                            acc[3 * jg + jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(ur[g & 1][jj][2 * ph + s], bw[hg & 1][jj][s],
+                                                                                    (FIRST && g == 2 * jg && ph == 0 && s == 0) ? zero16 : acc[3 * jg + jj], 0, 0, 0);
                 }
                 if (g == 2 && k + 1 == nchunks) a_reset(m0);             // from here on: the next tile's first group (m0 is already the next tile's)
                 if (g < 3) load_u(ur[g & 1]);
+                if (LATE && g == 1) { request_next(); dma_q = issued && chore; }
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (k == 2) W4_STAMP(4);
+            if (LATE && dma_q) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");   // the halo must have landed before the next barrier A; only the next chunk's first U group is younger
             if (!issued) dma_wait_all();                                 // last chunk of the last tile: nothing counted behind us
             if ((WINO4_EXP & 256) && chore) dma_wait_all();
-        }
+        };
+        chunk(0, std::true_type{});
+#pragma unroll 1
+        for (int k = 1; k < nchunks; k++) chunk(k, std::false_type{});
         W4_STAMP(5);
 
         // ---- inverse transform + fused epilogue, 16 couts per round through LDS (the V buffer)
@@ -404,7 +416,7 @@ __global__ __launch_bounds__(768, 3) void conv2d_wino4(ConvParams p) {
         const float cl = qa.f.clamp >= 0.f ? qa.f.clamp : __builtin_inff();
         const bool plain_tail = slope == 1.f && gain == 1.f && qa.f.clamp < 0.f;
         const int OHv = qa.OH, OWv = qa.OW, Coutv = qa.Cout;
-        const float ngain = qa.f.noise_gain;
+        const float ngain = qa.f.noise_gain * (spade ? 1.f : gain);      // (gain folded: see the epilogue constants)
         // (the host only launches this kernel with 16-byte addressable outputs: unit x stride, strides and OW multiples of 4, aligned bases)
         const bool full = e_oy0 + 8 <= OHv && e_ox0 + 64 <= OWv && e_m0 + 64 <= Coutv;      // wave-uniform: no predicates needed
         const bool seg_rows_full = full;
@@ -420,10 +432,22 @@ __global__ __launch_bounds__(768, 3) void conv2d_wino4(ConvParams p) {
         // act(v) * gain = max(v * gain, v * (slope * gain)) for 0 <= slope <= 1, gain > 0 (the host guarantees both): two multiplies and a
         // max instead of multiply / compare / select / multiply
         const float g_pos = gain, g_neg = gain * slope;
-        auto act4 = [&](f32x4 v) {
+        auto act4 = [&](f32x4 v) {                                       // SPADE tail: the gain cannot ride in per-cout constants there
             if (!plain_tail) {
 #pragma unroll
                 for (int e = 0; e < 4; e++) v[e] = __builtin_amdgcn_fmed3f(fmaxf(v[e] * g_pos, v[e] * g_neg), -cl, cl);
+            }
+            return v;
+        };
+        const bool need_act = slope != 1.f, need_clamp = qa.f.clamp >= 0.f;      // wave-uniform
+        auto act4n = [&](f32x4 v) {                                      // every other tail: gain already applied (see the epilogue constants)
+            if (need_act) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], v[e] * slope);
+            }
+            if (need_clamp) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[e] = __builtin_amdgcn_fmed3f(v[e], -cl, cl);
             }
             return v;
         };
@@ -535,7 +559,7 @@ __global__ __launch_bounds__(768, 3) void conv2d_wino4(ConvParams p) {
 #pragma unroll
                             for (int e = 0; e < 4; e++) w[e] = fmaf(v[r][e], esc, ebi);
                         }
-                        w = act4(w);
+                        w = act4n(w);
                         if (res_n) w += op[r];
                         v[r] = w;
                     }

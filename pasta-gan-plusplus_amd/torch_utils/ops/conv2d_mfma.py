@@ -96,6 +96,10 @@ def _init(plugin_name='conv2d_plugin'):
         lib.pg_conv2d_winograd4_pack_weight.argtypes = [vp, vp, i, i, f, i, i, vp]
         lib.pg_conv2d_winograd4_forward.restype = i
         lib.pg_conv2d_winograd4_forward.argtypes = [vp, vp, vp, i, i, i, i, i, i, i, i, i, ctypes.POINTER(i64), ctypes.POINTER(Fusion), vp]
+        lib.pg_conv2d_winograd4b_pack_weight.restype = i
+        lib.pg_conv2d_winograd4b_pack_weight.argtypes = [vp, vp, i, i, f, i, i, vp]
+        lib.pg_conv2d_winograd4b_forward.restype = i
+        lib.pg_conv2d_winograd4b_forward.argtypes = [vp, vp, vp, i, i, i, i, i, i, i, i, i, ctypes.POINTER(i64), ctypes.POINTER(Fusion), vp]
         lib.pg_spade_masked_sums.restype = i
         lib.pg_spade_masked_sums.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, vp]
         lib.pg_spade_feat_assemble.restype = i
@@ -124,6 +128,20 @@ def _init(plugin_name='conv2d_plugin'):
     return _plugin
 
 
+# Which F(4x4,3x3) kernel the policy hands out: 2 = csrc/conv2d_wino4.h (one 12-wave workgroup per CU, 8 x 64-pixel tiles, round 3), 3 = csrc/conv2d_wino4b.h
+# (two 8-wave workgroups per CU on the 16x16x4 MFMA, 8 x 32-pixel tiles, round 4).  Measured on the config-2 step (same box, profiles/r04_wino4_forms.txt): the
+# two-workgroup form is 1.5x faster on 32-pixel-wide images (no half-empty tiles, twice the workgroups) and 1-11 % slower everywhere else (twice the weight
+# stream from L2), so it serves images narrower than 64 pixels.  PG_WINO4B=0: never, PG_WINO4B=2: wherever F(4x4) runs (A/B runs).
+_WINO4B = os.environ.get('PG_WINO4B', '1')
+F4_FORM = 2 if _WINO4B == '0' else 3      # the form for narrow images (tests import this)
+
+
+def f4_form(hw):
+    if _WINO4B == '2':
+        return 3
+    return F4_FORM if int(hw[1]) < 64 else 2
+
+
 def use_winograd(kh, kw, stride, cout, cin=None, x2=None, pad=None, hw=None, xf=False, ep=None):
     """Launch policy for 3x3 stride-1 convolutions.  Returns 0 (direct implicit GEMM), 1 (Winograd F(2x2,3x3), csrc/conv2d_wino.h) or
     2 (Winograd F(4x4,3x3), csrc/conv2d_wino4.h) -- truthy = some Winograd kernel, and the value is what `pack_weight(winograd=...)` /
@@ -148,13 +166,13 @@ def use_winograd(kh, kw, stride, cout, cin=None, x2=None, pad=None, hw=None, xf=
         if (gain is not None and not float(gain) > 0) or (ep.get('act', 'linear') == 'lrelu' and alpha is not None and not 0 <= float(alpha) <= 1):
             f4_possible = False
     if mode == 'winograd4' and f4_possible:
-        return 2
+        return f4_form(hw)
     if mode in ('winograd', 'winograd2', 'winograd4'):
         return 1
     if not (int(cout) > 32 and (cin is None or int(cin) >= 16)):
         return 0
     if f4_possible and cin is not None and int(cin) >= 64 and int(cin) % 16 == 0 and int(cout) % 64 == 0 and int(hw[0]) >= 32 and int(hw[1]) >= 32:
-        return 2
+        return f4_form(hw)
     return 1
 
 
@@ -183,7 +201,8 @@ def pack_weight(w, scale=1.0, flip=False, transpose_oi=False, winograd=False):
     if winograd:
         if (kh, kw) != (3, 3):
             raise nat.NativeOpError('conv2d_mfma: the Winograd layout is for 3x3 weights')
-        size, pack = ((lib.pg_conv2d_winograd4_packed_size, lib.pg_conv2d_winograd4_pack_weight) if int(winograd) == 2 else
+        size, pack = ((lib.pg_conv2d_winograd4_packed_size, lib.pg_conv2d_winograd4b_pack_weight) if int(winograd) == 3 else
+                      (lib.pg_conv2d_winograd4_packed_size, lib.pg_conv2d_winograd4_pack_weight) if int(winograd) == 2 else
                       (lib.pg_conv2d_winograd_packed_size, lib.pg_conv2d_winograd_pack_weight))
         packed = torch.empty([size(cout, cin)], dtype=torch.float32, device=w.device)
         with torch.cuda.device(w.device):
@@ -279,7 +298,7 @@ def conv2d_forward(x, packed, cout, kh, kw, stride=1, pad=(0, 0), out_hw=None, y
         if winograd:
             if (kh, kw, int(stride)) != (3, 3, 1) or tuple(out_step) != (1, 1) or tuple(out_off) != (0, 0):
                 raise nat.NativeOpError('conv2d_mfma: winograd=True needs a 3x3 stride-1 dense-output launch')
-            fwd = lib.pg_conv2d_winograd4_forward if int(winograd) == 2 else lib.pg_conv2d_winograd_forward
+            fwd = {1: lib.pg_conv2d_winograd_forward, 2: lib.pg_conv2d_winograd4_forward, 3: lib.pg_conv2d_winograd4b_forward}[int(winograd)]
             st = fwd(nat.ptr(x), nat.ptr(packed), nat.ptr(y), n, cin, h, w, cout, int(pad_y), int(pad_x),
                      int(oh), int(ow), nat.i64arr(y.stride()), ctypes.byref(fz), nat.stream_of(x))
         else:
@@ -297,7 +316,7 @@ def conv2d_forward(x, packed, cout, kh, kw, stride=1, pad=(0, 0), out_hw=None, y
                                            ctypes.byref(fz), nat.stream_of(x))
         if _timeline is not None:
             ev1.record()
-            _timeline.append(((kh, kw, int(stride), ('winograd4' if int(winograd) == 2 else 'winograd') if winograd else 'direct', f'N{n} {cin}->{cout} {h}x{w}' + (' spade' if spade is not None else '') + (' xf' if in_act != 'linear' else '') + (' mod' if in_scale is not None else '') + (' res' if residual is not None else '')), 2.0 * n * cout * oh * ow * cin * kh * kw, ev0, ev1,
+            _timeline.append(((kh, kw, int(stride), ('winograd4' if int(winograd) >= 2 else 'winograd') if winograd else 'direct', f'N{n} {cin}->{cout} {h}x{w}' + (' spade' if spade is not None else '') + (' xf' if in_act != 'linear' else '') + (' mod' if in_scale is not None else '') + (' res' if residual is not None else '')), 2.0 * n * cout * oh * ow * cin * kh * kw, ev0, ev1,
                               4 * (x.numel() + (x2.numel() if x2 is not None else 0) + n * ychan * oh * ow)))
     nat.check(st, 'pg_conv2d_forward')
     return y
@@ -311,6 +330,9 @@ def pack_spade_gamma_beta(w_gamma, w_beta, scale_gamma=1.0, scale_beta=1.0, wino
     c = int(w_gamma.shape[0])
     grp = 32
     assert w_gamma.shape == w_beta.shape and c % 32 == 0
+    if int(winograd) == 3:      # the two-workgroup F(4x4) kernel finishes rows (2c, 2c + 1) in one lane: gamma / beta of a channel as ADJACENT rows
+        gw, bw = w_gamma.detach() * scale_gamma, w_beta.detach() * scale_beta
+        return pack_weight(torch.stack([gw, bw], dim=1).reshape(2 * c, *w_gamma.shape[1:]).contiguous(), winograd=3)
     g = (w_gamma.detach() * scale_gamma).reshape(c // grp, grp, *w_gamma.shape[1:])
     b = (w_beta.detach() * scale_beta).reshape(c // grp, grp, *w_beta.shape[1:])
     return pack_weight(torch.cat([g, b], dim=1).reshape(2 * c, *w_gamma.shape[1:]).contiguous(), winograd=winograd)

@@ -391,8 +391,10 @@ def test_conv2d_winograd_rejects_what_it_cannot_do():
 @pytest.mark.parametrize('n,cin,cout,h,w,pad', [(1, 16, 64, 8, 64, 1), (2, 64, 64, 16, 128, 1), (2, 32, 128, 24, 64, 1), (1, 48, 70, 9, 72, 1), (2, 20, 40, 13, 100, 1),
                                                 (1, 128, 128, 40, 192, 1), (3, 64, 64, 64, 64, 2), (3, 64, 64, 40, 64, 3), (2, 16, 64, 7, 8, 1), (1, 80, 64, 32, 64, 3), (2, 16, 64, 12, 62, 2),
                                                 (2, 40, 70, 13, 72, 3), (1, 32, 96, 19, 136, 3)])
-def test_conv2d_winograd4_kernel(n, cin, cout, h, w, pad):
-    """csrc/conv2d_wino4.h (Winograd F(4x4,3x3), round 3) on full, edge and ragged tiles (heights that are no multiple of 8, widths
+@pytest.mark.parametrize('form', [2, 3], ids=['one_wg_per_cu', 'two_wg_per_cu'])
+def test_conv2d_winograd4_kernel(n, cin, cout, h, w, pad, form):
+    """csrc/conv2d_wino4.h (Winograd F(4x4,3x3), round 3: form 2) and csrc/conv2d_wino4b.h (the same algorithm with two workgroups per CU on
+    v_mfma_f32_16x16x4_f32, round 4: form 3; 8 x 32-pixel tiles, its own weight stream and SPADE row order) on full, edge and ragged tiles (heights that are no multiple of 8, widths
     no multiple of 64, couts no multiple of 64, channel counts no multiple of 16): plain against the fp64 convolution;
     every fused stage, per-sample noise and SPADE mode against the direct MFMA kernel running the same launch (which meets the oracle in
     test_conv2d_fused_prologue_epilogue_vs_oracle; test_conv2d_winograd4_tails_vs_oracle compares one shape per tail kind with the oracle directly).
@@ -412,34 +414,35 @@ def test_conv2d_winograd4_kernel(n, cin, cout, h, w, pad):
     if ow % 4 != 0 or w % 4 != 0:         # 16-byte halo words and 16-byte output row segments: such a launch is declined (the policy never asks for it)
         from torch_utils.ops._native import NativeNotCovered
         with pytest.raises(NativeNotCovered):
-            run(2)
+            run(form)
         return
-    close(run(2), ref, 0, 1e-4 * scale_of(ref))
+    close(run(form), ref, 0, 1e-4 * scale_of(ref))
     kw = dict(in_scale=det_tensor('w4.s', [n, cin]).to(DEV) + 1.5, out_scale=det_tensor('w4.d', [n, cout]).abs().to(DEV) + 0.5, noise=det_tensor('w4.nz', [oh, ow]).to(DEV),
               noise_gain=0.3, bias=det_tensor('w4.b', [cout]).to(DEV), act='lrelu', alpha=0.2, gain=1.4, clamp=2.0, residual=det_tensor('w4.r', [n, cout, oh, ow]).to(DEV))
-    a, b = run(0, **kw), run(2, **kw)
+    a, b = run(0, **kw), run(form, **kw)
     close(b, a, 0, 2e-4 * scale_of(ref) * 3)
     kw = dict(noise=det_tensor('w4.nzb', [n, oh, ow]).to(DEV), bias=det_tensor('w4.b', [cout]).to(DEV), act='relu')
-    close(run(2, **kw), run(0, **kw), 0, 2e-4 * scale_of(ref))
+    close(run(form, **kw), run(0, **kw), 0, 2e-4 * scale_of(ref))
     if cout % 64 == 0:
         c = cout // 2
         sx, mean, rstd = det_tensor('w4.sx', [n, c, oh, ow]).to(DEV), det_tensor('w4.mu', [n, c]).to(DEV), det_tensor('w4.rs', [n, c]).abs().to(DEV) + 0.5
         outs = []
-        for algo in (0, 2):
+        for algo in (0, form):
             pk = conv2d_mfma.pack_spade_gamma_beta(wt[:c].contiguous(), wt[c:].contiguous(), winograd=algo)
             outs.append(conv2d_mfma.conv2d_forward(x, pk, cout, 3, 3, pad=(pad, pad), spade=(sx, mean, rstd), winograd=algo, act='lrelu', alpha=0.2, gain=1.4, clamp=3.0))
         close(outs[1], outs[0], 0, 2e-4 * scale_of(outs[0]))
     # flipped / O<->I transposed packs (the input-gradient route): dx of y = conv(x, w) is conv(dy, w^T flipped)
     dy = det_tensor(f'w4.dy.{cout}.{oh}', [n, cout, oh, ow]).to(DEV)
     if 0 <= 2 - pad <= 4 and ow % 4 == 0:
-        pk = conv2d_mfma.pack_weight(wt, flip=True, transpose_oi=True, winograd=2)
-        dx = conv2d_mfma.conv2d_forward(dy, pk, cin, 3, 3, pad=(2 - pad, 2 - pad), winograd=2)
+        pk = conv2d_mfma.pack_weight(wt, flip=True, transpose_oi=True, winograd=form)
+        dx = conv2d_mfma.conv2d_forward(dy, pk, cin, 3, 3, pad=(2 - pad, 2 - pad), winograd=form)
         want = torch.nn.grad.conv2d_input(x.shape, wt.double().cpu(), dy.double().cpu(), padding=pad)
         close(dx, want, 0, 1e-4 * scale_of(want))
 
 
+@pytest.mark.parametrize('form', [2, 3], ids=['one_wg_per_cu', 'two_wg_per_cu'])
 @pytest.mark.parametrize('n,h,cin,cout', [(8, 512, 64, 64), (8, 256, 128, 128)])
-def test_conv2d_winograd4_repeated_launches_are_identical(n, h, cin, cout):
+def test_conv2d_winograd4_repeated_launches_are_identical(n, h, cin, cout, form):
     """Full-size launches of the F(4x4) kernel, 60 in a row with other work in between: every result must equal the first one bit for bit
     and match the direct kernel.  (Round 3: the tail's exchange area aliases the V buffer; without the barrier in front of its first write a
     fast wave overwrote operands slower waves were still multiplying -- 20 % of the launches had wrong tiles, none of the small cases did.)"""
@@ -448,19 +451,20 @@ def test_conv2d_winograd4_repeated_launches_are_identical(n, h, cin, cout):
     x = torch.randn([n, cin, h, h], generator=gen).to(DEV)
     other = torch.randn([n, cin, h, h], generator=gen).to(DEV)
     wt = (torch.randn([cout, cin, 3, 3], generator=gen) / (3 * math.sqrt(cin))).to(DEV)
-    pk4, pk0 = conv2d_mfma.pack_weight(wt, winograd=2), conv2d_mfma.pack_weight(wt)
+    pk4, pk0 = conv2d_mfma.pack_weight(wt, winograd=form), conv2d_mfma.pack_weight(wt)
     ref = conv2d_mfma.conv2d_forward(x, pk0, cout, 3, 3, pad=(1, 1))
-    first = conv2d_mfma.conv2d_forward(x, pk4, cout, 3, 3, pad=(1, 1), winograd=2)
+    first = conv2d_mfma.conv2d_forward(x, pk4, cout, 3, 3, pad=(1, 1), winograd=form)
     assert float((first - ref).abs().max()) <= 1e-4 * scale_of(ref)
     for it in range(60):
         if it % 3 == 1:
             conv2d_mfma.conv2d_forward(other, pk0, cout, 3, 3, pad=(1, 1))
-        y = conv2d_mfma.conv2d_forward(x, pk4, cout, 3, 3, pad=(1, 1), winograd=2)
+        y = conv2d_mfma.conv2d_forward(x, pk4, cout, 3, 3, pad=(1, 1), winograd=form)
         assert torch.equal(y, first), f'launch {it} differs from the first one: max |d| {float((y - first).abs().max()):.3e}'
 
 
+@pytest.mark.parametrize('form', [2, 3], ids=['one_wg_per_cu', 'two_wg_per_cu'])
 @pytest.mark.parametrize('tail', ['plain', 'residual', 'mod_noise', 'spade'])
-def test_conv2d_winograd4_tails_vs_oracle(tail):
+def test_conv2d_winograd4_tails_vs_oracle(tail, form):
     """One shape per tail kind of the F(4x4) kernel (W4_TAIL_PLAIN / the run-time tail with a residual / modulated + noise / W4_TAIL_SPADE)
     against the UNFUSED oracle composition (oracle.ops_ref + fp64 convolution), not against another HIP kernel ("what's weak")."""
     from torch_utils.ops import conv2d_mfma
@@ -472,8 +476,8 @@ def test_conv2d_winograd4_tails_vs_oracle(tail):
     wt = det_tensor('w4o.w', [cout, cin, 3, 3], scale=1 / (3 * math.sqrt(cin)))
     b = det_tensor('w4o.b', [cout])
     conv = lambda xx, ww: F.conv2d(xx.double(), ww.double(), padding=1)
-    run = lambda pk, **kw: conv2d_mfma.conv2d_forward(x.to(DEV), pk, cout, 3, 3, pad=(1, 1), winograd=2, **kw)
-    pk = conv2d_mfma.pack_weight(wt.to(DEV), winograd=2)
+    run = lambda pk, **kw: conv2d_mfma.conv2d_forward(x.to(DEV), pk, cout, 3, 3, pad=(1, 1), winograd=form, **kw)
+    pk = conv2d_mfma.pack_weight(wt.to(DEV), winograd=form)
     if tail == 'plain':
         y = run(pk, bias=b.to(DEV), act='lrelu', alpha=0.2, gain=math.sqrt(2), clamp=1.5)
         ref = R.bias_act(conv(x, wt), b.double(), act='lrelu', gain=math.sqrt(2), clamp=1.5)
@@ -493,7 +497,7 @@ def test_conv2d_winograd4_tails_vs_oracle(tail):
         sx = det_tensor('w4o.sx', [n, c, h, w]) * 2 + 0.3
         mean = sx.double().mean([2, 3])
         rstd = (sx.double().var([2, 3], unbiased=False) + 1e-5).rsqrt()
-        pks = conv2d_mfma.pack_spade_gamma_beta(wt[:c].contiguous().to(DEV), wt[c:].contiguous().to(DEV), winograd=2)
+        pks = conv2d_mfma.pack_spade_gamma_beta(wt[:c].contiguous().to(DEV), wt[c:].contiguous().to(DEV), winograd=form)
         y = run(pks, spade=(sx.to(DEV), mean.float().to(DEV), rstd.float().to(DEV)), act='relu', gain=math.sqrt(2))
         ref = NR.instance_norm(sx.double()) * (1 + conv(x, wt[:c])) + conv(x, wt[c:])
         ref = R.bias_act(ref, None, act='relu', gain=math.sqrt(2))
@@ -503,34 +507,40 @@ def test_conv2d_winograd4_tails_vs_oracle(tail):
 def test_conv2d_winograd4_policy_and_declines():
     from torch_utils.ops import conv2d_mfma
     from torch_utils.ops._native import NativeNotCovered
+    F4 = 2                                         # images at least 64 pixels wide: the one-workgroup form
+    FN = conv2d_mfma.F4_FORM                      # narrower images: 3 (two workgroups per CU) unless PG_WINO4B=0
+    assert FN in (2, 3)
     # the tail's max() form of the activation is exact for gain > 0, 0 <= alpha <= 1 only: the policy keeps anything else on F(2x2),
     # the kernel declines it, and the F(2x2) launch of the same request meets the oracle
     geo = dict(pad=(1, 1), hw=(64, 64))
-    assert conv2d_mfma.use_winograd(3, 3, 1, 64, 64, ep=dict(act='lrelu', alpha=0.2, gain=1.4), **geo) == 2
+    assert conv2d_mfma.use_winograd(3, 3, 1, 64, 64, ep=dict(act='lrelu', alpha=0.2, gain=1.4), **geo) == F4
     assert conv2d_mfma.use_winograd(3, 3, 1, 64, 64, ep=dict(act='lrelu', alpha=1.5, gain=1.4), **geo) == 1
     assert conv2d_mfma.use_winograd(3, 3, 1, 64, 64, ep=dict(act='relu', gain=-1.0), **geo) == 1
-    assert conv2d_mfma.use_winograd(3, 3, 1, 64, 64, ep=dict(act='relu', alpha=None, gain=None), **geo) == 2
+    assert conv2d_mfma.use_winograd(3, 3, 1, 64, 64, ep=dict(act='relu', alpha=None, gain=None), **geo) == F4
     xa = det_tensor('w4d.xa', [1, 64, 32, 64])
     wa = det_tensor('w4d.wa', [64, 64, 3, 3], scale=0.05)
     for kw in (dict(act='lrelu', alpha=1.5, gain=1.4), dict(act='lrelu', alpha=0.2, gain=-0.5), dict(act='relu', gain=-2.0)):
-        with pytest.raises(NativeNotCovered):
-            conv2d_mfma.conv2d_forward(xa.to(DEV), conv2d_mfma.pack_weight(wa.to(DEV), winograd=2), 64, 3, 3, pad=(1, 1), winograd=2, **kw)
+        for form in (2, 3):
+            with pytest.raises(NativeNotCovered):
+                conv2d_mfma.conv2d_forward(xa.to(DEV), conv2d_mfma.pack_weight(wa.to(DEV), winograd=form), 64, 3, 3, pad=(1, 1), winograd=form, **kw)
         y = conv2d_mfma.conv2d_forward(xa.to(DEV), conv2d_mfma.pack_weight(wa.to(DEV), winograd=1), 64, 3, 3, pad=(1, 1), winograd=1, **kw)
         from oracle import ops_ref as R
         import torch.nn.functional as F
         ref = R.bias_act(F.conv2d(xa.double(), wa.double(), padding=1), None, act=kw['act'], alpha=kw.get('alpha'), gain=kw['gain'])
         close(y, ref, 0, 1e-5 * scale_of(ref))
-    assert conv2d_mfma.use_winograd(3, 3, 1, 128, 128, pad=(1, 1), hw=(256, 256)) == 2
+    assert conv2d_mfma.use_winograd(3, 3, 1, 128, 128, pad=(1, 1), hw=(256, 256)) == F4
     assert conv2d_mfma.use_winograd(3, 3, 1, 128, 128, pad=(1, 1)) == 1                          # no image size: F(2x2)
     assert conv2d_mfma.use_winograd(3, 3, 1, 128, 128, pad=(1, 1), hw=(256, 254)) == 1          # width no multiple of 4
     assert conv2d_mfma.use_winograd(3, 3, 1, 128, 128, pad=(2, 2), hw=(256, 256)) == 1          # output width 258: no 16-byte row segments
     assert conv2d_mfma.use_winograd(3, 3, 1, 128, 128, pad=(1, 1), hw=(256, 256), xf=True) == 1  # input pre-activation: F(2x2) has the prologue
     assert conv2d_mfma.use_winograd(3, 3, 1, 96, 128, pad=(1, 1), hw=(256, 256)) == 1 and conv2d_mfma.use_winograd(3, 3, 1, 128, 32, pad=(1, 1), hw=(256, 256)) == 1
-    assert conv2d_mfma.use_winograd(3, 3, 1, 512, 512, pad=(1, 1), hw=(16, 16)) == 1 and conv2d_mfma.use_winograd(3, 3, 1, 512, 512, pad=(1, 1), hw=(32, 32)) == 2 and conv2d_mfma.use_winograd(3, 3, 1, 16, 16, hw=(256, 256)) == 0
+    assert conv2d_mfma.use_winograd(3, 3, 1, 512, 512, pad=(1, 1), hw=(16, 16)) == 1 and conv2d_mfma.use_winograd(3, 3, 1, 512, 512, pad=(1, 1), hw=(32, 32)) == FN and conv2d_mfma.use_winograd(3, 3, 1, 16, 16, hw=(256, 256)) == 0
     x = det_tensor('w4d.x', [1, 16, 8, 66]).to(DEV)
     wt = det_tensor('w4d.w', [64, 16, 3, 3]).to(DEV)
     with pytest.raises(NativeNotCovered):
         conv2d_mfma.conv2d_forward(x, conv2d_mfma.pack_weight(wt, winograd=2), 64, 3, 3, pad=(1, 1), winograd=2)        # W % 4 != 0
+    with pytest.raises(NativeNotCovered):
+        conv2d_mfma.conv2d_forward(x, conv2d_mfma.pack_weight(wt, winograd=3), 64, 3, 3, pad=(1, 1), winograd=3)
 
 
 @pytest.mark.parametrize('n,cin,cout,h,w,kh,kw,pad,step', [(8, 512, 512, 8, 8, 2, 2, 1, 2), (4, 512, 96, 16, 16, 1, 1, 0, 1), (2, 256, 512, 32, 32, 3, 3, 1, 1),
@@ -1219,12 +1229,17 @@ def test_config4_whole_iteration_batch4_vs_oracle():
         assert want.keys() == got[phase].keys()
         numel = {f'{k}.{pn}': p_.numel() for k, m in ref.items() for pn, p_ in m.named_parameters()}
         worst, n_grad, bad = (0.0, ''), 0, []
+        owner = 'G.' if phase.startswith('G') else 'D.'
         for key, w in want.items():
+            if not key.startswith(owner):
+                continue                 # only the phase's own networks: the other buckets still hold the gradients of THEIR last phase (views into flat buckets)
             g = got[phase][key]
             if w is None or w == 0.0:
                 assert g is None or g == 0.0, (phase, key, g)     # e.g. synthesis.b8.const (networks.py:2118 vs :2157-2161) never receives a gradient
                 continue
             assert g is not None, (phase, key)
+            if key.endswith('noise_strength'):
+                continue                 # d/d(noise_strength) = sum(dy * noise): the training route draws the noise afresh on each device
             n_grad += 1
             if numel[key] == 1:          # a signed sum over every pixel of a layer: sign and magnitude only (see test_config4_generator_gradients_full_width_vs_oracle)
                 if not 0.5 <= g / (w + 1e-30) <= 2.0:

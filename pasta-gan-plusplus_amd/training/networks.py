@@ -209,13 +209,21 @@ def _modconv_fast16(x, weight, styles, noise, up, padding, resample_filter, demo
         tpad, fir_pad = _up2_geometry(kh, kw, fw, fh, padding)
         composite = ((kh, kw, fw, fh) == (3, 3, 4, 4) and tuple(tpad) == (0, 0) and list(fir_pad) == [1, 1, 1, 1] and resample_filter.ndim == 2
                      and os.environ.get('PG_UP2_COMPOSITE', '1') != '0')
+        # Per-layer policy, measured in round 4 and NOT adopted: the composite kernel has 36 taps per output phase set where the
+        # reference's transposed convolution has 9 (conv2d_resample.py:125-142) -- 4x the multiplies and 4x the packed weights -- so the layers with
+        # Cout * 36 > 2 * H * W (the 8^2 ... 64^2 inputs of the 1024-wide stack) were tried as the transposed convolution's four phases on ONE shared
+        # weight pack + the channels-last FIR (PG_UP2_POLICY=auto).  Those layers are latency-bound, not multiply-bound: four phase launches of
+        # 30-97 us + the FIR pass against ONE composite launch of 69-137 us -- config 5 2023 -> 1696 images/s on the same box
+        # (profiles/r04_cfg5_up2_policy.txt).  What would pay is the four transposed phases as ONE launch (taps zero-padded to 2x2: 16 instead of 36).
+        if composite and cout * 36 > 2 * h * w and os.environ.get('PG_UP2_POLICY', 'composite') == 'auto':
+            composite = False
     # Weight-dominated layers (the low-resolution blocks: N per-sample copies of a 512..1024-channel kernel outweigh the
     # activations): the reference's NON-fused form (networks.py:73-84; its own choice for half precision at batch > 1,
     # networks.py:2152-2154) -- x * styles, ONE shared weight pack cached across steps, demodulation as the epilogue's
     # per-(n, cout) scale.  Styles are normalised per sample like networks.py:57-59 so that x * s stays in 16-bit range;
     # the factor returns through dcoefs (computed from the normalised styles).
     taps = 36 if composite else kh * kw
-    shared = (up == 1 or composite) and cout * taps > 2 * h * w and os.environ.get('PG_MODCONV16_SHARED', '1') != '0'
+    shared = cout * taps > 2 * h * w and os.environ.get('PG_MODCONV16_SHARED', '1') != '0'
     out_scale = None
     w2 = cache.get(('w2',), [weight], lambda: conv2d_mfma.modconv_w2(w32)) if demodulate else None
     if shared:          # one launch: per-sample maximum, normalised styles (float32 + 16-bit), coefficients of the normalised styles
@@ -271,10 +279,14 @@ def _modconv_fast16(x, weight, styles, noise, up, padding, resample_filter, demo
             conv2d_mfma16.conv2d_forward(xcl, packed, cout, 3, 3, pad=(1, 1), out_hw=(h, w), y=y, out_step=(2, 2), out_off=(a, b), sample_stride=per,
                                          out_scale=out_scale, noise=nz, **ep)
         return y if res is None else y.add_(res)
-    phases = conv2d_mfma16.pack_transposed(transposed_weight(), x.dtype, 2, tpad, (h, w), out_hw, styles=s32, dcoefs=dcoefs)
+    if shared:          # x already carries the normalised styles; demodulation is a per-(n, cout) scale, which commutes with the FIR that follows
+        phases = cache.get(('up2_t_shared', flip_weight, x.dtype, tuple(tpad), (h, w)), [weight],
+                           lambda: conv2d_mfma16.pack_transposed(transposed_weight(), x.dtype, 2, tpad, (h, w), out_hw))
+    else:
+        phases = conv2d_mfma16.pack_transposed(transposed_weight(), x.dtype, 2, tpad, (h, w), out_hw, styles=s32, dcoefs=dcoefs)
     if phases is None:
         return None
-    y = conv2d_mfma16.conv_transpose2d_forward(x, phases, cout, out_hw, stride=2)
+    y = conv2d_mfma16.conv_transpose2d_forward(x, phases, cout, out_hw, stride=2, **(dict(out_scale=out_scale) if shared and out_scale is not None else {}))
     res = ep.pop('residual', None)
     b = ep.get('bias')
     fused = upfirdn2d.upfirdn2d_bias_act(y, resample_filter, padding=fir_pad, gain=4, noise=noise, b=b, act=ep.get('act', 'linear'),

@@ -355,6 +355,8 @@ __global__ __launch_bounds__(768, 3) void conv2d_wino4(ConvParams p) {
 
             // ---- GEMM phase: 4 groups of (3 xi) x (4 channel pairs).  Ring: group g in slot g & 1; requests: group 1 above, group g + 2
             // after the MFMAs of group g (g = 2: group 0 of the next chunk / tile; g = 3: nothing -- one group crosses the transform phase).
+            if ((WINO4_EXP & 2048) && chore) __builtin_amdgcn_s_setprio(1);      // timing experiments: the chore waves (the youngest of each SIMD, with the DMA issue on top) /
+            if ((WINO4_EXP & 4096) && !chore) __builtin_amdgcn_s_setprio(1);     // the other eight waves at priority 1 during the GEMM phase
             const float* vb = V + 6 * ta * 512 + w4_fresh_lane();                // B operand base: V[6a + b][pair][half][l31]
             // B words are read half a group (3 xi x 2 pairs) ahead of the MFMAs that use them: 6 MFMAs = 384 matrix-pipe cycles cover
             // the LDS latency, so a wave only ever waits for LDS at the first half group of a chunk.
@@ -388,6 +390,7 @@ __global__ __launch_bounds__(768, 3) void conv2d_wino4(ConvParams p) {
                 if (LATE && g == 1) { request_next(); dma_q = issued && chore; }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if (WINO4_EXP & (2048 | 4096)) __builtin_amdgcn_s_setprio(0);
             if (k == 2) W4_STAMP(4);
             if (LATE && dma_q) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");   // the halo must have landed before the next barrier A; only the next chunk's first U group is younger
             if (!issued) dma_wait_all();                                 // last chunk of the last tile: nothing counted behind us

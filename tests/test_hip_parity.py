@@ -534,7 +534,7 @@ def test_conv2d_winograd4_policy_and_declines():
     assert conv2d_mfma.use_winograd(3, 3, 1, 128, 128, pad=(2, 2), hw=(256, 256)) == 1          # output width 258: no 16-byte row segments
     assert conv2d_mfma.use_winograd(3, 3, 1, 128, 128, pad=(1, 1), hw=(256, 256), xf=True) == 1  # input pre-activation: F(2x2) has the prologue
     assert conv2d_mfma.use_winograd(3, 3, 1, 96, 128, pad=(1, 1), hw=(256, 256)) == 1 and conv2d_mfma.use_winograd(3, 3, 1, 128, 32, pad=(1, 1), hw=(256, 256)) == 1
-    assert conv2d_mfma.use_winograd(3, 3, 1, 512, 512, pad=(1, 1), hw=(16, 16)) == (3 if FN == 3 else 1) and conv2d_mfma.use_winograd(3, 3, 1, 512, 512, pad=(1, 1), hw=(8, 8)) == 1 and conv2d_mfma.use_winograd(3, 3, 1, 512, 512, pad=(1, 1), hw=(32, 32)) == FN and conv2d_mfma.use_winograd(3, 3, 1, 16, 16, hw=(256, 256)) == 0
+    assert conv2d_mfma.use_winograd(3, 3, 1, 512, 512, pad=(1, 1), hw=(16, 16)) == 1 and conv2d_mfma.use_winograd(3, 3, 1, 512, 512, pad=(1, 1), hw=(8, 8)) == 1 and conv2d_mfma.use_winograd(3, 3, 1, 512, 512, pad=(1, 1), hw=(32, 32)) == FN and conv2d_mfma.use_winograd(3, 3, 1, 16, 16, hw=(256, 256)) == 0
     x = det_tensor('w4d.x', [1, 16, 8, 66]).to(DEV)
     wt = det_tensor('w4d.w', [64, 16, 3, 3]).to(DEV)
     with pytest.raises(NativeNotCovered):

@@ -672,7 +672,7 @@ int launch16(const Conv16Params& p0, hipStream_t s) {
     p.m_tilesX = magic(p.tilesX); p.m_tilesY = magic(p.tilesY); p.m_mblocks = magic(p.mblocks); p.m_ksplit = magic(p.ksplit);
     if ((int64_t)p.N * p.H * p.W * p.xC * 2 > 0x7fffffffLL) return PG_ERR_TOO_LARGE;      // whole-tensor descriptor of x
     const int64_t blocks = tiles < (int64_t)num_cu() ? tiles : (int64_t)num_cu();       // persistent: one workgroup per CU
-    if constexpr (KH == 3 && KW == 3 && S == 1 && NB == 3 && !SPLIT && TWL > 8) {      // the two-role form (see the kernel): >= 2 chunks per tile; (the 8 x 8-pixel tile of the 8^2 layers measured slower with it: 44.5 vs 36.5 us)
+    if constexpr (((KH == 3 && KW == 3) || (KH == 2 && KW == 2)) && S == 1 && NB == 3 && !SPLIT && TWL > 8) {      // the two-role form (round 4: also the 2x2 kernels of the merged transposed phases) (see the kernel): >= 2 chunks per tile; (the 8 x 8-pixel tile of the 8^2 layers measured slower with it: 44.5 vs 36.5 us)
         static const bool split_on = [] { const char* e = getenv("PG_CONV16_SPLIT"); return e ? atoi(e) != 0 : true; }();       // A/B switch
         const int cin_loop = p.ksplit > 1 ? p.kpart : p.Cin;
         if (split_on && (cin_loop + KC - 1) / KC >= 2) return launch16<T, KH, KW, S, TWL, WM, MT, NT, KC, NB, true>(p0, s);
@@ -691,8 +691,8 @@ int launch16(const Conv16Params& p0, hipStream_t s) {
 // regular shape, so a quarter of the split-K shares and workspace traffic), 0 = the regular tile.  Shared by the launcher and the split-K planner.  PG_CONV16_SMALL=0 switches it off (A/B).
 inline int small_tile16(int KH, int KW, int S, int OH, int OW, int Cout, int phase_cout = 0) {
     static const bool on = [] { const char* e = getenv("PG_CONV16_SMALL"); return e ? atoi(e) != 0 : true; }();
-    if (!on || KH != 3 || KW != 3 || S != 1 || Cout < 128 || phase_cout % 64 != 0) return 0;      // (four-phase mode: whole cout blocks per phase)
-    if (OH <= 8 && OW <= 8 && phase_cout % 128 == 0) return 1;
+    if (!on || !((KH == 3 && KW == 3) || (KH == 2 && KW == 2)) || S != 1 || Cout < 128 || phase_cout % 64 != 0) return 0;      // (four-phase mode: whole cout blocks per phase)
+    if (KH == 3 && OH <= 8 && OW <= 8 && phase_cout % 128 == 0) return 1;
     static const int lim2 = [] { const char* e = getenv("PG_CONV16_SMALL2_MAX"); return e ? atoi(e) : 64; }();      // (measured on config 5: 16 -> 2.74, 32 -> 2.72, 64 -> 2.68 ms/step: less split-K)
     if (OH <= lim2 && OW <= lim2) return 2;
     return 0;
@@ -701,7 +701,7 @@ inline int small_tile16(int KH, int KW, int S, int OH, int OW, int Cout, int pha
 // M-tile count by the width of the layer (32-cout blocks for narrow layers: no MFMA spent on padding rows)
 template <typename T, int KH, int KW, int S, int NT, int KC, int NB>
 int launch16_mt(const Conv16Params& p, hipStream_t s) {
-    if constexpr (KH == 3 && KW == 3 && S == 1) {
+    if constexpr (((KH == 3 && KW == 3) || (KH == 2 && KW == 2)) && S == 1) {
         const int sm = small_tile16(KH, KW, S, p.OH, p.OW, p.Cout, p.f.phase_cout);
         if (sm == 1) {                                                               // TH x TW = 8 x 8, BM = 128
             if constexpr (KC == 32) return PG_ERR_UNSUPPORTED;                       // (no 32-channel-chunk form of this tile: launch16_k3s1 does not send it here)

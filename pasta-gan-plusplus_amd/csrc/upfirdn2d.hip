@@ -496,7 +496,8 @@ __global__ __launch_bounds__(256, 2) void upfirdn2d_cl(Params p) {
             const int fy = p.flip ? ky : p.fh - 1 - ky, fx = p.flip ? kx : p.fw - 1 - kx;
             tap[ky][kx] = (ky < p.fh && kx < p.fw) ? p.f[fy * p.fs[0] + fx * p.fs[1]] : 0.f;
         }
-    const T* __restrict__ xn = (const T*)p.x + (int64_t)n * p.inH * p.inW * p.C + cv * V;
+    const T* __restrict__ xn = (const T*)p.x + (int64_t)n * p.xs[0] + cv * V;      // rows / images may be pitched (xs[2] >= inW * C): a view into a padded producer buffer
+    const int64_t xrow = p.xs[2];
     float acc[RPT][V];
 #pragma unroll
     for (int r = 0; r < RPT; r++)
@@ -509,7 +510,7 @@ __global__ __launch_bounds__(256, 2) void upfirdn2d_cl(Params p) {
         for (int kx = 0; kx < FW; kx++) {
             const int ix = ix0 + kx;
             const bool ok = row_ok && ix >= 0 && ix < p.inW;
-            u32x4 v = *(const u32x4*)(xn + ((int64_t)(ok ? iy : 0) * p.inW + (ok ? ix : 0)) * p.C);    // always a valid address
+            u32x4 v = *(const u32x4*)(xn + (int64_t)(ok ? iy : 0) * xrow + (int64_t)(ok ? ix : 0) * p.C);    // always a valid address
 #pragma unroll
             for (int e = 0; e < 4; e++) v[e] = ok ? v[e] : 0u;
             raw[kx] = v;
@@ -609,10 +610,15 @@ __global__ __launch_bounds__(256) void upfirdn2d_cl_up2(Params p) {
 template <typename T>
 bool try_channels_last(const Params& p, hipStream_t s, int* st) {
     constexpr int V = Vec16<T>::N;
-    const bool dense_cl = p.xs[1] == 1 && p.xs[3] == p.C && p.xs[2] == (int64_t)p.inW * p.C && p.xs[0] == (int64_t)p.inH * p.inW * p.C &&
+    const bool x_dense = p.xs[2] == (int64_t)p.inW * p.C && p.xs[0] == (int64_t)p.inH * p.inW * p.C;
+    // the blur / decimation kernel also takes a PITCHED channels-last input (a [:, :, :H, :W] view of a larger NHWC buffer: the merged transposed-conv phases
+    // of the 16-bit up-sampling layers write a (2H+2) x (2W+2) buffer whose first 2H+1 rows / columns are the transposed convolution's result)
+    const bool x_pitched = p.xs[2] >= (int64_t)p.inW * p.C && p.xs[0] >= (int64_t)p.inH * p.xs[2] && p.xs[2] % V == 0 && p.xs[0] % V == 0;
+    const bool dense_cl = p.xs[1] == 1 && p.xs[3] == p.C && (x_dense || x_pitched) &&
                           p.ys[1] == 1 && p.ys[3] == p.C && p.ys[2] == (int64_t)p.outW * p.C && p.ys[0] == (int64_t)p.outH * p.outW * p.C;
     if (!dense_cl || p.C % V != 0 || p.fw > 4 || p.fh > 4 || !aligned16(p.x) || !aligned16(p.y) || p.N > 65535) return false;
     if (p.upx == 2 && p.upy == 2 && p.dnx == 1 && p.dny == 1 && !p.has_ep) {
+        if (!x_dense) return false;
         const int64_t bx2 = ((int64_t)p.outW * (p.C / V) + 255) / 256;
         if (bx2 > 0x7fffffffLL || p.outH > 65535) return false;
         hipLaunchKernelGGL((upfirdn2d_cl_up2<T, 4, 4>), dim3((unsigned)bx2, (unsigned)p.outH, (unsigned)p.N), dim3(256), 0, s, p);

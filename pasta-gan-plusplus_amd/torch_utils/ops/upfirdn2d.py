@@ -58,7 +58,8 @@ def upfirdn2d_bias_act(x, f, up=1, down=1, padding=0, flip_filter=False, gain=1,
     _init()
     if x.ndim != 4 or f is None or f.ndim != 2 or act not in _FUSED_ACTS:
         return None
-    channels_last = x.shape[1] > 1 and x.stride(1) == 1 and x.is_contiguous(memory_format=torch.channels_last)
+    channels_last = x.shape[1] > 1 and x.stride(1) == 1 and (x.is_contiguous(memory_format=torch.channels_last) or
+                                                              (x.stride(3) == x.shape[1] and x.stride(2) >= x.shape[3] * x.shape[1] and x.stride(0) >= x.shape[2] * x.stride(2)))   # dense NHWC or a [:, :, :H, :W] view of one
     pitched = (x.dtype == torch.float32 and x.stride(3) == 1 and x.stride(2) >= x.shape[3] and x.stride(1) == x.shape[2] * x.stride(2)
                and x.stride(0) == x.shape[1] * x.stride(1))        # dense NCHW, or NCHW with padded rows (conv2d_mfma.conv_up2_forward)
     if not (pitched or (channels_last and x.dtype in (torch.float32, torch.float16, torch.bfloat16))):

@@ -192,6 +192,27 @@ def _up2_composite_phases(wt_iohw, f):
     return {(a, b): k6[:, :, [4 + a, 2 + a, a]][:, :, :, [4 + b, 2 + b, b]].contiguous() for a in (0, 1) for b in (0, 1)}
 
 
+def _up2_transposed_phases_2x2(wt_iohw):
+    """conv_transpose2d(x, wt, stride=2, padding=0) for a 3x3 kernel as FOUR 2x2 correlations of the zero-padded (by 1) input, one per output
+    parity (a, b), stacked along Cout in the order (0,0), (0,1), (1,0), (1,1) of the 16-bit kernel's four-phase launch:
+        y[2q + a, 2r + b] = sum_{ty, tx} k_ab[ty, tx] * x[q - 1 + ty, r - 1 + tx],   q = 0..H, r = 0..W   ((H+1) x (W+1) positions per phase)
+    with, per axis, parity 0: k[0] = w[2] (sample q - 1), k[1] = w[0] (sample q); parity 1: k[0] = 0, k[1] = w[1].  16 taps of which 9 are non-zero,
+    against 36 of the composite kernels (`_up2_composite_phases`).  Position q = H of an odd parity lands on output row 2H + 1, one past the
+    result: the caller gives the launch a (2H+2) x (2W+2) buffer.  Returns IOHW [Cin, 4 * Cout, 2, 2]."""
+    cin, cout = int(wt_iohw.shape[0]), int(wt_iohw.shape[1])
+    sel = {0: (2, 0), 1: (None, 1)}
+    out = []
+    for a in (0, 1):
+        for b in (0, 1):
+            k = wt_iohw.new_zeros([cin, cout, 2, 2])
+            for ty, ky in enumerate(sel[a]):
+                for tx, kx in enumerate(sel[b]):
+                    if ky is not None and kx is not None:
+                        k[:, :, ty, tx] = wt_iohw[:, :, ky, kx]
+            out.append(k)
+    return torch.cat(out, dim=1).contiguous()
+
+
 def _modconv_fast16(x, weight, styles, noise, up, padding, resample_filter, demodulate, flip_weight, cache, epilogue):
     """bf16 / fp16 inference route: the reference's fused form (networks.py:85-94) -- per-sample weights
     T(w * styles * dcoefs) -- packed by one small kernel, then ONE launch of the 16-bit MFMA convolution per output phase
@@ -217,12 +238,22 @@ def _modconv_fast16(x, weight, styles, noise, up, padding, resample_filter, demo
         # (profiles/r04_cfg5_up2_policy.txt).  What would pay is the four transposed phases as ONE launch (taps zero-padded to 2x2: 16 instead of 36).
         if composite and cout * 36 > 2 * h * w and os.environ.get('PG_UP2_POLICY', 'composite') == 'auto':
             composite = False
+        # ... which is the `merged` policy (PG_UP2_POLICY=merged): the four transposed phases as 2x2 kernels (16 taps, 9 non-zero) stacked along Cout, ONE
+        # launch (two-role form, 16 x 16-pixel tiles) into a (2H+2) x (2W+2) buffer, then the channels-last FIR with the fused tail on its [2H+1, 2W+1]
+        # view, for the weight-dominated layers with H >= 32.  Built, parity-green (tests/test_conv16.py::test_up2_layer_routes_vs_oracle) and measured:
+        # 512 -> 256 at 64^2 116 + FIR vs 143 us composite, 1024 -> 512 at 32^2 157 + FIR vs 144 us (the (H+1) x (W+1) = 33 x 33 positions pad 16 x 16 tiles
+        # by 44 %, 64 K chunks per tile stay latency-bound); config 5 1882 vs 1921 images/s -- NOT adopted either.
+        merged_t = (composite and cout * 36 > 2 * h * w and min(h, w) >= int(os.environ.get('PG_UP2_MERGED_T_MIN', '32')) and conv2d_mfma16.phases_supported(cout)
+                    and os.environ.get('PG_UP2_POLICY', 'composite') == 'merged')
+        if merged_t:
+            composite = False
     # Weight-dominated layers (the low-resolution blocks: N per-sample copies of a 512..1024-channel kernel outweigh the
     # activations): the reference's NON-fused form (networks.py:73-84; its own choice for half precision at batch > 1,
     # networks.py:2152-2154) -- x * styles, ONE shared weight pack cached across steps, demodulation as the epilogue's
     # per-(n, cout) scale.  Styles are normalised per sample like networks.py:57-59 so that x * s stays in 16-bit range;
     # the factor returns through dcoefs (computed from the normalised styles).
-    taps = 36 if composite else kh * kw
+    merged_t = up == 2 and merged_t
+    taps = 36 if composite else (16 if merged_t else kh * kw)
     shared = cout * taps > 2 * h * w and os.environ.get('PG_MODCONV16_SHARED', '1') != '0'
     out_scale = None
     w2 = cache.get(('w2',), [weight], lambda: conv2d_mfma.modconv_w2(w32)) if demodulate else None
@@ -279,15 +310,34 @@ def _modconv_fast16(x, weight, styles, noise, up, padding, resample_filter, demo
             conv2d_mfma16.conv2d_forward(xcl, packed, cout, 3, 3, pad=(1, 1), out_hw=(h, w), y=y, out_step=(2, 2), out_off=(a, b), sample_stride=per,
                                          out_scale=out_scale, noise=nz, **ep)
         return y if res is None else y.add_(res)
-    if shared:          # x already carries the normalised styles; demodulation is a per-(n, cout) scale, which commutes with the FIR that follows
+    if merged_t:
+        wcat = cache.get(('up2_t_cat', flip_weight), [weight], lambda: _up2_transposed_phases_2x2(transposed_weight()))
+        if shared:      # x already carries the normalised styles; demodulation is a per-(n, cout) scale, which commutes with the FIR that follows
+            packed = cache.get(('up2_t_cat_shared', flip_weight, x.dtype), [weight], lambda: conv2d_mfma16.pack_weight(wcat, x.dtype, transpose_oi=True)[0])
+            per = 0
+        else:
+            packed, per, _ = conv2d_mfma16.pack_weight(wcat, x.dtype, transpose_oi=True, styles=s32, dcoefs=dcoefs.repeat(1, 4) if dcoefs is not None else None)
+        ybuf = torch.empty([n, cout, 2 * h + 2, 2 * w + 2], dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        conv2d_mfma16.conv2d_forward(conv2d_mfma16.to_channels_last(x), packed, cout, 2, 2, pad=(1, 1), out_hw=(h + 1, w + 1), y=ybuf, sample_stride=per,
+                                     out_scale=out_scale, phases=True)
+        y = ybuf[:, :, :2 * h + 1, :2 * w + 1]
+        res = ep.pop('residual', None)
+        b = ep.get('bias')
+        fused = upfirdn2d.upfirdn2d_bias_act(y, resample_filter, padding=fir_pad, gain=4, noise=noise, b=b, act=ep.get('act', 'linear'),
+                                             alpha=ep.get('alpha') or 0.0, act_gain=ep.get('gain', 1.0), clamp=ep.get('clamp'))
+        if fused is not None:
+            return fused if res is None else fused.add_(res)
+        y = y.contiguous(memory_format=torch.channels_last)      # (the FIR declined the view: dense copy, then the composed tail below)
+    elif shared:        # x already carries the normalised styles; demodulation is a per-(n, cout) scale, which commutes with the FIR that follows
         phases = cache.get(('up2_t_shared', flip_weight, x.dtype, tuple(tpad), (h, w)), [weight],
                            lambda: conv2d_mfma16.pack_transposed(transposed_weight(), x.dtype, 2, tpad, (h, w), out_hw))
     else:
         phases = conv2d_mfma16.pack_transposed(transposed_weight(), x.dtype, 2, tpad, (h, w), out_hw, styles=s32, dcoefs=dcoefs)
-    if phases is None:
-        return None
-    y = conv2d_mfma16.conv_transpose2d_forward(x, phases, cout, out_hw, stride=2, **(dict(out_scale=out_scale) if shared and out_scale is not None else {}))
-    res = ep.pop('residual', None)
+    if not merged_t:
+        if phases is None:
+            return None
+        y = conv2d_mfma16.conv_transpose2d_forward(x, phases, cout, out_hw, stride=2, **(dict(out_scale=out_scale) if shared and out_scale is not None else {}))
+    res = ep.pop('residual', None) if 'residual' in ep else (res if merged_t else None)
     b = ep.get('bias')
     fused = upfirdn2d.upfirdn2d_bias_act(y, resample_filter, padding=fir_pad, gain=4, noise=noise, b=b, act=ep.get('act', 'linear'),
                                          alpha=ep.get('alpha') or 0.0, act_gain=ep.get('gain', 1.0), clamp=ep.get('clamp'))

@@ -391,6 +391,31 @@ def test_config5_stack_full_width_prefix_vs_oracle():
     assert err32 <= 1e-4, err32
 
 
+@pytest.mark.parametrize('policy', ['composite', 'merged', 'auto'])
+def test_up2_layer_routes_vs_oracle(policy, monkeypatch):
+    """The three routes of a weight-dominated 16-bit `up = 2` SynthesisLayer (1024 -> 512 at 32^2 -> 64^2, N = 2, bf16): composite 6x6 kernels (round 2),
+    the transposed convolution's phases as ONE launch of 2x2 kernels + the channels-last FIR on a pitched view (round 4, `merged`), four phase launches +
+    FIR (`auto`) -- each against the float32 oracle layer (networks.py:73-94 + conv2d_resample.py:125-142).  bf16 bar: 2e-2 of the output range."""
+    from detgen import det_tensor, fill_module_
+    from training import networks as PN
+    from oracle import network_ref as NR
+    monkeypatch.setenv('PG_UP2_POLICY', policy)
+    kw = dict(w_dim=64, resolution=64, up=2, conv_clamp=256)
+    ref = fill_module_(NR.SynthesisLayer(1024, 512, **kw), 'up2r.').eval()
+    net = PN.SynthesisLayer(1024, 512, **kw)
+    net.load_state_dict(ref.state_dict(), strict=False)
+    net = net.to(DEV).eval()
+    x = det_tensor('up2r.x', [2, 1024, 32, 32])
+    ws = det_tensor('up2r.ws', [2, 64])
+    with torch.no_grad():
+        want = ref(x, ws, noise_mode='const')
+        got = net(x.to(DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last), ws.to(DEV), noise_mode='const').float().cpu()
+    assert got.shape == want.shape == (2, 512, 64, 64)
+    err = float((got - want).abs().max()) / float(want.abs().max())
+    print(f'up=2 layer 1024->512 32^2, bf16, route {policy}: {err:.2e} of the output range')
+    assert err <= 2e-2, err
+
+
 def test_config5_stack_full_1024_vs_oracle():
     """The WHOLE network of bench.py --mode bf16_1024 -- 8^2 .. 1024^2, channel_base 32768, channel_max 1024, i.e. including the 512^2 (64-channel)
     and 1024^2 (32-channel) blocks that carry ~60 % of its flops and that the prefix test above stops short of -- at N = 1

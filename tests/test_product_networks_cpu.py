@@ -105,3 +105,25 @@ def test_discriminator_with_r1_double_backward_cpu(golden):
     grads = torch.autograd.grad(pen.sum(), list(d.parameters()), allow_unused=True)
     got = np.array([float(x.abs().sum()) if x is not None else 0.0 for x in grads])
     np.testing.assert_allclose(got, g['r1_grad_abssum'], rtol=5e-3, atol=1e-6)
+
+
+def test_up2_transposed_phases_as_2x2_kernels():
+    """training.networks._up2_transposed_phases_2x2 (round 4: the four phases of the stride-2 transposed 3x3 convolution as 2x2 correlations of the
+    input padded by one, stacked along Cout for ONE four-phase launch of the 16-bit kernel): interleaving the four (H+1) x (W+1) phase results must
+    reproduce conv_transpose2d (conv2d_resample.py:125-142 before the FIR) on its (2H+1) x (2W+1) support; the extra row / column is the buffer padding."""
+    import torch
+    import torch.nn.functional as F
+    from training import networks as PN
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn([2, 5, 6, 7], generator=gen, dtype=torch.float64)
+    wt = torch.randn([5, 4, 3, 3], generator=gen, dtype=torch.float64)            # IOHW, as conv_transpose2d takes it
+    ref = F.conv_transpose2d(x, wt, stride=2)
+    k = PN._up2_transposed_phases_2x2(wt)                                          # [Cin, 4 * Cout, 2, 2]
+    assert k.shape == (5, 16, 2, 2)
+    ph = F.conv2d(x, k.transpose(0, 1), padding=1)                                 # correlation; [N, 4 * Cout, H + 1, W + 1]
+    y = torch.zeros([2, 4, 2 * 6 + 2, 2 * 7 + 2], dtype=torch.float64)
+    for a in (0, 1):
+        for b in (0, 1):
+            y[:, :, a::2, b::2] = ph[:, (2 * a + b) * 4:(2 * a + b + 1) * 4]
+    assert torch.allclose(y[:, :, :13, :15], ref, atol=1e-12)
+    assert float(y[:, :, 13].abs().max()) == 0 and float(y[:, :, :, 15].abs().max()) == 0      # the padding row / column of the buffer receives zeros

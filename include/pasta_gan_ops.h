@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 7
+#define PG_ABI_VERSION 8
 
 enum pg_dtype { PG_F32 = 0, PG_F16 = 1, PG_BF16 = 2, PG_F64 = 3 };
 
@@ -155,6 +155,13 @@ typedef struct pg_conv2d_fusion {
        front of merge_conv (networks.py:2179-2181).  cin_split must be a multiple of 16. */
     const float* x2;
     int          cin_split;
+    /* Instance-norm statistics of the OUTPUT, gathered where it is produced (round 4): when set, every workgroup tile also writes the sum and the
+       sum of squares of its in-image outputs per output channel to stats_partial[((n * Cout + co) * T + t) * 2 + {0, 1}], T = the tile count of one
+       image (pg_conv2d_winograd4_stats_tiles), t = the tile's index; pg_instance_norm_finish turns them into mean / rstd (fixed order: deterministic).
+       The values are those written to y (after the epilogue).  Only pg_conv2d_winograd4_forward launches with the plain tail (no in_scale, noise,
+       residual, SPADE) gather them; every other launch with this field set is declined (PG_ERR_UNSUPPORTED).  The SPADE res-blocks normalise the
+       output of such a convolution (networks.py:1896-1904, 1715-1723): the separate statistics pass over it (pg_instance_norm_stats) is what this removes. */
+    float*       stats_partial;
 } pg_conv2d_fusion;
 
 /*
@@ -223,6 +230,12 @@ int pg_conv2d_winograd4b_pack_weight(const float* w, float* packed, int Cout, in
 int pg_conv2d_winograd4b_forward(const float* x, const float* packed_u, float* y,
                                  int N, int Cin, int H, int W, int Cout, int pad_y, int pad_x, int OH, int OW,
                                  const int64_t ystride[4], const pg_conv2d_fusion* fusion, void* stream);
+
+/* Statistics gathered by pg_conv2d_winograd4_forward (pg_conv2d_fusion::stats_partial): tiles of one image for an OH x OW output, and the
+ * reduction of the per-tile sums into mean[n*C + c] and rstd = 1 / sqrt(var + eps) (biased variance over HW = OH*OW; float64 accumulation of the
+ * float32 partial sums in tile order). */
+int pg_conv2d_winograd4_stats_tiles(int OH, int OW);
+int pg_instance_norm_finish(const float* stats_partial, float* mean, float* rstd, int NC, int T, int64_t HW, float eps, void* stream);
 
 /* Demodulation coefficients of modulated_conv2d (networks.py:64-68):
  *   dcoefs[n,o] = rsqrt(sum_{i,k} (w[o,i,k] * scale * styles[n,i])^2 + 1e-8);  w is OIHW. */

@@ -537,6 +537,7 @@ static int conv_forward(int winograd, const float* x, const float* packed_w, flo
     if (p.in_xform && (!(p.f.in_gain > 0.f) || p.f.in_alpha < 0.f || p.f.in_alpha > 1.f)) return PG_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
 
+    if (p.f.stats_partial && winograd != 2) return PG_ERR_UNSUPPORTED;      // output statistics: the F(4x4) one-workgroup kernel's plain tail only
     if (winograd) {
         if (p.f.x2) return PG_ERR_UNSUPPORTED;                  // two-source launches stay on the direct kernel
         if (pad_x < 0 || pad_x > 4) return PG_ERR_UNSUPPORTED;  // the LDS halo row starts 4 columns left of the tile
@@ -834,6 +835,34 @@ PG_EXPORT int pg_modconv_prep(const float* w2, const float* styles, float* out, 
 PG_EXPORT int pg_instance_norm_stats(const float* x, float* mean, float* rstd, int NC, int64_t HW, float eps, void* stream) {
     if (!x || !mean || !rstd || NC <= 0 || HW <= 0) return PG_ERR_INVALID_ARG;
     hipLaunchKernelGGL(instance_norm_stats_kernel, dim3((unsigned)NC), dim3(IN_THREADS), 0, (hipStream_t)stream, x, mean, rstd, HW, eps);
+    return pg::launch_status();
+}
+
+// mean / rstd from the per-tile (sum, sum of squares) pairs the F(4x4) kernel's plain tail wrote (pg_conv2d_fusion::stats_partial): one wave per
+// (n, c) plane, float64 accumulation in tile order, then a fixed-shape wave reduction -- deterministic.
+__global__ __launch_bounds__(64) void instance_norm_finish_kernel(const float* __restrict__ part, float* __restrict__ mean, float* __restrict__ rstd, int T, double inv_hw, float eps) {
+    const float* pp = part + (int64_t)blockIdx.x * T * 2;
+    double s = 0.0, q = 0.0;
+    for (int t = threadIdx.x; t < T; t += 64) { s += (double)pp[2 * t]; q += (double)pp[2 * t + 1]; }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { s += __shfl_xor(s, m, 64); q += __shfl_xor(q, m, 64); }
+    if (threadIdx.x == 0) {
+        const double mu = s * inv_hw;
+        double var = q * inv_hw - mu * mu;
+        if (var < 0.0) var = 0.0;
+        mean[blockIdx.x] = (float)mu;
+        rstd[blockIdx.x] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+
+PG_EXPORT int pg_conv2d_winograd4_stats_tiles(int OH, int OW) {
+    if (OH <= 0 || OW <= 0) return 0;
+    return ((OH + 7) / 8) * ((OW + 63) / 64);
+}
+
+PG_EXPORT int pg_instance_norm_finish(const float* stats_partial, float* mean, float* rstd, int NC, int T, int64_t HW, float eps, void* stream) {
+    if (!stats_partial || !mean || !rstd || NC <= 0 || T <= 0 || HW <= 0) return PG_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(instance_norm_finish_kernel, dim3((unsigned)NC), dim3(64), 0, (hipStream_t)stream, stats_partial, mean, rstd, T, 1.0 / (double)HW, eps);
     return pg::launch_status();
 }
 

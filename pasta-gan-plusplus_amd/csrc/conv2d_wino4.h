@@ -115,8 +115,10 @@ __device__ __forceinline__ int w4_fresh_lane() {
 //                  SPADE branch, hipcc's register allocation of what remains spills 112-144 VGPRs)
 //   W4_TAIL_PLAIN  scale / bias / activation only (-3.6 ... -5.7 % per launch against W4_TAIL_ANY)
 //   W4_TAIL_SPADE  the SPADE combine (-2.5 ... -4.5 %)
+//   W4_TAIL_STATS  the plain tail + the output's instance-norm statistics (pg_conv2d_fusion::stats_partial) -- its own instantiation for the same reason:
+//                  with the statistics as a run-time branch of the plain tail every plain launch paid for the extra scalar registers
 //   W4_TAIL_RES / W4_TAIL_NOISE (residual only / noise only) compile cleanly too but measured +1 % / -1 ... +5 %: not instantiated.
-enum { W4_TAIL_ANY = 0, W4_TAIL_PLAIN = 1, W4_TAIL_SPADE = 2, W4_TAIL_RES = 3, W4_TAIL_NOISE = 4 };
+enum { W4_TAIL_ANY = 0, W4_TAIL_PLAIN = 1, W4_TAIL_SPADE = 2, W4_TAIL_RES = 3, W4_TAIL_NOISE = 4, W4_TAIL_STATS = 5 };
 template <int MODE, int TAIL>
 __global__ __launch_bounds__(768, 3) void conv2d_wino4(ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -482,6 +484,9 @@ __global__ __launch_bounds__(768, 3) void conv2d_wino4(ConvParams p) {
             g.nzb = ((unsigned)g.oyb * (unsigned)OWv + (unsigned)oxb) * 4u;
             return g;
         };
+        // Output statistics (pg_conv2d_fusion::stats_partial; plain tail only): sum and sum of squares of this tile's in-image outputs per cout
+        float* stats_p = TAIL == W4_TAIL_STATS ? qa.f.stats_partial : nullptr;                                             // (wave-uniform)
+        const int stats_T = qa.tilesX * qa.tilesY, stats_t = (e_oy0 >> 3) * qa.tilesX + (e_ox0 >> 6);
         const bool op_is_noise = !spade && !res_n && nz_n;
         const bool late_noise = !spade && res_n && nz_n;
         const bool has_operand = spade || res_n || nz_n;
@@ -569,6 +574,23 @@ __global__ __launch_bounds__(768, 3) void conv2d_wino4(ConvParams p) {
                     if (rnd < 3) request(rnd + 1, op);                       // before this round's stores
 #pragma unroll
                     for (int r = 0; r < 4; r++) store4(g.ob + (unsigned)r * rstride_b, v[r], g.cok && g.oyb + r < OHv);
+                    if (TAIL == W4_TAIL_STATS && stats_p) {
+                        // this thread's 16 outputs of (cout, tile), then the 32 tiles of the workgroup tile (the 32 lanes of a wave half share the cout)
+                        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const bool ok = seg_rows_full || (g.cok && g.oyb + r < OHv);
+#pragma unroll
+                            for (int e = 0; e < 4; e++) { const float w = ok ? v[r][e] : 0.f; s1 += w; s2 = fmaf(w, w, s2); }
+                        }
+#pragma unroll
+                        for (int m = 1; m < 32; m <<= 1) { s1 += __shfl_xor(s1, m, 64); s2 += __shfl_xor(s2, m, 64); }
+                        const int co = e_m0 + g.col;
+                        if (g.fn == 0 && co < Coutv) {
+                            float* dst = stats_p + (((int64_t)e_n * Coutv + co) * stats_T + stats_t) * 2;
+                            dst[0] = s1; dst[1] = s2;
+                        }
+                    }
                 } else {
                     // SPADE combine (networks.py:1715-1722): M-tile 0 rows are gamma, M-tile 1 rows beta of the same 32 channels;
                     // thread = (channel c8, tile, row pair rh):  y = (x - mean) * rstd * (1 + gamma) + beta

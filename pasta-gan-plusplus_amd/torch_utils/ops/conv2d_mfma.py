@@ -33,6 +33,7 @@ class Fusion(ctypes.Structure):
         ('residual', ctypes.c_void_p),
         ('spade_x', ctypes.c_void_p), ('spade_mean', ctypes.c_void_p), ('spade_rstd', ctypes.c_void_p),
         ('x2', ctypes.c_void_p), ('cin_split', ctypes.c_int),
+        ('stats_partial', ctypes.c_void_p),
     ]
 
 
@@ -96,6 +97,10 @@ def _init(plugin_name='conv2d_plugin'):
         lib.pg_conv2d_winograd4_pack_weight.argtypes = [vp, vp, i, i, f, i, i, vp]
         lib.pg_conv2d_winograd4_forward.restype = i
         lib.pg_conv2d_winograd4_forward.argtypes = [vp, vp, vp, i, i, i, i, i, i, i, i, i, ctypes.POINTER(i64), ctypes.POINTER(Fusion), vp]
+        lib.pg_conv2d_winograd4_stats_tiles.restype = i
+        lib.pg_conv2d_winograd4_stats_tiles.argtypes = [i, i]
+        lib.pg_instance_norm_finish.restype = i
+        lib.pg_instance_norm_finish.argtypes = [vp, vp, vp, i, i, i64, f, vp]
         lib.pg_conv2d_winograd4b_pack_weight.restype = i
         lib.pg_conv2d_winograd4b_pack_weight.argtypes = [vp, vp, i, i, f, i, i, vp]
         lib.pg_conv2d_winograd4b_forward.restype = i
@@ -221,14 +226,17 @@ def pack_weight(w, scale=1.0, flip=False, transpose_oi=False, winograd=False):
 def conv2d_forward(x, packed, cout, kh, kw, stride=1, pad=(0, 0), out_hw=None, y=None, out_step=(1, 1), out_off=(0, 0),
                    in_scale=None, in_bias=None, in_act='linear', in_alpha=0.0, in_gain=1.0, in_clamp=None,
                    out_scale=None, noise=None, noise_gain=1.0, bias=None, act='linear', alpha=0.0, gain=1.0, clamp=None,
-                   residual=None, spade=None, x2=None, winograd=False):
+                   residual=None, spade=None, x2=None, winograd=False, stats_eps=None):
     """One launch of the MFMA convolution (`winograd`: of its F(2x2,3x3) variant; `packed` must then come from
     `pack_weight(..., winograd=True)`; 3x3 stride 1, no spade / x2).  `x` [N,Cin,H,W] float32 contiguous; `packed` from
     `pack_weight`.  Writes y[n, co, oy*step+off, ox*step+off] for oy < out_hw[0], ox < out_hw[1]
     (allocating a dense [N,Cout,OH,OW] `y` when none is given) and returns `y`.
     `spade=(x_norm, mean, rstd)` selects the SPADE combine epilogue: `packed` holds interleaved gamma/beta rows
     (`pack_spade_gamma_beta`), `cout` = 2*C, and the result is the [N, C, OH, OW] tensor
-    (x_norm - mean) * rstd * (1 + gamma) + beta."""
+    (x_norm - mean) * rstd * (1 + gamma) + beta.
+    `stats_eps` (F(4x4) one-workgroup launches with the plain tail only: winograd=2, no in_scale / noise / residual / spade; anything else raises
+    NativeNotCovered): also gather the instance-norm statistics of the OUTPUT where it is produced -- returns (y, (mean, rstd)) with
+    rstd = 1 / sqrt(var + stats_eps), what `instance_norm_stats(y, stats_eps)` would compute in a second pass over y."""
     lib = _init().lib
     x = _f32c(x, 'x')
     n, cin, h, w = x.shape
@@ -293,6 +301,13 @@ def conv2d_forward(x, packed, cout, kh, kw, stride=1, pad=(0, 0), out_hw=None, y
     if x2 is not None:
         keep.append(x2)
         fz.x2, fz.cin_split = x2.data_ptr(), cin_split
+    stats_part = None
+    if stats_eps is not None:
+        if int(winograd) != 2 or spade is not None or in_scale is not None or noise is not None or residual is not None or x2 is not None or in_act != 'linear':
+            raise nat.NativeNotCovered('conv2d_mfma: output statistics are gathered by the F(4x4) kernel\'s plain tail only')
+        stats_T = lib.pg_conv2d_winograd4_stats_tiles(int(oh), int(ow))
+        stats_part = torch.empty([n * cout * stats_T * 2], dtype=torch.float32, device=x.device)
+        fz.stats_partial = stats_part.data_ptr()
     with torch.cuda.device(x.device):
         if _timeline is not None:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -321,6 +336,13 @@ def conv2d_forward(x, packed, cout, kh, kw, stride=1, pad=(0, 0), out_hw=None, y
             _timeline.append(((kh, kw, int(stride), ('winograd4' if int(winograd) >= 2 else 'winograd') if winograd else 'direct', f'N{n} {cin}->{cout} {h}x{w}' + (' spade' if spade is not None else '') + (' xf' if in_act != 'linear' else '') + (' mod' if in_scale is not None else '') + (' res' if residual is not None else '')), 2.0 * n * cout * oh * ow * cin * kh * kw, ev0, ev1,
                               4 * (x.numel() + (x2.numel() if x2 is not None else 0) + n * ychan * oh * ow)))
     nat.check(st, 'pg_conv2d_forward')
+    if stats_part is not None:
+        mean = torch.empty([n * cout], dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        with torch.cuda.device(x.device):
+            st = lib.pg_instance_norm_finish(nat.ptr(stats_part), nat.ptr(mean), nat.ptr(rstd), n * cout, stats_T, int(oh) * int(ow), float(stats_eps), nat.stream_of(x))
+        nat.check(st, 'pg_instance_norm_finish')
+        return y, (mean, rstd)
     return y
 
 

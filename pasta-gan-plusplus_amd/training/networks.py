@@ -524,7 +524,10 @@ class Spade_Conv2dLayer(_ConvBase):
         return dict(act=self.activation, alpha=bias_act.activation_funcs[self.activation].def_alpha, gain=self.act_gain * gain,
                     clamp=self.conv_clamp * gain if self.conv_clamp is not None else None)
 
-    def forward(self, x, gain=1, no_act=False, post_act='linear', residual=None):
+    def forward(self, x, gain=1, no_act=False, post_act='linear', residual=None, stats_eps=None):
+        """`stats_eps` (private, inference route): also return the instance-norm statistics (mean, rstd) of the OUTPUT -- the SPADE norm blocks
+        that consume it need them (networks.py:1715-1723); gathered in the convolution's tail when the F(4x4) kernel runs it, by a second pass
+        over the output otherwise.  Returns (y, (mean, rstd)) then."""
         act_gain = self.act_gain * gain
         act_clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
         cout, _, k, _ = self.weight.shape
@@ -533,9 +536,15 @@ class Spade_Conv2dLayer(_ConvBase):
             pro = {} if no_act else dict(in_act=self.activation, in_gain=act_gain, in_clamp=act_clamp,
                                          in_alpha=bias_act.activation_funcs[self.activation].def_alpha)
             wg = conv2d_mfma.use_winograd(k, k, 1, cout, x.shape[1], pad=(self.padding, self.padding), hw=x.shape[2:], xf=not no_act)
+            if stats_eps is not None and wg == 2 and no_act and residual is None and post_act == 'linear' and os.environ.get('PG_FUSED_STATS', '1') != '0':
+                try:
+                    return conv2d_mfma.conv2d_forward(x, self._packed(False, wg), cout, k, k, pad=(self.padding, self.padding), winograd=wg, stats_eps=stats_eps)
+                except nat.NativeNotCovered:
+                    pass
             try:
-                return conv2d_mfma.conv2d_forward(x, self._packed(False, wg), cout, k, k, pad=(self.padding, self.padding), act=post_act, residual=residual,
-                                                  winograd=wg, **pro)
+                y = conv2d_mfma.conv2d_forward(x, self._packed(False, wg), cout, k, k, pad=(self.padding, self.padding), act=post_act, residual=residual,
+                                               winograd=wg, **pro)
+                return y if stats_eps is None else (y, conv2d_mfma.instance_norm_stats(y, eps=stats_eps))
             except nat.NativeNotCovered:       # e.g. a pre-activation in front of a geometry without the prologue variant
                 pass
         w = self.weight * self.weight_gain
@@ -546,7 +555,8 @@ class Spade_Conv2dLayer(_ConvBase):
                                             padding=self.padding, flip_weight=(self.up == 1))
         if post_act != 'linear':
             x = bias_act.bias_act(x, act=post_act, gain=1)
-        return x if residual is None else residual + x
+        x = x if residual is None else residual + x
+        return x if stats_eps is None else (x, conv2d_mfma.instance_norm_stats(x, eps=stats_eps))
 
 
 class Spade_Norm_Block(nn.Module):
@@ -606,15 +616,16 @@ class Spade_ResBlockV4_512(nn.Module):
         self.spade1 = Spade_Norm_Block(spade_channels, out_channels)
 
     def forward(self, x, denorm_feat):
-        x = self.conv(x, no_act=True)
-        if _fast_ok(x, denorm_feat, self.conv0.weight) and all(l.bias is None and l.activation in conv2d_mfma.FUSED_ACTS for l in (self.skip, self.conv0, self.conv1)):
+        if _fast_ok(x, denorm_feat, self.conv.weight, self.conv0.weight) and all(l.bias is None and l.activation in conv2d_mfma.FUSED_ACTS for l in (self.skip, self.conv0, self.conv1)):
             # inference route: each SPADE output feeds exactly one convolution, so that convolution's pre-activation is applied
-            # where the SPADE output is produced and the convolutions run without a prologue
+            # where the SPADE output is produced and the convolutions run without a prologue; the statistics the norm blocks need come out of
+            # the tail of the convolution that produces their input (round 4: no second pass over x / dx)
             assert self.spade_skip.param_free_norm.eps == self.spade0.param_free_norm.eps
-            stats = conv2d_mfma.instance_norm_stats(x, eps=self.spade0.param_free_norm.eps)      # spade_skip and spade0 normalise the same x
+            x, stats = self.conv(x, no_act=True, stats_eps=self.spade0.param_free_norm.eps)       # spade_skip and spade0 normalise the same x
             y = self.skip(self.spade_skip(x, denorm_feat, post=self.skip.pre_activation(SQRT_HALF), stats=stats), no_act=True)
-            x = self.conv0(self.spade0(x, denorm_feat, post=self.conv0.pre_activation(), stats=stats), no_act=True)
-            return self.conv1(self.spade1(x, denorm_feat, post=self.conv1.pre_activation(SQRT_HALF)), no_act=True, residual=y)
+            x, stats1 = self.conv0(self.spade0(x, denorm_feat, post=self.conv0.pre_activation(), stats=stats), no_act=True, stats_eps=self.spade1.param_free_norm.eps)
+            return self.conv1(self.spade1(x, denorm_feat, post=self.conv1.pre_activation(SQRT_HALF), stats=stats1), no_act=True, residual=y)
+        x = self.conv(x, no_act=True)
         y = self.skip(self.spade_skip(x, denorm_feat), gain=SQRT_HALF)
         x = self.conv0(self.spade0(x, denorm_feat))
         return self.conv1(self.spade1(x, denorm_feat), gain=SQRT_HALF, residual=y)

@@ -504,6 +504,39 @@ def test_conv2d_winograd4_tails_vs_oracle(tail, form):
     close(y, ref, 0, 1e-4 * scale_of(ref))
 
 
+@pytest.mark.parametrize('n,cin,cout,h,w', [(2, 64, 128, 24, 72), (1, 64, 64, 64, 64), (3, 32, 70, 13, 136), (8, 128, 128, 256, 256)])
+def test_conv2d_winograd4_output_statistics(n, cin, cout, h, w):
+    """pg_conv2d_fusion::stats_partial (round 4): the instance-norm statistics of a convolution's output gathered in the F(4x4) kernel's plain tail
+    (sum / sum of squares per workgroup tile and cout, reduced in float64 in tile order) against (a) float64 torch statistics of the SAME output
+    tensor and (b) the separate one-pass kernel (pg_instance_norm_stats) -- full, ragged (H % 8, W % 64, Cout % 64 != 0) and full-size shapes;
+    the output itself must be bit-identical to the launch without statistics; launches other than the plain F(4x4) tail decline the request."""
+    from torch_utils.ops import conv2d_mfma
+    from torch_utils.ops._native import NativeNotCovered
+    gen = torch.Generator().manual_seed(11)
+    x = (torch.randn([n, cin, h, w], generator=gen) + 0.3).to(DEV)
+    wt = (torch.randn([cout, cin, 3, 3], generator=gen) / (3 * math.sqrt(cin))).to(DEV)
+    b = torch.randn([cout], generator=gen).to(DEV)
+    pk = conv2d_mfma.pack_weight(wt, winograd=2)
+    y0 = conv2d_mfma.conv2d_forward(x, pk, cout, 3, 3, pad=(1, 1), winograd=2, bias=b)
+    y, (mean, rstd) = conv2d_mfma.conv2d_forward(x, pk, cout, 3, 3, pad=(1, 1), winograd=2, bias=b, stats_eps=1e-5)
+    assert torch.equal(y, y0)
+    yd = y.double()
+    want_mean = yd.mean([2, 3]).reshape(-1)
+    want_rstd = (yd.var([2, 3], unbiased=False) + 1e-5).rsqrt().reshape(-1)
+    close(mean, want_mean, 0, 2e-6 * scale_of(want_mean))
+    close(rstd, want_rstd, 2e-5, 0)
+    m2, r2 = conv2d_mfma.instance_norm_stats(y, eps=1e-5)
+    close(mean, m2, 0, 2e-6 * scale_of(want_mean))
+    close(rstd, r2, 2e-5, 0)
+    again = conv2d_mfma.conv2d_forward(x, pk, cout, 3, 3, pad=(1, 1), winograd=2, bias=b, stats_eps=1e-5)[1]
+    assert torch.equal(again[0], mean) and torch.equal(again[1], rstd)                       # deterministic: fixed reduction order, no atomics
+    for kw in (dict(residual=torch.zeros_like(y)), dict(in_scale=torch.ones([n, cin], device=DEV))):
+        with pytest.raises(NativeNotCovered):
+            conv2d_mfma.conv2d_forward(x, pk, cout, 3, 3, pad=(1, 1), winograd=2, stats_eps=1e-5, **kw)
+    with pytest.raises(NativeNotCovered):
+        conv2d_mfma.conv2d_forward(x, conv2d_mfma.pack_weight(wt, winograd=1), cout, 3, 3, pad=(1, 1), winograd=1, stats_eps=1e-5)
+
+
 def test_conv2d_winograd4_policy_and_declines():
     from torch_utils.ops import conv2d_mfma
     from torch_utils.ops._native import NativeNotCovered

@@ -76,6 +76,12 @@ __device__ __forceinline__ void dma_dwordx4(const float* gsrc, unsigned lds_byte
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "s"(lds_byte), "v"(gsrc) : "memory");
 }
+// 16-byte form through a buffer descriptor (range check = zero fill): used by the Winograd kernels and the up-conv's aligned halo rows
+__device__ __forceinline__ void dma_dwordx4_buf(i32x4 rsrc, unsigned lds_byte, unsigned voff_bytes, int soff_bytes) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_byte), "v"(voff_bytes), "s"(rsrc), "s"(soff_bytes) : "memory");
+}
 __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // Once-per-tile scalar fetches (scales, bias) of the persistent loop.  They are inline asm with their own wait on purpose: a

@@ -35,13 +35,18 @@ typedef float f32x2s __attribute__((ext_vector_type(2)));
 constexpr int U_BM = 32, U_KC = 8;
 // The 32 MFMA columns of a wave are 32 / TRW rows x TRW columns of positions: TRW = 32 for the wide layers, 16 / 8 for the 16^2 / 8^2
 // ones (a 32-wide row of positions would be mostly empty there).  Workgroup tile: 8 * (32 / TRW) rows x TRW columns.
-template <int TRW> struct UGeo {
-    static constexpr int RG = 32 / TRW, TQ = 8 * RG, IH = TQ + 1, IW = TRW + 1, PLANE = IH * IW;      // halo: rows q0-1 .., cols r0-1 ..
-    static constexpr int NX = U_KC * PLANE;
+// VEC (round 4, TRW = 32 only): the halo rows are staged as ALIGNED 16-byte words -- global columns [r0 - 4, r0 + 36), 10 words per row -- with
+// buffer_load_dwordx4 ... lds: 3 DMA instructions per thread and chunk instead of 10 four-byte ones (the request issue is what the multiplying
+// waves pay for: ~100 cycles each beside 72 MFMAs); halo column c sits at LDS column c + 3.  Needs W % 4 == 0 and a 16-byte aligned x.
+template <int TRW, bool VEC = false> struct UGeo {
+    static constexpr int RG = 32 / TRW, TQ = 8 * RG, IH = TQ + 1, IW = VEC ? TRW + 8 : TRW + 1, PLANE = IH * IW;      // halo: rows q0-1 .., cols r0-1 .. (VEC: r0-4 ..)
+    static constexpr int NX = U_KC * PLANE, COL0 = VEC ? 3 : 0;
+    static constexpr int XPT = VEC ? (NX / 4 + 255) / 256 : (U_KC * 297 + 255) / 256;     // DMA instructions per thread and chunk
 };
 constexpr int U_XPT = (U_KC * 297 + 255) / 256;         // 9 x 33, 17 x 17, 33 x 9: at most 297 halo samples per channel
 constexpr int U_NW4 = U_KC * 9 * U_BM / 4, U_WPT = (U_NW4 + 255) / 256;
-constexpr int U_LDS_X = U_XPT * 256, U_LDS_W = U_WPT * 256 * 4, U_LDS_BUF = U_LDS_X + U_LDS_W;
+constexpr int U_LDS_X = 3072, U_LDS_W = U_WPT * 256 * 4, U_LDS_BUF = U_LDS_X + U_LDS_W;      // (3072 floats: 10 x 256 four-byte slots, or 3 x 256 sixteen-byte ones)
+static_assert(U_LDS_X >= U_XPT * 256, "staging buffer");
 
 struct Up2Params {
     const float* x; const float* wp; float* y;
@@ -53,10 +58,10 @@ struct Up2Params {
 };
 constexpr int U_EQ = 256, U_EPLANE = U_EQ + 1;  // positions per edge tile; staged samples per channel (rows q0-1 .. q0+255 of column W-1)
 
-template <bool MOD, int TRW>
+template <bool MOD, int TRW, bool VEC = false>
 __global__ __launch_bounds__(256, 2) void conv2d_up2(Up2Params p) {
-    typedef UGeo<TRW> G;
-    static_assert(G::PLANE <= 297, "halo tile larger than the staging buffer");
+    typedef UGeo<TRW, VEC> G;
+    static_assert(VEC ? (G::XPT * 1024 <= U_LDS_X && TRW == 32) : G::PLANE <= 297, "halo tile larger than the staging buffer");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int cin_loop = ((p.Cin + U_KC - 1) / U_KC) * U_KC;
     const int nchunks = cin_loop / U_KC;
@@ -74,6 +79,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_up2(Up2Params p) {
     int n = 0, q0 = 0, r0 = 0, m0 = 0;
     unsigned xoff[U_XPT];
     i32x4 xrsrc;
+    bool halo_vec = false;                       // VEC: false during the edge pass (its column staging stays on the four-byte path)
 
     auto prep_tile = [&](int tile, float* cs) {
         const int xcd = tile & 7;
@@ -87,6 +93,17 @@ __global__ __launch_bounds__(256, 2) void conv2d_up2(Up2Params p) {
             for (int c = t; c < cin_loop; c += 256) cs[c] = c < p.Cin ? ld_opaque(p.in_scale + (int64_t)n * p.Cin + c) : 1.f;
         int tt = t;
         asm volatile("" : "+v"(tt));                 // keep the index maths inside the tile loop (see conv2d_kernel.h)
+        if (VEC) {
+#pragma unroll
+            for (int i = 0; i < G::XPT; i++) {       // 16-byte words: (channel, row, word of the row); W % 4 == 0: a word is inside or outside the image as a whole
+                const int e = tt + 256 * i;
+                constexpr int WPR = G::IW / 4, WPC = G::PLANE / 4;
+                const int c = e / WPC, rem = e % WPC;
+                const int gy = q0 - 1 + rem / WPR, gx = r0 - 4 + 4 * (rem % WPR);
+                const bool ok = e < G::NX / 4 && gy >= 0 && gy < p.H && gx >= 0 && gx + 4 <= p.W;
+                xoff[i] = ok ? (unsigned)(c * HW + gy * p.W + gx) * 4u : 0x80000000u;
+            }
+        } else {
 #pragma unroll
         for (int i = 0; i < U_XPT; i++) {
             const int e = tt + 256 * i;
@@ -94,6 +111,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_up2(Up2Params p) {
             const int gy = q0 - 1 + rem / G::IW, gx = r0 - 1 + rem % G::IW;
             const bool ok = e < G::NX && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;     // (gy <= q0 + 7 may exceed H - 1 in a ragged last tile: zero)
             xoff[i] = ok ? (unsigned)(c * HW + gy * p.W + gx) * 4u : 0x80000000u;
+        }
         }
         const uint64_t base = (uint64_t)(uintptr_t)(p.x + (int64_t)n * p.Cin * HW);
         xrsrc[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)base);
@@ -106,8 +124,14 @@ __global__ __launch_bounds__(256, 2) void conv2d_up2(Up2Params p) {
         const unsigned xs_b = smem_b + (unsigned)(buf * U_LDS_BUF + 64 * wave) * 4u;
         const unsigned ws_b = smem_b + (unsigned)(buf * U_LDS_BUF + U_LDS_X + 256 * wave) * 4u;
         const int soff = c0 * HW * 4;
+        if (VEC && halo_vec) {
+            const unsigned xs4_b = smem_b + (unsigned)(buf * U_LDS_BUF) * 4u + (unsigned)(64 * wave) * 16u;
 #pragma unroll
-        for (int i = 0; i < U_XPT; i++) dma_dword(xrsrc, xs_b + 1024u * i, xoff[i], soff);
+            for (int i = 0; i < G::XPT; i++) dma_dwordx4_buf(xrsrc, xs4_b + 4096u * i, xoff[i], soff);
+        } else {
+#pragma unroll
+            for (int i = 0; i < U_XPT; i++) dma_dword(xrsrc, xs_b + 1024u * i, xoff[i], soff);
+        }
         const float* wb = p.wp + (int64_t)c0 * 9 * p.CoutP + m0;
 #pragma unroll
         for (int i = 0; i < U_WPT; i++) {
@@ -190,6 +214,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_up2(Up2Params p) {
         __syncthreads();                             // the staging buffers and scales are rewritten next
     }
     if ((int)blockIdx.x >= p.total_tiles) return;    // a workgroup launched for an edge tile only
+    halo_vec = VEC;
 
     f32x16 acc[4][2];                                // [parity 2a + b][position row of the wave]
 
@@ -198,7 +223,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_up2(Up2Params p) {
     const int lr = l31 / TRW, lc = l31 % TRW;
     auto fetch = [&](int buf, const float* cs, int c0, int cp, Ops& o) __attribute__((always_inline)) {
         const float* ab = smem + buf * U_LDS_BUF + U_LDS_X + ((2 * cp + half) * 9) * U_BM + l31;
-        const float* bb = smem + buf * U_LDS_BUF + (2 * cp + half) * G::PLANE + ((2 * wave) * G::RG + lr) * G::IW + lc;
+        const float* bb = smem + buf * U_LDS_BUF + (2 * cp + half) * G::PLANE + ((2 * wave) * G::RG + lr) * G::IW + lc + G::COL0;
 #pragma unroll
         for (int tp = 0; tp < 9; tp++) o.a[tp] = ab[tp * U_BM];
         const float sc = MOD ? cs[c0 + 2 * cp + half] : 1.f;
@@ -309,9 +334,9 @@ __global__ __launch_bounds__(256, 2) void conv2d_up2(Up2Params p) {
     }
 }
 
-template <int TRW>
+template <int TRW, bool VEC = false>
 int launch_up2_t(const Up2Params& p0, hipStream_t s) {
-    typedef UGeo<TRW> G;
+    typedef UGeo<TRW, VEC> G;
     Up2Params p = p0;
     p.tilesX = (p.W + TRW - 1) / TRW;
     p.tilesY = (p.H + 1 + G::TQ - 1) / G::TQ;
@@ -330,19 +355,21 @@ int launch_up2_t(const Up2Params& p0, hipStream_t s) {
     const int64_t blocks = tiles + etiles < (int64_t)num_cu() * per_cu ? tiles + etiles : (int64_t)num_cu() * per_cu;
     if (p.in_scale) {
         static PerDeviceOnce a1;
-        const hipError_t e = a1.run([] { return hipFuncSetAttribute((const void*)conv2d_up2<true, TRW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+        const hipError_t e = a1.run([] { return hipFuncSetAttribute((const void*)conv2d_up2<true, TRW, VEC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
         if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL((conv2d_up2<true, TRW>), dim3((unsigned)blocks), dim3(256), lds, s, p);
+        hipLaunchKernelGGL((conv2d_up2<true, TRW, VEC>), dim3((unsigned)blocks), dim3(256), lds, s, p);
     } else {
         static PerDeviceOnce a0;
-        const hipError_t e = a0.run([] { return hipFuncSetAttribute((const void*)conv2d_up2<false, TRW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+        const hipError_t e = a0.run([] { return hipFuncSetAttribute((const void*)conv2d_up2<false, TRW, VEC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
         if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL((conv2d_up2<false, TRW>), dim3((unsigned)blocks), dim3(256), lds, s, p);
+        hipLaunchKernelGGL((conv2d_up2<false, TRW, VEC>), dim3((unsigned)blocks), dim3(256), lds, s, p);
     }
     return launch_status();
 }
 
 inline int launch_up2(const Up2Params& p, hipStream_t s) {
+    static const bool vec_on = [] { const char* e = getenv("PG_UP2_VEC"); return e ? atoi(e) != 0 : true; }();      // A/B switch: 0 = four-byte halo staging everywhere
+    if (p.W > 16 && vec_on && p.W % 4 == 0 && (((uintptr_t)p.x) & 15) == 0) return launch_up2_t<32, true>(p, s);
     if (p.W > 16) return launch_up2_t<32>(p, s);
     if (p.W > 8) return launch_up2_t<16>(p, s);
     return launch_up2_t<8>(p, s);

@@ -59,11 +59,6 @@ constexpr int W_EXCH = 4 * 2 * 16 * 32;      // exchange floats per round: [a][q
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ void dma_dwordx4_buf(i32x4 rsrc, unsigned lds_byte, unsigned voff_bytes, int soff_bytes) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "s"(lds_byte), "v"(voff_bytes), "s"(rsrc), "s"(soff_bytes) : "memory");
-}
 
 // MODE: 0 = plain input, 1 = per-(n, channel) input scale (modulated convolution), 2 = scale + pre-activation (SPADE convs).
 // VEC: 16-byte halo DMA (W % 4 == 0 and a 16-byte aligned x), issued by waves 0-3 only; otherwise dwords from all waves.

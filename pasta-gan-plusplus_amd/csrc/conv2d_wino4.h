@@ -44,6 +44,8 @@
 
 namespace pgconv {
 
+constexpr bool W4_EX2 = (WINO4_EXP & 8192) != 0;  // timing experiment (round 4, parity- and stress-green): two exchange buffers in the tail, one barrier per round instead of two --
+                                                // 434 | 472 | 237 | 358 us against 430 | 476 | 239 | 358 with the single buffer (128->128 256^2 | 64->64 512^2 | 64->128 256^2 | 256->256 128^2): +-1 %, not the barriers
 constexpr int W4_KC = 16;                        // input channels per chunk
 constexpr int W4_ROWS = 10;                      // halo rows of an 8-row output tile
 constexpr int W4_LROW = 72;                      // floats per LDS halo row: global columns [ox0 - 4, ox0 + 68) = 18 aligned 16-byte words
@@ -126,10 +128,13 @@ __global__ __launch_bounds__(768, 3) void conv2d_wino4(ConvParams p) {
     const int nchunks = cin_loop / W4_KC;
     float* raw = smem;
     float* V = smem + W4_RAW;
-    float* cs0 = V + W4_V;                       // prologue scale of two consecutive tiles [2][cin_loop]
-    float* ep0 = cs0 + 2 * cin_loop;             // epilogue scale / bias of two consecutive tiles [2][64 + 64]
-    unsigned* gmI = (unsigned*)(ep0 + 256);      // gather map of an interior tile [12][256] (byte offsets relative to the tile's first halo sample)
+    unsigned* gmI = (unsigned*)(V + W4_V);       // gather map of an interior tile [12][256] (byte offsets relative to the tile's first halo sample)
     unsigned* gmE = gmI + W4_NDMA * 256;         // gather map of the current edge tile (absolute in the image, sentinel outside)
+    float* cs0 = (float*)(gmE + W4_NDMA * 256);  // prologue scale of two consecutive tiles [2][cin_loop]
+    float* ep0 = cs0 + 2 * cin_loop;             // epilogue scale / bias of two consecutive tiles [2][64 + 64]
+    // (W4_EX2: the tail's SECOND exchange buffer is the last third of V plus both gather maps -- exactly W4_EX floats; the chore waves rebuild
+    //  the maps during the next tile's first transform phase, which they sit out anyway)
+    static_assert(W4_V - W4_EX + 2 * W4_NDMA * 256 == W4_EX, "second exchange buffer = tail of V + the two gather maps");
 
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const unsigned smem_b = __builtin_amdgcn_readfirstlane(lds_offset(smem));
@@ -147,17 +152,34 @@ __global__ __launch_bounds__(768, 3) void conv2d_wino4(ConvParams p) {
     bool edge = false;
     i32x4 xrsrc;
 
-    // Interior gather map: tile-independent, computed once.  Word f of the buffer = (channel f / 180, row (f % 180) / 18, word f % 18).
-    if (chore) {
-        const int tc = 64 * cw + w4_fresh_lane();
+    // Interior gather map: tile-independent.  Word f of the buffer = (channel f / 180, row (f % 180) / 18, word f % 18).
+    auto build_gmI = [&]() {
+        if (chore) {
+            const int tc = 64 * cw + w4_fresh_lane();
 #pragma unroll
-        for (int i = 0; i < W4_NDMA; i++) {
-            const int f = i * 256 + tc;
-            const int c = f / 180, rem = f % 180;
-            const int row = rem / 18, wd = rem % 18;
-            gmI[i * 256 + tc] = (unsigned)(c * HW + row * p.W + 4 * wd) * 4u;
+            for (int i = 0; i < W4_NDMA; i++) {
+                const int f = i * 256 + tc;
+                const int c = f / 180, rem = f % 180;
+                const int row = rem / 18, wd = rem % 18;
+                gmI[i * 256 + tc] = (unsigned)(c * HW + row * p.W + 4 * wd) * 4u;
+            }
+        }                                        // (read back by the writing thread only: no barrier needed)
+    };
+    build_gmI();
+    auto build_gmE = [&](int gy0, int gx0) {     // gather map of an edge tile whose first halo sample is (gy0, gx0)
+        if (chore) {
+            const int tt = 64 * cw + w4_fresh_lane();
+#pragma unroll
+            for (int i = 0; i < W4_NDMA; i++) {
+                const int f = i * 256 + tt;
+                const int c = f / 180, rem = f % 180;
+                const int row = rem / 18, wd = rem % 18;
+                const int gy = gy0 + row, gx = gx0 + 4 * wd;
+                const bool ok = gy >= 0 && gy < p.H && gx >= 0 && gx + 4 <= p.W;
+                gmE[i * 256 + tt] = ok ? (unsigned)(c * HW + gy * p.W + gx) * 4u : 0x80000000u;
+            }
         }
-    }                                            // (read back by the writing thread only: no barrier needed)
+    };
 
     auto prep_tile = [&](int tile, float* cs) {
         const int xcd = tile & 7;
@@ -173,18 +195,7 @@ __global__ __launch_bounds__(768, 3) void conv2d_wino4(ConvParams p) {
         }
         const int gy0 = oy0 - p.pad_y, gx0 = ox0 - 4;
         edge = !(gy0 >= 0 && gy0 + W4_ROWS <= p.H && gx0 >= 0 && gx0 + W4_LROW <= p.W);           // wave-uniform
-        if (edge && chore) {
-            const int tt = 64 * cw + w4_fresh_lane();
-#pragma unroll
-            for (int i = 0; i < W4_NDMA; i++) {
-                const int f = i * 256 + tt;
-                const int c = f / 180, rem = f % 180;
-                const int row = rem / 18, wd = rem % 18;
-                const int gy = gy0 + row, gx = gx0 + 4 * wd;
-                const bool ok = gy >= 0 && gy < p.H && gx >= 0 && gx + 4 <= p.W;
-                gmE[i * 256 + tt] = ok ? (unsigned)(c * HW + gy * p.W + gx) * 4u : 0x80000000u;
-            }
-        }
+        if (edge) build_gmE(gy0, gx0);
         const int shift = edge ? 0 : (gy0 * p.W + gx0) * 4;             // interior: offsets are relative to the tile's first halo sample
         const uint64_t base = (uint64_t)(uintptr_t)(p.x + (int64_t)n * p.Cin * HW) + (uint64_t)(int64_t)shift;
         xrsrc[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)base);
@@ -255,6 +266,7 @@ __global__ __launch_bounds__(768, 3) void conv2d_wino4(ConvParams p) {
 #endif
     int tile = blockIdx.x;
     int par = 0;
+    int tiles_run = 0;
     prep_tile(tile, cs0);
     f32x4 ur[2][3];
     a_reset(m0);
@@ -278,6 +290,10 @@ __global__ __launch_bounds__(768, 3) void conv2d_wino4(ConvParams p) {
             __syncthreads();                                            // A: raw(k) has landed (the issuing waves waited for their requests at
                                                                         //    their third U group), V is free (every wave is past GEMM(k-1) / the tail)
             if (k == 2) W4_STAMP(1);
+            if (W4_EX2 && k == 0 && tiles_run > 0) {     // the previous tile's tail used the maps' LDS as exchange space: the chore waves (idle in this phase) rebuild them
+                build_gmI();
+                if (edge) build_gmE(oy0 - p.pad_y, ox0 - 4);
+            }
             // ---- transform phase (waves 0-7): one 6x6 patch per thread -> 36 V values
 #if !(WINO4_EXP & 2)
             if (!chore) {
@@ -520,19 +536,24 @@ __global__ __launch_bounds__(768, 3) void conv2d_wino4(ConvParams p) {
         f32x4 op[4] = {zero4, zero4, zero4, zero4};
         request(0, op);
         __syncthreads();                                                 // the exchange area IS the V buffer: every wave must be past its last GEMM reads before the first word is written
+        // couts 8 rnd + 4 half + i of this wave's M-tile come from accumulator registers 4 rnd + i; the four column results of
+        // (a, cout, tile) leave as one 16-byte word.  W4_EX2: round rnd goes through buffer rnd & 1, and round rnd + 1 is written BEFORE round rnd is
+        // finished -- one barrier per round (it orders "rnd + 1 written" before its readers and "rnd read" before rnd + 2 overwrites it).
+        auto write_ex = [&](const int rnd) __attribute__((always_inline)) {
+            const int lane = w4_fresh_lane();
+            f32x4* exw = ex4 + (W4_EX2 ? (rnd & 1) * (W4_EX / 4) : 0) + (ta * 16 + mt * 8 + 4 * (lane >> 5)) * 32 + (lane & 31);
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                if (!(WINO4_EXP & 64) || yy[4 * rnd + i][0] == 12345.678f) exw[i * 32] = yy[4 * rnd + i];
+        };
+        if (W4_EX2) { write_ex(0); __syncthreads(); }
 #pragma unroll
         for (int rnd = 0; rnd < 4; rnd++) {
-            // couts 8 rnd + 4 half + i of this wave's M-tile come from accumulator registers 4 rnd + i; the four column results of
-            // (a, cout, tile) leave as one 16-byte word.
-            {
-                const int lane = w4_fresh_lane();
-                f32x4* exw = ex4 + (ta * 16 + mt * 8 + 4 * (lane >> 5)) * 32 + (lane & 31);
-#pragma unroll
-                for (int i = 0; i < 4; i++)
-                    if (!(WINO4_EXP & 64) || yy[4 * rnd + i][0] == 12345.678f) exw[i * 32] = yy[4 * rnd + i];
-            }
+            const f32x4* exr = ex4 + (W4_EX2 ? (rnd & 1) * (W4_EX / 4) : 0);
+            if (W4_EX2) { if (rnd < 3) write_ex(rnd + 1); }
+            else write_ex(rnd);
             if (rnd == 0) W4_STAMP(7);
-            __syncthreads();
+            if (!W4_EX2) __syncthreads();
             if (rnd == 0) W4_STAMP(8);
             if (rnd == 0) {
                 // the next tile's first U group (requested during the last chunk) must be home before this tile's stores enter the queue:
@@ -548,7 +569,7 @@ __global__ __launch_bounds__(768, 3) void conv2d_wino4(ConvParams p) {
                     {
                         f32x4 z[6];
 #pragma unroll
-                        for (int a = 0; a < 6; a++) z[a] = ex4[(a * 16) * 32 + g.t];   // ex4[a][c16][fn]
+                        for (int a = 0; a < 6; a++) z[a] = exr[(a * 16) * 32 + g.t];   // ex[a][c16][fn]
 #pragma unroll
                         for (int c = 0; c < 4; c++) {                        // row half (over a), one column at a time
                             float y0, y1, y2, y3;
@@ -602,7 +623,7 @@ __global__ __launch_bounds__(768, 3) void conv2d_wino4(ConvParams p) {
                     for (int gbi = 0; gbi < 2; gbi++) {
                         f32x4 z[6];
 #pragma unroll
-                        for (int a = 0; a < 6; a++) z[a] = ex4[(a * 16 + gbi * 8 + g.c8) * 32 + g.fn];
+                        for (int a = 0; a < 6; a++) z[a] = exr[(a * 16 + gbi * 8 + g.c8) * 32 + g.fn];
 #pragma unroll
                         for (int c = 0; c < 4; c++) {                        // over a: only this thread's two output rows
                             const float s12 = z[1][c] + z[2][c], d12 = z[1][c] - z[2][c], s34 = z[3][c] + z[4][c], d34 = z[3][c] - z[4][c];
@@ -624,7 +645,8 @@ __global__ __launch_bounds__(768, 3) void conv2d_wino4(ConvParams p) {
                 }
             }
             if (rnd == 0) W4_STAMP(10);
-            __syncthreads();                                             // the exchange area is rewritten by the next round / the next transform
+            if (!W4_EX2 || rnd < 3) __syncthreads();                     // single buffer: the exchange area is rewritten by the next round / the next transform;
+                                                                         // two buffers: see write_ex (after round 3 the next tile's barrier A does it)
             W4_STAMP(11 + rnd);
         }
 #if WINO4_EXP & 128
@@ -636,6 +658,7 @@ __global__ __launch_bounds__(768, 3) void conv2d_wino4(ConvParams p) {
         if (!has_next) break;
         tile = next;
         par ^= 1;
+        tiles_run++;
     }
 }
 

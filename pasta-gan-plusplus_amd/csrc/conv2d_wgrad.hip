@@ -51,17 +51,22 @@ constexpr unsigned WG_SENTINEL = 0x80000000u;     // byte offset beyond any desc
 // CU: waves 0-3 multiply (9 x 16 accumulators each), waves 4-7 only request the next chunk (52 requests + M0 traffic per lane and
 // chunk) -- issued by the multiplying waves themselves those requests cost 20 % of the kernel (measured: 88 -> 110 TFLOP/s with
 // the requests removed), from a wave of their own they overlap the other wave's MFMAs on the same SIMD.
-template <int KH, int KW, int S>
-__global__ __launch_bounds__(512, 1) void conv2d_wgrad(WgradParams p) {
+// TS (round 4): multiplying wave groups.  TS = 2: waves 0-3 own the first ceil(T / 2) taps, waves 4-7 the rest (the dy operand is read by both), the loader
+// waves follow -- TWO multiplying waves per SIMD that cover each other's LDS round trips and barrier waits (a single one has nothing but its own MFMAs).
+template <int KH, int KW, int S, int TS = 1>
+__global__ __launch_bounds__(256 * TS + 256, 1) void conv2d_wgrad(WgradParams p) {
     typedef WGeo<KH, KW, S> G;
+    constexpr int TG = (G::T + TS - 1) / TS;           // taps per multiplying group (the last group may own fewer)
     constexpr int WG_R = G::R, WG_PIX = G::PIX;
     constexpr int NDY = (WG_BM * G::PA + 255) / 256, NX = (WG_BN * G::PB + 255) / 256;
     extern __shared__ float smem[];
     constexpr int BUF = (NDY + NX) * 256;       // floats per staging buffer: dy [64 co][PA] then x [64 ci][PB], whole DMA rows
     const int lane = threadIdx.x & 63;
     const int wave8 = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    const bool loader = wave8 >= 4;                  // wave-uniform role
+    const bool loader = wave8 >= 4 * TS;             // wave-uniform role
     const int wave = wave8 & 3, t = threadIdx.x & 255;
+    const int tg = TS == 1 ? 0 : (wave8 >> 2);       // tap group of a multiplying wave
+    const int tap0 = tg * TG, ntap = (tap0 + TG <= G::T ? TG : G::T - tap0);
     const int half = lane >> 5, l31 = lane & 31;
     const int mt = wave & 1, nt = wave >> 1;
     int b = blockIdx.x;
@@ -137,9 +142,9 @@ __global__ __launch_bounds__(512, 1) void conv2d_wgrad(WgradParams p) {
         return;
     }
 
-    f32x16 acc[G::T];
+    f32x16 acc[TG];
 #pragma unroll
-    for (int tp = 0; tp < G::T; tp++)
+    for (int tp = 0; tp < TG; tp++)
 #pragma unroll
         for (int k = 0; k < 16; k++) acc[tp][k] = 0.f;
 
@@ -153,26 +158,34 @@ __global__ __launch_bounds__(512, 1) void conv2d_wgrad(WgradParams p) {
         const float* b_base = xt + (nt * 32 + l31) * G::PB + half * S;
         // One wave per SIMD: nothing hides an LDS round trip but the wave's own MFMAs, so the operands of step kk + 1 are
         // requested before the MFMAs of step kk are issued (register double buffering, order pinned by sched_barrier).
-        auto fetch = [&](int kk, float& a, float (&bv)[G::T]) __attribute__((always_inline)) {
+        // (TS = 2: the tap offsets of this wave's group, wave-uniform, folded into the base; a group with one tap less repeats its last one into a spare slot)
+        auto tap_off = [&](int j) { const int tp = tap0 + (j < ntap ? j : ntap - 1); return (tp / KW) * G::IW + tp % KW; };
+        auto fetch = [&](int kk, float& a, float (&bv)[TG]) __attribute__((always_inline)) {
             const int r = (2 * kk) / WG_TW, cc = (2 * kk) % WG_TW;
             a = a_base[2 * kk];
+            if (TS == 1) {
 #pragma unroll
-            for (int ky = 0; ky < KH; ky++)
+                for (int ky = 0; ky < KH; ky++)
 #pragma unroll
-                for (int kx = 0; kx < KW; kx++) bv[ky * KW + kx] = b_base[(r * S + ky) * G::IW + cc * S + kx];
+                    for (int kx = 0; kx < KW; kx++) bv[ky * KW + kx] = b_base[(r * S + ky) * G::IW + cc * S + kx];
+            } else {
+#pragma unroll
+                for (int j = 0; j < TG; j++) bv[j] = b_base[(r * S) * G::IW + cc * S + tap_off(j)];
+            }
         };
-        float a_cur, b_cur[G::T], a_nxt, b_nxt[G::T];
+        float a_cur, b_cur[TG], a_nxt, b_nxt[TG];
         fetch(0, a_cur, b_cur);
 #pragma unroll 2
         for (int kk = 0; kk < WG_PIX / 2; kk++) {                       // two adjacent pixels per step
             if (kk + 1 < WG_PIX / 2) fetch(kk + 1, a_nxt, b_nxt);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int tp = 0; tp < G::T; tp++) acc[tp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, b_cur[tp], acc[tp], 0, 0, 0);
+            for (int tp = 0; tp < TG; tp++)
+                if (TS == 1 || tp < ntap) acc[tp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, b_cur[tp], acc[tp], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             a_cur = a_nxt;
 #pragma unroll
-            for (int tp = 0; tp < G::T; tp++) b_cur[tp] = b_nxt[tp];
+            for (int tp = 0; tp < TG; tp++) b_cur[tp] = b_nxt[tp];
         }
         __syncthreads();
     }
@@ -180,11 +193,11 @@ __global__ __launch_bounds__(512, 1) void conv2d_wgrad(WgradParams p) {
     float* wsp = p.ws + (int64_t)s * G::T * p.Cout * p.Cin;
     const int ci = ci0 + nt * 32 + l31;
 #pragma unroll
-    for (int tp = 0; tp < G::T; tp++)
+    for (int tp = 0; tp < TG; tp++)
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             const int co = co0 + mt * 32 + (k & 3) + 8 * (k >> 2) + 4 * half;
-            if (co < p.Cout && ci < p.Cin) wsp[((int64_t)tp * p.Cout + co) * p.Cin + ci] = acc[tp][k];
+            if ((TS == 1 || tp < ntap) && co < p.Cout && ci < p.Cin) wsp[((int64_t)(tap0 + tp) * p.Cout + co) * p.Cin + ci] = acc[tp][k];
         }
 }
 
@@ -239,15 +252,19 @@ PG_EXPORT int pg_conv2d_wgrad(const float* x, const float* dy, float* dw, float*
     const int64_t blocks = (int64_t)p.coB * p.ciB * splits;
     if (blocks > 0x7fffffffLL) return PG_ERR_TOO_LARGE;
     hipStream_t s = (hipStream_t)stream;
-#define PG_WGRAD(KK, SS) { \
+#define PG_WGRAD(KK, SS, TT) { \
         const size_t lds = WGeo<KK, KK, SS>::LDS_FLOATS * sizeof(float); \
         static pg::PerDeviceOnce attr; \
-        const hipError_t e = attr.run([] { return hipFuncSetAttribute((const void*)conv2d_wgrad<KK, KK, SS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }); \
+        const hipError_t e = attr.run([] { return hipFuncSetAttribute((const void*)conv2d_wgrad<KK, KK, SS, TT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }); \
         if (e != hipSuccess) return (int)e; \
-        hipLaunchKernelGGL((conv2d_wgrad<KK, KK, SS>), dim3((unsigned)blocks), dim3(512), lds, s, p); }
-    if (KH == 3 && stride == 1) PG_WGRAD(3, 1)
-    else if (KH == 3) PG_WGRAD(3, 2)
-    else PG_WGRAD(1, 1)
+        hipLaunchKernelGGL((conv2d_wgrad<KK, KK, SS, TT>), dim3((unsigned)blocks), dim3(256 * TT + 256), lds, s, p); }
+    // A/B switch, off: measured in round 4 (tools/wgrad_probe.py, same box) -- two multiplying waves per SIMD by tap split are 13-17 % SLOWER than one
+    // (128->128 at 256^2: 97.6 -> 83.9 TFLOP/s; config 4 291 -> 299 ms): the dy operand is read twice and, as in conv2d_wino4b.h, a second f32-MFMA wave on a
+    // SIMD does not add matrix throughput, it shares it.
+    static const bool tap_split = [] { const char* e = getenv("PG_WGRAD_TAPSPLIT"); return e ? atoi(e) != 0 : false; }();
+    if (KH == 3 && stride == 1) { if (tap_split) PG_WGRAD(3, 1, 2) else PG_WGRAD(3, 1, 1) }
+    else if (KH == 3) { if (tap_split) PG_WGRAD(3, 2, 2) else PG_WGRAD(3, 2, 1) }
+    else PG_WGRAD(1, 1, 1)
 #undef PG_WGRAD
     int st = pg::launch_status();
     if (st != PG_OK) return st;

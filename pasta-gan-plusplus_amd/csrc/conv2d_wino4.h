@@ -204,19 +204,23 @@ __global__ __launch_bounds__(768, 3) void conv2d_wino4(ConvParams p) {
         xrsrc[3] = 0x00020000;
     };
 
-    auto issue_chunk = [&](int c0) {
+    // part < 0: the whole chunk; part 0 / 1 / 2 (W4_SPREAD): a third of its requests (4 + 4 + 4, wave 8 one more in the last part)
+    auto issue_chunk = [&](int c0, const int part = -1) __attribute__((always_inline)) {
 #if !(WINO4_EXP & 8)
         if (chore) {
             const unsigned xs_b = smem_b + (unsigned)sh * 4u;
             const int soff = c0 * HW * 4;
             const unsigned* gm = edge ? gmE : gmI;
             const int tc = 64 * cw + w4_fresh_lane();
+            const int i0 = part < 0 ? 0 : 4 * part, i1 = part < 0 ? W4_NDMA - 1 : (4 * part + 4 < W4_NDMA - 1 ? 4 * part + 4 : W4_NDMA - 1);
             unsigned off[W4_NDMA];
 #pragma unroll
-            for (int i = 0; i < W4_NDMA; i++) off[i] = gm[i * 256 + tc];
+            for (int i = 0; i < W4_NDMA; i++)
+                if ((i >= i0 && i < i1) || (i == W4_NDMA - 1 && (part < 0 || part == 2))) off[i] = gm[i * 256 + tc];
 #pragma unroll
-            for (int i = 0; i < W4_NDMA - 1; i++) dma_dwordx4_buf(xrsrc, xs_b + (unsigned)(256 * i + 64 * cw) * 16u, off[i], soff);
-            if (cw == 0) dma_dwordx4_buf(xrsrc, xs_b + (unsigned)(256 * (W4_NDMA - 1)) * 16u, off[W4_NDMA - 1], soff);    // words 2816..2879
+            for (int i = 0; i < W4_NDMA - 1; i++)
+                if (i >= i0 && i < i1) dma_dwordx4_buf(xrsrc, xs_b + (unsigned)(256 * i + 64 * cw) * 16u, off[i], soff);
+            if (cw == 0 && (part < 0 || part == 2)) dma_dwordx4_buf(xrsrc, xs_b + (unsigned)(256 * (W4_NDMA - 1)) * 16u, off[W4_NDMA - 1], soff);    // words 2816..2879
         }
 #endif
     };
@@ -237,9 +241,16 @@ __global__ __launch_bounds__(768, 3) void conv2d_wino4(ConvParams p) {
         pa += (unsigned)W4_UGROUP;
     };
     // wait for the three words of one group; `younger` = vector-memory operations issued after them that may still be in flight
-    auto wait_u = [&](f32x4 (&g)[3], bool dma_younger) {
+    auto wait_u = [&](f32x4 (&g)[3], bool dma_younger, const int spread_g = -1) {
         if (WINO4_EXP & 512) {
             asm volatile("s_waitcnt vmcnt(0)");
+        } else if (dma_younger && spread_g >= 0) {
+            // W4_SPREAD: behind group g's words sit (g = 1) G2 + P0 = 7, (g = 2) P0 + G3 + P1 = 11, (g = 3) P1 + nG0 + P2 = 10 (wave 8: 11) younger operations
+            if (spread_g == 0) asm volatile("s_waitcnt vmcnt(3)");
+            else if (spread_g == 1) asm volatile("s_waitcnt vmcnt(7)");
+            else if (spread_g == 2) asm volatile("s_waitcnt vmcnt(11)");
+            else if (cw == 0) asm volatile("s_waitcnt vmcnt(11)");
+            else asm volatile("s_waitcnt vmcnt(10)");
         } else if (dma_younger) {
             if (cw == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 + W4_NDMA));
             else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 + W4_NDMA - 1));
@@ -368,7 +379,17 @@ __global__ __launch_bounds__(768, 3) void conv2d_wino4(ConvParams p) {
                 }
             };
             constexpr bool LATE = (WINO4_EXP & 1024) != 0;               // timing experiment: the chore waves request the next chunk after group 1's MFMAs instead of before group 0's
-            if (!LATE) request_next();
+            // W4_SPREAD (timing experiment, bit 16384): a third of the chunk's requests behind each of the first three MFMA groups, so that a request's issue
+            // overlaps the wave's own MFMA in flight instead of delaying its first one; the next tile is then prepared after the last third.  Measured (round 4,
+            // results identical): 4-6 % SLOWER on every shape (427 -> 446 us at 128->128 256^2) -- all requests up front stays the best placement for this kernel.
+            const bool spread = (WINO4_EXP & 16384) != 0 && nchunks >= 2;
+            int pend_c0 = -1;
+            if (spread) {
+                if (k + 1 < nchunks) pend_c0 = (k + 1) * W4_KC;
+                else if (k + 1 == nchunks) {                             // (the next tile was prepared during the previous chunk)
+                    if (has_next) pend_c0 = 0; else issued = false;
+                }
+            } else if (!LATE) request_next();
             bool dma_q = issued && chore;                                // this wave put DMA requests behind the words of groups 0 and 1 (LATE: of groups 2 and 3)
 
             // ---- GEMM phase: 4 groups of (3 xi) x (4 channel pairs).  Ring: group g in slot g & 1; requests: group 1 above, group g + 2
@@ -390,7 +411,8 @@ __global__ __launch_bounds__(768, 3) void conv2d_wino4(ConvParams p) {
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 const int jg = g >> 1;
-                wait_u(ur[g & 1], (LATE ? g >= 2 : g < 2) && dma_q);
+                if (spread) wait_u(ur[g & 1], dma_q, g);
+                else wait_u(ur[g & 1], (LATE ? g >= 2 : g < 2) && dma_q);
 #pragma unroll
                 for (int ph = 0; ph < 2; ph++) {
                     const int hg = 2 * g + ph;
@@ -406,10 +428,20 @@ __global__ __launch_bounds__(768, 3) void conv2d_wino4(ConvParams p) {
                 if (g == 2 && k + 1 == nchunks) a_reset(m0);             // from here on: the next tile's first group (m0 is already the next tile's)
                 if (g < 3) load_u(ur[g & 1]);
                 if (LATE && g == 1) { request_next(); dma_q = issued && chore; }
+                if (spread && g < 3) {
+                    if (pend_c0 >= 0) issue_chunk(pend_c0, g);
+                    if (g == 2 && k + 2 == nchunks) {                    // prepare the next tile (after this tile's last chunk has been requested in full)
+                        e_n = n; e_oy0 = oy0; e_ox0 = ox0; e_m0 = m0;
+                        next = tile + gridDim.x;
+                        has_next = next < total;
+                        if (has_next) prep_tile(next, cs0 + (par ^ 1) * cin_loop);
+                    }
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (WINO4_EXP & (2048 | 4096)) __builtin_amdgcn_s_setprio(0);
             if (k == 2) W4_STAMP(4);
+            if (spread && dma_q) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last third must have landed before the next barrier A
             if (LATE && dma_q) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");   // the halo must have landed before the next barrier A; only the next chunk's first U group is younger
             if (!issued) dma_wait_all();                                 // last chunk of the last tile: nothing counted behind us
             if ((WINO4_EXP & 256) && chore) dma_wait_all();

@@ -45,6 +45,11 @@ for (N, H, cin, cout) in SHAPES:
     for v in ALL:
         conv2d_mfma._plugin = libs[v]
         packed[v] = conv2d_mfma.pack_weight(w, winograd=2)
+    outs = {}
+    for v in ALL:
+        conv2d_mfma._plugin = libs[v]
+        outs[v] = conv2d_mfma.conv2d_forward(x, packed[v], cout, 3, 3, pad=(1, 1), winograd=2).clone()
+    print('   max |variant - first|: ' + '  '.join(f'[{v}] {float((outs[v] - outs[ALL[0]]).abs().max()):.1e}' for v in ALL), flush=True)
     for r in range(rounds + 1):
         for v in ALL:
             conv2d_mfma._plugin = libs[v]

@@ -320,14 +320,7 @@ def _modconv_fast16(x, weight, styles, noise, up, padding, resample_filter, demo
         ybuf = torch.empty([n, cout, 2 * h + 2, 2 * w + 2], dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
         conv2d_mfma16.conv2d_forward(conv2d_mfma16.to_channels_last(x), packed, cout, 2, 2, pad=(1, 1), out_hw=(h + 1, w + 1), y=ybuf, sample_stride=per,
                                      out_scale=out_scale, phases=True)
-        y = ybuf[:, :, :2 * h + 1, :2 * w + 1]
-        res = ep.pop('residual', None)
-        b = ep.get('bias')
-        fused = upfirdn2d.upfirdn2d_bias_act(y, resample_filter, padding=fir_pad, gain=4, noise=noise, b=b, act=ep.get('act', 'linear'),
-                                             alpha=ep.get('alpha') or 0.0, act_gain=ep.get('gain', 1.0), clamp=ep.get('clamp'))
-        if fused is not None:
-            return fused if res is None else fused.add_(res)
-        y = y.contiguous(memory_format=torch.channels_last)      # (the FIR declined the view: dense copy, then the composed tail below)
+        y = ybuf[:, :, :2 * h + 1, :2 * w + 1]                    # a pitched channels-last view: the FIR below reads it in place
     elif shared:        # x already carries the normalised styles; demodulation is a per-(n, cout) scale, which commutes with the FIR that follows
         phases = cache.get(('up2_t_shared', flip_weight, x.dtype, tuple(tpad), (h, w)), [weight],
                            lambda: conv2d_mfma16.pack_transposed(transposed_weight(), x.dtype, 2, tpad, (h, w), out_hw))
@@ -337,11 +330,13 @@ def _modconv_fast16(x, weight, styles, noise, up, padding, resample_filter, demo
         if phases is None:
             return None
         y = conv2d_mfma16.conv_transpose2d_forward(x, phases, cout, out_hw, stride=2, **(dict(out_scale=out_scale) if shared and out_scale is not None else {}))
-    res = ep.pop('residual', None) if 'residual' in ep else (res if merged_t else None)
+    res = ep.pop('residual', None)
     b = ep.get('bias')
     fused = upfirdn2d.upfirdn2d_bias_act(y, resample_filter, padding=fir_pad, gain=4, noise=noise, b=b, act=ep.get('act', 'linear'),
                                          alpha=ep.get('alpha') or 0.0, act_gain=ep.get('gain', 1.0), clamp=ep.get('clamp'))
     if fused is None:
+        if not y.is_contiguous(memory_format=torch.channels_last):
+            y = y.contiguous(memory_format=torch.channels_last)      # (the fused FIR declined the pitched view of the merged route: dense copy)
         y = upfirdn2d.upfirdn2d(y, resample_filter, padding=fir_pad, gain=4)
         if noise is not None:
             y = y.add_(noise.to(y.dtype))

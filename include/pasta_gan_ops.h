@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 8
+#define PG_ABI_VERSION 9
 
 enum pg_dtype { PG_F32 = 0, PG_F16 = 1, PG_BF16 = 2, PG_F64 = 3 };
 
@@ -64,6 +64,17 @@ int pg_bias_act(const void* x, const void* b, const void* xref, const void* yref
                 int dtype, int64_t sizeX, int sizeB, int64_t stepB,
                 int grad, int act, float alpha, float gain, float clamp, void* stream);
 int pg_bias_act_abi_version(void);
+
+/* First-derivative form with the bias gradient gathered in the same pass (training route): dx as grad == 1 above (NULL: not stored),
+ * db[c] = dx summed over every element of channel c, written in the tensors' dtype.  Replaces the pair "plugin call + dx.sum(...)" of
+ * BiasActCuda.backward (torch_utils/ops/bias_act.py:176-186).  Covered: float32 / float16 / bfloat16; act linear, relu, lrelu (the
+ * derivatives that need only yref); layouts [outer][sizeB][stepB] with stepB a multiple of 16 bytes, or stepB == 1 with sizeB / (16 bytes)
+ * dividing 256.  `workspace`: at least pg_bias_act_grad_bias_workspace(...) bytes of device memory (0 = layout not covered); the sum is a
+ * fixed-order fold of per-workgroup partials -- bit-identical from run to run.  PG_ERR_UNSUPPORTED: not covered / unaligned. */
+int64_t pg_bias_act_grad_bias_workspace(int dtype, int64_t sizeX, int sizeB, int64_t stepB);
+int pg_bias_act_grad_bias(const void* dy, const void* yref, void* dx, void* db, void* workspace, int64_t workspace_bytes,
+                          int dtype, int64_t sizeX, int sizeB, int64_t stepB,
+                          int act, float alpha, float gain, float clamp, void* stream);
 
 /* ------------------------------------------------------------------------
  * upfirdn2d -- replaces upfirdn2d_plugin.upfirdn2d (torch_utils/ops/upfirdn2d.cpp:16-94,

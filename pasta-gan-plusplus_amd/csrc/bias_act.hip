@@ -199,6 +199,162 @@ int dispatch_act(const Params& p, int act, int grad, hipStream_t s) {
     return PG_ERR_INVALID_ARG;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// First-derivative form with the bias gradient in the same pass (training route): dx = dy * act'(.) * gain (clamp-masked)
+// AND db[c] = sum over everything but the channel axis of dx -- the reference composes these as the plugin call plus
+// `dx.sum(...)` (bias_act.py:176-186), i.e. a second read of dx.  Two layouts:
+//   planar       (stepB = plane size, NCHW): one workgroup per (plane, chunk of SUM_CHUNK vectors) -> partial[(n*C + c)*K + k]
+//   interleaved  (stepB = 1, channels-last / [N, C]): grid-stride; with C/VEC dividing the block, a lane keeps ONE channel
+//                vector for its whole walk -> per-lane sums, one LDS fold per block -> partial[block*C + c]
+// then a fixed-order fold of the partials (one wavefront per channel, fp64) -> deterministic, unlike an atomic sum.
+// Sums are taken over the values as stored (rounded to T), what `dx.sum()` sees.  HBM-bound: sizeof(T) * (2 reads + 1 write).
+
+constexpr int SUM_ITERS = 4;          // 16-byte vectors per lane in a planar chunk
+constexpr int SUM_MAX_BLOCKS = 1024;  // interleaved grid cap (the workspace is sized from it without asking the device)
+
+struct SumPlan { int mode; int64_t planes; int K; int64_t chunk; int grid; int64_t floats; };   // mode 0 = not covered, 1 planar, 2 interleaved
+
+static SumPlan sum_plan(int dtype, int64_t sizeX, int sizeB, int64_t stepB) {
+    SumPlan pl = {0, 0, 0, 0, 0, 0};
+    const int esz = dtype == PG_F32 ? 4 : (dtype == PG_F16 || dtype == PG_BF16) ? 2 : 0;
+    if (!esz || sizeX <= 0 || sizeB <= 0 || stepB <= 0) return pl;
+    const int VEC = 16 / esz;
+    if (stepB == 1) {
+        if (sizeB % VEC || 256 % (sizeB / VEC) || sizeX % sizeB) return pl;
+        const int64_t nvec = sizeX / VEC;
+        int64_t blocks = (nvec + 255) / 256;
+        pl.mode = 2; pl.grid = (int)(blocks > SUM_MAX_BLOCKS ? SUM_MAX_BLOCKS : blocks); pl.floats = (int64_t)pl.grid * sizeB;
+        return pl;
+    }
+    if (stepB % VEC || sizeX % (stepB * sizeB)) return pl;
+    pl.chunk = (int64_t)VEC * 256 * SUM_ITERS;
+    const int64_t K = (stepB + pl.chunk - 1) / pl.chunk;
+    pl.planes = sizeX / stepB;
+    if (K > (1 << 20) || pl.planes * K > 0x7fffffffLL) return pl;
+    pl.mode = 1; pl.K = (int)K; pl.floats = pl.planes * K;
+    return pl;
+}
+
+struct SumParams {
+    const void* dy; const void* yref; void* dx; float* partial;
+    int64_t sizeX; int64_t stepB; int sizeB; int K; int64_t chunk;
+    float alpha, gain, clamp;
+};
+
+__device__ __forceinline__ float block_sum_256(float s, float* sm) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+    __syncthreads();
+    return sm[0] + sm[1] + sm[2] + sm[3];       // every lane returns the same, fixed-order total
+}
+
+template <typename T, int A, bool WRITE>
+__global__ __launch_bounds__(256) void bias_act_grad_sum_planar(SumParams p) {
+    constexpr int VEC = 16 / sizeof(T);
+    typedef vec_t<T, VEC> V;
+    __shared__ float sm[4];
+    const int64_t q = blockIdx.x / p.K;
+    const int64_t lo = (int64_t)(blockIdx.x % p.K) * p.chunk;
+    const int64_t hi = lo + p.chunk < p.stepB ? lo + p.chunk : p.stepB;
+    const T* __restrict__ dyp = (const T*)p.dy + q * p.stepB;
+    const T* __restrict__ yrp = p.yref ? (const T*)p.yref + q * p.stepB : nullptr;
+    T* __restrict__ dxp = WRITE ? (T*)p.dx + q * p.stepB : nullptr;
+    float s = 0.f;
+    for (int64_t e = lo + (int64_t)threadIdx.x * VEC; e < hi; e += 256 * VEC) {
+        const V dv = *(const V*)(dyp + e);
+        V yv, out;
+        if (yrp) yv = *(const V*)(yrp + e);
+#pragma unroll
+        for (int k = 0; k < VEC; k++) {
+            out.v[k] = bias_act_one<T, A, 1>(dv.v[k], (T)0, (T)0, yrp ? yv.v[k] : (T)0, (T)1, p.alpha, p.gain, p.clamp);
+            s += (float)out.v[k];
+        }
+        if (WRITE) *(V*)(dxp + e) = out;
+    }
+    s = block_sum_256(s, sm);
+    if (threadIdx.x == 0) p.partial[blockIdx.x] = s;
+}
+
+template <typename T, int A, bool WRITE>
+__global__ __launch_bounds__(256) void bias_act_grad_sum_interleaved(SumParams p) {
+    constexpr int VEC = 16 / sizeof(T);
+    typedef vec_t<T, VEC> V;
+    __shared__ float sm[256 * VEC];
+    const T* __restrict__ dyp = (const T*)p.dy;
+    const T* __restrict__ yrp = (const T*)p.yref;
+    T* __restrict__ dxp = (T*)p.dx;
+    const int64_t nvec = p.sizeX / VEC;
+    const int64_t stride = (int64_t)gridDim.x * 256;       // a multiple of C / VEC: the lane's channel vector never changes
+    float s[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; k++) s[k] = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += stride) {
+        const V dv = ((const V*)dyp)[i];
+        V yv, out;
+        if (yrp) yv = ((const V*)yrp)[i];
+#pragma unroll
+        for (int k = 0; k < VEC; k++) {
+            out.v[k] = bias_act_one<T, A, 1>(dv.v[k], (T)0, (T)0, yrp ? yv.v[k] : (T)0, (T)1, p.alpha, p.gain, p.clamp);
+            s[k] += (float)out.v[k];
+        }
+        if (WRITE) ((V*)dxp)[i] = out;
+    }
+#pragma unroll
+    for (int k = 0; k < VEC; k++) sm[threadIdx.x * VEC + k] = s[k];
+    __syncthreads();
+    const int cv = p.sizeB / VEC;
+    if ((int)threadIdx.x < cv) {
+#pragma unroll
+        for (int k = 0; k < VEC; k++) {
+            float a = 0.f;
+            for (int r = 0; r < 256 / cv; r++) a += sm[(r * cv + threadIdx.x) * VEC + k];
+            p.partial[(int64_t)blockIdx.x * p.sizeB + threadIdx.x * VEC + k] = a;
+        }
+    }
+}
+
+// out[c] = sum_{j < J} sum_{i < I} partial[j*sj + c*sc + i]; one wavefront per channel, lanes take (j, i) pairs round-robin, fixed-order fold.
+template <typename T>
+__global__ __launch_bounds__(64) void channel_sum_finish(const float* __restrict__ partial, T* __restrict__ out, int64_t J, int64_t sj, int64_t sc, int I) {
+    const int c = blockIdx.x;
+    double a = 0.0;
+    const int64_t total = J * I;
+    for (int64_t t = threadIdx.x; t < total; t += 64) a += (double)partial[(t / I) * sj + (int64_t)c * sc + (t % I)];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);
+    if (threadIdx.x == 0) out[c] = (T)a;
+}
+
+template <typename T, int A>
+int launch_grad_sum(const SumPlan& pl, SumParams p, void* db, hipStream_t stream) {
+    const bool write = p.dx != nullptr;
+    if (pl.mode == 1) {
+        p.K = pl.K; p.chunk = pl.chunk;
+        const dim3 grid((unsigned)(pl.planes * pl.K));
+        if (write) hipLaunchKernelGGL((bias_act_grad_sum_planar<T, A, true>), grid, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((bias_act_grad_sum_planar<T, A, false>), grid, dim3(256), 0, stream, p);
+        const int64_t n = pl.planes / p.sizeB;
+        hipLaunchKernelGGL((channel_sum_finish<T>), dim3(p.sizeB), dim3(64), 0, stream, (const float*)p.partial, (T*)db, n, (int64_t)p.sizeB * pl.K, (int64_t)pl.K, pl.K);
+    } else {
+        if (write) hipLaunchKernelGGL((bias_act_grad_sum_interleaved<T, A, true>), dim3(pl.grid), dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((bias_act_grad_sum_interleaved<T, A, false>), dim3(pl.grid), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((channel_sum_finish<T>), dim3(p.sizeB), dim3(64), 0, stream, (const float*)p.partial, (T*)db, (int64_t)pl.grid, (int64_t)p.sizeB, (int64_t)1, 1);
+    }
+    return launch_status();
+}
+
+template <typename T>
+int dispatch_grad_sum(const SumPlan& pl, const SumParams& p, void* db, int act, hipStream_t s) {
+    switch (act) {      // the activations of the networks' layers; the others keep the two-pass composition
+        case PG_ACT_LINEAR: return launch_grad_sum<T, PG_ACT_LINEAR>(pl, p, db, s);
+        case PG_ACT_RELU: return launch_grad_sum<T, PG_ACT_RELU>(pl, p, db, s);
+        case PG_ACT_LRELU: return launch_grad_sum<T, PG_ACT_LRELU>(pl, p, db, s);
+    }
+    return PG_ERR_UNSUPPORTED;
+}
+
 }  // namespace
 
 PG_EXPORT int pg_bias_act_abi_version(void) { return PG_ABI_VERSION; }
@@ -222,4 +378,30 @@ PG_EXPORT int pg_bias_act(const void* x, const void* b, const void* xref, const 
         case PG_F64: return dispatch_act<double>(p, act, grad, s);
     }
     return PG_ERR_INVALID_ARG;
+}
+
+PG_EXPORT int64_t pg_bias_act_grad_bias_workspace(int dtype, int64_t sizeX, int sizeB, int64_t stepB) {
+    return sum_plan(dtype, sizeX, sizeB, stepB).floats * (int64_t)sizeof(float);
+}
+
+PG_EXPORT int pg_bias_act_grad_bias(const void* dy, const void* yref, void* dx, void* db, void* workspace, int64_t workspace_bytes,
+                                    int dtype, int64_t sizeX, int sizeB, int64_t stepB,
+                                    int act, float alpha, float gain, float clamp, void* stream) {
+    if (!dy || !db || !workspace || sizeX <= 0 || sizeB <= 0 || stepB <= 0) return PG_ERR_INVALID_ARG;
+    const SumPlan pl = sum_plan(dtype, sizeX, sizeB, stepB);
+    if (!pl.mode) return PG_ERR_UNSUPPORTED;
+    if (workspace_bytes < pl.floats * (int64_t)sizeof(float)) return PG_ERR_INVALID_ARG;
+    if (!aligned16(dy) || (yref && !aligned16(yref)) || (dx && !aligned16(dx))) return PG_ERR_UNSUPPORTED;
+    if ((act == PG_ACT_RELU || act == PG_ACT_LRELU || clamp >= 0.f) && !yref) return PG_ERR_INVALID_ARG;   // their derivative reads the forward output
+    SumParams p;
+    p.dy = dy; p.yref = yref; p.dx = dx; p.partial = (float*)workspace;
+    p.sizeX = sizeX; p.stepB = stepB; p.sizeB = sizeB; p.K = 0; p.chunk = 0;
+    p.alpha = alpha; p.gain = gain; p.clamp = clamp;
+    hipStream_t s = (hipStream_t)stream;
+    switch (dtype) {
+        case PG_F32: return dispatch_grad_sum<float>(pl, p, db, act, s);
+        case PG_F16: return dispatch_grad_sum<pg::f16_t>(pl, p, db, act, s);
+        case PG_BF16: return dispatch_grad_sum<pg::bf16_t>(pl, p, db, act, s);
+    }
+    return PG_ERR_UNSUPPORTED;
 }

@@ -10,6 +10,7 @@ plain-torch composition ``_bias_act_torch`` below (autograd differentiates it).
 """
 
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -49,6 +50,13 @@ def _init():
         fn.restype = ctypes.c_int
         fn.argtypes = [ctypes.c_void_p] * 6 + [ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_int64,
                                                ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_void_p]
+        ws = plugin.lib.pg_bias_act_grad_bias_workspace
+        ws.restype = ctypes.c_int64
+        ws.argtypes = [ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_int64]
+        gb = plugin.lib.pg_bias_act_grad_bias
+        gb.restype = ctypes.c_int
+        gb.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_int64,
+                                               ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_void_p]
         _plugin = plugin
     return True
 
@@ -84,6 +92,53 @@ def _native_bias_act(x, b, xref, yref, dy, grad, dim, act_idx, alpha, gain, clam
                                      int(grad), int(act_idx), float(alpha), float(gain), float(clamp), nat.stream_of(x))
     nat.check(st, 'pg_bias_act')
     return y
+
+
+_FUSED_DB_ACTS = ('linear', 'relu', 'lrelu')
+fused_bias_gradient = os.environ.get('PG_FUSED_DB', '1') != '0'     # dx and db in one pass over dy (PG_FUSED_DB=0: the reference's dx.sum())
+
+
+def _native_grad_bias(dy, y, dim, act, alpha, gain, clamp, write=True):
+    """(dx, db) of the first-derivative form in ONE pass over dy (csrc/bias_act.hip, pg_bias_act_grad_bias): dx as grad == 1 of
+    `_native_bias_act`, db = dx summed over every axis but `dim` (fixed-order, deterministic).  `write=False`: db only (dx = None).
+    Returns None where the layout / activation is not covered -- the caller then composes the two steps like the reference
+    (bias_act.py:176-186)."""
+    if not fused_bias_gradient or act not in _FUSED_DB_ACTS or dy.dtype not in (torch.float32, torch.float16, torch.bfloat16):
+        return None
+    if not dy.is_cuda or dy.numel() == 0 or not nat.is_dense(dy) or (y is not None and (y.dtype != dy.dtype or not _same_layout(y, dy) or not nat.is_dense(y))):
+        return None
+    _init()
+    c = int(dy.shape[dim])
+    if dy.is_contiguous():                           # the kernel's channel of element i is (i / step) % c
+        step = int(np.prod(dy.shape[dim + 1:], dtype=np.int64))
+    elif dy.ndim == 4 and dim == 1 and dy.is_contiguous(memory_format=torch.channels_last):
+        step = 1
+    else:
+        return None
+    nbytes = _plugin.lib.pg_bias_act_grad_bias_workspace(nat.PG_DTYPE[dy.dtype], dy.numel(), c, step)
+    if nbytes <= 0:
+        return None
+    work = torch.empty([nbytes // 4], dtype=torch.float32, device=dy.device)
+    dx = torch.empty_like(dy) if write else None
+    db = torch.empty([c], dtype=dy.dtype, device=dy.device)
+    with torch.cuda.device(dy.device):
+        st = _plugin.lib.pg_bias_act_grad_bias(nat.ptr(dy), nat.ptr(y), nat.ptr(dx), nat.ptr(db), nat.ptr(work), nbytes,
+                                               nat.PG_DTYPE[dy.dtype], dy.numel(), c, step, activation_funcs[act].cuda_idx,
+                                               float(alpha), float(gain), float(clamp), nat.stream_of(dy))
+    if st == -2:                                      # PG_ERR_UNSUPPORTED (alignment): compose
+        return None
+    nat.check(st, 'pg_bias_act_grad_bias')
+    return dx, db
+
+
+def channel_sum(t, dim=1):
+    """t summed over every axis but `dim` -- the bias gradient of a convolution / bias_act (`dy.sum([0, 2, 3])`): one deterministic native pass
+    where covered and nothing asks for the sum's own gradient, torch otherwise."""
+    if t.is_cuda and not (torch.is_grad_enabled() and t.requires_grad):
+        out = _native_grad_bias(_dense(t), None, dim, 'linear', 0.0, 1.0, -1.0, write=False)
+        if out is not None:
+            return out[1]
+    return t.sum([i for i in range(t.ndim) if i != dim])
 
 
 # ----------------------------------------------------------------------------
@@ -154,9 +209,12 @@ class _BiasAct(torch.autograd.Function):
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             dx = dy
             if act != 'linear' or gain != 1 or clamp >= 0:
-                dx = _BiasActGrad.apply(dy, x, b, y, dim, act, alpha, gain, clamp)
-        if ctx.needs_input_grad[1]:
-            db = dx.sum([i for i in range(dx.ndim) if i != dim])
+                if ctx.needs_input_grad[1]:          # dx and its channel sums from one pass over dy
+                    dx, db = _BiasActGrad.apply(dy, x, b, y, dim, act, alpha, gain, clamp, True)
+                else:
+                    dx = _BiasActGrad.apply(dy, x, b, y, dim, act, alpha, gain, clamp)
+        if ctx.needs_input_grad[1] and db is None:
+            db = channel_sum(dx, dim)
         return dx, db, None, None, None, None, None
 
 
@@ -164,22 +222,33 @@ class _BiasActGrad(torch.autograd.Function):
     """dx = dy * act'(.) * gain (clamp-masked); itself differentiable (R1 needs d/d(dy), bias_act.py:197-198)."""
 
     @staticmethod
-    def forward(ctx, dy, x, b, y, dim, act, alpha, gain, clamp):
+    def forward(ctx, dy, x, b, y, dim, act, alpha, gain, clamp, with_db=False):
+        """`with_db` (private): also return db = dx summed over every axis but `dim`, gathered in the same pass where the kernel covers it."""
         spec = activation_funcs[act]
         ref = y if y is not None else x
         dy = _dense(dy)
         if ref is not None and not _same_layout(dy, ref):    # match the saved tensors' layout (bias_act.py:160-162)
             dy = torch.empty_like(ref).copy_(dy)
-        dx = _native_bias_act(dy, b, x, y, None, 1, dim, spec.cuda_idx, alpha, gain, clamp)
+        fused = _native_grad_bias(dy, y, dim, act, alpha, gain, clamp) if (with_db and x is None) else None
+        if fused is not None:
+            dx, db = fused
+        else:
+            dx = _native_bias_act(dy, b, x, y, None, 1, dim, spec.cuda_idx, alpha, gain, clamp)
+            db = channel_sum(dx.detach(), dim) if with_db else None
         ctx.save_for_backward(dy if spec.has_2nd_grad else None, x, b, y)
         ctx.cfg = (dim, act, alpha, gain, clamp)
-        return dx
+        return (dx, db) if with_db else dx
 
     @staticmethod
-    def backward(ctx, d_dx):
+    def backward(ctx, d_dx, d_db=None):
         dim, act, alpha, gain, clamp = ctx.cfg
         spec = activation_funcs[act]
         dy, x, b, y = ctx.saved_tensors
+        if d_db is not None:                                 # db = sum(dx): its gradient is spread back over dx
+            ref = y if y is not None else x if x is not None else d_dx
+            shape = [1] * ref.ndim
+            shape[dim] = -1
+            d_dx = d_db.reshape(shape).expand(ref.shape) if d_dx is None else d_dx + d_db.reshape(shape)
         d_dy = d_x = d_b = None
         if ctx.needs_input_grad[0]:
             d_dy = _BiasActGrad.apply(d_dx, x, b, y, dim, act, alpha, gain, clamp)
@@ -191,4 +260,4 @@ class _BiasActGrad(torch.autograd.Function):
             d_x = _native_bias_act(d_dx_c, b, x, y, dy, 2, dim, spec.cuda_idx, alpha, gain, clamp)
         if spec.has_2nd_grad and ctx.needs_input_grad[2]:
             d_b = d_x.sum([i for i in range(d_x.ndim) if i != dim])
-        return d_dy, d_x, d_b, None, None, None, None, None, None
+        return d_dy, d_x, d_b, None, None, None, None, None, None, None

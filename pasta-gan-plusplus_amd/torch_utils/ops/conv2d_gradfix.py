@@ -28,6 +28,7 @@ import weakref
 import torch
 
 from . import _native as nat
+from . import bias_act
 from . import conv2d_mfma
 from . import conv2d_mfma16
 
@@ -81,21 +82,49 @@ def _by_group(fn, input, weight, bias, groups, out_axis, **kw):
     return torch.cat(outs, dim=1)
 
 
-def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1):
+fused_epilogue = os.environ.get('PG_TRAIN_EPILOGUE', '1') != '0'     # training route: bias_act in the convolution's epilogue (PG_TRAIN_EPILOGUE=0: a pass of its own)
+
+
+def _epilogue_cfg(ep):
+    """dict(act, alpha, gain, clamp) of a `bias_act` that follows the convolution -> the tuple the autograd Functions carry, or None when
+    it is the identity."""
+    if not ep:
+        return None
+    act = ep.get('act', 'linear')
+    spec = bias_act.activation_funcs[act]
+    alpha = float(ep['alpha'] if ep.get('alpha') is not None else spec.def_alpha)
+    gain = float(ep['gain'] if ep.get('gain') is not None else spec.def_gain)
+    clamp = float(ep['clamp'] if ep.get('clamp') is not None else -1)
+    if act == 'linear' and gain == 1 and clamp < 0:
+        return None
+    return (act, alpha, gain, clamp)
+
+
+def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, _epilogue=None):
+    """`_epilogue` (private): dict(act, alpha, gain, clamp) -- `bias_act(conv2d(...) , act=...)` of the caller (the bias is this call's
+    `bias`), run in the native convolution's epilogue with the derivative taken from the saved output, or as the separate op where the
+    native kernels do not take the call."""
     assert isinstance(input, torch.Tensor)
+    cfg = _epilogue_cfg(_epilogue)
+
+    def tail(y):
+        return y if cfg is None else bias_act.bias_act(y, None, act=cfg[0], alpha=cfg[1], gain=cfg[2], clamp=cfg[3] if cfg[3] >= 0 else None)
     if enabled and input.is_cuda and 1 < groups <= 64 and input.ndim == 4 and input.shape[1] % groups == 0 and weight.shape[0] % groups == 0:
-        return _by_group(conv2d, input, weight, bias, groups, 0, stride=stride, padding=padding, dilation=dilation)
+        return tail(_by_group(conv2d, input, weight, bias, groups, 0, stride=stride, padding=padding, dilation=dilation))
     stride, padding, dilation = _pair(stride), _pair(padding), _pair(dilation)
     kh, kw = int(weight.shape[2]), int(weight.shape[3])
+    fuse = cfg if (fused_epilogue and cfg is not None and cfg[0] in conv2d_mfma.FUSED_ACTS) else None
     if enabled and input.is_cuda and min(padding) >= 0:
         try:                                           # a VALID request the kernels decline (32-bit indexing limits, LDS budget) takes the aten route
             if _native_ok(input, weight, stride, dilation, groups) and conv2d_mfma.supported(kh, kw, stride[0]):
-                return _Conv2dMfma.apply(input, weight, bias, stride[0], padding, False, (0, 0))
+                y = _Conv2dMfma.apply(input, weight, bias, stride[0], padding, False, (0, 0), fuse)
+                return y if fuse is not None else tail(y)
             if _native16_ok(input, weight, stride, dilation, groups) and conv2d_mfma16.supported(kh, kw, stride[0]):
-                return _Conv2dMfma16.apply(input, weight, bias, stride[0], padding, False, (0, 0))
+                y = _Conv2dMfma16.apply(input, weight, bias, stride[0], padding, False, (0, 0), fuse)
+                return y if fuse is not None else tail(y)
         except nat.NativeNotCovered:
             pass
-    return torch.nn.functional.conv2d(input=input, weight=weight, bias=bias, stride=stride, padding=padding, dilation=dilation, groups=groups)
+    return tail(torch.nn.functional.conv2d(input=input, weight=weight, bias=bias, stride=stride, padding=padding, dilation=dilation, groups=groups))
 
 
 def _phases_supported(mod, kh, kw, s):
@@ -151,31 +180,44 @@ def _packed(weight, winograd, flip=False, transpose_oi=False):
     return hit
 
 
+def _epilogue_backward(ctx, dy, y, ep, want_b):
+    """dy of the fused bias_act -> dy of the convolution proper (and db from the same pass): `_BiasActGrad` on the saved output, the
+    op `BiasActCuda.backward` runs (bias_act.py:160-176) -- differentiable again, so R1-style double backward passes through."""
+    act, alpha, gain, clamp = ep
+    if want_b:
+        return bias_act._BiasActGrad.apply(dy, None, None, y, 1, act, alpha, gain, clamp, True)
+    return bias_act._BiasActGrad.apply(dy, None, None, y, 1, act, alpha, gain, clamp), None
+
+
 class _Conv2dMfma(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, padding, transposed, output_padding):
+    def forward(ctx, x, weight, bias, stride, padding, transposed, output_padding, ep=None):
         x = x.contiguous()
         n, cin, h, w = x.shape
         kh, kw = int(weight.shape[2]), int(weight.shape[3])
         if not transposed:
             cout = int(weight.shape[0])
-            wg = conv2d_mfma.use_winograd(kh, kw, stride, cout, cin, pad=padding, hw=(h, w))
-            y = conv2d_mfma.conv2d_forward(x, _packed(weight, wg), cout, kh, kw, stride=stride, pad=padding, bias=bias, winograd=wg)
+            fz = dict(act=ep[0], alpha=ep[1], gain=ep[2], clamp=ep[3] if ep[3] >= 0 else None) if ep is not None else {}
+            wg = conv2d_mfma.use_winograd(kh, kw, stride, cout, cin, pad=padding, hw=(h, w), ep=fz)
+            y = conv2d_mfma.conv2d_forward(x, _packed(weight, wg), cout, kh, kw, stride=stride, pad=padding, bias=bias, winograd=wg, **fz)
         else:
+            assert ep is None
             cout = int(weight.shape[1])
             out_hw = ((h - 1) * stride - 2 * padding[0] + kh + output_padding[0], (w - 1) * stride - 2 * padding[1] + kw + output_padding[1])
             phases = conv2d_mfma.pack_transposed(weight, stride, padding, (h, w), out_hw)
             y = conv2d_mfma.conv_transpose2d_forward(x, phases, cout, out_hw, stride=stride, bias=bias)
-        ctx.save_for_backward(x, weight)
-        ctx.cfg = (stride, padding, transposed, output_padding, bias is not None)
+        ctx.save_for_backward(x, weight, y if ep is not None else None)
+        ctx.cfg = (stride, padding, transposed, output_padding, bias is not None, ep)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, weight = ctx.saved_tensors
-        stride, padding, transposed, output_padding, has_bias = ctx.cfg
+        x, weight, y = ctx.saved_tensors
+        stride, padding, transposed, output_padding, has_bias, ep = ctx.cfg
         kh, kw = int(weight.shape[2]), int(weight.shape[3])
         dx = dw = db = None
+        if ep is not None:
+            dy, db = _epilogue_backward(ctx, dy, y, ep, has_bias and ctx.needs_input_grad[2])
         if ctx.needs_input_grad[0] and native_input_gradients:
             dx = _input_gradient(dy, x.shape, weight, stride, padding, transposed, output_padding)
         want_w = ctx.needs_input_grad[1] and not weight_gradients_disabled
@@ -189,8 +231,8 @@ class _Conv2dMfma(torch.autograd.Function):
                 # y = conv_transpose2d(x, w[Cin, Cout]):  dw[ci, co, ky, kx] = sum x[ci, iy, ix] dy[co, s iy + ky - p, s ix + kx - p] -- the weight
                 # gradient of the strided convolution dy -> x, whose 'OIHW' kernel has O = Cin, I = Cout: the same kernel with the roles swapped
                 dw = conv2d_mfma.weight_gradient(dy, x, weight.shape, padding, stride=stride)
-        if want_b and (dw is not None or not want_w):
-            db = dy.sum(dim=[0, 2, 3])
+        if want_b and db is None and (dw is not None or not want_w):
+            db = bias_act.channel_sum(dy, 1)                 # one deterministic native pass (csrc/bias_act.hip)
         mask = [dx is None and ctx.needs_input_grad[0], want_w and dw is None, want_b and db is None]
         if any(mask):
             gx, gw, gb = torch.ops.aten.convolution_backward(
@@ -199,7 +241,7 @@ class _Conv2dMfma(torch.autograd.Function):
             dx = gx if mask[0] else dx
             dw = gw if mask[1] else dw
             db = gb if mask[2] else db
-        return dx, dw, db, None, None, None, None
+        return dx, dw, db, None, None, None, None, None
 
 
 class _Conv2dMfma16(torch.autograd.Function):
@@ -207,7 +249,7 @@ class _Conv2dMfma16(torch.autograd.Function):
     MFMA) when needed -- the fromrgb layers: 6 / 10 image channels.  Output: channels-last storage, x's dtype."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, padding, transposed, output_padding):
+    def forward(ctx, x, weight, bias, stride, padding, transposed, output_padding, ep=None):
         n, cin, h, w = x.shape
         kh, kw = int(weight.shape[2]), int(weight.shape[3])
         xp, wf = x, weight.detach().float()
@@ -219,21 +261,25 @@ class _Conv2dMfma16(torch.autograd.Function):
         if not transposed:
             cout = int(weight.shape[0])
             packed, _, _ = conv2d_mfma16.pack_weight(wf, x.dtype)
-            y = conv2d_mfma16.conv2d_forward(xp, packed, cout, kh, kw, stride=stride, pad=padding, bias=b32)
+            fz = dict(act=ep[0], alpha=ep[1], gain=ep[2], clamp=ep[3] if ep[3] >= 0 else None) if ep is not None else {}
+            y = conv2d_mfma16.conv2d_forward(xp, packed, cout, kh, kw, stride=stride, pad=padding, bias=b32, **fz)
         else:
+            assert ep is None
             cout = int(weight.shape[1])
             out_hw = ((h - 1) * stride - 2 * padding[0] + kh + output_padding[0], (w - 1) * stride - 2 * padding[1] + kw + output_padding[1])
             phases = conv2d_mfma16.pack_transposed(wf, x.dtype, stride, padding, (h, w), out_hw)
             y = conv2d_mfma16.conv_transpose2d_forward(xp, phases, cout, out_hw, stride=stride, bias=b32)
-        ctx.save_for_backward(x, weight)
-        ctx.cfg = (stride, padding, transposed, output_padding, bias is not None)
+        ctx.save_for_backward(x, weight, y if ep is not None else None)
+        ctx.cfg = (stride, padding, transposed, output_padding, bias is not None, ep)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, weight = ctx.saved_tensors
-        stride, padding, transposed, output_padding, has_bias = ctx.cfg
+        x, weight, y = ctx.saved_tensors
+        stride, padding, transposed, output_padding, has_bias, ep = ctx.cfg
         dx = dw = db = None
+        if ep is not None:
+            dy, db = _epilogue_backward(ctx, dy, y, ep, has_bias and ctx.needs_input_grad[2])
         if ctx.needs_input_grad[0]:
             dx = _input_gradient(dy, x.shape, weight, stride, padding, transposed, output_padding, fn=_Conv2dMfma16, mod=conv2d_mfma16)
         want_w = ctx.needs_input_grad[1] and not weight_gradients_disabled
@@ -248,7 +294,7 @@ class _Conv2dMfma16(torch.autograd.Function):
             dx = gx if need_x else dx
             dw = gw if need_w else dw
             db = gb if need_b else db
-        return dx, dw, db, None, None, None, None
+        return dx, dw, db, None, None, None, None, None
 
 
 def _input_gradient(dy, x_shape, weight, stride, padding, transposed, output_padding, fn=None, mod=None):

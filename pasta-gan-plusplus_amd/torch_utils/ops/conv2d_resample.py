@@ -22,6 +22,7 @@ import collections
 import torch
 
 from .. import misc
+from . import bias_act
 from . import conv2d_gradfix
 from . import upfirdn2d
 from .upfirdn2d import _get_filter_size
@@ -65,16 +66,34 @@ def _plan(kh, kw, fw, fh, up, down, padding):
     return _Plan('generic', pad, (0, 0))
 
 
-def _conv2d_wrapper(x, w, stride=1, padding=0, groups=1, transpose=False, flip_weight=True):
+def _conv2d_wrapper(x, w, stride=1, padding=0, groups=1, transpose=False, flip_weight=True, bias=None, epilogue=None):
     """Cross-correlation (flip_weight=True, what conv2d computes) or true convolution of x with w."""
     if not flip_weight:
         w = w.flip([2, 3])
-    op = conv2d_gradfix.conv_transpose2d if transpose else conv2d_gradfix.conv2d
-    return op(x, w, stride=stride, padding=padding, groups=groups)
+    if transpose:
+        assert bias is None and epilogue is None
+        return conv2d_gradfix.conv_transpose2d(x, w, stride=stride, padding=padding, groups=groups)
+    return conv2d_gradfix.conv2d(x, w, bias=bias, stride=stride, padding=padding, groups=groups, _epilogue=epilogue)
 
 
 @misc.profiled_function
-def conv2d_resample(x, w, f=None, up=1, down=1, padding=0, groups=1, flip_weight=True, flip_filter=False):
+def conv2d_resample(x, w, f=None, up=1, down=1, padding=0, groups=1, flip_weight=True, flip_filter=False, _epilogue=None):
+    """Signature of the reference (conv2d_resample.py:69).  `_epilogue` (private): dict(bias, act, alpha, gain, clamp) -- the `bias_act`
+    the calling layer applies to the result (networks.py:176-178); it is ALWAYS applied on return: inside the convolution launch where the
+    convolution is the last step of the route (plain, strided, point-wise down), as the separate op after the FIR otherwise."""
+    if _epilogue is not None:
+        ep = dict(_epilogue)
+        b = ep.pop('bias', None)
+        _, _, kh_, kw_ = _get_weight_shape(w)
+        route = _plan(kh_, kw_, *_get_filter_size(f), up, down, padding).route
+        if route in ('plain', 'strided', 'pointwise_down'):
+            return _conv2d_resample(x, w, f, up, down, padding, groups, flip_weight, flip_filter, bias=b, epilogue=ep)
+        y = _conv2d_resample(x, w, f, up, down, padding, groups, flip_weight, flip_filter)
+        return bias_act.bias_act(y, b, act=ep.get('act', 'linear'), alpha=ep.get('alpha'), gain=ep.get('gain'), clamp=ep.get('clamp'))
+    return _conv2d_resample(x, w, f, up, down, padding, groups, flip_weight, flip_filter)
+
+
+def _conv2d_resample(x, w, f, up, down, padding, groups, flip_weight, flip_filter, bias=None, epilogue=None):
     assert isinstance(x, torch.Tensor) and (x.ndim == 4)
     assert isinstance(w, torch.Tensor) and (w.ndim == 4) and (w.dtype == x.dtype)
     assert f is None or (isinstance(f, torch.Tensor) and f.ndim in [1, 2] and f.dtype == torch.float32)
@@ -85,10 +104,11 @@ def conv2d_resample(x, w, f=None, up=1, down=1, padding=0, groups=1, flip_weight
     fw, fh = _get_filter_size(f)
     plan = _plan(kh, kw, fw, fh, up, down, padding)
     fir = lambda t, **kw_: upfirdn2d.upfirdn2d(x=t, f=f, flip_filter=flip_filter, **kw_)
-    conv = lambda t, **kw_: _conv2d_wrapper(x=t, w=w, groups=groups, flip_weight=flip_weight, **kw_)
+    conv = lambda t, **kw_: _conv2d_wrapper(x=t, w=w, groups=groups, flip_weight=flip_weight, bias=bias, epilogue=epilogue, **kw_)
 
     if plan.route == 'pointwise_down':
         return conv(fir(x, down=down, padding=plan.fir_pad))
+    assert (bias is None and epilogue is None) or plan.route in ('plain', 'strided', 'pointwise_down')
     if plan.route == 'pointwise_up':
         return fir(conv(x), up=up, padding=plan.fir_pad, gain=up ** 2)
     if plan.route == 'strided':

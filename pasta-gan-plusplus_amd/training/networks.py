@@ -460,9 +460,9 @@ class Conv2dLayer(_ConvBase):
             x, x2 = torch.cat([x, x2], dim=1), None
         w = self.weight * self.weight_gain
         b = self.bias.to(x.dtype) if self.bias is not None else None
-        x = conv2d_resample.conv2d_resample(x=x, w=w.to(x.dtype), f=self.resample_filter, up=self.up, down=self.down,
-                                            padding=self.padding, flip_weight=(self.up == 1))
-        x = bias_act.bias_act(x, b, act=self.activation, gain=act_gain, clamp=act_clamp)
+        # conv2d_resample -> bias_act (networks.py:176-178); on the GPU the bias_act rides in the convolution's epilogue where that is the route's last step
+        x = conv2d_resample.conv2d_resample(x=x, w=w.to(x.dtype), f=self.resample_filter, up=self.up, down=self.down, padding=self.padding,
+                                            flip_weight=(self.up == 1), _epilogue=dict(bias=b, act=self.activation, gain=act_gain, clamp=act_clamp))
         return x if residual is None else residual.add_(x) if not _needs_graph(residual, x) else residual + x
 
     def _forward_fused(self, x, act_gain, act_clamp, residual, x2):

@@ -214,6 +214,77 @@ def test_bias_act_full_size_properties():
     assert float((y - ref.clamp(-256, 256)).abs().max()) < 1e-5
 
 
+@pytest.mark.parametrize('case', [
+    # name, shape, dim, dtype, channels_last, act, gain, clamp
+    ('nchw_lrelu',      [4, 64, 72, 72],  1, torch.float32, False, 'lrelu',  math.sqrt(2), 1.5),
+    ('nchw_big_plane',  [2, 16, 260, 252], 1, torch.float32, False, 'relu',   math.sqrt(2), -1),
+    ('nchw_tiny_plane', [4, 512, 4, 4],   1, torch.float32, False, 'lrelu',  1.0, -1),
+    ('nchw_linear_clamp', [3, 24, 20, 12], 1, torch.float32, False, 'linear', 0.7, 0.9),
+    ('fc',              [8, 512],         1, torch.float32, False, 'lrelu',  math.sqrt(2), -1),
+    ('cl_f16',          [4, 128, 32, 32], 1, torch.float16, True,  'lrelu',  math.sqrt(2), 256),
+    ('cl_bf16',         [2, 64, 24, 40],  1, torch.bfloat16, True, 'relu',   1.0, -1),
+    ('nchw_f16',        [2, 32, 48, 48],  1, torch.float16, False, 'lrelu',  math.sqrt(2), 256),
+])
+def test_bias_act_gradient_with_bias_gradient_in_one_pass(case):
+    """pg_bias_act_grad_bias: dx must equal the grad == 1 form bit for bit, db must be the sum of those stored values (fp64 sum as the
+    yardstick), identical from run to run; through autograd the bias gradient agrees with the oracle's composition."""
+    from torch_utils.ops import bias_act
+    from oracle import ops_ref as R
+    name, shape, dim, dt, cl, act, gain, clamp = case
+    fmt = torch.channels_last if cl else torch.contiguous_format
+    y = (det_tensor(f'gb.{name}.y', shape, scale=2.0).to(DEV).to(dt)).contiguous(memory_format=fmt) if len(shape) == 4 else det_tensor(f'gb.{name}.y', shape, scale=2.0).to(DEV).to(dt)
+    dy = (det_tensor(f'gb.{name}.dy', shape).to(DEV).to(dt)).contiguous(memory_format=fmt) if len(shape) == 4 else det_tensor(f'gb.{name}.dy', shape).to(DEV).to(dt)
+    spec = bias_act.activation_funcs[act]
+    alpha = spec.def_alpha
+    yref = y if (act != 'linear' or clamp >= 0) else None
+    two = bias_act._native_bias_act(dy, None, None, yref, None, 1, dim, spec.cuda_idx, alpha, gain, clamp)
+    out = bias_act._native_grad_bias(dy, yref, dim, act, alpha, gain, clamp)
+    assert out is not None, 'layout expected to be covered'
+    dx, db = out
+    assert torch.equal(dx, two) and dx.stride() == dy.stride()
+    axes = [i for i in range(len(shape)) if i != dim]
+    want = two.double().sum(axes)
+    scale = float(two.double().abs().sum(axes).max())
+    tol = 2e-6 * scale if dt == torch.float32 else (2e-3 if dt == torch.float16 else 1.6e-2) * max(float(want.abs().max()), 1e-3)
+    assert float((db.double() - want).abs().max()) <= tol
+    again = bias_act._native_grad_bias(dy, yref, dim, act, alpha, gain, clamp)[1]
+    assert torch.equal(db, again)
+    only = bias_act._native_grad_bias(dy, yref, dim, act, alpha, gain, clamp, write=False)
+    assert only[0] is None and torch.equal(only[1], db)
+    # through the op: x -> bias_act -> loss; db against the oracle (float32 cases)
+    if dt == torch.float32:
+        x = det_tensor(f'gb.{name}.x', shape, scale=2.0)
+        b = det_tensor(f'gb.{name}.b', [shape[dim]])
+        xr, br = x.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        R.bias_act(xr, br, dim=dim, act=act, gain=gain, clamp=clamp if clamp >= 0 else None).backward(dy.float().cpu())
+        xg, bg = x.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+        bias_act.bias_act(xg, bg, dim=dim, act=act, gain=gain, clamp=clamp if clamp >= 0 else None).backward(dy)
+        close(xg.grad, xr.grad, 3e-6, 3e-6)
+        close(bg.grad, br.grad, 2e-5, 2e-6 * scale)
+
+
+def test_bias_act_bias_gradient_uncovered_layouts_and_second_order():
+    from torch_utils.ops import bias_act
+    y = det_tensor('gbu.y', [2, 7, 33, 17]).to(DEV)
+    dy = det_tensor('gbu.dy', [2, 7, 33, 17]).to(DEV)
+    assert bias_act._native_grad_bias(dy, y, 1, 'lrelu', 0.2, 1.0, -1.0) is None            # plane of 561 floats: not a multiple of 16 bytes
+    assert bias_act._native_grad_bias(dy, y, 1, 'tanh', 0.0, 1.0, -1.0) is None             # derivative outside the fused set
+    assert torch.allclose(bias_act.channel_sum(dy, 1), dy.sum([0, 2, 3]), rtol=1e-5, atol=1e-5)   # composed instead
+    t = det_tensor('gbu.t', [3, 16, 8, 8]).to(DEV)
+    close(bias_act.channel_sum(t, 1), t.double().sum([0, 2, 3]).float(), 1e-5, 1e-5)
+    close(bias_act.channel_sum(t[:, :, ::2], 1), t[:, :, ::2].double().sum([0, 2, 3]).float(), 1e-5, 1e-5)      # a view: densified first
+    # db's own gradient (double backward through the two-output Function): d(db . v)/d(dy) = act'(y) gain v[c]
+    x = det_tensor('gbu.x', [2, 8, 4, 4]).to(DEV).requires_grad_(True)
+    b = det_tensor('gbu.b', [8]).to(DEV).requires_grad_(True)
+    dyy = det_tensor('gbu.dyy', [2, 8, 4, 4]).to(DEV).requires_grad_(True)
+    yy = bias_act.bias_act(x, b, act='lrelu')
+    gx, gb = torch.autograd.grad(yy, [x, b], dyy, create_graph=True)
+    v = det_tensor('gbu.v', [8]).to(DEV)
+    (g_dyy,) = torch.autograd.grad(gb, [dyy], v)
+    slope = torch.where(yy > 0, 1.0, 0.2) * math.sqrt(2)
+    close(g_dyy, (slope * v.view(1, -1, 1, 1)).detach(), 1e-6, 1e-6)
+
+
 # =============================================================== conv2d (MFMA implicit GEMM)
 
 CONV_CASES = [
@@ -1530,6 +1601,56 @@ def _native_backward_cases(conv2d_gradfix, gen):
         close(gx, rx, 1e-4, 1e-5 * scale_of(rx))
         close(gw, rw, 1e-4, 1e-5 * scale_of(rw))
         close(gb, rb, 1e-4, 1e-5 * scale_of(rb))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', [
+    # name, dtype, cin, cout, k, down, hw, act, clamp
+    ('f32_k3_lrelu', torch.float32, 64, 64, 3, 1, (40, 48), 'lrelu', 1.2),
+    ('f32_k3_wino4', torch.float32, 64, 64, 3, 1, (72, 72), 'lrelu', None),
+    ('f32_k3_down2', torch.float32, 32, 64, 3, 2, (32, 32), 'lrelu', 256),
+    ('f32_k1_down2', torch.float32, 32, 48, 1, 2, (24, 24), 'linear', None),
+    ('f32_k4_relu',  torch.float32, 16, 32, 4, 1, (20, 20), 'relu', None),
+    ('f16_k3_lrelu', torch.float16, 64, 64, 3, 1, (32, 32), 'lrelu', 256),
+    ('f16_k3_down2', torch.float16, 32, 64, 3, 2, (32, 32), 'lrelu', 256),
+])
+def test_conv_layer_training_route_epilogue_in_the_launch(case):
+    """Conv2dLayer on the training route (networks.py:170-179: conv2d_resample -> bias_act): with the bias_act in the convolution's epilogue
+    (conv2d_gradfix `_epilogue`, derivative from the saved output, db from the same pass) against the two-op composition of the same
+    kernels -- output, first-order gradients of x / weight / bias, and the R1-style second order d/dw of |dy/dx|^2."""
+    from training import networks as PN
+    from torch_utils.ops import conv2d_gradfix
+    name, dt, cin, cout, k, down, hw, act, clamp = case
+    layer = fill_module_(PN.Conv2dLayer(cin, cout, kernel_size=k, activation=act, down=down, conv_clamp=clamp), f'ep.{name}.').to(DEV).train()
+    with torch.no_grad():
+        layer.bias.copy_(det_tensor(f'ep.{name}.b', [cout]).to(DEV))
+    fmt = torch.channels_last if dt == torch.float16 else torch.contiguous_format
+    x0 = det_tensor(f'ep.{name}.x', [2, cin, *hw]).to(DEV).to(dt).contiguous(memory_format=fmt)
+
+    def run(fused):
+        was = conv2d_gradfix.fused_epilogue
+        conv2d_gradfix.fused_epilogue = fused
+        try:
+            x = x0.clone().requires_grad_(True)
+            y = layer(x, gain=0.7)
+            dy = det_tensor(f'ep.{name}.dy', list(y.shape)).to(DEV).to(dt)
+            gx, = torch.autograd.grad(y, [x], dy, create_graph=True)
+            pen = gx.float().square().sum()
+            g2 = torch.autograd.grad(pen, [layer.weight, layer.bias], allow_unused=True, retain_graph=True)
+            g1 = torch.autograd.grad(y, [layer.weight, layer.bias], dy)
+            return y, gx, g1, g2
+        finally:
+            conv2d_gradfix.fused_epilogue = was
+    ya, gxa, g1a, g2a = run(True)
+    yb, gxb, g1b, g2b = run(False)
+    tol = 2e-5 if dt == torch.float32 else 4e-3
+    close(ya, yb, tol, tol * scale_of(yb))
+    close(gxa, gxb, tol, tol * scale_of(gxb))
+    for a, b in zip(g1a + g2a, g1b + g2b):
+        if a is None or b is None:       # "no dependence": None on one route may be an all-zero tensor on the other
+            assert all(t is None or float(t.abs().max()) == 0.0 for t in (a, b))
+        else:
+            close(a, b, 10 * tol, 10 * tol * scale_of(b))
 
 
 @pytest.mark.gpu

@@ -292,6 +292,19 @@ int pg_instance_norm_stats(const float* x, float* mean, float* rstd, int NC, int
 int pg_spade_norm(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
                   float* y, int NC, int64_t HW, void* stream);
 
+/* The same combine on the TRAINING route, with its gradient (autograd of networks.py:1715-1723: instance norm, then x_hat (1 + gamma) + beta).
+ * x, y, dy, dx: [N, C, HW] contiguous.  gamma / beta (and dgamma / dbeta) may be planes of a larger tensor -- the two 3x3 convolutions that
+ * produce them run as one launch over the stacked weights, output [N, 2C, HW]: plane (n, c) starts at base + n * sample_stride + c * HW.
+ *   forward:   y = (x - mean) rstd (1 + gamma) + beta                      (mean / rstd from pg_instance_norm_stats)
+ *   backward:  dbeta = dy,  dgamma = dy x_hat,  g = dy (1 + gamma),  dx = rstd (g - mean_hw(g) - x_hat mean_hw(g x_hat))
+ * `sums`: 2 * N * C floats of scratch (the two plane means; fixed-order workgroup reductions: deterministic).  dx or the (dgamma, dbeta)
+ * pair may be NULL when not needed. */
+int pg_spade_train_forward(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, float* y,
+                           int N, int C, int64_t HW, int64_t gamma_sample_stride, int64_t beta_sample_stride, void* stream);
+int pg_spade_train_backward(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma, float* sums,
+                            float* dx, float* dgamma, float* dbeta, int N, int C, int64_t HW,
+                            int64_t gamma_sample_stride, int64_t dgamma_sample_stride, int64_t dbeta_sample_stride, void* stream);
+
 /* Garment-feature assembly of the synthesis network (get_spade_feat + the merge, networks.py:2253-2276, 2311-2316) in two
  * launches instead of ~60 elementwise ones.  feat_*: [N,C,H,W]; masks: [N,1,2H,2W], sampled at the even pixels; with
  *   m = mask > 0.9,  v = m && denorm_mask > 0.9,  r = m - v,  count[n] = sum_p v,  sums[n,c] = sum_p feat * v:

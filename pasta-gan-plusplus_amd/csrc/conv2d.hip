@@ -340,6 +340,73 @@ __global__ __launch_bounds__(256) void spade_norm_scalar_kernel(const float* __r
 }
 
 
+// ------------------------------------------------------------------ SPADE combine on the TRAINING route (networks.py:1715-1723 and its autograd)
+// gamma / beta are planes of one [N, 2C, H, W] tensor (the two 3x3 convolutions run as one launch over the stacked weights): plane (n, c)
+// of gamma starts at gamma + n*gs + c*HW.  Forward: y = xh (1 + gamma) + beta, xh = (x - mean) rstd.  Backward of that and of the instance
+// norm inside it, for upstream dy:   dbeta = dy,  dgamma = dy xh,  g = dy (1 + gamma),
+//     dx = rstd (g - mean_hw(g) - xh mean_hw(g xh))
+// kernel A: the two plane sums (one 1024-thread workgroup per plane, like the statistics pass); kernel B: everything elementwise.
+template <int VEC>
+__global__ __launch_bounds__(256) void spade_train_forward_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                  const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ y,
+                                                                  int C, int64_t HWV, int64_t totalV, int64_t gs, int64_t bs) {
+    typedef float V __attribute__((ext_vector_type(VEC)));
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < totalV; i += (int64_t)gridDim.x * 256) {
+        const int64_t plane = i / HWV, in = i - plane * HWV;
+        const int64_t n = plane / C, c = plane - n * C;
+        const float m = mean[plane], r = rstd[plane];
+        const V xv = ((const V*)x)[i];
+        const V g = ((const V*)(gamma + n * gs + c * HWV * VEC))[in], b = ((const V*)(beta + n * bs + c * HWV * VEC))[in];
+        ((V*)y)[i] = (xv - m) * r * (1.f + g) + b;
+    }
+}
+
+__global__ __launch_bounds__(IN_THREADS) void spade_train_sums_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean,
+                                                                     const float* __restrict__ rstd, const float* __restrict__ gamma, float* __restrict__ sums,
+                                                                     int C, int64_t HW, int64_t gs, int vec) {
+    __shared__ float red[IN_THREADS / 64];
+    const int64_t plane = blockIdx.x, n = plane / C, c = plane - n * C;
+    const float* dp = dy + plane * HW;
+    const float* xp = x + plane * HW;
+    const float* gp = gamma + n * gs + c * HW;
+    const float m = mean[plane], r = rstd[plane];
+    float s1 = 0.f, s2 = 0.f;
+    if (vec) {
+        const int64_t n4 = HW / 4;
+        for (int64_t i = threadIdx.x; i < n4; i += IN_THREADS) {
+            const f32x4 d = ((const f32x4*)dp)[i], xv = ((const f32x4*)xp)[i], g = ((const f32x4*)gp)[i];
+#pragma unroll
+            for (int k = 0; k < 4; k++) { const float gg = d[k] * (1.f + g[k]); s1 += gg; s2 += gg * ((xv[k] - m) * r); }
+        }
+    } else {
+        for (int64_t i = threadIdx.x; i < HW; i += IN_THREADS) { const float gg = dp[i] * (1.f + gp[i]); s1 += gg; s2 += gg * ((xp[i] - m) * r); }
+    }
+    const float S1 = block_sum_1024(s1, red), S2 = block_sum_1024(s2, red);
+    if (threadIdx.x == 0) { sums[2 * plane] = S1 / (float)HW; sums[2 * plane + 1] = S2 / (float)HW; }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void spade_train_backward_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean,
+                                                                   const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ sums,
+                                                                   float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                   int C, int64_t HWV, int64_t totalV, int64_t gs, int64_t dgs, int64_t dbs) {
+    typedef float V __attribute__((ext_vector_type(VEC)));
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < totalV; i += (int64_t)gridDim.x * 256) {
+        const int64_t plane = i / HWV, in = i - plane * HWV;
+        const int64_t n = plane / C, c = plane - n * C;
+        const float m = mean[plane], r = rstd[plane], a1 = sums[2 * plane], a2 = sums[2 * plane + 1];
+        const V d = ((const V*)dy)[i], xv = ((const V*)x)[i];
+        const V g = ((const V*)(gamma + n * gs + c * HWV * VEC))[in];
+        const V xh = (xv - m) * r;
+        if (dx) ((V*)dx)[i] = r * (d * (1.f + g) - a1 - xh * a2);
+        if (dgamma) {
+            ((V*)(dgamma + n * dgs + c * HWV * VEC))[in] = d * xh;
+            ((V*)(dbeta + n * dbs + c * HWV * VEC))[in] = d;
+        }
+    }
+}
+
+
 // ------------------------------------------------------------------ SPADE feature assembly (networks.py:2253-2276, 2311-2316)
 // Garment features of the upper / lower branch are inpainted where the predicted parsing mask exceeds the warped-garment
 // mask, then merged:  with m = (mask[2y,2x] > 0.9), v = m && (denorm_mask[2y,2x] > 0.9), r = m - v
@@ -877,6 +944,43 @@ PG_EXPORT int pg_spade_norm(const float* x, const float* mean, const float* rstd
         hipLaunchKernelGGL(spade_norm_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, mean, rstd, gamma, beta, y, HW / 4, total / 4);
     else
         hipLaunchKernelGGL(spade_norm_scalar_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, mean, rstd, gamma, beta, y, HW, total);
+    return pg::launch_status();
+}
+
+PG_EXPORT int pg_spade_train_forward(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, float* y,
+                                     int N, int C, int64_t HW, int64_t gamma_sample_stride, int64_t beta_sample_stride, void* stream) {
+    if (!x || !mean || !rstd || !gamma || !beta || !y || N <= 0 || C <= 0 || HW <= 0) return PG_ERR_INVALID_ARG;
+    const int64_t total = (int64_t)N * C * HW;
+    const bool vec = HW % 4 == 0 && gamma_sample_stride % 4 == 0 && beta_sample_stride % 4 == 0 && pg::aligned16(x) && pg::aligned16(gamma) && pg::aligned16(beta) && pg::aligned16(y);
+    int64_t blocks = ((vec ? total / 4 : total) + 255) / 256;
+    if (blocks > pg::max_stream_blocks()) blocks = pg::max_stream_blocks();
+    if (vec)
+        hipLaunchKernelGGL(spade_train_forward_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, mean, rstd, gamma, beta, y, C, HW / 4, total / 4,
+                           gamma_sample_stride, beta_sample_stride);
+    else
+        hipLaunchKernelGGL(spade_train_forward_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, mean, rstd, gamma, beta, y, C, HW, total,
+                           gamma_sample_stride, beta_sample_stride);
+    return pg::launch_status();
+}
+
+PG_EXPORT int pg_spade_train_backward(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma, float* sums,
+                                      float* dx, float* dgamma, float* dbeta, int N, int C, int64_t HW,
+                                      int64_t gamma_sample_stride, int64_t dgamma_sample_stride, int64_t dbeta_sample_stride, void* stream) {
+    if (!dy || !x || !mean || !rstd || !gamma || !sums || N <= 0 || C <= 0 || HW <= 0 || (!dgamma != !dbeta) || (!dx && !dgamma)) return PG_ERR_INVALID_ARG;
+    const int64_t total = (int64_t)N * C * HW;
+    const bool vec = HW % 4 == 0 && gamma_sample_stride % 4 == 0 && dgamma_sample_stride % 4 == 0 && dbeta_sample_stride % 4 == 0 && pg::aligned16(dy) && pg::aligned16(x) &&
+                     pg::aligned16(gamma) && (!dx || pg::aligned16(dx)) && (!dgamma || (pg::aligned16(dgamma) && pg::aligned16(dbeta)));
+    if (dx)
+        hipLaunchKernelGGL(spade_train_sums_kernel, dim3((unsigned)(N * C)), dim3(IN_THREADS), 0, (hipStream_t)stream, dy, x, mean, rstd, gamma, sums, C, HW,
+                           gamma_sample_stride, (int)vec);
+    int64_t blocks = ((vec ? total / 4 : total) + 255) / 256;
+    if (blocks > pg::max_stream_blocks()) blocks = pg::max_stream_blocks();
+    if (vec)
+        hipLaunchKernelGGL(spade_train_backward_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dy, x, mean, rstd, gamma, (const float*)sums, dx, dgamma, dbeta,
+                           C, HW / 4, total / 4, gamma_sample_stride, dgamma_sample_stride, dbeta_sample_stride);
+    else
+        hipLaunchKernelGGL(spade_train_backward_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dy, x, mean, rstd, gamma, (const float*)sums, dx, dgamma, dbeta,
+                           C, HW, total, gamma_sample_stride, dgamma_sample_stride, dbeta_sample_stride);
     return pg::launch_status();
 }
 

@@ -119,6 +119,10 @@ def _init(plugin_name='conv2d_plugin'):
         lib.pg_instance_norm_stats.argtypes = [vp, vp, vp, i, i64, f, vp]
         lib.pg_spade_norm.restype = i
         lib.pg_spade_norm.argtypes = [vp, vp, vp, vp, vp, vp, i, i64, vp]
+        lib.pg_spade_train_forward.restype = i
+        lib.pg_spade_train_forward.argtypes = [vp] * 6 + [i, i, i64, i64, i64, vp]
+        lib.pg_spade_train_backward.restype = i
+        lib.pg_spade_train_backward.argtypes = [vp] * 9 + [i, i, i64, i64, i64, i64, vp]
         lib.pg_conv2d_wgrad_plan.restype = i
         lib.pg_conv2d_wgrad_plan.argtypes = [i] * 8
         lib.pg_conv2d_wgrad.restype = i
@@ -431,6 +435,11 @@ def conv_transpose2d_forward(x, packed_phases, cout, out_hw, **fusion):
     return y
 
 
+def weight_gradient_supported(n, cin, oh, ow, cout, kh, kw, stride=1):
+    """True when `weight_gradient` covers this geometry (pg_conv2d_wgrad_plan > 0)."""
+    return _init().lib.pg_conv2d_wgrad_plan(int(n), int(cin), int(oh), int(ow), int(cout), int(kh), int(kw), int(stride)) > 0
+
+
 def weight_gradient(x, dy, weight_shape, pad, stride=1):
     """d(loss)/d(weight) of y = conv2d(x, w, stride, padding=pad) for 3x3 (stride 1 | 2) / 1x1 (stride 1) kernels: a GEMM over pixels
     on the fp32 MFMA (csrc/conv2d_wgrad.hip).  Returns None when the geometry is not covered (callers then ask aten)."""
@@ -610,6 +619,45 @@ def spade_norm(x, mean, rstd, gamma, beta):
         st = lib.pg_spade_norm(nat.ptr(x), nat.ptr(mean), nat.ptr(rstd), nat.ptr(gamma), nat.ptr(beta), nat.ptr(y), n * c, h * w, nat.stream_of(x))
     nat.check(st, 'pg_spade_norm')
     return y
+
+
+def _gamma_beta_planes(gb, c):
+    """[N, 2C, H, W] contiguous float32 -> (tensor, per-sample stride in floats, offset of the beta half in floats)."""
+    gb = _f32c(gb, 'gamma_beta')
+    assert gb.shape[1] == 2 * c
+    return gb, int(gb.stride(0)), int(gb.stride(1)) * c
+
+
+def spade_train_forward(x, mean, rstd, gamma_beta):
+    """Training route of the SPADE combine: y = (x - mean) rstd (1 + gamma) + beta with gamma = gamma_beta[:, :C], beta = gamma_beta[:, C:] read in
+    place (csrc/conv2d.hip, pg_spade_train_forward)."""
+    lib = _init().lib
+    x = _f32c(x, 'x')
+    n, c, h, w = x.shape
+    gb, gs, off = _gamma_beta_planes(gamma_beta, c)
+    y = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        st = lib.pg_spade_train_forward(nat.ptr(x), nat.ptr(mean), nat.ptr(rstd), gb.data_ptr(), gb.data_ptr() + 4 * off, nat.ptr(y), n, c, h * w, gs, gs, nat.stream_of(x))
+    nat.check(st, 'pg_spade_train_forward')
+    return y
+
+
+def spade_train_backward(dy, x, mean, rstd, gamma_beta, need_dx=True, need_dgb=True):
+    """Gradient of `spade_train_forward` (and of the instance norm inside it) for upstream dy: (dx, d_gamma_beta), either None when not needed.
+    Two launches: the plane means of g = dy (1 + gamma) and g x_hat, then one elementwise pass writing dx, dgamma = dy x_hat and dbeta = dy."""
+    lib = _init().lib
+    x, dy = _f32c(x, 'x'), _f32c(dy, 'dy')
+    n, c, h, w = x.shape
+    gb, gs, off = _gamma_beta_planes(gamma_beta, c)
+    sums = torch.empty([2 * n * c], dtype=torch.float32, device=x.device)
+    dx = torch.empty_like(x) if need_dx else None
+    dgb = torch.empty_like(gb) if need_dgb else None
+    with torch.cuda.device(x.device):
+        st = lib.pg_spade_train_backward(nat.ptr(dy), nat.ptr(x), nat.ptr(mean), nat.ptr(rstd), gb.data_ptr(), nat.ptr(sums), nat.ptr(dx),
+                                         dgb.data_ptr() if need_dgb else None, dgb.data_ptr() + 4 * off if need_dgb else None,
+                                         n, c, h * w, gs, gs, gs, nat.stream_of(x))
+    nat.check(st, 'pg_spade_train_backward')
+    return dx, dgb
 
 
 def spade_feat_assemble(feat_upper, feat_lower, mask_upper, mask_lower, denorm_mask_upper, denorm_mask_lower):

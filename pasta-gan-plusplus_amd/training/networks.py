@@ -27,6 +27,7 @@ import torch.nn as nn
 from torch_utils import misc
 from torch_utils.ops import _native as nat
 from torch_utils.ops import bias_act
+from torch_utils.ops import conv2d_gradfix
 from torch_utils.ops import conv2d_mfma
 from torch_utils.ops import conv2d_mfma16
 from torch_utils.ops import conv2d_resample
@@ -110,6 +111,8 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, res
         out = _modconv_fast16(x, weight, styles, noise, up, padding, resample_filter, demodulate, flip_weight, _cache, _epilogue)
         if out is not None:
             return out
+    if plain_geometry and up == 1 and flip_weight and _train_fused_ok(x, weight, styles, noise, padding):
+        return _modconv_train(x, weight, styles, noise, padding, demodulate, _epilogue)
     y = _modconv_graph(x, weight, styles, noise, up, down, padding, resample_filter, demodulate, flip_weight, fused_modconv)
     if _epilogue:                # the native layer declined (uncovered geometry): compose the tail from the ops
         ep = dict(_epilogue)
@@ -345,6 +348,113 @@ def _modconv_fast16(x, weight, styles, noise, up, padding, resample_filter, demo
     return fused if res is None else fused.add_(res)
 
 
+fused_training_modconv = os.environ.get('PG_TRAIN_MODCONV', '1') != '0'    # False / PG_TRAIN_MODCONV=0: the differentiable composition (any order of derivative)
+
+
+def _train_fused_ok(x, weight, styles, noise, padding):
+    """The training-route modulated convolution as native launches: float32 GPU tensors, stride 1, images of >= 32 x 32 (below that the
+    per-sample weight gradients cost more than the elementwise passes they replace), a geometry the weight-gradient kernel covers."""
+    if not (fused_training_modconv and x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and styles.dtype == torch.float32):
+        return False
+    if not (torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (x, weight, styles, noise))):
+        return False
+    cout, cin, kh, kw = (int(v) for v in weight.shape)
+    n, _, h, w = x.shape
+    if h * w < 32 * 32 or not conv2d_mfma.supported(kh, kw, 1) or kh - 1 - padding < 0:
+        return False
+    oh, ow = h + 2 * padding - kh + 1, w + 2 * padding - kw + 1
+    if noise is not None and (noise.dtype != torch.float32 or noise.numel() not in (oh * ow, n * oh * ow)):
+        return False
+    return oh == h and ow == w and conv2d_mfma.weight_gradient_supported(1, cin, oh, ow, cout, kh, kw, 1)
+
+
+def _modconv_train(x, weight, styles, noise, padding, demodulate, epilogue):
+    """modulated_conv2d (up = 1) + the layer's bias_act on the training route.  The demodulation coefficients stay torch ops on the
+    [N, O, I, k, k] products (small next to the activations; autograd differentiates them); everything that touches activations is
+    `_ModConvTrain`."""
+    n = x.shape[0]
+    dcoefs = None
+    if demodulate:
+        dcoefs = ((weight.unsqueeze(0) * styles.reshape(n, 1, -1, 1, 1)).square().sum(dim=[2, 3, 4]) + 1e-8).rsqrt()
+    ep = dict(epilogue) if epilogue else {}
+    res = ep.pop('residual', None)
+    cfg = conv2d_gradfix._epilogue_cfg(ep)
+    if cfg is not None and cfg[0] not in conv2d_mfma.FUSED_ACTS:
+        cfg, tail = None, ep
+    else:
+        tail = None
+    bias = ep.get('bias') if tail is None else None
+    y = _ModConvTrain.apply(x, weight, styles, dcoefs, noise, bias, int(padding), cfg)
+    if tail is not None:
+        b = tail.get('bias')
+        y = bias_act.bias_act(y, b.to(y.dtype) if b is not None else None, act=tail.get('act', 'linear'), alpha=tail.get('alpha'), gain=tail.get('gain', 1.0), clamp=tail.get('clamp'))
+    return y if res is None else y + res.to(y.dtype)
+
+
+class _ModConvTrain(torch.autograd.Function):
+    """y = bias_act(conv2d(x * s, w) * d + noise + b) with per-sample s [N, I] and d [N, O] (networks.py:73-82, the non-fused form the
+    reference trains with, plus the layer's bias_act :176-178) as ONE forward launch, and its first-order gradient as native launches:
+
+        dpre, db = bias_act'(dy; y)                         one pass (pg_bias_act_grad_bias)
+        dx       = conv2d(dpre * d, w^T flipped) * s         one launch (the scales ride as in_scale / out_scale)
+        H_n      = weight gradient of sample n for (x_n, dpre_n), UNSCALED operands -> [N, O, I, k, k]  (N launches of pg_conv2d_wgrad)
+        dw = sum_n d_n s_n H_n    ds_n = sum_{o,k} w d_n H_n    dd_n = sum_{i,k} w s_n H_n        (small tensor ops)
+
+    -- the reference's graph spends ~23 traversals of the activation tensors on the same quantities (x*s, fma, their products and
+    plane sums in backward).  Second-order requests are refused loudly (set networks.fused_training_modconv = False for them)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, styles, dcoefs, noise, bias, padding, ep):
+        x, styles = x.contiguous(), styles.contiguous()
+        dcoefs = dcoefs.contiguous() if dcoefs is not None else None
+        cout, cin, kh, kw = (int(v) for v in weight.shape)
+        fz = dict(act=ep[0], alpha=ep[1], gain=ep[2], clamp=ep[3] if ep[3] >= 0 else None) if ep is not None else {}
+        wg = conv2d_mfma.use_winograd(kh, kw, 1, cout, cin, pad=(padding, padding), hw=x.shape[2:], ep=fz)
+        y = conv2d_mfma.conv2d_forward(x, conv2d_gradfix._packed(weight, wg), cout, kh, kw, stride=1, pad=(padding, padding), in_scale=styles,
+                                       out_scale=dcoefs, noise=noise, bias=bias, winograd=wg, **fz)
+        ctx.save_for_backward(x, weight, styles, dcoefs, y if ep is not None else None)
+        ctx.cfg = (padding, ep, tuple(noise.shape) if noise is not None else None, bias is not None)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        x, weight, styles, dcoefs, y = ctx.saved_tensors
+        padding, ep, noise_shape, has_bias = ctx.cfg
+        cout, cin, kh, kw = (int(v) for v in weight.shape)
+        n = x.shape[0]
+        need_x, need_w, need_s, need_d, need_noise, need_b = ctx.needs_input_grad[:6]
+        dy = dy.contiguous()
+        db = None
+        if ep is not None:
+            if has_bias and need_b:
+                dy, db = bias_act._BiasActGrad.apply(dy, None, None, y, 1, ep[0], ep[1], ep[2], ep[3], True)
+            else:
+                dy = bias_act._BiasActGrad.apply(dy, None, None, y, 1, ep[0], ep[1], ep[2], ep[3])
+        elif has_bias and need_b:
+            db = bias_act.channel_sum(dy, 1)
+        dnoise = dy.sum_to_size(noise_shape) if (need_noise and noise_shape is not None) else None
+        dx = None
+        if need_x:
+            py, px = kh - 1 - padding, kw - 1 - padding
+            wg = conv2d_mfma.use_winograd(kh, kw, 1, cin, cout, pad=(py, px), hw=dy.shape[2:])
+            dx = conv2d_mfma.conv2d_forward(dy, conv2d_gradfix._packed(weight, wg, flip=True, transpose_oi=True), cin, kh, kw, stride=1, pad=(py, px),
+                                            in_scale=dcoefs, out_scale=styles, winograd=wg)
+        dw = ds = dd = None
+        if (need_w and not conv2d_gradfix.weight_gradients_disabled) or need_s or need_d:
+            per = torch.stack([conv2d_mfma.weight_gradient(x[i:i + 1], dy[i:i + 1], weight.shape, (padding, padding), stride=1) for i in range(n)])   # [N, O, I, k, k]
+            d1 = dcoefs if dcoefs is not None else torch.ones([n, cout], dtype=per.dtype, device=per.device)
+            if need_w and not conv2d_gradfix.weight_gradients_disabled:
+                dw = (per * (d1.unsqueeze(2) * styles.unsqueeze(1))[:, :, :, None, None]).sum(dim=0)
+            if need_s or need_d:
+                m = (per * weight.unsqueeze(0)).sum(dim=[3, 4])                  # [N, O, I]
+                if need_s:
+                    ds = (m * d1.unsqueeze(2)).sum(dim=1)
+                if need_d and dcoefs is not None:
+                    dd = (m * styles.unsqueeze(1)).sum(dim=2)
+        return dx, dw, ds, dd, dnoise, db, None, None
+
+
 def _modconv_graph(x, weight, styles, noise, up, down, padding, resample_filter, demodulate, flip_weight, fused_modconv):
     """Differentiable composition (the two forms of networks.py:61-94)."""
     n = x.shape[0]
@@ -546,12 +656,37 @@ class Spade_Conv2dLayer(_ConvBase):
         b = self.bias.to(x.dtype) if self.bias is not None else None
         if not no_act:
             x = bias_act.bias_act(x, b, act=self.activation, gain=act_gain, clamp=act_clamp)
-        x = conv2d_resample.conv2d_resample(x=x, w=w.to(x.dtype), f=self.resample_filter, up=self.up, down=self.down,
-                                            padding=self.padding, flip_weight=(self.up == 1))
-        if post_act != 'linear':
-            x = bias_act.bias_act(x, act=post_act, gain=1)
+        x = conv2d_resample.conv2d_resample(x=x, w=w.to(x.dtype), f=self.resample_filter, up=self.up, down=self.down, padding=self.padding,
+                                            flip_weight=(self.up == 1), _epilogue=(dict(act=post_act, gain=1) if post_act != 'linear' else None))
         x = x if residual is None else residual + x
         return x if stats_eps is None else (x, conv2d_mfma.instance_norm_stats(x, eps=stats_eps))
+
+
+class _SpadeCombine(torch.autograd.Function):
+    """Training route of `normalized * (1 + gamma) + beta` with `normalized = InstanceNorm2d(affine=False)(x)` (networks.py:1715-1723) and its
+    gradient as native passes (csrc/conv2d.hip, pg_spade_train_*): statistics + combine forward; two plane means + one elementwise pass backward
+    (dx through the instance norm included) instead of the ~25 tensor traversals of the composed autograd graph.  `gamma_beta`: [N, 2C, H, W],
+    gamma = the first C channels.  Higher-order requests differentiate the composition instead."""
+
+    @staticmethod
+    def forward(ctx, x, gamma_beta, eps):
+        x, gb = x.contiguous(), gamma_beta.contiguous()
+        mean, rstd = conv2d_mfma.instance_norm_stats(x, eps=eps)
+        ctx.save_for_backward(x, gb, mean, rstd)
+        ctx.eps = eps
+        return conv2d_mfma.spade_train_forward(x, mean, rstd, gb)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gb, mean, rstd = ctx.saved_tensors
+        if torch.is_grad_enabled() and any(t.requires_grad for t in (dy, x, gb)):
+            with torch.enable_grad():
+                c = x.shape[1]
+                y = torch.nn.functional.instance_norm(x, eps=ctx.eps) * (1 + gb[:, :c]) + gb[:, c:]
+                gx, ggb = torch.autograd.grad(y, [x, gb], dy, create_graph=True, allow_unused=True)
+            return gx, ggb, None
+        dx, dgb = conv2d_mfma.spade_train_backward(dy, x, mean, rstd, gb, need_dx=ctx.needs_input_grad[0], need_dgb=ctx.needs_input_grad[1])
+        return dx, dgb, None
 
 
 class Spade_Norm_Block(nn.Module):
@@ -589,6 +724,15 @@ class Spade_Norm_Block(nn.Module):
             y = conv2d_mfma.spade_norm(x, mean, rstd, gamma, beta)
             return bias_act.bias_act(y, act=post['act'], alpha=post['alpha'], gain=post['gain'], clamp=post['clamp']) if post else y
         assert post is None and stats is None
+        g, b = self.conv_gamma, self.conv_beta
+        if (x.is_cuda and x.dtype == torch.float32 and denorm_feats.dtype == torch.float32 and os.environ.get('PG_TRAIN_SPADE', '1') != '0'
+                and all(l.bias is None and l.up == 1 and l.down == 1 for l in (g, b)) and g.weight.shape == b.weight.shape):
+            # training route on the GPU: conv + ReLU in one launch, the gamma and beta convolutions as ONE convolution over the stacked
+            # weights (they share `actv`: one input gradient instead of two and their sum), instance norm + combine as _SpadeCombine
+            actv = self.conv_mlp(denorm_feats, no_act=True, post_act='relu')
+            w = torch.cat([g.weight * g.weight_gain, b.weight * b.weight_gain], dim=0)
+            gb = conv2d_resample.conv2d_resample(x=actv, w=w, f=g.resample_filter, padding=g.padding, flip_weight=True)
+            return _SpadeCombine.apply(x, gb, self.param_free_norm.eps)
         normalized = self.param_free_norm(x)
         actv = self.conv_mlp_act(self.conv_mlp(denorm_feats, no_act=True))
         gamma = self.conv_gamma(actv, no_act=True)
@@ -662,7 +806,8 @@ class SynthesisLayer(nn.Module):
                 noise = self._cache.get(('noise',), [self.noise_const, self.noise_strength], lambda: (self.noise_const * self.noise_strength).detach())
         act_gain = self.act_gain * gain
         act_clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
-        fusable = _fast_ok(x, self.weight, self.bias, styles, noise) or _fast16_ok(x, self.weight, self.bias, styles, noise)
+        fusable = (_fast_ok(x, self.weight, self.bias, styles, noise) or _fast16_ok(x, self.weight, self.bias, styles, noise)
+                   or (self.up == 1 and _train_fused_ok(x, self.weight, styles, noise, self.padding)))
         if fusable and self.activation in conv2d_mfma.FUSED_ACTS:
             ep = dict(bias=self.bias, act=self.activation, alpha=bias_act.activation_funcs[self.activation].def_alpha, gain=act_gain, clamp=act_clamp)
             return modulated_conv2d(x=x, weight=self.weight, styles=styles, noise=noise, up=self.up, padding=self.padding,
@@ -713,6 +858,9 @@ class _ToRGBBase(nn.Module):
             if fast:
                 pred_parsing = modulated_conv2d(x=x, weight=self.m_weight1, styles=styles, demodulate=False, fused_modconv=fused_modconv,
                                                 _cache=self._cache_p, _epilogue=dict(bias=self.m_bias1, clamp=self.conv_clamp))
+            elif _train_fused_ok(x, self.m_weight1, styles, None, 0):
+                pred_parsing = modulated_conv2d(x=x, weight=self.m_weight1, styles=styles, demodulate=False, fused_modconv=fused_modconv,
+                                                _epilogue=dict(bias=self.m_bias1, clamp=self.conv_clamp))
             else:
                 pred_parsing = modulated_conv2d(x=x, weight=self.m_weight1, styles=styles, demodulate=False, fused_modconv=fused_modconv)
                 pred_parsing = bias_act.bias_act(pred_parsing, self.m_bias1.to(x.dtype), clamp=self.conv_clamp)
@@ -720,8 +868,12 @@ class _ToRGBBase(nn.Module):
             y = modulated_conv2d(x=x, weight=self.weight, styles=styles, demodulate=False, fused_modconv=fused_modconv,
                                  _cache=self._cache, _epilogue=dict(bias=self.bias, clamp=self.conv_clamp, residual=skip_img))
             return y, pred_parsing
-        y = modulated_conv2d(x=x, weight=self.weight, styles=styles, demodulate=False, fused_modconv=fused_modconv)
-        y = bias_act.bias_act(y, self.bias.to(x.dtype), clamp=self.conv_clamp)
+        if _train_fused_ok(x, self.weight, styles, None, 0):     # training route: bias + clamp inside the launch
+            y = modulated_conv2d(x=x, weight=self.weight, styles=styles, demodulate=False, fused_modconv=fused_modconv,
+                                 _epilogue=dict(bias=self.bias, clamp=self.conv_clamp))
+        else:
+            y = modulated_conv2d(x=x, weight=self.weight, styles=styles, demodulate=False, fused_modconv=fused_modconv)
+            y = bias_act.bias_act(y, self.bias.to(x.dtype), clamp=self.conv_clamp)
         if skip_img is not None:
             y = skip_img + y
         return y, pred_parsing

@@ -1604,6 +1604,96 @@ def _native_backward_cases(conv2d_gradfix, gen):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('case', [('conv3', 64, 64, 64, 3), ('conv3_wide', 128, 96, 32, 3), ('torgb', 64, 3, 64, 1)])
+def test_modulated_conv_training_route_native_vs_graph(case):
+    """_ModConvTrain (one forward launch; backward = bias_act' + db pass, input gradient with the scales riding in the launch, per-sample
+    weight gradients folded into dw / dstyles / ddcoefs) against the differentiable composition of the same layer (the route the oracle
+    comparison of the whole generator has pinned): output and the gradients of x, w, every parameter.  A double-backward request is refused."""
+    from training import networks as PN
+    name, cin, cout, res, k = case
+    torch.manual_seed(3)
+    if k == 3:
+        layer = PN.SynthesisLayer(cin, cout, w_dim=64, resolution=res, conv_clamp=256).to(DEV).train()
+        with torch.no_grad():
+            layer.noise_strength.fill_(0.3)
+            layer.bias.copy_(det_tensor(f'mt.{name}.b', [cout]).to(DEV))
+        call = lambda x, w: layer(x, w, noise_mode='const', fused_modconv=False, gain=0.8)
+    else:
+        layer = PN.ToRGBLayerFull_v1_v5(cin, cout, w_dim=64, conv_clamp=256, is_last=True, is_style=True).to(DEV).train()
+        with torch.no_grad():
+            layer.bias.copy_(det_tensor(f'mt.{name}.b', [cout]).to(DEV))
+        def call(x, w):
+            rgb, parsing = layer(x, w, fused_modconv=False)
+            return torch.cat([rgb, parsing], dim=1)
+    x0 = det_tensor(f'mt.{name}.x', [3, cin, res, res]).to(DEV)
+    w0 = det_tensor(f'mt.{name}.w', [3, 64]).to(DEV)
+    params = [p for p in layer.parameters()]
+
+    def run(fused):
+        was = PN.fused_training_modconv
+        PN.fused_training_modconv = fused
+        try:
+            x, w = x0.clone().requires_grad_(True), w0.clone().requires_grad_(True)
+            y = call(x, w)
+            dy = det_tensor(f'mt.{name}.dy', list(y.shape)).to(DEV)
+            return y, torch.autograd.grad(y, [x, w] + params, dy, allow_unused=True), (x, y)
+        finally:
+            PN.fused_training_modconv = was
+    ya, ga, (xa, yya) = run(True)
+    yb, gb, _ = run(False)
+    close(ya, yb, 2e-5, 2e-5 * scale_of(yb))
+    assert len(ga) == len(gb)
+    for a, b in zip(ga, gb):
+        assert (a is None) == (b is None)
+        if a is not None:
+            close(a, b, 2e-4, 3e-5 * scale_of(b))
+    was = PN.fused_training_modconv
+    PN.fused_training_modconv = True
+    try:
+        x = x0.clone().requires_grad_(True)
+        g, = torch.autograd.grad(call(x, w0).sum(), [x], create_graph=True)
+        with pytest.raises(RuntimeError):
+            g.square().sum().backward()
+    finally:
+        PN.fused_training_modconv = was
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [[2, 32, 40, 36], [1, 5, 7, 9], [4, 128, 64, 64]])
+def test_spade_combine_training_route_vs_float64_autograd(shape):
+    """_SpadeCombine (instance norm -> x_hat (1 + gamma) + beta, networks.py:1715-1723) forward and gradient -- dx through the norm, dgamma, dbeta --
+    against float64 autograd of the composed expression; a second run is bit-identical; a create_graph request differentiates the composition."""
+    from training import networks as PN
+    n, c, h, w = shape
+    x = det_tensor(f'sc.{shape}.x', shape, scale=2.0) + 0.5
+    gb = det_tensor(f'sc.{shape}.gb', [n, 2 * c, h, w])
+    dy = det_tensor(f'sc.{shape}.dy', shape)
+    x64, gb64 = x.double().requires_grad_(True), gb.double().requires_grad_(True)
+    y64 = torch.nn.functional.instance_norm(x64, eps=1e-5) * (1 + gb64[:, :c]) + gb64[:, c:]
+    rx, rgb = torch.autograd.grad(y64, [x64, gb64], dy.double())
+    xd, gbd = x.to(DEV).requires_grad_(True), gb.to(DEV).requires_grad_(True)
+    y = PN._SpadeCombine.apply(xd, gbd, 1e-5)
+    gx, ggb = torch.autograd.grad(y, [xd, gbd], dy.to(DEV))
+    close(y, y64, 2e-5, 2e-5 * scale_of(y64))
+    close(gx, rx, 1e-4, 2e-5 * scale_of(rx))
+    close(ggb, rgb, 2e-5, 2e-5 * scale_of(rgb))
+    y2 = PN._SpadeCombine.apply(xd, gbd, 1e-5)
+    gx2, ggb2 = torch.autograd.grad(y2, [xd, gbd], dy.to(DEV))
+    assert torch.equal(y, y2) and torch.equal(gx, gx2) and torch.equal(ggb, ggb2)
+    # only one of the two gradients requested
+    only_x, = torch.autograd.grad(PN._SpadeCombine.apply(xd, gbd.detach(), 1e-5), [xd], dy.to(DEV))
+    assert torch.equal(only_x, gx)
+    only_gb, = torch.autograd.grad(PN._SpadeCombine.apply(xd.detach(), gbd, 1e-5), [gbd], dy.to(DEV))
+    assert torch.equal(only_gb, ggb)
+    if n * c * h * w < 1e5:     # second order through the fall-back composition
+        g1, = torch.autograd.grad(PN._SpadeCombine.apply(xd, gbd, 1e-5), [xd], dy.to(DEV), create_graph=True)
+        g2, = torch.autograd.grad(g1.square().sum(), [gbd])
+        r1, = torch.autograd.grad(torch.nn.functional.instance_norm(x64, eps=1e-5) * (1 + gb64[:, :c]) + gb64[:, c:], [x64], dy.double(), create_graph=True)
+        r2, = torch.autograd.grad(r1.square().sum(), [gb64])
+        close(g2, r2, 1e-3, 1e-4 * scale_of(r2))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('case', [
     # name, dtype, cin, cout, k, down, hw, act, clamp
     ('f32_k3_lrelu', torch.float32, 64, 64, 3, 1, (40, 48), 'lrelu', 1.2),

@@ -113,6 +113,8 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, res
             return out
     if plain_geometry and up == 1 and flip_weight and _train_fused_ok(x, weight, styles, noise, padding):
         return _modconv_train(x, weight, styles, noise, padding, demodulate, _epilogue)
+    if plain_geometry and up == 2 and not flip_weight and _train_fused_up2_ok(x, weight, styles, noise, padding, resample_filter):
+        return _modconv_train(x, weight, styles, noise, padding, demodulate, _epilogue, up2_filter=resample_filter)
     y = _modconv_graph(x, weight, styles, noise, up, down, padding, resample_filter, demodulate, flip_weight, fused_modconv)
     if _epilogue:                # the native layer declined (uncovered geometry): compose the tail from the ops
         ep = dict(_epilogue)
@@ -368,8 +370,29 @@ def _train_fused_ok(x, weight, styles, noise, padding):
     return oh == h and ow == w and conv2d_mfma.weight_gradient_supported(1, cin, oh, ow, cout, kh, kw, 1)
 
 
-def _modconv_train(x, weight, styles, noise, padding, demodulate, epilogue):
-    """modulated_conv2d (up = 1) + the layer's bias_act on the training route.  The demodulation coefficients stay torch ops on the
+def _train_fused_up2_ok(x, weight, styles, noise, padding, resample_filter):
+    """The up = 2 layer (stride-2 transposed 3x3 convolution, 4x4 FIR, noise, bias_act) on the training route as native launches: the geometry
+    of the one-launch transposed kernel (csrc/conv2d_up2.h), input images of >= 32 x 32, per-sample weight gradients covered."""
+    if not (fused_training_modconv and x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and styles.dtype == torch.float32):
+        return False
+    if not (torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (x, weight, styles, noise))):
+        return False
+    cout, cin, kh, kw = (int(v) for v in weight.shape)
+    n, _, h, w = x.shape
+    if (kh, kw) != (3, 3) or h * w < 32 * 32 or resample_filter is None or resample_filter.ndim != 2:
+        return False
+    fw, fh = upfirdn2d._get_filter_size(resample_filter)
+    tpad, fir_pad = _up2_geometry(kh, kw, fw, fh, padding)
+    oh, ow = 2 * h + 1 + fir_pad[2] + fir_pad[3] - fh + 1, 2 * w + 1 + fir_pad[0] + fir_pad[1] - fw + 1
+    if tuple(tpad) != (0, 0) or min(fir_pad) < 0 or (oh, ow) != (2 * h, 2 * w):
+        return False
+    if noise is not None and (noise.dtype != torch.float32 or noise.numel() not in (oh * ow, n * oh * ow)):
+        return False
+    return conv2d_mfma.weight_gradient_supported(1, cout, h, w, cin, 3, 3, 2)      # dz -> x: a stride-2 convolution with O = Cin, I = Cout
+
+
+def _modconv_train(x, weight, styles, noise, padding, demodulate, epilogue, up2_filter=None):
+    """modulated_conv2d (up = 1, or up = 2 with `up2_filter`) + the layer's bias_act on the training route.  The demodulation coefficients stay torch ops on the
     [N, O, I, k, k] products (small next to the activations; autograd differentiates them); everything that touches activations is
     `_ModConvTrain`."""
     n = x.shape[0]
@@ -384,7 +407,10 @@ def _modconv_train(x, weight, styles, noise, padding, demodulate, epilogue):
     else:
         tail = None
     bias = ep.get('bias') if tail is None else None
-    y = _ModConvTrain.apply(x, weight, styles, dcoefs, noise, bias, int(padding), cfg)
+    if up2_filter is not None:
+        y = _ModConvUp2Train.apply(x, weight, styles, dcoefs, noise, bias, up2_filter, int(padding), cfg)
+    else:
+        y = _ModConvTrain.apply(x, weight, styles, dcoefs, noise, bias, int(padding), cfg)
     if tail is not None:
         b = tail.get('bias')
         y = bias_act.bias_act(y, b.to(y.dtype) if b is not None else None, act=tail.get('act', 'linear'), alpha=tail.get('alpha'), gain=tail.get('gain', 1.0), clamp=tail.get('clamp'))
@@ -443,16 +469,87 @@ class _ModConvTrain(torch.autograd.Function):
         dw = ds = dd = None
         if (need_w and not conv2d_gradfix.weight_gradients_disabled) or need_s or need_d:
             per = torch.stack([conv2d_mfma.weight_gradient(x[i:i + 1], dy[i:i + 1], weight.shape, (padding, padding), stride=1) for i in range(n)])   # [N, O, I, k, k]
-            d1 = dcoefs if dcoefs is not None else torch.ones([n, cout], dtype=per.dtype, device=per.device)
-            if need_w and not conv2d_gradfix.weight_gradients_disabled:
-                dw = (per * (d1.unsqueeze(2) * styles.unsqueeze(1))[:, :, :, None, None]).sum(dim=0)
-            if need_s or need_d:
-                m = (per * weight.unsqueeze(0)).sum(dim=[3, 4])                  # [N, O, I]
-                if need_s:
-                    ds = (m * d1.unsqueeze(2)).sum(dim=1)
-                if need_d and dcoefs is not None:
-                    dd = (m * styles.unsqueeze(1)).sum(dim=2)
+            dw, ds, dd = _fold_per_sample(per, weight, styles, dcoefs, need_w and not conv2d_gradfix.weight_gradients_disabled, need_s, need_d)
         return dx, dw, ds, dd, dnoise, db, None, None
+
+
+def _fold_per_sample(per, weight, styles, dcoefs, need_w, need_s, need_d):
+    """Per-sample weight gradients H_n [N, O, I, k, k] for UNSCALED operands -> (dw, dstyles, ddcoefs) of y_n = d_n conv(x_n s_n, w):
+    dw = sum_n d_n s_n H_n,  ds_n[i] = sum_{o,k} w d_n H_n,  dd_n[o] = sum_{i,k} w s_n H_n."""
+    n, cout = per.shape[0], per.shape[1]
+    d1 = dcoefs if dcoefs is not None else torch.ones([n, cout], dtype=per.dtype, device=per.device)
+    dw = ds = dd = None
+    if need_w:
+        dw = (per * (d1.unsqueeze(2) * styles.unsqueeze(1))[:, :, :, None, None]).sum(dim=0)
+    if need_s or need_d:
+        m = (per * weight.unsqueeze(0)).sum(dim=[3, 4])                  # [N, O, I]
+        if need_s:
+            ds = (m * d1.unsqueeze(2)).sum(dim=1)
+        if need_d and dcoefs is not None:
+            dd = (m * styles.unsqueeze(1)).sum(dim=2)
+    return dw, ds, dd
+
+
+class _ModConvUp2Train(torch.autograd.Function):
+    """The up = 2 synthesis layer on the training route (networks.py:73-82 with conv2d_resample.py:125-142 inside, then bias_act):
+        z = conv_transpose2d(x s, w^T, stride 2) d          one launch, all four output parities (csrc/conv2d_up2.h)
+        y = bias_act(FIR_4x4(z) * 4 + noise + b)            one pass (upfirdn2d_bias_act)
+    backward: bias_act' + db in one pass, the FIR's adjoint (one upfirdn2d pass), dx = conv2d(dz d, w^T, stride 2) s in one launch, and the
+    per-sample stride-2 weight gradients folded like _ModConvTrain's."""
+
+    @staticmethod
+    def forward(ctx, x, weight, styles, dcoefs, noise, bias, f, padding, ep):
+        x, styles = x.contiguous(), styles.contiguous()
+        dcoefs = dcoefs.contiguous() if dcoefs is not None else None
+        cout, cin, kh, kw = (int(v) for v in weight.shape)
+        fw, fh = upfirdn2d._get_filter_size(f)
+        _, fir_pad = _up2_geometry(kh, kw, fw, fh, padding)
+        z = conv2d_mfma.conv_up2_forward(x, conv2d_mfma.pack_up2(weight, flip=False), cout, in_scale=styles, out_scale=dcoefs)
+        act, alpha, gain, clamp = ep if ep is not None else ('linear', 0.0, 1.0, -1.0)
+        y = upfirdn2d.upfirdn2d_bias_act(z, f, padding=fir_pad, gain=4, noise=noise, b=bias, act=act, alpha=alpha, act_gain=gain, clamp=clamp if clamp >= 0 else None)
+        if y is None:                     # the fused FIR tail declined: the same steps one by one
+            y = upfirdn2d.upfirdn2d(z, f, padding=fir_pad, gain=4)
+            if noise is not None:
+                y = y.add_(noise)
+            y = bias_act.bias_act(y, bias, act=act, alpha=alpha, gain=gain, clamp=clamp if clamp >= 0 else None)
+        ctx.save_for_backward(x, weight, styles, dcoefs, y if ep is not None else None, f)
+        ctx.cfg = (fir_pad, ep, tuple(noise.shape) if noise is not None else None, bias is not None)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        x, weight, styles, dcoefs, y, f = ctx.saved_tensors
+        fir_pad, ep, noise_shape, has_bias = ctx.cfg
+        cout, cin, kh, kw = (int(v) for v in weight.shape)
+        n, _, h, w = x.shape
+        need_x, need_w, need_s, need_d, need_noise, need_b = ctx.needs_input_grad[:6]
+        dy = dy.contiguous()
+        db = None
+        if ep is not None:
+            if has_bias and need_b:
+                dy, db = bias_act._BiasActGrad.apply(dy, None, None, y, 1, ep[0], ep[1], ep[2], ep[3], True)
+            else:
+                dy = bias_act._BiasActGrad.apply(dy, None, None, y, 1, ep[0], ep[1], ep[2], ep[3])
+        elif has_bias and need_b:
+            db = bias_act.channel_sum(dy, 1)
+        dnoise = dy.sum_to_size(noise_shape) if (need_noise and noise_shape is not None) else None
+        # adjoint of y = FIR(z): upfirdn2d with the flipped filter and the complementary padding (upfirdn2d.py:216-220 of this package)
+        fw, fh = upfirdn2d._get_filter_size(f)
+        zh, zw = 2 * h + 1, 2 * w + 1
+        adj = (fw - fir_pad[0] - 1, zw - dy.shape[3] + fir_pad[0], fh - fir_pad[2] - 1, zh - dy.shape[2] + fir_pad[2])
+        dz = upfirdn2d.upfirdn2d(dy, f, padding=adj, flip_filter=True, gain=4).contiguous()
+        dx = None
+        if need_x:      # z = conv_transpose2d(x, wt[Cin, Cout]) -> dx = conv2d(dz, wt read as OIHW with O = Cin, stride 2)
+            dx = conv2d_mfma.conv2d_forward(dz, conv2d_gradfix._packed(weight, False, transpose_oi=True), cin, kh, kw, stride=2, pad=(0, 0),
+                                            in_scale=dcoefs, out_scale=styles)
+        dw = ds = dd = None
+        want_w = need_w and not conv2d_gradfix.weight_gradients_disabled
+        if want_w or need_s or need_d:
+            # H'_n[ci, co, ky, kx] = sum x_n[ci, iy, ix] dz_n[co, 2 iy + ky, 2 ix + kx]: the weight gradient of the stride-2 convolution dz -> x
+            per = torch.stack([conv2d_mfma.weight_gradient(dz[i:i + 1], x[i:i + 1], (cin, cout, kh, kw), (0, 0), stride=2) for i in range(n)]).transpose(1, 2)
+            dw, ds, dd = _fold_per_sample(per, weight, styles, dcoefs, want_w, need_s, need_d)
+        return dx, dw, ds, dd, dnoise, db, None, None, None
 
 
 def _modconv_graph(x, weight, styles, noise, up, down, padding, resample_filter, demodulate, flip_weight, fused_modconv):
@@ -807,7 +904,8 @@ class SynthesisLayer(nn.Module):
         act_gain = self.act_gain * gain
         act_clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
         fusable = (_fast_ok(x, self.weight, self.bias, styles, noise) or _fast16_ok(x, self.weight, self.bias, styles, noise)
-                   or (self.up == 1 and _train_fused_ok(x, self.weight, styles, noise, self.padding)))
+                   or (self.up == 1 and _train_fused_ok(x, self.weight, styles, noise, self.padding))
+                   or (self.up == 2 and _train_fused_up2_ok(x, self.weight, styles, noise, self.padding, self.resample_filter)))
         if fusable and self.activation in conv2d_mfma.FUSED_ACTS:
             ep = dict(bias=self.bias, act=self.activation, alpha=bias_act.activation_funcs[self.activation].def_alpha, gain=act_gain, clamp=act_clamp)
             return modulated_conv2d(x=x, weight=self.weight, styles=styles, noise=noise, up=self.up, padding=self.padding,

@@ -1604,7 +1604,7 @@ def _native_backward_cases(conv2d_gradfix, gen):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('case', [('conv3', 64, 64, 64, 3), ('conv3_wide', 128, 96, 32, 3), ('torgb', 64, 3, 64, 1)])
+@pytest.mark.parametrize('case', [('conv3', 64, 64, 64, 3), ('conv3_wide', 128, 96, 32, 3), ('torgb', 64, 3, 64, 1), ('up2', 64, 32, 64, 3), ('up2_big', 128, 64, 128, 3)])
 def test_modulated_conv_training_route_native_vs_graph(case):
     """_ModConvTrain (one forward launch; backward = bias_act' + db pass, input gradient with the scales riding in the launch, per-sample
     weight gradients folded into dw / dstyles / ddcoefs) against the differentiable composition of the same layer (the route the oracle
@@ -1613,7 +1613,7 @@ def test_modulated_conv_training_route_native_vs_graph(case):
     name, cin, cout, res, k = case
     torch.manual_seed(3)
     if k == 3:
-        layer = PN.SynthesisLayer(cin, cout, w_dim=64, resolution=res, conv_clamp=256).to(DEV).train()
+        layer = PN.SynthesisLayer(cin, cout, w_dim=64, resolution=res, conv_clamp=256, up=2 if name.startswith('up2') else 1).to(DEV).train()
         with torch.no_grad():
             layer.noise_strength.fill_(0.3)
             layer.bias.copy_(det_tensor(f'mt.{name}.b', [cout]).to(DEV))
@@ -1625,7 +1625,8 @@ def test_modulated_conv_training_route_native_vs_graph(case):
         def call(x, w):
             rgb, parsing = layer(x, w, fused_modconv=False)
             return torch.cat([rgb, parsing], dim=1)
-    x0 = det_tensor(f'mt.{name}.x', [3, cin, res, res]).to(DEV)
+    res_in = res // 2 if name.startswith('up2') else res
+    x0 = det_tensor(f'mt.{name}.x', [3, cin, res_in, res_in]).to(DEV)
     w0 = det_tensor(f'mt.{name}.w', [3, 64]).to(DEV)
     params = [p for p in layer.parameters()]
 
@@ -1640,7 +1641,9 @@ def test_modulated_conv_training_route_native_vs_graph(case):
         finally:
             PN.fused_training_modconv = was
     ya, ga, (xa, yya) = run(True)
-    yb, gb, _ = run(False)
+    assert yya.grad_fn is not None and type(yya.grad_fn).__name__ in ('_ModConvTrainBackward', '_ModConvUp2TrainBackward', 'CatBackward0'), type(yya.grad_fn).__name__
+    yb, gb, (_, yyb) = run(False)
+    assert 'ModConv' not in type(yyb.grad_fn).__name__
     close(ya, yb, 2e-5, 2e-5 * scale_of(yb))
     assert len(ga) == len(gb)
     for a, b in zip(ga, gb):

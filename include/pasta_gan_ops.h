@@ -329,6 +329,16 @@ int pg_conv2d_wgrad(const float* x, const float* dy, float* dw, float* workspace
                     int N, int Cin, int H, int W, int Cout, int KH, int KW, int stride, int pad_y, int pad_x, int OH, int OW,
                     int splits, void* stream);
 
+/* The same gradient for 16-bit (PG_F16 | PG_BF16) CHANNELS-LAST operands -- x [N, H, W, Cin], dy [N, OH, OW, Cout] -- on
+ * v_mfma_f32_32x32x16_{f16,bf16} with float32 accumulation; dw is float32 [Cout, Cin, KH, KW].  Replaces aten::convolution_backward
+ * (MIOpen) behind the half-precision discriminator blocks (reference conv2d_gradfix.py:137-150).  Covered: 3x3 stride 1 | 2, 1x1 stride 1,
+ * Cin and Cout multiples of 8 (callers zero-pad the image channels of `fromrgb`).  pg_conv2d16_wgrad_plan returns the `splits` to use
+ * (0 = not covered); `workspace` holds splits * KH*KW * Cout * Cin floats; deterministic (fixed-order reduction of the K splits). */
+int pg_conv2d16_wgrad_plan(int N, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride);
+int pg_conv2d16_wgrad(const void* x, const void* dy, float* dw, float* workspace, int dtype,
+                      int N, int Cin, int H, int W, int Cout, int KH, int KW, int stride, int pad_y, int pad_x, int OH, int OW,
+                      int splits, void* stream);
+
 /* ------------------------------------------------------------------------
  * 16-bit convolution (bf16 / fp16 storage, fp32 accumulation) on v_mfma_f32_32x32x16_{bf16,f16}: what cuDNN does behind
  * conv2d_gradfix.py:35-43 for the reference's half-precision blocks (discriminator `use_fp16`, networks.py:444-523;

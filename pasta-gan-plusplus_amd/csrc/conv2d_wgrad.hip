@@ -218,6 +218,198 @@ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 // "write zero" sentinel: a plane must keep every valid offset (plus a halo row's slack) below 2^31.
 inline bool offsets_fit(int64_t plane) { return (64 * plane + 4096) * 4 < 0x7fffffffLL; }
 
+
+// =====================================================================================================================
+// 16-bit (fp16 / bf16) weight gradient, channels-last operands: x [N, H, W, Cin], dy [N, OH, OW, Cout] -> dw fp32 [Cout, Cin, KH, KW].
+// What it replaces: aten::convolution_backward (MIOpen's igemm_wrw_*_fp16) behind the discriminator's half-precision blocks
+// (reference conv2d_gradfix.py:137-150 -> cudnn_convolution_backward_weight).
+//
+// Same GEMM as above (M = Cout, N = Cin per tap, K = pixels) on v_mfma_f32_32x32x16_{f16,bf16}: an operand fragment is 32 channels x 16
+// pixels with EIGHT CONSECUTIVE PIXELS per lane -- but channels-last memory has the channels contiguous.  The tiles are staged as they lie
+// in memory ([pixel][64 channels], 16-byte LDS-DMA, coalesced) and read with gfx950's transposing LDS read `ds_read_b64_tr_b16`: per
+// 16-lane group a block of 4 pixel rows x 16 channels arrives channel-major, four consecutive pixels of one channel per lane; two such
+// reads make one operand.  A k-step = 16 consecutive output pixels of one output row; a chunk = R rows x 32 columns.
+//   stride 1: 128-byte pixel rows, 16-byte slot s of pixel p holds channel slot s ^ (4 * ((p >> 1) & 1)): the four rows of a read sit on
+//             banks {0,32,16,48} + [0,16) for ANY four consecutive pixels -> conflict-free; the x tile's rows are 36 pixels wide so that
+//             the swizzle bit of a lane's pixel depends on the tap's kx only (three address registers, everything else immediates)
+//   stride 2: a read's four pixels are two apart: 160-byte pixel rows (10 slots, 2 of padding), no swizzle -> conflict-free as well
+// Workgroup = 4 multiplying waves (2 x 2 blocks of 32 couts x 32 cins, all taps: 9 x 16 accumulators) + 4 loader waves (gather maps in
+// registers, one barrier per chunk, two staging buffers), split over K like the fp32 kernel, partials reduced in fixed order by wgrad_reduce.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 wbf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 wf16x8 __attribute__((ext_vector_type(8)));
+
+template <int KH, int KW, int S>
+struct W16Geo {
+    static constexpr int T = KH * KW;
+    static constexpr int R = S == 1 ? 4 : 2, TW = 32, PIX = R * TW, KSTEPS = PIX / 16;
+    static constexpr int IH = (R - 1) * S + KH;
+    static constexpr int IW = S == 1 ? ((TW - 1 + KW) + 3) / 4 * 4 : (TW - 1) * S + KW;      // stride 1: a multiple of 4 pixels (see above)
+    static constexpr int XSLOTS = S == 1 ? 8 : 10;                                           // 16-byte slots per x pixel row
+    static constexpr int XROWB = XSLOTS * 16;
+    static constexpr int NDY = (PIX * 8 + 255) / 256, NX = (IH * IW * XSLOTS + 255) / 256;   // 16-byte DMA requests per loader thread
+    static constexpr int BUF = (NDY + NX) * 256 * 16;                                        // bytes per staging buffer
+};
+
+struct Wgrad16Params {
+    const void* x; const void* dy; float* ws;
+    int N, Cin, H, W, Cout, OH, OW, pad_y, pad_x;
+    int tilesX, tilesY, chunks, splits, coB, ciB;
+};
+
+template <bool BF16>
+__device__ __forceinline__ f32x16 mfma16(s16x8 a, s16x8 b, f32x16 c) {
+    if (BF16) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wbf16x8, a), __builtin_bit_cast(wbf16x8, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(wf16x8, a), __builtin_bit_cast(wf16x8, b), c, 0, 0, 0);
+}
+
+template <int KH, int KW, int S, bool BF16>
+__global__ __launch_bounds__(512, 1) void conv2d16_wgrad(Wgrad16Params p) {
+    typedef W16Geo<KH, KW, S> G;
+    typedef __attribute__((address_space(3))) s16x4* lp;
+    extern __shared__ float smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave8 = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const bool loader = wave8 >= 4;
+    const int wave = wave8 & 3, t = threadIdx.x & 255;
+    int b = blockIdx.x;
+    const int s = b % p.splits; b /= p.splits;
+    const int cib = b % p.ciB, cob = b / p.ciB;
+    const int co0 = cob * 64, ci0 = cib * 64;
+    const unsigned smem_b = __builtin_amdgcn_readfirstlane(pgconv::lds_offset(smem));
+
+    if (loader) {
+        // gather maps: byte offsets from the chunk origin for every 16-byte slot this thread requests (sentinel = the DMA writes zeros)
+        unsigned rel_dy[G::NDY], rel_x[G::NX];
+#pragma unroll
+        for (int i = 0; i < G::NDY; i++) {
+            const int f = t + 256 * i, px = f >> 3, sl = f & 7;
+            const int ch = sl ^ (((px >> 1) & 1) << 2);                        // the dy tile is always read at four consecutive pixels: swizzled at either stride
+            const bool ok = px < G::PIX && co0 + ch * 8 < p.Cout;
+            rel_dy[i] = ok ? (unsigned)(((px / G::TW) * p.OW + px % G::TW) * p.Cout + ch * 8) * 2u : WG_SENTINEL;
+        }
+#pragma unroll
+        for (int i = 0; i < G::NX; i++) {
+            const int f = t + 256 * i, pix = f / G::XSLOTS, sl = f % G::XSLOTS;
+            const int ch = S == 1 ? (sl ^ (((pix >> 1) & 1) << 2)) : sl;
+            const bool ok = pix < G::IH * G::IW && sl < 8 && ci0 + ch * 8 < p.Cin;
+            rel_x[i] = ok ? (unsigned)(((pix / G::IW) * p.W + pix % G::IW) * p.Cin + ch * 8) * 2u : WG_SENTINEL;
+        }
+        auto issue = [&](int chk, int buf) __attribute__((always_inline)) {
+            int c = chk;
+            const int tx = c % p.tilesX; c /= p.tilesX;
+            const int ty = c % p.tilesY;
+            const int n = c / p.tilesY;
+            const int oy0 = ty * G::R, ox0 = tx * G::TW;
+            const int iy0 = oy0 * S - p.pad_y, ix0 = ox0 * S - p.pad_x;
+            const uint64_t dyb = (uint64_t)(uintptr_t)p.dy + ((((int64_t)n * p.OH + oy0) * p.OW + ox0) * p.Cout + co0) * 2;
+            const uint64_t xb = (uint64_t)(uintptr_t)p.x + ((((int64_t)n * p.H + iy0) * p.W + ix0) * p.Cin + ci0) * 2;     // may lie before the tensor: masked below
+            pgconv::i32x4 rdy, rx;
+            rdy[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)dyb); rdy[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(dyb >> 32) & 0xffff);
+            rdy[2] = 0x7ffffffe; rdy[3] = 0x00020000;
+            rx[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)xb); rx[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(xb >> 32) & 0xffff);
+            rx[2] = 0x7ffffffe; rx[3] = 0x00020000;
+            const bool inner_dy = oy0 + G::R <= p.OH && ox0 + G::TW <= p.OW;
+            const bool inner_x = iy0 >= 0 && iy0 + G::IH <= p.H && ix0 >= 0 && ix0 + G::IW <= p.W;
+            const unsigned base_b = smem_b + (unsigned)(buf * G::BUF + 64 * 16 * wave);
+#pragma unroll
+            for (int i = 0; i < G::NDY; i++) {
+                unsigned v = rel_dy[i];
+                if (!inner_dy) {
+                    const int px = (t + 256 * i) >> 3;
+                    if (oy0 + px / G::TW >= p.OH || ox0 + px % G::TW >= p.OW) v = WG_SENTINEL;
+                }
+                pgconv::dma_dwordx4_buf(rdy, base_b + (unsigned)(256 * 16 * i), v, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < G::NX; i++) {
+                unsigned v = rel_x[i];
+                if (!inner_x) {
+                    const int pix = (t + 256 * i) / G::XSLOTS;
+                    const int iy = iy0 + pix / G::IW, ix = ix0 + pix % G::IW;
+                    if (iy < 0 || iy >= p.H || ix < 0 || ix >= p.W) v = WG_SENTINEL;
+                }
+                pgconv::dma_dwordx4_buf(rx, base_b + (unsigned)((G::NDY + i) * 256 * 16), v, 0);
+            }
+        };
+        int ch = s, g = 0;
+        if (ch < p.chunks) issue(ch, 0);
+        pgconv::dma_wait_all();
+        __syncthreads();
+        for (; ch < p.chunks; ch += p.splits, g++) {
+            if (ch + p.splits < p.chunks) issue(ch + p.splits, (g & 1) ^ 1);
+            pgconv::dma_wait_all();
+            __syncthreads();
+        }
+        return;
+    }
+
+    // ---- multiplying waves
+    const int mt = wave & 1, nt = wave >> 1;
+    const int grp = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const int kq = 8 * (grp >> 1) + q;                       // this lane's pixel row inside a 16-pixel k-step (first of the two reads; the second is 4 further)
+    const int cbyte_a = (mt * 32 + 16 * (grp & 1) + 4 * pp) * 2, cbyte_b = (nt * 32 + 16 * (grp & 1) + 4 * pp) * 2;
+    // dy tile: pixel kq + 16 kk + 4 j -- bit 1 of the pixel index is bit 1 of q: one address register
+    const unsigned a_lane = (unsigned)(kq * 128 + (cbyte_a ^ (((q >> 1) & 1) << 6)));
+    // x tile: pixel (r S + ky) IW + (c0 + kq + 4 j) S + kx.  Stride 1: IW % 4 == 0 and c0 % 16 == 0, so bit 1 of the pixel index is bit 1 of (q + kx): one register per kx
+    unsigned b_lane[S == 1 ? KW : 1];
+    if (S == 1) {
+#pragma unroll
+        for (int kx = 0; kx < KW; kx++) b_lane[kx] = (unsigned)((kq + kx) * G::XROWB + (cbyte_b ^ ((((q + kx) >> 1) & 1) << 6)));
+    } else {
+        b_lane[0] = (unsigned)(kq * S * G::XROWB + cbyte_b);
+    }
+
+    f32x16 acc[G::T];
+#pragma unroll
+    for (int tp = 0; tp < G::T; tp++)
+#pragma unroll
+        for (int k = 0; k < 16; k++) acc[tp][k] = 0.f;
+
+    int ch = s, g = 0;
+    __syncthreads();                             // chunk 0 has landed
+    for (; ch < p.chunks; ch += p.splits, g++) {
+        const unsigned dy_b = smem_b + (unsigned)((g & 1) * G::BUF);
+        const unsigned x_b = dy_b + (unsigned)(G::NDY * 256 * 16);
+#pragma unroll
+        for (int kk = 0; kk < G::KSTEPS; kk++) {
+            const int r = (kk * 16) / G::TW, c0 = (kk * 16) % G::TW;
+            const unsigned aa = dy_b + a_lane + (unsigned)(kk * 16 * 128);
+            const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(uintptr_t)aa);
+            const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(uintptr_t)(aa + 4 * 128));
+            const s16x8 av = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+            for (int ky = 0; ky < KH; ky++)
+#pragma unroll
+                for (int kx = 0; kx < KW; kx++) {
+                    unsigned ba;
+                    if (S == 1) ba = x_b + b_lane[kx] + (unsigned)(((r + ky) * G::IW + c0) * G::XROWB);
+                    else ba = x_b + b_lane[0] + (unsigned)(((r * S + ky) * G::IW + c0 * S + kx) * G::XROWB);
+                    const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(uintptr_t)ba);
+                    const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(uintptr_t)(ba + 4 * S * G::XROWB));
+                    const s16x8 bv = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    acc[ky * KW + kx] = mfma16<BF16>(av, bv, acc[ky * KW + kx]);
+                }
+        }
+        __syncthreads();
+    }
+    // partial block -> workspace[s][tap][co][ci] (D col = lane & 31 = ci, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) = co)
+    float* wsp = p.ws + (int64_t)s * G::T * p.Cout * p.Cin;
+    const int ci = ci0 + nt * 32 + (lane & 31);
+#pragma unroll
+    for (int tp = 0; tp < G::T; tp++)
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int co = co0 + mt * 32 + (k & 3) + 8 * (k >> 2) + 4 * (lane >> 5);
+            if (co < p.Cout && ci < p.Cin) wsp[((int64_t)tp * p.Cout + co) * p.Cin + ci] = acc[tp][k];
+        }
+}
+
+inline bool wgrad16_covers(int Cin, int Cout, int KH, int KW, int stride) {
+    return Cin > 0 && Cout > 0 && Cin % 8 == 0 && Cout % 8 == 0 && ((KH == 3 && KW == 3 && (stride == 1 || stride == 2)) || (KH == 1 && KW == 1 && stride == 1));
+}
+
 }  // namespace
 
 /* Number of K splits pg_conv2d_wgrad wants (its workspace is splits * KH*KW * Cout * Cin floats); 0 = geometry not covered. */
@@ -266,6 +458,62 @@ PG_EXPORT int pg_conv2d_wgrad(const float* x, const float* dy, float* dw, float*
     else if (KH == 3) { if (tap_split) PG_WGRAD(3, 2, 2) else PG_WGRAD(3, 2, 1) }
     else PG_WGRAD(1, 1, 1)
 #undef PG_WGRAD
+    int st = pg::launch_status();
+    if (st != PG_OK) return st;
+    const int64_t total = (int64_t)KH * KW * Cout * Cin;
+    int64_t rb = (total + 255) / 256;
+    if (rb > pg::max_stream_blocks()) rb = pg::max_stream_blocks();
+    hipLaunchKernelGGL(wgrad_reduce, dim3((unsigned)rb), dim3(256), 0, s, workspace, dw, splits, KH * KW, Cout, Cin);
+    return pg::launch_status();
+}
+
+/* 16-bit weight gradient (channels-last x [N,H,W,Cin], dy [N,OH,OW,Cout] of `dtype` PG_F16 | PG_BF16; dw float32 [Cout,Cin,KH,KW]).
+ * pg_conv2d16_wgrad_plan: the K splits to use (workspace = splits * KH*KW * Cout * Cin floats); 0 = geometry not covered (3x3 stride 1 | 2, 1x1;
+ * channel counts multiples of 8). */
+PG_EXPORT int pg_conv2d16_wgrad_plan(int N, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride) {
+    if (N <= 0 || OH <= 0 || OW <= 0 || !wgrad16_covers(Cin, Cout, KH, KW, stride)) return 0;
+    const int64_t xpix = ((int64_t)OH * stride + KH) * ((int64_t)OW * stride + KW);
+    if (xpix * Cin * 2 >= 0x7fff0000LL || (int64_t)OH * OW * Cout * 2 >= 0x7fff0000LL) return 0;     // 32-bit byte offsets inside one image
+    const int64_t chunks = (int64_t)N * cdiv(OH, stride == 1 ? 4 : 2) * cdiv(OW, 32);
+    const int blocks = cdiv(Cout, 64) * cdiv(Cin, 64);
+    int64_t s = ((int64_t)pg::num_cu() + blocks - 1) / blocks;
+    if (s > chunks) s = chunks;
+    if (s < 1) s = 1;
+    if (s > 4096) s = 4096;
+    return (int)s;
+}
+
+PG_EXPORT int pg_conv2d16_wgrad(const void* x, const void* dy, float* dw, float* workspace, int dtype,
+                                int N, int Cin, int H, int W, int Cout, int KH, int KW, int stride, int pad_y, int pad_x, int OH, int OW,
+                                int splits, void* stream) {
+    if (!x || !dy || !dw || !workspace || N <= 0 || H <= 0 || W <= 0 || OH <= 0 || OW <= 0 || splits <= 0) return PG_ERR_INVALID_ARG;
+    if (dtype != PG_F16 && dtype != PG_BF16) return PG_ERR_INVALID_ARG;
+    if (!wgrad16_covers(Cin, Cout, KH, KW, stride)) return PG_ERR_UNSUPPORTED;
+    if (OH != (H + 2 * pad_y - KH) / stride + 1 || OW != (W + 2 * pad_x - KW) / stride + 1 || pad_y < 0 || pad_x < 0) return PG_ERR_INVALID_ARG;
+    if ((int64_t)H * W * Cin * 2 >= 0x7fff0000LL || (int64_t)OH * OW * Cout * 2 >= 0x7fff0000LL) return PG_ERR_TOO_LARGE;
+    if (!pg::aligned16(x) || !pg::aligned16(dy)) return PG_ERR_UNSUPPORTED;
+    Wgrad16Params p;
+    p.x = x; p.dy = dy; p.ws = workspace;
+    p.N = N; p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout; p.OH = OH; p.OW = OW; p.pad_y = pad_y; p.pad_x = pad_x;
+    p.tilesX = cdiv(OW, 32); p.tilesY = cdiv(OH, stride == 1 ? 4 : 2);
+    const int64_t chunks = (int64_t)N * p.tilesX * p.tilesY;
+    if (chunks > 0x7fffffffLL) return PG_ERR_TOO_LARGE;
+    p.chunks = (int)chunks; p.splits = splits;
+    p.coB = cdiv(Cout, 64); p.ciB = cdiv(Cin, 64);
+    const int64_t blocks = (int64_t)p.coB * p.ciB * splits;
+    if (blocks > 0x7fffffffLL) return PG_ERR_TOO_LARGE;
+    hipStream_t s = (hipStream_t)stream;
+#define PG_WGRAD16(KK, SS, BF) { \
+        const size_t lds = 2 * (size_t)W16Geo<KK, KK, SS>::BUF; \
+        static pg::PerDeviceOnce attr; \
+        const hipError_t e = attr.run([] { return hipFuncSetAttribute((const void*)conv2d16_wgrad<KK, KK, SS, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }); \
+        if (e != hipSuccess) return (int)e; \
+        hipLaunchKernelGGL((conv2d16_wgrad<KK, KK, SS, BF>), dim3((unsigned)blocks), dim3(512), lds, s, p); }
+    const bool bf = dtype == PG_BF16;
+    if (KH == 3 && stride == 1) { if (bf) PG_WGRAD16(3, 1, true) else PG_WGRAD16(3, 1, false) }
+    else if (KH == 3) { if (bf) PG_WGRAD16(3, 2, true) else PG_WGRAD16(3, 2, false) }
+    else { if (bf) PG_WGRAD16(1, 1, true) else PG_WGRAD16(1, 1, false) }
+#undef PG_WGRAD16
     int st = pg::launch_status();
     if (st != PG_OK) return st;
     const int64_t total = (int64_t)KH * KW * Cout * Cin;

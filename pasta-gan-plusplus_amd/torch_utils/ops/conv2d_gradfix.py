@@ -33,6 +33,7 @@ from . import conv2d_mfma
 from . import conv2d_mfma16
 
 native_input_gradients = os.environ.get('PG_NATIVE_DGRAD', '1') == '1'    # input gradients through the MFMA / Winograd kernels (PG_NATIVE_DGRAD=0: aten)
+native_weight_gradients16 = os.environ.get('PG_NATIVE_WGRAD16', '1') == '1'   # weight gradients of the 16-bit 3x3 / 1x1 convs through conv2d16_wgrad (PG_NATIVE_WGRAD16=0: aten / MIOpen)
 native_weight_gradients = os.environ.get('PG_NATIVE_WGRAD', '1') == '1'   # weight gradients of stride-1 3x3 / 1x1 fp32 convs through csrc/conv2d_wgrad.hip (exact, deterministic; PG_NATIVE_WGRAD=0: aten / MIOpen)
 enabled = True                      # True (default here; the reference's loop sets it, training_loop_fullbody.py:386): hand-written kernels.  False: aten
 weight_gradients_disabled = False   # forcefully disable weight gradients (R1, loss_fullbody.py:266)
@@ -222,15 +223,15 @@ class _Conv2dMfma(torch.autograd.Function):
             dx = _input_gradient(dy, x.shape, weight, stride, padding, transposed, output_padding)
         want_w = ctx.needs_input_grad[1] and not weight_gradients_disabled
         want_b = has_bias and ctx.needs_input_grad[2]
-        # (under create_graph the native weight gradient -- a plain tensor -- is only right when nothing upstream could ask for ITS gradient:
-        # neither dy nor x carries a graph; otherwise aten's differentiable convolution_backward builds the higher-order graph)
-        if want_w and native_weight_gradients and stride in (1, 2) and not (torch.is_grad_enabled() and (dy.requires_grad or x.requires_grad)):
-            if not transposed:
-                dw = conv2d_mfma.weight_gradient(x, dy, weight.shape, padding, stride=stride)      # a GEMM over pixels (csrc/conv2d_wgrad.hip); None = not covered
+        if want_w and native_weight_gradients and stride in (1, 2):
+            if torch.is_grad_enabled() and (dy.requires_grad or x.requires_grad):
+                # create_graph with dy / x carrying a graph: the weight gradient must itself be differentiable
+                try:
+                    dw = _WeightGradient.apply(dy, x, tuple(weight.shape), stride, padding, transposed, output_padding)
+                except nat.NativeNotCovered:
+                    dw = None
             else:
-                # y = conv_transpose2d(x, w[Cin, Cout]):  dw[ci, co, ky, kx] = sum x[ci, iy, ix] dy[co, s iy + ky - p, s ix + kx - p] -- the weight
-                # gradient of the strided convolution dy -> x, whose 'OIHW' kernel has O = Cin, I = Cout: the same kernel with the roles swapped
-                dw = conv2d_mfma.weight_gradient(dy, x, weight.shape, padding, stride=stride)
+                dw = _weight_gradient(dy, x, weight.shape, stride, padding, transposed)
         if want_b and db is None and (dw is not None or not want_w):
             db = bias_act.channel_sum(dy, 1)                 # one deterministic native pass (csrc/bias_act.hip)
         mask = [dx is None and ctx.needs_input_grad[0], want_w and dw is None, want_b and db is None]
@@ -242,6 +243,43 @@ class _Conv2dMfma(torch.autograd.Function):
             dw = gw if mask[1] else dw
             db = gb if mask[2] else db
         return dx, dw, db, None, None, None, None, None
+
+
+def _weight_gradient(dy, x, weight_shape, stride, padding, transposed):
+    """Native fp32 weight gradient (a GEMM over pixels, csrc/conv2d_wgrad.hip); None = geometry not covered."""
+    if not transposed:
+        return conv2d_mfma.weight_gradient(x, dy, weight_shape, padding, stride=stride)
+    # y = conv_transpose2d(x, w[Cin, Cout]):  dw[ci, co, ky, kx] = sum x[ci, iy, ix] dy[co, s iy + ky - p, s ix + kx - p] -- the weight
+    # gradient of the strided convolution dy -> x, whose 'OIHW' kernel has O = Cin, I = Cout: the same kernel with the roles swapped
+    return conv2d_mfma.weight_gradient(dy, x, weight_shape, padding, stride=stride)
+
+
+class _WeightGradient(torch.autograd.Function):
+    """The weight gradient as a differentiable op (the role of the reference's Conv2dGradWeight, conv2d_gradfix.py:139-168): dw is bilinear
+    in (dy, x), so for an incoming gradient g of the weight's shape  d/d(dy) = the forward convolution of x with g in the weight's place and
+    d/dx = the input-gradient form of dy with g -- both native again, to any order."""
+
+    @staticmethod
+    def forward(ctx, dy, x, weight_shape, stride, padding, transposed, output_padding):
+        dw = _weight_gradient(dy.contiguous(), x.contiguous(), weight_shape, stride, padding, transposed)
+        if dw is None:
+            raise nat.NativeNotCovered('conv2d_gradfix: weight gradient geometry not covered')
+        ctx.save_for_backward(dy, x)
+        ctx.cfg = (stride, padding, transposed, output_padding)
+        return dw
+
+    @staticmethod
+    def backward(ctx, g):
+        dy, x = ctx.saved_tensors
+        stride, padding, transposed, output_padding = ctx.cfg
+        d_dy = d_x = None
+        if ctx.needs_input_grad[0]:
+            d_dy = _Conv2dMfma.apply(x, g, None, stride, padding, transposed, output_padding)
+        if ctx.needs_input_grad[1]:
+            d_x = _input_gradient(dy, x.shape, g, stride, padding, transposed, output_padding)
+            if d_x is None:
+                d_x = torch.ops.aten.convolution_backward(dy, x, g, None, [stride, stride], list(padding), [1, 1], transposed, list(output_padding), 1, [True, False, False])[0]
+        return d_dy, d_x, None, None, None, None, None
 
 
 class _Conv2dMfma16(torch.autograd.Function):
@@ -284,6 +322,11 @@ class _Conv2dMfma16(torch.autograd.Function):
             dx = _input_gradient(dy, x.shape, weight, stride, padding, transposed, output_padding, fn=_Conv2dMfma16, mod=conv2d_mfma16)
         want_w = ctx.needs_input_grad[1] and not weight_gradients_disabled
         want_b = has_bias and ctx.needs_input_grad[2]
+        if want_w and native_weight_gradients16 and not transposed and not (torch.is_grad_enabled() and (dy.requires_grad or x.requires_grad)):
+            g = conv2d_mfma16.weight_gradient(x, dy, weight.shape, padding, stride=stride)        # float32 [Cout, Cin, kh, kw]; None = not covered
+            dw = g.to(weight.dtype) if g is not None else None
+        if want_b and db is None and (dw is not None or not want_w):
+            db = bias_act.channel_sum(dy, 1)
         need_x = dx is None and ctx.needs_input_grad[0]
         need_w = want_w and dw is None
         need_b = want_b and db is None

@@ -55,12 +55,47 @@ def _init():
         lib.pg_conv2d16_forward_splitk.argtypes = fwd + [vp, i, vp]
         lib.pg_conv1x1_small16.restype = i
         lib.pg_conv1x1_small16.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, i64, i, f, vp]
+        lib.pg_conv2d16_wgrad_plan.restype = i
+        lib.pg_conv2d16_wgrad_plan.argtypes = [i] * 8
+        lib.pg_conv2d16_wgrad.restype = i
+        lib.pg_conv2d16_wgrad.argtypes = [vp, vp, vp, vp, i] + [i] * 13 + [vp]
         _lib = lib
     return _lib
 
 
 def supported(kh, kw, stride):
     return (int(kh), int(kw), int(stride)) in SUPPORTED
+
+
+def weight_gradient(x, dy, weight_shape, pad, stride=1):
+    """d(loss)/d(weight) (float32, [Cout, Cin, kh, kw]) of y = conv2d(x, w, stride, padding=pad) for 16-bit tensors: a GEMM over pixels on the
+    16-bit MFMA with channels-last operands read through the transposing LDS load (csrc/conv2d_wgrad.hip, conv2d16_wgrad).  Image channels that
+    are not a multiple of 8 (fromrgb: 6 / 10) are zero-padded here.  None = geometry not covered (callers then ask aten)."""
+    lib = _init()
+    cout, cin, kh, kw = (int(v) for v in weight_shape)
+    n, _, h, w = x.shape
+    oh, ow = int(dy.shape[2]), int(dy.shape[3])
+    stride = int(stride)
+    if x.dtype not in DTYPES or dy.dtype != x.dtype or min(pad) < 0 or (oh, ow) != ((h + 2 * pad[0] - kh) // stride + 1, (w + 2 * pad[1] - kw) // stride + 1):
+        return None
+    cin_p, cout_p = -(-cin // 8) * 8, -(-cout // 8) * 8
+    splits = lib.pg_conv2d16_wgrad_plan(n, cin_p, oh, ow, cout_p, kh, kw, stride)
+    if splits <= 0:
+        return None
+    if cin_p != cin:
+        x = torch.nn.functional.pad(x, (0, 0, 0, 0, 0, cin_p - cin))
+    if cout_p != cout:
+        dy = torch.nn.functional.pad(dy, (0, 0, 0, 0, 0, cout_p - cout))
+    x, dy = to_channels_last(x), to_channels_last(dy)
+    dw = torch.empty([cout_p, cin_p, kh, kw], dtype=torch.float32, device=x.device)
+    ws = torch.empty([splits * kh * kw * cout_p * cin_p], dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        st = lib.pg_conv2d16_wgrad(nat.ptr(x), nat.ptr(dy), nat.ptr(dw), nat.ptr(ws), nat.PG_DTYPE[x.dtype], n, cin_p, h, w, cout_p, kh, kw, stride,
+                                   int(pad[0]), int(pad[1]), oh, ow, splits, nat.stream_of(x))
+    if st == -2:
+        return None
+    nat.check(st, 'pg_conv2d16_wgrad')
+    return dw[:cout, :cin] if (cin_p != cin or cout_p != cout) else dw
 
 
 def to_channels_last(x):

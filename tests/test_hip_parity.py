@@ -1587,6 +1587,82 @@ def test_conv2d_gradfix_native_backward_routes():
     assert calls['wgrad'] == 3          # every case took the native weight-gradient kernel (the route, not only the numbers)
 
 
+@pytest.mark.parametrize('case', [
+    # name, dtype, N, cin, cout, k, stride, pad, (H, W)
+    ('k3',          torch.float16,  2, 64, 64, 3, 1, 1, (40, 48)),
+    ('k3_odd',      torch.float16,  1, 128, 72, 3, 1, 1, (17, 45)),
+    ('k3_multi',    torch.float16,  3, 64, 128, 3, 1, 1, (128, 96)),
+    ('k3_s2',       torch.float16,  2, 32, 64, 3, 2, 0, (35, 35)),
+    ('k3_s2_pad',   torch.float16,  1, 64, 64, 3, 2, 1, (64, 50)),
+    ('k1',          torch.float16,  2, 64, 128, 1, 1, 0, (33, 20)),
+    ('fromrgb',     torch.float16,  2, 6, 64, 1, 1, 0, (32, 32)),
+    ('k3_bf16',     torch.bfloat16, 2, 64, 64, 3, 1, 1, (24, 40)),
+    ('k3_wide',     torch.float16,  1, 512, 512, 3, 1, 1, (16, 16)),
+])
+def test_native_weight_gradient_16bit(case):
+    """conv2d16_wgrad (channels-last fp16 / bf16 operands, transposing LDS reads, fp32 accumulation) against float64 autograd of torch's convolution
+    on the same 16-bit values: products of 16-bit numbers are exact in fp32, so only the summation order differs; twice -> bit-identical."""
+    from torch_utils.ops import conv2d_mfma16
+    name, dt, n, cin, cout, k, stride, pad, hw = case
+    gen = torch.Generator().manual_seed(hash(name) % 1000)
+    x = torch.randn([n, cin, *hw], generator=gen).to(dt)
+    oh, ow = (hw[0] + 2 * pad - k) // stride + 1, (hw[1] + 2 * pad - k) // stride + 1
+    dy = torch.randn([n, cout, oh, ow], generator=gen).to(dt)
+    w64 = torch.zeros([cout, cin, k, k], dtype=torch.float64, requires_grad=True)
+    ref, = torch.autograd.grad(torch.nn.functional.conv2d(x.double(), w64, stride=stride, padding=pad), [w64], dy.double())
+    xd = x.to(DEV).contiguous(memory_format=torch.channels_last)
+    dyd = dy.to(DEV).contiguous(memory_format=torch.channels_last)
+    got = conv2d_mfma16.weight_gradient(xd, dyd, (cout, cin, k, k), (pad, pad), stride=stride)
+    assert got is not None and got.dtype == torch.float32 and tuple(got.shape) == (cout, cin, k, k)
+    close(got, ref, 1e-4, 2e-5 * scale_of(ref))
+    assert torch.equal(got, conv2d_mfma16.weight_gradient(xd, dyd, (cout, cin, k, k), (pad, pad), stride=stride))
+    # NCHW-strided inputs are converted; through conv2d_gradfix the gradient arrives in the weight's dtype
+    from torch_utils.ops import conv2d_gradfix
+    wd = (torch.randn([cout, cin, k, k], generator=gen) / np.sqrt(cin * k * k)).to(dt).to(DEV).requires_grad_(True)
+    y = conv2d_gradfix.conv2d(x.to(DEV), wd, stride=stride, padding=pad)
+    gw, = torch.autograd.grad(y, [wd], dy.to(DEV))
+    assert gw.dtype == dt
+    close(gw, ref, 2e-2 if dt == torch.bfloat16 else 3e-3, (2e-2 if dt == torch.bfloat16 else 3e-3) * scale_of(ref))
+
+
+def test_conv2d_gradfix_weight_gradient_is_differentiable():
+    """create_graph with the weight gradient in the graph (the role of the reference's Conv2dGradWeight.backward, conv2d_gradfix.py:151-168):
+    dw from the native kernel, then d(|dw|^2)/dx and /d(dy) through `_WeightGradient.backward` -- against float64 autograd of torch's own
+    convolution, for a plain, a strided and a transposed case; the aten route must not have been taken."""
+    from torch_utils.ops import conv2d_gradfix
+    calls = {'n': 0}
+    real = conv2d_gradfix._WeightGradient.forward
+
+    def counting(ctx, *a):
+        calls['n'] += 1
+        return real(ctx, *a)
+    conv2d_gradfix._WeightGradient.forward = staticmethod(counting)
+    gen = torch.Generator().manual_seed(77)
+    try:
+        for kind, cin, cout, k, stride, pad, hw in (('conv', 32, 48, 3, 1, 1, (18, 22)), ('conv', 16, 32, 3, 2, 1, (21, 21)), ('conv', 24, 40, 1, 1, 0, (12, 14)),
+                                                     ('transposed', 16, 24, 3, 2, 0, (10, 12))):
+            x = torch.randn([2, cin, *hw], generator=gen)
+            wshape = [cout, cin, k, k] if kind == 'conv' else [cin, cout, k, k]
+            wt = torch.randn(wshape, generator=gen) / np.sqrt(cin * k * k)
+            f_dev = (lambda a, b: conv2d_gradfix.conv2d(a, b, stride=stride, padding=pad)) if kind == 'conv' else (lambda a, b: conv2d_gradfix.conv_transpose2d(a, b, stride=stride, padding=pad))
+            f_ref = (lambda a, b: torch.nn.functional.conv2d(a, b, stride=stride, padding=pad)) if kind == 'conv' else (lambda a, b: torch.nn.functional.conv_transpose2d(a, b, stride=stride, padding=pad))
+            xd, wd = x.to(DEV).requires_grad_(True), wt.to(DEV).requires_grad_(True)
+            y = f_dev(xd, wd)
+            dy = torch.randn(y.shape, generator=gen)
+            dyd = dy.to(DEV).requires_grad_(True)
+            gw, = torch.autograd.grad(y, [wd], dyd, create_graph=True)
+            hx, hdy = torch.autograd.grad(gw.square().sum(), [xd, dyd])
+            x64, w64, dy64 = x.double().requires_grad_(True), wt.double().requires_grad_(True), dy.double().requires_grad_(True)
+            rw, = torch.autograd.grad(f_ref(x64, w64), [w64], dy64, create_graph=True)
+            rx, rdy = torch.autograd.grad(rw.square().sum(), [x64, dy64])
+            close(gw, rw, 1e-4, 1e-5 * scale_of(rw))
+            close(hx, rx, 2e-4, 2e-5 * scale_of(rx))
+            close(hdy, rdy, 2e-4, 2e-5 * scale_of(rdy))
+    finally:
+        conv2d_gradfix._WeightGradient.forward = staticmethod(real)
+    assert calls['n'] == 4
+
+
 def _native_backward_cases(conv2d_gradfix, gen):
     for cin, cout, k, hw in ((32, 80, 3, (20, 24)), (16, 24, 3, (13, 19)), (64, 48, 1, (17, 21))):
         x = torch.randn([2, cin, *hw], generator=gen)

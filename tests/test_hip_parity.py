@@ -1294,6 +1294,11 @@ def test_config4_whole_iteration_batch4_vs_oracle():
     sig_of = lambda nets: {f'{k}.{pn}': (None if p_.grad is None else float(p_.grad.double().abs().sum())) for k, m in nets.items() for pn, p_ in m.named_parameters()}
 
     want_phases = ('Gmain', 'Dmain')
+    # Gmain runs with noise_strength = 0 (initial value): nothing random, 3e-3 as in the per-network tests.  By Dmain the Adam step has moved every
+    # noise_strength to +-4e-4 and the generator draws its noise afresh on each side (GPU generator here, CPU generator in the oracle): with nothing but the
+    # torch seed changed the Dmain signatures move by up to 2.3e-3 (tools/probes/dmain_noise_sensitivity.py, three seeds), so that phase gets 3e-3 on top of it.
+    bar = dict(Gmain=3e-3, Dmain=6e-3)
+    torch.manual_seed(1234)          # the draws must not depend on which tests ran before this one
     start, got, order = {}, {}, []
 
     def observer(event, ph):
@@ -1350,7 +1355,7 @@ def test_config4_whole_iteration_batch4_vs_oracle():
                     bad.append((key, g, w))
                 continue
             worst = max(worst, (abs(g - w) / (abs(w) + 1e-12), key))
-            if abs(g - w) > 3e-3 * abs(w) + 1e-6:
+            if abs(g - w) > bar[phase] * abs(w) + 1e-6:
                 bad.append((key, g, w))
         report.append(f'{phase}: {n_grad} parameters with gradients, worst signature mismatch {worst[0]:.2e} ({worst[1]}), oracle {time.perf_counter() - t0:.0f} s')
         assert not bad, (phase, bad[:8])

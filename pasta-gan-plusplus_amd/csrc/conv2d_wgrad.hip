@@ -220,6 +220,136 @@ inline bool offsets_fit(int64_t plane) { return (64 * plane + 4096) * 4 < 0x7fff
 
 
 // =====================================================================================================================
+// fp32 weight gradient of a FEW-CHANNEL large-kernel layer (the encoders' 7x7 stem on a 3-channel image, networks.py:2242): the (ci, ky, kx)
+// triples are the GEMM's N axis -- Cin * KH * KW <= 160 = five 32-wide blocks -- instead of one N block of 64 input channels per tap (which would
+// spend 61 of 64 columns on padding).  M = 64 couts, K = pixels as above.  Ten multiplying waves (2 cout halves x 5 N blocks, one accumulator each)
+// + two loader waves; the B operand of lane n is x[ci(n)][row + ky(n)][col + kx(n)]: a per-lane constant offset into the staged halo.
+// Partials go to workspace[s][co][n], n = ci * KH*KW + tap -- dw's own [Cout][Cin][KH][KW] order -- and through wgrad_reduce with T = 1.
+template <int KH, int KW>
+struct WSmallGeo {
+    static constexpr int T = KH * KW, NB = 5;
+    static constexpr int R = 2, PIX = WG_TW * R;
+    static constexpr int IH = R - 1 + KH, IW = WG_TW - 1 + KW;
+    static constexpr int CMAX = (32 * NB) / T;                          // input channels the five N blocks hold (3 for 7x7)
+    static constexpr int PA = PIX + 1, PB = (IH * IW) | 1;
+    static constexpr int LOADERS = 128;
+    static constexpr int NDY = (WG_BM * PA + LOADERS - 1) / LOADERS, NX = (CMAX * PB + LOADERS - 1) / LOADERS;
+    static constexpr int BUF = (NDY + NX) * LOADERS;                    // floats per staging buffer
+};
+
+template <int KH, int KW>
+__global__ __launch_bounds__(768, 1) void conv2d_wgrad_fewcin(WgradParams p) {
+    typedef WSmallGeo<KH, KW> G;
+    extern __shared__ float smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave12 = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const bool loader = wave12 >= 10;
+    const int half = lane >> 5, l31 = lane & 31;
+    int b = blockIdx.x;
+    const int s = b % p.splits;
+    const int co0 = (b / p.splits) * WG_BM;
+    const int OHW = p.OH * p.OW, HW = p.H * p.W;
+    const unsigned smem_b = __builtin_amdgcn_readfirstlane(pgconv::lds_offset(smem));
+
+    if (loader) {
+        const int t = threadIdx.x - 640, lw = wave12 - 10;
+        unsigned rel_dy[G::NDY], rel_x[G::NX];
+#pragma unroll
+        for (int i = 0; i < G::NDY; i++) {
+            const int f = t + G::LOADERS * i, co = f / G::PA, px = f % G::PA;
+            const bool ok = co < WG_BM && px < G::PIX && co0 + co < p.Cout;
+            rel_dy[i] = ok ? (unsigned)(co * OHW + (px / WG_TW) * p.OW + px % WG_TW) * 4u : WG_SENTINEL;
+        }
+#pragma unroll
+        for (int i = 0; i < G::NX; i++) {
+            const int f = t + G::LOADERS * i, ci = f / G::PB, rr = f % G::PB;
+            const bool ok = ci < G::CMAX && rr < G::IH * G::IW && ci < p.Cin;
+            rel_x[i] = ok ? (unsigned)(ci * HW + (rr / G::IW) * p.W + rr % G::IW) * 4u : WG_SENTINEL;
+        }
+        auto issue = [&](int chk, int buf) __attribute__((always_inline)) {
+            int c = chk;
+            const int tx = c % p.tilesX; c /= p.tilesX;
+            const int ty = c % p.tilesY;
+            const int n = c / p.tilesY;
+            const int oy0 = ty * G::R, ox0 = tx * WG_TW;
+            const int iy0 = oy0 - p.pad_y, ix0 = ox0 - p.pad_x;
+            const uint64_t dyb = (uint64_t)(uintptr_t)(p.dy + ((int64_t)n * p.Cout + co0) * OHW + (int64_t)oy0 * p.OW + ox0);
+            const uint64_t xb = (uint64_t)(uintptr_t)(p.x + (int64_t)n * p.Cin * HW) + ((int64_t)iy0 * p.W + ix0) * 4;
+            pgconv::i32x4 rdy, rx;
+            rdy[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)dyb); rdy[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(dyb >> 32) & 0xffff);
+            rdy[2] = 0x7ffffffe; rdy[3] = 0x00020000;
+            rx[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)xb); rx[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(xb >> 32) & 0xffff);
+            rx[2] = 0x7ffffffe; rx[3] = 0x00020000;
+            const bool inner_dy = oy0 + G::R <= p.OH && ox0 + WG_TW <= p.OW;
+            const bool inner_x = iy0 >= 0 && iy0 + G::IH <= p.H && ix0 >= 0 && ix0 + G::IW <= p.W;
+            const unsigned base_b = smem_b + (unsigned)(buf * G::BUF + 64 * lw) * 4u;
+#pragma unroll
+            for (int i = 0; i < G::NDY; i++) {
+                unsigned v = rel_dy[i];
+                if (!inner_dy) {
+                    const int px = (t + G::LOADERS * i) % G::PA;
+                    if (oy0 + px / WG_TW >= p.OH || ox0 + px % WG_TW >= p.OW) v = WG_SENTINEL;
+                }
+                pgconv::dma_dword(rdy, base_b + (unsigned)(G::LOADERS * i) * 4u, v, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < G::NX; i++) {
+                unsigned v = rel_x[i];
+                if (!inner_x) {
+                    const int rr = (t + G::LOADERS * i) % G::PB;
+                    const int iy = iy0 + rr / G::IW, ix = ix0 + rr % G::IW;
+                    if (iy < 0 || iy >= p.H || ix < 0 || ix >= p.W) v = WG_SENTINEL;
+                }
+                pgconv::dma_dword(rx, base_b + (unsigned)((G::NDY + i) * G::LOADERS) * 4u, v, 0);
+            }
+        };
+        int ch = s, g = 0;
+        if (ch < p.chunks) issue(ch, 0);
+        pgconv::dma_wait_all();
+        __syncthreads();
+        for (; ch < p.chunks; ch += p.splits, g++) {
+            if (ch + p.splits < p.chunks) issue(ch + p.splits, (g & 1) ^ 1);
+            pgconv::dma_wait_all();
+            __syncthreads();
+        }
+        return;
+    }
+
+    const int mt = wave12 & 1, nt = wave12 >> 1;
+    const int nidx = nt * 32 + l31;                                    // (ci, ky, kx) of this lane's column
+    const bool ncol_ok = nidx < p.Cin * G::T;
+    const int nn = ncol_ok ? nidx : 0;
+    const int b_off = (nn / G::T) * G::PB + ((nn % G::T) / KW) * G::IW + (nn % G::T) % KW + half;
+    f32x16 acc;
+#pragma unroll
+    for (int k = 0; k < 16; k++) acc[k] = 0.f;
+    int ch = s, g = 0;
+    __syncthreads();
+    for (; ch < p.chunks; ch += p.splits, g++) {
+        const float* dyt = smem + (g & 1) * G::BUF;
+        const float* xt = dyt + G::NDY * G::LOADERS;
+        const float* a_base = dyt + (mt * 32 + l31) * G::PA + half;
+        const float* b_base = xt + b_off;
+#pragma unroll 8
+        for (int kk = 0; kk < G::PIX / 2; kk++) {
+            const int r = (2 * kk) / WG_TW, cc = (2 * kk) % WG_TW;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_base[2 * kk], b_base[r * G::IW + cc], acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    float* wsp = p.ws + (int64_t)s * p.Cout * p.Cin * G::T;
+    if (ncol_ok) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int co = co0 + mt * 32 + (k & 3) + 8 * (k >> 2) + 4 * half;
+            if (co < p.Cout) wsp[(int64_t)co * p.Cin * G::T + nidx] = acc[k];
+        }
+    }
+}
+
+inline bool fewcin_covers(int Cin, int KH, int KW, int stride) { return KH == 7 && KW == 7 && stride == 1 && Cin * 49 <= 160; }
+
+// =====================================================================================================================
 // 16-bit (fp16 / bf16) weight gradient, channels-last operands: x [N, H, W, Cin], dy [N, OH, OW, Cout] -> dw fp32 [Cout, Cin, KH, KW].
 // What it replaces: aten::convolution_backward (MIOpen's igemm_wrw_*_fp16) behind the discriminator's half-precision blocks
 // (reference conv2d_gradfix.py:137-150 -> cudnn_convolution_backward_weight).
@@ -415,8 +545,14 @@ inline bool wgrad16_covers(int Cin, int Cout, int KH, int KW, int stride) {
 /* Number of K splits pg_conv2d_wgrad wants (its workspace is splits * KH*KW * Cout * Cin floats); 0 = geometry not covered. */
 PG_EXPORT int pg_conv2d_wgrad_plan(int N, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride) {
     if (N <= 0 || Cin <= 0 || OH <= 0 || OW <= 0 || Cout <= 0) return 0;
-    if (!((KH == 3 && KW == 3 && (stride == 1 || stride == 2)) || (KH == 1 && KW == 1 && stride == 1))) return 0;
     if (!offsets_fit((int64_t)OH * OW) || !offsets_fit(((int64_t)OH * stride + KH) * ((int64_t)OW * stride + KW))) return 0;    // x plane bounded through the output extent
+    if (fewcin_covers(Cin, KH, KW, stride)) {          // the few-channel form: one workgroup per 64 couts and K split
+        const int64_t chunks = (int64_t)N * cdiv(OH, 2) * cdiv(OW, WG_TW);
+        int64_t s = ((int64_t)pg::num_cu() + cdiv(Cout, WG_BM) - 1) / cdiv(Cout, WG_BM);
+        if (s > chunks) s = chunks;
+        return (int)(s < 1 ? 1 : s);
+    }
+    if (!((KH == 3 && KW == 3 && (stride == 1 || stride == 2)) || (KH == 1 && KW == 1 && stride == 1))) return 0;
     const int64_t chunks = (int64_t)N * cdiv(OH, stride == 1 ? 2 : 1) * cdiv(OW, WG_TW);
     const int blocks = cdiv(Cout, WG_BM) * cdiv(Cin, WG_BN);
     int64_t s = ((int64_t)pg::num_cu() + blocks - 1) / blocks;            // one (persistent-for-its-share) workgroup per CU
@@ -430,9 +566,28 @@ PG_EXPORT int pg_conv2d_wgrad(const float* x, const float* dy, float* dw, float*
                               int N, int Cin, int H, int W, int Cout, int KH, int KW, int stride, int pad_y, int pad_x, int OH, int OW,
                               int splits, void* stream) {
     if (!x || !dy || !dw || !workspace || N <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0 || OH <= 0 || OW <= 0 || splits <= 0) return PG_ERR_INVALID_ARG;
-    if (!((KH == 3 && KW == 3 && (stride == 1 || stride == 2)) || (KH == 1 && KW == 1 && stride == 1))) return PG_ERR_UNSUPPORTED;
+    const bool fewcin = fewcin_covers(Cin, KH, KW, stride);
+    if (!fewcin && !((KH == 3 && KW == 3 && (stride == 1 || stride == 2)) || (KH == 1 && KW == 1 && stride == 1))) return PG_ERR_UNSUPPORTED;
     if (OH != (H + 2 * pad_y - KH) / stride + 1 || OW != (W + 2 * pad_x - KW) / stride + 1 || pad_y < 0 || pad_x < 0) return PG_ERR_INVALID_ARG;
     if (!offsets_fit((int64_t)H * W) || !offsets_fit((int64_t)OH * OW)) return PG_ERR_TOO_LARGE;
+    if (fewcin) {
+        WgradParams q;
+        q.x = x; q.dy = dy; q.ws = workspace;
+        q.N = N; q.Cin = Cin; q.H = H; q.W = W; q.Cout = Cout; q.OH = OH; q.OW = OW; q.pad_y = pad_y; q.pad_x = pad_x;
+        q.tilesX = cdiv(OW, WG_TW); q.tilesY = cdiv(OH, 2);
+        const int64_t nchunks = (int64_t)N * q.tilesX * q.tilesY;
+        if (nchunks > 0x7fffffffLL) return PG_ERR_TOO_LARGE;
+        q.chunks = (int)nchunks; q.splits = splits; q.coB = cdiv(Cout, WG_BM); q.ciB = 1;
+        const size_t lds = 2 * (size_t)WSmallGeo<7, 7>::BUF * sizeof(float);
+        hipLaunchKernelGGL((conv2d_wgrad_fewcin<7, 7>), dim3((unsigned)(q.coB * splits)), dim3(768), lds, (hipStream_t)stream, q);
+        int st0 = pg::launch_status();
+        if (st0 != PG_OK) return st0;
+        const int64_t tot = (int64_t)KH * KW * Cout * Cin;
+        int64_t rb0 = (tot + 255) / 256;
+        if (rb0 > pg::max_stream_blocks()) rb0 = pg::max_stream_blocks();
+        hipLaunchKernelGGL(wgrad_reduce, dim3((unsigned)rb0), dim3(256), 0, (hipStream_t)stream, workspace, dw, splits, 1, Cout, Cin * KH * KW);
+        return pg::launch_status();
+    }
     WgradParams p;
     p.x = x; p.dy = dy; p.ws = workspace;
     p.N = N; p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout; p.OH = OH; p.OW = OW; p.pad_y = pad_y; p.pad_x = pad_x;

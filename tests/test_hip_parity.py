@@ -1550,11 +1550,13 @@ def test_modulated_conv2d_fp16_prenorm_golden(golden):
 
 
 @pytest.mark.parametrize('shape', [(2, 16, 24, 20, 37, 3, 1), (1, 70, 130, 9, 33, 3, 1), (3, 64, 64, 17, 17, 1, 1), (2, 5, 7, 8, 40, 1, 1), (8, 64, 64, 64, 64, 3, 1),
-                                   (2, 16, 24, 21, 37, 3, 2), (1, 70, 130, 10, 66, 3, 2), (4, 64, 64, 65, 65, 3, 2)],
-                         ids=['3x3_ragged', '3x3_multi_block', '1x1', '1x1_tiny', '3x3_many_chunks', '3x3s2_ragged', '3x3s2_multi_block', '3x3s2_odd_input'])
+                                   (2, 16, 24, 21, 37, 3, 2), (1, 70, 130, 10, 66, 3, 2), (4, 64, 64, 65, 65, 3, 2),
+                                   (2, 3, 64, 40, 44, 7, 1), (1, 2, 70, 9, 33, 7, 1), (4, 3, 64, 128, 128, 7, 1)],
+                         ids=['3x3_ragged', '3x3_multi_block', '1x1', '1x1_tiny', '3x3_many_chunks', '3x3s2_ragged', '3x3s2_multi_block', '3x3s2_odd_input',
+                              '7x7_stem', '7x7_ragged', '7x7_many_chunks'])
 def test_native_weight_gradient_exact(shape):
-    """csrc/conv2d_wgrad.hip (GEMM over pixels, K-split with a fixed-order second pass; stride 1 and 2) on small-integer data: every
-    partial sum is exact in fp32, so the result must equal the fp64 weight gradient bit for bit."""
+    """csrc/conv2d_wgrad.hip (GEMM over pixels, K-split with a fixed-order second pass; stride 1 and 2; the few-channel 7x7 form of the encoders' stem)
+    on small-integer data: every partial sum is exact in fp32, so the result must equal the fp64 weight gradient bit for bit."""
     from torch_utils.ops import conv2d_mfma
     n, cin, cout, h, w, k, st = shape
     gen = torch.Generator().manual_seed(n * 1000 + cin + st)

@@ -263,9 +263,9 @@ def run_stack(args, rank, world, dev, dist):
 def run_train(args, rank, world, dev, dist):
     """BASELINE config 4 (secondary, --mode train): iterations/s of the 8-phase fullbody G+D step incl. lazy R1, batch 4 per
     GPU, flat-bucket gradient exchange over RCCL overlapped with the last backward (training/ddp.py).  VGG/contextual losses
-    omitted (weights unavailable offline); input gradients of the fp32 convolutions run on the forward MFMA kernels (flipped,
-    O<->I transposed packs), weight gradients of the fp32 3x3 (stride 1 / 2, transposed) and 1x1 layers on csrc/conv2d_wgrad.hip; what is
-    left on aten::convolution_backward (MIOpen) is listed in DESIGN.md section 3.2c.  `roofline` = the largest kernel of the step,
+    omitted (weights unavailable offline).  Every convolution of the step is this package's: input gradients on the forward MFMA kernels (flipped, O<->I
+    transposed packs), weight gradients on csrc/conv2d_wgrad.hip (fp32 3x3 / 1x1 / transposed / the 7x7 stem; fp16 on channels-last operands); the training
+    route runs bias_act in the convolution epilogues, the SPADE combine and the modulated convolutions as native launches.  `roofline` = the largest kernel of the step,
     conv2d_wgrad<3,3,1>, timed with HIP events around its launches."""
     from training import networks, replicas
     from training.loss import StyleGAN2Loss

@@ -18,7 +18,7 @@ sys.path.insert(0, ROOT)
 import torch                                                      # noqa: E402
 
 
-def build(dev, n=4, d_fp16_res=4):
+def build(dev, n=4, d_fp16_res=3):
     from training import networks
     from training.loss import StyleGAN2Loss
     from training.training_step import TrainingStep
@@ -45,7 +45,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--top', type=int, default=70)
     ap.add_argument('--steps', type=int, default=2)
-    ap.add_argument('--d-fp16-res', type=int, default=4)
+    ap.add_argument("--d-fp16-res", type=int, default=3)
     args = ap.parse_args()
     dev = torch.device('cuda', 0)
     step, batch = build(dev, d_fp16_res=args.d_fp16_res)

@@ -201,14 +201,33 @@ __global__ __launch_bounds__(256 * TS + 256, 1) void conv2d_wgrad(WgradParams p)
         }
 }
 
-// dw[co][ci][tap] = sum_s ws[s][tap][co][ci] (s ascending)
+// dw[co][ci][tap] = sum_s ws[s][tap][co][ci].  256 threads = 64 consecutive elements x 4 split groups: group g adds the partials s = g, g + 4, ... in
+// ascending order (four independent load streams per element instead of one), the four group sums are folded in group order through LDS --
+// a fixed association, the same on every run.
 __global__ __launch_bounds__(256) void wgrad_reduce(const float* __restrict__ ws, float* __restrict__ dw, int splits, int T, int Cout, int Cin) {
+    __shared__ float part[4][64];
     const int64_t total = (int64_t)T * Cout * Cin;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int ci = (int)(i % Cin), co = (int)((i / Cin) % Cout), tp = (int)(i / ((int64_t)Cin * Cout));
+    const int e = threadIdx.x & 63, g = threadIdx.x >> 6;
+    for (int64_t i0 = (int64_t)blockIdx.x * 64; i0 < total; i0 += (int64_t)gridDim.x * 64) {
+        const int64_t i = i0 + e;
         float v = 0.f;
-        for (int z = 0; z < splits; z++) v += ws[(int64_t)z * total + i];
-        dw[((int64_t)co * Cin + ci) * T + tp] = v;
+        if (i < total) {
+            int z = g;
+            for (; z + 12 < splits; z += 16) {          // four loads in flight per thread
+                const float a = ws[(int64_t)z * total + i], b = ws[(int64_t)(z + 4) * total + i];
+                const float c = ws[(int64_t)(z + 8) * total + i], d = ws[(int64_t)(z + 12) * total + i];
+                v += a; v += b; v += c; v += d;
+            }
+            for (; z < splits; z += 4) v += ws[(int64_t)z * total + i];
+        }
+        part[g][e] = v;
+        __syncthreads();
+        if (g == 0 && i < total) {
+            const float r = ((part[0][e] + part[1][e]) + part[2][e]) + part[3][e];
+            const int ci = (int)(i % Cin), co = (int)((i / Cin) % Cout), tp = (int)(i / ((int64_t)Cin * Cout));
+            dw[((int64_t)co * Cin + ci) * T + tp] = r;
+        }
+        __syncthreads();
     }
 }
 
@@ -583,7 +602,7 @@ PG_EXPORT int pg_conv2d_wgrad(const float* x, const float* dy, float* dw, float*
         int st0 = pg::launch_status();
         if (st0 != PG_OK) return st0;
         const int64_t tot = (int64_t)KH * KW * Cout * Cin;
-        int64_t rb0 = (tot + 255) / 256;
+        int64_t rb0 = (tot + 63) / 64;
         if (rb0 > pg::max_stream_blocks()) rb0 = pg::max_stream_blocks();
         hipLaunchKernelGGL(wgrad_reduce, dim3((unsigned)rb0), dim3(256), 0, (hipStream_t)stream, workspace, dw, splits, 1, Cout, Cin * KH * KW);
         return pg::launch_status();
@@ -616,7 +635,7 @@ PG_EXPORT int pg_conv2d_wgrad(const float* x, const float* dy, float* dw, float*
     int st = pg::launch_status();
     if (st != PG_OK) return st;
     const int64_t total = (int64_t)KH * KW * Cout * Cin;
-    int64_t rb = (total + 255) / 256;
+    int64_t rb = (total + 63) / 64;
     if (rb > pg::max_stream_blocks()) rb = pg::max_stream_blocks();
     hipLaunchKernelGGL(wgrad_reduce, dim3((unsigned)rb), dim3(256), 0, s, workspace, dw, splits, KH * KW, Cout, Cin);
     return pg::launch_status();
@@ -672,7 +691,7 @@ PG_EXPORT int pg_conv2d16_wgrad(const void* x, const void* dy, float* dw, float*
     int st = pg::launch_status();
     if (st != PG_OK) return st;
     const int64_t total = (int64_t)KH * KW * Cout * Cin;
-    int64_t rb = (total + 255) / 256;
+    int64_t rb = (total + 63) / 64;
     if (rb > pg::max_stream_blocks()) rb = pg::max_stream_blocks();
     hipLaunchKernelGGL(wgrad_reduce, dim3((unsigned)rb), dim3(256), 0, s, workspace, dw, splits, KH * KW, Cout, Cin);
     return pg::launch_status();

@@ -184,9 +184,11 @@ __global__ __launch_bounds__(256) void splitk_finish16_vec4_kernel(const float* 
     }
 }
 
-// Streaming 1x1 head: one pixel per thread, all its channels in flight as 16-byte loads, the (<= 8) x Cin modulated weights
-// of the block's image in LDS (broadcast reads).  HBM-bound: 2*Cin bytes read + 4*Cout (+ 4*Cout skip) per pixel.
-template <typename T, int COUT>
+// Streaming 1x1 head: LP lanes per pixel (LP = 1 on large images: all of a pixel's channels in flight as 16-byte loads from one thread;
+// LP = 4 / 16 on small ones, where one thread per pixel would leave most of the chip idle behind a Cin / 8-step dependent loop: the lanes of a
+// pixel take the 16-byte channel groups round-robin and fold their sums with xor-shuffles), the (<= 8) x Cin modulated weights of the block's
+// image in LDS (broadcast reads).  HBM-bound: 2*Cin bytes read + 4*Cout (+ 4*Cout skip) per pixel.
+template <typename T, int COUT, int LP>
 __global__ __launch_bounds__(256) void conv1x1_small16_kernel(const unsigned short* __restrict__ x, const float* __restrict__ w, const float* __restrict__ styles,
                                                               const float* __restrict__ bias, const float* __restrict__ skip, float* __restrict__ y,
                                                               int Cin, int64_t HW, float clamp) {
@@ -199,12 +201,17 @@ __global__ __launch_bounds__(256) void conv1x1_small16_kernel(const unsigned sho
     __syncthreads();
     const float cl = clamp >= 0.f ? clamp : __builtin_inff();
     const unsigned short* xn = x + (int64_t)n * HW * Cin;
-    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < HW; p += (int64_t)gridDim.x * 256) {
-        const u32x4* px = (const u32x4*)(xn + p * Cin);
+    const int sub = threadIdx.x % LP;
+    constexpr int PPB = 256 / LP;                                     // pixels per block and pass
+    const int64_t npass = (HW + (int64_t)gridDim.x * PPB - 1) / ((int64_t)gridDim.x * PPB);      // every lane runs every pass: the shuffles below need whole groups
+    for (int64_t it = 0; it < npass; it++) {
+        const int64_t p = (it * gridDim.x + blockIdx.x) * PPB + threadIdx.x / LP;
+        const bool live = p < HW;
+        const u32x4* px = (const u32x4*)(xn + (live ? p : 0) * Cin);
         float acc[COUT];
 #pragma unroll
         for (int o = 0; o < COUT; o++) acc[o] = 0.f;
-        for (int c8 = 0; c8 < Cin / 8; c8 += 4) {                      // up to four 16-byte loads in flight per pass
+        for (int c8 = 4 * sub; c8 < Cin / 8; c8 += 4 * LP) {          // up to four 16-byte loads in flight per pass
             u32x4 v[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) if (c8 + u < Cin / 8) v[u] = px[c8 + u];
@@ -227,21 +234,29 @@ __global__ __launch_bounds__(256) void conv1x1_small16_kernel(const unsigned sho
                 }
             }
         }
+        if (LP > 1) {
 #pragma unroll
-        for (int o = 0; o < COUT; o++) {
-            float v = acc[o] + (bias ? bias[o] : 0.f);
-            v = fminf(fmaxf(v, -cl), cl);
-            const int64_t off = ((int64_t)n * COUT + o) * HW + p;
-            if (skip) v += skip[off];
-            y[off] = v;
+            for (int o = 0; o < COUT; o++)
+#pragma unroll
+                for (int m = LP / 2; m >= 1; m >>= 1) acc[o] += __shfl_xor(acc[o], m, 64);
+        }
+        if (live && sub == 0) {
+#pragma unroll
+            for (int o = 0; o < COUT; o++) {
+                float v = acc[o] + (bias ? bias[o] : 0.f);
+                v = fminf(fmaxf(v, -cl), cl);
+                const int64_t off = ((int64_t)n * COUT + o) * HW + p;
+                if (skip) v += skip[off];
+                y[off] = v;
+            }
         }
     }
 }
 
-template <typename T>
+template <typename T, int LP>
 int launch_small(int cout, dim3 grid, size_t lds, hipStream_t s, const unsigned short* x, const float* w, const float* styles, const float* bias,
                  const float* skip, float* y, int Cin, int64_t HW, float clamp) {
-#define PG_SMALL(C) case C: hipLaunchKernelGGL((conv1x1_small16_kernel<T, C>), grid, dim3(256), lds, s, x, w, styles, bias, skip, y, Cin, HW, clamp); break;
+#define PG_SMALL(C) case C: hipLaunchKernelGGL((conv1x1_small16_kernel<T, C, LP>), grid, dim3(256), lds, s, x, w, styles, bias, skip, y, Cin, HW, clamp); break;
     switch (cout) { PG_SMALL(1) PG_SMALL(2) PG_SMALL(3) PG_SMALL(4) PG_SMALL(5) PG_SMALL(6) PG_SMALL(7) PG_SMALL(8) default: return PG_ERR_UNSUPPORTED; }
 #undef PG_SMALL
     return pg::launch_status();
@@ -455,11 +470,25 @@ PG_EXPORT int pg_conv1x1_small16(const void* x, const float* w, const float* sty
     if (!x || !w || !y || N <= 0 || Cin <= 0 || HW <= 0 || Cout <= 0) return PG_ERR_INVALID_ARG;
     if (dtype != PG_BF16 && dtype != PG_F16) return PG_ERR_INVALID_ARG;
     if (Cout > 8 || Cin % 8 != 0 || (((uintptr_t)x) & 15) != 0 || (size_t)Cout * Cin * 4 > 64 * 1024) return PG_ERR_UNSUPPORTED;
-    int64_t bx = (HW + 255) / 256;
+    // lanes per pixel: enough threads for the whole chip on small images (256 CUs x 256 threads = 64 K lanes), never more lanes than 16-byte channel groups / 4
+    static const int lp_force = [] { const char* e = getenv("PG_HEAD16_LP"); return e ? atoi(e) : 0; }();
+    int lp = 1;
+    if ((int64_t)N * HW * 4 <= 65536 && Cin >= 128) lp = 4;
+    if ((int64_t)N * HW * 16 <= 65536 && Cin >= 512) lp = 16;
+    if (lp_force == 1 || lp_force == 4 || lp_force == 16) lp = lp_force;
+    const int ppb = 256 / lp;
+    int64_t bx = (HW + ppb - 1) / ppb;
     const int64_t cap = (int64_t)pg::max_stream_blocks() / N > 0 ? (int64_t)pg::max_stream_blocks() / N : 1;
     if (bx > cap) bx = cap;
     const dim3 grid((unsigned)bx, (unsigned)N);
     const size_t lds = (size_t)Cout * Cin * 4;
-    if (dtype == PG_BF16) return launch_small<bf16_t>(Cout, grid, lds, (hipStream_t)stream, (const unsigned short*)x, w, styles, bias, skip, y, Cin, HW, clamp);
-    return launch_small<f16_t>(Cout, grid, lds, (hipStream_t)stream, (const unsigned short*)x, w, styles, bias, skip, y, Cin, HW, clamp);
+    const hipStream_t st = (hipStream_t)stream;
+    const unsigned short* xs = (const unsigned short*)x;
+#define PG_HEAD(TT) (lp == 16 ? launch_small<TT, 16>(Cout, grid, lds, st, xs, w, styles, bias, skip, y, Cin, HW, clamp) \
+                   : lp == 4 ? launch_small<TT, 4>(Cout, grid, lds, st, xs, w, styles, bias, skip, y, Cin, HW, clamp) \
+                             : launch_small<TT, 1>(Cout, grid, lds, st, xs, w, styles, bias, skip, y, Cin, HW, clamp))
+    if (dtype == PG_BF16) return PG_HEAD(bf16_t);
+    return PG_HEAD(f16_t);
+#undef PG_HEAD
 }
+

@@ -290,9 +290,11 @@ def test_conv16_full_size_properties(dtype):
 
 
 @pytest.mark.parametrize('dtype', DTYPES, ids=['bf16', 'fp16'])
-def test_conv1x1_small_head(dtype):
+@pytest.mark.parametrize('shape', [(2, 64, 33, 47), (2, 512, 8, 8), (3, 256, 16, 24), (4, 1024, 4, 4), (1, 136, 9, 7)], ids=['one_lane', 'sixteen_lanes', 'four_lanes', 'tiny', 'ragged_groups'])
+def test_conv1x1_small_head(dtype, shape):
+    """The 16-bit ToRGB / parsing head (one streaming pass; 1, 4 or 16 lanes per pixel depending on the image size) against float64."""
     from torch_utils.ops import conv2d_mfma16 as M
-    n, cin, h, w = 2, 64, 33, 47
+    n, cin, h, w = shape
     gen = torch.Generator().manual_seed(13)
     x = torch.randn([n, cin, h, w], generator=gen).to(dtype)
     for cout in (3, 7):
@@ -304,7 +306,7 @@ def test_conv1x1_small_head(dtype):
         wm = wt.double()[None, :, :, 0, 0] * styles.double()[:, None, :]
         ref = torch.einsum('nchw,noc->nohw', x.double(), wm) + bias.double().reshape(1, -1, 1, 1)
         ref = ref.clamp(-3, 3) + skip.double()
-        assert float((y.double().cpu() - ref).abs().max()) <= 2e-4
+        assert float((y.double().cpu() - ref).abs().max()) <= 2e-4 * max(1.0, (cin / 64) ** 0.5)
 
 
 @pytest.mark.parametrize('dtype', DTYPES, ids=['bf16', 'fp16'])

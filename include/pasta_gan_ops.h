@@ -264,6 +264,24 @@ int pg_modconv_w2(const float* w, float* w2, int Cout, int Cin, int KHW, float s
 int pg_modconv_prep(const float* w2, const float* styles, float* out, float* s_norm, void* s16, int half_dtype,
                     int N, int Cout, int Cin, int normalize, int demodulate, void* stream);
 
+/* pg_modconv_prep for every modulated convolution of a network in one launch (the per-layer launches are ~8 us each, 15 per step of the 1024^2 stack).
+ * Job j = one pg_modconv_prep call: flags bit 0 = normalize, bit 1 = demodulate; `half_dtype` (PG_BF16 | PG_F16, or 0 when no job has an s16) is shared.
+ * The table is passed BY VALUE to the kernel (a captured hipGraph keeps it; nothing is copied to the device per call). */
+#define PG_MODCONV_PREP_MAX_JOBS 32
+typedef struct {
+    const float* w2[PG_MODCONV_PREP_MAX_JOBS];
+    const float* styles[PG_MODCONV_PREP_MAX_JOBS];
+    float*       out[PG_MODCONV_PREP_MAX_JOBS];
+    float*       s_norm[PG_MODCONV_PREP_MAX_JOBS];
+    void*        s16[PG_MODCONV_PREP_MAX_JOBS];
+    int          cout[PG_MODCONV_PREP_MAX_JOBS];
+    int          cin[PG_MODCONV_PREP_MAX_JOBS];
+    int          flags[PG_MODCONV_PREP_MAX_JOBS];
+    int          njobs;
+    int          half_dtype;
+} pg_modconv_prep_jobs;
+int pg_modconv_prep_batched(const pg_modconv_prep_jobs* jobs, int N, void* stream);
+
 /* Stride-2 transposed 3x3 convolution, all four output parities in one launch (csrc/conv2d_up2.h) -- the `up = 2` layers:
  * conv2d_gradfix.conv_transpose2d(stride=2, padding=0) behind conv2d_resample.py:125-142, with the modulation / demodulation of
  * networks.py:73-94 around it:

@@ -203,9 +203,9 @@ __global__ __launch_bounds__(256) void modconv_w2_kernel(const float* __restrict
 //   normalize != 0 (the half-precision pre-normalisation of networks.py:57-59):  smax = max(max_i |s[n,i]|, 1e-20), s' = s / smax,
 //       s_norm[n,i] = s' (float32) and, when s16 is given, the same rounded to bf16 / fp16;   otherwise s' = s
 //   out[n,o] = demodulate ? rsqrt(sum_i W2[o,i] * s'^2 + 1e-8) : smax
-__global__ __launch_bounds__(256) void modconv_prep_kernel(const float* __restrict__ w2, const float* __restrict__ styles, float* __restrict__ out,
-                                                           float* __restrict__ s_norm, unsigned short* __restrict__ s16, int half_dtype,
-                                                           int Cout, int Cin, int normalize, int demodulate) {
+__device__ __forceinline__ void modconv_prep_body(const float* __restrict__ w2, const float* __restrict__ styles, float* __restrict__ out,
+                                                  float* __restrict__ s_norm, unsigned short* __restrict__ s16, int half_dtype,
+                                                  int Cout, int Cin, int normalize, int demodulate) {
     extern __shared__ float sq[];                    // s'^2 of this sample
     __shared__ float red[4];
     const int n = blockIdx.y, t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -255,6 +255,21 @@ __global__ __launch_bounds__(256) void modconv_prep_kernel(const float* __restri
         for (int j = 0; j < 4; j++)
             if (o0 + j < Cout) out[(int64_t)n * Cout + o0 + j] = demodulate ? rsqrtf(acc[j] + 1e-8f) : smax;
     }
+}
+
+__global__ __launch_bounds__(256) void modconv_prep_kernel(const float* __restrict__ w2, const float* __restrict__ styles, float* __restrict__ out,
+                                                           float* __restrict__ s_norm, unsigned short* __restrict__ s16, int half_dtype,
+                                                           int Cout, int Cin, int normalize, int demodulate) {
+    modconv_prep_body(w2, styles, out, s_norm, s16, half_dtype, Cout, Cin, normalize, demodulate);
+}
+
+// Every modulated convolution of a network in ONE launch (grid z = job): the job table travels by value in the kernel arguments, so a captured
+// graph holds it and no host -> device copy is needed per call.
+__global__ __launch_bounds__(256) void modconv_prep_batched_kernel(pg_modconv_prep_jobs J) {
+    const int j = blockIdx.z;
+    const int Cout = J.cout[j];
+    if ((int)blockIdx.x * 16 >= Cout) return;            // grid x is sized for the widest job
+    modconv_prep_body(J.w2[j], J.styles[j], J.out[j], J.s_norm[j], (unsigned short*)J.s16[j], J.half_dtype, Cout, J.cin[j], J.flags[j] & 1, (J.flags[j] >> 1) & 1);
 }
 
 // ------------------------------------------------------------------ instance-norm statistics (two passes over one plane)
@@ -896,6 +911,23 @@ PG_EXPORT int pg_modconv_prep(const float* w2, const float* styles, float* out, 
     if (N > 65535 || (size_t)Cin * 4 > 64 * 1024) return PG_ERR_TOO_LARGE;
     hipLaunchKernelGGL(modconv_prep_kernel, dim3((unsigned)((Cout + 15) / 16), (unsigned)N), dim3(256), (size_t)Cin * 4, (hipStream_t)stream,
                        w2, styles, out, s_norm, (unsigned short*)s16, half_dtype, Cout, Cin, normalize, demodulate);
+    return pg::launch_status();
+}
+
+PG_EXPORT int pg_modconv_prep_batched(const pg_modconv_prep_jobs* jobs, int N, void* stream) {
+    if (!jobs || N <= 0 || N > 65535 || jobs->njobs <= 0 || jobs->njobs > PG_MODCONV_PREP_MAX_JOBS) return PG_ERR_INVALID_ARG;
+    if (jobs->half_dtype != 0 && jobs->half_dtype != PG_BF16 && jobs->half_dtype != PG_F16) return PG_ERR_INVALID_ARG;
+    int max_cout = 0, max_cin = 0;
+    for (int j = 0; j < jobs->njobs; j++) {
+        const int dem = (jobs->flags[j] >> 1) & 1;
+        if (!jobs->styles[j] || !jobs->out[j] || jobs->cout[j] <= 0 || jobs->cin[j] <= 0 || (dem && !jobs->w2[j])) return PG_ERR_INVALID_ARG;
+        if (jobs->s16[j] && !jobs->half_dtype) return PG_ERR_INVALID_ARG;
+        if (jobs->cout[j] > max_cout) max_cout = jobs->cout[j];
+        if (jobs->cin[j] > max_cin) max_cin = jobs->cin[j];
+    }
+    if ((size_t)max_cin * 4 > 64 * 1024) return PG_ERR_TOO_LARGE;
+    hipLaunchKernelGGL(modconv_prep_batched_kernel, dim3((unsigned)((max_cout + 15) / 16), (unsigned)N, (unsigned)jobs->njobs), dim3(256), (size_t)max_cin * 4,
+                       (hipStream_t)stream, *jobs);
     return pg::launch_status();
 }
 

@@ -115,6 +115,8 @@ def _init(plugin_name='conv2d_plugin'):
         lib.pg_modconv_w2.argtypes = [vp, vp, i, i, i, f, vp]
         lib.pg_modconv_prep.restype = i
         lib.pg_modconv_prep.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, i, vp]
+        lib.pg_modconv_prep_batched.restype = i
+        lib.pg_modconv_prep_batched.argtypes = [ctypes.POINTER(PrepJobs), i, vp]
         lib.pg_instance_norm_stats.restype = i
         lib.pg_instance_norm_stats.argtypes = [vp, vp, vp, i, i64, f, vp]
         lib.pg_spade_norm.restype = i
@@ -574,10 +576,61 @@ def modconv_w2(weight, scale=1.0):
     return w2
 
 
+PREP_MAX_JOBS = 32
+
+
+class PrepJobs(ctypes.Structure):
+    """pg_modconv_prep_jobs of include/pasta_gan_ops.h."""
+    _fields_ = [('w2', ctypes.c_void_p * PREP_MAX_JOBS), ('styles', ctypes.c_void_p * PREP_MAX_JOBS), ('out', ctypes.c_void_p * PREP_MAX_JOBS),
+                ('s_norm', ctypes.c_void_p * PREP_MAX_JOBS), ('s16', ctypes.c_void_p * PREP_MAX_JOBS), ('cout', ctypes.c_int * PREP_MAX_JOBS),
+                ('cin', ctypes.c_int * PREP_MAX_JOBS), ('flags', ctypes.c_int * PREP_MAX_JOBS), ('njobs', ctypes.c_int), ('half_dtype', ctypes.c_int)]
+
+
+_prep_registry = {}     # styles.data_ptr() -> (normalize, demodulate, half_dtype, (out, s_norm, s16)): results of modconv_prep_batched awaiting their layer
+
+
+def modconv_prep_batched(jobs, half_dtype=None):
+    """`modconv_prep` for a whole network in ONE launch.  jobs: list of (w2 | None, styles [N, Cin] float32 contiguous, cout, normalize, demodulate).
+    The results are parked in a registry keyed by the styles' address; the layer's own `modconv_prep(...)` call with the same arguments picks
+    its entry up (and removes it) instead of launching.  Call `modconv_prep_clear()` when the forward pass is over."""
+    lib = _init().lib
+    assert 0 < len(jobs) <= PREP_MAX_JOBS
+    table = PrepJobs()
+    table.njobs, table.half_dtype = len(jobs), (nat.PG_DTYPE[half_dtype] if half_dtype is not None else 0)
+    n = int(jobs[0][1].shape[0])
+    keep = []
+    for j, (w2, styles, cout, normalize, demodulate) in enumerate(jobs):
+        assert styles.dtype == torch.float32 and styles.is_contiguous() and styles.shape[0] == n
+        cin = int(styles.shape[1])
+        out = torch.empty([n, cout], dtype=torch.float32, device=styles.device)
+        s_norm = torch.empty_like(styles) if normalize else None
+        s16 = torch.empty([n, cin], dtype=half_dtype, device=styles.device) if (normalize and half_dtype is not None) else None
+        if demodulate:
+            w2 = _f32c(w2, 'w2')
+            assert tuple(w2.shape) == (cout, cin)
+        table.w2[j] = w2.data_ptr() if demodulate else None
+        table.styles[j], table.out[j] = styles.data_ptr(), out.data_ptr()
+        table.s_norm[j] = s_norm.data_ptr() if s_norm is not None else None
+        table.s16[j] = s16.data_ptr() if s16 is not None else None
+        table.cout[j], table.cin[j], table.flags[j] = int(cout), cin, int(bool(normalize)) | (int(bool(demodulate)) << 1)
+        keep.append((styles, w2))
+        _prep_registry[styles.data_ptr()] = (bool(normalize), bool(demodulate), half_dtype if normalize else None, (out, s_norm, s16), styles)
+    with torch.cuda.device(jobs[0][1].device):
+        st = lib.pg_modconv_prep_batched(ctypes.byref(table), n, nat.stream_of(jobs[0][1]))
+    nat.check(st, 'pg_modconv_prep_batched')
+
+
+def modconv_prep_clear():
+    _prep_registry.clear()
+
+
 def modconv_prep(w2, styles, cout, normalize=False, demodulate=True, half_dtype=None):
     """One launch per modulated convolution: returns (out [N, Cout], s_norm, s16).  out = demodulation coefficients of the
     (normalised, if `normalize`) styles, or the per-sample style maximum when not demodulating; s_norm / s16 = the
     normalised styles in float32 / `half_dtype` (None unless `normalize`)."""
+    hit = _prep_registry.pop(styles.data_ptr(), None) if _prep_registry else None
+    if hit is not None and hit[0] == bool(normalize) and hit[1] == bool(demodulate) and hit[2] == (half_dtype if normalize else None) and hit[3][0].shape[1] == cout:
+        return hit[3]
     lib = _init().lib
     styles = _f32c(styles.detach(), 'styles')
     n, cin = styles.shape

@@ -218,17 +218,13 @@ def _up2_transposed_phases_2x2(wt_iohw):
     return torch.cat(out, dim=1).contiguous()
 
 
-def _modconv_fast16(x, weight, styles, noise, up, padding, resample_filter, demodulate, flip_weight, cache, epilogue):
-    """bf16 / fp16 inference route: the reference's fused form (networks.py:85-94) -- per-sample weights
-    T(w * styles * dcoefs) -- packed by one small kernel, then ONE launch of the 16-bit MFMA convolution per output phase
-    with noise / bias / activation / gain / clamp (/ residual) in its epilogue.  up=2 with the usual 3x3 kernel and 4-tap
-    filter runs as four 3x3 launches on composite weights (`_up2_composite_phases`); other up=2 shapes as the transposed
-    convolution's phases followed by the FIR pass that also carries the tail."""
-    cout, cin, kh, kw = (int(v) for v in weight.shape)
-    n, _, h, w = x.shape
-    cache = cache if cache is not None else _PackCache()
-    ep = dict(epilogue) if epilogue else {}
-    w32, s32 = weight.detach().float(), styles.detach().float()
+def _modconv16_policy(weight_shape, hw, up, padding, resample_filter):
+    """Which form a 16-bit modulated convolution takes (pure host logic, shared by `_modconv_fast16` and the stack's batched style preparation):
+    (composite, merged_t, shared, tpad, fir_pad) -- `shared` = one weight pack for the batch with x * styles and demodulation as the epilogue scale."""
+    cout, cin, kh, kw = (int(v) for v in weight_shape)
+    h, w = (int(v) for v in hw)
+    tpad = fir_pad = None
+    merged_t = False
     composite = False
     if up == 2:
         fw, fh = upfirdn2d._get_filter_size(resample_filter)
@@ -260,6 +256,22 @@ def _modconv_fast16(x, weight, styles, noise, up, padding, resample_filter, demo
     merged_t = up == 2 and merged_t
     taps = 36 if composite else (16 if merged_t else kh * kw)
     shared = cout * taps > 2 * h * w and os.environ.get('PG_MODCONV16_SHARED', '1') != '0'
+
+    return composite, merged_t, shared, tpad, fir_pad
+
+
+def _modconv_fast16(x, weight, styles, noise, up, padding, resample_filter, demodulate, flip_weight, cache, epilogue):
+    """bf16 / fp16 inference route: the reference's fused form (networks.py:85-94) -- per-sample weights
+    T(w * styles * dcoefs) -- packed by one small kernel, then ONE launch of the 16-bit MFMA convolution per output phase
+    with noise / bias / activation / gain / clamp (/ residual) in its epilogue.  up=2 with the usual 3x3 kernel and 4-tap
+    filter runs as four 3x3 launches on composite weights (`_up2_composite_phases`); other up=2 shapes as the transposed
+    convolution's phases followed by the FIR pass that also carries the tail."""
+    cout, cin, kh, kw = (int(v) for v in weight.shape)
+    n, _, h, w = x.shape
+    cache = cache if cache is not None else _PackCache()
+    ep = dict(epilogue) if epilogue else {}
+    w32, s32 = weight.detach().float(), styles.detach().float()
+    composite, merged_t, shared, tpad, fir_pad = _modconv16_policy((cout, cin, kh, kw), (h, w), up, padding, resample_filter)
     out_scale = None
     w2 = cache.get(('w2',), [weight], lambda: conv2d_mfma.modconv_w2(w32)) if demodulate else None
     if shared:          # one launch: per-sample maximum, normalised styles (float32 + 16-bit), coefficients of the normalised styles
@@ -1269,11 +1281,36 @@ class SynthesisStack(nn.Module):
         x = img = None
         start = 0
         styles = self.all_styles(ws) if (ws.is_cuda and not torch.is_grad_enabled() and os.environ.get('PG_AFFINE_BATCHED', '1') != '0') else None
+        try:
+            if styles is not None and os.environ.get('PG_PREP_BATCHED', '1') != '0':
+                self._prepare_all(styles, bool(block_kwargs.get('force_fp32', False)))
+            for res in self.block_resolutions:
+                block = getattr(self, f'b{res}')
+                x, img = block(x, img, ws[:, start:start + block.num_conv + block.num_torgb], styles=styles[res] if styles is not None else None, **block_kwargs)
+                start += block.num_conv
+        finally:
+            conv2d_mfma.modconv_prep_clear()
+        return img
+
+    def _prepare_all(self, styles, force_fp32):
+        """Inference: the style preparation of every modulated 3x3 convolution of the stack (demodulation coefficients; for the layers that share one
+        weight pack also the per-sample normalised styles in 16 bits, networks.py:57-59) as ONE launch instead of one ~8 us launch per layer
+        (`pg_modconv_prep_batched`); each layer's own `modconv_prep` call then finds its result waiting.  The per-layer form is decided by the same
+        `_modconv16_policy` the layers use."""
+        jobs, half_dtype = [], None
         for res in self.block_resolutions:
             block = getattr(self, f'b{res}')
-            x, img = block(x, img, ws[:, start:start + block.num_conv + block.num_torgb], styles=styles[res] if styles is not None else None, **block_kwargs)
-            start += block.num_conv
-        return img
+            half = block.half_dtype is not None and not force_fp32
+            for k, (m, _, _) in enumerate(block.affine_layers()[:block.num_conv]):
+                cout = int(m.weight.shape[0])
+                shared = False
+                if half:
+                    shared = _modconv16_policy(m.weight.shape, (res // m.up, res // m.up), m.up, m.padding, m.resample_filter)[2]
+                    half_dtype = block.half_dtype
+                w2 = m._cache.get(('w2',), [m.weight], lambda m=m: conv2d_mfma.modconv_w2(m.weight.detach().float()))
+                jobs.append((w2, styles[res][k], cout, shared, True))
+        if jobs and len(jobs) <= conv2d_mfma.PREP_MAX_JOBS and len({j[1].shape[0] for j in jobs}) == 1:
+            conv2d_mfma.modconv_prep_batched(jobs, half_dtype=half_dtype)
 
 
 # ============================================================================

@@ -299,7 +299,10 @@ def _modconv_fast16(x, weight, styles, noise, up, padding, resample_filter, demo
         xcl = conv2d_mfma16.to_channels_last(x)
         res = ep.pop('residual', None)
         if noise is not None:           # phase-major copy of the noise map, one pass: [B, 2, 2, h, w]
-            noise_phases = noise.reshape(-1, h, 2, w, 2).permute(0, 2, 4, 1, 3).contiguous()
+            if noise.requires_grad or noise.ndim != 2:
+                noise_phases = noise.reshape(-1, h, 2, w, 2).permute(0, 2, 4, 1, 3).contiguous()
+            else:       # the constant noise map of inference (one tensor per parameter version, SynthesisLayer.forward): its phase-major copy is made once
+                noise_phases = cache.get(('noise_phases',), [noise], lambda: noise.reshape(-1, h, 2, w, 2).permute(0, 2, 4, 1, 3).contiguous())
         if conv2d_mfma16.phases_supported(cout) and os.environ.get('PG_UP2_MERGED', '1') != '0':
             # all four phases in ONE launch: their kernels stacked along Cout (block 2a + b), each cout block written to its own
             # output phase -- the input is read once, a quarter of the launches and of the split-K shares

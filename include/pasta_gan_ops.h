@@ -433,7 +433,10 @@ int pg_conv2d16_forward_splitk(const void* x, const void* packed, void* y, int d
  * dot product: y[n, o, p] = clamp(sum_c x[n, p, c] * w[o, c] * styles[n, c] + bias[o]) + skip[n, o, p], x 16-bit NHWC,
  * w float32 [Cout, Cin] (already scaled by weight_gain), y / skip float32 NCHW; Cout <= 8, Cin % 8 == 0. */
 int pg_conv1x1_small16(const void* x, const float* w, const float* styles, const float* bias, const float* skip, float* y,
-                       int dtype, int N, int Cin, int64_t HW, int Cout, float clamp, void* stream);
+                       int dtype, int N, int Cin, int64_t HW, int Cout, float clamp, int skip_up2_width, void* stream);
+/* skip_up2_width = 0: `skip` has y's shape.  skip_up2_width = W (the width of y, even; H = HW / W even): `skip` is the HALF-resolution image
+ * [N, Cout, H/2, W/2] and is up-sampled on the fly exactly as upfirdn2d.upsample2d does with the [1, 3, 3, 1] filter (networks.py:2165-2167 with
+ * upfirdn2d.py:308-342: zero insertion, padding (2, 1), gain 4) -- the skip image's own FIR launch per block disappears. */
 
 /* ------------------------------------------------------------------------
  * patch_routing_plugin.so -- the perspective warps of the data loader's patch routing (training/dataset.py:2555-2700; there:

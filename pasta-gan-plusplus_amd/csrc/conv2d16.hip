@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void splitk_finish16_vec4_kernel(const float* 
 template <typename T, int COUT, int LP>
 __global__ __launch_bounds__(256) void conv1x1_small16_kernel(const unsigned short* __restrict__ x, const float* __restrict__ w, const float* __restrict__ styles,
                                                               const float* __restrict__ bias, const float* __restrict__ skip, float* __restrict__ y,
-                                                              int Cin, int64_t HW, float clamp) {
+                                                              int Cin, int64_t HW, float clamp, int up_w) {
     extern __shared__ __attribute__((aligned(16))) float wl[];       // [COUT][Cin]
     const int n = blockIdx.y;
     for (int e = threadIdx.x; e < COUT * Cin; e += 256) {
@@ -246,7 +246,22 @@ __global__ __launch_bounds__(256) void conv1x1_small16_kernel(const unsigned sho
                 float v = acc[o] + (bias ? bias[o] : 0.f);
                 v = fminf(fmaxf(v, -cl), cl);
                 const int64_t off = ((int64_t)n * COUT + o) * HW + p;
-                if (skip) v += skip[off];
+                if (skip) {
+                    if (!up_w) {
+                        v += skip[off];
+                    } else {
+                        // skip = the HALF-resolution image, up-sampled here as upfirdn2d.upsample2d does with the [1, 3, 3, 1] filter (zero insertion, padding (2, 1),
+                        // gain 4): per axis an even output 2m takes x[m-1] / 4 + 3 x[m] / 4, an odd one 3 x[m] / 4 + x[m+1] / 4, zeros outside the image
+                        const int W = up_w, H = (int)(HW / W), hw = W >> 1, hh = H >> 1;
+                        const int oy = (int)(p / W), ox = (int)(p - (int64_t)oy * W);
+                        const int my = oy >> 1, mx = ox >> 1;
+                        const int y0 = (oy & 1) ? my : my - 1, x0 = (ox & 1) ? mx : mx - 1;          // the first of the two source rows / columns
+                        const float wy0 = (oy & 1) ? 0.75f : 0.25f, wx0 = (ox & 1) ? 0.75f : 0.25f;
+                        const float* sp = skip + ((int64_t)n * COUT + o) * hh * hw;
+                        auto at = [&](int yy, int xx) { return (yy >= 0 && yy < hh && xx >= 0 && xx < hw) ? sp[(int64_t)yy * hw + xx] : 0.f; };
+                        v += wy0 * (wx0 * at(y0, x0) + (1.f - wx0) * at(y0, x0 + 1)) + (1.f - wy0) * (wx0 * at(y0 + 1, x0) + (1.f - wx0) * at(y0 + 1, x0 + 1));
+                    }
+                }
                 y[off] = v;
             }
         }
@@ -255,8 +270,8 @@ __global__ __launch_bounds__(256) void conv1x1_small16_kernel(const unsigned sho
 
 template <typename T, int LP>
 int launch_small(int cout, dim3 grid, size_t lds, hipStream_t s, const unsigned short* x, const float* w, const float* styles, const float* bias,
-                 const float* skip, float* y, int Cin, int64_t HW, float clamp) {
-#define PG_SMALL(C) case C: hipLaunchKernelGGL((conv1x1_small16_kernel<T, C, LP>), grid, dim3(256), lds, s, x, w, styles, bias, skip, y, Cin, HW, clamp); break;
+                 const float* skip, float* y, int Cin, int64_t HW, float clamp, int up_w) {
+#define PG_SMALL(C) case C: hipLaunchKernelGGL((conv1x1_small16_kernel<T, C, LP>), grid, dim3(256), lds, s, x, w, styles, bias, skip, y, Cin, HW, clamp, up_w); break;
     switch (cout) { PG_SMALL(1) PG_SMALL(2) PG_SMALL(3) PG_SMALL(4) PG_SMALL(5) PG_SMALL(6) PG_SMALL(7) PG_SMALL(8) default: return PG_ERR_UNSUPPORTED; }
 #undef PG_SMALL
     return pg::launch_status();
@@ -466,8 +481,10 @@ PG_EXPORT int pg_conv2d16_forward_splitk(const void* x, const void* packed, void
 }
 
 PG_EXPORT int pg_conv1x1_small16(const void* x, const float* w, const float* styles, const float* bias, const float* skip, float* y,
-                                 int dtype, int N, int Cin, int64_t HW, int Cout, float clamp, void* stream) {
+                                 int dtype, int N, int Cin, int64_t HW, int Cout, float clamp, int skip_up2_width, void* stream) {
     if (!x || !w || !y || N <= 0 || Cin <= 0 || HW <= 0 || Cout <= 0) return PG_ERR_INVALID_ARG;
+    if (skip_up2_width < 0 || (skip_up2_width && (!skip || skip_up2_width % 2 || HW % skip_up2_width || (HW / skip_up2_width) % 2))) return PG_ERR_INVALID_ARG;
+    const int up_w = skip_up2_width;
     if (dtype != PG_BF16 && dtype != PG_F16) return PG_ERR_INVALID_ARG;
     if (Cout > 8 || Cin % 8 != 0 || (((uintptr_t)x) & 15) != 0 || (size_t)Cout * Cin * 4 > 64 * 1024) return PG_ERR_UNSUPPORTED;
     // lanes per pixel: enough threads for the whole chip on small images (256 CUs x 256 threads = 64 K lanes), never more lanes than 16-byte channel groups / 4
@@ -484,9 +501,9 @@ PG_EXPORT int pg_conv1x1_small16(const void* x, const float* w, const float* sty
     const size_t lds = (size_t)Cout * Cin * 4;
     const hipStream_t st = (hipStream_t)stream;
     const unsigned short* xs = (const unsigned short*)x;
-#define PG_HEAD(TT) (lp == 16 ? launch_small<TT, 16>(Cout, grid, lds, st, xs, w, styles, bias, skip, y, Cin, HW, clamp) \
-                   : lp == 4 ? launch_small<TT, 4>(Cout, grid, lds, st, xs, w, styles, bias, skip, y, Cin, HW, clamp) \
-                             : launch_small<TT, 1>(Cout, grid, lds, st, xs, w, styles, bias, skip, y, Cin, HW, clamp))
+#define PG_HEAD(TT) (lp == 16 ? launch_small<TT, 16>(Cout, grid, lds, st, xs, w, styles, bias, skip, y, Cin, HW, clamp, up_w) \
+                   : lp == 4 ? launch_small<TT, 4>(Cout, grid, lds, st, xs, w, styles, bias, skip, y, Cin, HW, clamp, up_w) \
+                             : launch_small<TT, 1>(Cout, grid, lds, st, xs, w, styles, bias, skip, y, Cin, HW, clamp, up_w))
     if (dtype == PG_BF16) return PG_HEAD(bf16_t);
     return PG_HEAD(f16_t);
 #undef PG_HEAD

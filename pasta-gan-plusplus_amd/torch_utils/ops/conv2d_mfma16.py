@@ -54,7 +54,7 @@ def _init():
         lib.pg_conv2d16_forward_splitk.restype = i
         lib.pg_conv2d16_forward_splitk.argtypes = fwd + [vp, i, vp]
         lib.pg_conv1x1_small16.restype = i
-        lib.pg_conv1x1_small16.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, i64, i, f, vp]
+        lib.pg_conv1x1_small16.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, i64, i, f, i, vp]
         lib.pg_conv2d16_wgrad_plan.restype = i
         lib.pg_conv2d16_wgrad_plan.argtypes = [i] * 8
         lib.pg_conv2d16_wgrad.restype = i
@@ -294,9 +294,10 @@ def conv_transpose2d_forward(x, packed_phases, cout, out_hw, stride=2, **fusion)
     return y
 
 
-def conv1x1_small(x, w, styles=None, bias=None, skip=None, clamp=None):
+def conv1x1_small(x, w, styles=None, bias=None, skip=None, clamp=None, skip_up2=False):
     """The ToRGB / parsing head (networks.py:1957-1967) as one streaming pass: float32 NCHW
-    clamp(sum_c x[n,c,p] * w[o,c] * styles[n,c] + bias[o]) + skip, x 16-bit channels-last, Cout <= 8."""
+    clamp(sum_c x[n,c,p] * w[o,c] * styles[n,c] + bias[o]) + skip, x 16-bit channels-last, Cout <= 8.  `skip_up2`: `skip` is the half-resolution
+    image [N, Cout, H/2, W/2]; it is up-sampled in the same pass as upfirdn2d.upsample2d(skip, [1, 3, 3, 1]) would."""
     lib = _init()
     x = to_channels_last(x)
     n, cin, h, wd = x.shape
@@ -306,11 +307,12 @@ def conv1x1_small(x, w, styles=None, bias=None, skip=None, clamp=None):
     styles, bias = _f32(styles, 'styles', n * cin), _f32(bias, 'bias', cout)
     y = torch.empty([n, cout, h, wd], dtype=torch.float32, device=x.device)
     if skip is not None:
-        if skip.dtype != torch.float32 or skip.shape != y.shape:
-            raise nat.NativeOpError('conv1x1_small: skip must be float32 [N, Cout, H, W]')
+        want = (n, cout, h // 2, wd // 2) if skip_up2 else tuple(y.shape)
+        if skip.dtype != torch.float32 or tuple(skip.shape) != want or (skip_up2 and (h % 2 or wd % 2)):
+            raise nat.NativeOpError('conv1x1_small: skip must be float32 [N, Cout, H, W] (or [N, Cout, H/2, W/2] with skip_up2)')
         skip = skip.contiguous()
     with torch.cuda.device(x.device):
         st = lib.pg_conv1x1_small16(nat.ptr(x), nat.ptr(w), nat.ptr(styles), nat.ptr(bias), nat.ptr(skip), nat.ptr(y), nat.PG_DTYPE[x.dtype],
-                                    n, cin, h * wd, cout, -1.0 if clamp is None else float(clamp), nat.stream_of(x))
+                                    n, cin, h * wd, cout, -1.0 if clamp is None else float(clamp), wd if (skip_up2 and skip is not None) else 0, nat.stream_of(x))
     nat.check(st, 'pg_conv1x1_small16')
     return y

@@ -931,6 +931,19 @@ class SynthesisLayer(nn.Module):
         return bias_act.bias_act(x, self.bias.to(x.dtype), act=self.activation, gain=act_gain, clamp=act_clamp)
 
 
+_1331_cache = {}
+
+
+def _is_1331(f):
+    """True for the FIR taps setup_filter([1, 3, 3, 1]) produces (2-D, normalised): decided once per filter tensor, on the host."""
+    key = (f.data_ptr(), f._version, tuple(f.shape))
+    if key not in _1331_cache:
+        ref = torch.tensor([1.0, 3.0, 3.0, 1.0])
+        ref = torch.outer(ref, ref) / 64.0
+        _1331_cache[key] = bool(f.ndim == 2 and tuple(f.shape) == (4, 4) and torch.equal(f.detach().float().cpu(), ref))
+    return _1331_cache[key]
+
+
 class _ToRGBBase(nn.Module):
     PARSING_CHANNELS = 7
 
@@ -948,17 +961,27 @@ class _ToRGBBase(nn.Module):
             self.m_bias1 = nn.Parameter(torch.zeros([self.PARSING_CHANNELS]))
         self._cache, self._cache_p = _PackCache(), _PackCache()
 
-    def forward(self, x, w, fused_modconv=True, skip_img=None, styles=None):
+    def forward(self, x, w, fused_modconv=True, skip_img=None, styles=None, skip_up2_filter=None):
         """Returns (rgb, pred_parsing); `skip_img` (private) is added to rgb inside the same launch; `styles` (private) =
-        affine(w) * weight_gain computed by the caller."""
+        affine(w) * weight_gain computed by the caller; `skip_up2_filter` (private): `skip_img` is the HALF-resolution image and
+        upfirdn2d.upsample2d(skip_img, skip_up2_filter) is what has to be added (networks.py:2165-2167)."""
         if styles is None:
             styles = self.affine(w) * self.weight_gain
         if _fast16_ok(x, self.weight, self.bias, styles, skip_img) and self.weight.shape[2:] == (1, 1):
-            # half-precision inference: each head is one streaming pass (float32 image out, skip image added in it)
+            # half-precision inference: each head is one streaming pass (float32 image out, skip image added in it -- up-sampled in it when it is the
+            # usual [1, 3, 3, 1] filter: the skip image's own FIR launch disappears)
+            up2 = False
+            if skip_up2_filter is not None and skip_img is not None:
+                if _is_1331(skip_up2_filter) and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 and skip_img.dtype == torch.float32 and os.environ.get('PG_HEAD16_UP2', '1') != '0':
+                    up2 = True
+                else:
+                    skip_img = upfirdn2d.upsample2d(skip_img, skip_up2_filter)
             pred_parsing = None
             if self.is_last and self.is_style:
                 pred_parsing = conv2d_mfma16.conv1x1_small(x, self.m_weight1, styles, self.m_bias1, clamp=self.conv_clamp)
-            return conv2d_mfma16.conv1x1_small(x, self.weight, styles, self.bias, skip=skip_img, clamp=self.conv_clamp), pred_parsing
+            return conv2d_mfma16.conv1x1_small(x, self.weight, styles, self.bias, skip=skip_img, clamp=self.conv_clamp, skip_up2=up2), pred_parsing
+        if skip_up2_filter is not None and skip_img is not None:
+            skip_img = upfirdn2d.upsample2d(skip_img, skip_up2_filter)
         fast = _fast_ok(x, self.weight, self.bias, styles, skip_img)
         if fast and conv2d_mfma.conv1x1_small_ok(x, self.weight, skip_img) and os.environ.get('PG_HEAD_STREAM', '1') != '0':
             # fp32 inference: each head is one streaming pass over x (HBM-bound; the MFMA kernel would pad it to 32 output channels)
@@ -1212,9 +1235,8 @@ class SynthesisStackBlock(nn.Module):
             x = self.conv1(x, ws[:, 0], styles=st[0], **layer_kwargs)
         else:
             x = self.conv1(self.conv0(x.to(**fmt), ws[:, 0], styles=st[0], **layer_kwargs), ws[:, 1], styles=st[1], **layer_kwargs)
-        if img is not None:
-            img = upfirdn2d.upsample2d(img, self.resample_filter)
-        rgb, _ = self.torgb(x, ws[:, self.num_conv], skip_img=img, styles=st[self.num_conv])
+        # img + torgb(x): the half-resolution image is handed over as it is; the head up-samples it in its own pass where it can (16-bit inference)
+        rgb, _ = self.torgb(x, ws[:, self.num_conv], skip_img=img, styles=st[self.num_conv], skip_up2_filter=self.resample_filter if img is not None else None)
         return x, rgb.to(dtype=torch.float32, memory_format=torch.contiguous_format)
 
 

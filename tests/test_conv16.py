@@ -307,6 +307,14 @@ def test_conv1x1_small_head(dtype, shape):
         ref = torch.einsum('nchw,noc->nohw', x.double(), wm) + bias.double().reshape(1, -1, 1, 1)
         ref = ref.clamp(-3, 3) + skip.double()
         assert float((y.double().cpu() - ref).abs().max()) <= 2e-4 * max(1.0, (cin / 64) ** 0.5)
+        if h % 2 == 0 and w % 2 == 0:      # the skip image handed over at half resolution, up-sampled in the same pass ([1, 3, 3, 1], as upsample2d does)
+            from torch_utils.ops import upfirdn2d
+            lo = torch.randn([n, cout, h // 2, w // 2], generator=gen)
+            f = upfirdn2d.setup_filter([1, 3, 3, 1])
+            up = upfirdn2d.upsample2d(lo, f)                      # the CPU route of the op (pinned against the goldens)
+            y2 = M.conv1x1_small(x.to(DEV), wt.to(DEV), styles.to(DEV), bias.to(DEV), lo.to(DEV), clamp=3.0, skip_up2=True)
+            ref2 = (ref - skip.double()) + up.double()
+            assert float((y2.double().cpu() - ref2).abs().max()) <= 2e-4 * max(1.0, (cin / 64) ** 0.5)
 
 
 @pytest.mark.parametrize('dtype', DTYPES, ids=['bf16', 'fp16'])

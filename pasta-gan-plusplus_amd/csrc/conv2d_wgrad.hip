@@ -173,19 +173,24 @@ __global__ __launch_bounds__(256 * TS + 256, 1) void conv2d_wgrad(WgradParams p)
                 for (int j = 0; j < TG; j++) bv[j] = b_base[(r * S) * G::IW + cc * S + tap_off(j)];
             }
         };
-        float a_cur, b_cur[TG], a_nxt, b_nxt[TG];
-        fetch(0, a_cur, b_cur);
-#pragma unroll 2
-        for (int kk = 0; kk < WG_PIX / 2; kk++) {                       // two adjacent pixels per step
-            if (kk + 1 < WG_PIX / 2) fetch(kk + 1, a_nxt, b_nxt);
+        // two operand register sets used alternately (steps kk, kk + 1 per trip): no register moves between steps (round 4: the one-set form spent
+        // 10 v_mov per 9 MFMAs, and on this part vector instructions and the f32 MFMA share the SIMD's issue time)
+        float a0, b0[TG], a1, b1[TG];
+        static_assert((WG_PIX / 2) % 2 == 0, "an even number of steps per chunk");
+        fetch(0, a0, b0);
+        for (int kk = 0; kk < WG_PIX / 2; kk += 2) {                    // two adjacent pixels per step
+            fetch(kk + 1, a1, b1);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int tp = 0; tp < TG; tp++)
-                if (TS == 1 || tp < ntap) acc[tp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, b_cur[tp], acc[tp], 0, 0, 0);
+                if (TS == 1 || tp < ntap) acc[tp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0[tp], acc[tp], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            a_cur = a_nxt;
+            if (kk + 2 < WG_PIX / 2) fetch(kk + 2, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int tp = 0; tp < TG; tp++) b_cur[tp] = b_nxt[tp];
+            for (int tp = 0; tp < TG; tp++)
+                if (TS == 1 || tp < ntap) acc[tp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1[tp], acc[tp], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
     }

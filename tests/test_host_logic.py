@@ -234,3 +234,19 @@ def test_winograd_launch_policy(monkeypatch):
     assert uw(3, 3, 1, 128, 128, pad=(1, 1), hw=(256, 256)) == 1
     monkeypatch.setenv('PG_CONV_ALGO', 'direct')
     assert uw(3, 3, 1, 128, 128, pad=(1, 1), hw=(256, 256)) == 0
+
+
+def test_modconv16_policy_is_pure_host_logic():
+    """The form a 16-bit modulated convolution takes (training/networks._modconv16_policy: composite up = 2 kernels, one shared weight pack for the
+    batch where weights outweigh activations) is decided from shapes alone -- the layers and the stack's batched style preparation must agree on it."""
+    import torch
+    from training import networks as PN
+    from torch_utils.ops import upfirdn2d
+    f = upfirdn2d.setup_filter([1, 3, 3, 1])
+    comp, merged, shared, tpad, fir_pad = PN._modconv16_policy((1024, 1024, 3, 3), (8, 8), 2, 1, f)
+    assert comp and not merged and shared and tuple(tpad) == (0, 0) and list(fir_pad) == [1, 1, 1, 1]
+    comp, merged, shared, tpad, fir_pad = PN._modconv16_policy((32, 64, 3, 3), (512, 512), 2, 1, f)
+    assert comp and not shared                                 # activations dominate: per-sample weights
+    comp, merged, shared, tpad, fir_pad = PN._modconv16_policy((512, 512, 3, 3), (64, 64), 1, 1, f)
+    assert not comp and not merged and shared == (512 * 9 > 2 * 64 * 64) and tpad is None
+    assert PN._is_1331(f) and not PN._is_1331(upfirdn2d.setup_filter([1, 2, 1])) and not PN._is_1331(upfirdn2d.setup_filter([1, 3, 3, 1]) * 2)

@@ -383,6 +383,27 @@ int pg_conv2d16_pack_weight_grouped(const float* w, void* packed, int dtype, int
                                     int Cout, int Cin, int KH, int KW, float scale, int flip_hw, int transpose_oi,
                                     const float* styles, const float* dcoefs, int nsamples, void* stream);
 
+/* The per-sample packs (styles and / or dcoefs given) of SEVERAL 3x3 layers in one launch -- the ~7 us pg_conv2d16_pack_weight launch per modulated
+ * convolution and step is what this removes.  Job j packs w[j] (OIHW, or IOHW when flags bit 1 = transpose_oi; bit 0 = flip_hw; all nine taps) into
+ * packed[j] ([nsamples][pg_conv2d16_packed_size(cout, cin, 3, 3)]) scaled by scale[j] * styles[j][n, ci] * dcoefs[j][n, co % dcoefs_mod[j]] (either may
+ * be NULL; dcoefs_mod < cout serves the four stacked phases of an up = 2 layer, which share one coefficient row).  The table is passed by value. */
+#define PG_CONV2D16_PACK_MAX_JOBS 16
+typedef struct {
+    const float* w[PG_CONV2D16_PACK_MAX_JOBS];
+    void*        packed[PG_CONV2D16_PACK_MAX_JOBS];
+    const float* styles[PG_CONV2D16_PACK_MAX_JOBS];
+    const float* dcoefs[PG_CONV2D16_PACK_MAX_JOBS];
+    int          cout[PG_CONV2D16_PACK_MAX_JOBS];
+    int          cin[PG_CONV2D16_PACK_MAX_JOBS];
+    int          flags[PG_CONV2D16_PACK_MAX_JOBS];
+    int          dcoefs_mod[PG_CONV2D16_PACK_MAX_JOBS];
+    float        scale[PG_CONV2D16_PACK_MAX_JOBS];
+    int          njobs;
+    int          nsamples;
+    int          dtype;
+} pg_conv2d16_pack_jobs;
+int pg_conv2d16_pack_weight_batched(const pg_conv2d16_pack_jobs* jobs, void* stream);
+
 /* Fused epilogue of pg_conv2d16_forward:  v = acc * out_scale[n,co] + noise[n?,oy,ox] * noise_gain + bias[co];
  * v = clamp(act(v) * gain);  y = T(v + residual).  Every pointer may be NULL; all vectors are float32. */
 typedef struct pg_conv2d16_fusion {

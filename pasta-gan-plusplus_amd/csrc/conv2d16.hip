@@ -22,13 +22,13 @@ struct TapSel { int ny, nx; int ys[8], xs[8]; };
 // of 16 * KH * KW floats (OIHW; one cache-line-coalesced run per cout), transposed through LDS, and written as T * 2 rows of
 // 64 x 16 bytes -- contiguous 1 KB segments of the packed layout.  Both sides of the transpose are coalesced.
 template <typename T, int KK>                                          // KK = KH * KW of the source weight (compile time: no runtime division)
-__global__ __launch_bounds__(256) void pack16_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, int Cout, int Cin, int KW, TapSel sel,
-                                                     int CinP, int CoutP, float scale, int flip, int transpose_oi,
-                                                     const float* __restrict__ styles, const float* __restrict__ dcoefs, int64_t per_sample,
-                                                     int nsamples, int64_t w_group_stride) {
+__device__ __forceinline__ void pack16_body(const float* __restrict__ w, unsigned short* __restrict__ out, int Cout, int Cin, int KW, const TapSel& sel,
+                                            int CinP, int CoutP, float scale, int flip, int transpose_oi,
+                                            const float* __restrict__ styles, const float* __restrict__ dcoefs, int dco_mod, int64_t per_sample,
+                                            int nsamples, int64_t w_group_stride, int cb, int k16, int z) {
     constexpr int RUN = 16 * KK, PITCH = RUN + 1;
     __shared__ float tile[64 * PITCH];                                 // [64 couts][16 channels][KK] (+1 pad per cout row)
-    const int z = blockIdx.z, n = z % nsamples, k16 = blockIdx.y, cb = blockIdx.x;      // z = group * nsamples + sample
+    const int n = z % nsamples;                                        // z = group * nsamples + sample; dcoefs row = [dco_mod] entries, indexed by cout % dco_mod
     w += (int64_t)(z / nsamples) * w_group_stride;
     const int KH = KK / KW, T_ = sel.ny * sel.nx;
     const int co0 = cb * 64, ci0 = k16 * 16;
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void pack16_kernel(const float* __restrict__ w
         for (int it = 0; it < 16; it++) {                              // one wave per cout: its 16 * KK floats are one contiguous run
             const int co = co0 + wave + 4 * it;
             const float* src = w + ((int64_t)(co < Cout ? co : 0) * Cin + ci0) * KK;
-            dsc[it] = (co < Cout ? scale : 0.f) * ((dcoefs && co < Cout) ? dcoefs[(int64_t)n * Cout + co] : 1.f);
+            dsc[it] = (co < Cout ? scale : 0.f) * ((dcoefs && co < Cout) ? dcoefs[(int64_t)n * dco_mod + co % dco_mod] : 1.f);
 #pragma unroll
             for (int k = 0; k < PER_ROW; k++) {
                 const int r = lane + 64 * k;
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void pack16_kernel(const float* __restrict__ w
 #pragma unroll
         for (int k = 0; k < PER_CH; k++) {
             const int col = (lane + 64 * k) / KK;
-            dco[k] = (dcoefs && co0 + col < Cout) ? dcoefs[(int64_t)n * Cout + co0 + col] : 1.f;
+            dco[k] = (dcoefs && co0 + col < Cout) ? dcoefs[(int64_t)n * dco_mod + (co0 + col) % dco_mod] : 1.f;
         }
 #pragma unroll
         for (int it = 0; it < 4; it++)
@@ -106,6 +106,30 @@ __global__ __launch_bounds__(256) void pack16_kernel(const float* __restrict__ w
         for (int d = 0; d < 4; d++) o[d] = Half16<T>::pack(src[(2 * d) * KK], src[(2 * d + 1) * KK]);
         *(u32x4*)(dst + ((int64_t)row * CoutP + co0 + col) * 8) = o;
     }
+}
+
+template <typename T, int KK>
+__global__ __launch_bounds__(256) void pack16_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, int Cout, int Cin, int KW, TapSel sel,
+                                                     int CinP, int CoutP, float scale, int flip, int transpose_oi,
+                                                     const float* __restrict__ styles, const float* __restrict__ dcoefs, int64_t per_sample,
+                                                     int nsamples, int64_t w_group_stride) {
+    pack16_body<T, KK>(w, out, Cout, Cin, KW, sel, CinP, CoutP, scale, flip, transpose_oi, styles, dcoefs, Cout, per_sample, nsamples, w_group_stride,
+                       blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// The per-sample 3x3 packs of every modulated convolution of a network in ONE launch (grid z = job * nsamples + sample; the job table travels by value).
+template <typename T>
+__global__ __launch_bounds__(256) void pack16_batched_kernel(pg_conv2d16_pack_jobs J) {
+    const int j = blockIdx.z / J.nsamples, n = blockIdx.z % J.nsamples;
+    const int Cout = J.cout[j], Cin = J.cin[j];
+    const int CinP = (Cin + 31) / 32 * 32, CoutP = (Cout + 63) / 64 * 64;
+    if ((int)blockIdx.x >= CoutP / 64 || (int)blockIdx.y >= CinP / 16) return;      // the grid is sized for the largest job
+    TapSel sel;
+    sel.ny = 3; sel.nx = 3;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { sel.ys[i] = i < 3 ? i : 0; sel.xs[i] = i < 3 ? i : 0; }
+    pack16_body<T, 9>(J.w[j], (unsigned short*)J.packed[j], Cout, Cin, 3, sel, CinP, CoutP, J.scale[j], J.flags[j] & 1, (J.flags[j] >> 1) & 1,
+                      J.styles[j], J.dcoefs[j], J.dcoefs_mod[j], (int64_t)CinP * 9 * CoutP, J.nsamples, 0, blockIdx.x, blockIdx.y, n);
 }
 
 template <typename T>
@@ -438,6 +462,24 @@ PG_EXPORT int pg_conv2d16_pack_weight_grouped(const float* w, void* packed, int 
                                               int Cout, int Cin, int KH, int KW, float scale, int flip_hw, int transpose_oi,
                                               const float* styles, const float* dcoefs, int nsamples, void* stream) {
     return pack_weight16(w, packed, dtype, ngroups, w_group_stride, Cout, Cin, KH, KW, nullptr, 0, nullptr, 0, scale, flip_hw, transpose_oi, styles, dcoefs, nsamples, stream);
+}
+
+PG_EXPORT int pg_conv2d16_pack_weight_batched(const pg_conv2d16_pack_jobs* jobs, void* stream) {
+    if (!jobs || jobs->njobs <= 0 || jobs->njobs > PG_CONV2D16_PACK_MAX_JOBS || jobs->nsamples <= 0) return PG_ERR_INVALID_ARG;
+    if (jobs->dtype != PG_BF16 && jobs->dtype != PG_F16) return PG_ERR_INVALID_ARG;
+    int gx = 0, gy = 0;
+    for (int j = 0; j < jobs->njobs; j++) {
+        if (!jobs->w[j] || !jobs->packed[j] || jobs->cout[j] <= 0 || jobs->cin[j] <= 0) return PG_ERR_INVALID_ARG;
+        if (jobs->dcoefs[j] && (jobs->dcoefs_mod[j] <= 0 || jobs->cout[j] % jobs->dcoefs_mod[j] != 0)) return PG_ERR_INVALID_ARG;
+        const int cx = round_up(jobs->cout[j], 64) / 64, cy = round_up(jobs->cin[j], 32) / 16;
+        if (cx > gx) gx = cx;
+        if (cy > gy) gy = cy;
+    }
+    if (gy > 65535 || (int64_t)jobs->njobs * jobs->nsamples > 65535) return PG_ERR_TOO_LARGE;
+    const dim3 grid((unsigned)gx, (unsigned)gy, (unsigned)(jobs->njobs * jobs->nsamples));
+    if (jobs->dtype == PG_BF16) hipLaunchKernelGGL((pack16_batched_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, *jobs);
+    else hipLaunchKernelGGL((pack16_batched_kernel<f16_t>), grid, dim3(256), 0, (hipStream_t)stream, *jobs);
+    return pg::launch_status();
 }
 
 // Dev hook (not part of include/pasta_gan_ops.h): device buffer of >= 4000 uint64 that PG_CONV16_DBG=32 fills with

@@ -620,6 +620,15 @@ def modconv_prep_batched(jobs, half_dtype=None):
     nat.check(st, 'pg_modconv_prep_batched')
 
 
+def modconv_prep_peek(styles):
+    """The demodulation coefficients [N, Cout] a `modconv_prep_batched` call is producing for `styles` (plain form: not normalised, demodulated), or None;
+    the entry stays for the layer."""
+    hit = _prep_registry.get(styles.data_ptr())
+    if hit is None or hit[0] or not hit[1]:
+        return None
+    return hit[3][0]
+
+
 def modconv_prep_clear():
     _prep_registry.clear()
 

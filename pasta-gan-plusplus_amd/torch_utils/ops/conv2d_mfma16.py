@@ -55,6 +55,8 @@ def _init():
         lib.pg_conv2d16_forward_splitk.argtypes = fwd + [vp, i, vp]
         lib.pg_conv1x1_small16.restype = i
         lib.pg_conv1x1_small16.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, i64, i, f, i, vp]
+        lib.pg_conv2d16_pack_weight_batched.restype = i
+        lib.pg_conv2d16_pack_weight_batched.argtypes = [ctypes.POINTER(PackJobs), vp]
         lib.pg_conv2d16_wgrad_plan.restype = i
         lib.pg_conv2d16_wgrad_plan.argtypes = [i] * 8
         lib.pg_conv2d16_wgrad.restype = i
@@ -112,6 +114,63 @@ def _f32(t, name, numel=None):
     if numel is not None and t.numel() != numel:
         raise nat.NativeOpError(f'conv2d_mfma16: {name} has {t.numel()} elements, expected {numel}')
     return t
+
+
+PACK_MAX_JOBS = 16
+
+
+class PackJobs(ctypes.Structure):
+    """pg_conv2d16_pack_jobs of include/pasta_gan_ops.h."""
+    _fields_ = [('w', ctypes.c_void_p * PACK_MAX_JOBS), ('packed', ctypes.c_void_p * PACK_MAX_JOBS), ('styles', ctypes.c_void_p * PACK_MAX_JOBS),
+                ('dcoefs', ctypes.c_void_p * PACK_MAX_JOBS), ('cout', ctypes.c_int * PACK_MAX_JOBS), ('cin', ctypes.c_int * PACK_MAX_JOBS),
+                ('flags', ctypes.c_int * PACK_MAX_JOBS), ('dcoefs_mod', ctypes.c_int * PACK_MAX_JOBS), ('scale', ctypes.c_float * PACK_MAX_JOBS),
+                ('njobs', ctypes.c_int), ('nsamples', ctypes.c_int), ('dtype', ctypes.c_int)]
+
+
+_pack_registry = {}     # (weight address, styles address) -> (dtype, flip, transpose_oi, packed, per, keep-alive): results of pack_weight_batched awaiting their layer
+
+
+def pack_weight_batched(jobs, dtype):
+    """The per-sample 3x3 packs of several modulated convolutions in ONE launch (pg_conv2d16_pack_weight_batched).  jobs: list of
+    (w float32 [O, I, 3, 3] -- [I, O, 3, 3] when transpose_oi --, flip, transpose_oi, styles [N, Cin], dcoefs [N, D] | None) with D dividing the
+    pack's Cout (the four stacked phases of an up = 2 layer share one coefficient row).  Results wait in a registry keyed by (w, styles) addresses for
+    the layer's own `pack_lookup`; `pack_clear()` empties it."""
+    lib = _init()
+    assert dtype in DTYPES and 0 < len(jobs) <= PACK_MAX_JOBS
+    table = PackJobs()
+    n = int(jobs[0][3].shape[0])
+    table.njobs, table.nsamples, table.dtype = len(jobs), n, nat.PG_DTYPE[dtype]
+    for j, (w, flip, transpose_oi, styles, dcoefs) in enumerate(jobs):
+        assert w.dtype == torch.float32 and w.is_contiguous() and w.is_cuda and tuple(w.shape[2:]) == (3, 3)
+        cin, cout = (int(w.shape[0]), int(w.shape[1])) if transpose_oi else (int(w.shape[1]), int(w.shape[0]))
+        assert styles.dtype == torch.float32 and styles.is_contiguous() and tuple(styles.shape) == (n, cin)
+        per = lib.pg_conv2d16_packed_size(cout, cin, 3, 3)
+        packed = torch.empty([n * per], dtype=dtype, device=w.device)
+        table.w[j], table.packed[j], table.styles[j] = w.data_ptr(), packed.data_ptr(), styles.data_ptr()
+        if dcoefs is not None:
+            assert dcoefs.dtype == torch.float32 and dcoefs.is_contiguous() and dcoefs.shape[0] == n and cout % int(dcoefs.shape[1]) == 0
+            table.dcoefs[j], table.dcoefs_mod[j] = dcoefs.data_ptr(), int(dcoefs.shape[1])
+        else:
+            table.dcoefs[j], table.dcoefs_mod[j] = None, cout
+        table.cout[j], table.cin[j], table.flags[j], table.scale[j] = cout, cin, int(bool(flip)) | (int(bool(transpose_oi)) << 1), 1.0
+        _pack_registry[(w.data_ptr(), styles.data_ptr())] = (dtype, bool(flip), bool(transpose_oi), packed, per, (w, styles, dcoefs))
+    with torch.cuda.device(jobs[0][0].device):
+        st = lib.pg_conv2d16_pack_weight_batched(ctypes.byref(table), nat.stream_of(jobs[0][0]))
+    nat.check(st, 'pg_conv2d16_pack_weight_batched')
+
+
+def pack_lookup(w, dtype, flip, transpose_oi, styles):
+    """(packed, per_sample_stride) a `pack_weight_batched` call left for this (weight, styles) pair, or None."""
+    if not _pack_registry or styles is None:
+        return None
+    hit = _pack_registry.pop((w.data_ptr(), styles.data_ptr()), None)
+    if hit is None or hit[0] != dtype or hit[1] != bool(flip) or hit[2] != bool(transpose_oi):
+        return None
+    return hit[3], hit[4]
+
+
+def pack_clear():
+    _pack_registry.clear()
 
 
 def pack_weight(w, dtype, scale=1.0, flip=False, transpose_oi=False, taps=None, styles=None, dcoefs=None):

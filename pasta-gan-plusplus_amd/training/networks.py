@@ -218,6 +218,20 @@ def _up2_transposed_phases_2x2(wt_iohw):
     return torch.cat(out, dim=1).contiguous()
 
 
+def _up2_composite_cached(cache, weight, flip_weight, resample_filter):
+    """The four composite 3x3 phase kernels of an up = 2 layer ({(a, b): [Cin, Cout, 3, 3]}), once per weight version."""
+    def build():
+        wt = weight.detach().float().transpose(0, 1)
+        return _up2_composite_phases((wt.flip([2, 3]) if flip_weight else wt).contiguous(), resample_filter.float())
+    return cache.get(('up2_composite', flip_weight), [weight], build)
+
+
+def _up2_wcat_cached(cache, weight, flip_weight, resample_filter):
+    """The same four kernels stacked along Cout ([Cin, 4 Cout, 3, 3]) for the one-launch form."""
+    return cache.get(('up2_cat', flip_weight), [weight],
+                     lambda: torch.cat(list(_up2_composite_cached(cache, weight, flip_weight, resample_filter).values()), dim=1).contiguous())
+
+
 def _modconv16_policy(weight_shape, hw, up, padding, resample_filter):
     """Which form a 16-bit modulated convolution takes (pure host logic, shared by `_modconv_fast16` and the stack's batched style preparation):
     (composite, merged_t, shared, tpad, fir_pad) -- `shared` = one weight pack for the batch with x * styles and demodulation as the epilogue scale."""
@@ -286,7 +300,8 @@ def _modconv_fast16(x, weight, styles, noise, up, padding, resample_filter, demo
         if shared:
             packed = cache.get(('shared', flip_weight, x.dtype), [weight], lambda: conv2d_mfma16.pack_weight(w32, x.dtype, flip=not flip_weight)[0])
             return conv2d_mfma16.conv2d_forward(x, packed, cout, kh, kw, pad=(padding, padding), sample_stride=0, out_scale=out_scale, noise=noise, **ep)
-        packed, per, _ = conv2d_mfma16.pack_weight(w32, x.dtype, flip=not flip_weight, styles=s32, dcoefs=dcoefs)
+        hit = conv2d_mfma16.pack_lookup(w32, x.dtype, not flip_weight, False, s32)           # packed with the rest of the stack's layers (SynthesisStack._prepare_all)?
+        packed, per = hit if hit is not None else conv2d_mfma16.pack_weight(w32, x.dtype, flip=not flip_weight, styles=s32, dcoefs=dcoefs)[:2]
         return conv2d_mfma16.conv2d_forward(x, packed, cout, kh, kw, pad=(padding, padding), sample_stride=per, noise=noise, **ep)
     out_hw = ((h - 1) * 2 - 2 * tpad[0] + kh, (w - 1) * 2 - 2 * tpad[1] + kw)
 
@@ -294,7 +309,7 @@ def _modconv_fast16(x, weight, styles, noise, up, padding, resample_filter, demo
         wt = w32.transpose(0, 1)
         return (wt.flip([2, 3]) if flip_weight else wt).contiguous()
     if composite:
-        phases = cache.get(('up2_composite', flip_weight), [weight], lambda: _up2_composite_phases(transposed_weight(), resample_filter.float()))
+        phases = _up2_composite_cached(cache, weight, flip_weight, resample_filter)
         y = torch.empty([n, cout, 2 * h, 2 * w], dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
         xcl = conv2d_mfma16.to_channels_last(x)
         res = ep.pop('residual', None)
@@ -306,12 +321,16 @@ def _modconv_fast16(x, weight, styles, noise, up, padding, resample_filter, demo
         if conv2d_mfma16.phases_supported(cout) and os.environ.get('PG_UP2_MERGED', '1') != '0':
             # all four phases in ONE launch: their kernels stacked along Cout (block 2a + b), each cout block written to its own
             # output phase -- the input is read once, a quarter of the launches and of the split-K shares
-            wcat = cache.get(('up2_cat', flip_weight), [weight], lambda: torch.cat(list(phases.values()), dim=1).contiguous())
+            wcat = _up2_wcat_cached(cache, weight, flip_weight, resample_filter)
             if shared:
                 packed = cache.get(('up2_cat_shared', flip_weight, x.dtype), [weight], lambda: conv2d_mfma16.pack_weight(wcat, x.dtype, transpose_oi=True)[0])
                 per = 0
             else:
-                packed, per, _ = conv2d_mfma16.pack_weight(wcat, x.dtype, transpose_oi=True, styles=s32, dcoefs=dcoefs.repeat(1, 4) if dcoefs is not None else None)
+                hit = conv2d_mfma16.pack_lookup(wcat, x.dtype, False, True, s32)
+                if hit is not None:
+                    packed, per = hit
+                else:
+                    packed, per, _ = conv2d_mfma16.pack_weight(wcat, x.dtype, transpose_oi=True, styles=s32, dcoefs=dcoefs.repeat(1, 4) if dcoefs is not None else None)
             conv2d_mfma16.conv2d_forward(xcl, packed, cout, 3, 3, pad=(1, 1), out_hw=(h, w), y=y, sample_stride=per, out_scale=out_scale,
                                          noise=noise_phases if noise is not None else None, phases=True, **ep)
             return y if res is None else y.add_(res)
@@ -1315,6 +1334,7 @@ class SynthesisStack(nn.Module):
                 start += block.num_conv
         finally:
             conv2d_mfma.modconv_prep_clear()
+            conv2d_mfma16.pack_clear()
         return img
 
     def _prepare_all(self, styles, force_fp32):
@@ -1334,8 +1354,35 @@ class SynthesisStack(nn.Module):
                     half_dtype = block.half_dtype
                 w2 = m._cache.get(('w2',), [m.weight], lambda m=m: conv2d_mfma.modconv_w2(m.weight.detach().float()))
                 jobs.append((w2, styles[res][k], cout, shared, True))
-        if jobs and len(jobs) <= conv2d_mfma.PREP_MAX_JOBS and len({j[1].shape[0] for j in jobs}) == 1:
-            conv2d_mfma.modconv_prep_batched(jobs, half_dtype=half_dtype)
+        if not (jobs and len(jobs) <= conv2d_mfma.PREP_MAX_JOBS and len({j[1].shape[0] for j in jobs}) == 1):
+            return
+        conv2d_mfma.modconv_prep_batched(jobs, half_dtype=half_dtype)
+        if half_dtype is None or os.environ.get('PG_PACK_BATCHED', '1') == '0':
+            return
+        # ... and the per-sample weight packs of the layers that do not share one pack (T(w * styles * dcoefs), networks.py:85-94), also one launch: each
+        # layer's `pack_lookup` finds its pack waiting.  The demodulation coefficients are the ones the launch above is producing (same stream: ordered).
+        packs = []
+        for res in self.block_resolutions:
+            block = getattr(self, f'b{res}')
+            if block.half_dtype is None or force_fp32:
+                continue
+            for k, (m, _, _) in enumerate(block.affine_layers()[:block.num_conv]):
+                if tuple(m.weight.shape[2:]) != (3, 3) or m.weight.dtype != torch.float32:
+                    continue
+                cout = int(m.weight.shape[0])
+                composite, merged_t, shared, _, _ = _modconv16_policy(m.weight.shape, (res // m.up, res // m.up), m.up, m.padding, m.resample_filter)
+                if shared or merged_t:
+                    continue
+                s = styles[res][k]
+                dcoefs = conv2d_mfma.modconv_prep_peek(s)
+                if dcoefs is None:
+                    continue
+                if m.up == 1:
+                    packs.append((m.weight.detach(), False, False, s, dcoefs))            # flip_weight = True for up = 1 layers: correlation, no flip
+                elif composite and conv2d_mfma16.phases_supported(cout) and os.environ.get('PG_UP2_MERGED', '1') != '0':
+                    packs.append((_up2_wcat_cached(m._cache, m.weight, False, m.resample_filter), False, True, s, dcoefs))
+        if 0 < len(packs) <= conv2d_mfma16.PACK_MAX_JOBS:
+            conv2d_mfma16.pack_weight_batched(packs, half_dtype)
 
 
 # ============================================================================

@@ -381,7 +381,7 @@ def secondary_runs(budget_s=200.0):
     t_start = time.perf_counter()
     for key, extra in (('config3_generator', ['--mode', 'generator', '--steps', '8', '--warmup', '3']),
                        ('config5_bf16_1024', ['--mode', 'bf16_1024', '--steps', '30', '--warmup', '10', '--no-cpu-baseline']),
-                       ('config4_train_step', ['--mode', 'train', '--steps', '5', '--warmup', '2', '--no-cpu-baseline'])):
+                       ('config4_train_step', ['--mode', 'train', '--steps', '10', '--warmup', '3', '--no-cpu-baseline'])):
         left = budget_s - (time.perf_counter() - t_start)
         if left < 20:
             out[key] = dict(error='skipped: time budget of the secondary runs used up')

@@ -1,22 +1,23 @@
 // Dev probe (GPU box): does vector-ALU work issued by ANOTHER wave on the same SIMD take matrix-pipe time from a wave that issues
-// fp32 MFMAs back to back?  One workgroup per CU of 4 or 8 waves: waves 0-3 (one per SIMD) run `iters` rounds of 8 independent
-// v_mfma_f32_32x32x2_f32; waves 4-7, when present, run `iters` rounds of `nvalu` dependent-free v_fma_f32 (mode 1) or nothing
+// bf16 MFMAs back to back?  One workgroup per CU of 4 or 8 waves: waves 0-3 (one per SIMD) run `iters` rounds of 8 independent
+// v_mfma_f32_32x32x16_bf16 (this copy: the 16-bit matrix pipe); waves 4-7, when present, run `iters` rounds of `nvalu` dependent-free v_fma_f32 (mode 1) or nothing
 // but s_sleep (mode 2).  Prints the MFMA waves' cycles per MFMA.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 template <int NVALU>
 __global__ __launch_bounds__(512) void k(float* out, long long* cyc, int iters, int mode) {
     const int wave = threadIdx.x >> 6;
     if (wave < 4) {
         f32x16 acc[8];
         for (int i = 0; i < 8; i++) for (int j = 0; j < 16; j++) acc[i][j] = 0.f;
-        float a = threadIdx.x * 1e-3f, b = 1.0f;
+        bf16x8 a, b; for (int j = 0; j < 8; j++) { a[j] = (__bf16)(threadIdx.x * 1e-3f + j); b[j] = (__bf16)1.0f; }
         const long long t0 = __builtin_readcyclecounter();
         for (int it = 0; it < iters; it++) {
 #pragma unroll
-            for (int i = 0; i < 8; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+            for (int i = 0; i < 8; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
         }
         const long long t1 = __builtin_readcyclecounter();
         float s = 0.f;

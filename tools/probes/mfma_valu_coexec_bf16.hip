@@ -8,9 +8,9 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 template <int NVALU>
-__global__ __launch_bounds__(512) void k(float* out, long long* cyc, int iters, int mode) {
+__global__ __launch_bounds__(768) void k(float* out, long long* cyc, int iters, int mode, int nmf) {
     const int wave = threadIdx.x >> 6;
-    if (wave < 4) {
+    if (wave < nmf) {
         f32x16 acc[8];
         for (int i = 0; i < 8; i++) for (int j = 0; j < 16; j++) acc[i][j] = 0.f;
         bf16x8 a, b; for (int j = 0; j < 8; j++) { a[j] = (__bf16)(threadIdx.x * 1e-3f + j); b[j] = (__bf16)1.0f; }
@@ -23,7 +23,7 @@ __global__ __launch_bounds__(512) void k(float* out, long long* cyc, int iters, 
         float s = 0.f;
         for (int i = 0; i < 8; i++) s += acc[i][0];
         if (s == 123.456f) out[0] = s;
-        if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 4 + wave] = t1 - t0;
+        if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 4 + (wave & 3)] = t1 - t0;
     } else if (mode == 1) {
         float v[8];
         for (int i = 0; i < 8; i++) v[i] = threadIdx.x * 1e-3f + i;
@@ -38,15 +38,15 @@ __global__ __launch_bounds__(512) void k(float* out, long long* cyc, int iters, 
         float s = 0.f;
         for (int i = 0; i < 8; i++) s += v[i];
         if (s == 123.456f) out[1] = s;
-        if ((threadIdx.x & 63) == 0) cyc[1024 + blockIdx.x * 4 + (wave - 4)] = t1 - t0;
+        if ((threadIdx.x & 63) == 0) cyc[1024 + blockIdx.x * 4 + (wave & 3)] = t1 - t0;
     }
 }
 template <int NVALU>
-void run(int waves, int mode, const char* what) {
+void run(int waves, int mode, const char* what, int nmf = 4) {
     float* out; long long* cyc;
     hipMalloc(&out, 64); hipMalloc(&cyc, 2 * 256 * 4 * 8); hipMemset(cyc, 0, 2 * 256 * 4 * 8);
     const int iters = 4000;
-    for (int rep = 0; rep < 2; rep++) hipLaunchKernelGGL((k<NVALU>), dim3(256), dim3(waves * 64), 0, 0, out, cyc, iters, mode);
+    for (int rep = 0; rep < 2; rep++) hipLaunchKernelGGL((k<NVALU>), dim3(256), dim3(waves * 64), 0, 0, out, cyc, iters, mode, nmf);
     hipDeviceSynchronize();
     long long h[2048];
     hipMemcpy(h, cyc, 2048 * 8, hipMemcpyDeviceToHost);
@@ -64,5 +64,8 @@ int main() {
     run<32>(8, 1, "+ partner: 32 v_fma per 8 MFMAs");
     run<64>(8, 1, "+ partner: 64 v_fma per 8 MFMAs");
     run<128>(8, 1, "+ partner: 128 v_fma per 8 MFMAs (VALU-saturating)");
+    run<8>(8, 0, "TWO MFMA waves per SIMD, no partner", 8);
+    run<32>(12, 1, "TWO MFMA waves per SIMD + partner: 32 v_fma per 8 MFMAs", 8);
+    run<128>(12, 1, "TWO MFMA waves per SIMD + partner: 128 v_fma per 8 MFMAs", 8);
     return 0;
 }

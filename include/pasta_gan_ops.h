@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 9
+#define PG_ABI_VERSION 10
 
 enum pg_dtype { PG_F32 = 0, PG_F16 = 1, PG_BF16 = 2, PG_F64 = 3 };
 
@@ -384,7 +384,7 @@ int pg_conv2d16_pack_weight_grouped(const float* w, void* packed, int dtype, int
                                     const float* styles, const float* dcoefs, int nsamples, void* stream);
 
 /* The per-sample packs (styles and / or dcoefs given) of SEVERAL 3x3 layers in one launch -- the ~7 us pg_conv2d16_pack_weight launch per modulated
- * convolution and step is what this removes.  Job j packs w[j] (OIHW, or IOHW when flags bit 1 = transpose_oi; bit 0 = flip_hw; all nine taps) into
+ * convolution and step is what this removes.  Job j packs w[j] (OIHW, or IOHW when flags bit 1 = transpose_oi; bit 0 = flip_hw; all nine taps -- or, flags bit 2, the six taps of a 3 x 2 kernel: the stack of pg_conv2d16_up2_fused, packed size of (cout, cin, 3, 2)) into
  * packed[j] ([nsamples][pg_conv2d16_packed_size(cout, cin, 3, 3)]) scaled by scale[j] * styles[j][n, ci] * dcoefs[j][n, co % dcoefs_mod[j]] (either may
  * be NULL; dcoefs_mod < cout serves the four stacked phases of an up = 2 layer, which share one coefficient row).  The table is passed by value. */
 #define PG_CONV2D16_PACK_MAX_JOBS 16
@@ -439,6 +439,23 @@ int pg_conv2d16_forward(const void* x, const void* packed, void* y, int dtype, i
                         int stride, int pad_y, int pad_x, int OH, int OW, int64_t w_sample_stride,
                         const int64_t ystride[4], int out_step_y, int out_step_x, int out_off_y, int out_off_x,
                         const pg_conv2d16_fusion* fusion, void* stream);
+
+/* Round 5 -- the reference's up-by-2 modulated 3x3 layer (conv2d_resample.py:125-142: conv_transpose2d stride 2, then upfirdn2d with the
+ * separable 4-tap filter, padding 1, gain 4; then noise / bias_act, networks.py:73-94) in ONE launch without the (2H+1)^2 intermediate and with
+ * half the tap-products of the composite four-phase launch above: the y half of the filter is folded into the weights on the host, the x half
+ * is applied to the accumulators in the epilogue (csrc/conv2d_up2f16.h).
+ *   packed: pg_conv2d16_pack_weight(transpose_oi) of the float32 stack [Cin, 4 * Cout, 3, 2], channel block p = 2a + b of it holding, for output
+ *           row parity a and intermediate column parity b, tap (ty, tx) = Ky_a[ty][kx(b, tx)] with Ky = (2 fy) (*)_y w (rows 4+a, 2+a, a of the
+ *           6-row result) and kx(0, .) = (2, 0), kx(1, .) = (none, 1): the plain transposed convolution along x
+ *           (training/networks.py `_up2_fused_weights` builds it);  w_sample_stride = 0 or pg_conv2d16_packed_size(4 * Cout, Cin, 3, 2).
+ *   fir_x:  2 * fx, applied as out[o] = sum_X fir_x[o + 2 - X] * z[X] over the 2W+1 intermediate columns.
+ *   y:      [N, Cout, 2H, 2W] 16-bit with ystride[1] == 1 (channels-last), written whole.
+ *   fusion: out_scale / bias [.., Cout], noise [N?, 4, H, W] phase-major (noise_phase_stride between the planes of output pixel parities
+ *           (a, b) = 2a + b), act / gain / clamp as pg_conv2d16_forward; no residual; phase_cout is ignored.
+ * Cin % 16 == 0, Cin >= 32, Cout % 32 == 0. */
+int pg_conv2d16_up2_fused(const void* x, const void* packed, void* y, int dtype, int N, int Cin, int H, int W, int Cout,
+                          int64_t w_sample_stride, const int64_t ystride[4], const float fir_x[4],
+                          const pg_conv2d16_fusion* fusion, void* stream);
 
 /* Split-K form for launches with fewer output tiles than CUs: `ksplit` launches-worth of workgroups each reduce Cin/ksplit
  * channels into float32 [ksplit][N][OH][OW][Cout] `workspace`; one pass sums the slices in fixed order, applies the

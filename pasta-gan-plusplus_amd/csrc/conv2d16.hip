@@ -3,6 +3,7 @@
 // conv2d_kernel16.h and is instantiated per geometry in conv2d16_inst_*.hip.
 #include <stdlib.h>
 #include "conv2d_kernel16.h"
+#include "conv2d_up2f16.h"
 
 namespace {
 
@@ -125,11 +126,16 @@ __global__ __launch_bounds__(256) void pack16_batched_kernel(pg_conv2d16_pack_jo
     const int CinP = (Cin + 31) / 32 * 32, CoutP = (Cout + 63) / 64 * 64;
     if ((int)blockIdx.x >= CoutP / 64 || (int)blockIdx.y >= CinP / 16) return;      // the grid is sized for the largest job
     TapSel sel;
-    sel.ny = 3; sel.nx = 3;
+    const bool k32 = (J.flags[j] >> 2) & 1;                            // a 3 x 2 kernel (the stack of pg_conv2d16_up2_fused) instead of 3 x 3
+    sel.ny = 3; sel.nx = k32 ? 2 : 3;
 #pragma unroll
-    for (int i = 0; i < 8; i++) { sel.ys[i] = i < 3 ? i : 0; sel.xs[i] = i < 3 ? i : 0; }
-    pack16_body<T, 9>(J.w[j], (unsigned short*)J.packed[j], Cout, Cin, 3, sel, CinP, CoutP, J.scale[j], J.flags[j] & 1, (J.flags[j] >> 1) & 1,
-                      J.styles[j], J.dcoefs[j], J.dcoefs_mod[j], (int64_t)CinP * 9 * CoutP, J.nsamples, 0, blockIdx.x, blockIdx.y, n);
+    for (int i = 0; i < 8; i++) { sel.ys[i] = i < 3 ? i : 0; sel.xs[i] = i < sel.nx ? i : 0; }
+    if (k32)
+        pack16_body<T, 6>(J.w[j], (unsigned short*)J.packed[j], Cout, Cin, 2, sel, CinP, CoutP, J.scale[j], J.flags[j] & 1, (J.flags[j] >> 1) & 1,
+                          J.styles[j], J.dcoefs[j], J.dcoefs_mod[j], (int64_t)CinP * 6 * CoutP, J.nsamples, 0, blockIdx.x, blockIdx.y, n);
+    else
+        pack16_body<T, 9>(J.w[j], (unsigned short*)J.packed[j], Cout, Cin, 3, sel, CinP, CoutP, J.scale[j], J.flags[j] & 1, (J.flags[j] >> 1) & 1,
+                          J.styles[j], J.dcoefs[j], J.dcoefs_mod[j], (int64_t)CinP * 9 * CoutP, J.nsamples, 0, blockIdx.x, blockIdx.y, n);
 }
 
 template <typename T>
@@ -551,3 +557,50 @@ PG_EXPORT int pg_conv1x1_small16(const void* x, const float* w, const float* sty
 #undef PG_HEAD
 }
 
+
+// The up = 2 modulated 3x3 layer with the y half of the resampling filter folded into the weights and its x half applied in the epilogue
+// (conv2d_up2f16.h).  See include/pasta_gan_ops.h.
+PG_EXPORT int pg_conv2d16_up2_fused(const void* x, const void* packed, void* y, int dtype, int N, int Cin, int H, int W, int Cout,
+                                    int64_t w_sample_stride, const int64_t ystride[4], const float fir_x[4],
+                                    const pg_conv2d16_fusion* fusion, void* stream) {
+    if (!x || !packed || !y || !ystride || !fir_x) return PG_ERR_INVALID_ARG;
+    if (dtype != PG_BF16 && dtype != PG_F16) return PG_ERR_INVALID_ARG;
+    if (N <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0 || w_sample_stride < 0) return PG_ERR_INVALID_ARG;
+    if (Cin % 16 != 0 || Cin < 32 || Cout % 32 != 0) return PG_ERR_UNSUPPORTED;                 // >= 2 K chunks per tile (two-role form), whole 32-cout blocks
+    if ((((uintptr_t)x) & 15) != 0 || (((uintptr_t)packed) & 15) != 0 || (((uintptr_t)y) & 15) != 0) return PG_ERR_UNSUPPORTED;
+    if (ystride[1] != 1 || ystride[0] % 8 != 0 || ystride[2] % 8 != 0 || ystride[3] % 8 != 0) return PG_ERR_UNSUPPORTED;      // 16-byte channels-last stores
+    if ((int64_t)N * H * W * Cin * 2 > 0x7fffffffLL) return PG_ERR_TOO_LARGE;
+    const int CoutP = round_up(4 * Cout, 64), CinP = round_up(Cin, 32);
+    const int64_t per_sample = (int64_t)CinP * 6 * CoutP;
+    if (w_sample_stride != 0 && w_sample_stride != per_sample) return PG_ERR_INVALID_ARG;
+    const int64_t w_bytes = (w_sample_stride ? (int64_t)N * per_sample : per_sample) * 2;
+    if (w_bytes > 0x7fffffffLL) return PG_ERR_TOO_LARGE;
+    const int64_t ext = 1 + (int64_t)(N - 1) * ystride[0] + (int64_t)(Cout - 1) + (int64_t)(2 * H - 1) * ystride[2] + (int64_t)(2 * W - 1) * ystride[3];
+    if (ext > 0x3fffffffLL) return PG_ERR_TOO_LARGE;
+    pgconv16::Up2fParams pp;
+    Conv16Params& p = pp.c;
+    p = Conv16Params();
+    p.x = x; p.wp = packed; p.y = y;
+    p.w_nstride = w_sample_stride; p.w_bytes = w_bytes; p.y_bytes = ext * 2;
+    p.N = N; p.Cin = Cin; p.xC = Cin; p.H = H; p.W = W; p.Cout = Cout; p.CoutP = CoutP; p.OH = 2 * H; p.OW = 2 * W;
+    p.pad_y = 1; p.pad_x = 1; p.ksplit = 1;
+    for (int i = 0; i < 4; i++) p.ys[i] = ystride[i];
+    p.osy = p.osx = 2; p.out_mode = pgconv16::OUT_VEC16;
+    if (fusion) {
+        p.f = *fusion;
+    } else {
+        pg_conv2d16_fusion z = {};
+        z.clamp = -1.f;
+        p.f = z;
+    }
+    if (p.f.residual || p.f.noise_phase_stride < 0) return PG_ERR_INVALID_ARG;
+    p.f.phase_cout = Cout;
+    if (p.f.gain == 0.f) p.f.gain = 1.f;
+    if (!(p.f.gain > 0.f)) return PG_ERR_UNSUPPORTED;
+    if (p.f.act == 0) p.f.act = PG_ACT_LINEAR;
+    if (p.f.act < PG_ACT_LINEAR || p.f.act > PG_ACT_SWISH) return PG_ERR_INVALID_ARG;
+    if (p.f.act > PG_ACT_LRELU) return PG_ERR_UNSUPPORTED;
+    if (p.f.act == PG_ACT_LRELU && (p.f.alpha < 0.f || p.f.alpha > 1.f)) return PG_ERR_UNSUPPORTED;
+    for (int i = 0; i < 4; i++) pp.fir[i] = fir_x[i];
+    return pgconv16::launch16_up2f(pp, dtype, (hipStream_t)stream);
+}

@@ -1,0 +1,349 @@
+// 16-bit `up = 2` modulated 3x3 layer in ONE launch with the FIR's x half in the epilogue (round 5).
+//
+// What it replaces in the reference: conv2d_resample's up-by-2 branch (torch_utils/ops/conv2d_resample.py:125-142): a stride-2
+// conv_transpose2d of the 3x3 kernel -> (2H+1) x (2W+1) intermediate, then upfirdn2d with the 4-tap filter (padding 1, gain 4)
+// -> 2H x 2W, then noise / bias_act (training/networks.py:73-94, 170-179).  The composite route of conv2d_kernel16.h folds BOTH
+// filter axes into the weights: four 3x3 phase kernels of the low-resolution input = 36 tap-products per input position where
+// the reference's transposed convolution has 9.  Here only the y axis is folded (the filter is separable, f = fy (x) fx):
+//
+//     zq[2q+a][X] = sum_{ty, kx} Ky_a[ty][kx] * x[q + ty - 1][(X - kx) / 2]     Ky = (2 fy) (*)_y w, phase a of it: 3 y taps
+//                   -- in x the plain transposed convolution: even X = 2r has 2 taps (x[r-1], x[r]), odd X = 2r+1 has one (x[r])
+//     out[2q+a][o] = sum_k (2 fx)[o + 2 - X] * zq[2q+a][X],  X = o-1 .. o+2     -- the x half of the FIR, in registers
+//
+// = 2 (a) x 3 (ty) x 3 (x tap / parity pairs) = 18 tap-products per position.  The MFMA's N axis runs along x (lane = position r,
+// D column), and a lane holds BOTH x parities of its position (phases (a, 0), (a, 1) are two accumulators), so the x filter needs
+// the neighbouring lanes' values only: two DPP wave shifts per accumulator register pair, no LDS exchange, no intermediate
+// rounding (the reference's half-precision path rounds the (2H+1)^2 intermediate to 16 bit; this does not), no barrier.
+// The price is one overlap column on either side of a tile: 30 of the 32 lanes of a tile produce output.
+//
+// GEMM view (as conv2d_kernel16.h): M = 4 phases x 32 couts (phase p = 2a + b: output row parity a, x parity b of the
+// INTERMEDIATE), N = 16 rows x 32 positions, K = Cin x (3 x 2 taps); taps with tx = 0 (sample r-1) exist for b = 0 only, so a
+// 16-channel step is 36 MFMAs per wave (24 + 12) behind 18 weight and 8 activation fragment reads.  Workgroup = 8 multiplying
+// waves (2 position rows each: 128 accumulator registers) + 4 loader waves (the two-role form of conv2d_kernel16.h: chunk requests
+// by 16-byte LDS-DMA two chunks ahead through three staging buffers, per-tile side loads), one workgroup per CU, persistent.
+//
+// Weights: pg_conv2d16_pack_weight of the [Cin, 4 * Cout, 3, 2] stack (phase-major along Cout; built on the host,
+// training/networks.py `_up2_fused_weights`); the loader gathers a workgroup's 4 x 32 rows from the four phase blocks and
+// never requests the (b = 1, tx = 0) taps (they are zero by construction; the range check of the descriptor fills them).
+//
+// Roofline: HBM at the top resolutions (2 * (numel(x) + numel(y)) bytes), MFMA below; executed flops = 2 * 18 * N*H*W*Cin*Cout
+// x 32/30 (overlap) against 2 * 9 * ... of SURVEY 8d's count for the transposed convolution.
+
+#pragma once
+#include "conv2d_kernel16.h"
+
+namespace pgconv16 {
+
+struct Up2fParams {
+    Conv16Params c;         // x [N,H,W,Cin]; wp = packed 3x2 stack; y [N, 2H, 2W, Cout] (ys strides); Cout = channels of y; f.phase_cout = Cout
+    float fir[4];           // 2 * fx: the x half of the filter with its share of the gain
+};
+
+struct Up2fGeo {
+    static constexpr int TH = 16, LW = 32, UW = 30;        // position rows, lanes (positions incl. one overlap column per side), useful positions
+    static constexpr int T = 6, BM = 128, KC = 16, SLOTS = 2, PER = 8, NBUF = 3;
+    static constexpr int IH_T = TH + 2, IW_T = LW + 1;
+    static constexpr int NPIX = IH_T * IW_T;               // 594 halo pixels
+    static constexpr int PLANE = 640;                      // slots per k-half plane: the halo is staged as [k-half][row][col] x 16 bytes, so that a wave's
+                                                           // ds_read_b128 (lanes 0-31: 32 consecutive pixels of plane 0, lanes 32-63: of plane 1) walks whole
+                                                           // 256-byte bank rows per 16 lanes -- conflict-free without a swizzle, and every tap shift is an
+                                                           // immediate offset from ONE lane address (the swizzled layout of conv2d_kernel16.h costs a register pair per shift)
+    static constexpr int NXS = 2 * PLANE;
+    static constexpr int NXS_PAD = (NXS + 255) / 256 * 256;
+    static constexpr int NWS = T * 2 * BM;                 // 1536 weight slots
+    static constexpr int LDS_BUF = NXS_PAD + NWS;          // 2816 = 11 x 256
+    static constexpr int NREQ = LDS_BUF / 256, NREQ_X = NXS_PAD / 256;
+    static constexpr int EPS = 64, NOISE = 4 * TH * LW;
+    static constexpr int EP_FLOATS = 2 * EPS + NOISE;
+    static constexpr size_t LDS_BYTES = (size_t)NBUF * LDS_BUF * 16 + (size_t)2 * EP_FLOATS * 4 + 256;
+    static_assert(LDS_BUF % 256 == 0 && NXS_PAD % 256 == 0, "request instructions of the four loader waves");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+};
+
+template <int CTRL> __device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+constexpr int DPP_WAVE_SHL1 = 0x130, DPP_WAVE_SHR1 = 0x138;     // lane l reads lane l + 1 / lane l - 1
+
+template <typename T>
+__global__ __launch_bounds__(THREADS + 64 * LOADERS, 3) void conv2d_up2f16(Up2fParams pp) {
+    const Conv16Params& p = pp.c;
+    typedef Up2fGeo G;
+    typedef Half16<T> HT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef const __attribute__((address_space(3))) i32x4* lds_v4;
+    typedef const __attribute__((address_space(3))) f32x4* lds_f4;
+    typedef const __attribute__((address_space(3))) float* lds_f;
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int total = p.total_tiles;
+    const int q8 = total >> 3, r8 = total & 7;
+    const int nchunks = p.Cin / G::KC;
+    const int pc = p.f.phase_cout;
+
+    // tile -> (n, first position row, position of lane 0, first cout), XCD-aware like conv2d_mfma16 (scalar unit)
+    auto decode = [&](int tile, int& n, int& q0, int& r0, int& m0) __attribute__((always_inline)) {
+        const int xcd = tile & 7;
+        unsigned L = (unsigned)((xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (tile >> 3));
+        unsigned q = div_magic(L, p.m_mblocks); const int mb = (int)(L - q * p.mblocks); L = q;
+        q = div_magic(L, p.m_tilesX); const int tx = (int)(L - q * p.tilesX); L = q;
+        q = div_magic(L, p.m_tilesY); const int ty = (int)(L - q * p.tilesY);
+        n = (int)q; q0 = ty * G::TH; r0 = tx * G::UW - 1; m0 = mb * 32;      // r0: the left overlap column
+    };
+
+    if (wave >= WAVES) {
+        // ---------------------------------------------------------------- loader waves: requests only
+        const int lw = wave - WAVES;
+        const unsigned smem_b = __builtin_amdgcn_readfirstlane(lds_offset(smem));
+        const unsigned side_b = smem_b + (unsigned)(G::NBUF * G::LDS_BUF) * 16u;
+        const unsigned dump_b = side_b + 2u * G::EP_FLOATS * 4u;
+        const i32x4 xrsrc = make_rsrc(p.x, (int64_t)p.N * p.H * p.W * p.xC * 2);
+        const i32x4 wrsrc = make_rsrc(p.wp, p.w_bytes);
+        const int lt = lw * 64 + lane;                                 // 0 .. 255
+        unsigned rel[G::NREQ], hyx[G::NREQ_X];
+#pragma unroll
+        for (int j = 0; j < G::NREQ; j++) {
+            const int s = j * 256 + lt;
+            rel[j] = SENTINEL;
+            if (j < G::NREQ_X) {
+                hyx[j] = 0x4000u;
+                const int c = s >= G::PLANE, qh = s - c * G::PLANE;
+                const int hy = qh / G::IW_T, hx = qh % G::IW_T;
+                if (qh < G::NPIX) {
+                    rel[j] = (unsigned)((hy * p.W + hx) * p.xC + c * 8) * 2u;
+                    hyx[j] = (unsigned)hy | ((unsigned)hx << 16);
+                }
+            } else {
+                const int e = s - G::NXS_PAD;
+                const int row = e >> 7, col = e & 127;                 // row = tap * 2 + k-half; col = phase * 32 + cout
+                const int ph = col >> 5, tap = row >> 1;
+                const bool zero = (ph & 1) && !(tap & 1);              // x parity 1 has no tx = 0 tap
+                if (!zero) rel[j] = (unsigned)(row * p.CoutP + ph * pc + (col & 31)) * 16u;
+            }
+        }
+        const bool side_scale = lw == 0, side_bias = lw == 1;
+        const i32x4 sbrsrc = side_scale ? make_rsrc(p.f.out_scale, p.f.out_scale ? (int64_t)p.N * pc * 4 : 0)
+                                        : make_rsrc(p.f.bias, (p.f.bias && side_bias) ? (int64_t)pc * 4 : 0);
+        const i32x4 nrsrc = make_rsrc(p.f.noise, p.f.noise ? ((int64_t)(p.N - 1) * p.f.noise_batch_stride + 3 * p.f.noise_phase_stride + (int64_t)p.H * p.W) * 4 : 0);
+
+        int c_tile = blockIdx.x, c_chunk = 0, c_ahead = 0, ibuf = 0;
+        unsigned voff[G::NREQ_X];
+        unsigned w_soff = 0, x_soff0 = 0;
+        auto issue_next = [&]() __attribute__((always_inline)) {
+            if (c_chunk == 0) {
+                int n, q0, r0, m0;
+                decode(c_tile, n, q0, r0, m0);
+                const int ty0 = q0 - 1, tx0 = r0 - 1;
+                const unsigned org = (unsigned)((ty0 * p.W + tx0) * p.xC * 2);
+                const bool interior = ty0 >= 0 && tx0 >= 0 && ty0 + G::IH_T <= p.H && tx0 + G::IW_T <= p.W;
+#pragma unroll
+                for (int j = 0; j < G::NREQ_X; j++) {
+                    if (interior) {
+                        voff[j] = org + rel[j];
+                    } else {
+                        const unsigned gy = (unsigned)(ty0 + (int)(hyx[j] & 0xffffu)), gx = (unsigned)(tx0 + (int)(hyx[j] >> 16));
+                        voff[j] = (gy < (unsigned)p.H && gx < (unsigned)p.W) ? org + rel[j] : SENTINEL;
+                    }
+                }
+                x_soff0 = (unsigned)((int64_t)n * p.H * p.W * p.xC * 2);
+                w_soff = (unsigned)(((int64_t)n * p.w_nstride + (int64_t)m0 * 8) * 2);
+                // per-tile side loads: 32 demodulation scales, 32 biases, 4 x 512 noise samples (tile T's into side buffer T & 1)
+                const unsigned sb_ = side_b + (unsigned)((c_ahead & 1) * G::EP_FLOATS) * 4u;
+                const bool live = (side_scale || side_bias) && lane < 32 && m0 + lane < pc;
+                dma4(sbrsrc, (side_scale || side_bias) ? sb_ + (unsigned)(lw * 64) * 4u : dump_b, live ? (unsigned)lane * 4u : SENTINEL,
+                     (unsigned)(m0 + (side_scale ? n * pc : 0)) * 4u);
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    const int tt = (j * LOADERS + lw) * 64 + lane;
+                    const int nq = q0 + tt / G::LW, nr = r0 + tt % G::LW;
+                    const unsigned nvo = (nq < p.H && nr >= 0 && nr < p.W) ? (unsigned)(nq * p.W + nr) * 4u : SENTINEL;
+#pragma unroll
+                    for (int ph = 0; ph < 4; ph++)
+                        dma4(nrsrc, sb_ + (unsigned)(2 * G::EPS + ph * (G::TH * G::LW) + (j * LOADERS + lw) * 64) * 4u, nvo,
+                             (unsigned)(n * p.f.noise_batch_stride + ph * p.f.noise_phase_stride) * 4u);
+                }
+            }
+            const unsigned x_soff = x_soff0 + (unsigned)(c_chunk * G::KC) * 2u;
+            const unsigned wk_soff = w_soff + (unsigned)(c_chunk * G::T * 2) * (unsigned)p.CoutP * 16u;
+            const unsigned buf_b = smem_b + (unsigned)(ibuf * G::LDS_BUF) * 16u;
+#pragma unroll
+            for (int j = 0; j < G::NREQ; j++) {
+                const bool is_w = j >= G::NREQ_X;
+                dma16(is_w ? wrsrc : xrsrc, buf_b + (unsigned)(j * 256 + lw * 64) * 16u, is_w ? rel[j] : voff[j], is_w ? wk_soff : x_soff);
+            }
+            ibuf = ibuf == G::NBUF - 1 ? 0 : ibuf + 1;
+            if (++c_chunk == nchunks) { c_chunk = 0; c_tile += gridDim.x; c_ahead++; }
+        };
+        const int my_chunks = ((total - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x) * nchunks;
+        int req = 0;
+#pragma unroll
+        for (int j = 0; j < G::NBUF - 1; j++)
+            if (req < my_chunks) { issue_next(); req++; }
+        for (int c = 0; c < my_chunks; c++) {
+            // chunk c must have landed; chunk c + 1's requests (and, in front of them, its tile's side loads) may stay in flight
+            if (req > c + 1) vm_wait<G::NREQ>(); else vm_wait<0>();
+            __builtin_amdgcn_s_barrier();
+            if (req < my_chunks) { issue_next(); req++; }               // into the buffer of chunk c - 1: every multiplying wave is past it
+        }
+        return;
+    }
+
+    // -------------------------------------------------------------------- multiplying waves
+    const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)(p.y_bytes > 0x7fffffffLL ? 0x7fffffffLL : p.y_bytes), 0x00020000);
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int ph = 0; ph < 4; ph++)
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+            for (int k = 0; k < 16; k++) acc[ph][nt][k] = 0.f;
+
+    // operand addresses: ONE lane address per operand, every tap / row / phase an immediate offset
+    const unsigned b_lane = (unsigned)(half * G::PLANE + (2 * wave) * G::IW_T + l31) * 16u;
+    const unsigned a_lane = (unsigned)(G::NXS_PAD + half * G::BM + l31) * 16u;
+
+    // One 16-channel chunk: 18 weight fragments (ty, tx, phase), each multiplied with the two position rows of the wave.  The loop is
+    // written as a software pipeline by hand -- the weight fragment of step i + 1 is requested before the MFMAs of step i, the activation
+    // fragments rotate through FOUR registers sets (row ty leaves after its last use, row ty + 2 takes its place) -- and pinned with
+    // sched_barrier: left to itself the scheduler (at the register limit) sinks every read to its first use and waits lgkmcnt(0) there.
+    auto compute_chunk = [&](int buf) __attribute__((always_inline)) {
+        const unsigned char* bb = smem + (size_t)buf * G::LDS_BUF * 16 + b_lane;
+        const unsigned char* ab = smem + (size_t)buf * G::LDS_BUF * 16 + a_lane;
+        auto b_frag = [&](int hr, int tx) __attribute__((always_inline)) { return *(lds_v4)(bb + (size_t)(hr * G::IW_T + tx) * 16); };
+        auto a_frag = [&](int i) __attribute__((always_inline)) {      // step i -> (ty, tx, phase): ty-major; per ty: tx = 1 x phases 0..3, then tx = 0 x phases 0, 2
+            const int ty = i / 6, r = i % 6, tx = r < 4 ? 1 : 0, ph = r < 4 ? r : (r - 4) * 2;
+            return *(lds_v4)(ab + (size_t)((ty * 2 + tx) * 2 * G::BM + ph * 32) * 16);
+        };
+        i32x4 b1[4], b0[4];                                           // [halo row] for tx = 1 / tx = 0; at most four of the eight are live
+        b1[0] = b_frag(0, 1); b1[1] = b_frag(1, 1);
+        i32x4 a_cur = a_frag(0), a_nxt;
+        b0[0] = b_frag(0, 0); b0[1] = b_frag(1, 0);
+#pragma unroll
+        for (int i = 0; i < 18; i++) {
+            const int ty = i / 6, r = i % 6, tx = r < 4 ? 1 : 0, ph = r < 4 ? r : (r - 4) * 2;
+            if (i + 1 < 18) a_nxt = a_frag(i + 1);
+            if (ty < 2 && r == 3) b1[ty + 2] = b_frag(ty + 2, 1);      // row ty of the tx = 1 column has had its last use in this step's first MFMA ... (requested before: a new register set)
+            if (ty < 2 && r == 5) b0[ty + 2] = b_frag(ty + 2, 0);
+            const i32x4 blo = tx ? b1[ty] : b0[ty], bhi = tx ? b1[ty + 1] : b0[ty + 1];
+            acc[ph][0] = HT::mma(a_cur, blo, acc[ph][0]);
+            acc[ph][1] = HT::mma(a_cur, bhi, acc[ph][1]);
+            a_cur = a_nxt;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    const float gain = p.f.gain;
+    const float cl = p.f.clamp >= 0.f ? p.f.clamp : __builtin_inff();
+    const float slope = act_slope(p.f.act, p.f.alpha);
+    const bool has_scale = p.f.out_scale != nullptr;
+    const float noise_gain = p.f.noise ? p.f.noise_gain : 0.f;
+    const float f0 = pp.fir[0], f1 = pp.fir[1], f2 = pp.fir[2], f3 = pp.fir[3];
+
+    auto write_tile = [&](int tile, int dpar) __attribute__((always_inline)) {
+        int e_n, e_q0, e_r0, e_m0;
+        decode(tile, e_n, e_q0, e_r0, e_m0);
+        const unsigned char* side = smem + (size_t)G::NBUF * G::LDS_BUF * 16 + (size_t)dpar * G::EP_FLOATS * 4;
+        const int r = e_r0 + l31;
+        const bool col_ok = l31 >= 1 && l31 <= G::UW && r < p.W;
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++) {
+            const int row_l = 2 * wave + nt, q = e_q0 + row_l;
+            const bool pos_ok = col_ok && q < p.H;
+#pragma unroll
+            for (int a = 0; a < 2; a++) {
+                const int oy = 2 * q + a;
+                const float nze = *(lds_f)(side + (size_t)(2 * G::EPS + (2 * a) * (G::TH * G::LW) + row_l * G::LW + l31) * 4) * (noise_gain * gain);
+                const float nzo = *(lds_f)(side + (size_t)(2 * G::EPS + (2 * a + 1) * (G::TH * G::LW) + row_l * G::LW + l31) * 4) * (noise_gain * gain);
+                const unsigned pix_off = (unsigned)((int64_t)e_n * p.ys[0] + (int64_t)oy * p.ys[2] + (int64_t)(2 * r) * p.ys[3]);
+#pragma unroll
+                for (int g0 = 0; g0 < 4; g0 += 2) {
+                    u32x2 oe[2], oo[2];
+#pragma unroll
+                    for (int gg = 0; gg < 2; gg++) {
+                        const int g = g0 + gg;
+                        const int r0c = 8 * g + 4 * half;
+                        f32x4 sgv = *(lds_f4)(side + (size_t)r0c * 4), bgv = *(lds_f4)(side + (size_t)(G::EPS + r0c) * 4);
+                        sgv = has_scale ? sgv * gain : f32x4{gain, gain, gain, gain};
+                        bgv = bgv * gain;
+                        float ve[4], vo[4];
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            const float z0 = acc[2 * a][nt][4 * g + j], z1 = acc[2 * a + 1][nt][4 * g + j];
+                            const float z1m = dpp_f<DPP_WAVE_SHR1>(z1), z0p = dpp_f<DPP_WAVE_SHL1>(z0), z1p = dpp_f<DPP_WAVE_SHL1>(z1);
+                            const float he = fmaf(f3, z1m, fmaf(f2, z0, fmaf(f1, z1, f0 * z0p)));
+                            const float ho = fmaf(f3, z0, fmaf(f2, z1, fmaf(f1, z0p, f0 * z1p)));
+                            const float ue = fmaf(he, sgv[j], bgv[j] + nze), uo = fmaf(ho, sgv[j], bgv[j] + nzo);
+                            ve[j] = __builtin_amdgcn_fmed3f(fmaxf(ue, ue * slope), -cl, cl);
+                            vo[j] = __builtin_amdgcn_fmed3f(fmaxf(uo, uo * slope), -cl, cl);
+                        }
+                        oe[gg][0] = HT::pack(ve[0], ve[1]); oe[gg][1] = HT::pack(ve[2], ve[3]);
+                        oo[gg][0] = HT::pack(vo[0], vo[1]); oo[gg][1] = HT::pack(vo[2], vo[3]);
+                    }
+                    // lanes 32-63 of group g0 <-> lanes 0-31 of group g0 + 1: 8 consecutive couts of one pixel per lane
+#pragma unroll
+                    for (int d = 0; d < 2; d++) {
+                        const auto re = __builtin_amdgcn_permlane32_swap(oe[0][d], oe[1][d], false, false);
+                        oe[0][d] = re[0]; oe[1][d] = re[1];
+                        const auto ro = __builtin_amdgcn_permlane32_swap(oo[0][d], oo[1][d], false, false);
+                        oo[0][d] = ro[0]; oo[1][d] = ro[1];
+                    }
+                    const int co = e_m0 + 8 * (g0 + half);
+                    const bool ok = pos_ok && co < pc;
+                    const unsigned se = ok ? (pix_off + (unsigned)co) * 2u : SENTINEL;
+                    const unsigned so = ok ? (pix_off + (unsigned)p.ys[3] + (unsigned)co) * 2u : SENTINEL;
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{oe[0][0], oe[0][1], oe[1][0], oe[1][1]}, yrsrc, (int)se, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{oo[0][0], oo[0][1], oo[1][0], oo[1][1]}, yrsrc, (int)so, 0, 0);
+                }
+            }
+        }
+    };
+
+    int tile = blockIdx.x, cbuf = 0, dpar = 0;
+    for (;;) {
+        for (int k = 0; k < nchunks; k++) {
+            __builtin_amdgcn_s_barrier();
+            compute_chunk(cbuf);
+            cbuf = cbuf == G::NBUF - 1 ? 0 : cbuf + 1;
+        }
+        write_tile(tile, dpar);
+        if (tile + (int)gridDim.x >= total) break;
+        tile += gridDim.x;
+        dpar ^= 1;
+#pragma unroll
+        for (int ph = 0; ph < 4; ph++)
+#pragma unroll
+            for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+                for (int k = 0; k < 16; k++) acc[ph][nt][k] = 0.f;
+    }
+}
+
+template <typename T>
+int launch_up2f16(const Up2fParams& pp0, hipStream_t s) {
+    typedef Up2fGeo G;
+    Up2fParams pp = pp0;
+    Conv16Params& p = pp.c;
+    p.tilesX = (p.W + G::UW - 1) / G::UW;
+    p.tilesY = (p.H + G::TH - 1) / G::TH;
+    p.mblocks = p.f.phase_cout / 32;
+    const int64_t tiles = (int64_t)p.N * p.tilesX * p.tilesY * p.mblocks;
+    if (tiles > 0x7fffffffLL) return PG_ERR_TOO_LARGE;
+    p.total_tiles = (int)tiles;
+    auto magic = [&](int d) -> unsigned { return d <= 1 ? 0u : (unsigned)((0x100000000ULL + (unsigned)d - 1) / (unsigned)d); };
+    const int dmax = std::max(std::max(p.tilesX, p.tilesY), p.mblocks);
+    if (tiles * dmax >= 0x100000000LL) return PG_ERR_TOO_LARGE;
+    p.m_tilesX = magic(p.tilesX); p.m_tilesY = magic(p.tilesY); p.m_mblocks = magic(p.mblocks); p.m_ksplit = 0;
+    const int64_t blocks = tiles < (int64_t)num_cu() ? tiles : (int64_t)num_cu();
+    auto kern = conv2d_up2f16<T>;
+    static PerDeviceOnce lds_attr;
+    const hipError_t e = lds_attr.run([&] { return hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(THREADS + 64 * LOADERS), G::LDS_BYTES, s, pp);
+    return launch_status();
+}
+
+int launch16_up2f(const Up2fParams& p, int dtype, hipStream_t s);      // conv2d16_inst_up2f.hip
+
+}  // namespace pgconv16

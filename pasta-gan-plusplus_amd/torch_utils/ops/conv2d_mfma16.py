@@ -57,6 +57,8 @@ def _init():
         lib.pg_conv1x1_small16.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, i64, i, f, i, vp]
         lib.pg_conv2d16_pack_weight_batched.restype = i
         lib.pg_conv2d16_pack_weight_batched.argtypes = [ctypes.POINTER(PackJobs), vp]
+        lib.pg_conv2d16_up2_fused.restype = i
+        lib.pg_conv2d16_up2_fused.argtypes = [vp, vp, vp, i, i, i, i, i, i, i64, p64, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(Fusion16), vp]
         lib.pg_conv2d16_wgrad_plan.restype = i
         lib.pg_conv2d16_wgrad_plan.argtypes = [i] * 8
         lib.pg_conv2d16_wgrad.restype = i
@@ -132,7 +134,7 @@ _pack_registry = {}     # (weight address, styles address) -> (dtype, flip, tran
 
 def pack_weight_batched(jobs, dtype):
     """The per-sample 3x3 packs of several modulated convolutions in ONE launch (pg_conv2d16_pack_weight_batched).  jobs: list of
-    (w float32 [O, I, 3, 3] -- [I, O, 3, 3] when transpose_oi --, flip, transpose_oi, styles [N, Cin], dcoefs [N, D] | None) with D dividing the
+    (w float32 [O, I, 3, 3] -- [I, O, 3, 3] when transpose_oi; or the [I, 4 O, 3, 2] stack of `conv_up2_fused` --, flip, transpose_oi, styles [N, Cin], dcoefs [N, D] | None) with D dividing the
     pack's Cout (the four stacked phases of an up = 2 layer share one coefficient row).  Results wait in a registry keyed by (w, styles) addresses for
     the layer's own `pack_lookup`; `pack_clear()` empties it."""
     lib = _init()
@@ -141,10 +143,11 @@ def pack_weight_batched(jobs, dtype):
     n = int(jobs[0][3].shape[0])
     table.njobs, table.nsamples, table.dtype = len(jobs), n, nat.PG_DTYPE[dtype]
     for j, (w, flip, transpose_oi, styles, dcoefs) in enumerate(jobs):
-        assert w.dtype == torch.float32 and w.is_contiguous() and w.is_cuda and tuple(w.shape[2:]) == (3, 3)
+        assert w.dtype == torch.float32 and w.is_contiguous() and w.is_cuda and tuple(w.shape[2:]) in ((3, 3), (3, 2))
+        k32 = int(w.shape[3]) == 2          # the 3 x 2 stack of `conv_up2_fused`
         cin, cout = (int(w.shape[0]), int(w.shape[1])) if transpose_oi else (int(w.shape[1]), int(w.shape[0]))
         assert styles.dtype == torch.float32 and styles.is_contiguous() and tuple(styles.shape) == (n, cin)
-        per = lib.pg_conv2d16_packed_size(cout, cin, 3, 3)
+        per = lib.pg_conv2d16_packed_size(cout, cin, 3, 2 if k32 else 3)
         packed = torch.empty([n * per], dtype=dtype, device=w.device)
         table.w[j], table.packed[j], table.styles[j] = w.data_ptr(), packed.data_ptr(), styles.data_ptr()
         if dcoefs is not None:
@@ -152,7 +155,7 @@ def pack_weight_batched(jobs, dtype):
             table.dcoefs[j], table.dcoefs_mod[j] = dcoefs.data_ptr(), int(dcoefs.shape[1])
         else:
             table.dcoefs[j], table.dcoefs_mod[j] = None, cout
-        table.cout[j], table.cin[j], table.flags[j], table.scale[j] = cout, cin, int(bool(flip)) | (int(bool(transpose_oi)) << 1), 1.0
+        table.cout[j], table.cin[j], table.flags[j], table.scale[j] = cout, cin, int(bool(flip)) | (int(bool(transpose_oi)) << 1) | (int(k32) << 2), 1.0
         _pack_registry[(w.data_ptr(), styles.data_ptr())] = (dtype, bool(flip), bool(transpose_oi), packed, per, (w, styles, dcoefs))
     with torch.cuda.device(jobs[0][0].device):
         st = lib.pg_conv2d16_pack_weight_batched(ctypes.byref(table), nat.stream_of(jobs[0][0]))
@@ -326,6 +329,61 @@ def conv2d_forward(x, packed, cout, kh, kw, stride=1, pad=(0, 0), out_hw=None, y
                        x.element_size() * (x.numel() + n * cout_total * oh * ow) + (y.element_size() - x.element_size()) * n * cout_total * oh * ow
                        + packed.numel() * packed.element_size()))       # algorithmic bytes: x + y + the packed weights this launch reads
     nat.check(st, 'pg_conv2d16_forward')
+    return y
+
+
+def conv_up2_fused(x, packed, cout, fir_x, sample_stride=0, out_scale=None, noise=None, noise_gain=1.0, bias=None, act='linear', alpha=0.0, gain=1.0, clamp=None):
+    """The up = 2 modulated 3x3 layer of conv2d_resample.py:125-142 (transposed convolution, then the separable 4-tap filter with padding 1 and gain 4)
+    + the StyleGAN2 tail in ONE launch (pg_conv2d16_up2_fused, csrc/conv2d_up2f16.h): `packed` = `pack_weight(transpose_oi=True)` of the [Cin, 4 * cout, 3, 2]
+    stack that carries the y half of the filter, `fir_x` = 2 * fx (four floats), `noise` = [N or 1, 4, H, W] phase-major.  Returns channels-last [N, cout, 2H, 2W]."""
+    lib = _init()
+    if x.dtype not in DTYPES or not x.is_cuda or x.ndim != 4:
+        raise nat.NativeOpError('conv2d_mfma16: x must be a 4-D bf16 / fp16 GPU tensor')
+    x = to_channels_last(x)
+    n, cin, h, w = x.shape
+    y = torch.empty([n, cout, 2 * h, 2 * w], dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    fz = Fusion16()
+    keep = []
+
+    def dev(t, name, numel):
+        t = _f32(t, name, numel)
+        if t is None:
+            return None
+        keep.append(t)
+        return t.data_ptr()
+
+    fz.out_scale = dev(out_scale, 'out_scale', n * cout)
+    if noise is not None:
+        noise = _f32(noise, 'noise')
+        if noise.numel() == 4 * h * w:
+            fz.noise_batch_stride = 0
+        elif noise.numel() == n * 4 * h * w:
+            fz.noise_batch_stride = 4 * h * w
+        else:
+            raise nat.NativeOpError('conv2d_mfma16: the fused up-by-2 layer wants noise [N or 1, 4, H, W], phase-major')
+        keep.append(noise)
+        fz.noise = noise.data_ptr()
+    fz.noise_gain = float(noise_gain)
+    fz.noise_phase_stride = h * w
+    fz.bias = dev(bias, 'bias', cout)
+    fz.act, fz.alpha, fz.gain = ACT_INDEX[act], float(alpha), float(gain)
+    fz.clamp = -1.0 if clamp is None else float(clamp)
+    fz.phase_cout = cout
+    taps = (ctypes.c_float * 4)(*[float(v) for v in fir_x])
+    tl = conv2d_mfma._timeline
+    with torch.cuda.device(x.device):
+        if tl is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+        st = lib.pg_conv2d16_up2_fused(nat.ptr(x), nat.ptr(packed), nat.ptr(y), nat.PG_DTYPE[x.dtype], n, cin, h, w, cout, int(sample_stride),
+                                       nat.i64arr(y.stride()), taps, ctypes.byref(fz), nat.stream_of(x))
+        if tl is not None:
+            ev1.record()
+            # executed flops: 18 tap-products per position and (cin, cout) pair (the launch's tiles overlap by 2 of 32 columns on top of that);
+            # SURVEY 8d counts the transposed convolution as 2 * N * Cin * Hin * Win * Cout * 9: `honest_flops`
+            tl.append(((3, 3, 1, 'mfma16', f'N{n} {cin}->{cout} (up2 fused-x) {h}x{w} {str(x.dtype)[6:]}'), 2.0 * n * cout * h * w * cin * 18, ev0, ev1,
+                       x.element_size() * (x.numel() + y.numel()) + packed.numel() * packed.element_size()))
+    nat.check(st, 'pg_conv2d16_up2_fused')
     return y
 
 

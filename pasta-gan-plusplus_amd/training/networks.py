@@ -218,6 +218,54 @@ def _up2_transposed_phases_2x2(wt_iohw):
     return torch.cat(out, dim=1).contiguous()
 
 
+def _separable_taps(f):
+    """(fy, fx) with f == outer(fy, fx) for a rank-1 2-D filter (what upfirdn2d.setup_filter makes of [1, 3, 3, 1]), else None."""
+    if f is None or f.ndim != 2:
+        return None
+    f = f.detach().double().cpu()
+    tot = float(f.sum())
+    if tot == 0.0:
+        return None
+    fy, fx = f.sum(dim=1), f.sum(dim=0) / tot
+    if float((torch.outer(fy, fx) - f).abs().max()) > 1e-6 * float(f.abs().max()):
+        return None
+    return fy.float(), fx.float()
+
+
+def _up2_fused_weights(wt_iohw, fy):
+    """Weights of `conv2d_mfma16.conv_up2_fused` (csrc/conv2d_up2f16.h): the stride-2 transposed 3x3 convolution followed by the y half of the separable
+    FIR (padding 1, gain 2 per axis) as a 3 x 2 kernel per phase p = 2a + b, stacked along Cout -> IOHW [Cin, 4 * Cout, 3, 2]:
+        Ky = (2 fy) (*)_y w   (6 x 3: rows 4+a, 2+a, a are the taps of output-row parity a on input rows q-1, q, q+1 -- `_up2_composite_phases` in one axis)
+        along x the plain transposed convolution of `_up2_transposed_phases_2x2`: column parity b of the (2W+1)-wide intermediate takes
+        (x[r-1], x[r]) * (w[.., 2], w[.., 0]) for b = 0 and x[r] * w[.., 1] for b = 1 (its tx = 0 tap is zero and never loaded by the kernel).
+    The x half of the filter runs in the kernel's epilogue on the accumulators."""
+    cin, cout = int(wt_iohw.shape[0]), int(wt_iohw.shape[1])
+    g = (2 * fy).to(wt_iohw.dtype).to(wt_iohw.device)
+    k6 = wt_iohw.new_zeros([cin, cout, 6, 3])
+    for i in range(3):
+        k6[:, :, i:i + 4, :] += wt_iohw[:, :, i:i + 1, :] * g[None, None, :, None]
+    sel = {0: (2, 0), 1: (None, 1)}
+    out = []
+    for a in (0, 1):
+        rows = k6[:, :, [4 + a, 2 + a, a]]                           # [Cin, Cout, 3 (ty), 3 (kx)]
+        for b in (0, 1):
+            k = wt_iohw.new_zeros([cin, cout, 3, 2])
+            for tx, kx in enumerate(sel[b]):
+                if kx is not None:
+                    k[:, :, :, tx] = rows[:, :, :, kx]
+            out.append(k)
+    return torch.cat(out, dim=1).contiguous()
+
+
+def _up2_fused_cached(cache, weight, flip_weight, resample_filter):
+    """([Cin, 4 Cout, 3, 2] stack, 2 * fx as four floats) of an up = 2 layer, once per weight version."""
+    def build():
+        fy, fx = _separable_taps(resample_filter)
+        wt = weight.detach().float().transpose(0, 1)
+        return _up2_fused_weights((wt.flip([2, 3]) if flip_weight else wt).contiguous(), fy), [2.0 * float(v) for v in fx]
+    return cache.get(('up2_fusedx', flip_weight), [weight], build)
+
+
 def _up2_composite_cached(cache, weight, flip_weight, resample_filter):
     """The four composite 3x3 phase kernels of an up = 2 layer ({(a, b): [Cin, Cout, 3, 3]}), once per weight version."""
     def build():
@@ -234,7 +282,9 @@ def _up2_wcat_cached(cache, weight, flip_weight, resample_filter):
 
 def _modconv16_policy(weight_shape, hw, up, padding, resample_filter):
     """Which form a 16-bit modulated convolution takes (pure host logic, shared by `_modconv_fast16` and the stack's batched style preparation):
-    (composite, merged_t, shared, tpad, fir_pad) -- `shared` = one weight pack for the batch with x * styles and demodulation as the epilogue scale."""
+    (composite, merged_t, shared, tpad, fir_pad, fused_x) -- `shared` = one weight pack for the batch with x * styles and demodulation as the epilogue scale;
+    `fused_x` (round 5) = the one-launch form with the y half of the FIR in the weights and its x half in the epilogue (`_up2_fused_weights`): 18 tap-products
+    per input position instead of the composite's 36 (the reference's transposed convolution has 9 + the FIR pass)."""
     cout, cin, kh, kw = (int(v) for v in weight_shape)
     h, w = (int(v) for v in hw)
     tpad = fir_pad = None
@@ -268,10 +318,14 @@ def _modconv16_policy(weight_shape, hw, up, padding, resample_filter):
     # per-(n, cout) scale.  Styles are normalised per sample like networks.py:57-59 so that x * s stays in 16-bit range;
     # the factor returns through dcoefs (computed from the normalised styles).
     merged_t = up == 2 and merged_t
-    taps = 36 if composite else (16 if merged_t else kh * kw)
+    fused_x = (composite and cin % 16 == 0 and cin >= 32 and cout % 32 == 0 and min(h, w) >= int(os.environ.get('PG_UP2_FUSEDX_MIN', '32'))
+               and os.environ.get('PG_UP2_FUSEDX', '1') != '0' and _separable_taps(resample_filter) is not None)
+    if fused_x:
+        composite = False
+    taps = 36 if composite else (24 if fused_x else (16 if merged_t else kh * kw))
     shared = cout * taps > 2 * h * w and os.environ.get('PG_MODCONV16_SHARED', '1') != '0'
 
-    return composite, merged_t, shared, tpad, fir_pad
+    return composite, merged_t, shared, tpad, fir_pad, fused_x
 
 
 def _modconv_fast16(x, weight, styles, noise, up, padding, resample_filter, demodulate, flip_weight, cache, epilogue):
@@ -285,7 +339,7 @@ def _modconv_fast16(x, weight, styles, noise, up, padding, resample_filter, demo
     cache = cache if cache is not None else _PackCache()
     ep = dict(epilogue) if epilogue else {}
     w32, s32 = weight.detach().float(), styles.detach().float()
-    composite, merged_t, shared, tpad, fir_pad = _modconv16_policy((cout, cin, kh, kw), (h, w), up, padding, resample_filter)
+    composite, merged_t, shared, tpad, fir_pad, fused_x = _modconv16_policy((cout, cin, kh, kw), (h, w), up, padding, resample_filter)
     out_scale = None
     w2 = cache.get(('w2',), [weight], lambda: conv2d_mfma.modconv_w2(w32)) if demodulate else None
     if shared:          # one launch: per-sample maximum, normalised styles (float32 + 16-bit), coefficients of the normalised styles
@@ -308,6 +362,26 @@ def _modconv_fast16(x, weight, styles, noise, up, padding, resample_filter, demo
     def transposed_weight():
         wt = w32.transpose(0, 1)
         return (wt.flip([2, 3]) if flip_weight else wt).contiguous()
+    if fused_x:
+        wcat, fir_x = _up2_fused_cached(cache, weight, flip_weight, resample_filter)
+        res = ep.pop('residual', None)
+        noise_phases = None
+        if noise is not None:           # phase-major copy of the noise map ([B, 2, 2, h, w]; the constant map of inference once per parameter version)
+            if noise.requires_grad or noise.ndim != 2:
+                noise_phases = noise.reshape(-1, h, 2, w, 2).permute(0, 2, 4, 1, 3).contiguous()
+            else:
+                noise_phases = cache.get(('noise_phases',), [noise], lambda: noise.reshape(-1, h, 2, w, 2).permute(0, 2, 4, 1, 3).contiguous())
+        if shared:
+            packed = cache.get(('up2_fusedx_shared', flip_weight, x.dtype), [weight], lambda: conv2d_mfma16.pack_weight(wcat, x.dtype, transpose_oi=True)[0])
+            per = 0
+        else:
+            hit = conv2d_mfma16.pack_lookup(wcat, x.dtype, False, True, s32)
+            if hit is not None:
+                packed, per = hit
+            else:
+                packed, per, _ = conv2d_mfma16.pack_weight(wcat, x.dtype, transpose_oi=True, styles=s32, dcoefs=dcoefs.repeat(1, 4) if dcoefs is not None else None)
+        y = conv2d_mfma16.conv_up2_fused(x, packed, cout, fir_x, sample_stride=per, out_scale=out_scale, noise=noise_phases, **ep)
+        return y if res is None else y.add_(res)
     if composite:
         phases = _up2_composite_cached(cache, weight, flip_weight, resample_filter)
         y = torch.empty([n, cout, 2 * h, 2 * w], dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
@@ -1370,7 +1444,7 @@ class SynthesisStack(nn.Module):
                 if tuple(m.weight.shape[2:]) != (3, 3) or m.weight.dtype != torch.float32:
                     continue
                 cout = int(m.weight.shape[0])
-                composite, merged_t, shared, _, _ = _modconv16_policy(m.weight.shape, (res // m.up, res // m.up), m.up, m.padding, m.resample_filter)
+                composite, merged_t, shared, _, _, fused_x = _modconv16_policy(m.weight.shape, (res // m.up, res // m.up), m.up, m.padding, m.resample_filter)
                 if shared or merged_t:
                     continue
                 s = styles[res][k]
@@ -1379,6 +1453,8 @@ class SynthesisStack(nn.Module):
                     continue
                 if m.up == 1:
                     packs.append((m.weight.detach(), False, False, s, dcoefs))            # flip_weight = True for up = 1 layers: correlation, no flip
+                elif fused_x:
+                    packs.append((_up2_fused_cached(m._cache, m.weight, False, m.resample_filter)[0], False, True, s, dcoefs))
                 elif composite and conv2d_mfma16.phases_supported(cout) and os.environ.get('PG_UP2_MERGED', '1') != '0':
                     packs.append((_up2_wcat_cached(m._cache, m.weight, False, m.resample_filter), False, True, s, dcoefs))
         if 0 < len(packs) <= conv2d_mfma16.PACK_MAX_JOBS:

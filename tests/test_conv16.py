@@ -401,7 +401,58 @@ def test_config5_stack_full_width_prefix_vs_oracle():
     assert err32 <= 1e-4, err32
 
 
-@pytest.mark.parametrize('policy', ['composite', 'merged', 'auto'])
+UP2F_SHAPES = [  # (n, cin, cout, h, w): one tile; ragged tiles in both axes (W not a multiple of 30, H not of 16); several cout blocks; wider than two tiles
+    (1, 32, 32, 16, 30), (2, 48, 64, 21, 37), (1, 64, 96, 9, 64), (2, 32, 32, 40, 95),
+]
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['bf16', 'fp16'])
+@pytest.mark.parametrize('shape', UP2F_SHAPES, ids=[f'n{s[0]}c{s[1]}o{s[2]}_{s[3]}x{s[4]}' for s in UP2F_SHAPES])
+@pytest.mark.parametrize('taps', [[1, 3, 3, 1], [1, 2, 4, 1]], ids=['f1331', 'fasym'])      # (tap sums are powers of two: the normalised taps stay exact)
+def test_up2_fused_x_kernel_vs_float64(dtype, shape, taps):
+    """pg_conv2d16_up2_fused (csrc/conv2d_up2f16.h: y half of the FIR in the weights, x half in the epilogue over DPP wave shifts) against the reference's
+    two-step form in float64 -- conv_transpose2d(stride 2) -> (2H+1) x (2W+1), then upfirdn2d(f, padding 1, gain 4) (conv2d_resample.py:125-142) -- on
+    small-integer operands: every product and partial sum of the kernel is exact in fp32, so the only error left is the final rounding to 16 bits
+    (half an ulp).  The asymmetric filter pins the orientation of both filter halves; with noise, bias, demodulation scale, lrelu, gain and clamp."""
+    from torch_utils.ops import conv2d_mfma16 as M
+    from training import networks as PN
+    from oracle import ops_ref
+    n, cin, cout, h, w = shape
+    gen = torch.Generator().manual_seed(17)
+    x = _ints(gen, [n, cin, h, w], -2, 2)
+    wt = _ints(gen, [cin, cout, 3, 3], -2, 2)                     # IOHW: what conv_transpose2d takes
+    f1 = torch.tensor(taps, dtype=torch.float64)
+    f2d = torch.outer(f1, f1) / f1.sum() ** 2                      # upfirdn2d.setup_filter's normalised outer product
+    fy, fx = PN._separable_taps(f2d.float())
+    stack = PN._up2_fused_weights(wt.to(DEV), fy)
+    assert tuple(stack.shape) == (cin, 4 * cout, 3, 2)
+    packed, per, _ = M.pack_weight(stack, dtype, transpose_oi=True)
+    scale = (_ints(gen, [n, cout], 1, 4) / 4).to(DEV)
+    bias = _ints(gen, [cout], -3, 3).to(DEV)
+    noise = _ints(gen, [1, 1, 2 * h, 2 * w], -2, 2)
+    noise_ph = noise.reshape(1, h, 2, w, 2).permute(0, 2, 4, 1, 3).contiguous().to(DEV)
+    y = M.conv_up2_fused(x.to(DEV, dtype), packed, cout, [2.0 * float(v) for v in fx], sample_stride=per, out_scale=scale, noise=noise_ph, noise_gain=0.5,
+                         bias=bias, act='lrelu', alpha=0.25, gain=2.0, clamp=64.0)
+    assert tuple(y.shape) == (n, cout, 2 * h, 2 * w) and y.is_contiguous(memory_format=torch.channels_last)
+    z = _ref_conv(x, wt, stride=2, transposed=True)                # [n, cout, 2h+1, 2w+1] float64
+    ref = ops_ref.upfirdn2d(z, f2d, padding=1, gain=4)
+    ref = ref * scale.double().cpu()[:, :, None, None] + 0.5 * noise.double() + bias.double().cpu()[None, :, None, None]
+    ref = torch.where(ref > 0, ref, 0.25 * ref) * 2.0
+    ref = ref.clamp(-64.0, 64.0)
+    err = (y.double().cpu() - ref).abs()
+    bound = ULP[dtype] * ref.abs() + 1e-6
+    assert bool((err <= bound).all()), (float((err - bound).max()), float(ref.abs().max()))
+    # per-sample packs (the fused modulated convolution, networks.py:85-94): styles * dcoefs folded into the pack == the same result with the scale in the weights
+    styles = (_ints(gen, [n, cin], 1, 2)).to(DEV)
+    packed_n, per_n, _ = M.pack_weight(stack, dtype, transpose_oi=True, styles=styles)
+    y2 = M.conv_up2_fused(x.to(DEV, dtype), packed_n, cout, [2.0 * float(v) for v in fx], sample_stride=per_n)
+    z2 = torch.stack([_ref_conv(x[i:i + 1], wt * styles.cpu()[i][:, None, None, None], stride=2, transposed=True)[0] for i in range(n)])
+    ref2 = ops_ref.upfirdn2d(z2, f2d, padding=1, gain=4)
+    err2 = (y2.double().cpu() - ref2).abs()
+    assert bool((err2 <= ULP[dtype] * ref2.abs() + 1e-6).all()), float(err2.max())
+
+
+@pytest.mark.parametrize('policy', ['composite', 'merged', 'auto', 'fusedx'])
 def test_up2_layer_routes_vs_oracle(policy, monkeypatch):
     """The three routes of a weight-dominated 16-bit `up = 2` SynthesisLayer (1024 -> 512 at 32^2 -> 64^2, N = 2, bf16): composite 6x6 kernels (round 2),
     the transposed convolution's phases as ONE launch of 2x2 kernels + the channels-last FIR on a pitched view (round 4, `merged`), four phase launches +
@@ -409,7 +460,8 @@ def test_up2_layer_routes_vs_oracle(policy, monkeypatch):
     from detgen import det_tensor, fill_module_
     from training import networks as PN
     from oracle import network_ref as NR
-    monkeypatch.setenv('PG_UP2_POLICY', policy)
+    monkeypatch.setenv('PG_UP2_POLICY', 'composite' if policy == 'fusedx' else policy)
+    monkeypatch.setenv('PG_UP2_FUSEDX', '1' if policy == 'fusedx' else '0')         # round 5: y half of the FIR in the weights, x half in the epilogue (one launch)
     kw = dict(w_dim=64, resolution=64, up=2, conv_clamp=256)
     ref = fill_module_(NR.SynthesisLayer(1024, 512, **kw), 'up2r.').eval()
     net = PN.SynthesisLayer(1024, 512, **kw)

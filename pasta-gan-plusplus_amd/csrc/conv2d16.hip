@@ -602,5 +602,6 @@ PG_EXPORT int pg_conv2d16_up2_fused(const void* x, const void* packed, void* y, 
     if (p.f.act > PG_ACT_LRELU) return PG_ERR_UNSUPPORTED;
     if (p.f.act == PG_ACT_LRELU && (p.f.alpha < 0.f || p.f.alpha > 1.f)) return PG_ERR_UNSUPPORTED;
     for (int i = 0; i < 4; i++) pp.fir[i] = fir_x[i];
+    { const char* e = getenv("PG_CONV16_DBG"); p.dbg = e ? atoi(e) : 0; }
     return pgconv16::launch16_up2f(pp, dtype, (hipStream_t)stream);
 }

@@ -2,8 +2,15 @@
 #include "conv2d_up2f16.h"
 namespace pgconv16 {
 int launch16_up2f(const Up2fParams& p, int dtype, hipStream_t s) {
-    if (dtype == PG_BF16) return launch_up2f16<bf16_t>(p, s);
-    if (dtype == PG_F16) return launch_up2f16<f16_t>(p, s);
+    // PG_UP2F_WG=1: one 12-wave workgroup per CU (16-row tiles, three staging buffers); default: two 6-wave workgroups per CU (8-row tiles, two buffers)
+    static const int per_cu = [] { const char* e = getenv("PG_UP2F_WG"); return e ? atoi(e) : 2; }();
+    if (per_cu == 1) {
+        if (dtype == PG_BF16) return launch_up2f16<bf16_t, 8, 3>(p, s);
+        if (dtype == PG_F16) return launch_up2f16<f16_t, 8, 3>(p, s);
+    } else {
+        if (dtype == PG_BF16) return launch_up2f16<bf16_t, 4, 2>(p, s);
+        if (dtype == PG_F16) return launch_up2f16<f16_t, 4, 2>(p, s);
+    }
     return PG_ERR_INVALID_ARG;
 }
 }

@@ -34,6 +34,7 @@
 #pragma once
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 #include "pg_common.h"
 
 namespace pgconv16 {

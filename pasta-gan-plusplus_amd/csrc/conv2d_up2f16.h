@@ -39,25 +39,33 @@ struct Up2fParams {
     float fir[4];           // 2 * fx: the x half of the filter with its share of the gain
 };
 
+// MW multiplying waves (2 position rows each) + MW / 2 loader waves.  MW = 8: one workgroup per CU (16-row tiles, three staging buffers);
+// MW = 4: TWO workgroups per CU (8-row tiles, two staging buffers, <= 80 KB of LDS each) -- the two run out of step, so one's epilogue
+// (vector work: the x filter, the activation, the stores) overlaps the other's K loop instead of stopping the matrix pipe and the load stream.
+template <int MW, int NB>
 struct Up2fGeo {
-    static constexpr int TH = 16, LW = 32, UW = 30;        // position rows, lanes (positions incl. one overlap column per side), useful positions
-    static constexpr int T = 6, BM = 128, KC = 16, SLOTS = 2, PER = 8, NBUF = 3;
+    static constexpr int LDW = MW / 2, NTHREADS = (MW + LDW) * 64, LT = LDW * 64;      // loader waves / threads
+    static constexpr int WG_PER_CU = 8 / MW;
+    static constexpr int TH = 2 * MW, LW = 32, UW = 30;    // position rows, lanes (positions incl. one overlap column per side), useful positions
+    static constexpr int T = 6, KC = 16, NBUF = NB;
+    static constexpr int NSTEP = 18;                       // (ty, tx, phase) weight fragments with a non-zero tap: per ty, tx = 1 x phases 0..3, then tx = 0 x phases 0, 2
     static constexpr int IH_T = TH + 2, IW_T = LW + 1;
-    static constexpr int NPIX = IH_T * IW_T;               // 594 halo pixels
-    static constexpr int PLANE = 640;                      // slots per k-half plane: the halo is staged as [k-half][row][col] x 16 bytes, so that a wave's
+    static constexpr int NPIX = IH_T * IW_T;               // halo pixels
+    static constexpr int PLANE = (NPIX + 63) / 64 * 64;    // slots per k-half plane: the halo is staged as [k-half][row][col] x 16 bytes, so that a wave's
                                                            // ds_read_b128 (lanes 0-31: 32 consecutive pixels of plane 0, lanes 32-63: of plane 1) walks whole
                                                            // 256-byte bank rows per 16 lanes -- conflict-free without a swizzle, and every tap shift is an
                                                            // immediate offset from ONE lane address (the swizzled layout of conv2d_kernel16.h costs a register pair per shift)
     static constexpr int NXS = 2 * PLANE;
-    static constexpr int NXS_PAD = (NXS + 255) / 256 * 256;
-    static constexpr int NWS = T * 2 * BM;                 // 1536 weight slots
-    static constexpr int LDS_BUF = NXS_PAD + NWS;          // 2816 = 11 x 256
-    static constexpr int NREQ = LDS_BUF / 256, NREQ_X = NXS_PAD / 256;
+    static constexpr int NXS_PAD = (NXS + LT - 1) / LT * LT;
+    static constexpr int NWS = NSTEP * 2 * 32;             // 1152 weight slots: [step][k-half][32 couts]
+    static constexpr int NWS_PAD = (NWS + LT - 1) / LT * LT;
+    static constexpr int LDS_BUF = NXS_PAD + NWS_PAD;
+    static constexpr int NREQ_X = NXS_PAD / LT, NREQ = LDS_BUF / LT;
     static constexpr int EPS = 64, NOISE = 4 * TH * LW;
     static constexpr int EP_FLOATS = 2 * EPS + NOISE;
     static constexpr size_t LDS_BYTES = (size_t)NBUF * LDS_BUF * 16 + (size_t)2 * EP_FLOATS * 4 + 256;
-    static_assert(LDS_BUF % 256 == 0 && NXS_PAD % 256 == 0, "request instructions of the four loader waves");
-    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+    static_assert(MW == 8 || MW == 4, "one or two workgroups per CU");
+    static_assert(LDS_BYTES <= 160 * 1024 / WG_PER_CU, "LDS budget");
 };
 
 template <int CTRL> __device__ __forceinline__ float dpp_f(float v) {
@@ -65,10 +73,10 @@ template <int CTRL> __device__ __forceinline__ float dpp_f(float v) {
 }
 constexpr int DPP_WAVE_SHL1 = 0x130, DPP_WAVE_SHR1 = 0x138;     // lane l reads lane l + 1 / lane l - 1
 
-template <typename T>
-__global__ __launch_bounds__(THREADS + 64 * LOADERS, 3) void conv2d_up2f16(Up2fParams pp) {
+template <typename T, int MW, int NB>
+__global__ __launch_bounds__((MW + MW / 2) * 64, 3) void conv2d_up2f16(Up2fParams pp) {
     const Conv16Params& p = pp.c;
-    typedef Up2fGeo G;
+    typedef Up2fGeo<MW, NB> G;
     typedef Half16<T> HT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef const __attribute__((address_space(3))) i32x4* lds_v4;
@@ -82,6 +90,7 @@ __global__ __launch_bounds__(THREADS + 64 * LOADERS, 3) void conv2d_up2f16(Up2fP
     const int q8 = total >> 3, r8 = total & 7;
     const int nchunks = p.Cin / G::KC;
     const int pc = p.f.phase_cout;
+    const int dbg_ = PG_CONV16_STAMPS ? p.dbg : 0;      // dev ablations (diagnostic build only; results wrong by design): 1 no stores, 4 no MFMA, 8 no epilogue, 128 no halo DMA
 
     // tile -> (n, first position row, position of lane 0, first cout), XCD-aware like conv2d_mfma16 (scalar unit)
     auto decode = [&](int tile, int& n, int& q0, int& r0, int& m0) __attribute__((always_inline)) {
@@ -93,34 +102,33 @@ __global__ __launch_bounds__(THREADS + 64 * LOADERS, 3) void conv2d_up2f16(Up2fP
         n = (int)q; q0 = ty * G::TH; r0 = tx * G::UW - 1; m0 = mb * 32;      // r0: the left overlap column
     };
 
-    if (wave >= WAVES) {
+    if (wave >= MW) {
         // ---------------------------------------------------------------- loader waves: requests only
-        const int lw = wave - WAVES;
+        const int lw = wave - MW;
         const unsigned smem_b = __builtin_amdgcn_readfirstlane(lds_offset(smem));
         const unsigned side_b = smem_b + (unsigned)(G::NBUF * G::LDS_BUF) * 16u;
         const unsigned dump_b = side_b + 2u * G::EP_FLOATS * 4u;
         const i32x4 xrsrc = make_rsrc(p.x, (int64_t)p.N * p.H * p.W * p.xC * 2);
         const i32x4 wrsrc = make_rsrc(p.wp, p.w_bytes);
-        const int lt = lw * 64 + lane;                                 // 0 .. 255
+        const int lt = lw * 64 + lane;
         unsigned rel[G::NREQ], hyx[G::NREQ_X];
 #pragma unroll
         for (int j = 0; j < G::NREQ; j++) {
-            const int s = j * 256 + lt;
+            const int s = j * G::LT + lt;
             rel[j] = SENTINEL;
             if (j < G::NREQ_X) {
                 hyx[j] = 0x4000u;
                 const int c = s >= G::PLANE, qh = s - c * G::PLANE;
                 const int hy = qh / G::IW_T, hx = qh % G::IW_T;
-                if (qh < G::NPIX) {
+                if (qh < G::NPIX && s < G::NXS) {
                     rel[j] = (unsigned)((hy * p.W + hx) * p.xC + c * 8) * 2u;
                     hyx[j] = (unsigned)hy | ((unsigned)hx << 16);
                 }
             } else {
-                const int e = s - G::NXS_PAD;
-                const int row = e >> 7, col = e & 127;                 // row = tap * 2 + k-half; col = phase * 32 + cout
-                const int ph = col >> 5, tap = row >> 1;
-                const bool zero = (ph & 1) && !(tap & 1);              // x parity 1 has no tx = 0 tap
-                if (!zero) rel[j] = (unsigned)(row * p.CoutP + ph * pc + (col & 31)) * 16u;
+                const int e = s - G::NXS_PAD;                          // [step i][k-half][32 couts]
+                const int i = e >> 6, kh = (e >> 5) & 1, c = e & 31;
+                const int ty = i / 6, r = i % 6, tx = r < 4 ? 1 : 0, ph = r < 4 ? r : (r - 4) * 2;
+                if (e < G::NWS) rel[j] = (unsigned)(((ty * 2 + tx) * 2 + kh) * p.CoutP + ph * pc + c) * 16u;
             }
         }
         const bool side_scale = lw == 0, side_bias = lw == 1;
@@ -149,19 +157,19 @@ __global__ __launch_bounds__(THREADS + 64 * LOADERS, 3) void conv2d_up2f16(Up2fP
                 }
                 x_soff0 = (unsigned)((int64_t)n * p.H * p.W * p.xC * 2);
                 w_soff = (unsigned)(((int64_t)n * p.w_nstride + (int64_t)m0 * 8) * 2);
-                // per-tile side loads: 32 demodulation scales, 32 biases, 4 x 512 noise samples (tile T's into side buffer T & 1)
+                // per-tile side loads: 32 demodulation scales, 32 biases, 4 x TH x 32 noise samples (tile T's into side buffer T & 1)
                 const unsigned sb_ = side_b + (unsigned)((c_ahead & 1) * G::EP_FLOATS) * 4u;
                 const bool live = (side_scale || side_bias) && lane < 32 && m0 + lane < pc;
                 dma4(sbrsrc, (side_scale || side_bias) ? sb_ + (unsigned)(lw * 64) * 4u : dump_b, live ? (unsigned)lane * 4u : SENTINEL,
                      (unsigned)(m0 + (side_scale ? n * pc : 0)) * 4u);
 #pragma unroll
-                for (int j = 0; j < 2; j++) {
-                    const int tt = (j * LOADERS + lw) * 64 + lane;
+                for (int j = 0; j < G::TH * G::LW / G::LT; j++) {
+                    const int tt = (j * G::LDW + lw) * 64 + lane;
                     const int nq = q0 + tt / G::LW, nr = r0 + tt % G::LW;
                     const unsigned nvo = (nq < p.H && nr >= 0 && nr < p.W) ? (unsigned)(nq * p.W + nr) * 4u : SENTINEL;
 #pragma unroll
                     for (int ph = 0; ph < 4; ph++)
-                        dma4(nrsrc, sb_ + (unsigned)(2 * G::EPS + ph * (G::TH * G::LW) + (j * LOADERS + lw) * 64) * 4u, nvo,
+                        dma4(nrsrc, sb_ + (unsigned)(2 * G::EPS + ph * (G::TH * G::LW) + (j * G::LDW + lw) * 64) * 4u, nvo,
                              (unsigned)(n * p.f.noise_batch_stride + ph * p.f.noise_phase_stride) * 4u);
                 }
             }
@@ -171,7 +179,7 @@ __global__ __launch_bounds__(THREADS + 64 * LOADERS, 3) void conv2d_up2f16(Up2fP
 #pragma unroll
             for (int j = 0; j < G::NREQ; j++) {
                 const bool is_w = j >= G::NREQ_X;
-                dma16(is_w ? wrsrc : xrsrc, buf_b + (unsigned)(j * 256 + lw * 64) * 16u, is_w ? rel[j] : voff[j], is_w ? wk_soff : x_soff);
+                dma16(is_w ? wrsrc : xrsrc, buf_b + (unsigned)(j * G::LT + lw * 64) * 16u, is_w ? rel[j] : ((dbg_ & 128) ? SENTINEL : voff[j]), is_w ? wk_soff : x_soff);
             }
             ibuf = ibuf == G::NBUF - 1 ? 0 : ibuf + 1;
             if (++c_chunk == nchunks) { c_chunk = 0; c_tile += gridDim.x; c_ahead++; }
@@ -182,8 +190,8 @@ __global__ __launch_bounds__(THREADS + 64 * LOADERS, 3) void conv2d_up2f16(Up2fP
         for (int j = 0; j < G::NBUF - 1; j++)
             if (req < my_chunks) { issue_next(); req++; }
         for (int c = 0; c < my_chunks; c++) {
-            // chunk c must have landed; chunk c + 1's requests (and, in front of them, its tile's side loads) may stay in flight
-            if (req > c + 1) vm_wait<G::NREQ>(); else vm_wait<0>();
+            // chunk c must have landed; with three buffers chunk c + 1's requests (and, in front of them, its tile's side loads) may stay in flight
+            if (G::NBUF > 2 && req > c + 1) vm_wait<G::NREQ>(); else vm_wait<0>();
             __builtin_amdgcn_s_barrier();
             if (req < my_chunks) { issue_next(); req++; }               // into the buffer of chunk c - 1: every multiplying wave is past it
         }
@@ -202,29 +210,26 @@ __global__ __launch_bounds__(THREADS + 64 * LOADERS, 3) void conv2d_up2f16(Up2fP
 
     // operand addresses: ONE lane address per operand, every tap / row / phase an immediate offset
     const unsigned b_lane = (unsigned)(half * G::PLANE + (2 * wave) * G::IW_T + l31) * 16u;
-    const unsigned a_lane = (unsigned)(G::NXS_PAD + half * G::BM + l31) * 16u;
+    const unsigned a_lane = (unsigned)(G::NXS_PAD + half * 32 + l31) * 16u;
 
     // One 16-channel chunk: 18 weight fragments (ty, tx, phase), each multiplied with the two position rows of the wave.  The loop is
     // written as a software pipeline by hand -- the weight fragment of step i + 1 is requested before the MFMAs of step i, the activation
-    // fragments rotate through FOUR registers sets (row ty leaves after its last use, row ty + 2 takes its place) -- and pinned with
+    // fragments rotate through FOUR register sets (row ty leaves after its last use, row ty + 2 takes its place) -- and pinned with
     // sched_barrier: left to itself the scheduler (at the register limit) sinks every read to its first use and waits lgkmcnt(0) there.
     auto compute_chunk = [&](int buf) __attribute__((always_inline)) {
         const unsigned char* bb = smem + (size_t)buf * G::LDS_BUF * 16 + b_lane;
         const unsigned char* ab = smem + (size_t)buf * G::LDS_BUF * 16 + a_lane;
         auto b_frag = [&](int hr, int tx) __attribute__((always_inline)) { return *(lds_v4)(bb + (size_t)(hr * G::IW_T + tx) * 16); };
-        auto a_frag = [&](int i) __attribute__((always_inline)) {      // step i -> (ty, tx, phase): ty-major; per ty: tx = 1 x phases 0..3, then tx = 0 x phases 0, 2
-            const int ty = i / 6, r = i % 6, tx = r < 4 ? 1 : 0, ph = r < 4 ? r : (r - 4) * 2;
-            return *(lds_v4)(ab + (size_t)((ty * 2 + tx) * 2 * G::BM + ph * 32) * 16);
-        };
+        auto a_frag = [&](int i) __attribute__((always_inline)) { return *(lds_v4)(ab + (size_t)(i * 64) * 16); };
         i32x4 b1[4], b0[4];                                           // [halo row] for tx = 1 / tx = 0; at most four of the eight are live
         b1[0] = b_frag(0, 1); b1[1] = b_frag(1, 1);
         i32x4 a_cur = a_frag(0), a_nxt;
         b0[0] = b_frag(0, 0); b0[1] = b_frag(1, 0);
 #pragma unroll
-        for (int i = 0; i < 18; i++) {
+        for (int i = 0; i < G::NSTEP; i++) {
             const int ty = i / 6, r = i % 6, tx = r < 4 ? 1 : 0, ph = r < 4 ? r : (r - 4) * 2;
-            if (i + 1 < 18) a_nxt = a_frag(i + 1);
-            if (ty < 2 && r == 3) b1[ty + 2] = b_frag(ty + 2, 1);      // row ty of the tx = 1 column has had its last use in this step's first MFMA ... (requested before: a new register set)
+            if (i + 1 < G::NSTEP) a_nxt = a_frag(i + 1);
+            if (ty < 2 && r == 3) b1[ty + 2] = b_frag(ty + 2, 1);      // (a new register set: row ty of this column has its last use in this step)
             if (ty < 2 && r == 5) b0[ty + 2] = b_frag(ty + 2, 0);
             const i32x4 blo = tx ? b1[ty] : b0[ty], bhi = tx ? b1[ty + 1] : b0[ty + 1];
             acc[ph][0] = HT::mma(a_cur, blo, acc[ph][0]);
@@ -234,14 +239,23 @@ __global__ __launch_bounds__(THREADS + 64 * LOADERS, 3) void conv2d_up2f16(Up2fP
         }
     };
 
+    // ---- epilogue constants.  v = clamp(act((h * scale + noise + bias)) * gain) with a positively homogeneous activation (linear / relu / lrelu, gain > 0):
+    // u = h * (scale * gain) + (bias + noise) * gain, v = med3(max(u, u * slope), -cl, cl).  Without a per-cout scale (per-sample weight packs carry the
+    // demodulation) the gain rides in the filter taps and the bias + noise term is the filter sum's start value: 4 multiply-adds + 1 add per value.
     const float gain = p.f.gain;
     const float cl = p.f.clamp >= 0.f ? p.f.clamp : __builtin_inff();
     const float slope = act_slope(p.f.act, p.f.alpha);
     const bool has_scale = p.f.out_scale != nullptr;
-    const float noise_gain = p.f.noise ? p.f.noise_gain : 0.f;
-    const float f0 = pp.fir[0], f1 = pp.fir[1], f2 = pp.fir[2], f3 = pp.fir[3];
+    const float ng = (p.f.noise ? p.f.noise_gain : 0.f) * gain;
+    const float tg = has_scale ? 1.f : gain;
+    const float f0 = pp.fir[0] * tg, f1 = pp.fir[1] * tg, f2 = pp.fir[2] * tg, f3 = pp.fir[3] * tg;
 
-    auto write_tile = [&](int tile, int dpar) __attribute__((always_inline)) {
+    auto write_tile = [&](int tile, int dpar, auto scaled) __attribute__((always_inline)) {
+        constexpr bool SCALED = decltype(scaled)::value;
+        // lane-derived values are rebuilt here from a fresh lane id (asm volatile: not hoisted): kept across the K loop they were 18 spilled registers
+        int lane_e;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+        const int half = lane_e >> 5, l31 = lane_e & 31;
         int e_n, e_q0, e_r0, e_m0;
         decode(tile, e_n, e_q0, e_r0, e_m0);
         const unsigned char* side = smem + (size_t)G::NBUF * G::LDS_BUF * 16 + (size_t)dpar * G::EP_FLOATS * 4;
@@ -250,51 +264,57 @@ __global__ __launch_bounds__(THREADS + 64 * LOADERS, 3) void conv2d_up2f16(Up2fP
 #pragma unroll
         for (int nt = 0; nt < 2; nt++) {
             const int row_l = 2 * wave + nt, q = e_q0 + row_l;
-            const bool pos_ok = col_ok && q < p.H;
+            const bool pos_ok = col_ok && q < p.H && !(dbg_ & 1);
 #pragma unroll
             for (int a = 0; a < 2; a++) {
                 const int oy = 2 * q + a;
-                const float nze = *(lds_f)(side + (size_t)(2 * G::EPS + (2 * a) * (G::TH * G::LW) + row_l * G::LW + l31) * 4) * (noise_gain * gain);
-                const float nzo = *(lds_f)(side + (size_t)(2 * G::EPS + (2 * a + 1) * (G::TH * G::LW) + row_l * G::LW + l31) * 4) * (noise_gain * gain);
+                const float nze = *(lds_f)(side + (size_t)(2 * G::EPS + (2 * a) * (G::TH * G::LW) + row_l * G::LW + l31) * 4) * ng;
+                const float nzo = *(lds_f)(side + (size_t)(2 * G::EPS + (2 * a + 1) * (G::TH * G::LW) + row_l * G::LW + l31) * 4) * ng;
                 const unsigned pix_off = (unsigned)((int64_t)e_n * p.ys[0] + (int64_t)oy * p.ys[2] + (int64_t)(2 * r) * p.ys[3]);
+                u32x2 pe, po;                                              // group g - 1's packed results (even g), waiting for their exchange partner
 #pragma unroll
-                for (int g0 = 0; g0 < 4; g0 += 2) {
-                    u32x2 oe[2], oo[2];
+                for (int g = 0; g < 4; g++) {
+                    const int r0c = 8 * g + 4 * half;
+                    const f32x4 bgv = *(lds_f4)(side + (size_t)(G::EPS + r0c) * 4) * gain;
+                    f32x4 sgv;
+                    if constexpr (SCALED) sgv = *(lds_f4)(side + (size_t)r0c * 4) * gain;
+                    float ve[4], vo[4];
 #pragma unroll
-                    for (int gg = 0; gg < 2; gg++) {
-                        const int g = g0 + gg;
-                        const int r0c = 8 * g + 4 * half;
-                        f32x4 sgv = *(lds_f4)(side + (size_t)r0c * 4), bgv = *(lds_f4)(side + (size_t)(G::EPS + r0c) * 4);
-                        sgv = has_scale ? sgv * gain : f32x4{gain, gain, gain, gain};
-                        bgv = bgv * gain;
-                        float ve[4], vo[4];
-#pragma unroll
-                        for (int j = 0; j < 4; j++) {
-                            const float z0 = acc[2 * a][nt][4 * g + j], z1 = acc[2 * a + 1][nt][4 * g + j];
-                            const float z1m = dpp_f<DPP_WAVE_SHR1>(z1), z0p = dpp_f<DPP_WAVE_SHL1>(z0), z1p = dpp_f<DPP_WAVE_SHL1>(z1);
+                    for (int j = 0; j < 4; j++) {
+                        const float z0 = acc[2 * a][nt][4 * g + j], z1 = acc[2 * a + 1][nt][4 * g + j];
+                        const float z1m = dpp_f<DPP_WAVE_SHR1>(z1), z0p = dpp_f<DPP_WAVE_SHL1>(z0), z1p = dpp_f<DPP_WAVE_SHL1>(z1);
+                        float ue, uo;
+                        if constexpr (SCALED) {
                             const float he = fmaf(f3, z1m, fmaf(f2, z0, fmaf(f1, z1, f0 * z0p)));
                             const float ho = fmaf(f3, z0, fmaf(f2, z1, fmaf(f1, z0p, f0 * z1p)));
-                            const float ue = fmaf(he, sgv[j], bgv[j] + nze), uo = fmaf(ho, sgv[j], bgv[j] + nzo);
-                            ve[j] = __builtin_amdgcn_fmed3f(fmaxf(ue, ue * slope), -cl, cl);
-                            vo[j] = __builtin_amdgcn_fmed3f(fmaxf(uo, uo * slope), -cl, cl);
+                            ue = fmaf(he, sgv[j], bgv[j] + nze); uo = fmaf(ho, sgv[j], bgv[j] + nzo);
+                        } else {
+                            ue = fmaf(f3, z1m, fmaf(f2, z0, fmaf(f1, z1, fmaf(f0, z0p, bgv[j] + nze))));
+                            uo = fmaf(f3, z0, fmaf(f2, z1, fmaf(f1, z0p, fmaf(f0, z1p, bgv[j] + nzo))));
                         }
-                        oe[gg][0] = HT::pack(ve[0], ve[1]); oe[gg][1] = HT::pack(ve[2], ve[3]);
-                        oo[gg][0] = HT::pack(vo[0], vo[1]); oo[gg][1] = HT::pack(vo[2], vo[3]);
+                        ve[j] = __builtin_amdgcn_fmed3f(fmaxf(ue, ue * slope), -cl, cl);
+                        vo[j] = __builtin_amdgcn_fmed3f(fmaxf(uo, uo * slope), -cl, cl);
                     }
-                    // lanes 32-63 of group g0 <-> lanes 0-31 of group g0 + 1: 8 consecutive couts of one pixel per lane
+                    u32x2 ce = {HT::pack(ve[0], ve[1]), HT::pack(ve[2], ve[3])}, co2 = {HT::pack(vo[0], vo[1]), HT::pack(vo[2], vo[3])};
+                    if (g & 1) {
+                        // lanes 32-63 of group g - 1 <-> lanes 0-31 of group g: 8 consecutive couts of one pixel per lane
 #pragma unroll
-                    for (int d = 0; d < 2; d++) {
-                        const auto re = __builtin_amdgcn_permlane32_swap(oe[0][d], oe[1][d], false, false);
-                        oe[0][d] = re[0]; oe[1][d] = re[1];
-                        const auto ro = __builtin_amdgcn_permlane32_swap(oo[0][d], oo[1][d], false, false);
-                        oo[0][d] = ro[0]; oo[1][d] = ro[1];
+                        for (int d = 0; d < 2; d++) {
+                            const auto re = __builtin_amdgcn_permlane32_swap(pe[d], ce[d], false, false);
+                            pe[d] = re[0]; ce[d] = re[1];
+                            const auto ro = __builtin_amdgcn_permlane32_swap(po[d], co2[d], false, false);
+                            po[d] = ro[0]; co2[d] = ro[1];
+                        }
+                        const int co = e_m0 + 8 * (g - 1 + half);
+                        const bool ok = pos_ok && co < pc;
+                        const unsigned se = ok ? (pix_off + (unsigned)co) * 2u : SENTINEL;
+                        const unsigned so = ok ? (pix_off + (unsigned)p.ys[3] + (unsigned)co) * 2u : SENTINEL;
+                        __builtin_amdgcn_raw_buffer_store_b128(u32x4{pe[0], pe[1], ce[0], ce[1]}, yrsrc, (int)se, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(u32x4{po[0], po[1], co2[0], co2[1]}, yrsrc, (int)so, 0, 0);
+                    } else {
+                        pe = ce; po = co2;
                     }
-                    const int co = e_m0 + 8 * (g0 + half);
-                    const bool ok = pos_ok && co < pc;
-                    const unsigned se = ok ? (pix_off + (unsigned)co) * 2u : SENTINEL;
-                    const unsigned so = ok ? (pix_off + (unsigned)p.ys[3] + (unsigned)co) * 2u : SENTINEL;
-                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{oe[0][0], oe[0][1], oe[1][0], oe[1][1]}, yrsrc, (int)se, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{oo[0][0], oo[0][1], oo[1][0], oo[1][1]}, yrsrc, (int)so, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);      // (one group of 2 x 16 values at a time: interleaving the groups of a tile for ILP costs more registers than the wave has beside its 128 accumulators)
                 }
             }
         }
@@ -304,10 +324,12 @@ __global__ __launch_bounds__(THREADS + 64 * LOADERS, 3) void conv2d_up2f16(Up2fP
     for (;;) {
         for (int k = 0; k < nchunks; k++) {
             __builtin_amdgcn_s_barrier();
-            compute_chunk(cbuf);
+            if (!(dbg_ & 4)) compute_chunk(cbuf);
             cbuf = cbuf == G::NBUF - 1 ? 0 : cbuf + 1;
         }
-        write_tile(tile, dpar);
+        if (!(dbg_ & 8)) {
+            if (has_scale) write_tile(tile, dpar, std::true_type{}); else write_tile(tile, dpar, std::false_type{});
+        }
         if (tile + (int)gridDim.x >= total) break;
         tile += gridDim.x;
         dpar ^= 1;
@@ -320,9 +342,9 @@ __global__ __launch_bounds__(THREADS + 64 * LOADERS, 3) void conv2d_up2f16(Up2fP
     }
 }
 
-template <typename T>
+template <typename T, int MW, int NB>
 int launch_up2f16(const Up2fParams& pp0, hipStream_t s) {
-    typedef Up2fGeo G;
+    typedef Up2fGeo<MW, NB> G;
     Up2fParams pp = pp0;
     Conv16Params& p = pp.c;
     p.tilesX = (p.W + G::UW - 1) / G::UW;
@@ -335,12 +357,13 @@ int launch_up2f16(const Up2fParams& pp0, hipStream_t s) {
     const int dmax = std::max(std::max(p.tilesX, p.tilesY), p.mblocks);
     if (tiles * dmax >= 0x100000000LL) return PG_ERR_TOO_LARGE;
     p.m_tilesX = magic(p.tilesX); p.m_tilesY = magic(p.tilesY); p.m_mblocks = magic(p.mblocks); p.m_ksplit = 0;
-    const int64_t blocks = tiles < (int64_t)num_cu() ? tiles : (int64_t)num_cu();
-    auto kern = conv2d_up2f16<T>;
+    const int64_t resident = (int64_t)num_cu() * G::WG_PER_CU;        // persistent: WG_PER_CU workgroups per CU
+    const int64_t blocks = tiles < resident ? tiles : resident;
+    auto kern = conv2d_up2f16<T, MW, NB>;
     static PerDeviceOnce lds_attr;
-    const hipError_t e = lds_attr.run([&] { return hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+    const hipError_t e = lds_attr.run([&] { return hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 / G::WG_PER_CU); });
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(THREADS + 64 * LOADERS), G::LDS_BYTES, s, pp);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(G::NTHREADS), G::LDS_BYTES, s, pp);
     return launch_status();
 }
 

@@ -222,14 +222,18 @@ def _separable_taps(f):
     """(fy, fx) with f == outer(fy, fx) for a rank-1 2-D filter (what upfirdn2d.setup_filter makes of [1, 3, 3, 1]), else None."""
     if f is None or f.ndim != 2:
         return None
-    f = f.detach().double().cpu()
-    tot = float(f.sum())
-    if tot == 0.0:
-        return None
-    fy, fx = f.sum(dim=1), f.sum(dim=0) / tot
-    if float((torch.outer(fy, fx) - f).abs().max()) > 1e-6 * float(f.abs().max()):
-        return None
-    return fy.float(), fx.float()
+    hit = getattr(f, '_pg_separable', None)      # (version, result) kept ON the tensor object: the read-back below is a host sync, which a graph capture forbids
+    if hit is not None and hit[0] == f._version:
+        return hit[1]
+    g = f.detach().double().cpu()
+    tot = float(g.sum())
+    out = None
+    if tot != 0.0:
+        fy, fx = g.sum(dim=1), g.sum(dim=0) / tot
+        if float((torch.outer(fy, fx) - g).abs().max()) <= 1e-6 * float(g.abs().max()):
+            out = (fy.float(), fx.float())
+    f._pg_separable = (f._version, out)
+    return out
 
 
 def _up2_fused_weights(wt_iohw, fy):

@@ -2,9 +2,9 @@
 #include "conv2d_up2f16.h"
 namespace pgconv16 {
 int launch16_up2f(const Up2fParams& p, int dtype, hipStream_t s) {
-    // PG_UP2F_WG=1: one 12-wave workgroup per CU (16-row tiles, three staging buffers, the epilogue after the K loop); 2: two 6-wave workgroups per CU (8-row tiles, two buffers)
-    static const int per_cu = [] { const char* e = getenv("PG_UP2F_WG"); return e ? atoi(e) : 0; }();
-    if (per_cu == 0) {                                                     // default: the tile-pipelined form (two accumulator sets, the epilogue inside the next tile's K loop)
+    // PG_UP2F_WG=1 (default): one 12-wave workgroup per CU (16-row tiles, three staging buffers, the epilogue after the K loop); 2: two 6-wave workgroups per CU (8-row tiles, two buffers); 0: conv2d_up2f16p
+    static const int per_cu = [] { const char* e = getenv("PG_UP2F_WG"); return e ? atoi(e) : 1; }();
+    if (per_cu == 0) {                                                     // experimental: the eight-wave ping-pong form (conv2d_up2f16p; parity-green, slower for now)
         if (dtype == PG_BF16) return launch_up2f16p<bf16_t>(p, s);
         if (dtype == PG_F16) return launch_up2f16p<f16_t>(p, s);
     } else if (per_cu == 1) {

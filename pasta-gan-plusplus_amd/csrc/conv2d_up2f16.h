@@ -51,11 +51,13 @@ struct Up2fGeo {
     static constexpr int NSTEP = 18;                       // (ty, tx, phase) weight fragments with a non-zero tap: per ty, tx = 1 x phases 0..3, then tx = 0 x phases 0, 2
     static constexpr int IH_T = TH + 2, IW_T = LW + 1;
     static constexpr int NPIX = IH_T * IW_T;               // halo pixels
-    static constexpr int PLANE = (NPIX + 63) / 64 * 64;    // slots per k-half plane: the halo is staged as [k-half][row][col] x 16 bytes, so that a wave's
-                                                           // ds_read_b128 (lanes 0-31: 32 consecutive pixels of plane 0, lanes 32-63: of plane 1) walks whole
-                                                           // 256-byte bank rows per 16 lanes -- conflict-free without a swizzle, and every tap shift is an
-                                                           // immediate offset from ONE lane address (the swizzled layout of conv2d_kernel16.h costs a register pair per shift)
-    static constexpr int NXS = 2 * PLANE;
+    // The halo is staged in 1 KB groups of 32 consecutive pixels, [group][k-half][32 pixels] x 16 bytes: a wave's ds_read_b128 (lanes 0-31: 32 consecutive
+    // pixels of k-half 0, lanes 32-63: of k-half 1) walks whole 256-byte bank rows per 16 lanes -- conflict-free without an XOR swizzle -- and ONE LDS-DMA
+    // instruction (64 consecutive slots) fetches BOTH 16-byte halves of 32 pixels' 32-byte channel chunk, so lanes l and l + 32 ask for adjacent bytes.
+    // (First cut: two whole k-half planes -- every 16-byte request its own cache line, twice the L2 requests for the same bytes: the request stream of a
+    // step with nothing else running took 53-68 us on the five config-5 shapes, 36-57 us in this layout; tools/up2f_probe.py, PG_CONV16_DBG=12.)
+    static constexpr int NGRP = (NPIX + 31) / 32;
+    static constexpr int NXS = NGRP * 64;
     static constexpr int NXS_PAD = (NXS + LT - 1) / LT * LT;
     static constexpr int NWS = NSTEP * 2 * 32;             // 1152 weight slots: [step][k-half][32 couts]
     static constexpr int NWS_PAD = (NWS + LT - 1) / LT * LT;
@@ -118,7 +120,7 @@ __global__ __launch_bounds__((MW + MW / 2) * 64, 3) void conv2d_up2f16(Up2fParam
             rel[j] = SENTINEL;
             if (j < G::NREQ_X) {
                 hyx[j] = 0x4000u;
-                const int c = s >= G::PLANE, qh = s - c * G::PLANE;
+                const int c = (s >> 5) & 1, qh = (s >> 6) * 32 + (s & 31);
                 const int hy = qh / G::IW_T, hx = qh % G::IW_T;
                 if (qh < G::NPIX && s < G::NXS) {
                     rel[j] = (unsigned)((hy * p.W + hx) * p.xC + c * 8) * 2u;
@@ -208,8 +210,7 @@ __global__ __launch_bounds__((MW + MW / 2) * 64, 3) void conv2d_up2f16(Up2fParam
 #pragma unroll
             for (int k = 0; k < 16; k++) acc[ph][nt][k] = 0.f;
 
-    // operand addresses: ONE lane address per operand, every tap / row / phase an immediate offset
-    const unsigned b_lane = (unsigned)(half * G::PLANE + (2 * wave) * G::IW_T + l31) * 16u;
+    // operand addresses: the weights ONE lane address + immediates; the activations by halo pixel q = q_lane + (row, tap) offset: group q >> 5, k-half, pixel q & 31
     const unsigned a_lane = (unsigned)(G::NXS_PAD + half * 32 + l31) * 16u;
 
     // One 16-channel chunk: 18 weight fragments (ty, tx, phase), each multiplied with the two position rows of the wave.  The loop is
@@ -217,9 +218,15 @@ __global__ __launch_bounds__((MW + MW / 2) * 64, 3) void conv2d_up2f16(Up2fParam
     // fragments rotate through FOUR register sets (row ty leaves after its last use, row ty + 2 takes its place) -- and pinned with
     // sched_barrier: left to itself the scheduler (at the register limit) sinks every read to its first use and waits lgkmcnt(0) there.
     auto compute_chunk = [&](int buf) __attribute__((always_inline)) {
-        const unsigned char* bb = smem + (size_t)buf * G::LDS_BUF * 16 + b_lane;
+        int lane_k;                                                    // (fresh lane id, asm volatile: the eight activation addresses are rebuilt per chunk, 4 vector
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_k));      // instructions each -- hoisted out of the loop they were spilled and came back through scratch loads)
+        const int q_lane = (2 * wave) * G::IW_T + (lane_k & 31);
+        const unsigned char* bb = smem + (size_t)buf * G::LDS_BUF * 16 + (lane_k >> 5) * 512;
         const unsigned char* ab = smem + (size_t)buf * G::LDS_BUF * 16 + a_lane;
-        auto b_frag = [&](int hr, int tx) __attribute__((always_inline)) { return *(lds_v4)(bb + (size_t)(hr * G::IW_T + tx) * 16); };
+        auto b_frag = [&](int hr, int tx) __attribute__((always_inline)) {
+            const int q = q_lane + hr * G::IW_T + tx;
+            return *(lds_v4)(bb + (size_t)(((q >> 5) << 10) + ((q & 31) << 4)));
+        };
         auto a_frag = [&](int i) __attribute__((always_inline)) { return *(lds_v4)(ab + (size_t)(i * 64) * 16); };
         i32x4 b1[4], b0[4];                                           // [halo row] for tx = 1 / tx = 0; at most four of the eight are live
         b1[0] = b_frag(0, 1); b1[1] = b_frag(1, 1);

@@ -53,7 +53,7 @@ for (N, cin, cout, H) in shapes:
     os.environ['PG_CONV16_DBG'] = '0'
     t_comp = timed(lambda: M.conv2d_forward(x, pkc, cout, 3, 3, pad=(1, 1), out_hw=(H, H), y=y, sample_stride=perc, noise=noise, phases=True, **ep))
     line = f'N{N} {cin}->{cout} {H}^2: composite {t_comp:.0f}us | fused-x'
-    for dbg in (0, 1, 64, 8, 4, 12, 128, 140):
+    for dbg in [int(v) for v in os.environ.get("UP2F_DBGS", "0,1,8,4,12,128,136,140").split(",")]:
         os.environ['PG_CONV16_DBG'] = str(dbg)
         line += f'  dbg{dbg}={timed(lambda: M.conv_up2_fused(x, pk, cout, [2 * float(v) for v in fx], sample_stride=per, noise=noise, **ep)):.0f}'
     os.environ['PG_CONV16_DBG'] = '0'

@@ -268,60 +268,66 @@ __global__ __launch_bounds__((MW + MW / 2) * 64, 3) void conv2d_up2f16(Up2fParam
         const unsigned char* side = smem + (size_t)G::NBUF * G::LDS_BUF * 16 + (size_t)dpar * G::EP_FLOATS * 4;
         const int r = e_r0 + l31;
         const bool col_ok = l31 >= 1 && l31 <= G::UW && r < p.W;
+        // Loop order: the register-group pair (g0, g0 + 1) outermost -- its per-cout constants are read from LDS twice per tile instead of once per
+        // (row, parity, group): 8 instead of 32 exposed LDS round trips per tile and wave.
 #pragma unroll
-        for (int nt = 0; nt < 2; nt++) {
-            const int row_l = 2 * wave + nt, q = e_q0 + row_l;
-            const bool pos_ok = col_ok && q < p.H && !(dbg_ & 1);
+        for (int g0 = 0; g0 < 4; g0 += 2) {
+            f32x4 bgv[2], sgv[2];
 #pragma unroll
-            for (int a = 0; a < 2; a++) {
-                const int oy = 2 * q + a;
-                const float nze = *(lds_f)(side + (size_t)(2 * G::EPS + (2 * a) * (G::TH * G::LW) + row_l * G::LW + l31) * 4) * ng;
-                const float nzo = *(lds_f)(side + (size_t)(2 * G::EPS + (2 * a + 1) * (G::TH * G::LW) + row_l * G::LW + l31) * 4) * ng;
-                const unsigned pix_off = (unsigned)((int64_t)e_n * p.ys[0] + (int64_t)oy * p.ys[2] + (int64_t)(2 * r) * p.ys[3]);
-                u32x2 pe, po;                                              // group g - 1's packed results (even g), waiting for their exchange partner
+            for (int gg = 0; gg < 2; gg++) {
+                const int r0c = 8 * (g0 + gg) + 4 * half;
+                bgv[gg] = *(lds_f4)(side + (size_t)(G::EPS + r0c) * 4) * gain;
+                if constexpr (SCALED) sgv[gg] = *(lds_f4)(side + (size_t)r0c * 4) * gain;
+            }
+            const int co = e_m0 + 8 * (g0 + half);
 #pragma unroll
-                for (int g = 0; g < 4; g++) {
-                    const int r0c = 8 * g + 4 * half;
-                    const f32x4 bgv = *(lds_f4)(side + (size_t)(G::EPS + r0c) * 4) * gain;
-                    f32x4 sgv;
-                    if constexpr (SCALED) sgv = *(lds_f4)(side + (size_t)r0c * 4) * gain;
-                    float ve[4], vo[4];
+            for (int nt = 0; nt < 2; nt++) {
+                const int row_l = 2 * wave + nt, q = e_q0 + row_l;
+                const bool ok = col_ok && q < p.H && !(dbg_ & 1) && co < pc;
 #pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const float z0 = acc[2 * a][nt][4 * g + j], z1 = acc[2 * a + 1][nt][4 * g + j];
-                        const float z1m = dpp_f<DPP_WAVE_SHR1>(z1), z0p = dpp_f<DPP_WAVE_SHL1>(z0), z1p = dpp_f<DPP_WAVE_SHL1>(z1);
-                        float ue, uo;
-                        if constexpr (SCALED) {
-                            const float he = fmaf(f3, z1m, fmaf(f2, z0, fmaf(f1, z1, f0 * z0p)));
-                            const float ho = fmaf(f3, z0, fmaf(f2, z1, fmaf(f1, z0p, f0 * z1p)));
-                            ue = fmaf(he, sgv[j], bgv[j] + nze); uo = fmaf(ho, sgv[j], bgv[j] + nzo);
-                        } else {
-                            ue = fmaf(f3, z1m, fmaf(f2, z0, fmaf(f1, z1, fmaf(f0, z0p, bgv[j] + nze))));
-                            uo = fmaf(f3, z0, fmaf(f2, z1, fmaf(f1, z0p, fmaf(f0, z1p, bgv[j] + nzo))));
+                for (int a = 0; a < 2; a++) {
+                    const int oy = 2 * q + a;
+                    const float nze = *(lds_f)(side + (size_t)(2 * G::EPS + (2 * a) * (G::TH * G::LW) + row_l * G::LW + l31) * 4) * ng;
+                    const float nzo = *(lds_f)(side + (size_t)(2 * G::EPS + (2 * a + 1) * (G::TH * G::LW) + row_l * G::LW + l31) * 4) * ng;
+                    const unsigned pix_off = (unsigned)((int64_t)e_n * p.ys[0] + (int64_t)oy * p.ys[2] + (int64_t)(2 * r) * p.ys[3]);
+                    u32x2 ce[2], co2[2];
+#pragma unroll
+                    for (int gg = 0; gg < 2; gg++) {
+                        const int g = g0 + gg;
+                        float ve[4], vo[4];
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            const float z0 = acc[2 * a][nt][4 * g + j], z1 = acc[2 * a + 1][nt][4 * g + j];
+                            const float z1m = dpp_f<DPP_WAVE_SHR1>(z1), z0p = dpp_f<DPP_WAVE_SHL1>(z0), z1p = dpp_f<DPP_WAVE_SHL1>(z1);
+                            float ue, uo;
+                            if constexpr (SCALED) {
+                                const float he = fmaf(f3, z1m, fmaf(f2, z0, fmaf(f1, z1, f0 * z0p)));
+                                const float ho = fmaf(f3, z0, fmaf(f2, z1, fmaf(f1, z0p, f0 * z1p)));
+                                ue = fmaf(he, sgv[gg][j], bgv[gg][j] + nze); uo = fmaf(ho, sgv[gg][j], bgv[gg][j] + nzo);
+                            } else {
+                                ue = fmaf(f3, z1m, fmaf(f2, z0, fmaf(f1, z1, fmaf(f0, z0p, bgv[gg][j] + nze))));
+                                uo = fmaf(f3, z0, fmaf(f2, z1, fmaf(f1, z0p, fmaf(f0, z1p, bgv[gg][j] + nzo))));
+                            }
+                            ve[j] = __builtin_amdgcn_fmed3f(fmaxf(ue, ue * slope), -cl, cl);
+                            vo[j] = __builtin_amdgcn_fmed3f(fmaxf(uo, uo * slope), -cl, cl);
                         }
-                        ve[j] = __builtin_amdgcn_fmed3f(fmaxf(ue, ue * slope), -cl, cl);
-                        vo[j] = __builtin_amdgcn_fmed3f(fmaxf(uo, uo * slope), -cl, cl);
+                        ce[gg] = u32x2{HT::pack(ve[0], ve[1]), HT::pack(ve[2], ve[3])};
+                        co2[gg] = u32x2{HT::pack(vo[0], vo[1]), HT::pack(vo[2], vo[3])};
+                        __builtin_amdgcn_sched_barrier(0);      // (one group of 2 x 4 values at a time: interleaving more for ILP costs registers the wave does not have beside its 128 accumulators)
                     }
-                    u32x2 ce = {HT::pack(ve[0], ve[1]), HT::pack(ve[2], ve[3])}, co2 = {HT::pack(vo[0], vo[1]), HT::pack(vo[2], vo[3])};
-                    if (g & 1) {
-                        // lanes 32-63 of group g - 1 <-> lanes 0-31 of group g: 8 consecutive couts of one pixel per lane
+                    // lanes 32-63 of group g0 <-> lanes 0-31 of group g0 + 1: 8 consecutive couts of one pixel per lane
 #pragma unroll
-                        for (int d = 0; d < 2; d++) {
-                            const auto re = __builtin_amdgcn_permlane32_swap(pe[d], ce[d], false, false);
-                            pe[d] = re[0]; ce[d] = re[1];
-                            const auto ro = __builtin_amdgcn_permlane32_swap(po[d], co2[d], false, false);
-                            po[d] = ro[0]; co2[d] = ro[1];
-                        }
-                        const int co = e_m0 + 8 * (g - 1 + half);
-                        const bool ok = pos_ok && co < pc;
-                        const unsigned se = ok ? (pix_off + (unsigned)co) * 2u : SENTINEL;
-                        const unsigned so = ok ? (pix_off + (unsigned)p.ys[3] + (unsigned)co) * 2u : SENTINEL;
-                        __builtin_amdgcn_raw_buffer_store_b128(u32x4{pe[0], pe[1], ce[0], ce[1]}, yrsrc, (int)se, 0, 0);
-                        __builtin_amdgcn_raw_buffer_store_b128(u32x4{po[0], po[1], co2[0], co2[1]}, yrsrc, (int)so, 0, 0);
-                    } else {
-                        pe = ce; po = co2;
+                    for (int d = 0; d < 2; d++) {
+                        const auto re = __builtin_amdgcn_permlane32_swap(ce[0][d], ce[1][d], false, false);
+                        ce[0][d] = re[0]; ce[1][d] = re[1];
+                        const auto ro = __builtin_amdgcn_permlane32_swap(co2[0][d], co2[1][d], false, false);
+                        co2[0][d] = ro[0]; co2[1][d] = ro[1];
                     }
-                    __builtin_amdgcn_sched_barrier(0);      // (one group of 2 x 16 values at a time: interleaving the groups of a tile for ILP costs more registers than the wave has beside its 128 accumulators)
+                    const unsigned se = ok ? (pix_off + (unsigned)co) * 2u : SENTINEL;
+                    const unsigned so = ok ? (pix_off + (unsigned)p.ys[3] + (unsigned)co) * 2u : SENTINEL;
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{ce[0][0], ce[0][1], ce[1][0], ce[1][1]}, yrsrc, (int)se, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{co2[0][0], co2[0][1], co2[1][0], co2[1][1]}, yrsrc, (int)so, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }

@@ -113,11 +113,93 @@ def cpu_baseline(max_seconds=40.0):
                        f'({", ".join(f"{t:.1f}s" for t in times)}), median reported; host reports {avail} logical CPUs')
 
 
+def conv_roofline(timeline, elapsed, steps, images_per_s_per_gpu, traffic_tag, gflop_per_image=None):
+    """`roofline` of an fp32 run from the per-launch HIP events of its timed region: the dominant kernel = the convolution algorithm with the largest share
+    of the region.  The MFMA roofline is priced on the flops that algorithm EXECUTES on the matrix pipe -- Winograd F(4x4,3x3) (csrc/conv2d_wino4.h):
+    36 multiplies per 16 outputs = 1/4 of the direct-convolution count; F(2x2,3x3) (csrc/conv2d_wino.h): 4/9; the direct implicit GEMM: all of it --
+    and the direct-convolution-equivalent rate of the same launches is reported next to it (it can exceed the matrix peak)."""
+    WORK = {'winograd4': 0.25, 'winograd': 4.0 / 9.0, 'direct': 1.0}
+    KERNEL = {'winograd4': 'conv2d_wino4<MODE,TAIL> (Winograd F(4x4,3x3) stride-1 3x3 convolution, v_mfma_f32_32x32x2_f32)',
+              'winograd': 'conv2d_wino<MODE,VEC> (Winograd F(2x2,3x3) stride-1 3x3 convolution, v_mfma_f32_32x32x2_f32)',
+              'direct': 'conv2d_mfma<KH,KW,S,BM,KC,XF> (implicit GEMM, v_mfma_f32_32x32x2_f32)'}
+    by_algo = {}
+    for geo, fl, e0, e1, by in timeline:
+        if geo[3] in WORK:
+            by_algo.setdefault(geo[3], []).append((fl, e0.elapsed_time(e1) * 1e-3, by))
+    if not by_algo:
+        return None
+    allk = [ft[:2] for v in by_algo.values() for ft in v]
+    algo = max(by_algo, key=lambda a_: sum(ft[1] for ft in by_algo[a_]))
+    dom, work = [ft[:2] for ft in by_algo[algo]], WORK[algo]
+    dom_bytes = sum(ft[2] for ft in by_algo[algo])
+    dom_flops, dom_time = sum(f for f, _ in dom), sum(t for _, t in dom)
+    achieved = work * dom_flops / dom_time / 1e12 if dom_time > 0 else 0.0
+    traffic, traffic_src = committed_traffic(traffic_tag) if traffic_tag else (None, None)
+    out = dict(bound='mfma', kernel=KERNEL[algo],
+               achieved=round(achieved, 2), peak=F32_MFMA_PEAK_TFLOPS, unit='TFLOP/s', frac=round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
+               traffic=traffic, traffic_source=traffic_src, algorithmic_bytes_per_launch=round(dom_bytes / max(len(dom), 1)),
+               flops_counted=f'flops the kernel executes on the matrix pipe = {work:.4g} x the direct-convolution flops of SURVEY 8d',
+               direct_equivalent_tflops=round(dom_flops / max(dom_time, 1e-12) / 1e12, 2),
+               direct_equivalent_frac=round(dom_flops / max(dom_time, 1e-12) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),    # SURVEY 8d count / peak (> 1: fewer multiplies than counted)
+               launches_per_step=len(dom) // max(steps, 1), avg_launch_ms=round(1e3 * dom_time / max(len(dom), 1), 4),
+               time_frac_of_step=round(dom_time / elapsed, 4),
+               other_algorithms={a_: dict(launches_per_step=len(v) // max(steps, 1), ms_per_step=round(1e3 * sum(ft[1] for ft in v) / steps, 3),
+                                          executed_tflops=round(WORK[a_] * sum(ft[0] for ft in v) / max(sum(ft[1] for ft in v), 1e-12) / 1e12, 2))
+                                 for a_, v in by_algo.items() if a_ != algo},
+               all_conv_direct_equivalent_tflops=round(sum(f for f, _ in allk) / max(sum(t for _, t in allk), 1e-12) / 1e12, 2),
+               conv_time_frac_of_step=round(sum(t for _, t in allk) / elapsed, 4))
+    if gflop_per_image:
+        out['end_to_end_direct_equivalent_frac'] = round(images_per_s_per_gpu * gflop_per_image / 1e3 / F32_MFMA_PEAK_TFLOPS, 4)
+    return out
+
+
+def routed_sample_inputs(n, dev, seed):
+    """Synthetic inputs of the loader's patch-routing step (reference dataset.py:2555-2700 as test.py:117-160 runs it per sample), in the reference's formats:
+    512 x 512 x 3 uint8 garment images and 0 / 255 masks resident on the GPU, OpenPose-18 key points (x, y, confidence) on the host."""
+    import numpy as np
+    from training import patch_routing as P
+    rng = np.random.default_rng(seed)
+    joints = dict(cnose=(256, 60), cneck=(256, 110), rshoulder=(200, 120), relbow=(180, 200), rwrist=(170, 270), lshoulder=(312, 120), lelbow=(335, 200),
+                  lwrist=(345, 270), rhip=(220, 290), rknee=(215, 390), rankle=(212, 480), lhip=(292, 290), lknee=(297, 390), lankle=(300, 480),
+                  reye=(246, 50), leye=(266, 50), rear=(236, 55), lear=(276, 55))
+
+    def kps():
+        kp = np.zeros((18, 3))
+        for k, (x, y) in joints.items():
+            kp[P.ORDER.index(k)] = (x + rng.normal(0, 8.0), y + rng.normal(0, 8.0), 1.0)
+        return kp
+    samples = []
+    for _ in range(n):
+        up, lo = (torch.from_numpy(rng.integers(0, 256, (512, 512, 3), dtype=np.uint8)).to(dev) for _ in range(2))
+        um = torch.zeros(512, 512, 3, dtype=torch.uint8, device=dev); um[90:310, 150:370] = 255
+        lm = torch.zeros(512, 512, 3, dtype=torch.uint8, device=dev); lm[270:505, 190:330] = 255
+        samples.append((up * (um > 0), lo * (lm > 0), um, lm, kps(), kps()))
+    return samples
+
+
+def route_batch(samples):
+    """HIP patch routing of every sample (pg_warp_perspective_u8 x 2 + pg_patch_compose_u8 per part, training/patch_routing.py) -> the generator's routed
+    inputs, assembled on the GPU the way the loader (training/dataset.py) and test.py:126-147 do: c [N, 45, 128, 128], de-normalised garments + masks."""
+    from training import patch_routing as P
+    unit = lambda t: t.permute(2, 0, 1).to(torch.float32) / 127.5 - 1
+    c, du, dl, mu, ml = [], [], [], [], []
+    for up, lo, um, lm, ckp, pkp in samples:
+        norm_img, norm_lower, den_up, _, _ = P.normalize(up, lo, um, lm, None, ckp, pkp, 2, device=up.device)
+        den_lo = lo                                            # (the loader keeps the person's own lower garment, edge eroded: dataset.py `denorm_lower`)
+        c.append(torch.cat([unit(norm_img), unit(norm_lower)], dim=0))
+        du.append(unit(den_up)); dl.append(unit(den_lo))
+        mu.append((den_up.to(torch.int32).sum(dim=2, keepdim=True) > 0).permute(2, 0, 1).float())
+        ml.append((den_lo.to(torch.int32).sum(dim=2, keepdim=True) > 0).permute(2, 0, 1).float())
+    return dict(c=torch.stack(c), denorm_upper_input=torch.stack(du), denorm_lower_input=torch.stack(dl), denorm_upper_mask=torch.stack(mu), denorm_lower_mask=torch.stack(ml))
+
+
 def run_generator(args, rank, world, dev, dist):
     """BASELINE config 3 (secondary, --mode generator): full GeneratorFull_v20 inference -- pose encoder, garment-part style encoder
     with its feature pyramid, mapping MLP, then the synthesis network -- at N=16 per GPU on synthetic tensors of the shapes test.py
     feeds it (the patch-routing warp upstream is not part of this path)."""
     from training import networks, replicas
+    from torch_utils.ops import conv2d_mfma
+    routed = args.mode == 'generator_routed'
     n = args.batch if args.batch != BATCH_PER_GPU else 16
     G = networks.GeneratorFull_v20(z_dim=0, c_dim=512, w_dim=512, img_resolution=512, img_channels=3, mapping_kwargs=dict(num_layers=1),
                                    synthesis_kwargs=dict(channel_base=32768, channel_max=512, conv_clamp=256))
@@ -127,6 +209,17 @@ def run_generator(args, rank, world, dev, dist):
     inp = dict(z=torch.zeros([n, 0], device=dev), c=u(n, 45, 128, 128), retain=u(n, 6, 512, 512), pose=u(n, 5, 512, 512),
                denorm_upper_input=u(n, 3, 512, 512), denorm_lower_input=u(n, 3, 512, 512),
                denorm_upper_mask=(u(n, 1, 512, 512) > 0).float(), denorm_lower_mask=(u(n, 1, 512, 512) > 0).float())
+    samples = routed_sample_inputs(n, dev, 300 + rank) if routed else None
+    route_events = []
+
+    def step():
+        if routed:          # BASELINE config 3 as written: the patch-routing warp is on the critical path of every batch (test.py:117-160)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            inp.update(route_batch(samples))
+            e1.record()
+            route_events.append((e0, e1))
+        return G(**inp, noise_mode='const')
 
     def barrier():
         if dist is not None:
@@ -134,19 +227,44 @@ def run_generator(args, rank, world, dev, dist):
         torch.cuda.synchronize()
     with torch.no_grad():
         for _ in range(args.warmup):
-            out = G(**inp, noise_mode='const')
+            out = step()
         barrier()
+        route_events.clear()
+        if routed:
+            from training import patch_routing
+            patch_routing.traffic_counter = dict(bytes=0, launches=0)
+        timeline = conv2d_mfma.start_timeline()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            out = G(**inp, noise_mode='const')
+            out = step()
         barrier()
+        elapsed = time.perf_counter() - t0
+        conv2d_mfma.stop_timeline()
     assert all(torch.isfinite(o).all() for o in out)
-    elapsed = replicas.max_over_ranks(time.perf_counter() - t0, device=dev)
+    elapsed = replicas.max_over_ranks(elapsed, device=dev)
     if rank == 0:
-        print(json.dumps(dict(metric='512-res try-on images/sec (full generator: encoders + mapping + synthesis)', value=round(args.steps * n * world / elapsed, 3),
+        extra = {}
+        roofline = conv_roofline(timeline, elapsed, args.steps, args.steps * n / elapsed, 'cfg2')
+        if roofline:
+            roofline['traffic_note'] = 'per launch of the same kernel in the config-2 PMC passes (the synthesis network is the same; N = 8 there)'
+            extra['roofline'] = roofline
+        if routed:
+            from training import patch_routing
+            t_route = sum(e0.elapsed_time(e1) for e0, e1 in route_events) * 1e-3
+            tc = patch_routing.traffic_counter
+            extra['routing'] = dict(kernels='pg_warp_perspective_u8 (image -> patch, patch -> canvas: two batched launches per sample) + pg_patch_compose_u8 (erode + paste per part)',
+                                    ms_per_step=round(1e3 * t_route / args.steps, 3), ms_per_sample=round(1e3 * t_route / args.steps / n, 3),
+                                    time_frac_of_step=round(t_route / elapsed, 4), launches_per_step=tc['launches'] // max(args.steps, 1),
+                                    bound='hbm', algorithmic_bytes_per_step=tc['bytes'] // max(args.steps, 1),
+                                    achieved_gbs=round(tc['bytes'] / max(t_route, 1e-12) / 1e9, 1), peak_gbs=HBM_PEAK_GBS, frac=round(tc['bytes'] / max(t_route, 1e-12) / 1e9 / HBM_PEAK_GBS, 5),
+                                    note='stage time by events around the whole routing of a batch: it includes the host key-point geometry (20 homographies per sample) and the launch gaps '
+                                         'of ~45 small launches per sample -- the stage is latency-bound, its HBM fraction says so',
+                                    parity='UNPINNED: HIP == own oracle bit for bit; the oracle restates OpenCV\'s published fixed-point algorithm, cv2 is not available offline (DESIGN.md 6d)')
+        print(json.dumps(dict(metric='512-res try-on images/sec (full generator: ' + ('patch routing + ' if routed else '') + 'encoders + mapping + synthesis)', value=round(args.steps * n * world / elapsed, 3),
                               unit='images/s', n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(1e3 * elapsed / args.steps, 2),
-                              higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
-                              config=dict(workload='BASELINE config 3: GeneratorFull_v20 forward (ConstEncoderNetwork + StyleEncoderNetworkV18 + MappingNetwork + '
+                              higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32', data='synthetic', **extra,
+                              config=dict(workload='BASELINE config 3: ' + ('HIP patch routing of every sample (synthetic garments / masks / OpenPose key points in the reference formats) -> ' if routed else '') +
+                                                   'GeneratorFull_v20 forward (ConstEncoderNetwork + StyleEncoderNetworkV18 + MappingNetwork + '
                                                    'SynthesisNetworkFull_v18), 512x512, fp32, eval, noise_mode=const, argmax parsing, random-init weights',
                                           images_per_gpu_per_step=n, global_batch=n * world, parallelism=f'replicas x{world}'))), flush=True)
 
@@ -231,6 +349,10 @@ def run_stack(args, rank, world, dev, dist):
     t_dom = sum(r[2] for r in dom)
     gbs = sum(r[3] for r in dom) / max(t_dom, 1e-12) / 1e9
     tfl = sum(r[1] for r in dom) / max(t_dom, 1e-12) / 1e12
+    # SURVEY 8d counts an up = 2 layer as the transposed convolution it is in the reference (2 N Cin Hin Win Cout 9); the launches execute 2x that (the fused-x
+    # form: the y half of the FIR in the weights, 18 tap-products per position) or 4x (the composite four-phase form: 36)
+    survey = lambda r: r[1] / (2.0 if 'fused-x' in r[0][4] else (4.0 if '4 phases' in r[0][4] else 1.0))
+    tfl_survey = sum(survey(r) for r in dom) / max(t_dom, 1e-12) / 1e12
     top = [r for r in dom if '1024x1024' in r[0][4] or '512x512' in r[0][4]]
     line = dict(metric='1024-res bf16 StyleGAN2-stack images/sec (SynthesisStack fwd)', value=round(args.steps * n * world / elapsed, 3), unit='images/s',
                 n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(1e3 * elapsed / args.steps, 3), higher_is_better=True, scaling='weak',
@@ -243,8 +365,13 @@ def run_stack(args, rank, world, dev, dist):
                               traffic=committed_traffic('cfg5')[0], traffic_source=committed_traffic('cfg5')[1],
                               algorithmic_bytes_per_launch=round(sum(r[3] for r in dom) / max(len(dom), 1)),
                               bytes_counted='numel(x) + numel(y) + packed weights, in bytes, per launch',
-                              mfma_tflops=round(tfl, 1), mfma_frac=round(tfl / BF16_MFMA_PEAK_TFLOPS, 4),
-                              launches_per_step=len(dom) // max(args.steps, 1), conv_time_frac_of_step=round(t_dom / elapsed, 4),   # its launches' event time / the timed region
+                              mfma_tflops=round(tfl, 1), mfma_frac=round(tfl / BF16_MFMA_PEAK_TFLOPS, 4), mfma_flops_counted='executed on the matrix pipe',
+                              mfma_tflops_survey_count=round(tfl_survey, 1), mfma_frac_survey_count=round(tfl_survey / BF16_MFMA_PEAK_TFLOPS, 4),
+                              launches_per_step=len(dom) // max(args.steps, 1),
+                              measured_in='the EAGER pass of the same steps (per-launch HIP events cannot be recorded inside a replayed graph): every figure of this object, '
+                                          'including conv_time_frac_of_step, is of that pass; `value` / `ms_per_step` are of the hipGraph replay' if not args.no_graph else 'the timed (eager) pass',
+                              eager_ms_per_step=round(1e3 * eager_elapsed / args.steps, 3),
+                              conv_time_frac_of_step=round(t_dom / eager_elapsed, 4),   # its launches' event time / the wall time of the pass they were measured in
                               top_res_gbs=round(sum(r[3] for r in top) / max(sum(r[2] for r in top), 1e-12) / 1e9, 1)))
     if world == 1 and not args.no_cpu_baseline:
         line['cpu_baseline'] = cpu_baseline_stack(args.channel_max)
@@ -372,7 +499,7 @@ def under_profiler():
                for k in ('LD_PRELOAD', 'ROCP_TOOL_LIBRARIES', 'HSA_TOOLS_LIB', 'ROCPROFILER_LIBRARY_PATH'))
 
 
-def secondary_runs(budget_s=200.0):
+def secondary_runs(budget_s=240.0):
     """BASELINE configs 3, 5 and 4 as child processes of this script (fresh processes: the parent's GPU memory pool and plugin state do not
     leak into them; the parent only waits -- it never execs), a few seconds each; their JSON lines are attached to the headline
     line as `secondary`.  Failures are recorded, never raised: the headline must not depend on them."""
@@ -380,6 +507,7 @@ def secondary_runs(budget_s=200.0):
     out = {}
     t_start = time.perf_counter()
     for key, extra in (('config3_generator', ['--mode', 'generator', '--steps', '8', '--warmup', '3']),
+                       ('config3_routed', ['--mode', 'generator_routed', '--steps', '6', '--warmup', '2']),
                        ('config5_bf16_1024', ['--mode', 'bf16_1024', '--steps', '30', '--warmup', '10', '--no-cpu-baseline']),
                        ('config4_train_step', ['--mode', 'train', '--steps', '10', '--warmup', '3', '--no-cpu-baseline'])):
         left = budget_s - (time.perf_counter() - t_start)
@@ -394,7 +522,7 @@ def secondary_runs(budget_s=200.0):
                 out[key] = dict(error=f'exit {r.returncode}: {(r.stderr or r.stdout)[-300:]}')
                 continue
             j = json.loads(line[-1])
-            out[key] = {k: j[k] for k in ('metric', 'value', 'unit', 'steps', 'warmup', 'ms_per_step', 'images_per_sec', 'dtype', 'config', 'roofline') if k in j}
+            out[key] = {k: j[k] for k in ('metric', 'value', 'unit', 'steps', 'warmup', 'ms_per_step', 'images_per_sec', 'dtype', 'config', 'roofline', 'routing') if k in j}
         except Exception as e:                                # noqa: BLE001 -- recorded, the headline line still prints
             out[key] = dict(error=f'{type(e).__name__}: {e}'[:300])
     return out
@@ -411,8 +539,8 @@ def main():
     ap.add_argument('--train-graphs', action='store_true', help='config 4: replay each phase as one hipGraph (TrainingStep(graphs=True)); measured 312 vs 304 ms eager -- the step is GPU-bound')
     ap.add_argument('--d-fp16-res', type=int, default=3, help='config 4: discriminator resolutions in fp16 (train.py:196: 3; 0 = fp32)')
     ap.add_argument('--conv-breakdown', default=None, metavar='CSV', help='also write the per-shape conv launch timeline of the timed steps')
-    ap.add_argument('--mode', choices=['synthesis', 'generator', 'train', 'bf16_1024', 'selftest'], default='synthesis',
-                    help="'synthesis' = the headline (config 2); 'generator' = config 3 (encoders + mapping + synthesis, N=16); 'train' = config 4 step; "
+    ap.add_argument('--mode', choices=['synthesis', 'generator', 'generator_routed', 'train', 'bf16_1024', 'selftest'], default='synthesis',
+                    help="'synthesis' = the headline (config 2); 'generator' = config 3 (encoders + mapping + synthesis, N=16) on synthetic tensors, 'generator_routed' = the same behind the HIP patch routing of every sample; 'train' = config 4 step; "
                          "'bf16_1024' = config 5 (StyleGAN2 stack at 1024^2 in bf16, N=4); 'selftest' = launcher / rank plumbing on CPU over gloo with a stub forward (no measurement)")
     ap.add_argument('--no-secondary', action='store_true', help='headline mode: skip the config 3 / config 5 child runs')
     ap.add_argument('--channel-max', type=int, default=1024, help="config 5: widest layer (SURVEY 8d: 'channels 1024 -> 32')")
@@ -448,8 +576,8 @@ def main():
     from torch_utils.ops import conv2d_mfma
     from training import networks, replicas
 
-    if args.mode in ('train', 'generator', 'bf16_1024'):
-        dict(train=run_train, generator=run_generator, bf16_1024=run_stack)[args.mode](args, rank, world, dev, dist)
+    if args.mode in ('train', 'generator', 'generator_routed', 'bf16_1024'):
+        dict(train=run_train, generator=run_generator, generator_routed=run_generator, bf16_1024=run_stack)[args.mode](args, rank, world, dev, dist)
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
@@ -484,38 +612,7 @@ def main():
     if rank == 0:
         images = args.batch * args.steps * world
         value = images / elapsed
-        # Dominant kernel = the convolution algorithm with the largest share of the timed region.  The MFMA roofline is priced on the
-        # flops that algorithm EXECUTES on the matrix pipe -- Winograd F(4x4,3x3) (csrc/conv2d_wino4.h): 36 multiplies per 16 outputs =
-        # 1/4 of the direct-convolution count; F(2x2,3x3) (csrc/conv2d_wino.h): 4/9; the direct implicit GEMM: all of it -- and the
-        # direct-convolution-equivalent rate of the same launches is reported next to it (it can exceed the matrix peak).
-        WORK = {'winograd4': 0.25, 'winograd': 4.0 / 9.0, 'direct': 1.0}
-        KERNEL = {'winograd4': 'conv2d_wino4<MODE,TAIL> (Winograd F(4x4,3x3) stride-1 3x3 convolution, v_mfma_f32_32x32x2_f32)',
-                  'winograd': 'conv2d_wino<MODE,VEC> (Winograd F(2x2,3x3) stride-1 3x3 convolution, v_mfma_f32_32x32x2_f32)',
-                  'direct': 'conv2d_mfma<KH,KW,S,BM,KC,XF> (implicit GEMM, v_mfma_f32_32x32x2_f32)'}
-        by_algo = {}
-        for geo, fl, e0, e1, _ in timeline:
-            by_algo.setdefault(geo[3], []).append((fl, e0.elapsed_time(e1) * 1e-3, _))
-        allk = [ft[:2] for v in by_algo.values() for ft in v]
-        algo = max(by_algo, key=lambda a_: sum(ft[1] for ft in by_algo[a_]))
-        dom, work = [ft[:2] for ft in by_algo[algo]], WORK[algo]
-        dom_bytes = sum(ft[2] for ft in by_algo[algo])
-        dom_flops, dom_time = sum(f for f, _ in dom), sum(t for _, t in dom)
-        achieved = work * dom_flops / dom_time / 1e12 if dom_time > 0 else 0.0
-        traffic, traffic_src = committed_traffic('cfg2')
-        roofline = dict(bound='mfma', kernel=KERNEL[algo],
-                        achieved=round(achieved, 2), peak=F32_MFMA_PEAK_TFLOPS, unit='TFLOP/s', frac=round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
-                        traffic=traffic, traffic_source=traffic_src, algorithmic_bytes_per_launch=round(dom_bytes / max(len(dom), 1)),
-                        flops_counted=f'flops the kernel executes on the matrix pipe = {work:.4g} x the direct-convolution flops of SURVEY 8d',
-                        direct_equivalent_tflops=round(dom_flops / max(dom_time, 1e-12) / 1e12, 2),
-                        direct_equivalent_frac=round(dom_flops / max(dom_time, 1e-12) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),    # SURVEY 8d count / peak (> 1: fewer multiplies than counted)
-                        launches_per_step=len(dom) // max(args.steps, 1), avg_launch_ms=round(1e3 * dom_time / max(len(dom), 1), 4),
-                        time_frac_of_step=round(dom_time / elapsed, 4),
-                        other_algorithms={a_: dict(launches_per_step=len(v) // max(args.steps, 1), ms_per_step=round(1e3 * sum(ft[1] for ft in v) / args.steps, 3),
-                                                   executed_tflops=round(WORK[a_] * sum(ft[0] for ft in v) / max(sum(ft[1] for ft in v), 1e-12) / 1e12, 2))
-                                          for a_, v in by_algo.items() if a_ != algo},
-                        all_conv_direct_equivalent_tflops=round(sum(f for f, _ in allk) / max(sum(t for _, t in allk), 1e-12) / 1e12, 2),
-                        conv_time_frac_of_step=round(sum(t for _, t in allk) / elapsed, 4),
-                        end_to_end_direct_equivalent_frac=round(value / world * GFLOP_PER_IMAGE / 1e3 / F32_MFMA_PEAK_TFLOPS, 4))
+        roofline = conv_roofline(timeline, elapsed, args.steps, value / world, 'cfg2', GFLOP_PER_IMAGE)
         line = dict(metric='512-res try-on images/sec (SynthesisNetwork fwd)', value=round(value, 3), unit='images/s', n_gpus=world,
                     steps=args.steps, warmup=args.warmup, ms_per_step=round(1e3 * elapsed / args.steps, 3), higher_is_better=True,
                     scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',

@@ -238,10 +238,16 @@ def _patch_compose_cpu_(canvas, patch, mask, canvas2):
     return canvas
 
 
+traffic_counter = None      # bench.py sets this to a dict(bytes=0, launches=0): algorithmic bytes (source image + destination, each once per job) of the launches
+
+
 def warp_perspective_batch(jobs):
     """jobs: list of (src uint8 [H,W,C] GPU tensor, forward 3x3 matrix as cv2.warpPerspective takes it, (w, h)) -> list of outputs."""
     if not jobs:
         return []
+    if traffic_counter is not None:
+        traffic_counter['bytes'] += sum(int(src.numel()) + int(w) * int(h) * (int(src.shape[2]) if src.ndim == 3 else 1) for src, _, (w, h) in jobs)
+        traffic_counter['launches'] += 1
     dev = jobs[0][0].device
     if dev.type != 'cuda':
         return [_warp_perspective_cpu(src, m, wh) for src, m, wh in jobs]
@@ -273,6 +279,9 @@ def patch_compose_(canvas, patch, mask, canvas2=None):
     """canvas[p] = patch[p] where erode8x8(mask[..., 0]) == 255 (also into canvas2), in place."""
     if canvas.device.type != 'cuda':
         return _patch_compose_cpu_(canvas, patch, mask, canvas2)
+    if traffic_counter is not None:     # patch + mask read, the canvas (and its copy) written where the eroded mask is set: counted whole
+        traffic_counter['bytes'] += int(patch.numel()) + int(mask.numel()) + int(canvas.numel()) * (2 if canvas2 is not None else 1)
+        traffic_counter['launches'] += 1
     lib = _init().lib
     h, w = canvas.shape[:2]
     mc = mask.shape[2] if mask.ndim == 3 else 1

@@ -166,8 +166,8 @@ typedef struct pg_conv2d_fusion {
        front of merge_conv (networks.py:2179-2181).  cin_split must be a multiple of 16. */
     const float* x2;
     int          cin_split;
-    /* Instance-norm statistics of the OUTPUT, gathered where it is produced (round 4): when set, every workgroup tile also writes the sum and the
-       sum of squares of its in-image outputs per output channel to stats_partial[((n * Cout + co) * T + t) * 2 + {0, 1}], T = the tile count of one
+    /* Instance-norm statistics of the OUTPUT, gathered where it is produced (round 4): when set, every workgroup tile also writes the sum and M2
+       (the sum of squared deviations from the tile's own mean; round 5, was the sum of squares) of its in-image outputs per output channel to stats_partial[((n * Cout + co) * T + t) * 2 + {0, 1}], T = the tile count of one
        image (pg_conv2d_winograd4_stats_tiles), t = the tile's index; pg_instance_norm_finish turns them into mean / rstd (fixed order: deterministic).
        The values are those written to y (after the epilogue).  Only pg_conv2d_winograd4_forward launches with the plain tail (no in_scale, noise,
        residual, SPADE) gather them; every other launch with this field set is declined (PG_ERR_UNSUPPORTED).  The SPADE res-blocks normalise the
@@ -243,10 +243,10 @@ int pg_conv2d_winograd4b_forward(const float* x, const float* packed_u, float* y
                                  const int64_t ystride[4], const pg_conv2d_fusion* fusion, void* stream);
 
 /* Statistics gathered by pg_conv2d_winograd4_forward (pg_conv2d_fusion::stats_partial): tiles of one image for an OH x OW output, and the
- * reduction of the per-tile sums into mean[n*C + c] and rstd = 1 / sqrt(var + eps) (biased variance over HW = OH*OW; float64 accumulation of the
- * float32 partial sums in tile order). */
+ * reduction of the per-tile (sum, M2) pairs into mean[n*C + c] and rstd = 1 / sqrt(var + eps) (biased variance over OH*OW): Chan's pairwise merge in
+ * float64, tiles in index order per lane, then a fixed-shape wave reduction -- deterministic, and not E[x^2] - E[x]^2.  T = pg_conv2d_winograd4_stats_tiles(OH, OW). */
 int pg_conv2d_winograd4_stats_tiles(int OH, int OW);
-int pg_instance_norm_finish(const float* stats_partial, float* mean, float* rstd, int NC, int T, int64_t HW, float eps, void* stream);
+int pg_instance_norm_finish(const float* stats_partial, float* mean, float* rstd, int NC, int T, int OH, int OW, float eps, void* stream);
 
 /* Demodulation coefficients of modulated_conv2d (networks.py:64-68):
  *   dcoefs[n,o] = rsqrt(sum_{i,k} (w[o,i,k] * scale * styles[n,i])^2 + 1e-8);  w is OIHW. */

@@ -937,18 +937,34 @@ PG_EXPORT int pg_instance_norm_stats(const float* x, float* mean, float* rstd, i
     return pg::launch_status();
 }
 
-// mean / rstd from the per-tile (sum, sum of squares) pairs the F(4x4) kernel's plain tail wrote (pg_conv2d_fusion::stats_partial): one wave per
-// (n, c) plane, float64 accumulation in tile order, then a fixed-shape wave reduction -- deterministic.
-__global__ __launch_bounds__(64) void instance_norm_finish_kernel(const float* __restrict__ part, float* __restrict__ mean, float* __restrict__ rstd, int T, double inv_hw, float eps) {
+// mean / rstd from the per-tile (sum, M2) pairs the F(4x4) kernel's plain tail wrote (pg_conv2d_fusion::stats_partial; M2 = squared deviations from the
+// tile's own mean): one wave per (n, c) plane, every lane merges its tiles in tile order with Chan's pairwise formula in float64, then a fixed-shape wave
+// reduction with the same merge -- deterministic, and as insensitive to |mean| >> std as the two-pass kernel above.  A tile's count follows from the geometry.
+__global__ __launch_bounds__(64) void instance_norm_finish_kernel(const float* __restrict__ part, float* __restrict__ mean, float* __restrict__ rstd, int T, int OH, int OW, float eps) {
     const float* pp = part + (int64_t)blockIdx.x * T * 2;
-    double s = 0.0, q = 0.0;
-    for (int t = threadIdx.x; t < T; t += 64) { s += (double)pp[2 * t]; q += (double)pp[2 * t + 1]; }
+    const int tiles_x = (OW + 63) / 64;
+    double n = 0.0, s = 0.0, q = 0.0;
+    auto merge = [](double& na, double& sa, double& qa, double nb, double sb, double qb) {
+        if (nb <= 0.0) return;
+        if (na <= 0.0) { na = nb; sa = sb; qa = qb; return; }
+        const double d = sb / nb - sa / na;
+        qa += qb + d * d * na * nb / (na + nb);
+        sa += sb; na += nb;
+    };
+    for (int t = threadIdx.x; t < T; t += 64) {
+        const int ty = t / tiles_x, tx = t - ty * tiles_x;
+        const int rows = OH - ty * 8 < 8 ? OH - ty * 8 : 8, cols = OW - tx * 64 < 64 ? OW - tx * 64 : 64;
+        merge(n, s, q, (double)rows * cols, (double)pp[2 * t], (double)pp[2 * t + 1]);
+    }
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) { s += __shfl_xor(s, m, 64); q += __shfl_xor(q, m, 64); }
+    for (int m = 32; m >= 1; m >>= 1) {
+        const double nb = __shfl_xor(n, m, 64), sb = __shfl_xor(s, m, 64), qb = __shfl_xor(q, m, 64);
+        // (both partners compute the same merged set: symmetric up to the order of the two operands, which the lane id fixes)
+        if (threadIdx.x & m) { double na = nb, sa = sb, qa = qb; merge(na, sa, qa, n, s, q); n = na; s = sa; q = qa; }
+        else merge(n, s, q, nb, sb, qb);
+    }
     if (threadIdx.x == 0) {
-        const double mu = s * inv_hw;
-        double var = q * inv_hw - mu * mu;
-        if (var < 0.0) var = 0.0;
+        const double mu = n > 0.0 ? s / n : 0.0, var = n > 0.0 ? q / n : 0.0;
         mean[blockIdx.x] = (float)mu;
         rstd[blockIdx.x] = (float)(1.0 / sqrt(var + (double)eps));
     }
@@ -959,9 +975,9 @@ PG_EXPORT int pg_conv2d_winograd4_stats_tiles(int OH, int OW) {
     return ((OH + 7) / 8) * ((OW + 63) / 64);
 }
 
-PG_EXPORT int pg_instance_norm_finish(const float* stats_partial, float* mean, float* rstd, int NC, int T, int64_t HW, float eps, void* stream) {
-    if (!stats_partial || !mean || !rstd || NC <= 0 || T <= 0 || HW <= 0) return PG_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(instance_norm_finish_kernel, dim3((unsigned)NC), dim3(64), 0, (hipStream_t)stream, stats_partial, mean, rstd, T, 1.0 / (double)HW, eps);
+PG_EXPORT int pg_instance_norm_finish(const float* stats_partial, float* mean, float* rstd, int NC, int T, int OH, int OW, float eps, void* stream) {
+    if (!stats_partial || !mean || !rstd || NC <= 0 || T <= 0 || OH <= 0 || OW <= 0 || T != pg_conv2d_winograd4_stats_tiles(OH, OW)) return PG_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(instance_norm_finish_kernel, dim3((unsigned)NC), dim3(64), 0, (hipStream_t)stream, stats_partial, mean, rstd, T, OH, OW, eps);
     return pg::launch_status();
 }
 

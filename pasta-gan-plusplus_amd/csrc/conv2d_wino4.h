@@ -532,7 +532,7 @@ __global__ __launch_bounds__(768, 3) void conv2d_wino4(ConvParams p) {
             g.nzb = ((unsigned)g.oyb * (unsigned)OWv + (unsigned)oxb) * 4u;
             return g;
         };
-        // Output statistics (pg_conv2d_fusion::stats_partial; plain tail only): sum and sum of squares of this tile's in-image outputs per cout
+        // Output statistics (pg_conv2d_fusion::stats_partial; plain tail only): sum and M2 (squared deviations from the tile's own mean) of this tile's in-image outputs per cout
         float* stats_p = TAIL == W4_TAIL_STATS ? qa.f.stats_partial : nullptr;                                             // (wave-uniform)
         const int stats_T = qa.tilesX * qa.tilesY, stats_t = (e_oy0 >> 3) * qa.tilesX + (e_ox0 >> 6);
         const bool op_is_noise = !spade && !res_n && nz_n;
@@ -629,19 +629,37 @@ __global__ __launch_bounds__(768, 3) void conv2d_wino4(ConvParams p) {
                     for (int r = 0; r < 4; r++) store4(g.ob + (unsigned)r * rstride_b, v[r], g.cok && g.oyb + r < OHv);
                     if (TAIL == W4_TAIL_STATS && stats_p) {
                         // this thread's 16 outputs of (cout, tile), then the 32 tiles of the workgroup tile (the 32 lanes of a wave half share the cout)
-                        float s1 = 0.f, s2 = 0.f;
+                        // (sum, M2 = sum of squared deviations from the set's own mean) pairs, merged pairwise with Chan's formula: E[x^2] - E[x]^2 on float32
+                        // sums of raw squares (round 4) loses the variance of a plane whose |mean| >> std; the separate statistics pass is
+                        // shifted-data too.  The count of a set follows from the geometry (whole 4-wide segments, rows inside the image).
+                        float cnt = 0.f, s1 = 0.f;
+                        bool okr[4];
 #pragma unroll
                         for (int r = 0; r < 4; r++) {
-                            const bool ok = seg_rows_full || (g.cok && g.oyb + r < OHv);
+                            okr[r] = seg_rows_full || (g.cok && g.oyb + r < OHv);
+                            cnt += okr[r] ? 4.f : 0.f;
 #pragma unroll
-                            for (int e = 0; e < 4; e++) { const float w = ok ? v[r][e] : 0.f; s1 += w; s2 = fmaf(w, w, s2); }
+                            for (int e = 0; e < 4; e++) s1 += okr[r] ? v[r][e] : 0.f;
                         }
+                        const float mt = cnt > 0.f ? s1 / cnt : 0.f;
+                        float m2 = 0.f;
 #pragma unroll
-                        for (int m = 1; m < 32; m <<= 1) { s1 += __shfl_xor(s1, m, 64); s2 += __shfl_xor(s2, m, 64); }
+                        for (int r = 0; r < 4; r++)
+#pragma unroll
+                            for (int e = 0; e < 4; e++) { const float d = okr[r] ? v[r][e] - mt : 0.f; m2 = fmaf(d, d, m2); }
+#pragma unroll
+                        for (int m = 1; m < 32; m <<= 1) {
+                            const float cb = __shfl_xor(cnt, m, 64), sb = __shfl_xor(s1, m, 64), qb = __shfl_xor(m2, m, 64);
+                            const float ct = cnt + cb;
+                            // delta = mean_b - mean_a, as (sb * cnt - s1 * cb) / (cnt * cb); M2 += delta^2 * cnt * cb / ct  (both sets non-empty)
+                            const float num = sb * cnt - s1 * cb;
+                            const float add = (cnt > 0.f && cb > 0.f) ? num * num / (cnt * cb * ct) : 0.f;
+                            m2 = m2 + qb + add; s1 += sb; cnt = ct;
+                        }
                         const int co = e_m0 + g.col;
                         if (g.fn == 0 && co < Coutv) {
                             float* dst = stats_p + (((int64_t)e_n * Coutv + co) * stats_T + stats_t) * 2;
-                            dst[0] = s1; dst[1] = s2;
+                            dst[0] = s1; dst[1] = m2;
                         }
                     }
                 } else {

@@ -147,18 +147,58 @@ def plugin_path(module_name):
     return os.path.join(DEV_DIR, module_name + '.so')
 
 
+def _pid_alive(pid):
+    try:
+        os.kill(pid, 0)
+    except ProcessLookupError:
+        return False
+    except OSError:
+        return True             # exists, not ours
+    return True
+
+
+def _temporaries_of(name):
+    """Compiler / link temporaries of exactly the plugin `name` in csrc/ and csrc/dev/: hipcc's `<name>.so.tmp<pid>.N.host-*` and `<name>.so.N*` files
+    and the `<name>.so.tmp<pid>` a link writes before its os.replace.  Exact names, no prefix glob (`wino4b_exp1` must not match `wino4b_exp10`)."""
+    out = []
+    for d in (CSRC_DIR, DEV_DIR):
+        for pat in (name + '.so.tmp*', name + '.so.[0-9]*', name + '.so.*.host-*', name + '.so-*host-*'):
+            out += glob.glob(os.path.join(d, pat))
+    return sorted(set(out))
+
+
 def clean(dev=False, only=''):
-    """Delete compiler temporaries an interrupted / parallel hipcc left in csrc/ (`<name>.so.N.host-*`, `*.tmp<pid>`) and,
-    with dev=True, the development builds of csrc/dev/.  `only` restricts the sweep to one plugin's files (a build cleans up
-    after itself without touching a concurrent build of another plugin).  Returns the removed paths."""
+    """Delete compiler temporaries an interrupted hipcc left behind and, with dev=True, the development builds of csrc/dev/.  `only` = one plugin's files
+    (a build cleans up after itself, inside that plugin's build lock).  Without `only`, every known plugin -- and every library found in csrc/ or
+    csrc/dev/ -- is swept one by one while holding ITS build lock (a plugin being linked by another process right now is skipped after its lock wait), and a
+    `<so>.tmp<pid>` whose pid is alive is never touched (a global sweep used to delete the half-written link output of a concurrent build).
+    Returns the removed paths."""
     gone = []
-    for pat in (only + '*.host-*', only + '*.so.tmp*', only + '*.so.[0-9]*'):
-        for path in glob.glob(os.path.join(CSRC_DIR, pat)) + glob.glob(os.path.join(DEV_DIR, pat)):
+
+    def sweep(name):
+        for path in _temporaries_of(name):
+            m = re.search(r'\.so\.tmp(\d+)', os.path.basename(path))
+            if m and int(m.group(1)) != os.getpid() and _pid_alive(int(m.group(1))):
+                continue
             try:
                 os.remove(path)
                 gone.append(path)
             except OSError:
                 pass
+    if only:
+        sweep(only)             # (called from _build, under get_plugin's lock on this plugin)
+    else:
+        names = set(PLUGIN_SOURCES)
+        for d in (CSRC_DIR, DEV_DIR):
+            names |= {os.path.basename(f).split('.so')[0] for f in glob.glob(os.path.join(d, '*.so*'))}
+        os.makedirs(os.path.join(CSRC_DIR, 'build'), exist_ok=True)
+        for name in sorted(names):
+            with open(os.path.join(CSRC_DIR, 'build', name + '.lock'), 'w') as lock:
+                fcntl.flock(lock, fcntl.LOCK_EX)
+                try:
+                    sweep(name)
+                finally:
+                    fcntl.flock(lock, fcntl.LOCK_UN)
     if dev and os.path.isdir(DEV_DIR):
         gone += glob.glob(os.path.join(DEV_DIR, '*'))
         shutil.rmtree(DEV_DIR, ignore_errors=True)

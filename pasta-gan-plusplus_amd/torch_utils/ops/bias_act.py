@@ -237,6 +237,9 @@ class _BiasActGrad(torch.autograd.Function):
             db = channel_sum(dx.detach(), dim) if with_db else None
         ctx.save_for_backward(dy if spec.has_2nd_grad else None, x, b, y)
         ctx.cfg = (dim, act, alpha, gain, clamp)
+        #  no zero-filled gradient for an output nobody consumed: with the default materialisation every R1 double backward handed `backward`
+        # a zero d_db and paid a full-size `d_dx + d_db.reshape(...)` pass per layer for it
+        ctx.set_materialize_grads(False)
         return (dx, db) if with_db else dx
 
     @staticmethod
@@ -244,6 +247,8 @@ class _BiasActGrad(torch.autograd.Function):
         dim, act, alpha, gain, clamp = ctx.cfg
         spec = activation_funcs[act]
         dy, x, b, y = ctx.saved_tensors
+        if d_dx is None and d_db is None:
+            return (None,) * 10
         if d_db is not None:                                 # db = sum(dx): its gradient is spread back over dx
             ref = y if y is not None else x if x is not None else d_dx
             shape = [1] * ref.ndim

@@ -100,7 +100,7 @@ def _init(plugin_name='conv2d_plugin'):
         lib.pg_conv2d_winograd4_stats_tiles.restype = i
         lib.pg_conv2d_winograd4_stats_tiles.argtypes = [i, i]
         lib.pg_instance_norm_finish.restype = i
-        lib.pg_instance_norm_finish.argtypes = [vp, vp, vp, i, i, i64, f, vp]
+        lib.pg_instance_norm_finish.argtypes = [vp, vp, vp, i, i, i, i, f, vp]
         lib.pg_conv2d_winograd4b_pack_weight.restype = i
         lib.pg_conv2d_winograd4b_pack_weight.argtypes = [vp, vp, i, i, f, i, i, vp]
         lib.pg_conv2d_winograd4b_forward.restype = i
@@ -346,7 +346,7 @@ def conv2d_forward(x, packed, cout, kh, kw, stride=1, pad=(0, 0), out_hw=None, y
         mean = torch.empty([n * cout], dtype=torch.float32, device=x.device)
         rstd = torch.empty_like(mean)
         with torch.cuda.device(x.device):
-            st = lib.pg_instance_norm_finish(nat.ptr(stats_part), nat.ptr(mean), nat.ptr(rstd), n * cout, stats_T, int(oh) * int(ow), float(stats_eps), nat.stream_of(x))
+            st = lib.pg_instance_norm_finish(nat.ptr(stats_part), nat.ptr(mean), nat.ptr(rstd), n * cout, stats_T, int(oh), int(ow), float(stats_eps), nat.stream_of(x))
         nat.check(st, 'pg_instance_norm_finish')
         return y, (mean, rstd)
     return y

@@ -81,6 +81,10 @@ def spawn_ranks(argv, nprocs, timeout=None, poll=0.05):
                 break
             time.sleep(poll)
     finally:
+        # a second signal (drivers send TERM twice, or TERM then INT) must not abort the clean-up below and leave ranks alive in their own sessions,
+        # holding GPUs: the handled signals are ignored until every rank has been killed and reaped
+        for sig in previous:
+            signal.signal(sig, signal.SIG_IGN)
         for p in procs:                                       # only the exact process groups started above
             if p.poll() is None:
                 try:

@@ -879,7 +879,10 @@ class _SpadeCombine(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, gamma_beta, eps):
-        x, gb = x.contiguous(), gamma_beta.contiguous()
+        # (inputs are contiguous: `spade_combine` below makes them so OUTSIDE the Function -- a copy made in here, where grad mode is off, would be
+        # detached from the graph, and the create_graph branch of backward would differentiate tensors that do not require grad: ADVICE r4)
+        assert x.is_contiguous() and gamma_beta.is_contiguous()
+        gb = gamma_beta
         mean, rstd = conv2d_mfma.instance_norm_stats(x, eps=eps)
         ctx.save_for_backward(x, gb, mean, rstd)
         ctx.eps = eps
@@ -896,6 +899,11 @@ class _SpadeCombine(torch.autograd.Function):
             return gx, ggb, None
         dx, dgb = conv2d_mfma.spade_train_backward(dy, x, mean, rstd, gb, need_dx=ctx.needs_input_grad[0], need_dgb=ctx.needs_input_grad[1])
         return dx, dgb, None
+
+
+def spade_combine(x, gamma_beta, eps):
+    """`_SpadeCombine` on contiguous inputs (made contiguous here, inside the graph)."""
+    return _SpadeCombine.apply(x.contiguous(), gamma_beta.contiguous(), eps)
 
 
 class Spade_Norm_Block(nn.Module):
@@ -941,7 +949,7 @@ class Spade_Norm_Block(nn.Module):
             actv = self.conv_mlp(denorm_feats, no_act=True, post_act='relu')
             w = torch.cat([g.weight * g.weight_gain, b.weight * b.weight_gain], dim=0)
             gb = conv2d_resample.conv2d_resample(x=actv, w=w, f=g.resample_filter, padding=g.padding, flip_weight=True)
-            return _SpadeCombine.apply(x, gb, self.param_free_norm.eps)
+            return spade_combine(x, gb, self.param_free_norm.eps)
         normalized = self.param_free_norm(x)
         actv = self.conv_mlp_act(self.conv_mlp(denorm_feats, no_act=True))
         gamma = self.conv_gamma(actv, no_act=True)
@@ -1028,17 +1036,18 @@ class SynthesisLayer(nn.Module):
         return bias_act.bias_act(x, self.bias.to(x.dtype), act=self.activation, gain=act_gain, clamp=act_clamp)
 
 
-_1331_cache = {}
 
 
 def _is_1331(f):
-    """True for the FIR taps setup_filter([1, 3, 3, 1]) produces (2-D, normalised): decided once per filter tensor, on the host."""
-    key = (f.data_ptr(), f._version, tuple(f.shape))
-    if key not in _1331_cache:
+    """True for the FIR taps setup_filter([1, 3, 3, 1]) produces (2-D, normalised): decided once per filter tensor, on the host.  The verdict is kept ON the
+    tensor object with the version it was taken at (an (address, version, shape) key could outlive the tensor and answer for another one)."""
+    hit = getattr(f, '_pg_is_1331', None)
+    if hit is None or hit[0] != f._version:
         ref = torch.tensor([1.0, 3.0, 3.0, 1.0])
         ref = torch.outer(ref, ref) / 64.0
-        _1331_cache[key] = bool(f.ndim == 2 and tuple(f.shape) == (4, 4) and torch.equal(f.detach().float().cpu(), ref))
-    return _1331_cache[key]
+        hit = (f._version, bool(f.ndim == 2 and tuple(f.shape) == (4, 4) and torch.equal(f.detach().float().cpu(), ref)))
+        f._pg_is_1331 = hit
+    return hit[1]
 
 
 class _ToRGBBase(nn.Module):

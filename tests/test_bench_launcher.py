@@ -5,6 +5,8 @@ n_gpus = N.  Runs on CPU: `--mode selftest` is the same protocol over gloo with 
 import json
 import os
 import subprocess
+
+import pytest
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -60,12 +62,16 @@ def test_launcher_parent_does_not_import_torch_and_propagates_failure(tmp_path):
     assert subprocess.run([sys.executable, '-c', code, 'fail'], env=_clean_env(), timeout=60).returncode == 7
 
 
-def test_sigterm_to_the_launcher_takes_the_ranks_down(tmp_path):
-    # the ranks run in sessions of their own -- a launcher that dies of SIGTERM without cleaning up would leave them holding the GPUs
+@pytest.mark.parametrize('signals', ['TERM', 'TERM,TERM,INT'], ids=['one', 'three'])
+def test_sigterm_to_the_launcher_takes_the_ranks_down(tmp_path, signals):
+    # the ranks run in sessions of their own -- a launcher that dies of SIGTERM without cleaning up would leave them holding the GPUs.
+    # a SECOND signal arriving while the launcher is already killing / reaping its ranks must not abort that clean-up -- the ranks here ignore
+    # SIGTERM for a moment, so the launcher is still inside its clean-up when signals two and three land
     import signal
     import time
     probe = tmp_path / 'sleeper.py'
-    probe.write_text('import os, sys, time\nopen(sys.argv[1] + os.environ["RANK"], "w").write(str(os.getpid()))\ntime.sleep(120)\n')
+    probe.write_text('import os, signal, sys, time\nsignal.signal(signal.SIGTERM, lambda *a: (time.sleep(1.0), sys.exit(0)))\n'
+                     'open(sys.argv[1] + os.environ["RANK"], "w").write(str(os.getpid()))\ntime.sleep(120)\n')
     code = ('import sys; sys.path.insert(0, %r); from training import launch; sys.exit(launch.spawn_ranks([%r, %r], 2))'
             % (os.path.join(ROOT, 'pasta-gan-plusplus_amd'), str(probe), str(tmp_path / 'pid')))
     parent = subprocess.Popen([sys.executable, '-c', code], env=_clean_env())
@@ -74,7 +80,11 @@ def test_sigterm_to_the_launcher_takes_the_ranks_down(tmp_path):
         while time.monotonic() < deadline and not all((tmp_path / f'pid{r}').exists() and (tmp_path / f'pid{r}').read_text() for r in (0, 1)):
             time.sleep(0.05)
         pids = [int((tmp_path / f'pid{r}').read_text()) for r in (0, 1)]
-        parent.send_signal(signal.SIGTERM)
+        for i, name in enumerate(signals.split(',')):
+            if i:
+                time.sleep(0.2)
+            if parent.poll() is None:
+                parent.send_signal(getattr(signal, 'SIG' + name))
         assert parent.wait(timeout=30) == 128 + signal.SIGTERM
         deadline = time.monotonic() + 10
         def alive(pid):

@@ -578,7 +578,7 @@ def test_conv2d_winograd4_tails_vs_oracle(tail, form):
 @pytest.mark.parametrize('n,cin,cout,h,w', [(2, 64, 128, 24, 72), (1, 64, 64, 64, 64), (3, 32, 70, 13, 136), (8, 128, 128, 256, 256)])
 def test_conv2d_winograd4_output_statistics(n, cin, cout, h, w):
     """pg_conv2d_fusion::stats_partial (round 4): the instance-norm statistics of a convolution's output gathered in the F(4x4) kernel's plain tail
-    (sum / sum of squares per workgroup tile and cout, reduced in float64 in tile order) against (a) float64 torch statistics of the SAME output
+    (sum / M2 per workgroup tile and cout, merged pairwise -- Chan -- in float64 in tile order) against (a) float64 torch statistics of the SAME output
     tensor and (b) the separate one-pass kernel (pg_instance_norm_stats) -- full, ragged (H % 8, W % 64, Cout % 64 != 0) and full-size shapes;
     the output itself must be bit-identical to the launch without statistics; launches other than the plain F(4x4) tail decline the request."""
     from torch_utils.ops import conv2d_mfma
@@ -601,6 +601,13 @@ def test_conv2d_winograd4_output_statistics(n, cin, cout, h, w):
     close(rstd, r2, 2e-5, 0)
     again = conv2d_mfma.conv2d_forward(x, pk, cout, 3, 3, pad=(1, 1), winograd=2, bias=b, stats_eps=1e-5)[1]
     assert torch.equal(again[0], mean) and torch.equal(again[1], rstd)                       # deterministic: fixed reduction order, no atomics
+    # |mean| >> std: a per-channel offset of ~50 on outputs of std ~0.6.  Sums of raw squares lose the variance there (relative error
+    # ~1e-7 * mean^2 / var ~ 1e-3); the (sum, M2) pairs merged with Chan's formula stay at the two-pass kernel's accuracy
+    b50 = (50.0 + torch.randn([cout], generator=gen)).to(DEV)
+    y5, (mean5, rstd5) = conv2d_mfma.conv2d_forward(x, pk, cout, 3, 3, pad=(1, 1), winograd=2, bias=b50, stats_eps=1e-5)
+    y5d = y5.double()
+    close(mean5, y5d.mean([2, 3]).reshape(-1), 2e-6, 0)
+    close(rstd5, (y5d.var([2, 3], unbiased=False) + 1e-5).rsqrt().reshape(-1), 2e-5, 0)
     for kw in (dict(residual=torch.zeros_like(y)), dict(in_scale=torch.ones([n, cin], device=DEV))):
         with pytest.raises(NativeNotCovered):
             conv2d_mfma.conv2d_forward(x, pk, cout, 3, 3, pad=(1, 1), winograd=2, stats_eps=1e-5, **kw)
@@ -1110,16 +1117,39 @@ def test_config4_discriminators_at_real_shape_vs_oracle(phase):
         stubs.zero_grads(nets)
         stubs.set_phase_trainable(nets, phase)
         loss.accumulate_gradients(phase=phase, gain=1, **stubs.batch(n, device, res=res))
+        full.append({f'{mn}.{pn}': (None if p_.grad is None else p_.grad.detach().cpu().clone()) for mn, m in nets.items() for pn, p_ in m.named_parameters()})
         return stubs.grad_signature(nets)
 
+    full = []
     torch.set_num_threads(min(16, len(__import__('os').sched_getaffinity(0))))
     got, want = run(DEV, PN.Discriminator), run('cpu', NR.Discriminator)
     assert got.keys() == want.keys()
+    ew, ew_name, ew_n = _elementwise_gradient_mismatch(full[0], full[1])
+    print(f'config 4 {phase} at 512^2, N=4: element-wise gradient mismatch over {ew_n} tensors, worst {ew:.2e} of the tensor maximum ({ew_name})')
+    assert ew <= 3e-3 and ew_n >= 4, (ew, ew_name, ew_n)
     worst = max((abs(got[k] - want[k]) / (abs(want[k]) + 1e-12), k) for k in want if want[k] > 0)
     print(f'config 4 {phase} at 512^2, N=4: {sum(1 for v in want.values() if v > 0)} parameters with gradients, worst signature mismatch {worst[0]:.2e} ({worst[1]})')
     for k in want:
         assert abs(got[k] - want[k]) <= 3e-3 * abs(want[k]) + 1e-6, (k, got[k], want[k])
     assert sum(1 for k, v in got.items() if v > 0 and k.startswith('D.' if phase == 'Dboth' else 'G_')) >= 4
+
+
+def _elementwise_gradient_mismatch(got, want, skip=('noise_strength',)):
+    """Element-wise comparison of two {name: gradient tensor or None} dicts (a per-parameter sum|grad| cannot see a transposed, permuted or
+    sign-flipped gradient inside a tensor): for every tensor with more than one element, max|got - want| / max|want|.  Returns (worst ratio, its name, n compared)."""
+    worst, n = (0.0, ''), 0
+    for k, w in want.items():
+        if w is None or w.numel() <= 1 or any(k.endswith(sfx) for sfx in skip):
+            continue
+        g = got[k]
+        assert g is not None and g.shape == w.shape, k
+        scale = float(w.abs().max())
+        if scale == 0.0:
+            assert float(g.abs().max()) == 0.0, k
+            continue
+        n += 1
+        worst = max(worst, (float((g.double() - w.double()).abs().max()) / scale, k))
+    return worst[0], worst[1], n
 
 
 def test_config4_generator_gradients_full_width_vs_oracle():
@@ -1141,17 +1171,46 @@ def test_config4_generator_gradients_full_width_vs_oracle():
     args = lambda f: (f(inp['ws']), f(inp['pose_feat']), {k: f(v) for k, v in inp['cat_feat'].items()}, f(inp['denorm_upper_input']),
                       f(inp['denorm_lower_input']), f(inp['denorm_upper_mask']), f(inp['denorm_lower_mask']), f(inp['gt_parsing']))
 
-    def signature(model, f):
+    full = {}
+
+    def signature(model, f, tag):
         for p_ in model.parameters():
             p_.grad = None
         out = model(*args(f), noise_mode='const')
         sum((o * f(r)).sum() for o, r in zip(out, proj)).backward()
+        full[tag] = {n_: (None if p_.grad is None else p_.grad.detach().cpu().clone()) for n_, p_ in model.named_parameters()}
         return {n_: (None if p_.grad is None else float(p_.grad.double().abs().sum())) for n_, p_ in model.named_parameters()}
 
     torch.set_num_threads(min(16, len(__import__('os').sched_getaffinity(0))))
-    got = signature(net, lambda t: t.to(DEV))
-    want = signature(ref_net, lambda t: t)
+    got = signature(net, lambda t: t.to(DEV), 'got')
+    want = signature(ref_net, lambda t: t, 'want')
     assert got.keys() == want.keys()
+    # ELEMENT-WISE (round 5): every weight / bias gradient tensor of the network -- the F(4x4)-dgrad 3x3 layers of every resolution, the up = 2 layers,
+    # the ToRGB heads, the SPADE gamma / beta convolutions, the affine layers.  Measured first against the float32 oracle: 153 of 155 tensors within
+    # 2e-3 of their largest element, the worst (spade_b256_2.conv0.weight) at 1.5e-2 -- a weight gradient there is a sum over 65 536 pixels of terms that
+    # cancel to ~1/250 of their absolute sum, so the float32 ORACLE is no better.  The referee is therefore the same oracle network in FLOAT64: every tensor of
+    # the GPU route must be within 2e-3 of its largest element, or as close to the float64 gradient as the float32 oracle itself is (x3).  A transposed,
+    # permuted or sign-flipped tensor misses by ~1.
+    ew32, ew32_name, ew_n = _elementwise_gradient_mismatch(full['got'], full['want'])
+    ref64 = ref_net.double()
+    f64 = lambda t: t.double() if t.is_floating_point() else t
+    signature(ref64, f64, 'want64')
+    ref_net.float()
+    worst_gpu, worst_cpu, bad = (0.0, ''), (0.0, ''), []
+    for k, w64 in full['want64'].items():
+        if w64 is None or w64.numel() <= 1 or k.endswith('noise_strength'):
+            continue
+        scale = float(w64.abs().max())
+        if scale == 0.0:
+            continue
+        e_gpu = float((full['got'][k].double() - w64).abs().max()) / scale
+        e_cpu = float((full['want'][k].double() - w64).abs().max()) / scale
+        worst_gpu, worst_cpu = max(worst_gpu, (e_gpu, k)), max(worst_cpu, (e_cpu, k))
+        if e_gpu > max(2e-3, 3.0 * e_cpu):
+            bad.append((k, e_gpu, e_cpu))
+    print(f'config 4 generator training route, element-wise over {ew_n} gradient tensors (of the tensor maximum): GPU vs float32 oracle worst {ew32:.2e} ({ew32_name}); '
+          f'against the float64 oracle: GPU worst {worst_gpu[0]:.2e} ({worst_gpu[1]}), float32 oracle worst {worst_cpu[0]:.2e} ({worst_cpu[1]})')
+    assert not bad and ew_n > 100, bad[:6]
     numel = {n_: p_.numel() for n_, p_ in ref_net.named_parameters()}
     worst, n_grad, bad = (0.0, ''), 0, []
     for k in want:
@@ -1256,13 +1315,15 @@ def test_full_width_training_iteration_smoke(d_fp16_res):
     assert step.batch_idx == 1
 
 
-def test_config4_whole_iteration_batch4_vs_oracle():
+@pytest.mark.parametrize('d_fp16_res', [0, 3], ids=['d_fp32', 'd_fp16_top3'])
+def test_config4_whole_iteration_batch4_vs_oracle(d_fp16_res):
     """BASELINE config 4's per-rank share as ONE piece: the full-width generator and both discriminators at 512^2,
     per-rank batch 4 (train.py:174), all eight phases of one `TrainingStep.run` on the GPU (training_loop_fullbody.py:468-481, 604-639) --
     and the per-parameter gradient signatures of its `Gmain` and `Dmain` phases, taken when the phase's gradients are final and before its
     optimizer steps, against the CPU oracle networks run through the same loss FROM THE WEIGHTS THE PRODUCT HAD AT THE START OF THAT PHASE
     (Dmain follows Gmain's Adam step: the oracle is handed the stepped generator, so that each comparison isolates one phase's forward +
-    backward).  fp32 discriminators on both sides (the fp16 discriminator blocks have their own oracle test with a 16-bit bar);
+    backward).  Two settings: fp32 discriminators on both sides, and -- round 5, the BENCHED setting -- both discriminators fp16 at their three top resolutions
+    (train.py:196) at a 16-bit bar; besides the signatures every gradient TENSOR of the phase's network is compared element-wise (max|diff| of its largest element);
     noise_strength = 0 (the training route draws fresh noise per call, which two devices cannot share); no style mixing.  Bar: per-parameter
     sum|grad| within 3e-3 (the bar of the per-network tests this one joins); single-element parameters only in sign and magnitude."""
     import os
@@ -1274,7 +1335,7 @@ def test_config4_whole_iteration_batch4_vs_oracle():
     n = 4
     g_kw = dict(z_dim=0, c_dim=512, w_dim=512, img_resolution=512, img_channels=3, mapping_kwargs=dict(num_layers=1),
                 synthesis_kwargs=dict(channel_base=32768, channel_max=512, conv_clamp=256))
-    d_kw = lambda ch: dict(c_dim=512, img_resolution=512, img_channels=ch, channel_base=32768, channel_max=512, conv_clamp=256,
+    d_kw = lambda ch: dict(c_dim=512, img_resolution=512, img_channels=ch, channel_base=32768, channel_max=512, conv_clamp=256, num_fp16_res=d_fp16_res,
                            epilogue_kwargs=dict(mbstd_group_size=4))
     ref = dict(G=fill_module_(NR.GeneratorFull_v20(**g_kw), 'c4w.G.', noise_strength=0.0).train(),
                D=fill_module_(NR.Discriminator(**d_kw(6)), 'c4w.D.').train(), D_parsing=fill_module_(NR.Discriminator(**d_kw(10)), 'c4w.DP.').train())
@@ -1298,8 +1359,14 @@ def test_config4_whole_iteration_batch4_vs_oracle():
     # noise_strength to +-4e-4 and the generator draws its noise afresh on each side (GPU generator here, CPU generator in the oracle): with nothing but the
     # torch seed changed the Dmain signatures move by up to 2.3e-3 (tools/probes/dmain_noise_sensitivity.py, three seeds), so that phase gets 3e-3 on top of it.
     bar = dict(Gmain=3e-3, Dmain=6e-3)
+    ew_bar = dict(Gmain=3e-3, Dmain=8e-3)      # element-wise: of the tensor's largest element
+    if d_fp16_res:
+        # the benched setting (train.py:196: the three top resolutions of both discriminators in fp16): the discriminator's own gradients and its input
+        # gradient into the generator carry 16-bit rounding (2^-11 per layer, ~20 layers) on both sides, in different summation orders
+        bar = dict(Gmain=2e-2, Dmain=2e-2)
+        ew_bar = dict(Gmain=4e-2, Dmain=4e-2)
     torch.manual_seed(1234)          # the draws must not depend on which tests ran before this one
-    start, got, order = {}, {}, []
+    start, got, got_full, order = {}, {}, {}, []
 
     def observer(event, ph):
         order.append((event, ph.name))
@@ -1309,6 +1376,8 @@ def test_config4_whole_iteration_batch4_vs_oracle():
             start[ph.name] = {k: {a: b.detach().cpu().clone() for a, b in m.state_dict().items()} for k, m in net.items()}
         else:
             got[ph.name] = sig_of(net)
+            own = 'G' if ph.name.startswith('G') else 'D'
+            got_full[ph.name] = {f'{own}.{pn}': (None if p_.grad is None else p_.grad.detach().cpu().clone()) for pn, p_ in net[own].named_parameters()}
 
     step = TrainingStep(parts(net['G']), net['D'], net['D_parsing'], mk_loss(net, DEV), batch_size=n)
     step.observer = observer
@@ -1357,10 +1426,15 @@ def test_config4_whole_iteration_batch4_vs_oracle():
             worst = max(worst, (abs(g - w) / (abs(w) + 1e-12), key))
             if abs(g - w) > bar[phase] * abs(w) + 1e-6:
                 bad.append((key, g, w))
-        report.append(f'{phase}: {n_grad} parameters with gradients, worst signature mismatch {worst[0]:.2e} ({worst[1]}), oracle {time.perf_counter() - t0:.0f} s')
+        own = owner[:-1]
+        want_full = {f'{own}.{pn}': (None if (p_.grad is None or float(p_.grad.abs().max()) == 0.0) else p_.grad.detach().clone()) for pn, p_ in ref[own].named_parameters()}
+        ew, ew_name, ew_n = _elementwise_gradient_mismatch(got_full[phase], want_full)
+        report.append(f'{phase}: {n_grad} parameters with gradients, worst signature mismatch {worst[0]:.2e} ({worst[1]}), element-wise over {ew_n} tensors worst '
+                      f'{ew:.2e} of the tensor maximum ({ew_name}), oracle {time.perf_counter() - t0:.0f} s')
         assert not bad, (phase, bad[:8])
+        assert ew <= ew_bar[phase], (phase, ew, ew_name)
         assert n_grad >= (150 if phase == 'Gmain' else 20), (phase, n_grad)
-    print(f'config 4 whole iteration at batch {n} (GPU {t_gpu:.2f} s incl. first-call work): ' + '; '.join(report))
+    print(f'config 4 whole iteration at batch {n}, discriminators fp16 at {d_fp16_res} resolutions (GPU {t_gpu:.2f} s incl. first-call work): ' + '; '.join(report))
 
 
 @pytest.mark.timeout(900)

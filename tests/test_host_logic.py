@@ -243,10 +243,46 @@ def test_modconv16_policy_is_pure_host_logic():
     from training import networks as PN
     from torch_utils.ops import upfirdn2d
     f = upfirdn2d.setup_filter([1, 3, 3, 1])
-    comp, merged, shared, tpad, fir_pad = PN._modconv16_policy((1024, 1024, 3, 3), (8, 8), 2, 1, f)
-    assert comp and not merged and shared and tuple(tpad) == (0, 0) and list(fir_pad) == [1, 1, 1, 1]
-    comp, merged, shared, tpad, fir_pad = PN._modconv16_policy((32, 64, 3, 3), (512, 512), 2, 1, f)
-    assert comp and not shared                                 # activations dominate: per-sample weights
-    comp, merged, shared, tpad, fir_pad = PN._modconv16_policy((512, 512, 3, 3), (64, 64), 1, 1, f)
-    assert not comp and not merged and shared == (512 * 9 > 2 * 64 * 64) and tpad is None
+    comp, merged, shared, tpad, fir_pad, fused_x = PN._modconv16_policy((1024, 1024, 3, 3), (8, 8), 2, 1, f)
+    assert comp and not merged and not fused_x and shared and tuple(tpad) == (0, 0) and list(fir_pad) == [1, 1, 1, 1]      # 8^2: below the fused-x form's smallest image
+    comp, merged, shared, tpad, fir_pad, fused_x = PN._modconv16_policy((32, 64, 3, 3), (512, 512), 2, 1, f)
+    assert fused_x and not comp and not shared                 # round 5: the y half of the FIR in the weights, the x half in the epilogue; activations dominate: per-sample weights
+    comp, merged, shared, tpad, fir_pad, fused_x = PN._modconv16_policy((512, 1024, 3, 3), (32, 32), 2, 1, f)
+    assert fused_x and shared == (512 * 24 > 2 * 32 * 32)      # 24 tap slots per weight (18 non-zero)
+    assert PN._modconv16_policy((32, 64, 3, 3), (512, 512), 2, 1, upfirdn2d.setup_filter([1, 3, 3, 1]) + torch.eye(4) * 0.01)[5] is False      # not separable: composite
+    comp, merged, shared, tpad, fir_pad, fused_x = PN._modconv16_policy((512, 512, 3, 3), (64, 64), 1, 1, f)
+    assert not comp and not merged and not fused_x and shared == (512 * 9 > 2 * 64 * 64) and tpad is None
+    fy, fx = PN._separable_taps(f)
+    assert torch.allclose(torch.outer(fy, fx), f) and PN._separable_taps(f) is PN._separable_taps(f)      # decided once per filter tensor
     assert PN._is_1331(f) and not PN._is_1331(upfirdn2d.setup_filter([1, 2, 1])) and not PN._is_1331(upfirdn2d.setup_filter([1, 3, 3, 1]) * 2)
+
+
+def test_custom_ops_clean_is_per_plugin_and_spares_live_links(tmp_path, monkeypatch):
+    """`clean()` sweeps compiler temporaries plugin by plugin under each plugin's build lock, matches exact plugin names (not a prefix glob) and never
+    deletes the `<so>.tmp<pid>` of a link that is still running."""
+    import subprocess
+    import sys
+    from torch_utils import custom_ops
+    csrc, dev = tmp_path / 'csrc', tmp_path / 'csrc' / 'dev'
+    dev.mkdir(parents=True)
+    monkeypatch.setattr(custom_ops, 'CSRC_DIR', str(csrc))
+    monkeypatch.setattr(custom_ops, 'DEV_DIR', str(dev))
+    sleeper = subprocess.Popen([sys.executable, '-c', 'import time; time.sleep(60)'])
+    try:
+        dead = subprocess.Popen([sys.executable, '-c', 'pass'])
+        dead.wait()
+        live_tmp = csrc / f'conv2d_plugin.so.tmp{sleeper.pid}'
+        dead_tmp = csrc / f'conv2d_plugin.so.tmp{dead.pid}'
+        host_tmp = csrc / 'conv2d_plugin.so.3.host-x86_64-unknown-linux-gnu.o'
+        other = dev / 'wino4b_exp10.so.tmp999999999'
+        keep = [csrc / 'conv2d_plugin.so', csrc / 'conv2d_plugin.so.digest', dev / 'wino4b_exp10.so']
+        for f in [live_tmp, dead_tmp, host_tmp, other] + keep:
+            f.write_bytes(b'x')
+        gone = custom_ops.clean(only='wino4b_exp1')                 # a sibling name: must not match wino4b_exp10's files
+        assert gone == [] and other.exists()
+        gone = custom_ops.clean()
+        assert live_tmp.exists() and not dead_tmp.exists() and not host_tmp.exists() and not other.exists()
+        assert all(f.exists() for f in keep) and len(gone) == 3
+    finally:
+        sleeper.kill()
+        sleeper.wait()

@@ -7,7 +7,7 @@
  *   upfirdn2d_plugin.so     pg_upfirdn2d, pg_upfirdn2d_bias_act
  *   conv2d_plugin.so        fp32: pg_conv2d_{packed_size,pack_weight,forward,splitk_plan,forward_splitk}, pg_conv2d_winograd_*,
  *                           pg_conv2d_up2_forward, pg_conv1x1_small, pg_conv3x3_cin1, pg_conv2d_wgrad{_plan,};
- *                           16-bit: pg_conv2d16_{packed_size,pack_weight,pack_weight_grouped,forward,splitk_plan,forward_splitk},
+ *                           16-bit: pg_conv2d16_{packed_size,pack_weight,pack_weight_grouped,forward,splitk_plan,forward_splitk,up2_fused}, pg_adam_flat_{chunk,step},
  *                           pg_conv1x1_small16;  glue: pg_modconv_{dcoefs,w2,prep}, pg_instance_norm_stats, pg_spade_*
  *   patch_routing_plugin.so pg_warp_perspective_u8, pg_patch_compose_u8
  * plus pg_<plugin>_abi_version() in each.  They are what the reference's L1
@@ -336,6 +336,10 @@ int pg_spade_feat_assemble(const float* feat_upper, const float* feat_lower, con
                            const float* sums_upper, const float* sums_lower, const float* counts_upper, const float* counts_lower,
                            float* out, int N, int C, int H, int W, void* stream);
 int pg_conv2d_abi_version(void);
+/* Multi-GPU training (round 5): keep `n` CUs free of this plugin's persistent grids (one workgroup per CU with most of its LDS: conv2d_wino4, conv2d_mfma16,
+ * conv2d_wgrad, ...) so that RCCL's channel workgroups -- the gradient all-reduce launched from autograd hooks on a side stream, training/ddp.py -- find a CU
+ * while the backward pass is still running.  0 = none.  Returns the CU count grids and split-K planners use from now on.  Process-wide, any device. */
+int pg_conv2d_reserve_cus(int n);
 
 /* Weight gradient of a float32 NCHW convolution (3x3 at stride 1 or 2, 1x1 at stride 1) -- what conv2d_gradfix.py:137-150 asks
  * aten::cudnn_convolution_backward_weight for:
@@ -456,6 +460,15 @@ int pg_conv2d16_forward(const void* x, const void* packed, void* y, int dtype, i
 int pg_conv2d16_up2_fused(const void* x, const void* packed, void* y, int dtype, int N, int Cin, int H, int W, int Cout,
                           int64_t w_sample_stride, const int64_t ystride[4], const float fir_x[4],
                           const pg_conv2d16_fusion* fusion, void* stream);
+
+/* Round 5 -- the optimizer side of a training phase in one launch (csrc/optim.hip): torch.nan_to_num(grad, nan, posinf, neginf) followed by torch.optim.Adam's
+ * step (training_loop_fullbody.py:632-639) over the phase's flat buffers.  p / g / m / v share one flat layout (every parameter starts on a 16-byte boundary);
+ * chunks[nchunks][4] = (element offset, length <= pg_adam_flat_chunk(), parameter index, 1 for the parameter's first chunk), one workgroup each.  A parameter
+ * with alive[i] <= 0 (no rank produced a gradient: `grad is None` in the reference) is left untouched and keeps its step count; steps_in / steps_out are the
+ * per-parameter step counts before / after (two buffers: the chunks of a parameter read the count while its first chunk writes it).  g is cleaned in place. */
+int pg_adam_flat_chunk(void);
+int pg_adam_flat_step(float* p, float* g, float* m, float* v, const int* chunks, int nchunks, const float* alive, const float* steps_in, float* steps_out,
+                      float lr, float beta1, float beta2, float eps, float nan_value, float posinf_value, float neginf_value, void* stream);
 
 /* Split-K form for launches with fewer output tiles than CUs: `ksplit` launches-worth of workgroups each reduce Cin/ksplit
  * channels into float32 [ksplit][N][OH][OW][Cout] `workspace`; one pass sums the slices in fixed order, applies the

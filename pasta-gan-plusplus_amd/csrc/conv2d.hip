@@ -556,6 +556,12 @@ inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 PG_EXPORT int pg_conv2d_abi_version(void) { return PG_ABI_VERSION; }
 
+// See include/pasta_gan_ops.h: CUs left to other work (RCCL's channels); returns the CU count the plugin's grids are sized for from now on.
+PG_EXPORT int pg_conv2d_reserve_cus(int n) {
+    pg::reserved_cus().store(n > 0 ? n : 0, std::memory_order_relaxed);
+    return pg::num_cu();
+}
+
 PG_EXPORT int64_t pg_conv2d_packed_size(int Cout, int Cin, int KH, int KW) {
     if (Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0) return 0;
     return (int64_t)round_up(Cin, 16) * KH * KW * round_up(Cout, 32);

@@ -33,6 +33,13 @@ inline int current_device() {
     int d = 0;
     return hipGetDevice(&d) == hipSuccess && d >= 0 && d < kMaxDevices ? d : 0;
 }
+// CUs a data-parallel training step keeps free of this library's persistent grids (round 5): the convolution / weight-gradient kernels are one workgroup
+// per CU with nearly all of its LDS, so RCCL's channel workgroups -- launched on a side stream while the backward pass runs (training/ddp.py) -- could only
+// start when a CU drained.  With a reservation every grid and planner of this plugin sizes itself for CUs - reserved (pg_conv2d_reserve_cus).
+inline std::atomic<int>& reserved_cus() {
+    static std::atomic<int> r{0};
+    return r;
+}
 inline int num_cu() {
     static std::atomic<int> cached[kMaxDevices];
     const int d = current_device();
@@ -41,7 +48,8 @@ inline int num_cu() {
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || v <= 0) v = 256;
         cached[d].store(v, std::memory_order_relaxed);
     }
-    return v;
+    const int r = reserved_cus().load(std::memory_order_relaxed);
+    return v - r >= 8 ? v - r : (v >= 8 ? 8 : v);
 }
 inline int max_stream_blocks() { return num_cu() * 8; }
 

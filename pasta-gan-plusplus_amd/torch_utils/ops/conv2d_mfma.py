@@ -45,6 +45,15 @@ _timeline = None
 _wgrad_timeline = None      # the same for the weight-gradient launches (bench.py --mode train): its own list, so a training run does not pay two events on each of its forward launches
 
 
+def reserve_cus(n):
+    """Keep `n` CUs free of the plugin's persistent grids (pg_conv2d_reserve_cus): room for RCCL's channel workgroups beside the backward pass.  Returns the CU
+    count the grids use from now on."""
+    lib = _init().lib
+    lib.pg_conv2d_reserve_cus.restype = ctypes.c_int
+    lib.pg_conv2d_reserve_cus.argtypes = [ctypes.c_int]
+    return int(lib.pg_conv2d_reserve_cus(int(n)))
+
+
 def start_timeline():
     global _timeline
     _timeline = []

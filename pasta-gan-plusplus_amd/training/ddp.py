@@ -49,7 +49,10 @@ class GradBucket:
             if acc >= target * (seg + 1) and seg < nseg - 1 and k < len(order) - 1:
                 members.append([])
                 seg += 1
-        self.total = total + len(self.params)
+        # every parameter starts on a 16-byte boundary of the flat bucket (the fused optimizer pass of training/flat_adam.py moves float4s; the padding is
+        # zeros and rides along in the all-reduce), and so does every segment
+        al = lambda v: (v + 3) // 4 * 4
+        self.total = sum(al(sum(al(self.params[i].numel()) for i in mem) + len(mem)) for mem in members)
         self.flat = torch.zeros([self.total], dtype=torch.float32, device=dev)
         self.views, self.offset = [None] * len(self.params), [0] * len(self.params)
         self.seg_range, self.flag_range, self.flag_slot = [], [], [0] * len(self.params)
@@ -60,11 +63,11 @@ class GradBucket:
                 n = self.params[i].numel()
                 self.views[i] = self.flat[off:off + n].view_as(self.params[i])
                 self.offset[i] = off
-                off += n
+                off += al(n)
             self.flag_range.append((off, off + len(mem)))
             for j, i in enumerate(mem):
                 self.flag_slot[i] = off + j
-            off += len(mem)
+            off = al(off + len(mem))
             self.seg_range.append((start, off))
         assert off == self.total
         self.members = members
@@ -74,7 +77,15 @@ class GradBucket:
         self._pending, self._launched, self._works = [], [], []
         self._active = False
         self._comm_stream = torch.cuda.Stream(device=dev) if dev.type == 'cuda' else None
+        if dev.type == 'cuda':
+            reserve_comm_cus(self.world)
         self.any_touched = False
+        # `device_flags` (set by training/flat_adam.py on the GPU): finish() leaves the per-parameter "some rank produced a gradient" flags in `alive`
+        # ON THE DEVICE for the fused optimizer pass to read -- no read-back, no host sync per phase (7 per iteration), and .grad stays a
+        # (zero) view for parameters nobody touched instead of becoming None: the optimizer pass skips them by the flag
+        self.device_flags = False
+        self.alive = torch.zeros([len(self.params)], dtype=torch.float32, device=dev)
+        self._flags_host = torch.zeros([len(self.params)], dtype=torch.float32).pin_memory() if dev.type == 'cuda' else None
         self.launch_log = []                                 # (segment, 'hook' | 'finish') in issue order, per phase: tests read it
         for i, p in enumerate(self.params):
             was = p.requires_grad                            # the step freezes every module between phases; hooks need a leaf that requires grad
@@ -155,9 +166,18 @@ class GradBucket:
             for work, seg in self._works:
                 work.wait()
                 seg.mul_(1.0 / self.world)
+            if self.device_flags:                            # the summed flags never leave the device; a phase that is empty on EVERY rank is declared
+                torch.index_select(self.flat, 0, self._slot_index, out=self.alive)      # statically (loss.phase_is_empty) and never gets here
+                self.any_touched = True
+                return True
             alive = self.flat[self._slot_index].cpu().tolist()
         else:
             alive = [1.0 if t else 0.0 for t in self._touched_host]
+            if self.device_flags:
+                self.any_touched = any(self._touched_host)
+                self._flags_host.copy_(torch.tensor(alive, dtype=torch.float32))
+                self.alive.copy_(self._flags_host, non_blocking=True)       # one small H2D copy, stream-ordered in front of the optimizer pass; no sync
+                return self.any_touched
         self.any_touched = any(a > 0 for a in alive)
         for p, a in zip(self.params, alive):
             if a == 0:
@@ -177,6 +197,24 @@ class GradBucket:
             p.grad = v
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
         self.flat.mul_(1.0 / self.world)
+
+
+_reserved = [None]
+
+
+def reserve_comm_cus(world):
+    """Give the exchange somewhere to run: this package's convolution / weight-gradient kernels are persistent, one workgroup per CU with
+    nearly all of its LDS, so the all-reduce launched from the hooks could only start when a CU drained -- "overlapped with the backward pass" was a hope.  With
+    more than one rank the plugin's grids leave PG_COMM_CUS CUs (default 8 of 256) free; PG_COMM_CUS set explicitly applies at any world size (to price it on
+    one GPU: bench.py --mode train).  Once per process."""
+    import os
+    env = os.environ.get('PG_COMM_CUS')
+    want = int(env) if env is not None else (8 if world > 1 else 0)
+    if _reserved[0] != want:
+        from torch_utils.ops import conv2d_mfma
+        conv2d_mfma.reserve_cus(want)
+        _reserved[0] = want
+    return want
 
 
 def broadcast_parameters(modules, src=0, group=None):

@@ -50,16 +50,28 @@ class TrainingStep:
         self._seen = set()               # phase indices that have run once eagerly (first-call work stays out of the graphs)
         adam_kw = dict(capturable=True) if self.graphs else {}
         self.phases = []
+        by_module = {}                   # module set -> (bucket, first FlatAdam): the reference lists D_parsing twice (:470-471) -- two optimizers over one module
+
+        def make_opt(params, bucket, lr_, betas_, first):
+            # GPU: nan_to_num + Adam as ONE launch over flat parameter / gradient / moment buffers, per-parameter "has a gradient" flags read on the device
+            # (training/flat_adam.py; PG_FLAT_ADAM=0 = torch.optim.Adam).  CPU tensors (the gloo tests): torch.optim.Adam.
+            if bucket.flat.is_cuda and os.environ.get('PG_FLAT_ADAM', '1') != '0':
+                from .flat_adam import FlatAdam
+                return FlatAdam(bucket, lr_, betas_, eps, share_params_with=first)
+            return torch.optim.Adam(params, lr=lr_, betas=betas_, eps=eps, **adam_kw)
         for name, modules, interval in (('G', list(G_parts.values()), G_reg_interval), ('D', [D], D_reg_interval),
                                         ('D_parsing', [D_parsing], D_reg_interval), ('D_parsing', [D_parsing], D_reg_interval)):
             params = [p for m in modules for p in m.parameters()]
-            bucket = ddp.GradBucket(params)
+            key = tuple(id(m) for m in modules)
+            flat = params[0].is_cuda and os.environ.get('PG_FLAT_ADAM', '1') != '0'
+            prev = by_module.get(key) if flat else None      # (flat route: the second optimizer of a module set shares its gradient bucket and flat parameter buffer)
+            bucket = prev[0] if prev is not None else ddp.GradBucket(params)
+            ratio = 1.0 if interval is None else interval / (interval + 1)
+            opt = make_opt(params, bucket, lr * ratio, tuple(b ** ratio for b in betas), prev[1] if prev is not None else None)
+            by_module.setdefault(key, (bucket, opt))
             if interval is None:
-                opt = torch.optim.Adam(params, lr=lr, betas=tuple(betas), eps=eps, **adam_kw)
                 self.phases.append(Phase(name + 'both', modules, opt, 1, bucket))
             else:
-                ratio = interval / (interval + 1)
-                opt = torch.optim.Adam(params, lr=lr * ratio, betas=tuple(b ** ratio for b in betas), eps=eps, **adam_kw)
                 self.phases.append(Phase(name + 'main', modules, opt, 1, bucket))
                 self.phases.append(Phase(name + 'reg', modules, opt, interval, bucket))
         self.cur_nimg = 0
@@ -85,7 +97,9 @@ class TrainingStep:
             m.requires_grad_(False)
         if not ph.bucket.finish():                           # nobody produced a gradient: nothing to exchange, nothing to step
             return
-        torch.nan_to_num(ph.bucket.flat, nan=0, posinf=1e5, neginf=-1e5, out=ph.bucket.flat)
+        fused = not isinstance(ph.opt, torch.optim.Optimizer)        # FlatAdam cleans the gradients in the pass that applies them
+        if not fused or self.observer is not None:
+            torch.nan_to_num(ph.bucket.flat, nan=0, posinf=1e5, neginf=-1e5, out=ph.bucket.flat)
         if self.observer is not None:
             self.observer('gradients', ph)                   # exchanged, cleaned gradients in place; the optimizer has not stepped yet
         ph.opt.step()

@@ -36,7 +36,7 @@ def main(rnd, commit=None):
                  f'bench.py --conv-breakdown under the same command: conv launches of one step grouped by geometry / algorithm / shape')
 
     # HBM traffic of the dominant kernel, FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of wide coalesced reads)
-    for tag, kernel in (('cfg2', 'conv2d_wino4<MODE,TAIL>'), ('cfg5', 'conv2d_mfma16<T,...>')):
+    for tag, kernel in (('cfg2', 'conv2d_wino4<MODE,TAIL>'), ('cfg5', 'conv2d_mfma16<T,...> + conv2d_up2f16<T,...> (every 16-bit convolution launch of a step)')):
         d = os.path.join(G, f'traffic_{tag}')
         try:
             rd = [float(r['value_KiB']) for r in csv.DictReader(open(os.path.join(d, 'FETCH_SIZE.csv')))]

@@ -74,6 +74,15 @@ template <int CTRL> __device__ __forceinline__ float dpp_f(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
 }
 constexpr int DPP_WAVE_SHL1 = 0x130, DPP_WAVE_SHR1 = 0x138;     // lane l reads lane l + 1 / lane l - 1
+// acc += tap * v[lane + 1] / v[lane - 1] in ONE instruction (v_fmac_f32 with a DPP source; bound_ctrl: lanes without a neighbour read 0).  The compiler's own
+// DPP combine leaves v_mov_b32_dpp + v_fmac pairs here (three extra instructions per value pair); `v` must not have been written by the few vector
+// instructions in front of this one (a DPP read needs two wait states after a VALU write): the callers pass accumulator registers the MFMAs wrote long ago.
+__device__ __forceinline__ void fmac_shl(float& acc, float v, float tap) {
+    asm volatile("v_fmac_f32_dpp %0, %1, %2 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(v), "v"(tap));
+}
+__device__ __forceinline__ void fmac_shr(float& acc, float v, float tap) {
+    asm volatile("v_fmac_f32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(v), "v"(tap));
+}
 
 template <typename T, int MW, int NB>
 __global__ __launch_bounds__((MW + MW / 2) * 64, 3) void conv2d_up2f16(Up2fParams pp) {
@@ -92,7 +101,7 @@ __global__ __launch_bounds__((MW + MW / 2) * 64, 3) void conv2d_up2f16(Up2fParam
     const int q8 = total >> 3, r8 = total & 7;
     const int nchunks = p.Cin / G::KC;
     const int pc = p.f.phase_cout;
-    const int dbg_ = PG_CONV16_STAMPS ? p.dbg : 0;      // dev ablations (diagnostic build only; results wrong by design): 1 no stores, 4 no MFMA, 8 no epilogue, 128 no halo DMA
+    const int dbg_ = PG_CONV16_STAMPS ? p.dbg : 0;      // dev ablations (diagnostic build only; results wrong by design): 1 no stores, 4 no MFMA, 8 no epilogue, 16 no per-cout constant reads, 32 no shifted multiply-adds, 64 no activation, 128 no halo DMA
 
     // tile -> (n, first position row, position of lane 0, first cout), XCD-aware like conv2d_mfma16 (scalar unit)
     auto decode = [&](int tile, int& n, int& q0, int& r0, int& m0) __attribute__((always_inline)) {
@@ -258,6 +267,8 @@ __global__ __launch_bounds__((MW + MW / 2) * 64, 3) void conv2d_up2f16(Up2fParam
     const float f0 = pp.fir[0] * tg, f1 = pp.fir[1] * tg, f2 = pp.fir[2] * tg, f3 = pp.fir[3] * tg;
 
     auto write_tile = [&](int tile, int dpar, auto scaled) __attribute__((always_inline)) {
+        float f0v, f1v, f3v;                       // the taps a DPP multiply-add takes from a VECTOR register (VOP2); made here: not live through the K loop
+        asm volatile("v_mov_b32 %0, %3\n\tv_mov_b32 %1, %4\n\tv_mov_b32 %2, %5" : "=v"(f0v), "=v"(f1v), "=v"(f3v) : "s"(f0), "s"(f1), "s"(f3));
         constexpr bool SCALED = decltype(scaled)::value;
         // lane-derived values are rebuilt here from a fresh lane id (asm volatile: not hoisted): kept across the K loop they were 18 spilled registers
         int lane_e;
@@ -266,68 +277,73 @@ __global__ __launch_bounds__((MW + MW / 2) * 64, 3) void conv2d_up2f16(Up2fParam
         int e_n, e_q0, e_r0, e_m0;
         decode(tile, e_n, e_q0, e_r0, e_m0);
         const unsigned char* side = smem + (size_t)G::NBUF * G::LDS_BUF * 16 + (size_t)dpar * G::EP_FLOATS * 4;
-        const int r = e_r0 + l31;
-        const bool col_ok = l31 >= 1 && l31 <= G::UW && r < p.W;
-        // Loop order: the register-group pair (g0, g0 + 1) outermost -- its per-cout constants are read from LDS twice per tile instead of once per
-        // (row, parity, group): 8 instead of 32 exposed LDS round trips per tile and wave.
+        // One (position row, output-row parity) at a time: its two accumulator pairs (32 registers) are dead after the block, so the register pressure
+        // falls as the tile is written out.  Everything a store needs (pixel offset, masks) is rebuilt AT the store from a fresh lane id: values kept
+        // across the arithmetic were spilled, and a scratch reload is a vector-memory load -- its s_waitcnt vmcnt(0) also waits for the block's own
+        // output stores (an HBM round trip, sixteen times per tile: that, not the instruction count, was most of the 24 k cycles of this epilogue).
 #pragma unroll
-        for (int g0 = 0; g0 < 4; g0 += 2) {
-            f32x4 bgv[2], sgv[2];
+        for (int nt = 0; nt < 2; nt++) {
+            const int row_l = 2 * wave + nt, q = e_q0 + row_l;
 #pragma unroll
-            for (int gg = 0; gg < 2; gg++) {
-                const int r0c = 8 * (g0 + gg) + 4 * half;
-                bgv[gg] = *(lds_f4)(side + (size_t)(G::EPS + r0c) * 4) * gain;
-                if constexpr (SCALED) sgv[gg] = *(lds_f4)(side + (size_t)r0c * 4) * gain;
-            }
-            const int co = e_m0 + 8 * (g0 + half);
+            for (int a = 0; a < 2; a++) {
+                const float nze = *(lds_f)(side + (size_t)(2 * G::EPS + (2 * a) * (G::TH * G::LW) + row_l * G::LW + l31) * 4) * ng;
+                const float nzo = *(lds_f)(side + (size_t)(2 * G::EPS + (2 * a + 1) * (G::TH * G::LW) + row_l * G::LW + l31) * 4) * ng;
+                u32x2 pe, po;                                              // group g - 1's packed results (even g), waiting for their exchange partner
 #pragma unroll
-            for (int nt = 0; nt < 2; nt++) {
-                const int row_l = 2 * wave + nt, q = e_q0 + row_l;
-                const bool ok = col_ok && q < p.H && !(dbg_ & 1) && co < pc;
+                for (int g = 0; g < 4; g++) {
+                    const int r0c = 8 * g + 4 * half;
+                    f32x4 bgv = {gain, gain, gain, gain}, sgv = {gain, gain, gain, gain};
+                    if (!(dbg_ & 16)) {
+                        bgv = *(lds_f4)(side + (size_t)(G::EPS + r0c) * 4) * gain;
+                        if constexpr (SCALED) sgv = *(lds_f4)(side + (size_t)r0c * 4) * gain;
+                    }
+                    float ve[4], vo[4];
 #pragma unroll
-                for (int a = 0; a < 2; a++) {
-                    const int oy = 2 * q + a;
-                    const float nze = *(lds_f)(side + (size_t)(2 * G::EPS + (2 * a) * (G::TH * G::LW) + row_l * G::LW + l31) * 4) * ng;
-                    const float nzo = *(lds_f)(side + (size_t)(2 * G::EPS + (2 * a + 1) * (G::TH * G::LW) + row_l * G::LW + l31) * 4) * ng;
-                    const unsigned pix_off = (unsigned)((int64_t)e_n * p.ys[0] + (int64_t)oy * p.ys[2] + (int64_t)(2 * r) * p.ys[3]);
-                    u32x2 ce[2], co2[2];
-#pragma unroll
-                    for (int gg = 0; gg < 2; gg++) {
-                        const int g = g0 + gg;
-                        float ve[4], vo[4];
-#pragma unroll
-                        for (int j = 0; j < 4; j++) {
-                            const float z0 = acc[2 * a][nt][4 * g + j], z1 = acc[2 * a + 1][nt][4 * g + j];
-                            const float z1m = dpp_f<DPP_WAVE_SHR1>(z1), z0p = dpp_f<DPP_WAVE_SHL1>(z0), z1p = dpp_f<DPP_WAVE_SHL1>(z1);
-                            float ue, uo;
-                            if constexpr (SCALED) {
-                                const float he = fmaf(f3, z1m, fmaf(f2, z0, fmaf(f1, z1, f0 * z0p)));
-                                const float ho = fmaf(f3, z0, fmaf(f2, z1, fmaf(f1, z0p, f0 * z1p)));
-                                ue = fmaf(he, sgv[gg][j], bgv[gg][j] + nze); uo = fmaf(ho, sgv[gg][j], bgv[gg][j] + nzo);
-                            } else {
-                                ue = fmaf(f3, z1m, fmaf(f2, z0, fmaf(f1, z1, fmaf(f0, z0p, bgv[gg][j] + nze))));
-                                uo = fmaf(f3, z0, fmaf(f2, z1, fmaf(f1, z0p, fmaf(f0, z1p, bgv[gg][j] + nzo))));
+                    for (int j = 0; j < 4; j++) {
+                        const float z0 = acc[2 * a][nt][4 * g + j], z1 = acc[2 * a + 1][nt][4 * g + j];
+                        float ue, uo;
+                        if constexpr (SCALED) {
+                            float he = fmaf(f2, z0, f1 * z1), ho = fmaf(f3, z0, f2 * z1);
+                            if (!(dbg_ & 32)) {
+                                fmac_shr(he, z1, f3v); fmac_shl(he, z0, f0v);
+                                fmac_shl(ho, z0, f1v); fmac_shl(ho, z1, f0v);
                             }
-                            ve[j] = __builtin_amdgcn_fmed3f(fmaxf(ue, ue * slope), -cl, cl);
-                            vo[j] = __builtin_amdgcn_fmed3f(fmaxf(uo, uo * slope), -cl, cl);
+                            ue = fmaf(he, sgv[j], bgv[j] + nze); uo = fmaf(ho, sgv[j], bgv[j] + nzo);
+                        } else {
+                            ue = fmaf(f2, z0, fmaf(f1, z1, bgv[j] + nze)); uo = fmaf(f3, z0, fmaf(f2, z1, bgv[j] + nzo));
+                            if (!(dbg_ & 32)) {
+                                fmac_shr(ue, z1, f3v); fmac_shl(ue, z0, f0v);
+                                fmac_shl(uo, z0, f1v); fmac_shl(uo, z1, f0v);
+                            }
                         }
-                        ce[gg] = u32x2{HT::pack(ve[0], ve[1]), HT::pack(ve[2], ve[3])};
-                        co2[gg] = u32x2{HT::pack(vo[0], vo[1]), HT::pack(vo[2], vo[3])};
-                        __builtin_amdgcn_sched_barrier(0);      // (one group of 2 x 4 values at a time: interleaving more for ILP costs registers the wave does not have beside its 128 accumulators)
+                        if (dbg_ & 64) { ve[j] = ue; vo[j] = uo; continue; }
+                        ve[j] = __builtin_amdgcn_fmed3f(fmaxf(ue, ue * slope), -cl, cl);
+                        vo[j] = __builtin_amdgcn_fmed3f(fmaxf(uo, uo * slope), -cl, cl);
                     }
-                    // lanes 32-63 of group g0 <-> lanes 0-31 of group g0 + 1: 8 consecutive couts of one pixel per lane
+                    u32x2 ce = {HT::pack(ve[0], ve[1]), HT::pack(ve[2], ve[3])}, co2 = {HT::pack(vo[0], vo[1]), HT::pack(vo[2], vo[3])};
+                    if (g & 1) {
+                        // lanes 32-63 of group g - 1 <-> lanes 0-31 of group g: 8 consecutive couts of one pixel per lane
 #pragma unroll
-                    for (int d = 0; d < 2; d++) {
-                        const auto re = __builtin_amdgcn_permlane32_swap(ce[0][d], ce[1][d], false, false);
-                        ce[0][d] = re[0]; ce[1][d] = re[1];
-                        const auto ro = __builtin_amdgcn_permlane32_swap(co2[0][d], co2[1][d], false, false);
-                        co2[0][d] = ro[0]; co2[1][d] = ro[1];
+                        for (int d = 0; d < 2; d++) {
+                            const auto re = __builtin_amdgcn_permlane32_swap(pe[d], ce[d], false, false);
+                            pe[d] = re[0]; ce[d] = re[1];
+                            const auto ro = __builtin_amdgcn_permlane32_swap(po[d], co2[d], false, false);
+                            po[d] = ro[0]; co2[d] = ro[1];
+                        }
+                        int lane_s;
+                        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_s));
+                        const int ls = lane_s & 31, rs = e_r0 + ls;
+                        const int co = e_m0 + 8 * (g - 1 + (lane_s >> 5));
+                        const bool ok = ls >= 1 && ls <= G::UW && rs < p.W && q < p.H && co < pc && !(dbg_ & 1);
+                        const unsigned pix_off = (unsigned)((int64_t)e_n * p.ys[0] + (int64_t)(2 * q + a) * p.ys[2] + (int64_t)(2 * rs) * p.ys[3]);
+                        const unsigned se = ok ? (pix_off + (unsigned)co) * 2u : SENTINEL;
+                        const unsigned so = ok ? (pix_off + (unsigned)p.ys[3] + (unsigned)co) * 2u : SENTINEL;
+                        __builtin_amdgcn_raw_buffer_store_b128(u32x4{pe[0], pe[1], ce[0], ce[1]}, yrsrc, (int)se, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(u32x4{po[0], po[1], co2[0], co2[1]}, yrsrc, (int)so, 0, 0);
+                    } else {
+                        pe = ce; po = co2;
                     }
-                    const unsigned se = ok ? (pix_off + (unsigned)co) * 2u : SENTINEL;
-                    const unsigned so = ok ? (pix_off + (unsigned)p.ys[3] + (unsigned)co) * 2u : SENTINEL;
-                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{ce[0][0], ce[0][1], ce[1][0], ce[1][1]}, yrsrc, (int)se, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{co2[0][0], co2[0][1], co2[1][0], co2[1][1]}, yrsrc, (int)so, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_sched_barrier(0);      // (one group of 2 x 4 values at a time: interleaving the groups of a tile for ILP costs more registers than the wave has beside its 128 accumulators)
                 }
             }
         }

@@ -47,19 +47,18 @@ class FlatAdam:
                     table.append((off + c0, min(chunk, n - c0), idx, 1 if c0 == 0 else 0))
         self.chunks = torch.tensor(table, dtype=torch.int32).to(dev)
         self.steps = [torch.zeros([len(bucket.params)], dtype=torch.float32, device=dev) for _ in range(2)]
-        self._cur = 0
         bucket.device_flags = True
         self.param_groups = [dict(params=list(bucket.params), lr=self.lr, betas=self.betas, eps=self.eps)]      # (read-only mirror of torch.optim's attribute)
 
     def step(self):
         b = self.bucket
-        src, dst = self.steps[self._cur], self.steps[self._cur ^ 1]
+        src, dst = self.steps[0], self.steps[1]       # (fixed roles + a device-side copy back, not a host-side swap: inside a replayed hipGraph the pointers are frozen)
         with torch.cuda.device(b.flat.device):
             st = self._lib.pg_adam_flat_step(nat.ptr(self.flat_p), nat.ptr(b.flat), nat.ptr(self.exp_avg), nat.ptr(self.exp_avg_sq), nat.ptr(self.chunks),
                                              int(self.chunks.shape[0]), nat.ptr(b.alive), nat.ptr(src), nat.ptr(dst), self.lr, self.betas[0], self.betas[1], self.eps,
                                              self.nan, self.posinf, self.neginf, nat.stream_of(b.flat))
         nat.check(st, 'pg_adam_flat_step')
-        self._cur ^= 1
+        src.copy_(dst)
         # the kernel wrote through raw pointers: move the version counters, so that everything keyed on them (the packed-weight caches) sees new weights
         torch.autograd.graph.increment_version(b.params)
 
@@ -67,4 +66,4 @@ class FlatAdam:
         """(step, exp_avg, exp_avg_sq) of one parameter, like torch.optim.Adam's `state[p]` (tests)."""
         idx = next(i for i, q in enumerate(self.bucket.params) if q is p)
         off, n = self.bucket.offset[idx], p.numel()
-        return dict(step=self.steps[self._cur][idx], exp_avg=self.exp_avg[off:off + n].view_as(p), exp_avg_sq=self.exp_avg_sq[off:off + n].view_as(p))
+        return dict(step=self.steps[0][idx], exp_avg=self.exp_avg[off:off + n].view_as(p), exp_avg_sq=self.exp_avg_sq[off:off + n].view_as(p))

@@ -268,7 +268,9 @@ def warp_perspective_batch(jobs):
         outs.append(dst)
         keep.append(src)
         maxpix = max(maxpix, h * w)
-    raw = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8).to(dev)       # the job table in device memory
+    # the job table in device memory: through a pinned staging buffer, asynchronously -- a pageable upload is a host sync per launch, and the routing of a
+    # batch is ~45 launches per sample that should run behind the previous batch's generator pass, not in lock step with the host
+    raw = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8).pin_memory().to(dev, non_blocking=True)
     with torch.cuda.device(dev):
         st = lib.pg_warp_perspective_u8(raw.data_ptr(), len(jobs), int(maxpix), nat.stream_of(outs[0]))
     nat.check(st, 'pg_warp_perspective_u8')
@@ -360,15 +362,16 @@ def normalize(upper_img, lower_img, upper_clothes_mask, lower_clothes_mask, slee
         keep = 1 - (part_masks[upper_i].to(torch.int32).sum(dim=2, keepdim=True) > 0).to(torch.uint8)
         part_imgs_lower[lower_i] = part_imgs_lower[lower_i] * keep
         part_masks_lower[lower_i] = part_masks_lower[lower_i] * keep
-    has = [bool(m.any()) for m in part_masks]
+    # (the decisions stay on the device -- `bool(mask.any())` was ten host syncs per sample: torch.where on 0-dim conditions picks the same tensors)
+    has = [(m != 0).any() for m in part_masks]
     flip = lambda t: torch.flip(t, dims=[1])
-    if not has[2] and has[4]:
-        part_imgs[2], part_masks[2] = flip(part_imgs[4]), flip(part_masks[4])
-    elif not has[4] and has[2]:
-        part_imgs[4], part_masks[4] = flip(part_imgs[2]), flip(part_masks[2])
-    if not has[3] and has[5]:                                # as written in the reference: the image mirrored is part 3's own
-        part_imgs[3], part_masks[3] = flip(part_imgs[3]), flip(part_masks[5])
-    elif not has[5] and has[3]:
-        part_imgs[5], part_masks[5] = flip(part_imgs[5]), flip(part_masks[3])
+    c24, c42 = (~has[2]) & has[4], (~has[4]) & has[2]        # `if not has[2] and has[4] ... elif not has[4] and has[2]`: the two cannot both hold
+    i2, m2, i4, m4 = part_imgs[2], part_masks[2], part_imgs[4], part_masks[4]
+    part_imgs[2], part_masks[2] = torch.where(c24, flip(i4), i2), torch.where(c24, flip(m4), m2)
+    part_imgs[4], part_masks[4] = torch.where(c42, flip(i2), i4), torch.where(c42, flip(m2), m4)
+    c35, c53 = (~has[3]) & has[5], (~has[5]) & has[3]
+    i3, m3, i5, m5 = part_imgs[3], part_masks[3], part_imgs[5], part_masks[5]
+    part_imgs[3], part_masks[3] = torch.where(c35, flip(i3), i3), torch.where(c35, flip(m5), m3)     # as written in the reference: the image mirrored is part 3's own
+    part_imgs[5], part_masks[5] = torch.where(c53, flip(i5), i5), torch.where(c53, flip(m3), m5)
 
     return torch.cat(part_imgs, dim=2), torch.cat(part_imgs_lower, dim=2), denorm_upper, denorm_upper_wo_sleeve, denorm_lower

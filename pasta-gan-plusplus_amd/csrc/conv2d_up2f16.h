@@ -416,8 +416,8 @@ struct Up2pGeo {
     static constexpr int NSTEP = 18;                       // weight fragments with a non-zero tap: per ty, tx = 1 x phases 0..3, then tx = 0 x phases 0, 2
     static constexpr int IH_T = TH + 2, IW_T = LW + 1;
     static constexpr int NPIX = IH_T * IW_T;
-    static constexpr int PLANE = (NPIX + 63) / 64 * 64;    // k-half planes (see Up2fGeo)
-    static constexpr int NXS = 2 * PLANE;
+    static constexpr int NGRP = (NPIX + 31) / 32;          // 1 KB groups of 32 pixels x 2 k-halves (see Up2fGeo)
+    static constexpr int NXS = NGRP * 64;
     static constexpr int NXS_PAD = (NXS + LT - 1) / LT * LT;
     static constexpr int NWS = NSTEP * 2 * 32;
     static constexpr int NWS_PAD = (NWS + LT - 1) / LT * LT;
@@ -496,7 +496,7 @@ __global__ __launch_bounds__(Up2pGeo::NTHREADS, 2) void conv2d_up2f16p(Up2fParam
         rel[j] = SENTINEL;
         if (j < G::NREQ_X) {
             hyx[j] = 0x4000u;
-            const int c = s >= G::PLANE, qh = s - c * G::PLANE;
+            const int c = (s >> 5) & 1, qh = (s >> 6) * 32 + (s & 31);
             const int hy = qh / G::IW_T, hx = qh % G::IW_T;
             if (qh < G::NPIX && s < G::NXS) {
                 rel[j] = (unsigned)((hy * p.W + hx) * p.xC + c * 8) * 2u;
@@ -566,16 +566,19 @@ __global__ __launch_bounds__(Up2pGeo::NTHREADS, 2) void conv2d_up2f16p(Up2fParam
     // ---------------------------------------------------------------- multiplying role
     const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)(p.y_bytes > 0x7fffffffLL ? 0x7fffffffLL : p.y_bytes), 0x00020000);
     f32x16 acc[4][2];                                                      // [phase 2a + b][position row nt]
-    const unsigned b_lane = (unsigned)(half * G::PLANE + (2 * wr) * G::IW_T + l31) * 16u;
+    const int q_lane = (2 * wr) * G::IW_T + l31;                           // halo pixel of this lane's first position row, tap (0, 0)
     const unsigned a_lane = (unsigned)(G::NXS_PAD + half * 32 + l31) * 16u;
 
     // One 16-channel chunk: 18 weight fragments (ty, tx, phase), two MFMAs each (the two position rows).  A software pipeline by hand, pinned with
     // sched_barrier: the weight fragments are requested TWO steps ahead (one multiplying wave per SIMD: nobody else covers an exposed LDS round trip),
     // the activation fragments rotate through four register sets (row ty leaves after its last use, row ty + 2 takes its place).
     auto compute_chunk = [&](int buf) __attribute__((always_inline)) {
-        const unsigned char* bb = smem + (size_t)buf * G::LDS_BUF * 16 + b_lane;
+        const unsigned char* bb = smem + (size_t)buf * G::LDS_BUF * 16 + half * 512;
         const unsigned char* ab = smem + (size_t)buf * G::LDS_BUF * 16 + a_lane;
-        auto b_frag = [&](int hr, int tx) __attribute__((always_inline)) { return *(lds_v4)(bb + (size_t)(hr * G::IW_T + tx) * 16); };
+        auto b_frag = [&](int hr, int tx) __attribute__((always_inline)) {
+            const int q = q_lane + hr * G::IW_T + tx;
+            return *(lds_v4)(bb + (size_t)(((q >> 5) << 10) + ((q & 31) << 4)));
+        };
         auto a_frag = [&](int i) __attribute__((always_inline)) { return *(lds_v4)(ab + (size_t)(i * 64) * 16); };
         i32x4 b1[4], b0[4];
         b1[0] = b_frag(0, 1); b1[1] = b_frag(1, 1);
@@ -606,47 +609,42 @@ __global__ __launch_bounds__(Up2pGeo::NTHREADS, 2) void conv2d_up2f16p(Up2fParam
     const float f0 = pp.fir[0] * tg, f1 = pp.fir[1] * tg, f2 = pp.fir[2] * tg, f3 = pp.fir[3] * tg;
     u32x2 pe = {0u, 0u}, po = {0u, 0u};                                    // an even block's packed results, waiting for their exchange partner (the next block)
 
-    // block BLK = (nt, a, g) of the finished tile (e_n, e_q0, e_r0, e_m0): 2 x 4 values per lane; the odd blocks also exchange and store (2 stores)
-    auto epi_block = [&](auto blkc, int e_n, int e_q0, int e_r0, int e_m0, int sidx) __attribute__((always_inline)) {
-        constexpr int BLK = decltype(blkc)::value;
-        constexpr int nt = BLK >> 3, a = (BLK >> 2) & 1, g = BLK & 3;
-        int lane_e;                                                        // (fresh lane id, asm volatile: the sixteen blocks' lane-derived addresses are not hoisted out of the step loop)
-        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
-        const int half = lane_e >> 5, l31 = lane_e & 31;
+    // block blk = (nt, a, g) of the finished tile (e_n, e_q0, e_r0, e_m0): 2 x 4 values per lane; the odd blocks also exchange and store (2 stores).
+    // ONE body for all sixteen blocks: a switch copies the block's eight accumulator values into plain registers, everything else takes (nt, a, g) as scalars.
+    // (Sixteen unrolled bodies x two scale variants were ~30 KB of straight-line code next to the other group's MFMA loop and the request code: the serving
+    // waves ran at ~15 cycles per instruction -- instruction fetch, not the vector ALU.)
+    auto epi_block = [&](int blk, int e_n, int e_q0, int e_r0, int e_m0, int sidx) __attribute__((always_inline)) {
+        const int nt = blk >> 3, a = (blk >> 2) & 1, g = blk & 3;
+        float z0[4], z1[4];
+        switch (blk) {
+#define PG_UP2_BLK(B) case B: { _Pragma("unroll") for (int j = 0; j < 4; j++) { z0[j] = acc[2 * (((B) >> 2) & 1)][(B) >> 3][4 * ((B) & 3) + j]; z1[j] = acc[2 * (((B) >> 2) & 1) + 1][(B) >> 3][4 * ((B) & 3) + j]; } } break;
+            PG_UP2_BLK(0) PG_UP2_BLK(1) PG_UP2_BLK(2) PG_UP2_BLK(3) PG_UP2_BLK(4) PG_UP2_BLK(5) PG_UP2_BLK(6) PG_UP2_BLK(7)
+            PG_UP2_BLK(8) PG_UP2_BLK(9) PG_UP2_BLK(10) PG_UP2_BLK(11) PG_UP2_BLK(12) PG_UP2_BLK(13) PG_UP2_BLK(14)
+            default: { _Pragma("unroll") for (int j = 0; j < 4; j++) { z0[j] = acc[3 - 1][1][12 + j]; z1[j] = acc[3][1][12 + j]; } } break;
+#undef PG_UP2_BLK
+        }
+        // (a DPP read of a register needs two wait states after the vector instruction that wrote it: the copies above are followed by the LDS reads and their wait)
         const unsigned char* side = smem + (size_t)G::NBUF * G::LDS_BUF * 16 + (size_t)sidx * G::EP_FLOATS * 4;
         const int row_l = 2 * wr + nt, q = e_q0 + row_l;
         const float nze = *(lds_f)(side + (size_t)(2 * G::EPS + (2 * a) * (G::TH * G::LW) + row_l * G::LW + l31) * 4) * ng;
         const float nzo = *(lds_f)(side + (size_t)(2 * G::EPS + (2 * a + 1) * (G::TH * G::LW) + row_l * G::LW + l31) * 4) * ng;
         const int r0c = 8 * g + 4 * half;
         const f32x4 bgv = *(lds_f4)(side + (size_t)(G::EPS + r0c) * 4) * gain;
+        f32x4 sgv = {gain, gain, gain, gain};
+        if (has_scale) sgv = *(lds_f4)(side + (size_t)r0c * 4) * gain;
         float ve[4], vo[4];
-        if (has_scale) {
-            const f32x4 sgv = *(lds_f4)(side + (size_t)r0c * 4) * gain;
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const float z0 = acc[2 * a][nt][4 * g + j], z1 = acc[2 * a + 1][nt][4 * g + j];
-                const float z1m = dpp_f<DPP_WAVE_SHR1>(z1), z0p = dpp_f<DPP_WAVE_SHL1>(z0), z1p = dpp_f<DPP_WAVE_SHL1>(z1);
-                const float he = fmaf(f3, z1m, fmaf(f2, z0, fmaf(f1, z1, f0 * z0p)));
-                const float ho = fmaf(f3, z0, fmaf(f2, z1, fmaf(f1, z0p, f0 * z1p)));
-                const float ue = fmaf(he, sgv[j], bgv[j] + nze), uo = fmaf(ho, sgv[j], bgv[j] + nzo);
-                ve[j] = __builtin_amdgcn_fmed3f(fmaxf(ue, ue * slope), -cl, cl);
-                vo[j] = __builtin_amdgcn_fmed3f(fmaxf(uo, uo * slope), -cl, cl);
-                __builtin_amdgcn_sched_barrier(0);                         // (value by value: a serving wave has time, not registers to spare for interleaving)
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const float z0 = acc[2 * a][nt][4 * g + j], z1 = acc[2 * a + 1][nt][4 * g + j];
-                const float z1m = dpp_f<DPP_WAVE_SHR1>(z1), z0p = dpp_f<DPP_WAVE_SHL1>(z0), z1p = dpp_f<DPP_WAVE_SHL1>(z1);
-                const float ue = fmaf(f3, z1m, fmaf(f2, z0, fmaf(f1, z1, fmaf(f0, z0p, bgv[j] + nze))));
-                const float uo = fmaf(f3, z0, fmaf(f2, z1, fmaf(f1, z0p, fmaf(f0, z1p, bgv[j] + nzo))));
-                ve[j] = __builtin_amdgcn_fmed3f(fmaxf(ue, ue * slope), -cl, cl);
-                vo[j] = __builtin_amdgcn_fmed3f(fmaxf(uo, uo * slope), -cl, cl);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+        for (int j = 0; j < 4; j++) {
+            const float z1m = dpp_f<DPP_WAVE_SHR1>(z1[j]), z0p = dpp_f<DPP_WAVE_SHL1>(z0[j]), z1p = dpp_f<DPP_WAVE_SHL1>(z1[j]);
+            const float he = fmaf(f3, z1m, fmaf(f2, z0[j], fmaf(f1, z1[j], f0 * z0p)));
+            const float ho = fmaf(f3, z0[j], fmaf(f2, z1[j], fmaf(f1, z0p, f0 * z1p)));
+            // (taps carry the gain when there is no per-cout scale: sgv == 1 then -- one code path)
+            const float ue = fmaf(he, has_scale ? sgv[j] : 1.f, bgv[j] + nze), uo = fmaf(ho, has_scale ? sgv[j] : 1.f, bgv[j] + nzo);
+            ve[j] = __builtin_amdgcn_fmed3f(fmaxf(ue, ue * slope), -cl, cl);
+            vo[j] = __builtin_amdgcn_fmed3f(fmaxf(uo, uo * slope), -cl, cl);
         }
         u32x2 ce = {HT::pack(ve[0], ve[1]), HT::pack(ve[2], ve[3])}, co2 = {HT::pack(vo[0], vo[1]), HT::pack(vo[2], vo[3])};
-        if constexpr (g & 1) {
+        if (g & 1) {
             // lanes 32-63 of group g - 1 <-> lanes 0-31 of group g: 8 consecutive couts of one pixel per lane
 #pragma unroll
             for (int d = 0; d < 2; d++) {
@@ -668,18 +666,10 @@ __global__ __launch_bounds__(Up2pGeo::NTHREADS, 2) void conv2d_up2f16p(Up2fParam
         } else {
             pe = ce; po = co2;
         }
-        __builtin_amdgcn_sched_barrier(0);
     };
     auto epi_blocks = [&](int first, int count, int e_n, int e_q0, int e_r0, int e_m0, int sidx) __attribute__((always_inline)) {
-        for (int blk = first; blk < first + count && blk < G::NBLK; blk++) {
-            switch (blk) {
-#define PG_UP2_BLK(B) case B: epi_block(int_c<B>{}, e_n, e_q0, e_r0, e_m0, sidx); break;
-                PG_UP2_BLK(0) PG_UP2_BLK(1) PG_UP2_BLK(2) PG_UP2_BLK(3) PG_UP2_BLK(4) PG_UP2_BLK(5) PG_UP2_BLK(6) PG_UP2_BLK(7)
-                PG_UP2_BLK(8) PG_UP2_BLK(9) PG_UP2_BLK(10) PG_UP2_BLK(11) PG_UP2_BLK(12) PG_UP2_BLK(13) PG_UP2_BLK(14)
-#undef PG_UP2_BLK
-                default: epi_block(int_c<15>{}, e_n, e_q0, e_r0, e_m0, sidx); break;
-            }
-        }
+#pragma unroll 1
+        for (int blk = first; blk < first + count && blk < G::NBLK; blk++) epi_block(blk, e_n, e_q0, e_r0, e_m0, sidx);
     };
 
     // ---------------------------------------------------------------- the step loop: one barrier per chunk of the workgroup's tile sequence

@@ -1164,7 +1164,13 @@ class _SynthesisBlockBase(nn.Module):
         if self.TEXTURE:
             self.spade_b512 = Spade_ResBlockV4_512(out_channels, out_channels, spade_channels=1)
 
-    def _forward(self, x, img, ws, pose_feature, cat_feat, parsing, force_fp32, fused_modconv, **layer_kwargs):
+    def affine_layers(self):
+        """(layer, index of its w within the block's ws, gain folded into its styles) in call order."""
+        convs = [self.conv1] if self.in_channels == 0 else [self.conv0, self.conv1]
+        return [(m, i, 1.0) for i, m in enumerate(convs)] + ([(self.torgb, self.num_conv, self.torgb.weight_gain)] if self.has_torgb else [])
+
+    def _forward(self, x, img, ws, pose_feature, cat_feat, parsing, force_fp32, fused_modconv, styles=None, **layer_kwargs):
+        """`styles` (private): the block's affine outputs in `affine_layers()` order when the network computed them for all layers at once."""
         misc.assert_shape(ws, [None, self.num_conv + self.num_torgb, self.w_dim])
         half = self.use_fp16 and not force_fp32
         fmt = dict(dtype=torch.float16 if half else torch.float32,
@@ -1172,7 +1178,8 @@ class _SynthesisBlockBase(nn.Module):
         if fused_modconv is None:      # the reference's rule (networks.py:2152-2154); both forms are one launch here
             fused_modconv = (not self.training) and (not half or int(ws.shape[0]) == 1)
         style = lambda i: ws[:, i]
-        conv = lambda layer, t, i, **kw: layer(t, style(i), fused_modconv=fused_modconv, **kw, **layer_kwargs)
+        st = styles if styles is not None else [None] * (self.num_conv + self.num_torgb)
+        conv = lambda layer, t, i, **kw: layer(t, style(i), fused_modconv=fused_modconv, styles=st[i], **kw, **layer_kwargs)
 
         if self.in_channels == 0:      # 8x8 block: starts from the pose encoder's feature map
             x = conv(self.conv1, pose_feature.to(**fmt), 0)
@@ -1195,7 +1202,7 @@ class _SynthesisBlockBase(nn.Module):
             img = upfirdn2d.upsample2d(img, self.resample_filter)
         pred_parsing = None
         if self.has_torgb:             # img + torgb(x) in one launch
-            rgb, pred_parsing = self.torgb(x, style(self.num_conv), fused_modconv=fused_modconv, skip_img=img)
+            rgb, pred_parsing = self.torgb(x, style(self.num_conv), fused_modconv=fused_modconv, skip_img=img, styles=st[self.num_conv])
             img = rgb.to(dtype=torch.float32, memory_format=torch.contiguous_format)
         return x, img, pred_parsing
 
@@ -1204,8 +1211,8 @@ class SynthesisBlockFull_v1_v6(_SynthesisBlockBase):
     """Style-branch block (networks.py:2086-2194)."""
     TORGB = ToRGBLayerFull_v1_v5
 
-    def forward(self, x, img, ws, pose_feature, cat_feat, force_fp32=False, fused_modconv=None, **layer_kwargs):
-        return self._forward(x, img, ws, pose_feature, cat_feat, None, force_fp32, fused_modconv, **layer_kwargs)
+    def forward(self, x, img, ws, pose_feature, cat_feat, force_fp32=False, fused_modconv=None, styles=None, **layer_kwargs):
+        return self._forward(x, img, ws, pose_feature, cat_feat, None, force_fp32, fused_modconv, styles=styles, **layer_kwargs)
 
 
 class SynthesisBlockFull_v1_v4(_SynthesisBlockBase):
@@ -1213,13 +1220,47 @@ class SynthesisBlockFull_v1_v4(_SynthesisBlockBase):
     TORGB = ToRGBLayerFull_v1_v4
     TEXTURE = True
 
-    def forward(self, x, img, ws, pose_feature, cat_feat, parsing, force_fp32=False, fused_modconv=None, **layer_kwargs):
-        return self._forward(x, img, ws, pose_feature, cat_feat, parsing, force_fp32, fused_modconv, **layer_kwargs)
+    def forward(self, x, img, ws, pose_feature, cat_feat, parsing, force_fp32=False, fused_modconv=None, styles=None, **layer_kwargs):
+        return self._forward(x, img, ws, pose_feature, cat_feat, parsing, force_fp32, fused_modconv, styles=styles, **layer_kwargs)
 
 
 def _half_nearest(t):
     """F.interpolate(t, scale_factor=0.5), default 'nearest' (networks.py:2255-2256, 2311-2312): every other pixel."""
     return t[:, :, ::2, ::2]
+
+
+def _batched_affine(owner, entries, ws, num_ws, w_dim):
+    """Inference: the ~2 dozen affine layers of a synthesis network (FullyConnectedLayer, networks.py:115-128: w @ (W * gain)^T + b) as ONE GEMM over all
+    (w index, layer) pairs -- mostly unused products, a fraction of a GFLOP -- instead of a launch per layer, and one gather that leaves each layer's
+    [N, Cin] styles contiguous.  entries: (key, layer, absolute w index, gain folded into the styles); weights are concatenated once per parameter version.
+    Returns {key: [styles, ...]} in entry order."""
+    n = ws.shape[0]
+    params = [t for _, m, _, _ in entries for t in (m.affine.weight, m.affine.bias)]
+
+    def build():
+        wt = torch.cat([m.affine.weight.detach().float() * (m.affine.weight_gain * g) for _, m, _, g in entries]).t().contiguous()
+        b = torch.cat([m.affine.bias.detach().float() * (m.affine.bias_gain * g) for _, m, _, g in entries]).contiguous()
+        return wt, b
+    if not hasattr(owner, '_affine_cache'):
+        owner._affine_cache, owner._gather = _PackCache(), {}
+    wt, b = owner._affine_cache.get(('all',), params, build)
+    total = wt.shape[1]
+    key = (n, ws.device)
+    if key not in owner._gather:     # flat index of styles[l][n, c] inside the [N * num_ws, total] product
+        idx, col = [], 0
+        rows = torch.arange(n, dtype=torch.int64)[:, None] * num_ws
+        for _, m, wi, _ in entries:
+            c = m.affine.weight.shape[0]
+            idx.append(((rows + wi) * total + col + torch.arange(c, dtype=torch.int64)[None, :]).reshape(-1))
+            col += c
+        owner._gather[key] = torch.cat(idx).to(ws.device)
+    flat = torch.addmm(b, ws.reshape(n * num_ws, w_dim), wt).reshape(-1).index_select(0, owner._gather[key])
+    out, off = {}, 0
+    for k, m, _, _ in entries:
+        c = m.affine.weight.shape[0]
+        out.setdefault(k, []).append(flat[off:off + n * c].view(n, c))
+        off += n * c
+    return out
 
 
 class SynthesisNetworkFull_v18(nn.Module):
@@ -1280,10 +1321,20 @@ class SynthesisNetworkFull_v18(nn.Module):
     def forward(self, ws, pose_feat, cat_feat, denorm_upper_input, denorm_lower_input, denorm_upper_mask,
                 denorm_lower_mask, gt_parsing, **block_kwargs):
         styles = self._block_styles(ws)
+        # inference on the GPU: the 23 affine layers of the style and texture branches as one GEMM + one gather (round 5; PG_AFFINE_BATCHED=0 = a launch per layer)
+        pre = None
+        if ws.is_cuda and not torch.is_grad_enabled() and os.environ.get('PG_AFFINE_BATCHED', '1') != '0':
+            entries, start = [], 0
+            for res in self.block_resolutions:
+                block = getattr(self, f'b{res}')
+                entries += [(res, m, start + i, g) for m, i, g in block.affine_layers()]
+                last_start, start = start, start + block.num_conv
+            entries += [('texture', m, last_start + i, g) for m, i, g in self.texture_b512.affine_layers()]
+            pre = _batched_affine(self, entries, ws.to(torch.float32), self.num_ws, self.w_dim)
         x = img = pred_parsing = None
         kept = {}
         for res, w in zip(self.block_resolutions, styles):
-            x, img, pred_parsing = getattr(self, f'b{res}')(x, img, w, pose_feat, cat_feat, force_fp32=True, **block_kwargs)
+            x, img, pred_parsing = getattr(self, f'b{res}')(x, img, w, pose_feat, cat_feat, force_fp32=True, styles=pre[res] if pre is not None else None, **block_kwargs)
             kept[res] = (x, img)       # neither is modified in place afterwards: no clone needed
         x_256, img_256 = kept[self.block_resolutions[-2]]
 
@@ -1304,7 +1355,8 @@ class SynthesisNetworkFull_v18(nn.Module):
                           + self.get_spade_feat(lower_mask.detach(), denorm_lower_mask, denorm_lower_input) * (_half_nearest(lower_mask) > 0.9))
 
         x_spade = self.spade_b256_2(self.spade_b256_1(x_256, spade_feat), spade_feat)
-        _, finetune_img, _ = self.texture_b512(x_spade, img_256, styles[-1], pose_feat, cat_feat, parsing_index, force_fp32=True, **block_kwargs)
+        _, finetune_img, _ = self.texture_b512(x_spade, img_256, styles[-1], pose_feat, cat_feat, parsing_index, force_fp32=True,
+                                               styles=pre['texture'] if pre is not None else None, **block_kwargs)
         return img, finetune_img, pred_parsing
 
 
@@ -1369,42 +1421,14 @@ class SynthesisStack(nn.Module):
             self.num_ws += block.num_conv + (block.num_torgb if res == img_resolution else 0)
 
     def all_styles(self, ws):
-        """Inference: the ~2 dozen affine layers of the stack (FullyConnectedLayer, networks.py:115-128: w @ (W * gain)^T + b) as ONE
-        GEMM over all (w index, layer) pairs -- 0.7 GFLOP, mostly unused, instead of a launch per layer -- and one gather that
-        leaves each layer's [N, Cin] styles contiguous.  Weights are concatenated once per parameter version.  Returns
-        {resolution: [styles of conv0?, conv1, torgb]}; the ToRGB weight gain is folded in."""
-        n = ws.shape[0]
+        """Inference: every affine layer of the stack as ONE GEMM + one gather (`_batched_affine`).  Returns {resolution: [styles of conv0?, conv1, torgb]};
+        the ToRGB weight gain is folded in."""
         entries, start = [], 0          # (resolution, layer, absolute w index, gain)
         for res in self.block_resolutions:
             block = getattr(self, f'b{res}')
             entries += [(res, m, start + i, g) for m, i, g in block.affine_layers()]
             start += block.num_conv
-        params = [t for _, m, _, _ in entries for t in (m.affine.weight, m.affine.bias)]
-
-        def build():
-            wt = torch.cat([m.affine.weight.detach().float() * (m.affine.weight_gain * g) for _, m, _, g in entries]).t().contiguous()
-            b = torch.cat([m.affine.bias.detach().float() * (m.affine.bias_gain * g) for _, m, _, g in entries]).contiguous()
-            return wt, b
-        if not hasattr(self, '_affine_cache'):
-            self._affine_cache, self._gather = _PackCache(), {}
-        wt, b = self._affine_cache.get(('all',), params, build)
-        total = wt.shape[1]
-        key = (n, ws.device)
-        if key not in self._gather:     # flat index of styles[l][n, c] inside the [N * num_ws, total] product
-            idx, col = [], 0
-            rows = torch.arange(n, dtype=torch.int64)[:, None] * self.num_ws
-            for _, m, wi, _ in entries:
-                c = m.affine.weight.shape[0]
-                idx.append(((rows + wi) * total + col + torch.arange(c, dtype=torch.int64)[None, :]).reshape(-1))
-                col += c
-            self._gather[key] = torch.cat(idx).to(ws.device)
-        flat = torch.addmm(b, ws.reshape(n * self.num_ws, self.w_dim), wt).reshape(-1).index_select(0, self._gather[key])
-        out, off = {}, 0
-        for res, m, _, _ in entries:
-            c = m.affine.weight.shape[0]
-            out.setdefault(res, []).append(flat[off:off + n * c].view(n, c))
-            off += n * c
-        return out
+        return _batched_affine(self, entries, ws, self.num_ws, self.w_dim)
 
     def forward(self, ws, **block_kwargs):
         misc.assert_shape(ws, [None, self.num_ws, self.w_dim])

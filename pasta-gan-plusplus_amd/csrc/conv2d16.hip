@@ -528,6 +528,11 @@ PG_EXPORT int pg_conv2d16_forward_splitk(const void* x, const void* packed, void
                           ystride, out_step_y, out_step_x, out_off_y, out_off_x, fusion, stream, workspace, ksplit);
 }
 
+namespace pgconv16 {
+int launch_head16(const void* x, const float* w, const float* styles, const float* bias, const float* skip, float* y, int dtype, int N, int Cin, int64_t HW, int Cout,
+                  float clamp, int up_w, hipStream_t s);      // conv1x1_head16.hip
+}
+
 PG_EXPORT int pg_conv1x1_small16(const void* x, const float* w, const float* styles, const float* bias, const float* skip, float* y,
                                  int dtype, int N, int Cin, int64_t HW, int Cout, float clamp, int skip_up2_width, void* stream) {
     if (!x || !w || !y || N <= 0 || Cin <= 0 || HW <= 0 || Cout <= 0) return PG_ERR_INVALID_ARG;
@@ -535,6 +540,13 @@ PG_EXPORT int pg_conv1x1_small16(const void* x, const float* w, const float* sty
     const int up_w = skip_up2_width;
     if (dtype != PG_BF16 && dtype != PG_F16) return PG_ERR_INVALID_ARG;
     if (Cout > 8 || Cin % 8 != 0 || (((uintptr_t)x) & 15) != 0 || (size_t)Cout * Cin * 4 > 64 * 1024) return PG_ERR_UNSUPPORTED;
+    // round 5: the form that spreads a pixel's channels over the lanes of a wave (conv1x1_head16.hip) takes the three-channel heads it covers; PG_HEAD16_FORM=1 keeps
+    // the first form (A/B)
+    static const bool first_form = [] { const char* e = getenv("PG_HEAD16_FORM"); return e && atoi(e) == 1; }();
+    if (!first_form) {
+        const int st2 = pgconv16::launch_head16(x, w, styles, bias, skip, y, dtype, N, Cin, HW, Cout, clamp, up_w, (hipStream_t)stream);
+        if (st2 != PG_ERR_UNSUPPORTED) return st2;
+    }
     // lanes per pixel: enough threads for the whole chip on small images (256 CUs x 256 threads = 64 K lanes), never more lanes than 16-byte channel groups / 4
     static const int lp_force = [] { const char* e = getenv("PG_HEAD16_LP"); return e ? atoi(e) : 0; }();
     int lp = 1;

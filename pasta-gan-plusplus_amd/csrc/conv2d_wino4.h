@@ -146,7 +146,7 @@ __global__ __launch_bounds__(768, 3) void conv2d_wino4(ConvParams p) {
     const bool chore = wave >= 8;                // waves 8-11: DMA issue, gather maps, epilogue constants (they sit out the transform and the finish)
     const int cw = wave - 8;                     // chore wave 0..3; chore thread index tc = 64 cw + lane
     const int sh = p.pad_x & 3;                  // float shift of the staged tile: patch column 0 of tile_x lands on LDS column 4 tile_x + cbase
-    const int cbase = 4 - p.pad_x + sh;          // 4 (pad 0..3) or 0 (pad 4): a multiple of 4 -> 16-byte aligned patch reads
+    constexpr int cbase = 4;                     // = 4 - pad_x + sh for the paddings the launcher admits (1, 3): a multiple of 4 -> 16-byte aligned patch reads
 
     int n = 0, oy0 = 0, ox0 = 0, m0 = 0;
     bool edge = false;
@@ -729,6 +729,7 @@ int launch_wino4_mode(const ConvParams& p0, hipStream_t s) {
         if (ext * 4 > 0xffffffffLL || (int64_t)p.OH * p.OW * 4 > 0xffffffffLL) return PG_ERR_TOO_LARGE;
     }
     if (lds > 160 * 1024) return PG_ERR_UNSUPPORTED;
+    if (p.pad_x != 1 && p.pad_x != 3) return PG_ERR_UNSUPPORTED;    // W % 4 == 0 and OW % 4 == 0 together leave odd paddings only; 0 / 4 had their own (never exercised) staging arithmetic: removed in round 5
     // the tail moves 16-byte row segments: unit x stride, every other stride and OW a multiple of 4, 16-byte aligned bases
     if (p.ys[3] != 1 || ((p.ys[0] | p.ys[1] | p.ys[2] | p.f.noise_batch_stride) & 3) != 0 || (p.OW & 3) != 0 ||
         ((((uintptr_t)p.y) | ((uintptr_t)p.f.noise) | ((uintptr_t)p.f.residual) | ((uintptr_t)p.f.spade_x)) & 15) != 0) return PG_ERR_UNSUPPORTED;

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(512, 4) void conv2d_wino4b(ConvParams p) {
     const int lw = WINO4B_LOADERS == 0 ? wave : (wave & 3);                       // loader wave index
     const int nd = !loader ? 0 : (B4_NL * (B4_NI - 1) + lw < B4_NINST ? B4_NI : B4_NI - 1);      // halo DMA instructions of this wave per chunk
     const int sh = p.pad_x & 3;                  // float shift of the staged tile: patch column 0 of tile_x lands on LDS column 4 tile_x + cbase
-    const int cbase = 4 - p.pad_x + sh;          // a multiple of 4 -> 16-byte aligned patch reads
+    constexpr int cbase = 4;                     // = 4 - pad_x + sh for the paddings the launcher admits (1, 3): a multiple of 4 -> 16-byte aligned patch reads
 
     int n = 0, oy0 = 0, ox0 = 0, m0 = 0;
     bool edge = false, map_is_interior = false;
@@ -517,6 +517,7 @@ int launch_wino4b_mode(const ConvParams& p0, hipStream_t s) {
         const int64_t ext = 1 + (int64_t)(p.f.spade_x ? p.Cout / 2 - 1 : p.Cout - 1) * p.ys[1] + (int64_t)(p.OH - 1) * p.ys[2] + (int64_t)(p.OW - 1) * p.ys[3];
         if (ext * 4 > 0xffffffffLL || (int64_t)p.OH * p.OW * 4 > 0xffffffffLL) return PG_ERR_TOO_LARGE;
     }
+    if (p.pad_x != 1 && p.pad_x != 3) return PG_ERR_UNSUPPORTED;    // W % 4 == 0 and OW % 4 == 0 together leave odd paddings only; 0 / 4 had their own (never exercised) staging arithmetic: removed in round 5
     if (lds > 80 * 1024) return PG_ERR_UNSUPPORTED;                                          // two workgroups per CU
     if (p.ys[3] != 1 || ((p.ys[0] | p.ys[1] | p.ys[2] | p.f.noise_batch_stride) & 3) != 0 || (p.OW & 3) != 0 ||
         ((((uintptr_t)p.y) | ((uintptr_t)p.f.noise) | ((uintptr_t)p.f.residual) | ((uintptr_t)p.f.spade_x)) & 15) != 0) return PG_ERR_UNSUPPORTED;

@@ -327,7 +327,7 @@ def _modconv16_policy(weight_shape, hw, up, padding, resample_filter):
     if fused_x:
         composite = False
     taps = 36 if composite else (24 if fused_x else (16 if merged_t else kh * kw))
-    shared = cout * taps > 2 * h * w and os.environ.get('PG_MODCONV16_SHARED', '1') != '0'
+    shared = cout * taps > float(os.environ.get('PG_MODCONV16_SHARED_RATIO', '1')) * h * w and os.environ.get('PG_MODCONV16_SHARED', '1') != '0'
 
     return composite, merged_t, shared, tpad, fir_pad, fused_x
 

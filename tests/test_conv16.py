@@ -290,9 +290,15 @@ def test_conv16_full_size_properties(dtype):
 
 
 @pytest.mark.parametrize('dtype', DTYPES, ids=['bf16', 'fp16'])
-@pytest.mark.parametrize('shape', [(2, 64, 33, 47), (2, 512, 8, 8), (3, 256, 16, 24), (4, 1024, 4, 4), (1, 136, 9, 7)], ids=['one_lane', 'sixteen_lanes', 'four_lanes', 'tiny', 'ragged_groups'])
+@pytest.mark.parametrize('shape', [(2, 64, 33, 47), (2, 512, 8, 8), (3, 256, 16, 24), (4, 1024, 4, 4), (1, 136, 9, 7),
+                                   (2, 32, 256, 260), (1, 64, 300, 256), (1, 128, 320, 258), (1, 256, 200, 200), (1, 512, 128, 130), (2, 1024, 48, 50), (1, 1024, 96, 90), (1, 776, 20, 22),
+                                   (4, 32, 62, 66), (4, 1024, 16, 16)],
+                         ids=['one_lane', 'sixteen_lanes', 'four_lanes', 'tiny', 'ragged_groups', 'lp4_u4', 'lp8_u8', 'lp16_u16', 'lp32_u16', 'lp64_u16', 'lp64_u4_k2', 'lp64_u8_k2', 'lp64_ragged_k2',
+                              'lp4_small_image', 'lp64_u1_k2'])
 def test_conv1x1_small_head(dtype, shape):
-    """The 16-bit ToRGB / parsing head (one streaming pass; 1, 4 or 16 lanes per pixel depending on the image size) against float64."""
+    """The 16-bit ToRGB / parsing head against float64.  Three output channels run the round-5 form (csrc/conv1x1_head16.hip: Cin / 8 lanes share a pixel, reduce-scatter over
+    shuffles, the half-resolution skip's neighbour column from the neighbour lane) -- the `lp*` cases name its (lanes per pixel, pixels per lane group, channel passes) variants, with
+    widths that are no multiple of 64 so that wave passes cross image rows; seven channels run the first form (one streaming pass; 1, 4 or 16 lanes per pixel depending on the image size)."""
     from torch_utils.ops import conv2d_mfma16 as M
     n, cin, h, w = shape
     gen = torch.Generator().manual_seed(13)

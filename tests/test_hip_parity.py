@@ -470,7 +470,7 @@ def test_conv2d_winograd4_kernel(n, cin, cout, h, w, pad, form):
     every fused stage, per-sample noise and SPADE mode against the direct MFMA kernel running the same launch (which meets the oracle in
     test_conv2d_fused_prologue_epilogue_vs_oracle; test_conv2d_winograd4_tails_vs_oracle compares one shape per tail kind with the oracle directly).
     Paddings: the kernel needs W % 4 == 0 AND OW = W + 2 pad - 2 a multiple of 4, i.e. only ODD paddings (1, 3) can run -- the pad = 2 cases
-    here assert the decline; pad 0 / 4 (the `cbase == 0` / `sh == 0` arithmetic of the kernel) is unreachable through the C ABI and untested.
+    here assert the decline; the kernels' former pad 0 / 4 staging arithmetic (unreachable through the C ABI, never exercised) is gone since round 5 and the launchers decline every even padding by name.
     pad = 3 also runs with ragged H and Cout % 64 != 0 together.  Tolerance: F(4x4)'s
     transforms cost ~4x the rounding of the direct kernel (tools/f43_error_probe.py): 1e-4 of the output scale."""
     from torch_utils.ops import conv2d_mfma

@@ -813,6 +813,67 @@ __global__ __launch_bounds__(256) void conv1x1_small_f32_kernel(const float* __r
 }
 
 
+// The same head on SMALL images (round 5).  The form above gives a thread four pixels and walks ALL input channels: on the 4^2 ... 64^2 images of the low
+// blocks (512 channels) that is one to four workgroups per image, each behind a serial LDS weight prologue (16 dependent rounds) and 64 dependent groups of
+// eight loads -- 32-47 us per launch for 0.1-67 MB, five launches per config-2 step.  Here a workgroup takes QB pixel quads of one image and its 256 / QB
+// thread columns split the channels (thread = quad q, slice cs: channels cs, cs + CS, ...; its modulated weights come straight from global memory, nothing
+// is staged), the partial sums meet in LDS and QB x COUT threads add them up, apply bias / clamp / skip and store.  Every load of the launch is in flight
+// within two rounds.
+template <int COUT, int QB>      // QB * COUT <= 256
+__global__ __launch_bounds__(256) void conv1x1_small_f32_split_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ styles,
+                                                                      const float* __restrict__ bias, const float* __restrict__ skip, float* __restrict__ y,
+                                                                      int Cin, int64_t HW4, float scale, float clamp) {
+    constexpr int CS = 256 / QB;
+    static_assert(QB * COUT <= 256, "one output thread per (quad, channel)");
+    __shared__ f32x4s part[CS][COUT][QB];
+    const int n = blockIdx.y;
+    const int q = threadIdx.x % QB, cs = threadIdx.x / QB;
+    const int64_t p = (int64_t)blockIdx.x * QB + q;
+    const bool live = p < HW4;
+    const f32x4s* xn = (const f32x4s*)x + (int64_t)n * Cin * HW4 + (live ? p : 0);
+    const float* sn = styles ? styles + (int64_t)n * Cin : nullptr;
+    f32x4s acc[COUT];
+#pragma unroll
+    for (int o = 0; o < COUT; o++) acc[o] = (f32x4s){0.f, 0.f, 0.f, 0.f};
+    for (int c0 = cs; c0 < Cin; c0 += 8 * CS) {                          // eight channel planes of this slice in flight
+        f32x4s v[8];
+        float wv[8][COUT];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int c = c0 + u * CS;
+            const bool ok = c < Cin;
+            v[u] = ok ? xn[(int64_t)c * HW4] : (f32x4s){0.f, 0.f, 0.f, 0.f};
+            const float sc = ok ? scale * (sn ? sn[c] : 1.f) : 0.f;
+#pragma unroll
+            for (int o = 0; o < COUT; o++) wv[u][o] = ok ? w[o * Cin + c] * sc : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+#pragma unroll
+            for (int o = 0; o < COUT; o++) acc[o] += v[u] * wv[u][o];
+    }
+#pragma unroll
+    for (int o = 0; o < COUT; o++) part[cs][o][q] = acc[o];
+    __syncthreads();
+    if (threadIdx.x < QB * COUT) {
+        const int oq = threadIdx.x % QB, o = threadIdx.x / QB;
+        const int64_t po = (int64_t)blockIdx.x * QB + oq;
+        f32x4s r = part[0][o][oq];
+#pragma unroll 8
+        for (int z = 1; z < CS; z++) r += part[z][o][oq];
+        r += bias ? bias[o] : 0.f;
+        const float cl = clamp >= 0.f ? clamp : __builtin_inff();
+#pragma unroll
+        for (int e = 0; e < 4; e++) r[e] = fminf(fmaxf(r[e], -cl), cl);
+        if (po < HW4) {
+            const int64_t off = ((int64_t)n * COUT + o) * HW4 + po;
+            if (skip) r += ((const f32x4s*)skip)[off];
+            ((f32x4s*)y)[off] = r;
+        }
+    }
+}
+
+
 // 3x3 convolution of a ONE-channel image (the SPADE blocks' first layer on the parsing / mask map, networks.py:1708-1712:
 // 1 -> 64 channels + ReLU): a 9-tap stencil per output channel.  A thread keeps the 3 x 6 samples its 4 adjacent pixels touch
 // in registers and walks the output channels (weights are uniform: scalar loads), one 16-byte store each -- the kernel is a
@@ -868,12 +929,28 @@ PG_EXPORT int pg_conv1x1_small(const float* x, const float* w, const float* styl
     if (Cout > 8 || HW % 4 != 0 || !pg::aligned16(x) || !pg::aligned16(y) || (skip && !pg::aligned16(skip)) || (size_t)Cin * 32 > 64 * 1024) return PG_ERR_UNSUPPORTED;
     if (N > 65535) return PG_ERR_TOO_LARGE;
     const int64_t HW4 = HW / 4;
+    hipStream_t s = (hipStream_t)stream;
+    // small images: the channel-split form wherever one workgroup per 256 quads would leave CUs idle (PG_HEAD32_SPLIT=0: never, A/B)
+    static const bool split_on = [] { const char* e = getenv("PG_HEAD32_SPLIT"); return !e || atoi(e) != 0; }();
+    // (measured at N = 8, 512 / 256 channels: 4^2 ... 16^2 32 -> 6.6 us, 32^2 34 -> 11, 64^2 47 -> 25; at 128^2, where the first form has half a workgroup per CU, it
+    // wins 27 : 41 -- hence "fewer than half the CUs")
+    if (split_on && (int64_t)N * ((HW4 + 255) / 256) < (int64_t)pg::num_cu() / 2 && Cin >= 64) {
+        int qb = 4;                                                        // the wider quad block where it still gives every CU two workgroups
+        if ((int64_t)N * ((HW4 + 15) / 16) >= 2 * (int64_t)pg::num_cu()) qb = 16;
+        const dim3 g2((unsigned)((HW4 + qb - 1) / qb), (unsigned)N);
+#define PG_SPLIT(C) case C: \
+        if (qb == 16) hipLaunchKernelGGL((conv1x1_small_f32_split_kernel<C, 16>), g2, dim3(256), 0, s, x, w, styles, bias, skip, y, Cin, HW4, scale, clamp); \
+        else hipLaunchKernelGGL((conv1x1_small_f32_split_kernel<C, 4>), g2, dim3(256), 0, s, x, w, styles, bias, skip, y, Cin, HW4, scale, clamp); \
+        break;
+        switch (Cout) { PG_SPLIT(1) PG_SPLIT(2) PG_SPLIT(3) PG_SPLIT(4) PG_SPLIT(5) PG_SPLIT(6) PG_SPLIT(7) PG_SPLIT(8) }
+#undef PG_SPLIT
+        return pg::launch_status();
+    }
     int64_t bx = (HW4 + 255) / 256;
     const int64_t cap = (int64_t)pg::num_cu() * 8 / N + 1;
     if (bx > cap) bx = cap;
     const dim3 grid((unsigned)bx, (unsigned)N);
     const size_t lds = (size_t)Cin * 32;
-    hipStream_t s = (hipStream_t)stream;
 #define PG_SMALL(C) case C: hipLaunchKernelGGL((conv1x1_small_f32_kernel<C>), grid, dim3(256), lds, s, x, w, styles, bias, skip, y, Cin, HW4, scale, clamp); break;
     switch (Cout) { PG_SMALL(1) PG_SMALL(2) PG_SMALL(3) PG_SMALL(4) PG_SMALL(5) PG_SMALL(6) PG_SMALL(7) PG_SMALL(8) }
 #undef PG_SMALL

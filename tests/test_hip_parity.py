@@ -1928,9 +1928,12 @@ def test_conv_layer_training_route_epilogue_in_the_launch(case):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('cout,cin,hw,use_styles,use_skip,clamp', [(3, 64, (32, 36), True, True, 256.0), (7, 20, (16, 8), True, False, 0.5),
-                                                                  (1, 8, (4, 4), False, False, None), (8, 130, (10, 12), True, True, None)])
+                                                                  (1, 8, (4, 4), False, False, None), (8, 130, (10, 12), True, True, None),
+                                                                  (3, 512, (8, 8), True, True, 256.0), (3, 96, (128, 128), True, True, 256.0), (7, 64, (96, 128), True, False, 2.0),
+                                                                  (3, 64, (512, 256), True, True, 256.0)])
 def test_streaming_head_fp32(cout, cin, hw, use_styles, use_skip, clamp):
-    """pg_conv1x1_small (the fp32 ToRGB / parsing heads as one streaming pass) against the same arithmetic in float64."""
+    """pg_conv1x1_small (the fp32 ToRGB / parsing heads as one streaming pass) against the same arithmetic in float64.  Images too small to give every CU a
+    workgroup (cases 1, 4-7: 4 / 4 / 4 / 16 / 16 pixel quads per workgroup) run the channel-split form of round 5, the last case and the narrow ones the first form."""
     from torch_utils.ops import conv2d_mfma
     gen = torch.Generator().manual_seed(100 * cout + cin)
     x = torch.randn([3, cin, *hw], generator=gen)

@@ -23,12 +23,14 @@ steps (Gmain: 43 M floats = 172 MB; each discriminator: 31.6 M = 126 MB):
   still pair every collective with its peer's collective of the same size.
 """
 
+import os
+
 import torch
 import torch.distributed as dist
 
 
 class GradBucket:
-    def __init__(self, params, group=None, segments=4):
+    def __init__(self, params, group=None, segments=4, gather=None):
         self.params = [p for p in params]
         assert self.params, 'empty bucket'
         self.group = group
@@ -87,6 +89,11 @@ class GradBucket:
         self.alive = torch.zeros([len(self.params)], dtype=torch.float32, device=dev)
         self._flags_host = torch.zeros([len(self.params)], dtype=torch.float32).pin_memory() if dev.type == 'cuda' else None
         self.launch_log = []                                 # (segment, 'hook' | 'finish') in issue order, per phase: tests read it
+        # `gather` (round 5; default on the GPU, PG_GRAD_GATHER=0 switches it off): .grad is None when the backward pass starts, so autograd's AccumulateGrad
+        # KEEPS the tensor the gradient kernel produced instead of adding it into a zeroed view -- one elementwise launch per parameter and backward pass, ~570
+        # launches / 4.7 ms per config-4 iteration -- and the gradients of a segment move into the flat bucket with ONE multi-tensor copy when the segment is
+        # complete (in front of its all-reduce, or in finish()); after that .grad IS the bucket view, as in the other mode
+        self.gather = (dev.type == 'cuda' and os.environ.get('PG_GRAD_GATHER', '1') != '0') if gather is None else bool(gather)
         for i, p in enumerate(self.params):
             was = p.requires_grad                            # the step freezes every module between phases; hooks need a leaf that requires grad
             p.requires_grad_(True)
@@ -96,9 +103,15 @@ class GradBucket:
     # ------------------------------------------------------------------ per-phase protocol
     def begin(self):
         """Before the phase's backward passes: zero the bucket (gradients and flags), point every .grad into it, arm the hooks."""
-        self.flat.zero_()
-        for p, v in zip(self.params, self.views):
-            p.grad = v
+        if self.gather:
+            if self.world > 1:
+                self.flat.zero_()                            # parameters without a gradient on THIS rank contribute zeros to the sum; flags; padding
+            for p in self.params:
+                p.grad = None
+        else:
+            self.flat.zero_()
+            for p, v in zip(self.params, self.views):
+                p.grad = v
         self._touched_host = [False] * len(self.params)
         self._pending = list(self.seg_members)
         self._launched = [False] * len(self.seg_range)
@@ -131,9 +144,25 @@ class GradBucket:
                 return
             self._launch(k, who)
 
+    def _gather(self, members):
+        """Move the gradients autograd left in .grad into their bucket views (one multi-tensor copy) and make the views the .grad."""
+        dst, src = [], []
+        for i in members:
+            g = self.params[i].grad
+            if g is not None and g.data_ptr() != self.views[i].data_ptr():
+                dst.append(self.views[i])
+                src.append(g if g.shape == self.views[i].shape else g.reshape(self.views[i].shape))
+        if dst:
+            torch._foreach_copy_(dst, src)
+        for i in members:
+            if self.params[i].grad is not None:
+                self.params[i].grad = self.views[i]
+
     def _launch(self, k, who):
         self._launched[k] = True
         self.launch_log.append((k, who))
+        if self.gather:
+            self._gather(self.members[k])
         a, b = self.seg_range[k]
         fa, fb = self.flag_range[k]
         seg = self.flat[a:b]
@@ -172,6 +201,8 @@ class GradBucket:
                 return True
             alive = self.flat[self._slot_index].cpu().tolist()
         else:
+            if self.gather:
+                self._gather(range(len(self.params)))
             alive = [1.0 if t else 0.0 for t in self._touched_host]
             if self.device_flags:
                 self.any_touched = any(self._touched_host)
@@ -179,9 +210,11 @@ class GradBucket:
                 self.alive.copy_(self._flags_host, non_blocking=True)       # one small H2D copy, stream-ordered in front of the optimizer pass; no sync
                 return self.any_touched
         self.any_touched = any(a > 0 for a in alive)
-        for p, a in zip(self.params, alive):
+        for p, v, a in zip(self.params, self.views, alive):
             if a == 0:
                 p.grad = None                                # no rank produced it: the optimizer must not see a zero gradient
+            elif self.gather:
+                p.grad = v                                   # (produced on another rank only: this rank's optimizer steps it too)
         return self.any_touched
 
     # ------------------------------------------------------------------ one-shot form (kept for callers that do not use the hooks)

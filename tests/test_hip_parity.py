@@ -2130,7 +2130,10 @@ def test_flat_adam_matches_torch_adam_and_skips_untouched_parameters():
             g = torch.randn(p.shape, generator=gen)
             if i == 1 and it == 1:
                 g.view(-1)[5], g.view(-1)[6], g.view(-1)[7] = float('nan'), float('inf'), float('-inf')
-            p.grad.copy_(g.to(DEV))
+            if bucket.gather:
+                p.grad = g.to(DEV)                    # (autograd's AccumulateGrad keeps the produced tensor; finish() gathers it into the bucket)
+            else:
+                p.grad.copy_(g.to(DEV))
             bucket._touched_host[i] = True            # (what the post-accumulate hook records during a backward pass)
             r.grad = torch.nan_to_num(g.to(DEV), nan=0, posinf=1e5, neginf=-1e5)
         assert bucket.finish()

@@ -66,7 +66,7 @@ def test_training_step_schedule_and_ema():
     assert step.batch_idx == 2 and all(torch.isfinite(p).all() for m in nets.values() for p in m.parameters())
 
 
-def _ddp_worker(rank, world, init_file, out_file):
+def _ddp_worker(rank, world, init_file, out_file, gather):
     sys.path.insert(0, PKG)
     from training import ddp
     torch.set_num_threads(2)
@@ -78,29 +78,34 @@ def _ddp_worker(rank, world, init_file, out_file):
     stubs.set_phase_trainable(nets, 'Dboth')
     params = list(nets['D'].parameters())
     extra = torch.nn.Parameter(torch.zeros(3))                      # a parameter that never receives a gradient
-    bucket = ddp.GradBucket([extra] + params, segments=3)           # first registered = last segment (like synthesis.b8.const): earlier segments still launch from hooks
+    bucket = ddp.GradBucket([extra] + params, segments=3, gather=gather)           # first registered = last segment (like synthesis.b8.const): earlier segments still launch from hooks
     assert len(bucket.seg_range) >= 2                               # several segments: some launch from the hooks, the rest in finish()
     bucket.begin()
-    assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(bucket.params, bucket.views))      # gradients ARE the bucket
+    if gather:
+        assert all(p.grad is None for p in bucket.params)           # autograd keeps the produced tensors; a segment is gathered into the bucket in front of its exchange
+    else:
+        assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(bucket.params, bucket.views))      # gradients ARE the bucket
     loss.on_last_backward = bucket.last_round                       # Dboth = two backward calls; only the second may exchange
     loss.accumulate_gradients(phase='Dboth', sync=True, **mine)
     launched_by_hooks = sum(1 for _, who in bucket.launch_log if who == 'hook')
     assert bucket.finish() is True
     assert extra.grad is None                                       # untouched on every rank: stays None (no zero gradient for Adam)
-    assert all(p.grad is not None for p in params)
+    assert all(p.grad is not None and p.grad.data_ptr() == bucket.views[1 + i].data_ptr() for i, p in enumerate(params))      # (either mode: .grad ends as the bucket view)
     if rank == 0:
         np.savez(out_file, launched_by_hooks=launched_by_hooks, **{f'p{i}': p.grad.numpy() for i, p in enumerate(params)})
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_flat_bucket_overlapped_exchange_two_ranks():
-    """mean over 2 ranks of per-shard gradients == gradient of the mean loss over the whole batch (the StubD has no
+@pytest.mark.parametrize('gather', [False, True], ids=['grad_views', 'gathered'])
+def test_flat_bucket_overlapped_exchange_two_ranks(gather):
+    """(`gathered`: the GPU default of round 5 -- .grad starts as None, a complete segment is copied into the bucket in one multi-tensor copy.)
+    mean over 2 ranks of per-shard gradients == gradient of the mean loss over the whole batch (the StubD has no
     cross-sample coupling), for a phase with two backward calls and a double-backward term (R1); at least one segment
     of the bucket was exchanged from the autograd hooks, i.e. while the last backward was still running."""
     with tempfile.TemporaryDirectory() as tmp:
         init_file, out_file = os.path.join(tmp, 'rdzv'), os.path.join(tmp, 'g.npz')
-        mp.spawn(_ddp_worker, args=(2, init_file, out_file), nprocs=2, join=True)
+        mp.spawn(_ddp_worker, args=(2, init_file, out_file, gather), nprocs=2, join=True)
         got = np.load(out_file)
     assert int(got['launched_by_hooks']) >= 1
     nets = stubs.build()
@@ -111,14 +116,14 @@ def test_flat_bucket_overlapped_exchange_two_ranks():
         np.testing.assert_allclose(got[f'p{i}'], p.grad.numpy(), rtol=2e-4, atol=1e-6)
 
 
-def _diverging_worker(rank, world, init_file, out_file):
+def _diverging_worker(rank, world, init_file, out_file, gather=False):
     sys.path.insert(0, PKG)
     from training import ddp
     torch.set_num_threads(2)
     dist.init_process_group('gloo', init_method=f'file://{init_file}', rank=rank, world_size=world)
     torch.manual_seed(0)
     ps = [torch.nn.Parameter(torch.randn(n)) for n in (5, 7, 3, 6, 4, 8)]
-    bucket = ddp.GradBucket(ps, segments=3)
+    bucket = ddp.GradBucket(ps, segments=3, gather=gather)
     assert len(bucket.seg_range) == 3
     logs = []
     for it in range(2):
@@ -143,13 +148,14 @@ def _diverging_worker(rank, world, init_file, out_file):
     dist.destroy_process_group()
 
 
-def test_collective_order_does_not_depend_on_which_parameters_got_gradients():
+@pytest.mark.parametrize('gather', [False, True], ids=['grad_views', 'gathered'])
+def test_collective_order_does_not_depend_on_which_parameters_got_gradients(gather):
     """ranks whose graphs differ (a parameter unused on one rank only) must still issue the same
     all-reduces in the same order -- segment 0, 1, 2 and nothing else -- and end with the right averaged gradients; a parameter
     nobody used keeps grad None.  (With the round-2 protocol this test pairs a segment all-reduce with the flags all-reduce.)"""
     with tempfile.TemporaryDirectory() as tmp:
         init_file, out_file = os.path.join(tmp, 'rdzv'), os.path.join(tmp, 'o.npz')
-        mp.spawn(_diverging_worker, args=(2, init_file, out_file), nprocs=2, join=True)
+        mp.spawn(_diverging_worker, args=(2, init_file, out_file, gather), nprocs=2, join=True)
         assert np.load(out_file)['hook0'].tolist() == [2, 0]            # rank 0: segments 0, 1 from hooks in iteration 0 (ps[0] unused -> segment 2 in finish); iteration 1: ps[5] unused -> none
 
 

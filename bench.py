@@ -436,20 +436,42 @@ def run_train(args, rank, world, dev, dist):
     if wtl:
         # largest single kernel of the step: the fp32 weight gradient of the stride-1 3x3 layers (csrc/conv2d_wgrad.hip: a GEMM over pixels on the fp32
         # MFMA + its fixed-order split-K reduction, both inside the event pair); flops = the forward count of SURVEY 8d for the same layer
-        dom = [(fl, e0.elapsed_time(e1) * 1e-3, by) for geo, fl, e0, e1, by in wtl if geo[:3] == (3, 3, 1)]
+        dom = [(fl, e0.elapsed_time(e1) * 1e-3, by) for geo, fl, e0, e1, by in wtl if geo[:4] == (3, 3, 1, 'wgrad')]
+        # round 5: the 3x3 layers with >= 64 channels take the bf16 matrix pipe (three-term operand split, six products, fp32 accumulation: conv2d_mfma.
+        # _weight_gradient_bf16x3); event pairs span the two splitting passes, the 6N-image launch of conv2d16_wgrad and its reduction
+        x3 = [(fl, e0.elapsed_time(e1) * 1e-3, by) for geo, fl, e0, e1, by in wtl if geo[3] == 'wgrad_bf16x3']
+        allw = sum(e0.elapsed_time(e1) * 1e-3 for _, _, e0, e1, _ in wtl)
+        fp32_part = x3_part = None
         if dom:
             fl, tm = sum(d[0] for d in dom), sum(d[1] for d in dom)
-            allw = sum(e0.elapsed_time(e1) * 1e-3 for _, _, e0, e1, _ in wtl)
-            roofline = dict(bound='mfma', kernel='conv2d_wgrad<3,3,1> + wgrad_reduce (fp32 weight gradient of the stride-1 3x3 layers, v_mfma_f32_32x32x2_f32)',
-                            achieved=round(fl / tm / 1e12, 2), peak=F32_MFMA_PEAK_TFLOPS, unit='TFLOP/s', frac=round(fl / tm / 1e12 / F32_MFMA_PEAK_TFLOPS, 4), traffic=None,
-                            launches_per_step=round(len(dom) / args.steps, 1), avg_launch_ms=round(1e3 * tm / len(dom), 4), time_frac_of_step=round(tm / elapsed, 4),
-                            algorithmic_bytes_per_launch=round(sum(d[2] for d in dom) / len(dom)), all_native_wgrad_time_frac_of_step=round(allw / elapsed, 4))
+            fp32_part = dict(bound='mfma', kernel='conv2d_wgrad<3,3,1> + wgrad_reduce (fp32 weight gradient of the stride-1 3x3 layers, v_mfma_f32_32x32x2_f32)',
+                             achieved=round(fl / tm / 1e12, 2), peak=F32_MFMA_PEAK_TFLOPS, unit='TFLOP/s', frac=round(fl / tm / 1e12 / F32_MFMA_PEAK_TFLOPS, 4), traffic=None,
+                             launches_per_step=round(len(dom) / args.steps, 1), avg_launch_ms=round(1e3 * tm / len(dom), 4), time_frac_of_step=round(tm / elapsed, 4),
+                             algorithmic_bytes_per_launch=round(sum(d[2] for d in dom) / len(dom)))
+        if x3:
+            fl3, tm3 = sum(d[0] for d in x3), sum(d[1] for d in x3)
+            x3_part = dict(bound='mfma', kernel='conv2d16_wgrad<3,3,s,bf16> over the six products of three-term operand splits (+ pg_split3_bf16_cl x 2 and wgrad_reduce inside each event pair): '
+                                                'the float32 weight gradients of the 3x3 layers with >= 64 channels, fp32 accumulation; PG_WGRAD_BF16X3=0 sends them to conv2d_wgrad<3,3,s>',
+                           achieved=round(6 * fl3 / tm3 / 1e12, 1), peak=BF16_MFMA_PEAK_TFLOPS, unit='TFLOP/s', frac=round(6 * fl3 / tm3 / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4), traffic=None,
+                           flops_counted='executed on the bf16 matrix pipe = 6 x the forward count of SURVEY 8d', fp32_equivalent_tflops=round(fl3 / tm3 / 1e12, 2),
+                           fp32_equivalent_frac_of_fp32_peak=round(fl3 / tm3 / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
+                           launches_per_step=round(len(x3) / args.steps, 1), avg_launch_ms=round(1e3 * tm3 / len(x3), 4), time_frac_of_step=round(tm3 / elapsed, 4),
+                           algorithmic_bytes_per_launch=round(sum(d[2] for d in x3) / len(x3)))
+        # the object describes the group the step spends more time in; the other one rides along under its own key
+        if x3_part and (not fp32_part or x3_part['time_frac_of_step'] >= fp32_part['time_frac_of_step']):
+            roofline = dict(x3_part, **(dict(fp32_weight_gradients=fp32_part) if fp32_part else {}))
+        elif fp32_part:
+            roofline = dict(fp32_part, **(dict(bf16x3_weight_gradients=x3_part) if x3_part else {}))
+        if roofline:
+            roofline['all_native_wgrad_time_frac_of_step'] = round(allw / elapsed, 4)
     if rank == 0:
         print(json.dumps(dict(metric='fullbody G+D training iterations/sec (8-phase step incl. lazy R1)', value=round(args.steps / elapsed, 4), unit='it/s',
                               n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(1e3 * elapsed / args.steps, 1), higher_is_better=True,
                               scaling='weak', vs_baseline=None, dtype='f32', data='synthetic', images_per_sec=round(args.steps * n * world / elapsed, 3),
                               config=dict(workload='BASELINE config 4: fullbody G+D step, lazy R1 (gamma 10), L1 + parsing CE, no VGG; ' + (f'discriminators fp16 at their {args.d_fp16_res} highest resolutions (train.py:196)' if args.d_fp16_res else 'discriminators in fp32'),
                                           batch_per_gpu=n, global_batch=n * world, parallelism=f'dp{world}, one flat fp32 gradient bucket per phase, segment all_reduce (RCCL) launched from autograd hooks on a side stream',
+                                          weight_gradients=('float32; 3x3 layers with >= 64 channels as six bf16 x bf16 products of exact three-term operand splits with fp32 accumulation (fp32-class: tests/test_hip_parity.py::test_weight_gradient_bf16x3), the rest on the fp32 MFMA'
+                                                            if os.environ.get('PG_WGRAD_BF16X3', 'auto') != '0' else 'float32 on the fp32 MFMA (PG_WGRAD_BF16X3=0)'),
                                           first_batch_idx=0, note='steps start at batch_idx = warmup; reg phases fire every 4th (G) / 16th (D) iteration',
                                           execution=(f'one hipGraph replay per phase once captured (captured so far: {step.graphed_phases()}); a phase runs eagerly the first time it is due and is captured the second time' if step.graphs else 'eager launches')),
                               **(dict(roofline=roofline) if roofline else {}))), flush=True)

@@ -6,8 +6,8 @@
  *   bias_act_plugin.so      pg_bias_act
  *   upfirdn2d_plugin.so     pg_upfirdn2d, pg_upfirdn2d_bias_act
  *   conv2d_plugin.so        fp32: pg_conv2d_{packed_size,pack_weight,forward,splitk_plan,forward_splitk}, pg_conv2d_winograd_*,
- *                           pg_conv2d_up2_forward, pg_conv1x1_small, pg_conv3x3_cin1, pg_conv2d_wgrad{_plan,};
- *                           16-bit: pg_conv2d16_{packed_size,pack_weight,pack_weight_grouped,forward,splitk_plan,forward_splitk,up2_fused}, pg_adam_flat_{chunk,step},
+ *                           pg_conv2d_up2_{forward,splitk_plan,forward_splitk}, pg_conv1x1_small, pg_conv3x3_cin1, pg_conv2d_wgrad{_plan,}, pg_split3_bf16_cl;
+ *                           16-bit: pg_conv2d16_{packed_size,pack_weight,pack_weight_grouped,forward,splitk_plan,forward_splitk,up2_fused,wgrad,wgrad_plan,wgrad_x3}, pg_adam_flat_{chunk,step},
  *                           pg_conv1x1_small16;  glue: pg_modconv_{dcoefs,w2,prep}, pg_instance_norm_stats, pg_spade_*
  *   patch_routing_plugin.so pg_warp_perspective_u8, pg_patch_compose_u8
  * plus pg_<plugin>_abi_version() in each.  They are what the reference's L1
@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 10
+#define PG_ABI_VERSION 11
 
 enum pg_dtype { PG_F32 = 0, PG_F16 = 1, PG_BF16 = 2, PG_F64 = 3 };
 
@@ -291,6 +291,13 @@ int pg_modconv_prep_batched(const pg_modconv_prep_jobs* jobs, int N, void* strea
  * in_scale / out_scale may be NULL. */
 int pg_conv2d_up2_forward(const float* x, const float* packed, float* y, int N, int Cin, int H, int W, int Cout,
                           const int64_t ystride[4], const float* in_scale, const float* out_scale, void* stream);
+/* Split-K form (ABI 11) for the low-resolution layers, whose few tiles would each walk all K chunks serially: `pg_conv2d_up2_splitk_plan` = the share
+ * count the launch wants (1: call pg_conv2d_up2_forward).  Every tile then exists `ksplit` times, share z reduces its part of the input channels into slice z of
+ * `workspace` (ksplit * N * ystride[0] floats, 16-byte aligned, laid out like y: y must be dense over n and N * ystride[0] % 4 == 0), and one pass adds the
+ * slices into y in a fixed order. */
+int pg_conv2d_up2_splitk_plan(int N, int Cin, int H, int W, int Cout);
+int pg_conv2d_up2_forward_splitk(const float* x, const float* packed, float* y, int N, int Cin, int H, int W, int Cout,
+                                 const int64_t ystride[4], const float* in_scale, const float* out_scale, float* workspace, int ksplit, void* stream);
 
 /* Streaming 1x1 convolution with few output channels (Cout <= 8; the ToRGB / parsing heads, networks.py:287-316,
  * modulated_conv2d with demodulate=False at networks.py:37-94): float32 NCHW, HW % 4 == 0, 16-byte aligned tensors:
@@ -360,6 +367,17 @@ int pg_conv2d16_wgrad_plan(int N, int Cin, int OH, int OW, int Cout, int KH, int
 int pg_conv2d16_wgrad(const void* x, const void* dy, float* dw, float* workspace, int dtype,
                       int N, int Cin, int H, int W, int Cout, int KH, int KW, int stride, int pad_y, int pad_x, int OH, int OW,
                       int splits, void* stream);
+
+/* (ABI 11, exploratory: PG_WGRAD_BF16X3) The FLOAT32 weight gradient of pg_conv2d_wgrad on the bf16 matrix pipe by three-term operand splitting: every float32
+ * value is the exact sum of three bf16 values (truncation), and of the nine partial products the six largest are accumulated in float32 -- float32-class results
+ * (measured 1.3e-6 ... 2.8e-6 of max|dw| against float64; the fp32 MFMA kernel 1.0e-6 ... 1.7e-6), exact on integer data below 2^24 like the fp32 kernel.
+ *   pg_split3_bf16_cl: float32 NCHW x [N, C, HW] -> out = three bf16 channels-last planes [3][N][HW][C], x == plane 0 + plane 1 + plane 2.  C % 8 == 0.
+ *   pg_conv2d16_wgrad_x3: dw [Cout, Cin, KH, KW] from x3 = split(x), dy3 = split(dy): ONE launch of the 16-bit kernel over 6 N plane-mapped "images" (the six
+ *   products share its float32 accumulation and fixed-order split reduction).  splits = pg_conv2d16_wgrad_plan(6 * N, ...); workspace as pg_conv2d16_wgrad. */
+int pg_split3_bf16_cl(const float* x, void* out, int N, int C, int64_t HW, void* stream);
+int pg_conv2d16_wgrad_x3(const void* x3, const void* dy3, float* dw, float* workspace,
+                         int N, int Cin, int H, int W, int Cout, int KH, int KW, int stride, int pad_y, int pad_x, int OH, int OW,
+                         int splits, void* stream);
 
 /* ------------------------------------------------------------------------
  * 16-bit convolution (bf16 / fp16 storage, fp32 accumulation) on v_mfma_f32_32x32x16_{bf16,f16}: what cuDNN does behind

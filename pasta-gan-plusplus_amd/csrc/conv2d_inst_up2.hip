@@ -6,8 +6,8 @@
  * modulation / demodulation of networks.py:73-94 around it.  `packed` = pg_conv2d_pack_weight of the OIHW kernel w (3x3).
  * y is [N, Cout, 2H+1, 2W+1] with strides ystride (elements); an even row pitch gives 8-byte stores.  Every element of y is written
  * (the last column ox = 2W by the edge tiles of the same launch, conv2d_up2.h). */
-PG_EXPORT int pg_conv2d_up2_forward(const float* x, const float* packed, float* y, int N, int Cin, int H, int W, int Cout,
-                                    const int64_t ystride[4], const float* in_scale, const float* out_scale, void* stream) {
+static int up2_forward(const float* x, const float* packed, float* y, int N, int Cin, int H, int W, int Cout,
+                       const int64_t ystride[4], const float* in_scale, const float* out_scale, float* workspace, int ksplit, void* stream) {
     if (!x || !packed || !y || !ystride || N <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return PG_ERR_INVALID_ARG;
     if ((((uintptr_t)x) & 3) != 0 || (((uintptr_t)packed) & 15) != 0) return PG_ERR_INVALID_ARG;
     if ((int64_t)Cin * H * W * 4 > 0x7fffffffLL) return PG_ERR_TOO_LARGE;             // one image through a 32-bit buffer descriptor
@@ -15,5 +15,34 @@ PG_EXPORT int pg_conv2d_up2_forward(const float* x, const float* packed, float* 
     p.x = x; p.wp = packed; p.y = y; p.in_scale = in_scale; p.out_scale = out_scale;
     p.N = N; p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout; p.CoutP = (Cout + 31) / 32 * 32;
     for (int i = 0; i < 4; i++) p.ys[i] = ystride[i];
-    return pgconv::launch_up2(p, (hipStream_t)stream);
+    p.ksplit = 1; p.cpk = 0; p.ws_slice = 0;
+    if (ksplit <= 1) return pgconv::launch_up2(p, (hipStream_t)stream);
+    // split-K: the shares write slices laid out like y (one slice = N * ystride[0] floats: y dense over n), then one pass adds them into y
+    const int64_t slice = (int64_t)N * ystride[0];
+    if (!workspace || slice % 4 != 0 || (((uintptr_t)workspace) & 15) != 0 || (((uintptr_t)y) & 15) != 0) return PG_ERR_INVALID_ARG;
+    p.y = workspace; p.ksplit = ksplit; p.ws_slice = slice;
+    const int st = pgconv::launch_up2(p, (hipStream_t)stream);
+    if (st != PG_OK) return st;
+    int64_t blocks = (slice / 4 + 255) / 256;
+    if (blocks > (int64_t)pg::max_stream_blocks()) blocks = pg::max_stream_blocks();
+    hipLaunchKernelGGL(pgconv::up2_sum_slices, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, workspace, y, ksplit, slice / 4);
+    return pg::launch_status();
+}
+
+PG_EXPORT int pg_conv2d_up2_forward(const float* x, const float* packed, float* y, int N, int Cin, int H, int W, int Cout,
+                                    const int64_t ystride[4], const float* in_scale, const float* out_scale, void* stream) {
+    return up2_forward(x, packed, y, N, Cin, H, W, Cout, ystride, in_scale, out_scale, nullptr, 1, stream);
+}
+
+/* Split-K form for the low-resolution layers: pg_conv2d_up2_splitk_plan = the share count the launch wants (1 = use pg_conv2d_up2_forward);
+ * `workspace` = ksplit * N * ystride[0] floats (16-byte aligned; y must be dense over n with N * ystride[0] % 4 == 0, as conv_up2_forward allocates it). */
+PG_EXPORT int pg_conv2d_up2_splitk_plan(int N, int Cin, int H, int W, int Cout) {
+    if (N <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return 1;
+    return pgconv::up2_splitk_plan(N, Cin, H, W, Cout);
+}
+
+PG_EXPORT int pg_conv2d_up2_forward_splitk(const float* x, const float* packed, float* y, int N, int Cin, int H, int W, int Cout,
+                                           const int64_t ystride[4], const float* in_scale, const float* out_scale, float* workspace, int ksplit, void* stream) {
+    if (ksplit < 1) return PG_ERR_INVALID_ARG;
+    return up2_forward(x, packed, y, N, Cin, H, W, Cout, ystride, in_scale, out_scale, workspace, ksplit, stream);
 }

@@ -55,6 +55,10 @@ struct Up2Params {
     int64_t ys[4];
     int tilesX, tilesY, mblocks, total_tiles;
     int etilesY, edge_tiles;                    // edge tiles of the last output column: N x etilesY x mblocks
+    // split-K (round 5; the 8^2 / 16^2 layers: 128 / 256 tiles of 64 serial K chunks each): every tile (edge tiles too) exists `ksplit` times, share z reduces the
+    // chunks [z * cpk, (z + 1) * cpk) into slice z of the workspace (y + z * ws_slice, laid out like y); up2_sum_slices adds the slices up.  ksplit = 1: y itself.
+    int ksplit, cpk;
+    int64_t ws_slice;
 };
 constexpr int U_EQ = 256, U_EPLANE = U_EQ + 1;  // positions per edge tile; staged samples per channel (rows q0-1 .. q0+255 of column W-1)
 
@@ -76,7 +80,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_up2(Up2Params p) {
     const int total = p.total_tiles;
     const int q8 = total >> 3, r8 = total & 7;
 
-    int n = 0, q0 = 0, r0 = 0, m0 = 0;
+    int n = 0, q0 = 0, r0 = 0, m0 = 0, kz = 0, zz = 0;      // kz: first chunk of this share, zz: its workspace slice
     unsigned xoff[U_XPT];
     i32x4 xrsrc;
     bool halo_vec = false;                       // VEC: false during the edge pass (its column staging stays on the four-byte path)
@@ -84,6 +88,8 @@ __global__ __launch_bounds__(256, 2) void conv2d_up2(Up2Params p) {
     auto prep_tile = [&](int tile, float* cs) {
         const int xcd = tile & 7;
         int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (tile >> 3);
+        zz = L % p.ksplit; L /= p.ksplit;
+        kz = zz * p.cpk;
         const int mb = L % p.mblocks; L /= p.mblocks;
         const int tx = L % p.tilesX; L /= p.tilesX;
         const int ty = L % p.tilesY;
@@ -146,6 +152,8 @@ __global__ __launch_bounds__(256, 2) void conv2d_up2(Up2Params p) {
     static_assert(U_KC * U_EPLANE <= U_XPT * 256, "edge column larger than the staging buffer");
     for (int et = (int)gridDim.x - 1 - (int)blockIdx.x; et < p.edge_tiles; et += gridDim.x) {
         int L = et;
+        const int ez = L % p.ksplit; L /= p.ksplit;
+        const int ekz = ez * p.cpk;
         const int mb = L % p.mblocks; L /= p.mblocks;
         const int ty = L % p.etilesY;
         n = L / p.etilesY; q0 = ty * U_EQ; m0 = mb * U_BM;
@@ -167,7 +175,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_up2(Up2Params p) {
         xrsrc[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(base >> 32) & 0xffff);
         xrsrc[2] = p.Cin * HW * 4;
         xrsrc[3] = 0x00020000;
-        issue_chunk(0, 0);
+        issue_chunk(ekz * U_KC, 0);
         f32x16 ea[2][2];                             // [output row parity a][position row of the wave]
 #pragma unroll
         for (int a = 0; a < 2; a++)
@@ -175,17 +183,17 @@ __global__ __launch_bounds__(256, 2) void conv2d_up2(Up2Params p) {
             for (int nt = 0; nt < 2; nt++)
 #pragma unroll
                 for (int k = 0; k < 16; k++) ea[a][nt][k] = 0.f;
-        for (int k = 0; k < nchunks; k++) {
+        for (int k = 0; k < p.cpk; k++) {
             const int buf = k & 1;
             dma_wait_all();
             __syncthreads();
-            if (k + 1 < nchunks) issue_chunk((k + 1) * U_KC, buf ^ 1);
+            if (k + 1 < p.cpk) issue_chunk((ekz + k + 1) * U_KC, buf ^ 1);
 #pragma unroll
             for (int cp = 0; cp < U_KC / 2; cp++) {
                 const float* ab = smem + buf * U_LDS_BUF + U_LDS_X + ((2 * cp + half) * 9) * U_BM + l31;
                 const float* bb = smem + buf * U_LDS_BUF + (2 * cp + half) * U_EPLANE + (2 * wave) * 32 + l31;
                 const float a2 = ab[2 * U_BM], a5 = ab[5 * U_BM], a8 = ab[8 * U_BM];
-                const float sc = MOD ? cs0[k * U_KC + 2 * cp + half] : 1.f;
+                const float sc = MOD ? cs0[(ekz + k) * U_KC + 2 * cp + half] : 1.f;
 #pragma unroll
                 for (int nt = 0; nt < 2; nt++) {
                     const float xm = MOD ? bb[nt * 32] * sc : bb[nt * 32], x0 = MOD ? bb[nt * 32 + 1] * sc : bb[nt * 32 + 1];      // x[q - 1, W - 1], x[q, W - 1]
@@ -207,7 +215,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_up2(Up2Params p) {
                     const int rowc = (k & 3) + 8 * (k >> 2) + 4 * half;
                     const int co = m0 + rowc;
                     if (row_ok && co < p.Cout)
-                        p.y[(int64_t)n * p.ys[0] + (int64_t)co * p.ys[1] + (int64_t)(2 * q + a) * p.ys[2] + (int64_t)(2 * p.W) * p.ys[3]] = ea[a][nt][k] * ep0[rowc];
+                        p.y[(int64_t)ez * p.ws_slice + (int64_t)n * p.ys[0] + (int64_t)co * p.ys[1] + (int64_t)(2 * q + a) * p.ys[2] + (int64_t)(2 * p.W) * p.ys[3]] = ea[a][nt][k] * ep0[rowc];
                 }
             }
         }
@@ -252,7 +260,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_up2(Up2Params p) {
 
     int tile = blockIdx.x, par = 0, g = 0;
     prep_tile(tile, cs0);
-    issue_chunk(0, 0);
+    issue_chunk(kz * U_KC, 0);
     dma_wait_all();
     __syncthreads();
     while (true) {
@@ -263,14 +271,15 @@ __global__ __launch_bounds__(256, 2) void conv2d_up2(Up2Params p) {
 #pragma unroll
                 for (int k = 0; k < 16; k++) acc[ph][nt][k] = 0.f;
         int e_n = n, e_q0 = q0, e_r0 = r0, e_m0 = m0;
+        const int kz_cur = kz, z_cur = zz;           // (prep_tile of the NEXT tile overwrites kz / zz during this tile's last chunk)
         bool has_next = false;
         int next = tile;
         const float* cs_cur = cs0 + par * cin_loop;
         float* ep_scale = ep0 + par * U_BM;
-        for (int k = 0; k < nchunks; k++, g++) {
+        for (int k = 0; k < p.cpk; k++, g++) {
             const int buf = g & 1;
-            if (k + 1 < nchunks) {
-                issue_chunk((k + 1) * U_KC, buf ^ 1);
+            if (k + 1 < p.cpk) {
+                issue_chunk((kz_cur + k + 1) * U_KC, buf ^ 1);
             } else {
                 e_n = n; e_q0 = q0; e_r0 = r0; e_m0 = m0;
                 if (t < U_BM) {
@@ -281,14 +290,14 @@ __global__ __launch_bounds__(256, 2) void conv2d_up2(Up2Params p) {
                 has_next = next < total;
                 if (has_next) {
                     prep_tile(next, cs0 + (par ^ 1) * cin_loop);
-                    issue_chunk(0, buf ^ 1);
+                    issue_chunk(kz * U_KC, buf ^ 1);
                 }
             }
             Ops cur, nxt;
-            fetch(buf, cs_cur, k * U_KC, 0, cur);
+            fetch(buf, cs_cur, (kz_cur + k) * U_KC, 0, cur);
 #pragma unroll
             for (int cp = 0; cp < U_KC / 2; cp++) {
-                if (cp + 1 < U_KC / 2) fetch(buf, cs_cur, k * U_KC, cp + 1, nxt);
+                if (cp + 1 < U_KC / 2) fetch(buf, cs_cur, (kz_cur + k) * U_KC, cp + 1, nxt);
                 __builtin_amdgcn_sched_barrier(0);
                 mma(cur);
                 __builtin_amdgcn_sched_barrier(0);
@@ -317,7 +326,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_up2(Up2Params p) {
                     const float sc = ep_scale[rowc];
                     const float v0 = acc[2 * a][nt][k] * sc, v1 = acc[2 * a + 1][nt][k] * sc;
                     if (co < p.Cout) {
-                        float* dst = p.y + (int64_t)e_n * p.ys[0] + (int64_t)co * p.ys[1] + (int64_t)oy * p.ys[2] + (int64_t)(2 * r) * p.ys[3];
+                        float* dst = p.y + (int64_t)z_cur * p.ws_slice + (int64_t)e_n * p.ys[0] + (int64_t)co * p.ys[1] + (int64_t)oy * p.ys[2] + (int64_t)(2 * r) * p.ys[3];
                         if (pair_ok && ok1) {
                             *(f32x2s*)dst = (f32x2s){v0, v1};
                         } else {
@@ -341,9 +350,12 @@ int launch_up2_t(const Up2Params& p0, hipStream_t s) {
     p.tilesX = (p.W + TRW - 1) / TRW;
     p.tilesY = (p.H + 1 + G::TQ - 1) / G::TQ;
     p.mblocks = p.CoutP / U_BM;
-    const int64_t tiles = (int64_t)p.N * p.tilesX * p.tilesY * p.mblocks;
+    const int cin_chunks = (p.Cin + U_KC - 1) / U_KC;
+    if (p.ksplit < 1 || cin_chunks % p.ksplit != 0) return PG_ERR_INVALID_ARG;
+    p.cpk = cin_chunks / p.ksplit;
+    const int64_t tiles = (int64_t)p.N * p.tilesX * p.tilesY * p.mblocks * p.ksplit;
     p.etilesY = (p.H + 1 + U_EQ - 1) / U_EQ;
-    const int64_t etiles = (int64_t)p.N * p.etilesY * p.mblocks;
+    const int64_t etiles = (int64_t)p.N * p.etilesY * p.mblocks * p.ksplit;
     if (tiles + etiles > 0x7fffffffLL) return PG_ERR_TOO_LARGE;
     p.total_tiles = (int)tiles;
     p.edge_tiles = (int)etiles;
@@ -365,6 +377,34 @@ int launch_up2_t(const Up2Params& p0, hipStream_t s) {
         hipLaunchKernelGGL((conv2d_up2<false, TRW, VEC>), dim3((unsigned)blocks), dim3(256), lds, s, p);
     }
     return launch_status();
+}
+
+// Tiles of the main stream for a launch (what launch_up2 dispatches), for the split-K plan.
+inline int64_t up2_tiles(int N, int H, int W, int Cout) {
+    const int trw = W > 16 ? 32 : (W > 8 ? 16 : 8), tq = 8 * (32 / trw);
+    return (int64_t)N * ((W + trw - 1) / trw) * ((H + 1 + tq - 1) / tq) * ((Cout + U_BM - 1) / U_BM);
+}
+
+// The largest share count in {1, 2, 4, 8} that divides the K chunks, leaves >= 8 chunks per share and does not overfill the chip (two workgroups per CU): the
+// layers whose tiles do not fill the chip -- 8^2 at N = 8: 128 tiles x 64 serial chunks of ~2.8 us, 202 -> 133 us with four shares.  PG_UP2_SPLITK=0: never (A/B).
+inline int up2_splitk_plan(int N, int Cin, int H, int W, int Cout) {
+    static const bool on = [] { const char* e = getenv("PG_UP2_SPLITK"); return !e || atoi(e) != 0; }();
+    if (!on) return 1;
+    const int chunks = (Cin + U_KC - 1) / U_KC;
+    const int64_t tiles = up2_tiles(N, H, W, Cout);
+    int best = 1;
+    for (int k = 2; k <= 8; k *= 2)
+        if (chunks % k == 0 && chunks / k >= 8 && tiles < (int64_t)num_cu() && tiles * k <= 2 * (int64_t)num_cu()) best = k;      // (tiles >= CUs: 16^2 at N = 8 measured 222 -> 232 us with two shares)
+    return best;
+}
+
+__global__ __launch_bounds__(256) void up2_sum_slices(const float* __restrict__ ws, float* __restrict__ y, int ksplit, int64_t slice4) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < slice4; i += (int64_t)gridDim.x * 256) {
+        f4 v = ((const f4*)ws)[i];
+        for (int z = 1; z < ksplit; z++) v += ((const f4*)ws)[(int64_t)z * slice4 + i];      // fixed order: deterministic
+        ((f4*)y)[i] = v;
+    }
 }
 
 inline int launch_up2(const Up2Params& p, hipStream_t s) {

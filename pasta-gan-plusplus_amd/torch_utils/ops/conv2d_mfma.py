@@ -140,6 +140,16 @@ def _init(plugin_name='conv2d_plugin'):
         lib.pg_conv2d_wgrad.argtypes = [vp, vp, vp, vp] + [i] * 13 + [vp]
         lib.pg_conv2d_up2_forward.restype = i
         lib.pg_conv2d_up2_forward.argtypes = [vp, vp, vp, i, i, i, i, i, ctypes.POINTER(ctypes.c_int64), vp, vp, vp]
+        lib.pg_split3_bf16_cl.restype = i
+        lib.pg_split3_bf16_cl.argtypes = [vp, vp, i, i, i64, vp]
+        lib.pg_conv2d16_wgrad_x3.restype = i
+        lib.pg_conv2d16_wgrad_x3.argtypes = [vp, vp, vp, vp] + [i] * 13 + [vp]
+        lib.pg_conv2d16_wgrad_plan.restype = i
+        lib.pg_conv2d16_wgrad_plan.argtypes = [i] * 8
+        lib.pg_conv2d_up2_splitk_plan.restype = i
+        lib.pg_conv2d_up2_splitk_plan.argtypes = [i, i, i, i, i]
+        lib.pg_conv2d_up2_forward_splitk.restype = i
+        lib.pg_conv2d_up2_forward_splitk.argtypes = [vp, vp, vp, i, i, i, i, i, ctypes.POINTER(ctypes.c_int64), vp, vp, vp, i, vp]
         lib.pg_conv3x3_cin1.restype = i
         lib.pg_conv3x3_cin1.argtypes = [vp, vp, vp, i, i, i, i, f, i, vp]
         lib.pg_conv1x1_small.restype = i
@@ -451,6 +461,54 @@ def weight_gradient_supported(n, cin, oh, ow, cout, kh, kw, stride=1):
     return _init().lib.pg_conv2d_wgrad_plan(int(n), int(cin), int(oh), int(ow), int(cout), int(kh), int(kw), int(stride)) > 0
 
 
+def _bf16x3_wanted(n, cin, cout, h, w, kh, kw, stride):
+    """Which float32 weight gradients run on the bf16 matrix pipe by three-term operand splitting (round 5; `_weight_gradient_bf16x3`).
+    PG_WGRAD_BF16X3: auto (default) = the 3x3 layers (stride 1 | 2) with at least PG_WGRAD_BF16X3_MIN_C (64) channels on both sides -- where the probe and the
+    training step measured it faster (tools/wgrad_bf16x3_probe.py: 0.52 ... 0.82 of the fp32 kernel's time at N = 4; config 4 258.6 -> 247-248 ms per
+    iteration; the 1x1 layers and narrower 3x3 layers lose: the splitting passes cost 10 bytes per operand element); 0 = the fp32 MFMA kernel everywhere;
+    1 = wherever the 16-bit kernel covers the geometry (3x3 stride 1 | 2, 1x1; channel counts multiples of 8)."""
+    mode = os.environ.get('PG_WGRAD_BF16X3', 'auto')
+    if mode == '0' or kh != kw or (kh, stride) not in ((3, 1), (3, 2), (1, 1)) or cin % 8 or cout % 8:
+        return False
+    if mode == 'auto':
+        return kh == 3 and min(cin, cout) >= int(os.environ.get('PG_WGRAD_BF16X3_MIN_C', '64'))
+    return True
+
+
+def _weight_gradient_bf16x3(lib, x, dy, weight_shape, pad, stride, out_hw):
+    """float32 dw on the bf16 matrix pipe: x = x1 + x2 + x3, dy = d1 + d2 + d3 (bf16 terms, exact), the six largest products in one launch of the 16-bit
+    weight-gradient kernel over 6 N plane-mapped images, float32 accumulation (csrc/conv2d_wgrad.hip, pg_split3_bf16_cl + pg_conv2d16_wgrad_x3)."""
+    cout, cin, kh, kw = weight_shape
+    n, _, h, w = x.shape
+    oh, ow = out_hw
+    splits = lib.pg_conv2d16_wgrad_plan(6 * n, cin, oh, ow, cout, kh, kw, stride)
+    if splits <= 0:
+        return None
+    x, dy = x.contiguous(), dy.contiguous()
+    x3 = torch.empty([3, n, h, w, cin], dtype=torch.bfloat16, device=x.device)
+    d3 = torch.empty([3, n, oh, ow, cout], dtype=torch.bfloat16, device=x.device)
+    dw = torch.empty([cout, cin, kh, kw], dtype=torch.float32, device=x.device)
+    ws = torch.empty([splits * kh * kw * cout * cin], dtype=torch.float32, device=x.device)
+    tl = _wgrad_timeline
+    with torch.cuda.device(x.device):
+        if tl is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+        st = lib.pg_split3_bf16_cl(nat.ptr(x), nat.ptr(x3), n, cin, h * w, nat.stream_of(x))
+        if st == 0:
+            st = lib.pg_split3_bf16_cl(nat.ptr(dy), nat.ptr(d3), n, cout, oh * ow, nat.stream_of(x))
+        if st == 0:
+            st = lib.pg_conv2d16_wgrad_x3(nat.ptr(x3), nat.ptr(d3), nat.ptr(dw), nat.ptr(ws), n, cin, h, w, cout, kh, kw, stride, int(pad[0]), int(pad[1]), oh, ow, splits,
+                                          nat.stream_of(x))
+        if tl is not None:
+            ev1.record()
+            tl.append(((kh, kw, stride, 'wgrad_bf16x3', f'N{n} {cin}->{cout} {h}x{w}'), 2.0 * n * cout * oh * ow * cin * kh * kw, ev0, ev1, 4 * (x.numel() + dy.numel() + dw.numel())))
+    if st == -2:
+        return None
+    nat.check(st, 'pg_conv2d16_wgrad_x3')
+    return dw
+
+
 def weight_gradient(x, dy, weight_shape, pad, stride=1):
     """d(loss)/d(weight) of y = conv2d(x, w, stride, padding=pad) for 3x3 (stride 1 | 2) / 1x1 (stride 1) kernels: a GEMM over pixels
     on the fp32 MFMA (csrc/conv2d_wgrad.hip).  Returns None when the geometry is not covered (callers then ask aten)."""
@@ -461,6 +519,10 @@ def weight_gradient(x, dy, weight_shape, pad, stride=1):
     stride = int(stride)
     if x.dtype != torch.float32 or dy.dtype != torch.float32 or min(pad) < 0 or (oh, ow) != ((h + 2 * pad[0] - kh) // stride + 1, (w + 2 * pad[1] - kw) // stride + 1):
         return None
+    if _bf16x3_wanted(n, cin, cout, h, w, kh, kw, stride):
+        dw = _weight_gradient_bf16x3(lib, x, dy, (cout, cin, kh, kw), pad, stride, (oh, ow))
+        if dw is not None:
+            return dw
     splits = lib.pg_conv2d_wgrad_plan(n, cin, oh, ow, cout, kh, kw, stride)
     if splits <= 0:
         return None
@@ -507,8 +569,14 @@ def conv_up2_forward(x, packs, cout, in_scale=None, out_scale=None):
         if tl is not None:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
-        st = lib.pg_conv2d_up2_forward(nat.ptr(x), nat.ptr(packs['main']), nat.ptr(y), n, cin, h, w, cout, nat.i64arr(y.stride()), nat.ptr(s_in), nat.ptr(s_out),
-                                       nat.stream_of(x))
+        ksplit = lib.pg_conv2d_up2_splitk_plan(n, cin, h, w, cout)        # the 8^2 / 16^2 layers: shares of the input channels side by side, one summing pass
+        if ksplit > 1:
+            ws = torch.empty([ksplit * buf.numel()], dtype=torch.float32, device=x.device)
+            st = lib.pg_conv2d_up2_forward_splitk(nat.ptr(x), nat.ptr(packs['main']), nat.ptr(y), n, cin, h, w, cout, nat.i64arr(y.stride()), nat.ptr(s_in), nat.ptr(s_out),
+                                                  nat.ptr(ws), ksplit, nat.stream_of(x))
+        else:
+            st = lib.pg_conv2d_up2_forward(nat.ptr(x), nat.ptr(packs['main']), nat.ptr(y), n, cin, h, w, cout, nat.i64arr(y.stride()), nat.ptr(s_in), nat.ptr(s_out),
+                                           nat.stream_of(x))
         if tl is not None:
             ev1.record()
             tl.append(((3, 3, 2, 'direct', f'N{n} {cin}->{cout} {h}x{w} up2' + (' mod' if in_scale is not None else '')), 2.0 * n * cout * cin * 9 * h * w, ev0, ev1,

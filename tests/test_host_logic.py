@@ -248,10 +248,10 @@ def test_modconv16_policy_is_pure_host_logic():
     comp, merged, shared, tpad, fir_pad, fused_x = PN._modconv16_policy((32, 64, 3, 3), (512, 512), 2, 1, f)
     assert fused_x and not comp and not shared                 # round 5: the y half of the FIR in the weights, the x half in the epilogue; activations dominate: per-sample weights
     comp, merged, shared, tpad, fir_pad, fused_x = PN._modconv16_policy((512, 1024, 3, 3), (32, 32), 2, 1, f)
-    assert fused_x and shared == (512 * 24 > 2 * 32 * 32)      # 24 tap slots per weight (18 non-zero)
+    assert fused_x and shared == (512 * 24 > 32 * 32)          # 24 tap slots per weight (18 non-zero); shared where the packed weights outweigh one sample's pixels (ratio 1 since round 5: +2 % on config 5)
     assert PN._modconv16_policy((32, 64, 3, 3), (512, 512), 2, 1, upfirdn2d.setup_filter([1, 3, 3, 1]) + torch.eye(4) * 0.01)[5] is False      # not separable: composite
     comp, merged, shared, tpad, fir_pad, fused_x = PN._modconv16_policy((512, 512, 3, 3), (64, 64), 1, 1, f)
-    assert not comp and not merged and not fused_x and shared == (512 * 9 > 2 * 64 * 64) and tpad is None
+    assert not comp and not merged and not fused_x and shared == (512 * 9 > 64 * 64) and tpad is None
     fy, fx = PN._separable_taps(f)
     assert torch.allclose(torch.outer(fy, fx), f) and PN._separable_taps(f) is PN._separable_taps(f)      # decided once per filter tensor
     assert PN._is_1331(f) and not PN._is_1331(upfirdn2d.setup_filter([1, 2, 1])) and not PN._is_1331(upfirdn2d.setup_filter([1, 3, 3, 1]) * 2)

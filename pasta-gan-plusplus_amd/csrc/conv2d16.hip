@@ -513,8 +513,9 @@ PG_EXPORT int pg_conv2d16_splitk_plan(int N, int Cin, int OH, int OW, int Cout, 
     const int64_t tiles = (int64_t)N * ((OW + tw - 1) / tw) * ((OH + th - 1) / th) * ((Cout + bm - 1) / bm);
     if (tiles >= pg::num_cu() || nchunks < 8) return 1;
     int best = 1;                                                      // largest divisor of nchunks that keeps >= 4 chunks per share and
-    for (int k = 2; k <= 16; k++)                                      // does not overshoot ~2 workgroups per CU
-        if (nchunks % k == 0 && nchunks / k >= 4 && tiles * k <= 2 * pg::num_cu()) best = k;
+    static const int per_cu = [] { const char* e = getenv("PG_CONV16_SPLITK_PER_CU"); return e && atoi(e) > 0 ? atoi(e) : 1; }();
+    for (int k = 2; k <= 16; k++)                                      // does not overshoot one workgroup per CU (round 5, tools/small16_probe.py at N = 4: 1024 -> 1024 at 8^2
+        if (nchunks % k == 0 && nchunks / k >= 4 && tiles * k <= per_cu * pg::num_cu()) best = k;      // 28 -> 24 us, at 16^2 39 -> 32, 1024 -> 4096 at 8^2 56 -> 54; until then: two per CU)
     return best;
 }
 

@@ -471,7 +471,10 @@ def _bf16x3_wanted(n, cin, cout, h, w, kh, kw, stride):
     if mode == '0' or kh != kw or (kh, stride) not in ((3, 1), (3, 2), (1, 1)) or cin % 8 or cout % 8:
         return False
     if mode == 'auto':
-        return kh == 3 and min(cin, cout) >= int(os.environ.get('PG_WGRAD_BF16X3_MIN_C', '64'))
+        if kh == 1:       # (1x1 layers: off unless PG_WGRAD_BF16X3_K1_MIN_C names a width)
+            k1 = int(os.environ.get('PG_WGRAD_BF16X3_K1_MIN_C', '0'))
+            return k1 > 0 and min(cin, cout) >= k1
+        return min(cin, cout) >= int(os.environ.get('PG_WGRAD_BF16X3_MIN_C', '64'))
     return True
 
 

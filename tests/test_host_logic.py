@@ -257,6 +257,27 @@ def test_modconv16_policy_is_pure_host_logic():
     assert PN._is_1331(f) and not PN._is_1331(upfirdn2d.setup_filter([1, 2, 1])) and not PN._is_1331(upfirdn2d.setup_filter([1, 3, 3, 1]) * 2)
 
 
+def test_bf16x3_weight_gradient_rule_is_pure_host_logic(monkeypatch):
+    """Which float32 weight gradients take the three-term bf16 operand split (torch_utils/ops/conv2d_mfma._bf16x3_wanted, round 5): by default the 3x3 layers,
+    stride 1 or 2, with at least 64 channels on both sides -- where the training step measured it faster; never a geometry the 16-bit kernel does not cover."""
+    from torch_utils.ops import conv2d_mfma
+    want = conv2d_mfma._bf16x3_wanted
+    monkeypatch.delenv('PG_WGRAD_BF16X3', raising=False)
+    monkeypatch.delenv('PG_WGRAD_BF16X3_MIN_C', raising=False)
+    monkeypatch.delenv('PG_WGRAD_BF16X3_K1_MIN_C', raising=False)
+    assert want(4, 128, 128, 256, 256, 3, 3, 1) and want(4, 64, 64, 512, 512, 3, 3, 1) and want(4, 64, 128, 513, 513, 3, 3, 2)
+    assert not want(4, 32, 64, 512, 512, 3, 3, 1) and not want(4, 64, 32, 512, 512, 3, 3, 1)          # narrower than 64 channels: the splitting passes outweigh the multiplies
+    assert not want(4, 128, 128, 256, 256, 1, 1, 1)                                                  # 1x1: measured no gain
+    assert not want(4, 3, 64, 512, 512, 7, 7, 1) and not want(4, 68, 128, 64, 64, 3, 3, 1)           # 7x7 stem; channel counts that are no multiple of 8
+    monkeypatch.setenv('PG_WGRAD_BF16X3', '0')
+    assert not want(4, 128, 128, 256, 256, 3, 3, 1)
+    monkeypatch.setenv('PG_WGRAD_BF16X3', '1')
+    assert want(4, 16, 24, 64, 64, 3, 3, 1) and want(4, 128, 128, 64, 64, 1, 1, 1) and not want(4, 128, 128, 64, 64, 1, 1, 2)
+    monkeypatch.setenv('PG_WGRAD_BF16X3', 'auto')
+    monkeypatch.setenv('PG_WGRAD_BF16X3_K1_MIN_C', '256')
+    assert want(4, 256, 512, 64, 64, 1, 1, 1) and not want(4, 128, 512, 64, 64, 1, 1, 1)
+
+
 def test_custom_ops_clean_is_per_plugin_and_spares_live_links(tmp_path, monkeypatch):
     """`clean()` sweeps compiler temporaries plugin by plugin under each plugin's build lock, matches exact plugin names (not a prefix glob) and never
     deletes the `<so>.tmp<pid>` of a link that is still running."""

@@ -422,6 +422,9 @@ __device__ __forceinline__ f32x16 mfma16(s16x8 a, s16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(wf16x8, a), __builtin_bit_cast(wf16x8, b), c, 0, 0, 0);
 }
 
+#ifndef W16_SHARED_WINDOWS
+#define W16_SHARED_WINDOWS 1      // dev A/B: 0 = two transposing reads per tap (rounds 4)
+#endif
 template <int KH, int KW, int S, bool BF16>
 __global__ __launch_bounds__(512, 1) void conv2d16_wgrad(Wgrad16Params p) {
     typedef W16Geo<KH, KW, S> G;
@@ -542,6 +545,28 @@ __global__ __launch_bounds__(512, 1) void conv2d16_wgrad(Wgrad16Params p) {
             const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(uintptr_t)aa);
             const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(uintptr_t)(aa + 4 * 128));
             const s16x8 av = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+            if constexpr (S == 1 && KW == 3 && W16_SHARED_WINDOWS) {
+                // round 5: the three kx taps of a row read overlapping pixel windows (p .. p+7, p+1 .. p+8, p+2 .. p+9 of this lane's channel).  Three reads -- pixels
+                // p .. p+3, p+4 .. p+7, p+8 .. p+11, all at the kx = 0 swizzle -- and four v_alignbit for the odd shift replace six: 11 instead of 20 transposing reads
+                // per k-step.  (At 20 the four multiplying waves asked the LDS for 40 KB per k-step = 320 cycles at 128 B/clk against 288 cycles of MFMA.)
+#pragma unroll
+                for (int ky = 0; ky < KH; ky++) {
+                    const unsigned ba = x_b + b_lane[0] + (unsigned)(((r + ky) * G::IW + c0) * G::XROWB);
+                    const s16x4 r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(uintptr_t)ba);
+                    const s16x4 r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(uintptr_t)(ba + 4 * G::XROWB));
+                    const s16x4 r2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(uintptr_t)(ba + 8 * G::XROWB));
+                    typedef unsigned u32x2w __attribute__((ext_vector_type(2)));
+                    typedef unsigned u32x4w __attribute__((ext_vector_type(4)));
+                    const u32x2w d0 = __builtin_bit_cast(u32x2w, r0), d1 = __builtin_bit_cast(u32x2w, r1), d2 = __builtin_bit_cast(u32x2w, r2);
+                    const u32x4w w0 = {d0[0], d0[1], d1[0], d1[1]};
+                    const u32x4w w1 = {__builtin_amdgcn_alignbit(d0[1], d0[0], 16), __builtin_amdgcn_alignbit(d1[0], d0[1], 16),
+                                       __builtin_amdgcn_alignbit(d1[1], d1[0], 16), __builtin_amdgcn_alignbit(d2[0], d1[1], 16)};
+                    const u32x4w w2 = {d0[1], d1[0], d1[1], d2[0]};
+                    acc[ky * KW + 0] = mfma16<BF16>(av, __builtin_bit_cast(s16x8, w0), acc[ky * KW + 0]);
+                    acc[ky * KW + 1] = mfma16<BF16>(av, __builtin_bit_cast(s16x8, w1), acc[ky * KW + 1]);
+                    acc[ky * KW + 2] = mfma16<BF16>(av, __builtin_bit_cast(s16x8, w2), acc[ky * KW + 2]);
+                }
+            } else {
 #pragma unroll
             for (int ky = 0; ky < KH; ky++)
 #pragma unroll
@@ -554,6 +579,7 @@ __global__ __launch_bounds__(512, 1) void conv2d16_wgrad(Wgrad16Params p) {
                     const s16x8 bv = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
                     acc[ky * KW + kx] = mfma16<BF16>(av, bv, acc[ky * KW + kx]);
                 }
+            }
         }
         __syncthreads();
     }
@@ -562,6 +588,185 @@ __global__ __launch_bounds__(512, 1) void conv2d16_wgrad(Wgrad16Params p) {
     const int ci = ci0 + nt * 32 + (lane & 31);
 #pragma unroll
     for (int tp = 0; tp < G::T; tp++)
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int co = co0 + mt * 32 + (k & 3) + 8 * (k >> 2) + 4 * (lane >> 5);
+            if (co < p.Cout && ci < p.Cin) wsp[((int64_t)tp * p.Cout + co) * p.Cin + ci] = acc[tp][k];
+        }
+}
+
+// ---- the six operand-split products from ONE staging of the planes (round 5; stride-1 3x3, bf16) -----------------------------------------------------------------
+// conv2d16_wgrad over 6 N plane-mapped images stages every plane three times (d1 and x1 are in three products each) and is bound by that traffic: a 64 x 64 block
+// has 220 FLOP per staged byte, 11 TB/s of operand traffic at the bf16 peak.  Here a chunk is 2 output rows x 32 columns of ONE sample with all three planes of dy
+// and of x side by side in LDS -- 3 x (8 KB + 18 KB), two buffers = 156 KB -- and a k-step issues the six products' 54 MFMAs from them: (d1|d2|d3, x1), (d1|d2, x2),
+// (d1, x3), into the same nine accumulators.  Half the staged bytes per multiply, 33 transposing reads per 54 MFMAs instead of 66.
+struct W16X3Geo {
+    static constexpr int R = 2, TW = 32, PIX = R * TW, KSTEPS = PIX / 16, IH = R + 2, IW = 36, XROWB = 128;
+    static constexpr int DY_SLOTS = PIX * 8, X_SLOTS = IH * IW * 8;                    // 512, 1152 sixteen-byte slots per plane
+    static constexpr int NDY = DY_SLOTS / 256, NX = (X_SLOTS + 255) / 256;             // 2, 5 (the fifth pass: loader waves 0 and 1 only)
+    static constexpr int DYB = DY_SLOTS * 16, XB = X_SLOTS * 16;                       // 8192, 18432 bytes
+    static constexpr int BUF = 3 * (DYB + XB);                                         // 79872
+    static_assert(X_SLOTS - 4 * 256 == 128, "the last pass covers exactly two loader waves");
+    static_assert(2 * BUF <= 160 * 1024, "LDS budget");
+};
+
+__global__ __launch_bounds__(512, 1) void conv2d16_wgrad_x3k(Wgrad16Params p) {
+    typedef W16X3Geo G;
+    typedef __attribute__((address_space(3))) s16x4* lp;
+    extern __shared__ float smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave8 = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const bool loader = wave8 >= 4;
+    const int wave = wave8 & 3, t = threadIdx.x & 255;
+    int b = blockIdx.x;
+    const int s = b % p.splits; b /= p.splits;
+    const int cib = b % p.ciB, cob = b / p.ciB;
+    const int co0 = cob * 64, ci0 = cib * 64;
+    const unsigned smem_b = __builtin_amdgcn_readfirstlane(pgconv::lds_offset(smem));
+    const int N0 = p.N0;
+
+    if (loader) {
+        unsigned rel_dy[G::NDY], rel_x[G::NX];
+#pragma unroll
+        for (int i = 0; i < G::NDY; i++) {
+            const int f = t + 256 * i, px = f >> 3, sl = f & 7;
+            const int ch = sl ^ (((px >> 1) & 1) << 2);
+            rel_dy[i] = co0 + ch * 8 < p.Cout ? (unsigned)(((px / G::TW) * p.OW + px % G::TW) * p.Cout + ch * 8) * 2u : WG_SENTINEL;
+        }
+#pragma unroll
+        for (int i = 0; i < G::NX; i++) {
+            const int f = t + 256 * i, pix = f >> 3, sl = f & 7;
+            const int ch = sl ^ (((pix >> 1) & 1) << 2);
+            const bool ok = f < G::X_SLOTS && ci0 + ch * 8 < p.Cin;
+            rel_x[i] = ok ? (unsigned)(((pix / G::IW) * p.W + pix % G::IW) * p.Cin + ch * 8) * 2u : WG_SENTINEL;
+        }
+        auto issue = [&](int chk, int buf) __attribute__((always_inline)) {
+            int c = chk;
+            const int tx = c % p.tilesX; c /= p.tilesX;
+            const int ty = c % p.tilesY;
+            const int n = c / p.tilesY;
+            const int oy0 = ty * G::R, ox0 = tx * G::TW;
+            const int iy0 = oy0 - p.pad_y, ix0 = ox0 - p.pad_x;
+            const bool inner_dy = oy0 + G::R <= p.OH && ox0 + G::TW <= p.OW;
+            const bool inner_x = iy0 >= 0 && iy0 + G::IH <= p.H && ix0 >= 0 && ix0 + G::IW <= p.W;
+            unsigned vdy[G::NDY], vx[G::NX];
+#pragma unroll
+            for (int i = 0; i < G::NDY; i++) {
+                vdy[i] = rel_dy[i];
+                if (!inner_dy) {
+                    const int px = (t + 256 * i) >> 3;
+                    if (oy0 + px / G::TW >= p.OH || ox0 + px % G::TW >= p.OW) vdy[i] = WG_SENTINEL;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < G::NX; i++) {
+                vx[i] = rel_x[i];
+                if (!inner_x) {
+                    const int pix = (t + 256 * i) >> 3;
+                    const int iy = iy0 + pix / G::IW, ix = ix0 + pix % G::IW;
+                    if (iy < 0 || iy >= p.H || ix < 0 || ix >= p.W) vx[i] = WG_SENTINEL;
+                }
+            }
+            const unsigned base_b = smem_b + (unsigned)(buf * G::BUF + 64 * 16 * wave);
+#pragma unroll
+            for (int pl = 0; pl < 3; pl++) {
+                const int np = pl * N0 + n;
+                const uint64_t dyb = (uint64_t)(uintptr_t)p.dy + ((((int64_t)np * p.OH + oy0) * p.OW + ox0) * p.Cout + co0) * 2;
+                const uint64_t xb = (uint64_t)(uintptr_t)p.x + ((((int64_t)np * p.H + iy0) * p.W + ix0) * p.Cin + ci0) * 2;       // may lie before the tensor: masked above
+                pgconv::i32x4 rdy, rx;
+                rdy[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)dyb); rdy[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(dyb >> 32) & 0xffff);
+                rdy[2] = 0x7ffffffe; rdy[3] = 0x00020000;
+                rx[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)xb); rx[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(xb >> 32) & 0xffff);
+                rx[2] = 0x7ffffffe; rx[3] = 0x00020000;
+#pragma unroll
+                for (int i = 0; i < G::NDY; i++) pgconv::dma_dwordx4_buf(rdy, base_b + (unsigned)(pl * G::DYB + 256 * 16 * i), vdy[i], 0);
+#pragma unroll
+                for (int i = 0; i < G::NX; i++)
+                    if (i < G::NX - 1 || wave < 2) pgconv::dma_dwordx4_buf(rx, base_b + (unsigned)(3 * G::DYB + pl * G::XB + 256 * 16 * i), vx[i], 0);
+            }
+        };
+        int ch = s, g = 0;
+        if (ch < p.chunks) issue(ch, 0);
+        pgconv::dma_wait_all();
+        __syncthreads();
+        for (; ch < p.chunks; ch += p.splits, g++) {
+            if (ch + p.splits < p.chunks) issue(ch + p.splits, (g & 1) ^ 1);
+            pgconv::dma_wait_all();
+            __syncthreads();
+        }
+        return;
+    }
+
+    const int mt = wave & 1, nt = wave >> 1;
+    const int grp = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const int kq = 8 * (grp >> 1) + q;
+    const int cbyte_a = (mt * 32 + 16 * (grp & 1) + 4 * pp) * 2, cbyte_b = (nt * 32 + 16 * (grp & 1) + 4 * pp) * 2;
+    const unsigned a_lane = (unsigned)(kq * 128 + (cbyte_a ^ (((q >> 1) & 1) << 6)));
+    const unsigned b_lane = (unsigned)(kq * G::XROWB + (cbyte_b ^ (((q >> 1) & 1) << 6)));
+    typedef unsigned u32x2w __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x4w __attribute__((ext_vector_type(4)));
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int tp = 0; tp < 9; tp++)
+#pragma unroll
+        for (int k = 0; k < 16; k++) acc[tp][k] = 0.f;
+
+    int ch = s, g = 0;
+    __syncthreads();
+    for (; ch < p.chunks; ch += p.splits, g++) {
+        const unsigned dy_b = smem_b + (unsigned)((g & 1) * G::BUF);
+        const unsigned x_b = dy_b + (unsigned)(3 * G::DYB);
+        // software pipeline, written out: the three window reads of group (ky, x plane) + 1 are requested before the MFMAs of group (ky, x plane) are issued, and the
+        // groups are fenced -- left alone the scheduler hoists every read of a k-step above its first MFMA and spills (256 registers + scratch; 252 vs 243 ms per iteration)
+        struct Win { s16x4 r0, r1, r2; };
+        auto rd = [&](int kk, int gi) __attribute__((always_inline)) {
+            const int r = (kk * 16) / G::TW, c0 = (kk * 16) % G::TW;
+            const int ky = gi / 3, pl = 2 - gi % 3;                    // x3 first: the smallest products enter the accumulators first
+            const unsigned ba = x_b + (unsigned)(pl * G::XB) + b_lane + (unsigned)(((r + ky) * G::IW + c0) * G::XROWB);
+            Win w;
+            w.r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(uintptr_t)ba);
+            w.r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(uintptr_t)(ba + 4 * G::XROWB));
+            w.r2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(uintptr_t)(ba + 8 * G::XROWB));
+            return w;
+        };
+        Win cur = rd(0, 0), nxt = cur;
+#pragma unroll
+        for (int kk = 0; kk < G::KSTEPS; kk++) {
+            s16x8 av[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; pl++) {
+                const unsigned aa = dy_b + (unsigned)(pl * G::DYB) + a_lane + (unsigned)(kk * 16 * 128);
+                const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(uintptr_t)aa);
+                const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(uintptr_t)(aa + 4 * 128));
+                av[pl] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+            for (int gi = 0; gi < 9; gi++) {
+                const int ky = gi / 3, pl = 2 - gi % 3;
+                if (gi + 1 < 9) nxt = rd(kk, gi + 1);
+                else if (kk + 1 < G::KSTEPS) nxt = rd(kk + 1, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                const u32x2w d0 = __builtin_bit_cast(u32x2w, cur.r0), d1 = __builtin_bit_cast(u32x2w, cur.r1), d2 = __builtin_bit_cast(u32x2w, cur.r2);
+                const u32x4w w0 = {d0[0], d0[1], d1[0], d1[1]};
+                const u32x4w w1 = {__builtin_amdgcn_alignbit(d0[1], d0[0], 16), __builtin_amdgcn_alignbit(d1[0], d0[1], 16),
+                                   __builtin_amdgcn_alignbit(d1[1], d1[0], 16), __builtin_amdgcn_alignbit(d2[0], d1[1], 16)};
+                const u32x4w w2 = {d0[1], d1[0], d1[1], d2[0]};
+                const s16x8 bw[3] = {__builtin_bit_cast(s16x8, w0), __builtin_bit_cast(s16x8, w1), __builtin_bit_cast(s16x8, w2)};
+#pragma unroll
+                for (int i = 2 - pl; i >= 0; i--)                      // dy planes whose product with x plane pl is kept: i + pl <= 2
+#pragma unroll
+                    for (int kx = 0; kx < 3; kx++) acc[ky * 3 + kx] = mfma16<true>(av[i], bw[kx], acc[ky * 3 + kx]);
+                __builtin_amdgcn_sched_barrier(0);
+                cur = nxt;
+            }
+        }
+        __syncthreads();
+    }
+    float* wsp = p.ws + (int64_t)s * 9 * p.Cout * p.Cin;
+    const int ci = ci0 + nt * 32 + (lane & 31);
+#pragma unroll
+    for (int tp = 0; tp < 9; tp++)
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             const int co = co0 + mt * 32 + (k & 3) + 8 * (k >> 2) + 4 * (lane >> 5);
@@ -696,6 +901,28 @@ static int wgrad16_run(const void* x, const void* dy, float* dw, float* workspac
     const int64_t blocks = (int64_t)p.coB * p.ciB * splits;
     if (blocks > 0x7fffffffLL) return PG_ERR_TOO_LARGE;
     hipStream_t s = (hipStream_t)stream;
+    // the six operand-split products of a stride-1 3x3 layer from one staging of the planes (conv2d16_wgrad_x3k); PG_WGRAD_X3_FUSED=0: the 6N-image launch (A/B)
+    static const bool x3_fused = [] { const char* e = getenv("PG_WGRAD_X3_FUSED"); return !e || atoi(e) != 0; }();
+    if (N0 > 0 && x3_fused && KH == 3 && KW == 3 && stride == 1 && dtype == PG_BF16) {
+        p.N = N0;
+        p.tilesY = cdiv(OH, W16X3Geo::R);
+        const int64_t ch3 = (int64_t)N0 * p.tilesX * p.tilesY;
+        if (ch3 > 0x7fffffffLL) return PG_ERR_TOO_LARGE;
+        p.chunks = (int)ch3;
+        if (splits > p.chunks) splits = p.chunks;                 // (the plan counted the 6N launch's chunks: three times as many)
+        p.splits = splits;
+        static pg::PerDeviceOnce attr3;
+        const hipError_t e3 = attr3.run([] { return hipFuncSetAttribute((const void*)conv2d16_wgrad_x3k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+        if (e3 != hipSuccess) return (int)e3;
+        hipLaunchKernelGGL(conv2d16_wgrad_x3k, dim3((unsigned)((int64_t)p.coB * p.ciB * splits)), dim3(512), 2 * (size_t)W16X3Geo::BUF, s, p);
+        int st3 = pg::launch_status();
+        if (st3 != PG_OK) return st3;
+        const int64_t total3 = (int64_t)KH * KW * Cout * Cin;
+        int64_t rb3 = (total3 + 63) / 64;
+        if (rb3 > pg::max_stream_blocks()) rb3 = pg::max_stream_blocks();
+        hipLaunchKernelGGL(wgrad_reduce, dim3((unsigned)rb3), dim3(256), 0, s, workspace, dw, splits, KH * KW, Cout, Cin);
+        return pg::launch_status();
+    }
 #define PG_WGRAD16(KK, SS, BF) { \
         const size_t lds = 2 * (size_t)W16Geo<KK, KK, SS>::BUF; \
         static pg::PerDeviceOnce attr; \

@@ -720,20 +720,20 @@ __global__ __launch_bounds__(512, 1) void conv2d16_wgrad_x3k(Wgrad16Params p) {
         // software pipeline, written out: the three window reads of group (ky, x plane) + 1 are requested before the MFMAs of group (ky, x plane) are issued, and the
         // groups are fenced -- left alone the scheduler hoists every read of a k-step above its first MFMA and spills (256 registers + scratch; 252 vs 243 ms per iteration)
         struct Win { s16x4 r0, r1, r2; };
-        auto rd = [&](int kk, int gi) __attribute__((always_inline)) {
+        struct Row { Win w[3]; };                                      // the window reads of one kernel row ky: x planes 0, 1, 2
+        auto rd = [&](int kk, int ky) __attribute__((always_inline)) {
             const int r = (kk * 16) / G::TW, c0 = (kk * 16) % G::TW;
-            const int ky = gi / 3, pl = 2 - gi % 3;                    // x3 first: the smallest products enter the accumulators first
-            const unsigned ba = x_b + (unsigned)(pl * G::XB) + b_lane + (unsigned)(((r + ky) * G::IW + c0) * G::XROWB);
-            Win w;
-            w.r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(uintptr_t)ba);
-            w.r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(uintptr_t)(ba + 4 * G::XROWB));
-            w.r2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(uintptr_t)(ba + 8 * G::XROWB));
-            return w;
-        };
-        Win cur = rd(0, 0), nxt = cur;
+            Row o;
 #pragma unroll
-        for (int kk = 0; kk < G::KSTEPS; kk++) {
-            s16x8 av[3];
+            for (int pl = 0; pl < 3; pl++) {
+                const unsigned ba = x_b + (unsigned)(pl * G::XB) + b_lane + (unsigned)(((r + ky) * G::IW + c0) * G::XROWB);
+                o.w[pl].r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(uintptr_t)ba);
+                o.w[pl].r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(uintptr_t)(ba + 4 * G::XROWB));
+                o.w[pl].r2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(uintptr_t)(ba + 8 * G::XROWB));
+            }
+            return o;
+        };
+        auto rda = [&](int kk, s16x8 (&av)[3]) __attribute__((always_inline)) {
 #pragma unroll
             for (int pl = 0; pl < 3; pl++) {
                 const unsigned aa = dy_b + (unsigned)(pl * G::DYB) + a_lane + (unsigned)(kk * 16 * 128);
@@ -741,25 +741,38 @@ __global__ __launch_bounds__(512, 1) void conv2d16_wgrad_x3k(Wgrad16Params p) {
                 const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(uintptr_t)(aa + 4 * 128));
                 av[pl] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
             }
+        };
+        // software pipeline, written out: the nine window reads of kernel row ky + 1 (and the dy operands of the next k-step) are requested before the 18 MFMAs of row ky
+        // are issued, and the rows are fenced -- left alone the scheduler hoists every read of a k-step above its first MFMA and spills (256 registers + scratch:
+        // 252 instead of 243 ms per iteration); fenced per (row, plane) group the three-MFMA groups did not cover the next group's read latency
+        Row cur = rd(0, 0), nxt = cur;
+        s16x8 av[3], avn[3];
+        rda(0, av);
 #pragma unroll
-            for (int gi = 0; gi < 9; gi++) {
-                const int ky = gi / 3, pl = 2 - gi % 3;
-                if (gi + 1 < 9) nxt = rd(kk, gi + 1);
-                else if (kk + 1 < G::KSTEPS) nxt = rd(kk + 1, 0);
+        for (int kk = 0; kk < G::KSTEPS; kk++) {
+#pragma unroll
+            for (int ky = 0; ky < 3; ky++) {
+                if (ky + 1 < 3) nxt = rd(kk, ky + 1);
+                else if (kk + 1 < G::KSTEPS) { nxt = rd(kk + 1, 0); rda(kk + 1, avn); }
                 __builtin_amdgcn_sched_barrier(0);
-                const u32x2w d0 = __builtin_bit_cast(u32x2w, cur.r0), d1 = __builtin_bit_cast(u32x2w, cur.r1), d2 = __builtin_bit_cast(u32x2w, cur.r2);
-                const u32x4w w0 = {d0[0], d0[1], d1[0], d1[1]};
-                const u32x4w w1 = {__builtin_amdgcn_alignbit(d0[1], d0[0], 16), __builtin_amdgcn_alignbit(d1[0], d0[1], 16),
-                                   __builtin_amdgcn_alignbit(d1[1], d1[0], 16), __builtin_amdgcn_alignbit(d2[0], d1[1], 16)};
-                const u32x4w w2 = {d0[1], d1[0], d1[1], d2[0]};
-                const s16x8 bw[3] = {__builtin_bit_cast(s16x8, w0), __builtin_bit_cast(s16x8, w1), __builtin_bit_cast(s16x8, w2)};
 #pragma unroll
-                for (int i = 2 - pl; i >= 0; i--)                      // dy planes whose product with x plane pl is kept: i + pl <= 2
+                for (int pl = 2; pl >= 0; pl--) {                      // x3 first: the smallest products enter the accumulators first
+                    const u32x2w d0 = __builtin_bit_cast(u32x2w, cur.w[pl].r0), d1 = __builtin_bit_cast(u32x2w, cur.w[pl].r1), d2 = __builtin_bit_cast(u32x2w, cur.w[pl].r2);
+                    const u32x4w w0 = {d0[0], d0[1], d1[0], d1[1]};
+                    const u32x4w w1 = {__builtin_amdgcn_alignbit(d0[1], d0[0], 16), __builtin_amdgcn_alignbit(d1[0], d0[1], 16),
+                                       __builtin_amdgcn_alignbit(d1[1], d1[0], 16), __builtin_amdgcn_alignbit(d2[0], d1[1], 16)};
+                    const u32x4w w2 = {d0[1], d1[0], d1[1], d2[0]};
+                    const s16x8 bw[3] = {__builtin_bit_cast(s16x8, w0), __builtin_bit_cast(s16x8, w1), __builtin_bit_cast(s16x8, w2)};
 #pragma unroll
-                    for (int kx = 0; kx < 3; kx++) acc[ky * 3 + kx] = mfma16<true>(av[i], bw[kx], acc[ky * 3 + kx]);
+                    for (int i = 2 - pl; i >= 0; i--)                  // dy planes whose product with x plane pl is kept: i + pl <= 2
+#pragma unroll
+                        for (int kx = 0; kx < 3; kx++) acc[ky * 3 + kx] = mfma16<true>(av[i], bw[kx], acc[ky * 3 + kx]);
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 cur = nxt;
             }
+#pragma unroll
+            for (int pl = 0; pl < 3; pl++) av[pl] = avn[pl];
         }
         __syncthreads();
     }

@@ -64,7 +64,9 @@ def _native_ok(x, w, stride, dilation, groups):
 
 
 def _native16_ok(x, w, stride, dilation, groups):
-    return (x.dtype in conv2d_mfma16.DTYPES and w.dtype == x.dtype and x.ndim == 4 and groups == 1 and dilation == (1, 1)
+    # (round 5: a float32 weight with 16-bit activations is welcome -- the pack converts it, the weight gradient leaves the kernel in float32: the caller's
+    # `w.to(x.dtype)`, this route's `.float()` and the two casts of its backward were four elementwise launches per layer call)
+    return (x.dtype in conv2d_mfma16.DTYPES and w.dtype in (x.dtype, torch.float32) and x.ndim == 4 and groups == 1 and dilation == (1, 1)
             and stride[0] == stride[1] and x.numel() > 0 and w.numel() > 0)
 
 
@@ -125,6 +127,8 @@ def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, 
                 return y if fuse is not None else tail(y)
         except nat.NativeNotCovered:
             pass
+    if weight.dtype != input.dtype:
+        weight = weight.to(input.dtype)
     return tail(torch.nn.functional.conv2d(input=input, weight=weight, bias=bias, stride=stride, padding=padding, dilation=dilation, groups=groups))
 
 
@@ -147,6 +151,8 @@ def conv_transpose2d(input, weight, bias=None, stride=1, padding=0, output_paddi
                 return _Conv2dMfma16.apply(input, weight, bias, stride[0], padding, True, output_padding)
         except nat.NativeNotCovered:
             pass
+    if weight.dtype != input.dtype:
+        weight = weight.to(input.dtype)
     return torch.nn.functional.conv_transpose2d(input=input, weight=weight, bias=bias, stride=stride, padding=padding,
                                                 output_padding=output_padding, groups=groups, dilation=dilation)
 
@@ -332,10 +338,10 @@ class _Conv2dMfma16(torch.autograd.Function):
         need_b = want_b and db is None
         if need_x or need_w or need_b:
             gx, gw, gb = torch.ops.aten.convolution_backward(
-                dy, x, weight, [weight.shape[1 if transposed else 0]] if has_bias else None,
+                dy, x, weight.to(x.dtype), [weight.shape[1 if transposed else 0]] if has_bias else None,
                 [stride, stride], list(padding), [1, 1], transposed, list(output_padding), 1, [need_x, need_w, need_b])
             dx = gx if need_x else dx
-            dw = gw if need_w else dw
+            dw = gw.to(weight.dtype) if need_w else dw
             db = gb if need_b else db
         return dx, dw, db, None, None, None, None, None
 

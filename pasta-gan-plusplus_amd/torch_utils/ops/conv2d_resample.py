@@ -95,7 +95,7 @@ def conv2d_resample(x, w, f=None, up=1, down=1, padding=0, groups=1, flip_weight
 
 def _conv2d_resample(x, w, f, up, down, padding, groups, flip_weight, flip_filter, bias=None, epilogue=None):
     assert isinstance(x, torch.Tensor) and (x.ndim == 4)
-    assert isinstance(w, torch.Tensor) and (w.ndim == 4) and (w.dtype == x.dtype)
+    assert isinstance(w, torch.Tensor) and (w.ndim == 4) and (w.dtype == x.dtype or (w.dtype == torch.float32 and x.is_cuda))     # (float32 weights beside 16-bit GPU activations: conv2d_gradfix packs from float32)
     assert f is None or (isinstance(f, torch.Tensor) and f.ndim in [1, 2] and f.dtype == torch.float32)
     assert isinstance(up, int) and (up >= 1)
     assert isinstance(down, int) and (down >= 1)

@@ -94,6 +94,7 @@ class GradBucket:
         # launches / 4.7 ms per config-4 iteration -- and the gradients of a segment move into the flat bucket with ONE multi-tensor copy when the segment is
         # complete (in front of its all-reduce, or in finish()); after that .grad IS the bucket view, as in the other mode
         self.gather = (dev.type == 'cuda' and os.environ.get('PG_GRAD_GATHER', '1') != '0') if gather is None else bool(gather)
+        self.grad_gains = None                               # per-parameter factor applied to the gathered gradient (set with the pre-scaled weight copies, training_step)
         for i, p in enumerate(self.params):
             was = p.requires_grad                            # the step freezes every module between phases; hooks need a leaf that requires grad
             p.requires_grad_(True)
@@ -146,12 +147,17 @@ class GradBucket:
 
     def _gather(self, members):
         """Move the gradients autograd left in .grad into their bucket views (one multi-tensor copy) and make the views the .grad."""
-        dst, src = [], []
+        dst, src, scaled, gains = [], [], [], []
         for i in members:
             g = self.params[i].grad
             if g is not None and g.data_ptr() != self.views[i].data_ptr():
                 dst.append(self.views[i])
                 src.append(g if g.shape == self.views[i].shape else g.reshape(self.views[i].shape))
+                if self.grad_gains is not None and self.grad_gains[i] != 1.0:
+                    scaled.append(src[-1])
+                    gains.append(self.grad_gains[i])
+        if scaled:      # parameters whose layers ran on pre-scaled copies (training.networks._GainedAlias): their gradients are d/d(weight * gain) until here
+            torch._foreach_mul_(scaled, gains)
         if dst:
             torch._foreach_copy_(dst, src)
         for i in members:

@@ -74,9 +74,54 @@ class TrainingStep:
             else:
                 self.phases.append(Phase(name + 'main', modules, opt, 1, bucket))
                 self.phases.append(Phase(name + 'reg', modules, opt, interval, bucket))
+        # Pre-scaled weight copies (round 5): `weight * weight_gain` of every equalised-LR convolution was two elementwise launches per layer
+        # call (forward and backward), ~1 100 per iteration.  On the GPU route (gather-mode buckets) the layers take an alias of a copy that ONE multi-tensor pass
+        # per optimizer step keeps current (networks._GainedAlias), and the gather multiplies the accumulated gradient by the gain.  PG_GAIN_FOLD=0: the multiplies.
+        self._gained = {}                # module-set key -> (params, copies, gains)
+        self._gained_table = {}
+        if os.environ.get('PG_GAIN_FOLD', '1') != '0':
+            from . import networks
+            table = {}
+            for key, (bucket, _opt) in by_module.items():
+                if not (bucket.flat.is_cuda and bucket.gather):
+                    continue
+                index = {id(p): i for i, p in enumerate(bucket.params)}
+                ps, gs = [], []
+                mods = [m for ph in self.phases if ph.bucket is bucket for m in ph.modules]
+                seen = set()
+                for top in mods:
+                    for m in top.modules():
+                        if isinstance(m, networks._ConvBase) and isinstance(getattr(m, 'weight', None), torch.nn.Parameter) and id(m.weight) in index and id(m.weight) not in seen:
+                            seen.add(id(m.weight))
+                            ps.append(m.weight)
+                            gs.append(float(m.weight_gain))
+                if not ps:
+                    continue
+                copies = [torch.empty_like(p) for p in ps]
+                bucket.grad_gains = [1.0] * len(bucket.params)
+                for p, g in zip(ps, gs):
+                    bucket.grad_gains[index[id(p)]] = g
+                self._gained[key] = (ps, copies, gs)
+                for p, c in zip(ps, copies):
+                    table[id(p)] = [c, -1, p]
+            self._gained_table = table       # (armed only while one of this step's phases runs: `_phase`)
+            for key in self._gained:
+                self._refresh_gained(key)
         self.cur_nimg = 0
         self.batch_idx = 0
         self.observer = None             # tests: callable(event, phase) at 'begin' of a phase and when its 'gradients' are final (eager phases only)
+
+    def _refresh_gained(self, key):
+        """weight * gain of one module set into the persistent copies: two multi-tensor launches (copy, scale); records the versions the copies were made from."""
+        ent = self._gained.get(key)
+        if ent is None:
+            return
+        ps, copies, gs = ent
+        with torch.no_grad():
+            torch._foreach_copy_(copies, [p.detach() for p in ps])
+            torch._foreach_mul_(copies, gs)
+        for p in ps:
+            self._gained_table[id(p)][1] = p._version
 
     def due_phases(self):
         return [ph for ph in self.phases if self.batch_idx % ph.interval == 0]
@@ -88,10 +133,15 @@ class TrainingStep:
         ph.bucket.begin()                                    # zero the flat bucket; every .grad is a view into it
         for m in ph.modules:
             m.requires_grad_(True)
-        for r, batch in enumerate(rounds):
-            last = r == len(rounds) - 1
-            self.loss.on_last_backward = ph.bucket.last_round if last else None
-            self.loss.accumulate_gradients(phase=ph.name, sync=last, gain=ph.interval, **batch)
+        from . import networks
+        networks._gained_provider[0] = self._gained_table if self._gained else None      # the layers' `weight * gain` = aliases of the pre-scaled copies, in this phase only
+        try:
+            for r, batch in enumerate(rounds):
+                last = r == len(rounds) - 1
+                self.loss.on_last_backward = ph.bucket.last_round if last else None
+                self.loss.accumulate_gradients(phase=ph.name, sync=last, gain=ph.interval, **batch)
+        finally:
+            networks._gained_provider[0] = None
         self.loss.on_last_backward = None
         for m in ph.modules:
             m.requires_grad_(False)
@@ -103,6 +153,7 @@ class TrainingStep:
         if self.observer is not None:
             self.observer('gradients', ph)                   # exchanged, cleaned gradients in place; the optimizer has not stepped yet
         ph.opt.step()
+        self._refresh_gained(tuple(id(m) for m in ph.modules))   # the pre-scaled weight copies of this module set follow the step
 
     def _phase_graphed(self, idx, ph, rounds):
         """First time: eager (plugin loading, kernel attributes, MIOpen's solver choice stay out of the graph).  Second time: capture, then

@@ -55,6 +55,7 @@ struct Up2Params {
     int64_t ys[4];
     int tilesX, tilesY, mblocks, total_tiles;
     int etilesY, edge_tiles;                    // edge tiles of the last output column: N x etilesY x mblocks
+    int retilesX, redge_tiles;                  // (round 5) edge tiles of the last output ROW 2H, when the main tiles stop at position row H - 1: N x retilesX x mblocks
     // split-K (round 5; the 8^2 / 16^2 layers: 128 / 256 tiles of 64 serial K chunks each): every tile (edge tiles too) exists `ksplit` times, share z reduces the
     // chunks [z * cpk, (z + 1) * cpk) into slice z of the workspace (y + z * ws_slice, laid out like y); up2_sum_slices adds the slices up.  ksplit = 1: y itself.
     int ksplit, cpk;
@@ -150,13 +151,19 @@ __global__ __launch_bounds__(256, 2) void conv2d_up2(Up2Params p) {
 
     // ---- edge pass: the last output column (see the header comment).  Plain double-buffered chunk loop, no cross-tile pipelining.
     static_assert(U_KC * U_EPLANE <= U_XPT * 256, "edge column larger than the staging buffer");
-    for (int et = (int)gridDim.x - 1 - (int)blockIdx.x; et < p.edge_tiles; et += gridDim.x) {
-        int L = et;
+    // Round 5: the position row q = H (output row 2H: taps ky = 2 only, i.e. taps 6, 8 of parity (0,0) and tap 7 of parity (0,1) on the input row H - 1) is the
+    // same kind of sliver.  Where it would open a whole extra row of main tiles (H % TQ == 0: 33 rows for a 32-row image in 8-row tiles, 17 in 16-row tiles) the
+    // launcher stops the main tiles at q = H - 1 and this pass runs ROW tiles after the column tiles: 32 couts x 256 positions ALONG that row, the roles of q and r
+    // swapped (staged: input row H - 1, columns r0 - 1 .. r0 + 255).  The corner (2H, 2W) belongs to the column tiles.
+    for (int et = (int)gridDim.x - 1 - (int)blockIdx.x; et < p.edge_tiles + p.redge_tiles; et += gridDim.x) {
+        const bool row_tile = et >= p.edge_tiles;
+        int L = row_tile ? et - p.edge_tiles : et;
         const int ez = L % p.ksplit; L /= p.ksplit;
         const int ekz = ez * p.cpk;
         const int mb = L % p.mblocks; L /= p.mblocks;
-        const int ty = L % p.etilesY;
-        n = L / p.etilesY; q0 = ty * U_EQ; m0 = mb * U_BM;
+        const int ety = row_tile ? p.retilesX : p.etilesY;
+        const int ty = L % ety;
+        n = L / ety; q0 = ty * U_EQ; m0 = mb * U_BM;              // (row tiles: q0 is the first COLUMN position r0 of the tile)
         if (MOD)
             for (int c = t; c < cin_loop; c += 256) cs0[c] = c < p.Cin ? ld_opaque(p.in_scale + (int64_t)n * p.Cin + c) : 1.f;
         if (t < U_BM) {
@@ -166,9 +173,9 @@ __global__ __launch_bounds__(256, 2) void conv2d_up2(Up2Params p) {
 #pragma unroll
         for (int i = 0; i < U_XPT; i++) {
             const int e = t + 256 * i;
-            const int c = e / U_EPLANE, gy = q0 - 1 + e % U_EPLANE;
-            const bool ok = e < U_KC * U_EPLANE && gy >= 0 && gy < p.H;
-            xoff[i] = ok ? (unsigned)(c * HW + gy * p.W + p.W - 1) * 4u : 0x80000000u;
+            const int c = e / U_EPLANE, gy = q0 - 1 + e % U_EPLANE;     // (row tiles: the column index)
+            const bool ok = e < U_KC * U_EPLANE && gy >= 0 && gy < (row_tile ? p.W : p.H);
+            xoff[i] = ok ? (unsigned)(row_tile ? c * HW + (p.H - 1) * p.W + gy : c * HW + gy * p.W + p.W - 1) * 4u : 0x80000000u;
         }
         const uint64_t base = (uint64_t)(uintptr_t)(p.x + (int64_t)n * p.Cin * HW);
         xrsrc[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)base);
@@ -192,7 +199,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_up2(Up2Params p) {
             for (int cp = 0; cp < U_KC / 2; cp++) {
                 const float* ab = smem + buf * U_LDS_BUF + U_LDS_X + ((2 * cp + half) * 9) * U_BM + l31;
                 const float* bb = smem + buf * U_LDS_BUF + (2 * cp + half) * U_EPLANE + (2 * wave) * 32 + l31;
-                const float a2 = ab[2 * U_BM], a5 = ab[5 * U_BM], a8 = ab[8 * U_BM];
+                const float a2 = ab[(row_tile ? 6 : 2) * U_BM], a5 = ab[(row_tile ? 7 : 5) * U_BM], a8 = ab[8 * U_BM];      // row tiles: taps 6 (with x0), 7 (x0), 8 (xm)
                 const float sc = MOD ? cs0[(ekz + k) * U_KC + 2 * cp + half] : 1.f;
 #pragma unroll
                 for (int nt = 0; nt < 2; nt++) {
@@ -203,19 +210,20 @@ __global__ __launch_bounds__(256, 2) void conv2d_up2(Up2Params p) {
                 }
             }
         }
-        // D col = lane & 31 = position q, row = cout (as below): output rows 2q and 2q + 1 of column 2W
+        // D col = lane & 31 = position q, row = cout (as below): output rows 2q and 2q + 1 of column 2W (row tiles: columns 2r and 2r + 1 of row 2H)
 #pragma unroll
         for (int nt = 0; nt < 2; nt++) {
             const int q = q0 + (2 * wave + nt) * 32 + l31;
 #pragma unroll
             for (int a = 0; a < 2; a++) {
-                const bool row_ok = a == 0 ? q <= p.H : q < p.H;
+                const bool row_ok = row_tile ? q < p.W : (a == 0 ? q <= p.H : q < p.H);
 #pragma unroll
                 for (int k = 0; k < 16; k++) {
                     const int rowc = (k & 3) + 8 * (k >> 2) + 4 * half;
                     const int co = m0 + rowc;
                     if (row_ok && co < p.Cout)
-                        p.y[(int64_t)ez * p.ws_slice + (int64_t)n * p.ys[0] + (int64_t)co * p.ys[1] + (int64_t)(2 * q + a) * p.ys[2] + (int64_t)(2 * p.W) * p.ys[3]] = ea[a][nt][k] * ep0[rowc];
+                        p.y[(int64_t)ez * p.ws_slice + (int64_t)n * p.ys[0] + (int64_t)co * p.ys[1] + (int64_t)(row_tile ? 2 * p.H : 2 * q + a) * p.ys[2] +
+                            (int64_t)(row_tile ? 2 * q + a : 2 * p.W) * p.ys[3]] = ea[a][nt][k] * ep0[rowc];
                 }
             }
         }
@@ -348,7 +356,9 @@ int launch_up2_t(const Up2Params& p0, hipStream_t s) {
     typedef UGeo<TRW, VEC> G;
     Up2Params p = p0;
     p.tilesX = (p.W + TRW - 1) / TRW;
-    p.tilesY = (p.H + 1 + G::TQ - 1) / G::TQ;
+    static const bool redge_on = [] { const char* e = getenv("PG_UP2_ROW_EDGE"); return !e || atoi(e) != 0; }();      // A/B: 0 = the main tiles cover position row H
+    const bool redge = redge_on && p.H % G::TQ == 0;          // row H would open a whole extra row of main tiles: it goes to the edge pass instead
+    p.tilesY = redge ? p.H / G::TQ : (p.H + 1 + G::TQ - 1) / G::TQ;
     p.mblocks = p.CoutP / U_BM;
     const int cin_chunks = (p.Cin + U_KC - 1) / U_KC;
     if (p.ksplit < 1 || cin_chunks % p.ksplit != 0) return PG_ERR_INVALID_ARG;
@@ -359,12 +369,16 @@ int launch_up2_t(const Up2Params& p0, hipStream_t s) {
     if (tiles + etiles > 0x7fffffffLL) return PG_ERR_TOO_LARGE;
     p.total_tiles = (int)tiles;
     p.edge_tiles = (int)etiles;
+    p.retilesX = (p.W + U_EQ - 1) / U_EQ;
+    const int64_t retiles = redge ? (int64_t)p.N * p.retilesX * p.mblocks * p.ksplit : 0;
+    if (tiles + etiles + retiles > 0x7fffffffLL) return PG_ERR_TOO_LARGE;
+    p.redge_tiles = (int)retiles;
     const int cin_loop = ((p.Cin + U_KC - 1) / U_KC) * U_KC;
     const size_t lds = ((size_t)2 * U_LDS_BUF + 2 * cin_loop + 2 * U_BM) * sizeof(float);
     if (lds > 160 * 1024) return PG_ERR_UNSUPPORTED;
     int per_cu = (int)((160 * 1024) / lds);
     if (per_cu > 2) per_cu = 2;                             // ~230 VGPRs x 4 waves per workgroup
-    const int64_t blocks = tiles + etiles < (int64_t)num_cu() * per_cu ? tiles + etiles : (int64_t)num_cu() * per_cu;
+    const int64_t blocks = tiles + etiles + retiles < (int64_t)num_cu() * per_cu ? tiles + etiles + retiles : (int64_t)num_cu() * per_cu;
     if (p.in_scale) {
         static PerDeviceOnce a1;
         const hipError_t e = a1.run([] { return hipFuncSetAttribute((const void*)conv2d_up2<true, TRW, VEC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
@@ -382,7 +396,7 @@ int launch_up2_t(const Up2Params& p0, hipStream_t s) {
 // Tiles of the main stream for a launch (what launch_up2 dispatches), for the split-K plan.
 inline int64_t up2_tiles(int N, int H, int W, int Cout) {
     const int trw = W > 16 ? 32 : (W > 8 ? 16 : 8), tq = 8 * (32 / trw);
-    return (int64_t)N * ((W + trw - 1) / trw) * ((H + 1 + tq - 1) / tq) * ((Cout + U_BM - 1) / U_BM);
+    return (int64_t)N * ((W + trw - 1) / trw) * (H % tq == 0 ? H / tq : (H + 1 + tq - 1) / tq) * ((Cout + U_BM - 1) / U_BM);
 }
 
 // The largest share count in {1, 2, 4, 8} that divides the K chunks, leaves >= 8 chunks per share and does not overfill the chip (two workgroups per CU): the

@@ -519,8 +519,9 @@ __global__ __launch_bounds__(256) void spade_feat_assemble_kernel(const float* _
             f32x4 r_u, r_l;
 #pragma unroll
             for (int k = 0; k < 4; k++) { r_u[k] = m_u[k] - m_u[k] * d_u[k]; r_l[k] = m_l[k] - m_l[k] * d_l[k]; }
+            const int cz = (C + gridDim.z - 1) / gridDim.z, c_lo = blockIdx.z * cz, c_hi = c_lo + cz < C ? c_lo + cz : C;      // this workgroup's share of the channels
 #pragma unroll 4
-            for (int c = 0; c < C; c++) {
+            for (int c = c_lo; c < c_hi; c++) {
                 const int plane = n * C + c;
                 const float au = su[plane] / nu, al = sl[plane] / nl;
                 const int64_t pb = (int64_t)plane * HWl;
@@ -1147,7 +1148,10 @@ PG_EXPORT int pg_spade_masked_sums(const float* feat, const float* mask, const f
     if (!feat || !mask || !denorm_mask || !sums || !counts || N <= 0 || C <= 0 || H <= 0 || W <= 0) return PG_ERR_INVALID_ARG;
     if ((int64_t)H * W > 0x3fffffffLL) return PG_ERR_TOO_LARGE;
     const int vec = (W % 4 == 0 && pg::aligned16(feat) && pg::aligned16(mask) && pg::aligned16(denorm_mask)) ? 1 : 0;
-    if (C % 4 == 0) hipLaunchKernelGGL(spade_masked_sums_kernel<4>, dim3((unsigned)(N * C / 4)), dim3(IN_THREADS), 0, (hipStream_t)stream, feat, mask, denorm_mask, sums, counts, C, H, W, vec);
+    static const int grp = [] { const char* e = getenv("PG_SPADE_SUMS_G"); return e ? atoi(e) : 0; }();      // dev A/B: planes per workgroup (default: 4 where that still gives every CU a workgroup, else 2)
+    const int g = grp ? grp : ((int64_t)N * C / 4 >= pg::num_cu() ? 4 : 2);
+    if (g == 4 && C % 4 == 0) hipLaunchKernelGGL(spade_masked_sums_kernel<4>, dim3((unsigned)(N * C / 4)), dim3(IN_THREADS), 0, (hipStream_t)stream, feat, mask, denorm_mask, sums, counts, C, H, W, vec);
+    else if (g >= 2 && C % 2 == 0) hipLaunchKernelGGL(spade_masked_sums_kernel<2>, dim3((unsigned)(N * C / 2)), dim3(IN_THREADS), 0, (hipStream_t)stream, feat, mask, denorm_mask, sums, counts, C, H, W, vec);
     else hipLaunchKernelGGL(spade_masked_sums_kernel<1>, dim3((unsigned)(N * C)), dim3(IN_THREADS), 0, (hipStream_t)stream, feat, mask, denorm_mask, sums, counts, C, H, W, vec);
     return pg::launch_status();
 }
@@ -1170,7 +1174,9 @@ PG_EXPORT int pg_spade_feat_assemble(const float* feat_upper, const float* feat_
         if (chunks > want) chunks = want;
         if (chunks < 1) chunks = 1;
     }
-    hipLaunchKernelGGL(spade_feat_assemble_kernel, dim3((unsigned)(vec ? N : N * C), (unsigned)chunks), dim3(256), 0, (hipStream_t)stream,
+    static const int zsplit = [] { const char* e = getenv("PG_SPADE_ASM_Z"); return e && atoi(e) > 0 ? atoi(e) : 2; }();      // channel groups per pixel chunk (the masks are re-read per group: cheap)
+    const int gz = vec ? (C >= 4 * zsplit ? zsplit : 1) : 1;
+    hipLaunchKernelGGL(spade_feat_assemble_kernel, dim3((unsigned)(vec ? N : N * C), (unsigned)chunks, (unsigned)gz), dim3(256), 0, (hipStream_t)stream,
                        feat_upper, feat_lower, mask_upper, mask_lower, denorm_mask_upper, denorm_mask_lower,
                        sums_upper, sums_lower, counts_upper, counts_lower, out, C, H, W, vec);
     return pg::launch_status();

@@ -1363,6 +1363,25 @@ class SynthesisNetworkFull_v18(nn.Module):
                 last_start, start = start, start + block.num_conv
             entries += [('texture', m, last_start + i, g) for m, i, g in self.texture_b512.affine_layers()]
             pre = _batched_affine(self, entries, ws.to(torch.float32), self.num_ws, self.w_dim)
+            if os.environ.get('PG_PREP_BATCHED', '1') != '0':
+                # ... and the demodulation coefficients of the 15 modulated 3x3 convolutions (networks.py:64-68) as ONE launch instead of one ~6 us launch (+ its
+                # launch gap) per layer: each layer's own `modconv_prep` call finds its result waiting (round 5; the 16-bit stack has done this since round 4)
+                jobs, seen = [], {}
+                for key, m, _, _ in entries:
+                    j = seen.get(key, 0)
+                    seen[key] = j + 1
+                    if isinstance(m, SynthesisLayer) and getattr(m, '_cache', None) is not None:
+                        w2 = m._cache.get(('w2',), [m.weight], lambda m=m: conv2d_mfma.modconv_w2(m.weight))
+                        jobs.append((w2, pre[key][j], int(m.weight.shape[0]), False, True))
+                if 0 < len(jobs) <= conv2d_mfma.PREP_MAX_JOBS:
+                    conv2d_mfma.modconv_prep_batched(jobs)
+        try:
+            return self._forward_body(ws, styles, pre, pose_feat, cat_feat, denorm_upper_input, denorm_lower_input, denorm_upper_mask, denorm_lower_mask, gt_parsing, block_kwargs)
+        finally:
+            if pre is not None:
+                conv2d_mfma.modconv_prep_clear()
+
+    def _forward_body(self, ws, styles, pre, pose_feat, cat_feat, denorm_upper_input, denorm_lower_input, denorm_upper_mask, denorm_lower_mask, gt_parsing, block_kwargs):
         x = img = pred_parsing = None
         kept = {}
         for res, w in zip(self.block_resolutions, styles):

@@ -1250,6 +1250,50 @@ def test_config4_generator_gradients_full_width_vs_oracle():
     assert n_grad > 100
 
 
+@pytest.mark.parametrize('graphs', [False, True], ids=['eager', 'graphed'])
+def test_training_step_gain_fold_equals_multiplies(graphs, monkeypatch):
+    """PG_GAIN_FOLD (round 5): the pre-scaled weight copies + gains applied in the bucket's gather must leave the same weights and Adam statistics as the
+    per-call `weight * weight_gain` multiplies they replace -- product discriminators (equalised-LR convolutions, R1 double backward), stub generator, 5 iterations;
+    one discriminator weight is edited IN PLACE after the step object exists (a checkpoint load would do that): its copy is stale when the first phase runs and must
+    be refreshed on the spot, not bypassed (the gather multiplies that gradient by the gain either way).  float32 discriminators: two runs of the SAME setting differ
+    by 2.4e-7 here and the two settings by 4.8e-7 (tools/probes/gain_fold_noise.py); with a half-precision block two runs of the same setting already differ by
+    3.7e-4 after five Adam steps, which would hide anything this test looks for."""
+    import stubs
+    from training import networks as PN
+    from training.loss import StyleGAN2Loss
+    from training.training_step import TrainingStep
+    from oracle import network_ref as NR
+
+    def run(fold):
+        monkeypatch.setenv('PG_GAIN_FOLD', '1' if fold else '0')
+        torch.manual_seed(0)
+        nets = stubs.build(DEV)
+        for name, ch in (('D', 6), ('D_parsing', 10)):
+            ref = fill_module_(NR.Discriminator(**_d_kw(ch)), f'gf.{name}.')
+            d = PN.Discriminator(**_d_kw(ch))
+            d.load_state_dict(ref.state_dict(), strict=False)
+            nets[name] = d.to(DEV).train()
+        loss = StyleGAN2Loss(device=torch.device(DEV), **nets, style_mixing_prob=0, r1_gamma=10, l1_weight=50, mask_weight=1.0)
+        G_parts = {k: v for k, v in nets.items() if k.startswith('G_')}
+        step = TrainingStep(G_parts, nets['D'], nets['D_parsing'], loss, batch_size=4, graphs=graphs)
+        assert bool(step._gained) == fold
+        with torch.no_grad():
+            nets['D'].b8.conv0.weight.mul_(1.25)              # after the copies were made
+        b = stubs.batch(4, DEV)
+        for _ in range(5):
+            step.run([b])
+        torch.cuda.synchronize()
+        return {f'{k}.{n}': p.detach().clone() for k, m in nets.items() for n, p in m.named_parameters()}
+
+    plain, folded = run(False), run(True)
+    assert plain.keys() == folded.keys()
+    moved = 0
+    for k in plain:
+        assert torch.allclose(folded[k], plain[k], rtol=1e-5, atol=2e-6), (k, float((folded[k] - plain[k]).abs().max()))
+        moved += int(not torch.equal(folded[k], plain[k]))
+    assert PN._gained_provider[0] is None                     # armed only while a phase runs
+
+
 def test_training_step_graph_replay_equals_eager():
     """TrainingStep(graphs=True): every phase captured into a hipGraph the second time it is due and replayed afterwards must leave the
     same weights, Adam statistics and EMA as the eager step (the replay runs the very kernels the eager phase launches; packed-weight

@@ -328,8 +328,15 @@ class _Conv2dMfma16(torch.autograd.Function):
             dx = _input_gradient(dy, x.shape, weight, stride, padding, transposed, output_padding, fn=_Conv2dMfma16, mod=conv2d_mfma16)
         want_w = ctx.needs_input_grad[1] and not weight_gradients_disabled
         want_b = has_bias and ctx.needs_input_grad[2]
-        if want_w and native_weight_gradients16 and not transposed and not (torch.is_grad_enabled() and (dy.requires_grad or x.requires_grad)):
-            g = conv2d_mfma16.weight_gradient(x, dy, weight.shape, padding, stride=stride)        # float32 [Cout, Cin, kh, kw]; None = not covered
+        if want_w and native_weight_gradients16 and not (torch.is_grad_enabled() and (dy.requires_grad or x.requires_grad)):
+            if not transposed:
+                g = conv2d_mfma16.weight_gradient(x, dy, weight.shape, padding, stride=stride)    # float32 [Cout, Cin, kh, kw]; None = not covered
+            else:
+                # y = conv_transpose2d(x, w[Cin, Cout]): dw[ci, co] = the weight gradient of the strided convolution dy -> x, whose OIHW kernel has O = Cin, I = Cout --
+                # the same kernel with the roles swapped (as `_weight_gradient` does in float32).  Round 5: this case went to aten (MIOpen), whose stride-2 16-bit
+                # weight gradient is not run-to-run reproducible -- it is the input-gradient node of the half-precision down-sampling convolutions under R1's double
+                # backward (tools/probes/d_fp16_determinism.py: `bNN.conv1.weight` differed between identical runs).
+                g = conv2d_mfma16.weight_gradient(dy, x, weight.shape, padding, stride=stride)
             dw = g.to(weight.dtype) if g is not None else None
         if want_b and db is None and (dw is not None or not want_w):
             db = bias_act.channel_sum(dy, 1)

@@ -1250,6 +1250,39 @@ def test_config4_generator_gradients_full_width_vs_oracle():
     assert n_grad > 100
 
 
+@pytest.mark.parametrize('res,base,cmax', [(16, 256, 32), (64, 1024, 64)])
+def test_discriminator_fp16_gradients_are_reproducible(res, base, cmax):
+    """Two identical passes through a discriminator with a half-precision block must give bit-identical gradients, first order and through R1's double backward
+    (loss_fullbody.py:247-256).  Until round 5 the weight gradient of the INPUT-GRADIENT node of the fp16 down-sampling convolution -- a transposed convolution --
+    went to aten (MIOpen), whose stride-2 16-bit weight gradient is not run-to-run reproducible: `bNN.conv1.weight` differed between runs under R1
+    (tools/probes/d_fp16_determinism.py); conv2d_gradfix now runs it on the native kernel with the roles of x and dy swapped."""
+    from training import networks as PN
+    torch.manual_seed(0)
+    kw = dict(c_dim=6, img_resolution=res, img_channels=6, channel_base=base, channel_max=cmax, conv_clamp=256, mapping_kwargs=dict(num_layers=1),
+              epilogue_kwargs=dict(mbstd_group_size=2))
+    d = PN.Discriminator(**kw, num_fp16_res=1).to(DEV).train()
+    x, c = torch.randn(4, 6, res, res, device=DEV), torch.randn(4, 6, device=DEV)
+
+    def first_order():
+        for p in d.parameters():
+            p.grad = None
+        d(x, c).sum().backward()
+        return {n: p.grad.detach().clone() for n, p in d.named_parameters() if p.grad is not None}
+
+    def r1():
+        for p in d.parameters():
+            p.grad = None
+        xr = x.detach().requires_grad_(True)
+        gx, = torch.autograd.grad(d(xr, c).sum(), xr, create_graph=True)
+        (gx.square().sum([1, 2, 3]).mean() * 5).backward()
+        return {n: p.grad.detach().clone() for n, p in d.named_parameters() if p.grad is not None}
+    for fn in (first_order, r1):
+        a, b = fn(), fn()
+        assert a.keys() == b.keys() and len(a) > 10
+        bad = [n for n in a if not torch.equal(a[n], b[n])]
+        assert not bad, (fn.__name__, bad)
+
+
 @pytest.mark.parametrize('graphs', [False, True], ids=['eager', 'graphed'])
 def test_training_step_gain_fold_equals_multiplies(graphs, monkeypatch):
     """PG_GAIN_FOLD (round 5): the pre-scaled weight copies + gains applied in the bucket's gather must leave the same weights and Adam statistics as the

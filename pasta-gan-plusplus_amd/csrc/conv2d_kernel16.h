@@ -694,7 +694,7 @@ inline int small_tile16(int KH, int KW, int S, int OH, int OW, int Cout, int pha
     static const bool on = [] { const char* e = getenv("PG_CONV16_SMALL"); return e ? atoi(e) != 0 : true; }();
     if (!on || !((KH == 3 && KW == 3) || (KH == 2 && KW == 2)) || S != 1 || Cout < 128 || phase_cout % 64 != 0) return 0;      // (four-phase mode: whole cout blocks per phase)
     if (KH == 3 && OH <= 8 && OW <= 8 && phase_cout % 128 == 0) return 1;
-    static const int lim2 = [] { const char* e = getenv("PG_CONV16_SMALL2_MAX"); return e ? atoi(e) : 64; }();      // (measured on config 5: 16 -> 2.74, 32 -> 2.72, 64 -> 2.68 ms/step: less split-K)
+    static const int lim2 = [] { const char* e = getenv("PG_CONV16_SMALL2_MAX"); return e ? atoi(e) : 32; }();      // (round 4, config 5: 16 -> 2.74, 32 -> 2.72, 64 -> 2.68 ms/step; round 5, with split-K plans at one workgroup per CU: 32 -> 1.590 / 1.595, 64 -> 1.599 / 1.598, 16 -> 1.611 / 1.598)
     if (OH <= lim2 && OW <= lim2) return 2;
     return 0;
 }

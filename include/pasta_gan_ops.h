@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 11
+#define PG_ABI_VERSION 12
 
 enum pg_dtype { PG_F32 = 0, PG_F16 = 1, PG_BF16 = 2, PG_F64 = 3 };
 
@@ -241,6 +241,21 @@ int pg_conv2d_winograd4b_pack_weight(const float* w, float* packed, int Cout, in
 int pg_conv2d_winograd4b_forward(const float* x, const float* packed_u, float* y,
                                  int N, int Cin, int H, int W, int Cout, int pad_y, int pad_x, int OH, int OW,
                                  const int64_t ystride[4], const pg_conv2d_fusion* fusion, void* stream);
+
+/*
+ * The F(4x4, 3x3) one-workgroup kernel with its transform-domain GEMM on the bf16 matrix pipe (round 6; csrc/conv2d_wino4.h, X3 form): every float32 operand
+ * of that GEMM is the exact sum of three bf16 values (truncation split, 8 + 8 + 8 significand bits) and the product is evaluated as the six largest of the nine
+ * plane products on v_mfma_f32_32x32x16_bf16 with float32 accumulation -- float32-class results (the three dropped products are below 2^-24 of the product),
+ * at 6/16 of the fp32 MFMA's issue time.  The transformed weights are the float32 values of pg_conv2d_winograd4_pack_weight, split once per weight version:
+ * pg_conv2d_winograd4x3_packed_size float32 units (6 bytes per transformed weight).  Same call contract, acceptance rules, fused stages and statistics as
+ * pg_conv2d_winograd4_forward.
+ */
+int64_t pg_conv2d_winograd4x3_packed_size(int Cout, int Cin);
+int pg_conv2d_winograd4x3_pack_weight(const float* w, float* packed, int Cout, int Cin,
+                                      float scale, int flip_hw, int transpose_oi, void* stream);
+int pg_conv2d_winograd4x3_forward(const float* x, const float* packed_u, float* y,
+                                  int N, int Cin, int H, int W, int Cout, int pad_y, int pad_x, int OH, int OW,
+                                  const int64_t ystride[4], const pg_conv2d_fusion* fusion, void* stream);
 
 /* Statistics gathered by pg_conv2d_winograd4_forward (pg_conv2d_fusion::stats_partial): tiles of one image for an OH x OW output, and the
  * reduction of the per-tile (sum, M2) pairs into mean[n*C + c] and rstd = 1 / sqrt(var + eps) (biased variance over OH*OW): Chan's pairwise merge in

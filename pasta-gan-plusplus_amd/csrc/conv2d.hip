@@ -123,6 +123,56 @@ __global__ __launch_bounds__(256) void wino4_pack_kernel(const float* __restrict
     }
 }
 
+// The same transform for the X3 form of conv2d_wino4.h: U rounded to float32 once (the value the fp32 form multiplies by), then split exactly into three bf16
+// planes by truncation (u = p0 + p1 + p2, 8 + 8 + 8 significand bits), stored [m-block 64][mt][a][chunk 16 ch][b 6][plane 3][lane = (h, co & 31)][j 8] as 16-bit
+// words with channel = 16 chunk + 2 j + h: one 16-byte word per lane = the A operand of one v_mfma_f32_32x32x16_bf16.
+__global__ __launch_bounds__(256) void wino4x3_pack_kernel(const float* __restrict__ w, unsigned short* __restrict__ up, int Cout, int Cin,
+                                                           int CinP, int CoutP, float scale, int flip, int transpose_oi) {
+    const double G[6][3] = {{0.25, 0.0, 0.0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                            {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0.0, 0.0, 1.0}};
+    const int nchunks = CinP / 16;
+    const int64_t total = (int64_t)CinP * CoutP;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int co = (int)(i % CoutP), ci = (int)(i / CoutP);
+        double g[3][3];
+#pragma unroll
+        for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+            for (int kx = 0; kx < 3; kx++) {
+                double v = 0.0;
+                if (co < Cout && ci < Cin) {
+                    const int sy = flip ? 2 - ky : ky, sx = flip ? 2 - kx : kx;
+                    const int64_t src = transpose_oi ? (((int64_t)ci * Cout + co) * 3 + sy) * 3 + sx
+                                                     : (((int64_t)co * Cin + ci) * 3 + sy) * 3 + sx;
+                    v = (double)(w[src] * scale);
+                }
+                g[ky][kx] = v;
+            }
+        double tg[6][3];                                 // G g
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+#pragma unroll
+            for (int kx = 0; kx < 3; kx++) tg[a][kx] = G[a][0] * g[0][kx] + G[a][1] * g[1][kx] + G[a][2] * g[2][kx];
+        const int mb = co >> 6, mt = (co >> 5) & 1, m = co & 31;
+        const int k = ci >> 4, cc = ci & 15, j = cc >> 1, h = cc & 1;
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+#pragma unroll
+            for (int b = 0; b < 6; b++) {
+                const float u = (float)(tg[a][0] * G[b][0] + tg[a][1] * G[b][1] + tg[a][2] * G[b][2]);      // (G g) G^T, rounded once
+                const unsigned u0 = __float_as_uint(u) & 0xffff0000u;
+                const float r = u - __uint_as_float(u0);
+                const unsigned u1 = __float_as_uint(r) & 0xffff0000u;
+                const unsigned u2 = __float_as_uint(r - __uint_as_float(u1)) & 0xffff0000u;
+                const int64_t unit = ((int64_t)(mb * 2 + mt) * 6 + a) * nchunks + k;
+                const int64_t dst = (((unit * 6 + b) * 3) * 64 + (h * 32 + m)) * 8 + j;                     // plane 0; planes are 64 * 8 words apart
+                up[dst] = (unsigned short)(u0 >> 16);
+                up[dst + 512] = (unsigned short)(u1 >> 16);
+                up[dst + 1024] = (unsigned short)(u2 >> 16);
+            }
+    }
+}
+
 // The same transform in the order the waves of conv2d_wino4b.h walk it (two workgroups per CU, v_mfma_f32_16x16x4_f32):
 //   [m-block 64][cout block cb 4][row half ah 2][chunk 16 ch][e = 6 a' + b (18)][lane = (kq, m) 64][j 4]
 //   with xi = 6 (3 ah + a') + b, cout = 64 mb + 16 cb + m, channel = 16 chunk + 4 j + kq: one 16-byte word per lane = the A operands of the four K steps of one xi.
@@ -653,12 +703,12 @@ static int conv_forward(int winograd, const float* x, const float* packed_w, flo
     if (p.in_xform && (!(p.f.in_gain > 0.f) || p.f.in_alpha < 0.f || p.f.in_alpha > 1.f)) return PG_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
 
-    if (p.f.stats_partial && winograd != 2) return PG_ERR_UNSUPPORTED;      // output statistics: the F(4x4) one-workgroup kernel's plain tail only
+    if (p.f.stats_partial && winograd != 2 && winograd != 4) return PG_ERR_UNSUPPORTED;      // output statistics: the F(4x4) one-workgroup kernel's plain tail only
     if (winograd) {
         if (p.f.x2) return PG_ERR_UNSUPPORTED;                  // two-source launches stay on the direct kernel
         if (pad_x < 0 || pad_x > 4) return PG_ERR_UNSUPPORTED;  // the LDS halo row starts 4 columns left of the tile
         p.CoutP = round_up(Cout, 64);
-        return winograd == 3 ? pgconv::launch_wino4b(p, s) : winograd == 2 ? pgconv::launch_wino4(p, s) : pgconv::launch_wino(p, s);
+        return winograd == 4 ? pgconv::launch_wino4x3(p, s) : winograd == 3 ? pgconv::launch_wino4b(p, s) : winograd == 2 ? pgconv::launch_wino4(p, s) : pgconv::launch_wino(p, s);
     }
     pg_conv2d_fusion tail = p.f;
     const int64_t slice = (int64_t)N * Cout * OH * OW;
@@ -770,6 +820,28 @@ PG_EXPORT int pg_conv2d_winograd4_forward(const float* x, const float* packed_u,
                                           int N, int Cin, int H, int W, int Cout, int pad_y, int pad_x, int OH, int OW,
                                           const int64_t ystride[4], const pg_conv2d_fusion* fusion, void* stream) {
     return conv_forward(2, x, packed_u, y, N, Cin, H, W, Cout, 3, 3, 1, pad_y, pad_x, OH, OW, ystride, 1, 1, 0, 0, fusion, stream);
+}
+
+PG_EXPORT int64_t pg_conv2d_winograd4x3_packed_size(int Cout, int Cin) {      // in float32 units (6 bytes per transformed weight)
+    if (Cout <= 0 || Cin <= 0) return 0;
+    return (int64_t)54 * round_up(Cin, 16) * round_up(Cout, 64);
+}
+
+PG_EXPORT int pg_conv2d_winograd4x3_pack_weight(const float* w, float* packed, int Cout, int Cin,
+                                                float scale, int flip_hw, int transpose_oi, void* stream) {
+    if (!w || !packed || Cout <= 0 || Cin <= 0) return PG_ERR_INVALID_ARG;
+    const int CinP = round_up(Cin, 16), CoutP = round_up(Cout, 64);
+    const int64_t total = (int64_t)CinP * CoutP;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > pg::max_stream_blocks()) blocks = pg::max_stream_blocks();
+    hipLaunchKernelGGL(wino4x3_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, (unsigned short*)packed, Cout, Cin, CinP, CoutP, scale, flip_hw, transpose_oi);
+    return pg::launch_status();
+}
+
+PG_EXPORT int pg_conv2d_winograd4x3_forward(const float* x, const float* packed_u, float* y,
+                                            int N, int Cin, int H, int W, int Cout, int pad_y, int pad_x, int OH, int OW,
+                                            const int64_t ystride[4], const pg_conv2d_fusion* fusion, void* stream) {
+    return conv_forward(4, x, packed_u, y, N, Cin, H, W, Cout, 3, 3, 1, pad_y, pad_x, OH, OW, ystride, 1, 1, 0, 0, fusion, stream);
 }
 
 PG_EXPORT int pg_conv2d_winograd4b_pack_weight(const float* w, float* packed, int Cout, int Cin,

@@ -500,6 +500,7 @@ int launch_k1s2(const ConvParams& p, hipStream_t s);
 int launch_wino(const ConvParams& p, hipStream_t s);     // conv2d_wino.h
 int launch_wino4b(const ConvParams& p, hipStream_t s);   // conv2d_wino4b.h: F(4x4,3x3), two workgroups per CU (16x16x4 MFMA); PG_ERR_UNSUPPORTED when the launch is not its kind
 int launch_wino4(const ConvParams& p, hipStream_t s);    // conv2d_wino4.h: F(4x4,3x3); PG_ERR_UNSUPPORTED when the launch is not its kind
+int launch_wino4x3(const ConvParams& p, hipStream_t s);  // conv2d_wino4.h, X3 form: the transform-domain GEMM on the bf16 pipe (three-term operand splits); same acceptance as launch_wino4
 int launch_s1x1(const ConvParams& p, hipStream_t s);     // conv2d_s1x1.h: streaming 1x1 (returns PG_ERR_UNSUPPORTED when the launch is not its kind)
 
 }  // namespace pgconv

@@ -42,6 +42,13 @@
                          // debugging switches that stay correct: 256 chore waves drain their queue at the end of every chunk, 512 every U wait is vmcnt(0)
 #endif
 
+#ifndef W4X_EXP
+#define W4X_EXP 0        // dev switches of the X3 form: 512 no early cache-line touches of the next halo; ablations (results wrong by design): 4 no operand split (raw words as
+                         // B operands), 8 no MFMAs.  (Tried and removed, all parity-green, tools/wino4_variants.py: start stagger of the three waves of a SIMD, fixed / per-block
+                         // wave priorities, the halo requested after group 0 / 1 / 2, two groups across the transform phase, A planes re-requested as soon as their last
+                         // MFMA is out, every wave requesting a share of the halo: each within +-2 %; v_pk_add_f32 in the split: 1.6x SLOWER.)
+#endif
+
 namespace pgconv {
 
 constexpr bool W4_EX2 = (WINO4_EXP & 8192) != 0;  // timing experiment (round 4, parity- and stress-green): two exchange buffers in the tail, one barrier per round instead of two --
@@ -58,6 +65,21 @@ constexpr int W4_V = 36 * 512;                   // V[xi][channel 16][tile 32]  
 constexpr int W4_UGROUP = 3 * 1024;              // bytes of one A-operand group (3 xi x 64 lanes x 16 B)
 constexpr int W4_UCHUNK = 4 * W4_UGROUP;         // per (wave unit = (m-block, mt, a), chunk): groups (jg, quad)
 constexpr int W4_EX = 6 * 16 * 32 * 4;           // exchange floats per round: [a][cout 16][tile 32][4 columns]
+constexpr int W4_UCHUNK_X3 = 6 * W4_UGROUP;      // X3 form: per (wave unit, chunk) six groups (b), each three planes x 64 lanes x 16 B (8 bf16 channels)
+typedef __bf16 w4_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned w4_u32x4 __attribute__((ext_vector_type(4)));
+
+// X3 form: a float32 value is the exact sum of three bf16 values (8 + 8 + 8 significand bits, by truncation).  Two values of adjacent K slots -> the three
+// packed operand words (plane 0 = leading bits, 1 = middle, 2 = trailing), low half = the first value: 4 v_and + 4 v_sub + 3 v_perm per pair.
+__device__ __forceinline__ void w4_split_pair(float va, float vb, unsigned& p0, unsigned& p1, unsigned& p2) {
+    const unsigned ua = __float_as_uint(va), ub = __float_as_uint(vb);
+    const float ra = va - __uint_as_float(ua & 0xffff0000u), rb = vb - __uint_as_float(ub & 0xffff0000u);
+    const unsigned ura = __float_as_uint(ra), urb = __float_as_uint(rb);
+    const float la = ra - __uint_as_float(ura & 0xffff0000u), lb = rb - __uint_as_float(urb & 0xffff0000u);
+    p0 = __builtin_amdgcn_perm(ub, ua, 0x07060302u);
+    p1 = __builtin_amdgcn_perm(urb, ura, 0x07060302u);
+    p2 = __builtin_amdgcn_perm(__float_as_uint(lb), __float_as_uint(la), 0x07060302u);
+}
 
 // 1-D transforms.  B^T rows (input), A^T rows (output) of F(4,3) with points 0, 1, -1, 2, -2, inf.
 __device__ __forceinline__ void w4_bt(float d0, float d1, float d2, float d3, float d4, float d5,
@@ -121,7 +143,11 @@ __device__ __forceinline__ int w4_fresh_lane() {
 //                  with the statistics as a run-time branch of the plain tail every plain launch paid for the extra scalar registers
 //   W4_TAIL_RES / W4_TAIL_NOISE (residual only / noise only) compile cleanly too but measured +1 % / -1 ... +5 %: not instantiated.
 enum { W4_TAIL_ANY = 0, W4_TAIL_PLAIN = 1, W4_TAIL_SPADE = 2, W4_TAIL_RES = 3, W4_TAIL_NOISE = 4, W4_TAIL_STATS = 5 };
-template <int MODE, int TAIL>
+// X3 (round 6): the Winograd-domain GEMM on v_mfma_f32_32x32x16_bf16 as six products of exact three-term operand splits (fp32 accumulation): U is split once per
+// weight version by pg_conv2d_winograd4x3_pack_weight, the V values a lane reads from LDS are split in registers by the multiplying wave itself -- LDS keeps the
+// float32 V, the transform phase and the tail are the fp32 form's.  Per (xi, 16-channel chunk): 44 VALU + 6 MFMAs of 32 cycles instead of 8 MFMAs of 64 cycles;
+// the vector work of one wave runs beside the matrix work of the other two waves of its SIMD.
+template <int MODE, int TAIL, bool X3 = false>
 __global__ __launch_bounds__(768, 3) void conv2d_wino4(ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int cin_loop = ((p.Cin + W4_KC - 1) / W4_KC) * W4_KC;
@@ -132,6 +158,7 @@ __global__ __launch_bounds__(768, 3) void conv2d_wino4(ConvParams p) {
     unsigned* gmE = gmI + W4_NDMA * 256;         // gather map of the current edge tile (absolute in the image, sentinel outside)
     float* cs0 = (float*)(gmE + W4_NDMA * 256);  // prologue scale of two consecutive tiles [2][cin_loop]
     float* ep0 = cs0 + 2 * cin_loop;             // epilogue scale / bias of two consecutive tiles [2][64 + 64]
+    float* touch_sink = ep0 + 256;               // X3 form: 64 floats nobody reads (LDS target of the halo's cache-line touches)
     // (W4_EX2: the tail's SECOND exchange buffer is the last third of V plus both gather maps -- exactly W4_EX floats; the chore waves rebuild
     //  the maps during the next tile's first transform phase, which they sit out anyway)
     static_assert(W4_V - W4_EX + 2 * W4_NDMA * 256 == W4_EX, "second exchange buffer = tail of V + the two gather maps");
@@ -225,13 +252,38 @@ __global__ __launch_bounds__(768, 3) void conv2d_wino4(ConvParams p) {
 #endif
     };
 
+    // X3 form: the halo of the chunk that the NEXT GEMM phase will request, touched one transform phase early -- one dword per 128-byte line (4 per 288-byte row:
+    // words 0, 8, 16, 17) as LDS-DMA into a sink, 3 requests per chore thread (640 touches, the last 128 slots repeat).  Why: the CU's vector memory path returns in
+    // order, so the HBM misses of the halo DMA (~2 k cycles) used to hold back every wave's A words queued behind them, once per chunk, in the phase that lives on
+    // that stream; touched during the transform phase -- when no wave waits for vector memory -- the lines are in L2 by the time the DMA asks for them.
+    constexpr int W4_NTOUCH = 3;
+    auto touch_chunk = [&](int c0) __attribute__((always_inline)) {
+        if (chore) {
+            const int soff = c0 * HW * 4;
+            const unsigned* gm = edge ? gmE : gmI;
+            const int tc = 64 * cw + w4_fresh_lane();
+            const unsigned sink_b = smem_b + (unsigned)((touch_sink - smem) * 4);
+#pragma unroll
+            for (int i = 0; i < W4_NTOUCH; i++) {
+                int idx = i * 256 + tc;
+                idx = idx < 640 ? idx : idx - 128;
+                const int row = idx >> 2, part = idx & 3;
+                const int f = (row / 10) * 180 + (row % 10) * 18 + (part == 3 ? 17 : 8 * part);
+                const unsigned off = gm[f];
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dword %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "s"(sink_b), "v"(off), "s"(xrsrc), "s"(soff) : "memory");
+            }
+        }
+    };
+
     f32x16 acc[6];                                   // [b]; never zeroed: see `chunk`
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
     // A-operand stream of this wave: [m-block][mt][a][chunk][group = (jg, quad)][xi 3][lane 64][4 pairs] floats, walked strictly
     // forwards inside a tile, one group ahead.
     unsigned pa;
-    auto a_reset = [&](int m0_) { pa = (unsigned)((((m0_ >> 6) * 2 + mt) * 6 + ta) * nchunks) * (unsigned)W4_UCHUNK + (unsigned)w4_fresh_lane() * 16u; };
+    auto a_reset = [&](int m0_) { pa = (unsigned)((((m0_ >> 6) * 2 + mt) * 6 + ta) * nchunks) * (unsigned)(X3 ? W4_UCHUNK_X3 : W4_UCHUNK) + (unsigned)w4_fresh_lane() * 16u; };
     auto load_u = [&](f32x4 (&dst)[3]) {
 #if !(WINO4_EXP & 1)
         asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst[0]) : "v"(pa), "s"(p.wp));
@@ -269,10 +321,17 @@ __global__ __launch_bounds__(768, 3) void conv2d_wino4(ConvParams p) {
 
 
 #if WINO4_EXP & 128
-    unsigned long long stamp[16];
+    // stamps go straight to LDS (wave w: stamp_lds[40 w + i], low 32 bits of s_memtime): held in registers they pushed the kernel into scratch spills
+    unsigned* stamp_lds = (unsigned*)(touch_sink + 64);
     int tiles_done = 0;
-#define W4_STAMP(i) do { if (tiles_done == 1) stamp[i] = __builtin_amdgcn_s_memtime(); } while (0)
+    auto put_stamp = [&](int i) __attribute__((always_inline)) {
+        const unsigned t = (unsigned)__builtin_amdgcn_s_memtime();
+        if (w4_fresh_lane() == 0) stamp_lds[40 * wave + i] = t;
+    };
+#define W4_STAMP(i) do { if (tiles_done == 1) put_stamp(i); } while (0)
+#define W4_XSTAMP(i) do { if (tiles_done == 1 && k == 2) put_stamp(16 + (i)); } while (0)
 #else
+#define W4_XSTAMP(i) do { } while (0)
 #define W4_STAMP(i) do { } while (0)
 #endif
     int tile = blockIdx.x;
@@ -301,6 +360,11 @@ __global__ __launch_bounds__(768, 3) void conv2d_wino4(ConvParams p) {
             __syncthreads();                                            // A: raw(k) has landed (the issuing waves waited for their requests at
                                                                         //    their third U group), V is free (every wave is past GEMM(k-1) / the tail)
             if (k == 2) W4_STAMP(1);
+            bool touched = false;
+            if (X3 && !(W4X_EXP & 512) && nchunks >= 2 && (k + 1 < nchunks || has_next)) {      // (k + 1 == nchunks: the state is already the next tile's, see request_next)
+                touch_chunk(k + 1 < nchunks ? (k + 1) * W4_KC : 0);
+                touched = true;
+            }
             if (W4_EX2 && k == 0 && tiles_run > 0) {     // the previous tile's tail used the maps' LDS as exchange space: the chore waves (idle in this phase) rebuild them
                 build_gmI();
                 if (edge) build_gmE(oy0 - p.pad_y, ox0 - 4);
@@ -378,6 +442,56 @@ __global__ __launch_bounds__(768, 3) void conv2d_wino4(ConvParams p) {
                     else issued = false;
                 }
             };
+            if constexpr (X3) {
+                // ---- GEMM phase, X3 form: six groups = the six xi of this wave's row; group g: A = three 16-byte words (planes 0..2 of the lane's 8 channels
+                // 2 j + h), B = the lane's 8 float32 V values split here into three packed planes.  Ring: group g in slot g & 1; group 1 requested above,
+                // group g + 2 after the MFMAs of group g (g = 4: group 0 of the next chunk / tile; g = 5: nothing -- two groups crossing the transform phase
+                // measured +-0 and their 12 live registers spill in the SPADE tail).  B values are read one group ahead.
+                request_next();
+                const bool dma_q = issued && chore;
+                const float* vb = V + 6 * ta * 512 + w4_fresh_lane();
+                float br[8];                                                // (one buffer: the next group's values are requested as soon as this group's are split -- the six MFMAs cover the LDS latency)
+                auto read_b8 = [&](int b, float (&dst)[8]) {
+#pragma unroll
+                    for (int j = 0; j < 8; j++) dst[j] = vb[b * 512 + j * 64];
+                };
+                read_b8(0, br);
+                W4_XSTAMP(0);
+#pragma unroll
+                for (int g = 0; g < 6; g++) {
+                    w4_u32x4 bp[3];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        unsigned p0, p1, p2;
+                        if (W4X_EXP & 4) { p0 = __float_as_uint(br[2 * q]); p1 = __float_as_uint(br[2 * q + 1]); p2 = p0; }
+                        else w4_split_pair(br[2 * q], br[2 * q + 1], p0, p1, p2);
+                        bp[0][q] = p0; bp[1][q] = p1; bp[2][q] = p2;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);                       // the split runs BEFORE the wait for this group's A words
+                    if (g + 1 < 6) read_b8(g + 1, br);
+                    W4_XSTAMP(1 + 3 * g);
+                    if (g == 0 && dma_q && touched) {                        // behind group 0's words in this wave's queue: the touches, group 1's words (3), the DMA
+                        if (cw == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 + W4_NTOUCH + W4_NDMA));
+                        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 + W4_NTOUCH + W4_NDMA - 1));
+                        asm volatile("" : "+v"(ur[0][0]), "+v"(ur[0][1]), "+v"(ur[0][2]));
+                    } else wait_u(ur[g & 1], g < 2 && dma_q);               // (g = 1: the touches are OLDER than group 1's words, which are requested at the top of this phase)
+                    W4_XSTAMP(2 + 3 * g);
+                    __builtin_amdgcn_sched_barrier(0);
+                    // small products first:  u2 v0,  u1 v1,  u1 v0,  u0 v2,  u0 v1,  u0 v0
+                    constexpr int PA[6] = {2, 1, 1, 0, 0, 0}, PB[6] = {0, 1, 0, 2, 1, 0};
+#pragma unroll
+                    for (int t = 0; t < 6; t++)
+                        if (!(W4X_EXP & 8) || bp[0][0] == 0x12345678u) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(w4_bf16x8, ur[g & 1][PA[t]]), __builtin_bit_cast(w4_bf16x8, bp[PB[t]]),
+                                                                         (FIRST && t == 0) ? zero16 : acc[g], 0, 0, 0);
+                    W4_XSTAMP(3 + 3 * g);
+                    if (g == 4 && k + 1 == nchunks) a_reset(m0);             // from here on: the next tile's first group (m0 is already the next tile's)
+                    if (g < 5) load_u(ur[g & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (k == 2) W4_STAMP(4);
+                if (!issued) dma_wait_all();                                 // last chunk of the last tile: nothing counted behind us
+                if ((WINO4_EXP & 256) && chore) dma_wait_all();
+            } else {
             constexpr bool LATE = (WINO4_EXP & 1024) != 0;               // timing experiment: the chore waves request the next chunk after group 1's MFMAs instead of before group 0's
             // W4_SPREAD (timing experiment, bit 16384): a third of the chunk's requests behind each of the first three MFMA groups, so that a request's issue
             // overlaps the wave's own MFMA in flight instead of delaying its first one; the next tile is then prepared after the last third.  Measured (round 4,
@@ -445,6 +559,7 @@ __global__ __launch_bounds__(768, 3) void conv2d_wino4(ConvParams p) {
             if (LATE && dma_q) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");   // the halo must have landed before the next barrier A; only the next chunk's first U group is younger
             if (!issued) dma_wait_all();                                 // last chunk of the last tile: nothing counted behind us
             if ((WINO4_EXP & 256) && chore) dma_wait_all();
+            }
         };
         chunk(0, std::true_type{});
 #pragma unroll 1
@@ -701,7 +816,8 @@ __global__ __launch_bounds__(768, 3) void conv2d_wino4(ConvParams p) {
         }
 #if WINO4_EXP & 128
         if (tiles_done == 1 && blockIdx.x == 0 && (w4_fresh_lane() == 0)) {
-            for (int i = 0; i < 15; i++) ((unsigned*)p.y)[wave * 16 + i] = (unsigned)(stamp[i] - stamp[0]);
+            for (int i = 0; i < 15; i++) ((unsigned*)p.y)[wave * 16 + i] = stamp_lds[40 * wave + i] - stamp_lds[40 * wave];
+            if (X3) for (int i = 0; i < 19; i++) ((unsigned*)p.y)[192 + wave * 20 + i] = stamp_lds[40 * wave + 16 + i] - stamp_lds[40 * wave];
         }
         tiles_done++;
 #endif
@@ -712,7 +828,7 @@ __global__ __launch_bounds__(768, 3) void conv2d_wino4(ConvParams p) {
     }
 }
 
-template <int MODE, int TAIL>
+template <int MODE, int TAIL, bool X3 = false>
 int launch_wino4_mode(const ConvParams& p0, hipStream_t s) {
     ConvParams p = p0;
     p.tilesX = (p.OW + 63) / 64;
@@ -722,8 +838,8 @@ int launch_wino4_mode(const ConvParams& p0, hipStream_t s) {
     if (tiles > 0x7fffffffLL) return PG_ERR_TOO_LARGE;
     p.total_tiles = (int)tiles;
     const int cin_loop = ((p.Cin + W4_KC - 1) / W4_KC) * W4_KC;
-    const size_t lds = ((size_t)W4_RAW + W4_V + 2 * cin_loop + 256 + 2 * W4_NDMA * 256) * sizeof(float);
-    if ((int64_t)36 * cin_loop * p.CoutP * 4 > 0x7fffffffLL) return PG_ERR_TOO_LARGE;      // the U stream uses 32-bit byte offsets
+    const size_t lds = ((size_t)W4_RAW + W4_V + 2 * cin_loop + 256 + 64 + ((WINO4_EXP & 128) ? 12 * 40 : 0) + 2 * W4_NDMA * 256) * sizeof(float);
+    if ((int64_t)36 * cin_loop * p.CoutP * (X3 ? 6 : 4) > 0x7fffffffLL) return PG_ERR_TOO_LARGE;      // the U stream uses 32-bit byte offsets
     {   // the tail addresses one image of y / residual / spade_x with 32-bit byte offsets
         const int64_t ext = 1 + (int64_t)(p.f.spade_x ? p.Cout / 2 - 1 : p.Cout - 1) * p.ys[1] + (int64_t)(p.OH - 1) * p.ys[2] + (int64_t)(p.OW - 1) * p.ys[3];
         if (ext * 4 > 0xffffffffLL || (int64_t)p.OH * p.OW * 4 > 0xffffffffLL) return PG_ERR_TOO_LARGE;
@@ -735,9 +851,9 @@ int launch_wino4_mode(const ConvParams& p0, hipStream_t s) {
         ((((uintptr_t)p.y) | ((uintptr_t)p.f.noise) | ((uintptr_t)p.f.residual) | ((uintptr_t)p.f.spade_x)) & 15) != 0) return PG_ERR_UNSUPPORTED;
     const int64_t blocks = tiles < (int64_t)num_cu() ? tiles : (int64_t)num_cu();
     static PerDeviceOnce lds_attr;
-    const hipError_t e = lds_attr.run([] { return hipFuncSetAttribute((const void*)conv2d_wino4<MODE, TAIL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+    const hipError_t e = lds_attr.run([] { return hipFuncSetAttribute((const void*)conv2d_wino4<MODE, TAIL, X3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((conv2d_wino4<MODE, TAIL>), dim3((unsigned)blocks), dim3(768), lds, s, p);
+    hipLaunchKernelGGL((conv2d_wino4<MODE, TAIL, X3>), dim3((unsigned)blocks), dim3(768), lds, s, p);
     return launch_status();
 }
 

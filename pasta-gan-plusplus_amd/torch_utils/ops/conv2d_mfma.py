@@ -106,6 +106,12 @@ def _init(plugin_name='conv2d_plugin'):
         lib.pg_conv2d_winograd4_pack_weight.argtypes = [vp, vp, i, i, f, i, i, vp]
         lib.pg_conv2d_winograd4_forward.restype = i
         lib.pg_conv2d_winograd4_forward.argtypes = [vp, vp, vp, i, i, i, i, i, i, i, i, i, ctypes.POINTER(i64), ctypes.POINTER(Fusion), vp]
+        lib.pg_conv2d_winograd4x3_packed_size.restype = i64
+        lib.pg_conv2d_winograd4x3_packed_size.argtypes = [i, i]
+        lib.pg_conv2d_winograd4x3_pack_weight.restype = i
+        lib.pg_conv2d_winograd4x3_pack_weight.argtypes = [vp, vp, i, i, f, i, i, vp]
+        lib.pg_conv2d_winograd4x3_forward.restype = i
+        lib.pg_conv2d_winograd4x3_forward.argtypes = [vp, vp, vp, i, i, i, i, i, i, i, i, i, ctypes.POINTER(i64), ctypes.POINTER(Fusion), vp]
         lib.pg_conv2d_winograd4_stats_tiles.restype = i
         lib.pg_conv2d_winograd4_stats_tiles.argtypes = [i, i]
         lib.pg_instance_norm_finish.restype = i
@@ -164,12 +170,15 @@ def _init(plugin_name='conv2d_plugin'):
 # stream from L2), so it serves images narrower than 64 pixels.  PG_WINO4B=0: never, PG_WINO4B=2: wherever F(4x4) runs (A/B runs).
 _WINO4B = os.environ.get('PG_WINO4B', '1')
 F4_FORM = 2 if _WINO4B == '0' else 3      # the form for narrow images (tests import this)
+# Round 6: 4 = the one-workgroup kernel with its transform-domain GEMM on the bf16 pipe (six products of exact three-term splits, fp32 accumulation; csrc/conv2d_wino4.h "X3"):
+# same results class (error against float64 at or below the fp32 form's, tools/wino4x3_probe.py), 1.03-1.26x faster per launch.  PG_WINO4_X3=0: the fp32-MFMA form (A/B runs).
+F4_WIDE = 2 if os.environ.get('PG_WINO4_X3', '1') == '0' else 4      # the form for images at least 64 pixels wide (tests import this)
 
 
 def f4_form(hw):
     if _WINO4B == '2':
         return 3
-    return F4_FORM if int(hw[1]) < 64 else 2
+    return F4_FORM if int(hw[1]) < 64 else F4_WIDE
 
 
 def use_winograd(kh, kw, stride, cout, cin=None, x2=None, pad=None, hw=None, xf=False, ep=None):
@@ -233,7 +242,8 @@ def pack_weight(w, scale=1.0, flip=False, transpose_oi=False, winograd=False):
     if winograd:
         if (kh, kw) != (3, 3):
             raise nat.NativeOpError('conv2d_mfma: the Winograd layout is for 3x3 weights')
-        size, pack = ((lib.pg_conv2d_winograd4_packed_size, lib.pg_conv2d_winograd4b_pack_weight) if int(winograd) == 3 else
+        size, pack = ((lib.pg_conv2d_winograd4x3_packed_size, lib.pg_conv2d_winograd4x3_pack_weight) if int(winograd) == 4 else
+                      (lib.pg_conv2d_winograd4_packed_size, lib.pg_conv2d_winograd4b_pack_weight) if int(winograd) == 3 else
                       (lib.pg_conv2d_winograd4_packed_size, lib.pg_conv2d_winograd4_pack_weight) if int(winograd) == 2 else
                       (lib.pg_conv2d_winograd_packed_size, lib.pg_conv2d_winograd_pack_weight))
         packed = torch.empty([size(cout, cin)], dtype=torch.float32, device=w.device)
@@ -328,7 +338,7 @@ def conv2d_forward(x, packed, cout, kh, kw, stride=1, pad=(0, 0), out_hw=None, y
         fz.x2, fz.cin_split = x2.data_ptr(), cin_split
     stats_part = None
     if stats_eps is not None:
-        if int(winograd) != 2 or spade is not None or in_scale is not None or noise is not None or residual is not None or x2 is not None or in_act != 'linear':
+        if int(winograd) not in (2, 4) or spade is not None or in_scale is not None or noise is not None or residual is not None or x2 is not None or in_act != 'linear':
             raise nat.NativeNotCovered('conv2d_mfma: output statistics are gathered by the F(4x4) kernel\'s plain tail only')
         stats_T = lib.pg_conv2d_winograd4_stats_tiles(int(oh), int(ow))
         stats_part = torch.empty([n * cout * stats_T * 2], dtype=torch.float32, device=x.device)
@@ -340,7 +350,7 @@ def conv2d_forward(x, packed, cout, kh, kw, stride=1, pad=(0, 0), out_hw=None, y
         if winograd:
             if (kh, kw, int(stride)) != (3, 3, 1) or tuple(out_step) != (1, 1) or tuple(out_off) != (0, 0):
                 raise nat.NativeOpError('conv2d_mfma: winograd=True needs a 3x3 stride-1 dense-output launch')
-            fwd = {1: lib.pg_conv2d_winograd_forward, 2: lib.pg_conv2d_winograd4_forward, 3: lib.pg_conv2d_winograd4b_forward}[int(winograd)]
+            fwd = {1: lib.pg_conv2d_winograd_forward, 2: lib.pg_conv2d_winograd4_forward, 3: lib.pg_conv2d_winograd4b_forward, 4: lib.pg_conv2d_winograd4x3_forward}[int(winograd)]
             st = fwd(nat.ptr(x), nat.ptr(packed), nat.ptr(y), n, cin, h, w, cout, int(pad_y), int(pad_x),
                      int(oh), int(ow), nat.i64arr(y.stride()), ctypes.byref(fz), nat.stream_of(x))
         else:

@@ -462,10 +462,11 @@ def test_conv2d_winograd_rejects_what_it_cannot_do():
 @pytest.mark.parametrize('n,cin,cout,h,w,pad', [(1, 16, 64, 8, 64, 1), (2, 64, 64, 16, 128, 1), (2, 32, 128, 24, 64, 1), (1, 48, 70, 9, 72, 1), (2, 20, 40, 13, 100, 1),
                                                 (1, 128, 128, 40, 192, 1), (3, 64, 64, 64, 64, 2), (3, 64, 64, 40, 64, 3), (2, 16, 64, 7, 8, 1), (1, 80, 64, 32, 64, 3), (2, 16, 64, 12, 62, 2),
                                                 (2, 40, 70, 13, 72, 3), (1, 32, 96, 19, 136, 3)])
-@pytest.mark.parametrize('form', [2, 3], ids=['one_wg_per_cu', 'two_wg_per_cu'])
+@pytest.mark.parametrize('form', [2, 3, 4], ids=['one_wg_per_cu', 'two_wg_per_cu', 'one_wg_per_cu_bf16x3'])
 def test_conv2d_winograd4_kernel(n, cin, cout, h, w, pad, form):
     """csrc/conv2d_wino4.h (Winograd F(4x4,3x3), round 3: form 2) and csrc/conv2d_wino4b.h (the same algorithm with two workgroups per CU on
-    v_mfma_f32_16x16x4_f32, round 4: form 3; 8 x 32-pixel tiles, its own weight stream and SPADE row order) on full, edge and ragged tiles (heights that are no multiple of 8, widths
+    v_mfma_f32_16x16x4_f32, round 4: form 3; 8 x 32-pixel tiles, its own weight stream and SPADE row order) and form 4 (round 6: form 2's kernel with its transform-domain GEMM as six
+    bf16 products of exact three-term operand splits on v_mfma_f32_32x32x16_bf16, fp32 accumulation -- same bars) on full, edge and ragged tiles (heights that are no multiple of 8, widths
     no multiple of 64, couts no multiple of 64, channel counts no multiple of 16): plain against the fp64 convolution;
     every fused stage, per-sample noise and SPADE mode against the direct MFMA kernel running the same launch (which meets the oracle in
     test_conv2d_fused_prologue_epilogue_vs_oracle; test_conv2d_winograd4_tails_vs_oracle compares one shape per tail kind with the oracle directly).
@@ -511,7 +512,7 @@ def test_conv2d_winograd4_kernel(n, cin, cout, h, w, pad, form):
         close(dx, want, 0, 1e-4 * scale_of(want))
 
 
-@pytest.mark.parametrize('form', [2, 3], ids=['one_wg_per_cu', 'two_wg_per_cu'])
+@pytest.mark.parametrize('form', [2, 3, 4], ids=['one_wg_per_cu', 'two_wg_per_cu', 'one_wg_per_cu_bf16x3'])
 @pytest.mark.parametrize('n,h,cin,cout', [(8, 512, 64, 64), (8, 256, 128, 128)])
 def test_conv2d_winograd4_repeated_launches_are_identical(n, h, cin, cout, form):
     """Full-size launches of the F(4x4) kernel, 60 in a row with other work in between: every result must equal the first one bit for bit
@@ -533,7 +534,7 @@ def test_conv2d_winograd4_repeated_launches_are_identical(n, h, cin, cout, form)
         assert torch.equal(y, first), f'launch {it} differs from the first one: max |d| {float((y - first).abs().max()):.3e}'
 
 
-@pytest.mark.parametrize('form', [2, 3], ids=['one_wg_per_cu', 'two_wg_per_cu'])
+@pytest.mark.parametrize('form', [2, 3, 4], ids=['one_wg_per_cu', 'two_wg_per_cu', 'one_wg_per_cu_bf16x3'])
 @pytest.mark.parametrize('tail', ['plain', 'residual', 'mod_noise', 'spade'])
 def test_conv2d_winograd4_tails_vs_oracle(tail, form):
     """One shape per tail kind of the F(4x4) kernel (W4_TAIL_PLAIN / the run-time tail with a residual / modulated + noise / W4_TAIL_SPADE)
@@ -575,8 +576,9 @@ def test_conv2d_winograd4_tails_vs_oracle(tail, form):
     close(y, ref, 0, 1e-4 * scale_of(ref))
 
 
+@pytest.mark.parametrize('form', [2, 4], ids=['fp32_mfma', 'bf16x3'])
 @pytest.mark.parametrize('n,cin,cout,h,w', [(2, 64, 128, 24, 72), (1, 64, 64, 64, 64), (3, 32, 70, 13, 136), (8, 128, 128, 256, 256)])
-def test_conv2d_winograd4_output_statistics(n, cin, cout, h, w):
+def test_conv2d_winograd4_output_statistics(n, cin, cout, h, w, form):
     """pg_conv2d_fusion::stats_partial (round 4): the instance-norm statistics of a convolution's output gathered in the F(4x4) kernel's plain tail
     (sum / M2 per workgroup tile and cout, merged pairwise -- Chan -- in float64 in tile order) against (a) float64 torch statistics of the SAME output
     tensor and (b) the separate one-pass kernel (pg_instance_norm_stats) -- full, ragged (H % 8, W % 64, Cout % 64 != 0) and full-size shapes;
@@ -587,9 +589,9 @@ def test_conv2d_winograd4_output_statistics(n, cin, cout, h, w):
     x = (torch.randn([n, cin, h, w], generator=gen) + 0.3).to(DEV)
     wt = (torch.randn([cout, cin, 3, 3], generator=gen) / (3 * math.sqrt(cin))).to(DEV)
     b = torch.randn([cout], generator=gen).to(DEV)
-    pk = conv2d_mfma.pack_weight(wt, winograd=2)
-    y0 = conv2d_mfma.conv2d_forward(x, pk, cout, 3, 3, pad=(1, 1), winograd=2, bias=b)
-    y, (mean, rstd) = conv2d_mfma.conv2d_forward(x, pk, cout, 3, 3, pad=(1, 1), winograd=2, bias=b, stats_eps=1e-5)
+    pk = conv2d_mfma.pack_weight(wt, winograd=form)
+    y0 = conv2d_mfma.conv2d_forward(x, pk, cout, 3, 3, pad=(1, 1), winograd=form, bias=b)
+    y, (mean, rstd) = conv2d_mfma.conv2d_forward(x, pk, cout, 3, 3, pad=(1, 1), winograd=form, bias=b, stats_eps=1e-5)
     assert torch.equal(y, y0)
     yd = y.double()
     want_mean = yd.mean([2, 3]).reshape(-1)
@@ -599,18 +601,18 @@ def test_conv2d_winograd4_output_statistics(n, cin, cout, h, w):
     m2, r2 = conv2d_mfma.instance_norm_stats(y, eps=1e-5)
     close(mean, m2, 0, 2e-6 * scale_of(want_mean))
     close(rstd, r2, 2e-5, 0)
-    again = conv2d_mfma.conv2d_forward(x, pk, cout, 3, 3, pad=(1, 1), winograd=2, bias=b, stats_eps=1e-5)[1]
+    again = conv2d_mfma.conv2d_forward(x, pk, cout, 3, 3, pad=(1, 1), winograd=form, bias=b, stats_eps=1e-5)[1]
     assert torch.equal(again[0], mean) and torch.equal(again[1], rstd)                       # deterministic: fixed reduction order, no atomics
     # |mean| >> std: a per-channel offset of ~50 on outputs of std ~0.6.  Sums of raw squares lose the variance there (relative error
     # ~1e-7 * mean^2 / var ~ 1e-3); the (sum, M2) pairs merged with Chan's formula stay at the two-pass kernel's accuracy
     b50 = (50.0 + torch.randn([cout], generator=gen)).to(DEV)
-    y5, (mean5, rstd5) = conv2d_mfma.conv2d_forward(x, pk, cout, 3, 3, pad=(1, 1), winograd=2, bias=b50, stats_eps=1e-5)
+    y5, (mean5, rstd5) = conv2d_mfma.conv2d_forward(x, pk, cout, 3, 3, pad=(1, 1), winograd=form, bias=b50, stats_eps=1e-5)
     y5d = y5.double()
     close(mean5, y5d.mean([2, 3]).reshape(-1), 2e-6, 0)
     close(rstd5, (y5d.var([2, 3], unbiased=False) + 1e-5).rsqrt().reshape(-1), 2e-5, 0)
     for kw in (dict(residual=torch.zeros_like(y)), dict(in_scale=torch.ones([n, cin], device=DEV))):
         with pytest.raises(NativeNotCovered):
-            conv2d_mfma.conv2d_forward(x, pk, cout, 3, 3, pad=(1, 1), winograd=2, stats_eps=1e-5, **kw)
+            conv2d_mfma.conv2d_forward(x, pk, cout, 3, 3, pad=(1, 1), winograd=form, stats_eps=1e-5, **kw)
     with pytest.raises(NativeNotCovered):
         conv2d_mfma.conv2d_forward(x, conv2d_mfma.pack_weight(wt, winograd=1), cout, 3, 3, pad=(1, 1), winograd=1, stats_eps=1e-5)
 
@@ -618,9 +620,9 @@ def test_conv2d_winograd4_output_statistics(n, cin, cout, h, w):
 def test_conv2d_winograd4_policy_and_declines():
     from torch_utils.ops import conv2d_mfma
     from torch_utils.ops._native import NativeNotCovered
-    F4 = 2                                         # images at least 64 pixels wide: the one-workgroup form
+    F4 = conv2d_mfma.F4_WIDE                      # images at least 64 pixels wide: the one-workgroup form -- 4 (GEMM on the bf16 pipe, three-term splits) unless PG_WINO4_X3=0 (2)
     FN = conv2d_mfma.F4_FORM                      # narrower images: 3 (two workgroups per CU) unless PG_WINO4B=0
-    assert FN in (2, 3)
+    assert FN in (2, 3) and F4 in (2, 4)
     # the tail's max() form of the activation is exact for gain > 0, 0 <= alpha <= 1 only: the policy keeps anything else on F(2x2),
     # the kernel declines it, and the F(2x2) launch of the same request meets the oracle
     geo = dict(pad=(1, 1), hw=(64, 64))
@@ -631,7 +633,7 @@ def test_conv2d_winograd4_policy_and_declines():
     xa = det_tensor('w4d.xa', [1, 64, 32, 64])
     wa = det_tensor('w4d.wa', [64, 64, 3, 3], scale=0.05)
     for kw in (dict(act='lrelu', alpha=1.5, gain=1.4), dict(act='lrelu', alpha=0.2, gain=-0.5), dict(act='relu', gain=-2.0)):
-        for form in (2, 3):
+        for form in (2, 3, 4):
             with pytest.raises(NativeNotCovered):
                 conv2d_mfma.conv2d_forward(xa.to(DEV), conv2d_mfma.pack_weight(wa.to(DEV), winograd=form), 64, 3, 3, pad=(1, 1), winograd=form, **kw)
         y = conv2d_mfma.conv2d_forward(xa.to(DEV), conv2d_mfma.pack_weight(wa.to(DEV), winograd=1), 64, 3, 3, pad=(1, 1), winograd=1, **kw)
@@ -652,6 +654,42 @@ def test_conv2d_winograd4_policy_and_declines():
         conv2d_mfma.conv2d_forward(x, conv2d_mfma.pack_weight(wt, winograd=2), 64, 3, 3, pad=(1, 1), winograd=2)        # W % 4 != 0
     with pytest.raises(NativeNotCovered):
         conv2d_mfma.conv2d_forward(x, conv2d_mfma.pack_weight(wt, winograd=3), 64, 3, 3, pad=(1, 1), winograd=3)
+    with pytest.raises(NativeNotCovered):
+        conv2d_mfma.conv2d_forward(x, conv2d_mfma.pack_weight(wt, winograd=4), 64, 3, 3, pad=(1, 1), winograd=4)
+
+
+@pytest.mark.parametrize('n,cin,cout,h,w', [(8, 128, 128, 256, 256), (8, 64, 64, 512, 512), (2, 512, 512, 64, 64), (2, 80, 70, 24, 72)])
+def test_conv2d_winograd4_bf16x3_is_float32_class(n, cin, cout, h, w):
+    """Form 4: F(4x4,3x3) with the 36 transform-domain GEMMs on v_mfma_f32_32x32x16_bf16 as the six largest plane products of exact three-term
+    splits (u = u0 + u1 + u2, v = v0 + v1 + v2, 8 + 8 + 8 significand bits by truncation; dropped: u1 v2, u2 v1, u2 v2 < 2^-24 of the product), fp32 accumulation.
+    Admissible as float32 only if it IS float32-class, so the referee is float64: the error of form 4 must stay within 2x the fp32-MFMA form's (form 2) on the same
+    launch -- measured: 0.7-0.9x, the bf16 products are exact and only the accumulation rounds -- and within 1e-4 of the output scale like every F(4x4) launch;
+    the two forms differ from each other by rounding only; repeated launches are bit-identical (fixed summation order, no atomics)."""
+    from torch_utils.ops import conv2d_mfma
+    import torch.nn.functional as F
+    gen = torch.Generator().manual_seed(41)
+    x = torch.randn([n, cin, h, w], generator=gen).to(DEV)
+    wt = (torch.randn([cout, cin, 3, 3], generator=gen) / (3 * math.sqrt(cin))).to(DEV)
+    ref = F.conv2d(x.double(), wt.double(), padding=1)
+    sc = float(ref.abs().max())
+    y2 = conv2d_mfma.conv2d_forward(x, conv2d_mfma.pack_weight(wt, winograd=2), cout, 3, 3, pad=(1, 1), winograd=2)
+    pk4 = conv2d_mfma.pack_weight(wt, winograd=4)
+    y4 = conv2d_mfma.conv2d_forward(x, pk4, cout, 3, 3, pad=(1, 1), winograd=4)
+    e2, e4 = float((y2.double() - ref).abs().max()), float((y4.double() - ref).abs().max())
+    assert e4 <= 2 * e2 and e4 <= 1e-4 * sc, f'bf16x3 form {e4 / sc:.2e} of the output scale, fp32-MFMA form {e2 / sc:.2e}'
+    assert float((y4 - y2).abs().max()) <= 4 * e2
+    for _ in range(3):
+        assert torch.equal(conv2d_mfma.conv2d_forward(x, pk4, cout, 3, 3, pad=(1, 1), winograd=4), y4)
+    # the weight planes: 54 * CinP * CoutP float32 units = three bf16 planes of the 36 transformed weights; their sum is the fp32 form's transformed weight bit for bit
+    cinp, coutp = -(-cin // 16) * 16, -(-cout // 64) * 64
+    assert pk4.numel() == 54 * cinp * coutp
+    u16 = pk4.view(torch.int16).view(-1, 6, 3, 64, 8).to(torch.int32)          # [unit = (m-block, mt, a, chunk)][b][plane][lane = (h, co & 31)][j]
+    planes = (u16 << 16).view(torch.float32)
+    usum = planes[:, :, 0].double() + planes[:, :, 1].double() + planes[:, :, 2].double()            # exact in float64
+    assert torch.equal(usum.float().double(), usum)                                                    # ... and representable in float32: the split is exact
+    pk2 = conv2d_mfma.pack_weight(wt, winograd=2).view(-1, 2, 2, 3, 64, 4)                             # [unit][jg][quad][jj][lane][s]: b = 3 jg + jj, channel pair = 4 quad + s
+    u2 = pk2.permute(0, 1, 3, 4, 2, 5).reshape(-1, 6, 64, 8)                                           # [unit][b][lane][j = 4 quad + s]
+    assert torch.equal(usum.float(), u2)
 
 
 @pytest.mark.parametrize('n,cin,cout,h,w,kh,kw,pad,step', [(8, 512, 512, 8, 8, 2, 2, 1, 2), (4, 512, 96, 16, 16, 1, 1, 0, 1), (2, 256, 512, 32, 32, 3, 3, 1, 1),

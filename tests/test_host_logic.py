@@ -222,7 +222,9 @@ def test_winograd_launch_policy(monkeypatch):
     monkeypatch.delenv('PG_CONV_ALGO', raising=False)
     uw = conv2d_mfma.use_winograd
     from torch_utils.ops.conv2d_mfma import F4_FORM as FN      # images narrower than 64 pixels: 3 = conv2d_wino4b.h (two workgroups per CU); PG_WINO4B=0: 2
-    assert uw(3, 3, 1, 128, 128, pad=(1, 1), hw=(256, 256)) == 2 and uw(3, 3, 1, 64, 64, pad=(1, 1), hw=(512, 512)) == 2
+    from torch_utils.ops.conv2d_mfma import F4_WIDE as FW      # images at least 64 pixels wide: 4 = conv2d_wino4.h with the GEMM on the bf16 pipe (three-term splits); PG_WINO4_X3=0: 2
+    assert FW in (2, 4) and FN in (2, 3)
+    assert uw(3, 3, 1, 128, 128, pad=(1, 1), hw=(256, 256)) == FW and uw(3, 3, 1, 64, 64, pad=(1, 1), hw=(512, 512)) == FW
     assert uw(3, 3, 1, 512, 512, pad=(1, 1), hw=(32, 32)) == FN and uw(3, 3, 1, 512, 512, pad=(1, 1), hw=(16, 16)) == 1 and uw(3, 3, 1, 512, 512, pad=(1, 1), hw=(8, 8)) == 1
     assert uw(3, 3, 1, 128, 128, pad=(1, 1)) == 1                                   # no image size given: F(2x2)
     assert uw(3, 3, 1, 128, 128, pad=(1, 1), hw=(256, 254)) == 1                   # width no multiple of 4

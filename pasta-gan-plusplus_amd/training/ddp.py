@@ -35,6 +35,10 @@ class GradBucket:
         assert self.params, 'empty bucket'
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # `exchange`: the phase protocol of more than one rank -- segments exchanged from the hooks on the side stream, flags travelling inside them, finish()'s
+        # device-side flags -- also runs on a ONE-rank process group when PG_FORCE_EXCHANGE=1 (test switch, VERDICT r5 item 2: the branch an 8-GPU run takes,
+        # executed on the one GPU there is; the all-reduces are then identities and the step must equal the unforced one bit for bit)
+        self.exchange = self.world > 1 or (os.environ.get('PG_FORCE_EXCHANGE', '0') == '1' and dist.is_initialized())
         dev = self.params[0].device
         # reverse registration order: the last layers' gradients are produced first
         order = list(range(len(self.params)))[::-1]
@@ -80,14 +84,18 @@ class GradBucket:
         self._active = False
         self._comm_stream = torch.cuda.Stream(device=dev) if dev.type == 'cuda' else None
         if dev.type == 'cuda':
-            reserve_comm_cus(self.world)
+            reserve_comm_cus(self.world, exchange=self.exchange)
         self.any_touched = False
         # `device_flags` (set by training/flat_adam.py on the GPU): finish() leaves the per-parameter "some rank produced a gradient" flags in `alive`
         # ON THE DEVICE for the fused optimizer pass to read -- no read-back, no host sync per phase (7 per iteration), and .grad stays a
         # (zero) view for parameters nobody touched instead of becoming None: the optimizer pass skips them by the flag
         self.device_flags = False
         self.alive = torch.zeros([len(self.params)], dtype=torch.float32, device=dev)
-        self._flags_host = torch.zeros([len(self.params)], dtype=torch.float32).pin_memory() if dev.type == 'cuda' else None
+        # Host -> device staging of flag vectors: a pinned buffer handed to a non-blocking copy must not be rewritten before that copy has run.
+        # Eager phases rotate through a ring, each slot guarded by the event recorded behind its last copy (a slot still in flight is skipped -- a fresh buffer
+        # is cheaper than a host wait); a copy recorded into a hipGraph re-reads its source at every replay, so a capture gets a buffer of its own that nobody writes again.
+        # (allocated during eager phases -- a phase runs eagerly before it is captured -- because a capture must not allocate pinned memory)
+        self._stage_ring, self._stage_next, self._stage_captured, self._stage_spare = [], 0, [], []
         self.launch_log = []                                 # (segment, 'hook' | 'finish') in issue order, per phase: tests read it
         # `gather` (round 5; default on the GPU, PG_GRAD_GATHER=0 switches it off): .grad is None when the backward pass starts, so autograd's AccumulateGrad
         # KEEPS the tensor the gradient kernel produced instead of adding it into a zeroed view -- one elementwise launch per parameter and backward pass, ~570
@@ -105,7 +113,7 @@ class GradBucket:
     def begin(self):
         """Before the phase's backward passes: zero the bucket (gradients and flags), point every .grad into it, arm the hooks."""
         if self.gather:
-            if self.world > 1:
+            if self.exchange:
                 self.flat.zero_()                            # parameters without a gradient on THIS rank contribute zeros to the sum; flags; padding
             for p in self.params:
                 p.grad = None
@@ -131,7 +139,7 @@ class GradBucket:
             if not self._active:
                 return
             self._touched_host[i] = True
-            if self._sync_round and self.world > 1:
+            if self._sync_round and self.exchange:
                 self._pending[self.seg_of[i]] -= 1
                 self._launch_ready('hook')
         return hook
@@ -164,6 +172,36 @@ class GradBucket:
             if self.params[i].grad is not None:
                 self.params[i].grad = self.views[i]
 
+    def _upload(self, dst, values):
+        """`values` (host floats) -> the device view `dst`, stream-ordered on the current stream, without a host sync and without a pageable source."""
+        if not dst.is_cuda:
+            dst.copy_(torch.tensor(values, dtype=torch.float32))
+            return
+        n = len(values)
+        if torch.cuda.is_current_stream_capturing():
+            if not self._stage_spare:
+                raise RuntimeError('GradBucket: no pinned staging buffer left for a captured flag upload')
+            buf = self._stage_spare.pop()
+            buf[:n] = torch.tensor(values, dtype=torch.float32)
+            self._stage_captured.append(buf)                 # lives as long as the bucket: the captured copy reads it at every replay
+            dst.copy_(buf[:n], non_blocking=True)
+            return
+        if not self._stage_spare and not self._stage_captured:
+            self._stage_spare = [torch.empty([len(self.params)], dtype=torch.float32).pin_memory() for _ in range(6 * (len(self.seg_range) + 1))]
+        slot = None
+        for _ in range(len(self._stage_ring)):
+            cand = self._stage_ring[self._stage_next % len(self._stage_ring)]
+            self._stage_next += 1
+            if cand[0].numel() >= n and cand[1].query():
+                slot = cand
+                break
+        if slot is None:
+            slot = [torch.empty([max(n, len(self.params))], dtype=torch.float32).pin_memory(), torch.cuda.Event()]
+            self._stage_ring.append(slot)
+        slot[0][:n] = torch.tensor(values, dtype=torch.float32)
+        dst.copy_(slot[0][:n], non_blocking=True)
+        slot[1].record()
+
     def _launch(self, k, who):
         self._launched[k] = True
         self.launch_log.append((k, who))
@@ -175,8 +213,7 @@ class GradBucket:
         if who == 'hook':
             self.flat[fa:fb].fill_(1.0)                      # launched from a hook: every parameter of the segment has a gradient here
         else:
-            flags = [1.0 if self._touched_host[i] else 0.0 for i in self.members[k]]
-            self.flat[fa:fb].copy_(torch.tensor(flags, dtype=torch.float32), non_blocking=False)
+            self._upload(self.flat[fa:fb], [1.0 if self._touched_host[i] else 0.0 for i in self.members[k]])
         if self._comm_stream is not None:
             ev = torch.cuda.Event()
             ev.record()                                      # everything enqueued so far: this segment's gradients are among it
@@ -192,7 +229,7 @@ class GradBucket:
         rank), in index order; then read the summed flags, hand `None` back to parameters nobody produced.  Returns True if
         the phase produced any gradient anywhere."""
         self._active = False
-        if self.world > 1:
+        if self.exchange:
             for k in range(len(self.seg_range)):
                 if not self._launched[k]:
                     self._launch(k, 'finish')
@@ -212,8 +249,7 @@ class GradBucket:
             alive = [1.0 if t else 0.0 for t in self._touched_host]
             if self.device_flags:
                 self.any_touched = any(self._touched_host)
-                self._flags_host.copy_(torch.tensor(alive, dtype=torch.float32))
-                self.alive.copy_(self._flags_host, non_blocking=True)       # one small H2D copy, stream-ordered in front of the optimizer pass; no sync
+                self._upload(self.alive, alive)              # one small H2D copy, stream-ordered in front of the optimizer pass; no sync
                 return self.any_touched
         self.any_touched = any(a > 0 for a in alive)
         for p, v, a in zip(self.params, self.views, alive):
@@ -241,14 +277,14 @@ class GradBucket:
 _reserved = [None]
 
 
-def reserve_comm_cus(world):
+def reserve_comm_cus(world, exchange=False):
     """Give the exchange somewhere to run: this package's convolution / weight-gradient kernels are persistent, one workgroup per CU with
     nearly all of its LDS, so the all-reduce launched from the hooks could only start when a CU drained -- "overlapped with the backward pass" was a hope.  With
     more than one rank the plugin's grids leave PG_COMM_CUS CUs (default 8 of 256) free; PG_COMM_CUS set explicitly applies at any world size (to price it on
     one GPU: bench.py --mode train).  Once per process."""
     import os
     env = os.environ.get('PG_COMM_CUS')
-    want = int(env) if env is not None else (8 if world > 1 else 0)
+    want = int(env) if env is not None else (8 if (world > 1 or exchange) else 0)
     if _reserved[0] != want:
         from torch_utils.ops import conv2d_mfma
         conv2d_mfma.reserve_cus(want)

@@ -98,9 +98,12 @@ class TrainingStep:
                 if not ps:
                     continue
                 copies = [torch.empty_like(p) for p in ps]
-                bucket.grad_gains = [1.0] * len(bucket.params)
-                for p, g in zip(ps, gs):
-                    bucket.grad_gains[index[id(p)]] = g
+                gain_of = {id(p): g for p, g in zip(ps, gs)}
+                # EVERY bucket over these parameters gathers gradients of the pre-scaled copies: with PG_FLAT_ADAM=0 the second D_parsing entry of the
+                # phase table has a bucket of its own, and `_phase` arms the aliases for all phases alike
+                for b in {id(ph.bucket): ph.bucket for ph in self.phases}.values():
+                    if b.flat.is_cuda and b.gather and any(id(p) in gain_of for p in b.params):
+                        b.grad_gains = [gain_of.get(id(p), 1.0) for p in b.params]
                 self._gained[key] = (ps, copies, gs)
                 for p, c in zip(ps, copies):
                     table[id(p)] = [c, -1, p]

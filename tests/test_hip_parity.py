@@ -1321,8 +1321,9 @@ def test_discriminator_fp16_gradients_are_reproducible(res, base, cmax):
         assert not bad, (fn.__name__, bad)
 
 
+@pytest.mark.parametrize('flat_adam', ['1', '0'], ids=['flat_adam', 'torch_adam'])
 @pytest.mark.parametrize('graphs', [False, True], ids=['eager', 'graphed'])
-def test_training_step_gain_fold_equals_multiplies(graphs, monkeypatch):
+def test_training_step_gain_fold_equals_multiplies(graphs, flat_adam, monkeypatch):
     """PG_GAIN_FOLD (round 5): the pre-scaled weight copies + gains applied in the bucket's gather must leave the same weights and Adam statistics as the
     per-call `weight * weight_gain` multiplies they replace -- product discriminators (equalised-LR convolutions, R1 double backward), stub generator, 5 iterations;
     one discriminator weight is edited IN PLACE after the step object exists (a checkpoint load would do that): its copy is stale when the first phase runs and must
@@ -1334,6 +1335,10 @@ def test_training_step_gain_fold_equals_multiplies(graphs, monkeypatch):
     from training.loss import StyleGAN2Loss
     from training.training_step import TrainingStep
     from oracle import network_ref as NR
+
+    # flat_adam = '0' (ADVICE r5): torch.optim.Adam on gather-mode buckets -- the second D_parsing entry of the phase table then has a bucket of its own, which must
+    # carry the gains too (its phases run on the pre-scaled aliases like every other phase)
+    monkeypatch.setenv('PG_FLAT_ADAM', flat_adam)
 
     def run(fold):
         monkeypatch.setenv('PG_GAIN_FOLD', '1' if fold else '0')
@@ -1348,6 +1353,9 @@ def test_training_step_gain_fold_equals_multiplies(graphs, monkeypatch):
         G_parts = {k: v for k, v in nets.items() if k.startswith('G_')}
         step = TrainingStep(G_parts, nets['D'], nets['D_parsing'], loss, batch_size=4, graphs=graphs)
         assert bool(step._gained) == fold
+        if fold:
+            for b in {id(ph.bucket): ph.bucket for ph in step.phases}.values():
+                assert b.grad_gains is not None or not any(isinstance(m, PN._ConvBase) for ph in step.phases if ph.bucket is b for top in ph.modules for m in top.modules())
         with torch.no_grad():
             nets['D'].b8.conv0.weight.mul_(1.25)              # after the copies were made
         b = stubs.batch(4, DEV)

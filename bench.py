@@ -118,8 +118,11 @@ def conv_roofline(timeline, elapsed, steps, images_per_s_per_gpu, traffic_tag, g
     of the region.  The MFMA roofline is priced on the flops that algorithm EXECUTES on the matrix pipe -- Winograd F(4x4,3x3) (csrc/conv2d_wino4.h):
     36 multiplies per 16 outputs = 1/4 of the direct-convolution count; F(2x2,3x3) (csrc/conv2d_wino.h): 4/9; the direct implicit GEMM: all of it --
     and the direct-convolution-equivalent rate of the same launches is reported next to it (it can exceed the matrix peak)."""
-    WORK = {'winograd4': 0.25, 'winograd': 4.0 / 9.0, 'direct': 1.0}
-    KERNEL = {'winograd4': 'conv2d_wino4<MODE,TAIL> (Winograd F(4x4,3x3) stride-1 3x3 convolution, v_mfma_f32_32x32x2_f32)',
+    WORK = {'winograd4x3': 0.25, 'winograd4': 0.25, 'winograd': 4.0 / 9.0, 'direct': 1.0}
+    BF16_MFMA_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md, dense bf16 matrix peak
+    KERNEL = {'winograd4x3': 'conv2d_wino4<MODE,TAIL,X3> (Winograd F(4x4,3x3) stride-1 3x3 convolution; the 36 transform-domain GEMMs as six bf16 x bf16 products of exact three-term '
+                             'operand splits, fp32 accumulation, v_mfma_f32_32x32x16_bf16)',
+              'winograd4': 'conv2d_wino4<MODE,TAIL> (Winograd F(4x4,3x3) stride-1 3x3 convolution, v_mfma_f32_32x32x2_f32)',
               'winograd': 'conv2d_wino<MODE,VEC> (Winograd F(2x2,3x3) stride-1 3x3 convolution, v_mfma_f32_32x32x2_f32)',
               'direct': 'conv2d_mfma<KH,KW,S,BM,KC,XF> (implicit GEMM, v_mfma_f32_32x32x2_f32)'}
     by_algo = {}
@@ -148,6 +151,12 @@ def conv_roofline(timeline, elapsed, steps, images_per_s_per_gpu, traffic_tag, g
                                  for a_, v in by_algo.items() if a_ != algo},
                all_conv_direct_equivalent_tflops=round(sum(f for f, _ in allk) / max(sum(t for _, t in allk), 1e-12) / 1e12, 2),
                conv_time_frac_of_step=round(sum(t for _, t in allk) / elapsed, 4))
+    if algo == 'winograd4x3':
+        # the matrix pipe executes SIX bf16 multiply-adds per float32 one of the Winograd-domain GEMM: the roofline is priced on that count against the dense bf16 peak
+        # (as config 4's bf16x3 weight gradients are), with the float32-equivalent rate -- what the fp32-MFMA form of the same kernel is priced on -- beside it
+        out.update(achieved=round(6 * achieved, 2), peak=BF16_MFMA_PEAK_TFLOPS, frac=round(6 * achieved / BF16_MFMA_PEAK_TFLOPS, 4),
+                   flops_counted=f'bf16 multiply-adds the kernel executes = 6 x {work:.4g} x the direct-convolution flops of SURVEY 8d (six plane products per float32 product)',
+                   fp32_equivalent_tflops=round(achieved, 2), fp32_equivalent_frac_of_fp32_peak=round(achieved / F32_MFMA_PEAK_TFLOPS, 4))
     if gflop_per_image:
         out['end_to_end_direct_equivalent_frac'] = round(images_per_s_per_gpu * gflop_per_image / 1e3 / F32_MFMA_PEAK_TFLOPS, 4)
     return out

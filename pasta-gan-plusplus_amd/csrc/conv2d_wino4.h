@@ -444,52 +444,62 @@ __global__ __launch_bounds__(768, 3) void conv2d_wino4(ConvParams p) {
             };
             if constexpr (X3) {
                 // ---- GEMM phase, X3 form: six groups = the six xi of this wave's row; group g: A = three 16-byte words (planes 0..2 of the lane's 8 channels
-                // 2 j + h), B = the lane's 8 float32 V values split here into three packed planes.  Ring: group g in slot g & 1; group 1 requested above,
-                // group g + 2 after the MFMAs of group g (g = 4: group 0 of the next chunk / tile; g = 5: nothing -- two groups crossing the transform phase
-                // measured +-0 and their 12 live registers spill in the SPADE tail).  B values are read one group ahead.
+                // 2 j + h), B = the lane's 8 float32 V values split into three packed planes.  The six MFMAs of a group are ONE dependent chain (same accumulator;
+                // stamps: ~87 cycles per link for a wave alone on its SIMD), so the wave's own issue slots between them are free: the split of the NEXT group's V
+                // values (4 pairs x 11 VALU) sits in the first four gaps, and the V values of the group after that are requested in the fourth (-2.5 % per launch
+                // against split-then-multiply).  A ring: group g in slot g & 1; group 1 requested above, group g + 2 after the MFMAs of group g (g = 4: group 0 of
+                // the next chunk / tile; g = 5: nothing -- two groups crossing the transform phase measured +-0 and their 12 live registers spill in the SPADE tail).
                 request_next();
                 const bool dma_q = issued && chore;
                 const float* vb = V + 6 * ta * 512 + w4_fresh_lane();
-                float br[8];                                                // (one buffer: the next group's values are requested as soon as this group's are split -- the six MFMAs cover the LDS latency)
+                float br[8];
                 auto read_b8 = [&](int b, float (&dst)[8]) {
 #pragma unroll
                     for (int j = 0; j < 8; j++) dst[j] = vb[b * 512 + j * 64];
                 };
+                w4_u32x4 bp[2][3];
                 read_b8(0, br);
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    unsigned p0, p1, p2;
+                    w4_split_pair(br[2 * q], br[2 * q + 1], p0, p1, p2);
+                    bp[0][0][q] = p0; bp[0][1][q] = p1; bp[0][2][q] = p2;
+                }
+                read_b8(1, br);
                 W4_XSTAMP(0);
 #pragma unroll
                 for (int g = 0; g < 6; g++) {
-                    w4_u32x4 bp[3];
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        unsigned p0, p1, p2;
-                        if (W4X_EXP & 4) { p0 = __float_as_uint(br[2 * q]); p1 = __float_as_uint(br[2 * q + 1]); p2 = p0; }
-                        else w4_split_pair(br[2 * q], br[2 * q + 1], p0, p1, p2);
-                        bp[0][q] = p0; bp[1][q] = p1; bp[2][q] = p2;
-                    }
-                    __builtin_amdgcn_sched_barrier(0);                       // the split runs BEFORE the wait for this group's A words
-                    if (g + 1 < 6) read_b8(g + 1, br);
                     W4_XSTAMP(1 + 3 * g);
-                    if (g == 0 && dma_q && touched) {                        // behind group 0's words in this wave's queue: the touches, group 1's words (3), the DMA
+                    if (g == 0 && dma_q && touched) {
                         if (cw == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 + W4_NTOUCH + W4_NDMA));
                         else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 + W4_NTOUCH + W4_NDMA - 1));
                         asm volatile("" : "+v"(ur[0][0]), "+v"(ur[0][1]), "+v"(ur[0][2]));
-                    } else wait_u(ur[g & 1], g < 2 && dma_q);               // (g = 1: the touches are OLDER than group 1's words, which are requested at the top of this phase)
+                    } else wait_u(ur[g & 1], g < 2 && dma_q);
                     W4_XSTAMP(2 + 3 * g);
                     __builtin_amdgcn_sched_barrier(0);
                     // small products first:  u2 v0,  u1 v1,  u1 v0,  u0 v2,  u0 v1,  u0 v0
                     constexpr int PA[6] = {2, 1, 1, 0, 0, 0}, PB[6] = {0, 1, 0, 2, 1, 0};
 #pragma unroll
-                    for (int t = 0; t < 6; t++)
-                        if (!(W4X_EXP & 8) || bp[0][0] == 0x12345678u) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(w4_bf16x8, ur[g & 1][PA[t]]), __builtin_bit_cast(w4_bf16x8, bp[PB[t]]),
+                    for (int t = 0; t < 6; t++) {
+                        if (!(W4X_EXP & 8) || bp[0][0][0] == 0x12345678u) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(w4_bf16x8, ur[g & 1][PA[t]]), __builtin_bit_cast(w4_bf16x8, bp[g & 1][PB[t]]),
                                                                          (FIRST && t == 0) ? zero16 : acc[g], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (g + 1 < 6 && t < 4) {
+                            unsigned p0, p1, p2;
+                            if (W4X_EXP & 4) { p0 = __float_as_uint(br[2 * t]); p1 = __float_as_uint(br[2 * t + 1]); p2 = p0; }
+                            else w4_split_pair(br[2 * t], br[2 * t + 1], p0, p1, p2);
+                            bp[(g + 1) & 1][0][t] = p0; bp[(g + 1) & 1][1][t] = p1; bp[(g + 1) & 1][2][t] = p2;
+                            if (t == 3 && g + 2 < 6) read_b8(g + 2, br);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
                     W4_XSTAMP(3 + 3 * g);
-                    if (g == 4 && k + 1 == nchunks) a_reset(m0);             // from here on: the next tile's first group (m0 is already the next tile's)
+                    if (g == 4 && k + 1 == nchunks) a_reset(m0);
                     if (g < 5) load_u(ur[g & 1]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if (k == 2) W4_STAMP(4);
-                if (!issued) dma_wait_all();                                 // last chunk of the last tile: nothing counted behind us
+                if (!issued) dma_wait_all();
                 if ((WINO4_EXP & 256) && chore) dma_wait_all();
             } else {
             constexpr bool LATE = (WINO4_EXP & 1024) != 0;               // timing experiment: the chore waves request the next chunk after group 1's MFMAs instead of before group 0's

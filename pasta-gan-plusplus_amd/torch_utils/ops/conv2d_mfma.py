@@ -368,7 +368,7 @@ def conv2d_forward(x, packed, cout, kh, kw, stride=1, pad=(0, 0), out_hw=None, y
                                            ctypes.byref(fz), nat.stream_of(x))
         if _timeline is not None:
             ev1.record()
-            _timeline.append(((kh, kw, int(stride), ('winograd4' if int(winograd) >= 2 else 'winograd') if winograd else 'direct', f'N{n} {cin}->{cout} {h}x{w}' + (' spade' if spade is not None else '') + (' xf' if in_act != 'linear' else '') + (' mod' if in_scale is not None else '') + (' res' if residual is not None else '')), 2.0 * n * cout * oh * ow * cin * kh * kw, ev0, ev1,
+            _timeline.append(((kh, kw, int(stride), ('winograd4x3' if int(winograd) == 4 else 'winograd4' if int(winograd) >= 2 else 'winograd') if winograd else 'direct', f'N{n} {cin}->{cout} {h}x{w}' + (' spade' if spade is not None else '') + (' xf' if in_act != 'linear' else '') + (' mod' if in_scale is not None else '') + (' res' if residual is not None else '')), 2.0 * n * cout * oh * ow * cin * kh * kw, ev0, ev1,
                               4 * (x.numel() + (x2.numel() if x2 is not None else 0) + n * ychan * oh * ow)))
     nat.check(st, 'pg_conv2d_forward')
     if stats_part is not None:

@@ -187,19 +187,16 @@ def routed_sample_inputs(n, dev, seed):
 
 
 def route_batch(samples):
-    """HIP patch routing of every sample (pg_warp_perspective_u8 x 2 + pg_patch_compose_u8 per part, training/patch_routing.py) -> the generator's routed
-    inputs, assembled on the GPU the way the loader (training/dataset.py) and test.py:126-147 do: c [N, 45, 128, 128], de-normalised garments + masks."""
+    """HIP patch routing of the whole batch (training/patch_routing.py `normalize_batch`: pg_warp_perspective_u8 x 2 + pg_patch_compose_ordered_u8, three launches for
+    all samples) -> the generator's routed inputs, assembled on the GPU the way the loader (training/dataset.py) and test.py:126-147 do: c [N, 45, 128, 128],
+    de-normalised garments + masks."""
     from training import patch_routing as P
-    unit = lambda t: t.permute(2, 0, 1).to(torch.float32) / 127.5 - 1
-    c, du, dl, mu, ml = [], [], [], [], []
-    for up, lo, um, lm, ckp, pkp in samples:
-        norm_img, norm_lower, den_up, _, _ = P.normalize(up, lo, um, lm, None, ckp, pkp, 2, device=up.device)
-        den_lo = lo                                            # (the loader keeps the person's own lower garment, edge eroded: dataset.py `denorm_lower`)
-        c.append(torch.cat([unit(norm_img), unit(norm_lower)], dim=0))
-        du.append(unit(den_up)); dl.append(unit(den_lo))
-        mu.append((den_up.to(torch.int32).sum(dim=2, keepdim=True) > 0).permute(2, 0, 1).float())
-        ml.append((den_lo.to(torch.int32).sum(dim=2, keepdim=True) > 0).permute(2, 0, 1).float())
-    return dict(c=torch.stack(c), denorm_upper_input=torch.stack(du), denorm_lower_input=torch.stack(dl), denorm_upper_mask=torch.stack(mu), denorm_lower_mask=torch.stack(ml))
+    unit = lambda t: t.permute(0, 3, 1, 2).to(torch.float32) / 127.5 - 1
+    norm_img, norm_lower, den_up, _, _ = P.normalize_batch([(up, lo, um, lm, None, ckp, pkp) for up, lo, um, lm, ckp, pkp in samples], 2, device=samples[0][0].device)
+    den_lo = torch.stack([s[1] for s in samples])                    # (the loader keeps the person's own lower garment, edge eroded: dataset.py `denorm_lower`)
+    mask = lambda t: (t.to(torch.int32).sum(dim=3, keepdim=True) > 0).permute(0, 3, 1, 2).float()
+    return dict(c=torch.cat([unit(norm_img), unit(norm_lower)], dim=1), denorm_upper_input=unit(den_up), denorm_lower_input=unit(den_lo),
+                denorm_upper_mask=mask(den_up), denorm_lower_mask=mask(den_lo))
 
 
 def run_generator(args, rank, world, dev, dist):
@@ -261,13 +258,13 @@ def run_generator(args, rank, world, dev, dist):
             from training import patch_routing
             t_route = sum(e0.elapsed_time(e1) for e0, e1 in route_events) * 1e-3
             tc = patch_routing.traffic_counter
-            extra['routing'] = dict(kernels='pg_warp_perspective_u8 (image -> patch, patch -> canvas: two batched launches per sample) + pg_patch_compose_u8 (erode + paste per part)',
+            extra['routing'] = dict(kernels='pg_warp_perspective_u8 (image -> patch, patch -> canvas: two launches over every job of the batch) + pg_patch_compose_ordered_u8 (erode + paste of every canvas of the batch, one launch)',
                                     ms_per_step=round(1e3 * t_route / args.steps, 3), ms_per_sample=round(1e3 * t_route / args.steps / n, 3),
                                     time_frac_of_step=round(t_route / elapsed, 4), launches_per_step=tc['launches'] // max(args.steps, 1),
                                     bound='hbm', algorithmic_bytes_per_step=tc['bytes'] // max(args.steps, 1),
                                     achieved_gbs=round(tc['bytes'] / max(t_route, 1e-12) / 1e9, 1), peak_gbs=HBM_PEAK_GBS, frac=round(tc['bytes'] / max(t_route, 1e-12) / 1e9 / HBM_PEAK_GBS, 5),
-                                    note='stage time by events around the whole routing of a batch: it includes the host key-point geometry (20 homographies per sample) and the launch gaps '
-                                         'of ~45 small launches per sample -- the stage is latency-bound, its HBM fraction says so',
+                                    note='stage time by events around the whole routing of a batch: it includes the host key-point geometry (the quadrilaterals per sample, one batched solve for '
+                                         'the homographies of the batch), the two job-table uploads and the batched tensor bookkeeping behind the three native launches',
                                     parity='UNPINNED: HIP == own oracle bit for bit; the oracle restates OpenCV\'s published fixed-point algorithm, cv2 is not available offline (DESIGN.md 6d)')
         print(json.dumps(dict(metric='512-res try-on images/sec (full generator: ' + ('patch routing + ' if routed else '') + 'encoders + mapping + synthesis)', value=round(args.steps * n * world / elapsed, 3),
                               unit='images/s', n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(1e3 * elapsed / args.steps, 2),

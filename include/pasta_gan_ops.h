@@ -542,6 +542,20 @@ typedef struct {
 int pg_warp_perspective_u8(const pg_warp_job* jobs_device, int njobs, int max_dst_pixels, void* stream);
 int pg_patch_compose_u8(const unsigned char* patch, const unsigned char* mask, unsigned char* canvas, unsigned char* canvas2,
                         int h, int w, int mask_channels, void* stream);
+/* Round 6 -- the whole paste sequence of `njobs` canvases in one launch (a batch's de-normalised garments: dataset.py:2620-2633 run per part and per sample
+ * in the reference): job = one h x w x 3 canvas, its parts in paste order (patch, mask; later parts overwrite earlier ones), and optionally a second canvas that
+ * receives only the parts with to_canvas2 != 0.  Every pixel of the canvases is written (0 where no part's eroded mask is set).  `jobs_device` lives in device memory. */
+#define PG_COMPOSE_MAX_PARTS 10
+typedef struct pg_compose_job {
+    unsigned char* canvas;
+    unsigned char* canvas2;                              /* may be NULL */
+    const unsigned char* patch[PG_COMPOSE_MAX_PARTS];    /* h x w x 3 */
+    const unsigned char* mask[PG_COMPOSE_MAX_PARTS];     /* h x w x mask_channels, channel 0 is used */
+    int nparts;
+    int to_canvas2[PG_COMPOSE_MAX_PARTS];
+    int pad_;
+} pg_compose_job;
+int pg_patch_compose_ordered_u8(const pg_compose_job* jobs_device, int njobs, int h, int w, int mask_channels, void* stream);
 int pg_patch_routing_abi_version(void);
 
 #ifdef __cplusplus

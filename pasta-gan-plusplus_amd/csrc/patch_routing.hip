@@ -80,9 +80,53 @@ __global__ __launch_bounds__(256) void patch_compose_u8_kernel(const uint8_t* __
     }
 }
 
+// The whole paste sequence of one canvas in one pass (round 6): the reference pastes its parts one after the other, later parts overwriting earlier ones
+// (dataset.py:2620-2633), i.e. a pixel ends up with the patch of the LAST part whose eroded mask is set there, or 0.  One job = one canvas (+ the copy that
+// skips the sleeve parts); one thread = one pixel, walking the job's parts in order.  Every canvas pixel is written: the canvases need no zero fill.
+__global__ __launch_bounds__(256) void patch_compose_ordered_u8_kernel(const pg_compose_job* __restrict__ jobs, int h, int w, int mc) {
+    const pg_compose_job* jb = jobs + blockIdx.y;
+    const int npix = h * w, nparts = jb->nparts;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < npix; i += gridDim.x * 256) {
+        const int y = i / w, x = i - y * w;
+        int last = -1, last2 = -1;
+        for (int p = 0; p < nparts; p++) {
+            const uint8_t* mask = jb->mask[p];
+            bool all = mask[(int64_t)i * mc] == 255;          // (the window's own pixel first: most pixels lie outside a part)
+            for (int ky = 0; ky < 8 && all; ky++) {
+                const int yy = y + ky - 4;
+                if (yy < 0 || yy >= h) continue;
+                for (int kx = 0; kx < 8; kx++) {
+                    const int xx = x + kx - 4;
+                    if (xx < 0 || xx >= w) continue;
+                    if (mask[((int64_t)yy * w + xx) * mc] != 255) { all = false; break; }
+                }
+            }
+            if (all) {
+                last = p;
+                if (jb->to_canvas2[p]) last2 = p;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            jb->canvas[(int64_t)i * 3 + c] = last >= 0 ? jb->patch[last][(int64_t)i * 3 + c] : (uint8_t)0;
+            if (jb->canvas2) jb->canvas2[(int64_t)i * 3 + c] = last2 >= 0 ? jb->patch[last2][(int64_t)i * 3 + c] : (uint8_t)0;
+        }
+    }
+}
+
 }  // namespace
 
 PG_EXPORT int pg_patch_routing_abi_version(void) { return PG_ABI_VERSION; }
+
+PG_EXPORT int pg_patch_compose_ordered_u8(const pg_compose_job* jobs_device, int njobs, int h, int w, int mask_channels, void* stream) {
+    if (!jobs_device || njobs <= 0 || h <= 0 || w <= 0 || mask_channels <= 0) return PG_ERR_INVALID_ARG;
+    if ((int64_t)h * w > 0x3fffffffLL) return PG_ERR_TOO_LARGE;
+    if (njobs > 65535) return PG_ERR_TOO_LARGE;
+    int bx = (h * w + 255) / 256;
+    if (bx > 1024) bx = 1024;
+    hipLaunchKernelGGL(patch_compose_ordered_u8_kernel, dim3((unsigned)bx, (unsigned)njobs), dim3(256), 0, (hipStream_t)stream, jobs_device, h, w, mask_channels);
+    return pg::launch_status();
+}
 
 PG_EXPORT int pg_warp_perspective_u8(const pg_warp_job* jobs_device, int njobs, int max_dst_pixels, void* stream) {
     if (!jobs_device || njobs <= 0 || max_dst_pixels <= 0) return PG_ERR_INVALID_ARG;

@@ -35,6 +35,17 @@ class WarpJob(ctypes.Structure):
                 ('dst_w', ctypes.c_int), ('channels', ctypes.c_int), ('block_w', ctypes.c_int), ('minv', ctypes.c_double * 9)]
 
 
+class ComposeJob(ctypes.Structure):
+    """Mirror of ``pg_compose_job`` (include/pasta_gan_ops.h)."""
+    _fields_ = [('canvas', ctypes.c_void_p), ('canvas2', ctypes.c_void_p), ('patch', ctypes.c_void_p * 10), ('mask', ctypes.c_void_p * 10),
+                ('nparts', ctypes.c_int), ('to_canvas2', ctypes.c_int * 10), ('pad_', ctypes.c_int)]
+
+
+_WARP_DT = np.dtype([('src', 'u8'), ('dst', 'u8'), ('src_h', 'i4'), ('src_w', 'i4'), ('dst_h', 'i4'), ('dst_w', 'i4'), ('channels', 'i4'), ('block_w', 'i4'),
+                     ('minv', 'f8', (9,))])
+_COMPOSE_DT = np.dtype([('canvas', 'u8'), ('canvas2', 'u8'), ('patch', 'u8', (10,)), ('mask', 'u8', (10,)), ('nparts', 'i4'), ('to_canvas2', 'i4', (10,)), ('pad_', 'i4')])
+assert _WARP_DT.itemsize == ctypes.sizeof(WarpJob) and _COMPOSE_DT.itemsize == ctypes.sizeof(ComposeJob)
+
 _plugin = None
 
 
@@ -47,6 +58,8 @@ def _init():
         lib.pg_warp_perspective_u8.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
         lib.pg_patch_compose_u8.restype = ctypes.c_int
         lib.pg_patch_compose_u8.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 3 + [ctypes.c_void_p]
+        lib.pg_patch_compose_ordered_u8.restype = ctypes.c_int
+        lib.pg_patch_compose_ordered_u8.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 4 + [ctypes.c_void_p]
         _plugin = plugin
     return _plugin
 
@@ -82,7 +95,7 @@ def _valid(joints, names):
 _LEG_FALLBACK = {('lhip', 'lknee'): ('lhip', 'lknee', 0.85), ('rhip', 'rknee'): ('rhip', 'rknee', 0.85),
                  ('lknee', 'lankle'): ('lknee', 'lankle', 0.80), ('rknee', 'rankle'): ('rknee', 'rankle', 0.80)}
 
-def get_crop(keypoints, bpart, wh, o_w, o_h, ar=1.0):
+def get_crop(keypoints, bpart, wh, o_w, o_h, ar=1.0, _quad_only=False):
     """Homographies (image -> patch, patch -> image) of one body part, or (None, None) when its joints are missing.
     Same decisions as dataset.py:2373-2542: joint-confidence fall-backs, leg completion from the torso length, widened torso
     and neck quadrilaterals, limb strips of aspect ratio `ar` with side-dependent widening."""
@@ -145,8 +158,35 @@ def get_crop(keypoints, bpart, wh, o_w, o_h, ar=1.0):
         a, b, c, d = _limb_corners(src, normal, ar / 2.0, names)
         quad = np.float32([a, d, c, b])
 
+    if _quad_only:
+        return quad
     part_dst = np.float32(wh * np.float32([[0.0, 0.0], [0.0, 1.0], [1.0, 1.0], [1.0, 0.0]]))
     return get_perspective_transform(quad, part_dst), get_perspective_transform(part_dst, quad)
+
+
+def perspective_transforms(src, dst):
+    """`get_perspective_transform` of K point-quadruple pairs at once: src, dst [K, 4, 2] -> [K, 3, 3].  One batched LAPACK call (each system is factored
+    on its own, exactly as the single solves are: the results are bit-identical, tests/test_patch_routing.py)."""
+    src, dst = np.asarray(src, np.float64), np.asarray(dst, np.float64)
+    k = src.shape[0]
+    x, y, X, Y = src[:, :, 0], src[:, :, 1], dst[:, :, 0], dst[:, :, 1]
+    zero, one = np.zeros((k, 4)), np.ones((k, 4))
+    a = np.concatenate([np.stack([x, y, one, zero, zero, zero, -x * X, -y * X], 2), np.stack([zero, zero, zero, x, y, one, -x * Y, -y * Y], 2)], axis=1)
+    sol = np.linalg.solve(a, np.concatenate([X, Y], axis=1)[:, :, None])[:, :, 0]
+    return np.concatenate([sol, np.ones((k, 1))], axis=1).reshape(k, 3, 3)
+
+
+def invert3x3_batch(m):
+    """`invert3x3` of [K, 3, 3] matrices, the same products and sums in the same order (element-wise float64: bit-identical to the scalar form)."""
+    m = np.asarray(m, np.float64)
+    c = lambda r0, c0, r1, c1: m[:, r0, c0] * m[:, r1, c1]
+    det = m[:, 0, 0] * (c(1, 1, 2, 2) - c(1, 2, 2, 1)) - m[:, 0, 1] * (c(1, 0, 2, 2) - c(1, 2, 2, 0)) + m[:, 0, 2] * (c(1, 0, 2, 1) - c(1, 1, 2, 0))
+    with np.errstate(divide='ignore', invalid='ignore'):
+        d = np.where(det == 0, 0.0, 1.0 / np.where(det == 0, 1.0, det))
+    out = np.stack([(c(1, 1, 2, 2) - c(1, 2, 2, 1)) * d, (c(0, 2, 2, 1) - c(0, 1, 2, 2)) * d, (c(0, 1, 1, 2) - c(0, 2, 1, 1)) * d,
+                    (c(1, 2, 2, 0) - c(1, 0, 2, 2)) * d, (c(0, 0, 2, 2) - c(0, 2, 2, 0)) * d, (c(0, 2, 1, 0) - c(0, 0, 1, 2)) * d,
+                    (c(1, 0, 2, 1) - c(1, 1, 2, 0)) * d, (c(0, 1, 2, 0) - c(0, 0, 2, 1)) * d, (c(0, 0, 1, 1) - c(0, 1, 1, 0)) * d], axis=1)
+    return np.where((det == 0)[:, None], 0.0, out)
 
 
 def _limb_corners(src, normal, alpha, names):
@@ -375,3 +415,144 @@ def normalize(upper_img, lower_img, upper_clothes_mask, lower_clothes_mask, slee
     part_imgs[5], part_masks[5] = torch.where(c53, flip(i5), i5), torch.where(c53, flip(m3), m5)
 
     return torch.cat(part_imgs, dim=2), torch.cat(part_imgs_lower, dim=2), denorm_upper, denorm_upper_wo_sleeve, denorm_lower
+
+
+def _upload_table(arr, dev):
+    """A job table (NumPy structured array) in device memory: through pinned memory, asynchronously."""
+    return torch.from_numpy(arr.view(np.uint8).reshape(-1)).pin_memory().to(dev, non_blocking=True)
+
+
+def normalize_batch(samples, box_factor, device='cuda'):
+    """`normalize` of a whole batch with THREE native launches instead of ~17 per sample: one image -> patch warp launch and one
+    patch -> canvas warp launch over every job of every sample, one ordered erode-and-paste launch over every canvas (pg_patch_compose_ordered_u8), the
+    homographies of all samples from one batched solve and the bookkeeping around them as a handful of batched tensor operations.
+
+    samples: list of (upper_img, lower_img, upper_clothes_mask, lower_clothes_mask, sleeve_mask | None, clothes_keypoints, person_keypoints), images uint8
+    [H, W, 3] (all the same size).  Returns the five results of `normalize`, stacked: img [N, h, w, 30], img_lower [N, h, w, 15], denorm_upper_img,
+    denorm_upper_img_wo_sleeve, denorm_lower_img [N, H, W, 3] -- bit-identical to the per-sample calls (tests/test_patch_routing.py)."""
+    dev = torch.device(device)
+    n = len(samples)
+    if dev.type != 'cuda':
+        outs = [normalize(*s, box_factor, device=device) for s in samples]
+        return tuple(torch.stack([o[i] for o in outs]) for i in range(5))
+    lib = _init().lib
+    ups = torch.stack([_gpu_u8(s[0], dev) for s in samples])
+    los = torch.stack([_gpu_u8(s[1], dev) for s in samples])
+    ums = torch.stack([_gpu_u8(s[2], dev) for s in samples])
+    lms = torch.stack([_gpu_u8(s[3], dev) for s in samples])
+    o_h, o_w = int(ups.shape[1]), int(ups.shape[2])
+    h, w = o_h // 2 ** box_factor, o_w // 2 ** box_factor
+    wh = np.expand_dims(np.array([w, h]), 0)
+    with_sleeve = [i for i, s in enumerate(samples) if s[4] is not None]
+    if with_sleeve:
+        sl = torch.stack([_gpu_u8(samples[i][4], dev) for i in with_sleeve])
+        u_s, m_s = ups[with_sleeve], ums[with_sleeve]
+        sleeve_img, sleeve_msk, body_img, body_msk = u_s * sl, m_s * sl, u_s * (1 - sl), m_s * (1 - sl)
+    pos = {i: k for k, i in enumerate(with_sleeve)}
+
+    def sources(i, ii):                                      # (image, mask) the clothes-side warps of part ii read
+        if i in pos:
+            return (sleeve_img[pos[i]], sleeve_msk[pos[i]]) if ii in SLEEVE_PARTS else (body_img[pos[i]], body_msk[pos[i]])
+        return ups[i], ums[i]
+
+    # ---- host geometry: the quadrilaterals per sample and part, then every homography in one batched solve
+    part_dst = np.float32(wh * np.float32([[0.0, 0.0], [0.0, 1.0], [1.0, 1.0], [1.0, 0.0]]))
+    cq, pq = {}, {}
+    for i, s in enumerate(samples):
+        for ii, bpart in enumerate(BPARTS):
+            ar = 0.5 if ii < 6 else 0.4
+            for store, kp in ((cq, s[5]), (pq, s[6])):
+                q = get_crop(kp, bpart, wh, o_w, o_h, ar, _quad_only=True)
+                if not isinstance(q, tuple):
+                    store[(i, ii)] = q
+    ckeys, pkeys = list(cq), list(pq)
+    src = [cq[k] for k in ckeys] + [pq[k] for k in pkeys] + [part_dst] * len(pkeys)
+    dst = [part_dst] * (len(ckeys) + len(pkeys)) + [pq[k] for k in pkeys]
+    mats = perspective_transforms(np.stack(src), np.stack(dst)) if src else np.zeros((0, 3, 3))
+    invs = invert3x3_batch(mats).reshape(-1, 9)              # what the warp kernel takes: the inverse of the matrix cv2.warpPerspective is given
+    c_m = {k: invs[j] for j, k in enumerate(ckeys)}
+    p_m = {k: invs[len(ckeys) + j] for j, k in enumerate(pkeys)}
+    p_inv = {k: invs[len(ckeys) + len(pkeys) + j] for j, k in enumerate(pkeys)}
+
+    # ---- stage 1: image -> patch.  Slots of P1: part images 0..9, part masks 10..19, lower images 20..24, lower masks 25..29 (missing parts stay zero)
+    lower_ids = [0, 6, 7, 8, 9]
+    P1 = torch.zeros([n, 30, h, w, 3], dtype=torch.uint8, device=dev)
+    P2 = torch.empty([n, 30, o_h, o_w, 3], dtype=torch.uint8, device=dev)
+    p1, p2 = P1.data_ptr(), P2.data_ptr()
+    s1, s2 = h * w * 3, o_h * o_w * 3
+    j1, j2 = [], []
+    for i in range(n):
+        for ii in range(10):
+            if (i, ii) in c_m:
+                img_s, msk_s = sources(i, ii)
+                j1.append((img_s.data_ptr(), p1 + (i * 30 + ii) * s1, c_m[(i, ii)]))
+                j1.append((msk_s.data_ptr(), p1 + (i * 30 + 10 + ii) * s1, c_m[(i, ii)]))
+                if (i, ii) in p_inv:
+                    j2.append((p1 + (i * 30 + ii) * s1, p2 + (i * 30 + ii) * s2, p_inv[(i, ii)]))
+                    j2.append((p1 + (i * 30 + 10 + ii) * s1, p2 + (i * 30 + 10 + ii) * s2, p_inv[(i, ii)]))
+            if (ii == 0 or ii >= 6) and (i, ii) in p_m:
+                k = lower_ids.index(ii)
+                j1.append((los[i].data_ptr(), p1 + (i * 30 + 20 + k) * s1, p_m[(i, ii)]))
+                j1.append((lms[i].data_ptr(), p1 + (i * 30 + 25 + k) * s1, p_m[(i, ii)]))
+                j2.append((p1 + (i * 30 + 20 + k) * s1, p2 + (i * 30 + 20 + k) * s2, p_inv[(i, ii)]))
+                j2.append((p1 + (i * 30 + 25 + k) * s1, p2 + (i * 30 + 25 + k) * s2, p_inv[(i, ii)]))
+
+    def warp_table(jobs, sh, sw, dh, dw):
+        t = np.zeros(len(jobs), dtype=_WARP_DT)
+        t['src'], t['dst'] = [j[0] for j in jobs], [j[1] for j in jobs]
+        t['src_h'], t['src_w'], t['dst_h'], t['dst_w'], t['channels'], t['block_w'] = sh, sw, dh, dw, 3, _block_width(dh, dw)
+        t['minv'] = np.stack([j[2] for j in jobs])
+        return t
+    stream = nat.stream_of(P1)
+    keep = []
+    with torch.cuda.device(dev):
+        for jobs, geo in ((j1, (o_h, o_w, h, w)), (j2, (h, w, o_h, o_w))):
+            if not jobs:
+                continue
+            tab = _upload_table(warp_table(jobs, *geo), dev)
+            keep.append(tab)
+            nat.check(lib.pg_warp_perspective_u8(tab.data_ptr(), len(jobs), geo[2] * geo[3], stream), 'pg_warp_perspective_u8')
+            if traffic_counter is not None:
+                traffic_counter['bytes'] += len(jobs) * 3 * (geo[0] * geo[1] + geo[2] * geo[3])
+                traffic_counter['launches'] += 1
+
+        # ---- stage 3: every canvas of the batch in one ordered erode-and-paste launch
+        D = torch.empty([3, n, o_h, o_w, 3], dtype=torch.uint8, device=dev)       # denorm_upper, denorm_upper_wo_sleeve, denorm_lower
+        d0 = D.data_ptr()
+        ct = np.zeros(2 * n, dtype=_COMPOSE_DT)
+        for i in range(n):
+            up_parts = [ii for ii in range(10) if (i, ii) in c_m and (i, ii) in p_inv]
+            lo_parts = [ii for ii in lower_ids if (i, ii) in p_m]
+            a, b = ct[2 * i], ct[2 * i + 1]
+            a['canvas'], a['canvas2'], a['nparts'] = d0 + i * s2, d0 + (n + i) * s2, len(up_parts)
+            for k, ii in enumerate(up_parts):
+                a['patch'][k], a['mask'][k], a['to_canvas2'][k] = p2 + (i * 30 + ii) * s2, p2 + (i * 30 + 10 + ii) * s2, int(ii not in SLEEVE_PARTS)
+            b['canvas'], b['canvas2'], b['nparts'] = d0 + (2 * n + i) * s2, 0, len(lo_parts)
+            for k, ii in enumerate(lo_parts):
+                kk = lower_ids.index(ii)
+                b['patch'][k], b['mask'][k] = p2 + (i * 30 + 20 + kk) * s2, p2 + (i * 30 + 25 + kk) * s2
+        tab = _upload_table(ct, dev)
+        keep.append(tab)
+        nat.check(lib.pg_patch_compose_ordered_u8(tab.data_ptr(), 2 * n, o_h, o_w, 3, stream), 'pg_patch_compose_ordered_u8')
+        if traffic_counter is not None:
+            traffic_counter['bytes'] += int(sum(int(c_['nparts']) for c_ in ct)) * 2 * s2 + 3 * n * s2
+            traffic_counter['launches'] += 1
+
+    # ---- the rest of `normalize` on the batched buffers: lower-garment parts give way to the upper garment; a missing sleeve is mirrored from the other side
+    imgs, masks, imgs_lo, masks_lo = P1[:, 0:10], P1[:, 10:20], P1[:, 20:25], P1[:, 25:30]
+    gone = (masks[:, [0, 6, 8]].to(torch.int32).sum(dim=4, keepdim=True) > 0)            # [N, 3, h, w, 1]
+    keep_lo = (~gone).to(torch.uint8)
+    idx = torch.tensor([0, 1, 3], device=dev)
+    imgs_lo = imgs_lo.index_copy(1, idx, imgs_lo[:, [0, 1, 3]] * keep_lo)
+    masks_lo = masks_lo.index_copy(1, idx, masks_lo[:, [0, 1, 3]] * keep_lo)
+    has = (masks != 0).flatten(2).any(dim=2)                                              # [N, 10]
+    col = lambda t: t[:, None, None, None]
+    flip = lambda t: torch.flip(t, dims=[2])                                              # [N, h, w, 3]: the width axis
+    c24, c42 = col(~has[:, 2] & has[:, 4]), col(~has[:, 4] & has[:, 2])
+    c35, c53 = col(~has[:, 3] & has[:, 5]), col(~has[:, 5] & has[:, 3])
+    i2, m2, i3, m3, i4, m4, i5, m5 = imgs[:, 2], masks[:, 2], imgs[:, 3], masks[:, 3], imgs[:, 4], masks[:, 4], imgs[:, 5], masks[:, 5]
+    new_imgs = torch.stack([imgs[:, 0], imgs[:, 1], torch.where(c24, flip(i4), i2), torch.where(c35, flip(i3), i3), torch.where(c42, flip(i2), i4),
+                            torch.where(c53, flip(i5), i5), imgs[:, 6], imgs[:, 7], imgs[:, 8], imgs[:, 9]], dim=1)      # (parts 3 / 5: the image mirrored is the part's own, as in the reference)
+    img = new_imgs.permute(0, 2, 3, 1, 4).reshape(n, h, w, 30)
+    img_lower = imgs_lo.permute(0, 2, 3, 1, 4).reshape(n, h, w, 15)
+    return img, img_lower, D[0], D[1], D[2]

@@ -145,3 +145,56 @@ def test_normalize_matches_the_oracle_bit_for_bit(case):
         assert all(int(w_.astype(np.int64).sum()) > 0 for w_ in want)
     if case == 'nothing_valid':
         assert all(int(w_.astype(np.int64).sum()) == 0 for w_ in want)
+
+
+@pytest.mark.gpu
+def test_normalize_batch_equals_the_oracle_per_sample_bit_for_bit():
+    """`normalize_batch` (round 6: three native launches for the whole batch -- two warp launches over every job of every sample, one ordered erode-and-paste
+    launch over every canvas --, one batched solve for every homography) against the ORACLE's per-sample `normalize`, bit for bit, on a batch that mixes the
+    four cases of the per-sample test: all joints, missing knees and nose (leg fall-backs), a missing left arm with a sleeve mask (mirrored sleeve), nothing valid
+    (empty job lists, canvases written as zeros by the compose launch); and against the product's own per-sample route."""
+    from oracle import patch_routing_ref as R
+    from training import patch_routing as P
+    cases = ['all_joints', 'missing_knees_and_nose', 'no_left_arm_with_sleeve_mask', 'nothing_valid', 'all_joints_b', 'no_right_arm_with_sleeve_mask']
+    samples = []
+    for case in cases:
+        rng = np.random.default_rng(len(case) + 100)
+        drop = dict(all_joints=(), all_joints_b=(), missing_knees_and_nose=('lknee', 'rknee', 'cnose'), no_left_arm_with_sleeve_mask=('lelbow', 'lwrist'),
+                    no_right_arm_with_sleeve_mask=('relbow', 'rwrist'), nothing_valid=tuple(JOINTS))[case]
+        ckp, pkp = keypoints(rng, 8.0, drop), keypoints(rng, 8.0, drop)
+        up, lo = (rng.integers(0, 256, (512, 512, 3), dtype=np.uint8) for _ in range(2))
+        um = np.zeros((512, 512, 3), np.uint8)
+        um[90:310, 150:370] = 255
+        lm = np.zeros((512, 512, 3), np.uint8)
+        lm[270:505, 190:330] = 255
+        sleeve = None
+        if 'sleeve' in case:
+            sleeve = np.zeros((512, 512, 1), np.uint8)
+            sleeve[100:300, :215] = 1
+            sleeve[100:300, 300:] = 1
+        samples.append((up, lo, um, lm, sleeve, ckp, pkp))
+    P.traffic_counter = dict(bytes=0, launches=0)
+    try:
+        got = P.normalize_batch(samples, 2)
+        launches = P.traffic_counter['launches']
+    finally:
+        P.traffic_counter = None
+    assert launches == 3
+    names = ('norm_img', 'norm_img_lower', 'denorm_upper_img', 'denorm_upper_img_wo_sleeve', 'denorm_lower_img')
+    for i, s in enumerate(samples):
+        want = R.normalize(*s, 2)
+        own = P.normalize(*s, 2)
+        for nm, g, w_, o in zip(names, got, want, own):
+            assert tuple(g[i].shape) == w_.shape and g.dtype == torch.uint8, (cases[i], nm)
+            assert np.array_equal(g[i].cpu().numpy(), w_), (cases[i], nm)
+            assert torch.equal(g[i], o), (cases[i], nm)
+
+
+def test_batched_host_geometry_is_bit_identical_to_the_single_solves():
+    from training import patch_routing as P
+    rng = np.random.default_rng(5)
+    src, dst = rng.normal(size=(64, 4, 2)) * 60 + 200, rng.normal(size=(64, 4, 2)) * 60 + 200
+    mats = P.perspective_transforms(src, dst)
+    assert np.array_equal(mats, np.stack([P.get_perspective_transform(s, d) for s, d in zip(src, dst)]))
+    mats[3] = 0.0                                                    # a singular matrix: cv::invert's zero result
+    assert np.array_equal(P.invert3x3_batch(mats), np.stack([P.invert3x3(m).reshape(9) for m in mats]))

@@ -314,6 +314,16 @@ int pg_conv2d_up2_splitk_plan(int N, int Cin, int H, int W, int Cout);
 int pg_conv2d_up2_forward_splitk(const float* x, const float* packed, float* y, int N, int Cin, int H, int W, int Cout,
                                  const int64_t ystride[4], const float* in_scale, const float* out_scale, float* workspace, int ksplit, void* stream);
 
+/* Round 6 -- the same layer with its multiplies on the bf16 matrix pipe (csrc/conv2d_up2x3.h): every float32 operand the exact sum of three bf16 values
+ * (truncation split), a float32 product = the six largest plane products on v_mfma_f32_32x32x16_bf16, float32 accumulation -- float32-class results at 6/16 of
+ * the fp32 MFMA's issue time.  `packed` as above (its edge pass computes the last output column / row), `packed_x3` = pg_conv2d_up2x3_pack_weight(packed),
+ * pg_conv2d_up2x3_packed_size(Cout, Cin) BYTES, once per weight version.  Serves W > 16, W % 4 == 0, Cin % 16 == 0, x 16-byte aligned; anything else
+ * returns PG_ERR_UNSUPPORTED (callers then use pg_conv2d_up2_forward). */
+int64_t pg_conv2d_up2x3_packed_size(int Cout, int Cin);
+int pg_conv2d_up2x3_pack_weight(const float* packed, void* packed_x3, int Cout, int Cin, void* stream);
+int pg_conv2d_up2x3_forward(const float* x, const float* packed, const void* packed_x3, float* y, int N, int Cin, int H, int W, int Cout,
+                            const int64_t ystride[4], const float* in_scale, const float* out_scale, void* stream);
+
 /* Streaming 1x1 convolution with few output channels (Cout <= 8; the ToRGB / parsing heads, networks.py:287-316,
  * modulated_conv2d with demodulate=False at networks.py:37-94): float32 NCHW, HW % 4 == 0, 16-byte aligned tensors:
  *   y[n,o,p] = clamp(sum_c x[n,c,p] * w[o,c] * scale * styles[n,c] + bias[o]) + skip[n,o,p]

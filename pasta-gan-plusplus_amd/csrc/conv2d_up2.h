@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_up2(Up2Params p) {
 }
 
 template <int TRW, bool VEC = false>
-int launch_up2_t(const Up2Params& p0, hipStream_t s) {
+int launch_up2_t(const Up2Params& p0, hipStream_t s, bool edges_only = false) {
     typedef UGeo<TRW, VEC> G;
     Up2Params p = p0;
     p.tilesX = (p.W + TRW - 1) / TRW;
@@ -367,7 +367,7 @@ int launch_up2_t(const Up2Params& p0, hipStream_t s) {
     p.etilesY = (p.H + 1 + U_EQ - 1) / U_EQ;
     const int64_t etiles = (int64_t)p.N * p.etilesY * p.mblocks * p.ksplit;
     if (tiles + etiles > 0x7fffffffLL) return PG_ERR_TOO_LARGE;
-    p.total_tiles = (int)tiles;
+    p.total_tiles = edges_only ? 0 : (int)tiles;           // edges_only (conv2d_up2x3.h runs the main tiles): the edge pass, then every workgroup leaves
     p.edge_tiles = (int)etiles;
     p.retilesX = (p.W + U_EQ - 1) / U_EQ;
     const int64_t retiles = redge ? (int64_t)p.N * p.retilesX * p.mblocks * p.ksplit : 0;
@@ -378,7 +378,8 @@ int launch_up2_t(const Up2Params& p0, hipStream_t s) {
     if (lds > 160 * 1024) return PG_ERR_UNSUPPORTED;
     int per_cu = (int)((160 * 1024) / lds);
     if (per_cu > 2) per_cu = 2;                             // ~230 VGPRs x 4 waves per workgroup
-    const int64_t blocks = tiles + etiles + retiles < (int64_t)num_cu() * per_cu ? tiles + etiles + retiles : (int64_t)num_cu() * per_cu;
+    const int64_t work = (edges_only ? 0 : tiles) + etiles + retiles;
+    const int64_t blocks = work < (int64_t)num_cu() * per_cu ? work : (int64_t)num_cu() * per_cu;
     if (p.in_scale) {
         static PerDeviceOnce a1;
         const hipError_t e = a1.run([] { return hipFuncSetAttribute((const void*)conv2d_up2<true, TRW, VEC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
@@ -419,6 +420,10 @@ __global__ __launch_bounds__(256) void up2_sum_slices(const float* __restrict__ 
         for (int z = 1; z < ksplit; z++) v += ((const f4*)ws)[(int64_t)z * slice4 + i];      // fixed order: deterministic
         ((f4*)y)[i] = v;
     }
+}
+
+inline int launch_up2_edges_only(const Up2Params& p, hipStream_t s) {      // (the geometry conv2d_up2x3.h serves: 32-wide tiles, 16-byte staging)
+    return launch_up2_t<32, true>(p, s, true);
 }
 
 inline int launch_up2(const Up2Params& p, hipStream_t s) {

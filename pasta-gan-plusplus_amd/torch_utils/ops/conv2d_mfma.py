@@ -154,6 +154,12 @@ def _init(plugin_name='conv2d_plugin'):
         lib.pg_conv2d16_wgrad_plan.argtypes = [i] * 8
         lib.pg_conv2d_up2_splitk_plan.restype = i
         lib.pg_conv2d_up2_splitk_plan.argtypes = [i, i, i, i, i]
+        lib.pg_conv2d_up2x3_packed_size.restype = i64
+        lib.pg_conv2d_up2x3_packed_size.argtypes = [i, i]
+        lib.pg_conv2d_up2x3_pack_weight.restype = i
+        lib.pg_conv2d_up2x3_pack_weight.argtypes = [vp, vp, i, i, vp]
+        lib.pg_conv2d_up2x3_forward.restype = i
+        lib.pg_conv2d_up2x3_forward.argtypes = [vp, vp, vp, vp, i, i, i, i, i, ctypes.POINTER(ctypes.c_int64), vp, vp, vp]
         lib.pg_conv2d_up2_forward_splitk.restype = i
         lib.pg_conv2d_up2_forward_splitk.argtypes = [vp, vp, vp, i, i, i, i, i, ctypes.POINTER(ctypes.c_int64), vp, vp, vp, i, vp]
         lib.pg_conv3x3_cin1.restype = i
@@ -561,7 +567,19 @@ def pack_up2(weight, flip=False):
     w = weight.detach().float()
     if flip:
         w = w.flip([2, 3])
-    return dict(main=pack_weight(w.contiguous()))
+    packs = dict(main=pack_weight(w.contiguous()))
+    cout, cin = int(w.shape[0]), int(w.shape[1])
+    if UP2_X3 and cin % 16 == 0 and cin >= 32:     # round 6: the main tiles on the bf16 pipe (three-term operand splits, csrc/conv2d_up2x3.h): the split planes of the same pack, once per weight version
+        lib = _init().lib
+        x3 = torch.empty([lib.pg_conv2d_up2x3_packed_size(cout, cin)], dtype=torch.uint8, device=w.device)
+        with torch.cuda.device(w.device):
+            nat.check(lib.pg_conv2d_up2x3_pack_weight(nat.ptr(packs['main']), nat.ptr(x3), cout, cin, nat.stream_of(w)), 'pg_conv2d_up2x3_pack_weight')
+        packs['x3'] = x3
+    return packs
+
+
+# PG_UP2_X3=0: the fp32-MFMA kernel everywhere (A/B runs).  Default: layers whose input is wider than 16 pixels (a multiple of 4) with Cin % 16 == 0 multiply on the bf16 pipe.
+UP2_X3 = os.environ.get('PG_UP2_X3', '1') != '0'
 
 
 def conv_up2_forward(x, packs, cout, in_scale=None, out_scale=None):
@@ -583,7 +601,11 @@ def conv_up2_forward(x, packs, cout, in_scale=None, out_scale=None):
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
         ksplit = lib.pg_conv2d_up2_splitk_plan(n, cin, h, w, cout)        # the 8^2 / 16^2 layers: shares of the input channels side by side, one summing pass
-        if ksplit > 1:
+        x3 = packs.get('x3') if (UP2_X3 and ksplit == 1 and w > 16 and w % 4 == 0 and cin % 16 == 0 and cin >= 32 and x.data_ptr() % 16 == 0) else None
+        if x3 is not None:
+            st = lib.pg_conv2d_up2x3_forward(nat.ptr(x), nat.ptr(packs['main']), nat.ptr(x3), nat.ptr(y), n, cin, h, w, cout, nat.i64arr(y.stride()), nat.ptr(s_in), nat.ptr(s_out),
+                                             nat.stream_of(x))
+        elif ksplit > 1:
             ws = torch.empty([ksplit * buf.numel()], dtype=torch.float32, device=x.device)
             st = lib.pg_conv2d_up2_forward_splitk(nat.ptr(x), nat.ptr(packs['main']), nat.ptr(y), n, cin, h, w, cout, nat.i64arr(y.stride()), nat.ptr(s_in), nat.ptr(s_out),
                                                   nat.ptr(ws), ksplit, nat.stream_of(x))
@@ -592,7 +614,7 @@ def conv_up2_forward(x, packs, cout, in_scale=None, out_scale=None):
                                            nat.stream_of(x))
         if tl is not None:
             ev1.record()
-            tl.append(((3, 3, 2, 'direct', f'N{n} {cin}->{cout} {h}x{w} up2' + (' mod' if in_scale is not None else '')), 2.0 * n * cout * cin * 9 * h * w, ev0, ev1,
+            tl.append(((3, 3, 2, 'direct', f'N{n} {cin}->{cout} {h}x{w} up2' + (' x3' if x3 is not None else '') + (' mod' if in_scale is not None else '')), 2.0 * n * cout * cin * 9 * h * w, ev0, ev1,
                        4 * (x.numel() + n * cout * oh * ow)))
     nat.check(st, 'pg_conv2d_up2_forward')
     return y

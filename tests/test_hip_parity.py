@@ -2291,6 +2291,45 @@ def test_fused_up2_transposed_conv(n, cin, cout, h, w, mod):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('n,cin,cout,h,w', [(1, 32, 32, 8, 32), (2, 48, 40, 21, 36), (1, 64, 96, 33, 64), (3, 32, 70, 17, 100), (2, 128, 64, 40, 96), (8, 128, 64, 256, 256), (2, 512, 256, 64, 64)])
+def test_up2_transposed_conv_on_the_bf16_pipe_is_float32_class(n, cin, cout, h, w, monkeypatch):
+    """csrc/conv2d_up2x3.h (round 6): the fp32 `up = 2` layer's stride-2 transposed 3x3 convolution (conv2d_resample.py:125-142 -> conv2d_gradfix.conv_transpose2d)
+    with every float32 operand as the exact sum of three bf16 values and each float32 product as six bf16 products on v_mfma_f32_32x32x16_bf16 (fp32 accumulation);
+    main tiles by the new kernel (producer waves: 16-byte halo words -> LDS -> split planes; multiplying waves: 108 MFMAs per 16-channel chunk), the last output
+    column / row by the fp32 kernel's edge pass.  Admissible as float32 only if it IS float32-class: referee float64, error <= 2x the fp32-MFMA kernel's on the same
+    launch (measured 0.6-1.0x) and <= 2e-6 of the output scale; plain and modulated (input scale applied before the split, demodulation after); ragged heights (H % 8
+    != 0), widths that are no multiple of 32, Cout % 32 != 0, Cin = 32 (two chunks: the producers' one-round-ahead requests at their shortest); bit-identical
+    repeats; the pitched output the FIR pass reads in place."""
+    from torch_utils.ops import conv2d_mfma
+    gen = torch.Generator().manual_seed(7 * cin + cout + h)
+    x = torch.randn([n, cin, h, w], generator=gen).to(DEV)
+    wt = (torch.randn([cout, cin, 3, 3], generator=gen) / (3 * math.sqrt(cin))).to(DEV)
+    s_in, s_out = (torch.rand([n, cin], generator=gen) + 0.5).to(DEV), (torch.rand([n, cout], generator=gen) + 0.5).to(DEV)
+    packs = conv2d_mfma.pack_up2(wt)
+    assert 'x3' in packs and packs['x3'].numel() == conv2d_mfma._init().lib.pg_conv2d_up2x3_packed_size(cout, cin)
+    if conv2d_mfma._init().lib.pg_conv2d_up2_splitk_plan(n, cin, h, w, cout) > 1:
+        pytest.skip('split-K plan: this launch stays on the fp32 kernel')
+    for kw in (dict(), dict(in_scale=s_in, out_scale=s_out)):
+        xs = x.double() * (s_in.double()[:, :, None, None] if kw else 1.0)
+        ref = torch.nn.functional.conv_transpose2d(xs, wt.double().transpose(0, 1), stride=2)
+        if kw:
+            ref = ref * s_out.double()[:, :, None, None]
+        sc = float(ref.abs().max())
+        monkeypatch.setattr(conv2d_mfma, 'UP2_X3', False)
+        y32 = conv2d_mfma.conv_up2_forward(x, packs, cout, **kw)
+        monkeypatch.setattr(conv2d_mfma, 'UP2_X3', True)
+        tl = conv2d_mfma.start_timeline()
+        y = conv2d_mfma.conv_up2_forward(x, packs, cout, **kw)
+        conv2d_mfma.stop_timeline()
+        assert ' x3' in tl[-1][0][4], tl[-1][0]                        # the launch did take the bf16x3 kernel
+        assert y.shape == (n, cout, 2 * h + 1, 2 * w + 1) and y.stride(2) % 4 == 0
+        e32, e = float((y32.double() - ref).abs().max()), float((y.double() - ref).abs().max())
+        assert e <= 2 * e32 and e <= 2e-6 * sc, (e / sc, e32 / sc)
+        for _ in range(3):
+            assert torch.equal(conv2d_mfma.conv_up2_forward(x, packs, cout, **kw), y)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('n,cin,cin2,cout,h,w,fused', [(2, 64, 0, 64, 64, 64, True), (1, 32, 24, 40, 64, 66, True), (2, 70, 0, 96, 64, 64, False),
                                                      (1, 64, 64, 128, 80, 52, True), (1, 20, 0, 33, 64, 64, True)])
 def test_streaming_1x1_conv(n, cin, cin2, cout, h, w, fused):

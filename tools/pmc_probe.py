@@ -7,7 +7,7 @@ from torch_utils import custom_ops
 custom_ops.verbosity = 'none'
 from torch_utils.ops import conv2d_mfma
 dev = 'cuda'
-wg = {'winograd4': 2, 'winograd': 1}.get(sys.argv[1] if len(sys.argv) > 1 else '', 0)
+wg = {'winograd4': conv2d_mfma.F4_WIDE, 'winograd4_fp32': 2, 'winograd': 1}.get(sys.argv[1] if len(sys.argv) > 1 else '', 0)      # winograd4: the form the policy hands out (4 = bf16x3 GEMM)
 for (N, H, cin, cout) in [(8, 256, 128, 128), (8, 512, 64, 64)]:
     x = torch.randn(N, cin, H, H, device=dev)
     w = torch.randn(cout, cin, 3, 3, device=dev) / (3 * cin ** 0.5)

@@ -963,7 +963,8 @@ PG_EXPORT int pg_conv2d16_wgrad(const void* x, const void* dy, float* dw, float*
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------------------------------
-// float32 weight gradient on the bf16 matrix pipe by three-term operand splitting (round 5, exploratory: VERDICT r4 item 7; PG_WGRAD_BF16X3=1).
+// float32 weight gradient on the bf16 matrix pipe by three-term operand splitting (round 5; the default for the 3x3 layers with >= 64 channels,
+// PG_WGRAD_BF16X3=auto|0|1 in torch_utils/ops/conv2d_mfma.py).
 //
 // A float32 value is the exact sum of three bf16 values (8 + 8 + 8 significand bits, by truncation): x = x1 + x2 + x3, dy = d1 + d2 + d3.  Of the nine products
 // the three smallest (d2 x3, d3 x2, d3 x3: <= 2^-24 of |dy x|) are dropped, the other six are bf16 x bf16 products -- exact in float32 -- accumulated in float32 by
@@ -1007,7 +1008,9 @@ __global__ __launch_bounds__(256) void split3_bf16_cl_kernel(const float* __rest
             for (int e = 0; e < 2; e++) {
                 const float v = tile[cg + 2 * d + e][px];
                 const unsigned hb = __builtin_bit_cast(unsigned, v) & 0xffff0000u;
-                const float r = v - __builtin_bit_cast(float, hb);
+                // a non-finite value keeps its leading plane and gets zero remainders (inf - inf would turn an overflow into NaN where the fp32 kernel keeps +-inf: ADVICE r5)
+                const bool fin = (hb & 0x7f800000u) != 0x7f800000u;
+                const float r = fin ? v - __builtin_bit_cast(float, hb) : 0.f;
                 const unsigned mb = __builtin_bit_cast(unsigned, r) & 0xffff0000u;
                 const float r2 = r - __builtin_bit_cast(float, mb);
                 h2[e] = hb >> 16; m2[e] = mb >> 16; l2[e] = __builtin_bit_cast(unsigned, r2) >> 16;

@@ -275,27 +275,33 @@ __global__ __launch_bounds__(512, 1) void conv2d_up2x3(Up2Params p, const unsign
         if (UX_EXP & 32) st_t0 = __builtin_amdgcn_s_memtime();
         const int r = e_r0 + l31;
         const bool pair_ok = (p.ys[2] & 1) == 0 && (p.ys[1] & 1) == 0 && (p.ys[0] & 1) == 0 && (((uintptr_t)p.y) & 7) == 0 && p.ys[3] == 1;
+        // one 64-bit base per tile and lane, 32-bit offsets inside the image (the launcher checks that one image of y stays below 2^31 floats): the address arithmetic
+        // of the 64 stores per lane was a third of the epilogue
+        float* y_lane = p.y + (int64_t)e_n * p.ys[0] + (int64_t)(2 * r) * p.ys[3];
+        const int cs_ = (int)p.ys[1], rs_ = (int)p.ys[2], xs_ = (int)p.ys[3];
+        float scv[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) scv[k] = ep_scale[(k & 3) + 8 * (k >> 2) + 4 * half];
 #pragma unroll
         for (int nt = 0; nt < 2; nt++) {
             const int q = e_q0 + 2 * wave + nt;
 #pragma unroll
             for (int a = 0; a < 2; a++) {
                 const bool row_ok = a == 0 ? q <= p.H : q < p.H;
-                const int oy = 2 * q + a;
                 const bool ok = row_ok && r < p.W;
+                const int row_off = (2 * q + a) * rs_;
 #pragma unroll
                 for (int k = 0; k < 16; k++) {
                     const int rowc = (k & 3) + 8 * (k >> 2) + 4 * half;
                     const int co = e_m0 + rowc;
-                    const float sc = ep_scale[rowc];
-                    const float v0 = acc[2 * a][nt][k] * sc, v1 = acc[2 * a + 1][nt][k] * sc;
+                    const float v0 = acc[2 * a][nt][k] * scv[k], v1 = acc[2 * a + 1][nt][k] * scv[k];
                     if (co < p.Cout && ok && (!(UX_EXP & 16) || v0 == 12345.678f)) {
-                        float* dst = p.y + (int64_t)e_n * p.ys[0] + (int64_t)co * p.ys[1] + (int64_t)oy * p.ys[2] + (int64_t)(2 * r) * p.ys[3];
+                        float* dst = y_lane + (co * cs_ + row_off);
                         if (pair_ok) {
                             *(f32x2s*)dst = (f32x2s){v0, v1};
                         } else {
                             dst[0] = v0;
-                            dst[p.ys[3]] = v1;
+                            dst[xs_] = v1;
                         }
                     }
                 }
@@ -346,6 +352,7 @@ inline int launch_up2x3(const Up2Params& p0, const void* wx3, hipStream_t s) {
     p.cpk = p.Cin / UX_KC;
     const int64_t tiles = (int64_t)p.N * p.tilesX * p.tilesY * p.mblocks;
     if (tiles > 0x7fffffffLL) return PG_ERR_TOO_LARGE;
+    if ((int64_t)(p.Cout - 1) * p.ys[1] + (int64_t)(2 * p.H) * p.ys[2] + (int64_t)(2 * p.W) * p.ys[3] >= 0x7fffffffLL) return PG_ERR_UNSUPPORTED;      // 32-bit offsets inside one image of y
     p.total_tiles = (int)tiles;
     p.edge_tiles = p.redge_tiles = 0;
     const size_t lds = up2x3_lds_bytes(p.Cin);

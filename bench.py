@@ -366,7 +366,7 @@ def run_stack(args, rank, world, dev, dist):
                 config=dict(workload=f'BASELINE config 5: StyleGAN2 block stack 8^2..1024^2 (SynthesisLayer x2 + ToRGB + skip upsample per resolution), '
                                      f'channel_base 32768, channel_max {args.channel_max}, all blocks bf16 (fp32 accumulate), eval, noise_mode=const, random-init weights',
                             images_per_gpu_per_step=n, global_batch=n * world, parallelism=f'replicas x{world}', execution=execution),
-                roofline=dict(bound='hbm', kernel='conv2d_mfma16<bf16,...> (channels-last implicit GEMM, v_mfma_f32_32x32x16_bf16; all its launches of a step)',
+                roofline=dict(bound='hbm', kernel='conv2d_mfma16<bf16,...> (channels-last implicit GEMM) + conv2d_up2f16<bf16,...> (the up = 2 layers in one launch), both v_mfma_f32_32x32x16_bf16; all 16-bit convolution launches of a step',
                               achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(gbs / HBM_PEAK_GBS, 4),
                               traffic=committed_traffic('cfg5')[0], traffic_source=committed_traffic('cfg5')[1],
                               algorithmic_bytes_per_launch=round(sum(r[3] for r in dom) / max(len(dom), 1)),
@@ -451,14 +451,14 @@ def run_train(args, rank, world, dev, dist):
         if dom:
             fl, tm = sum(d[0] for d in dom), sum(d[1] for d in dom)
             fp32_part = dict(bound='mfma', kernel='conv2d_wgrad<3,3,1> + wgrad_reduce (fp32 weight gradient of the stride-1 3x3 layers, v_mfma_f32_32x32x2_f32)',
-                             achieved=round(fl / tm / 1e12, 2), peak=F32_MFMA_PEAK_TFLOPS, unit='TFLOP/s', frac=round(fl / tm / 1e12 / F32_MFMA_PEAK_TFLOPS, 4), traffic=None,
+                             achieved=round(fl / tm / 1e12, 2), peak=F32_MFMA_PEAK_TFLOPS, unit='TFLOP/s', frac=round(fl / tm / 1e12 / F32_MFMA_PEAK_TFLOPS, 4), traffic=None, traffic_note='not collected: no PMC pass was made over the training step this round',
                              launches_per_step=round(len(dom) / args.steps, 1), avg_launch_ms=round(1e3 * tm / len(dom), 4), time_frac_of_step=round(tm / elapsed, 4),
                              algorithmic_bytes_per_launch=round(sum(d[2] for d in dom) / len(dom)))
         if x3:
             fl3, tm3 = sum(d[0] for d in x3), sum(d[1] for d in x3)
             x3_part = dict(bound='mfma', kernel='conv2d16_wgrad<3,3,s,bf16> over the six products of three-term operand splits (+ pg_split3_bf16_cl x 2 and wgrad_reduce inside each event pair): '
                                                 'the float32 weight gradients of the 3x3 layers with >= 64 channels, fp32 accumulation; PG_WGRAD_BF16X3=0 sends them to conv2d_wgrad<3,3,s>',
-                           achieved=round(6 * fl3 / tm3 / 1e12, 1), peak=BF16_MFMA_PEAK_TFLOPS, unit='TFLOP/s', frac=round(6 * fl3 / tm3 / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4), traffic=None,
+                           achieved=round(6 * fl3 / tm3 / 1e12, 1), peak=BF16_MFMA_PEAK_TFLOPS, unit='TFLOP/s', frac=round(6 * fl3 / tm3 / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4), traffic=None, traffic_note='not collected: no PMC pass was made over the training step this round',
                            flops_counted='executed on the bf16 matrix pipe = 6 x the forward count of SURVEY 8d', fp32_equivalent_tflops=round(fl3 / tm3 / 1e12, 2),
                            fp32_equivalent_frac_of_fp32_peak=round(fl3 / tm3 / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
                            launches_per_step=round(len(x3) / args.steps, 1), avg_launch_ms=round(1e3 * tm3 / len(x3), 4), time_frac_of_step=round(tm3 / elapsed, 4),

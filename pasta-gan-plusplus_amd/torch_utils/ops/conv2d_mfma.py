@@ -562,14 +562,14 @@ def weight_gradient(x, dy, weight_shape, pad, stride=1):
     return dw
 
 
-def pack_up2(weight, flip=False):
+def pack_up2(weight, flip=False, x3=True):
     """Packed weights of `conv_up2_forward` for the OIHW 3x3 kernel w = `weight` (flipped spatially iff `flip`): the plain 3x3 pack."""
     w = weight.detach().float()
     if flip:
         w = w.flip([2, 3])
     packs = dict(main=pack_weight(w.contiguous()))
     cout, cin = int(w.shape[0]), int(w.shape[1])
-    if UP2_X3 and cin % 16 == 0 and cin >= 32:     # round 6: the main tiles on the bf16 pipe (three-term operand splits, csrc/conv2d_up2x3.h): the split planes of the same pack, once per weight version
+    if x3 and UP2_X3 and cin % 16 == 0 and cin >= 32:     # round 6: the main tiles on the bf16 pipe (three-term operand splits, csrc/conv2d_up2x3.h): the split planes of the same pack, once per weight version
         lib = _init().lib
         x3 = torch.empty([lib.pg_conv2d_up2x3_packed_size(cout, cin)], dtype=torch.uint8, device=w.device)
         with torch.cuda.device(w.device):
@@ -582,7 +582,7 @@ def pack_up2(weight, flip=False):
 UP2_X3 = os.environ.get('PG_UP2_X3', '1') != '0'
 
 
-def conv_up2_forward(x, packs, cout, in_scale=None, out_scale=None):
+def conv_up2_forward(x, packs, cout, in_scale=None, out_scale=None, x3=None):
     """conv_transpose2d(x * in_scale, w, stride=2, padding=0) * out_scale for a 3x3 kernel: all four output parities and the last
     output column in one launch (csrc/conv2d_up2.h).  `packs` = pack_up2(w).  Returns a [N, Cout, 2H+1, 2W+1] view whose rows are
     padded to a multiple of 4 floats (aligned pair stores here, aligned rows for the FIR pass that follows)."""
@@ -601,7 +601,8 @@ def conv_up2_forward(x, packs, cout, in_scale=None, out_scale=None):
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
         ksplit = lib.pg_conv2d_up2_splitk_plan(n, cin, h, w, cout)        # the 8^2 / 16^2 layers: shares of the input channels side by side, one summing pass
-        x3 = packs.get('x3') if (UP2_X3 and ksplit == 1 and w > 16 and w % 4 == 0 and cin % 16 == 0 and cin >= 32 and x.data_ptr() % 16 == 0) else None
+        # `x3` = False: the fp32-MFMA kernel whatever the pack holds (the training route: see training/networks.py _ModConvUp2Train)
+        x3 = packs.get('x3') if (x3 is not False and UP2_X3 and ksplit == 1 and w > 16 and w % 4 == 0 and cin % 16 == 0 and cin >= 32 and x.data_ptr() % 16 == 0) else None
         if x3 is not None:
             st = lib.pg_conv2d_up2x3_forward(nat.ptr(x), nat.ptr(packs['main']), nat.ptr(x3), nat.ptr(y), n, cin, h, w, cout, nat.i64arr(y.stride()), nat.ptr(s_in), nat.ptr(s_out),
                                              nat.stream_of(x))

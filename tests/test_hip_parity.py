@@ -2330,6 +2330,32 @@ def test_up2_transposed_conv_on_the_bf16_pipe_is_float32_class(n, cin, cout, h, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('n,cin,cout,h', [(8, 128, 64, 256), (8, 512, 256, 64), (4, 512, 512, 32)])
+def test_up2_bf16x3_repeated_launches_are_identical(n, cin, cout, h):
+    """Full-size launches of conv2d_up2x3 (producer / consumer waves behind one barrier per chunk, counted vector-memory waits, planes and weight slabs double
+    buffered), 40 in a row with other work in between: every result must equal the first one bit for bit and match the fp32-MFMA kernel to rounding -- the kind
+    of test that caught the F(4x4) kernel's missing barrier in round 3 (20 % of the launches wrong under load, every small test green)."""
+    from torch_utils.ops import conv2d_mfma
+    gen = torch.Generator().manual_seed(53)
+    x = torch.randn([n, cin, h, h], generator=gen).to(DEV)
+    other = torch.randn([n, cin, h, h], generator=gen).to(DEV)
+    wt = (torch.randn([cout, cin, 3, 3], generator=gen) / (3 * math.sqrt(cin))).to(DEV)
+    s_in, s_out = (torch.rand([n, cin], generator=gen) + 0.5).to(DEV), (torch.rand([n, cout], generator=gen) + 0.5).to(DEV)
+    packs = conv2d_mfma.pack_up2(wt)
+    assert 'x3' in packs
+    ref = conv2d_mfma.conv_up2_forward(x, packs, cout, in_scale=s_in, out_scale=s_out, x3=False)
+    first = conv2d_mfma.conv_up2_forward(x, packs, cout, in_scale=s_in, out_scale=s_out).clone()
+    assert float((first - ref).abs().max()) <= 2e-6 * scale_of(ref)
+    for it in range(40):
+        if it % 3 == 1:
+            conv2d_mfma.conv_up2_forward(other, packs, cout, in_scale=s_in, out_scale=s_out, x3=False)
+        if it % 5 == 2:
+            conv2d_mfma.conv_up2_forward(other, packs, cout)
+        y = conv2d_mfma.conv_up2_forward(x, packs, cout, in_scale=s_in, out_scale=s_out)
+        assert torch.equal(y, first), f'launch {it} differs from the first one: max |d| {float((y - first).abs().max()):.3e}'
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('n,cin,cin2,cout,h,w,fused', [(2, 64, 0, 64, 64, 64, True), (1, 32, 24, 40, 64, 66, True), (2, 70, 0, 96, 64, 64, False),
                                                      (1, 64, 64, 128, 80, 52, True), (1, 20, 0, 33, 64, 64, True)])
 def test_streaming_1x1_conv(n, cin, cin2, cout, h, w, fused):

@@ -2345,7 +2345,7 @@ def test_up2_bf16x3_repeated_launches_are_identical(n, cin, cout, h):
     assert 'x3' in packs
     ref = conv2d_mfma.conv_up2_forward(x, packs, cout, in_scale=s_in, out_scale=s_out, x3=False)
     first = conv2d_mfma.conv_up2_forward(x, packs, cout, in_scale=s_in, out_scale=s_out).clone()
-    assert float((first - ref).abs().max()) <= 2e-6 * scale_of(ref)
+    assert float((first - ref).abs().max()) <= 4e-6 * scale_of(ref)       # two fp32-class kernels against each other (K up to 4608); each vs float64 is tested above
     for it in range(40):
         if it % 3 == 1:
             conv2d_mfma.conv_up2_forward(other, packs, cout, in_scale=s_in, out_scale=s_out, x3=False)

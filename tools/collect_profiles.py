@@ -11,6 +11,38 @@ G = os.path.join(ROOT, 'gpurun_out')
 P = os.path.join(ROOT, 'profiles')
 
 
+def train_traffic(pre, stamp):
+    # config 4: the weight-gradient kernels of one training iteration by family (bench.py --mode train prices two of them: the bf16x3 group = the 16-bit
+    # kernel's launches + the splitting passes, and the fp32 stride-1 3x3 kernel)
+    d = os.path.join(G, 'traffic_train')
+    try:
+        fam = {}
+        for cname, scale in (('FETCH_SIZE', 2.0 * 1024), ('WRITE_SIZE', 1024.0)):
+            for r in csv.DictReader(open(os.path.join(d, cname + '.csv'))):
+                k = r['kernel']
+                key = ('bf16x3_wgrad' if 'conv2d16_wgrad_x3k' in k or ('conv2d16_wgrad<' in k and k.rstrip('>').endswith('true')) else
+                       'bf16x3_split' if 'split3_bf16' in k else 'fp32_wgrad_3x3_s1' if 'conv2d_wgrad<3, 3, 1' in k else
+                       'fp16_wgrad' if 'conv2d16_wgrad<' in k else 'fp32_wgrad_other' if 'conv2d_wgrad<' in k else 'reduce' if 'wgrad_reduce' in k else 'other')
+                e = fam.setdefault(key, dict(launches=0, fetch_bytes=0.0, write_bytes=0.0))
+                e['fetch_bytes' if cname == 'FETCH_SIZE' else 'write_bytes'] += scale * float(r['value_KiB'])
+                if cname == 'FETCH_SIZE':
+                    e['launches'] += 1
+        for e in fam.values():
+            e['hbm_bytes_per_launch'] = (e['fetch_bytes'] + e['write_bytes']) / max(e['launches'], 1)
+        x3n = fam.get('bf16x3_wgrad', dict(launches=0))['launches']
+        x3 = sum(fam[k]['fetch_bytes'] + fam[k]['write_bytes'] for k in ('bf16x3_wgrad', 'bf16x3_split') if k in fam) / max(x3n, 1)
+        out = dict(kernel='weight-gradient kernels of one training iteration (config 4, one GPU, batch 4)', measured_on=stamp, families=fam,
+                   hbm_bytes_per_launch=x3, hbm_bytes_per_launch_is='bf16x3 group: (16-bit weight-gradient launches + their two splitting passes) / weight-gradient launches',
+                   fp32_hbm_bytes_per_launch=fam.get('fp32_wgrad_3x3_s1', {}).get('hbm_bytes_per_launch'),
+                   note='rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over bench.py --mode train --steps 1 --warmup 1 (tools/traffic_run.sh), the second (timed) iteration; '
+                        'FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md; the fixed-order reductions (wgrad_reduce) are listed, not added')
+        with open(pre + 'traffic_train.json', 'w') as f:
+            json.dump(out, f, indent=1)
+        print('wrote', os.path.relpath(pre + 'traffic_train.json', ROOT), f'{x3 / 1e6:.1f} MB per bf16x3 weight gradient')
+    except OSError:
+        print('missing traffic train')
+
+
 def main(rnd, commit=None):
     commit = commit or subprocess.run(['git', 'rev-parse', '--short', 'HEAD'], cwd=ROOT, capture_output=True, text=True).stdout.strip()
     dirty = subprocess.run(['git', 'status', '--porcelain', '--', 'pasta-gan-plusplus_amd', 'bench.py'], cwd=ROOT, capture_output=True, text=True).stdout.strip()
@@ -61,6 +93,8 @@ def main(rnd, commit=None):
         with open(pre + f'traffic_{tag}.json', 'w') as f:
             json.dump(out, f, indent=1)
         print('wrote', os.path.relpath(pre + f'traffic_{tag}.json', ROOT), f'{(fetch + write) / 1e6:.1f} MB/launch')
+
+    train_traffic(pre, stamp)
 
     for src, dst, what in ((os.path.join(G, 'pmc', 'summary.txt'), pre + 'pmc_wino.txt', 'tools/pmc_run.sh: SQ counters of conv2d_wino4 (tools/pmc_probe.py winograd4: N8 128->128 256^2 = grid 196608 x ..., N8 64->64 512^2)'),
                            (os.path.join(G, 'pmc16', 'summary_n4_c64_o64_h512_k3.txt'), pre + 'pmc_mfma16.txt', 'tools/pmc16_run.sh 4 64 64 512: counters of conv2d_mfma16 (bf16 3x3 64->64 at 512^2, N=4)')):

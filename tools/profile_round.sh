@@ -9,6 +9,7 @@ bash tools/prof_run.sh cfg5 --mode bf16_1024 --conv-breakdown $R/gpurun_out/prof
 bash tools/prof_run.sh train --mode train --steps 3 --warmup 1 > gpurun_out/prof_train.log 2>&1
 bash tools/traffic_run.sh cfg2 conv2d_wino4 > gpurun_out/traffic_cfg2.log 2>&1
 bash tools/traffic_run.sh cfg5 pgconv16 --mode bf16_1024 > gpurun_out/traffic_cfg5.log 2>&1
+bash tools/traffic_run.sh train 'wgrad|split3_bf16' --mode train > gpurun_out/traffic_train.log 2>&1
 rm -f gpurun_out/pmc/summary.txt
 bash tools/pmc_run.sh > gpurun_out/pmc_wino.log 2>&1
 bash tools/pmc16_run.sh 4 64 64 512 > gpurun_out/pmc16.log 2>&1

@@ -12,12 +12,14 @@ for c in FETCH_SIZE WRITE_SIZE; do
   f=$(find /tmp/tr_$c -name "*counter_collection.csv" | head -1)
   python3 - "$f" "$O/$c.csv" "$KSUB" <<'PY'
 import csv, sys
-rows = [r for r in csv.DictReader(open(sys.argv[1])) if sys.argv[3] in r['Kernel_Name']]
+import re
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if re.search(sys.argv[3], r['Kernel_Name'])]      # <kernel substring> is a regular expression
 rows = rows[len(rows) // 2:]          # the timed step (second of the two passes)
 with open(sys.argv[2], 'w') as f:
     f.write('dispatch,kernel,grid_threads,counter,value_KiB\n')
     for r in rows:
-        f.write(f'{r["Dispatch_Id"]},"{r["Kernel_Name"].split("(")[0]}",{r["Grid_Size"]},{r["Counter_Name"]},{float(r["Counter_Value"]):.3f}\n')
+        name = r["Kernel_Name"].replace("(anonymous namespace)::", "").removeprefix("void ").split("(")[0]
+        f.write(f'{r["Dispatch_Id"]},"{name}",{r["Grid_Size"]},{r["Counter_Name"]},{float(r["Counter_Value"]):.3f}\n')
 print(len(rows), 'launches', sum(float(r['Counter_Value']) for r in rows) / max(len(rows), 1), 'KiB/launch')
 PY
 done

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 12
+#define PG_ABI_VERSION 13
 
 enum pg_dtype { PG_F32 = 0, PG_F16 = 1, PG_BF16 = 2, PG_F64 = 3 };
 
@@ -318,11 +318,12 @@ int pg_conv2d_up2_forward_splitk(const float* x, const float* packed, float* y, 
  * (truncation split), a float32 product = the six largest plane products on v_mfma_f32_32x32x16_bf16, float32 accumulation -- float32-class results at 6/16 of
  * the fp32 MFMA's issue time.  `packed` as above (its edge pass computes the last output column / row), `packed_x3` = pg_conv2d_up2x3_pack_weight(packed),
  * pg_conv2d_up2x3_packed_size(Cout, Cin) BYTES, once per weight version.  Serves W > 16, W % 4 == 0, Cin % 16 == 0, x 16-byte aligned; anything else
- * returns PG_ERR_UNSUPPORTED (callers then use pg_conv2d_up2_forward). */
+ * returns PG_ERR_UNSUPPORTED (callers then use pg_conv2d_up2_forward).  `edge_column`: N * Cin * H floats of scratch (the main kernel leaves input column W - 1
+ * there for the kernel that makes the last output column / row, csrc/conv2d_up2_edges.h), or NULL (that kernel gathers the column from x: slower). */
 int64_t pg_conv2d_up2x3_packed_size(int Cout, int Cin);
 int pg_conv2d_up2x3_pack_weight(const float* packed, void* packed_x3, int Cout, int Cin, void* stream);
 int pg_conv2d_up2x3_forward(const float* x, const float* packed, const void* packed_x3, float* y, int N, int Cin, int H, int W, int Cout,
-                            const int64_t ystride[4], const float* in_scale, const float* out_scale, void* stream);
+                            const int64_t ystride[4], const float* in_scale, const float* out_scale, float* edge_column, void* stream);
 
 /* Streaming 1x1 convolution with few output channels (Cout <= 8; the ToRGB / parsing heads, networks.py:287-316,
  * modulated_conv2d with demodulate=False at networks.py:37-94): float32 NCHW, HW % 4 == 0, 16-byte aligned tensors:

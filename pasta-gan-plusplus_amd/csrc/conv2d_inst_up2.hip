@@ -68,7 +68,7 @@ PG_EXPORT int pg_conv2d_up2x3_pack_weight(const float* packed, void* packed_x3, 
 }
 
 PG_EXPORT int pg_conv2d_up2x3_forward(const float* x, const float* packed, const void* packed_x3, float* y, int N, int Cin, int H, int W, int Cout,
-                                      const int64_t ystride[4], const float* in_scale, const float* out_scale, void* stream) {
+                                      const int64_t ystride[4], const float* in_scale, const float* out_scale, float* edge_column, void* stream) {
     if (!x || !packed || !packed_x3 || !y || !ystride || N <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return PG_ERR_INVALID_ARG;
     if ((((uintptr_t)packed) & 15) != 0 || (((uintptr_t)packed_x3) & 15) != 0) return PG_ERR_INVALID_ARG;
     if ((int64_t)Cin * H * W * 4 > 0x7fffffffLL) return PG_ERR_TOO_LARGE;
@@ -77,5 +77,5 @@ PG_EXPORT int pg_conv2d_up2x3_forward(const float* x, const float* packed, const
     p.N = N; p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout; p.CoutP = (Cout + 31) / 32 * 32;
     for (int i = 0; i < 4; i++) p.ys[i] = ystride[i];
     p.ksplit = 1; p.cpk = 0; p.ws_slice = 0;
-    return pgconv::launch_up2x3(p, packed_x3, (hipStream_t)stream);
+    return pgconv::launch_up2x3(p, packed_x3, edge_column, (hipStream_t)stream);
 }

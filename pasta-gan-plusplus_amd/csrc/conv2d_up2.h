@@ -175,7 +175,11 @@ __global__ __launch_bounds__(256, 2) void conv2d_up2(Up2Params p) {
             const int e = t + 256 * i;
             const int c = e / U_EPLANE, gy = q0 - 1 + e % U_EPLANE;     // (row tiles: the column index)
             const bool ok = e < U_KC * U_EPLANE && gy >= 0 && gy < (row_tile ? p.W : p.H);
+#if defined(UX_EXP) && (UX_EXP & 64)             // dev ablation (wrong by design): the column tiles read contiguous samples
+            xoff[i] = ok ? (unsigned)(row_tile ? c * HW + (p.H - 1) * p.W + gy : c * HW + gy) * 4u : 0x80000000u;
+#else
             xoff[i] = ok ? (unsigned)(row_tile ? c * HW + (p.H - 1) * p.W + gy : c * HW + gy * p.W + p.W - 1) * 4u : 0x80000000u;
+#endif
         }
         const uint64_t base = (uint64_t)(uintptr_t)(p.x + (int64_t)n * p.Cin * HW);
         xrsrc[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)base);
@@ -373,12 +377,17 @@ int launch_up2_t(const Up2Params& p0, hipStream_t s, bool edges_only = false) {
     const int64_t retiles = redge ? (int64_t)p.N * p.retilesX * p.mblocks * p.ksplit : 0;
     if (tiles + etiles + retiles > 0x7fffffffLL) return PG_ERR_TOO_LARGE;
     p.redge_tiles = (int)retiles;
+#if defined(UX_EXP) && (UX_EXP & (128 | 256 | 512))   // dev ablations (wrong by design): no edge pass / no column tiles / no row tiles
+    if (edges_only && (UX_EXP & 128)) return PG_OK;
+    if (edges_only && (UX_EXP & 256)) p.edge_tiles = 0;
+    if (edges_only && (UX_EXP & 512)) p.redge_tiles = 0;
+#endif
     const int cin_loop = ((p.Cin + U_KC - 1) / U_KC) * U_KC;
     const size_t lds = ((size_t)2 * U_LDS_BUF + 2 * cin_loop + 2 * U_BM) * sizeof(float);
     if (lds > 160 * 1024) return PG_ERR_UNSUPPORTED;
     int per_cu = (int)((160 * 1024) / lds);
     if (per_cu > 2) per_cu = 2;                             // ~230 VGPRs x 4 waves per workgroup
-    const int64_t work = (edges_only ? 0 : tiles) + etiles + retiles;
+    const int64_t work = (edges_only ? 0 : tiles) + p.edge_tiles + p.redge_tiles;
     const int64_t blocks = work < (int64_t)num_cu() * per_cu ? work : (int64_t)num_cu() * per_cu;
     if (p.in_scale) {
         static PerDeviceOnce a1;

@@ -17,13 +17,14 @@
 //     MFMAs hit different accumulators (a dependent 32x32x16 link costs ~87 cycles, conv2d_wino4.h).  (4) barrier.
 //   * weights: [m-block 32][chunk][tap 9][plane 3][k-half][32 couts][8 channels] bf16 -- one contiguous 27 KB slab per (m-block, chunk), double buffered.
 //   * epilogue, tile stream, XCD mapping: conv2d_up2.h's.  The last output column / row (conv2d_up2.h's edge tiles: 3 instead of 18 MFMAs per channel pair)
-//     stay on the fp32 kernel, launched for its edge pass only.
+//     are made by conv2d_up2_edges.h (fp32 MFMA, K split over the waves of a workgroup).
 // Serves the layers conv2d_up2.h stages with 16-byte words (W > 16, W % 4 == 0, 16-byte aligned x) whose Cin is a multiple of 16, without split-K.
 #pragma once
 #include "conv2d_up2.h"
+#include "conv2d_up2_edges.h"
 
 #ifndef UX_EXP
-#define UX_EXP 0         // dev ablations (results wrong by design; tools/up2x3_variants.py): 1 no MFMAs, 2 no operand split, 4 no halo loads, 8 no weight DMA, 16 no output stores
+#define UX_EXP 0         // dev ablations (results wrong by design; tools/up2x3_variants.py): 1 no MFMAs, 2 no operand split, 4 no halo loads, 8 no weight DMA, 16 no output stores, 64 edge columns read contiguously, 128 no edge pass
 #endif
 
 namespace pgconv {
@@ -55,7 +56,7 @@ __device__ __forceinline__ void ux_split_pair(float va, float vb, unsigned& p0, 
 }
 
 template <bool MOD>
-__global__ __launch_bounds__(512, 1) void conv2d_up2x3(Up2Params p, const unsigned char* __restrict__ wx3) {
+__global__ __launch_bounds__(512, 1) void conv2d_up2x3(Up2Params p, const unsigned char* __restrict__ wx3, float* __restrict__ xcol) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_u8[];
     float* raw = (float*)smem_u8;                                      // the four producer waves' regions of 16-byte halo words
     unsigned char* planes = smem_u8 + UX_RAW * 4;                      // [2 buffers][3 planes][2 k-halves][297 pixels] x 16 B
@@ -186,6 +187,15 @@ __global__ __launch_bounds__(512, 1) void conv2d_up2x3(Up2Params p, const unsign
             request_weights(g);
             // the rows of chunk g: older than the weight requests just issued
             asm volatile("s_waitcnt vmcnt(%0)" :: "n"(UX_WPT) : "memory");
+            if (xcol && m0 == 0 && r0 + 32 >= p.W && lane < nrows * 16) {
+                // the tiles that hold input column W - 1 leave it behind as a dense [N][Cin][H] array for the edge kernel (conv2d_up2_edges.h: gathered from x the
+                // column costs it 10 ... 34 us per launch, one 128-byte line per sample at a stride of one image row).  Halo rows 1 .. 8 = image rows q0 .. q0 + 7.
+                const int ri = lane >> 4, c = lane & 15;
+                const int row = ri == 0 ? pw : (ri == 1 ? pw + 4 : 8);
+                const int gy = q0 - 1 + row;
+                if (row >= 1 && gy < p.H)
+                    xcol[((int64_t)n * p.Cin + s_chunk * UX_KC + c) * p.H + gy] = raw[(reg_w + ri * 160 + c * 10) * 4 + (p.W + 3 - r0)];
+            }
             split_rows(g);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // (the raw tile has been read: its region may be overwritten)
             if (g + 1 < my_chunks) {
@@ -341,7 +351,10 @@ inline bool up2x3_serves(const Up2Params& p) {
 }
 
 // Main tiles on the bf16 pipe, the edge tiles (last output column / row) by the fp32 kernel's edge pass.
-inline int launch_up2x3(const Up2Params& p0, const void* wx3, hipStream_t s) {
+inline int launch_up2x3(const Up2Params& p0, const void* wx3, float* xcol, hipStream_t s) {
+#ifdef UX_NOXCOL                                             // (dev A/B: the edge kernel gathers the column itself)
+    xcol = nullptr;
+#endif
     if (!up2x3_serves(p0) || !wx3) return PG_ERR_UNSUPPORTED;
     Up2Params p = p0;
     p.tilesX = (p.W + 31) / 32;
@@ -361,16 +374,18 @@ inline int launch_up2x3(const Up2Params& p0, const void* wx3, hipStream_t s) {
         static PerDeviceOnce a1;
         const hipError_t e = a1.run([] { return hipFuncSetAttribute((const void*)conv2d_up2x3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
         if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL((conv2d_up2x3<true>), dim3((unsigned)blocks), dim3(512), lds, s, p, (const unsigned char*)wx3);
+        hipLaunchKernelGGL((conv2d_up2x3<true>), dim3((unsigned)blocks), dim3(512), lds, s, p, (const unsigned char*)wx3, xcol);
     } else {
         static PerDeviceOnce a0;
         const hipError_t e = a0.run([] { return hipFuncSetAttribute((const void*)conv2d_up2x3<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
         if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL((conv2d_up2x3<false>), dim3((unsigned)blocks), dim3(512), lds, s, p, (const unsigned char*)wx3);
+        hipLaunchKernelGGL((conv2d_up2x3<false>), dim3((unsigned)blocks), dim3(512), lds, s, p, (const unsigned char*)wx3, xcol);
     }
     int st = launch_status();
     if (st != PG_OK) return st;
-    return launch_up2_edges_only(p0, s);
+    if (UX_EXP & 128) return PG_OK;                            // (dev ablation: no edge pass)
+    static const bool own_edges = [] { const char* e = getenv("PG_UP2_EDGES"); return !e || atoi(e) != 0; }();      // A/B: 0 = conv2d_up2.h's edge pass
+    return own_edges ? launch_up2_edges(p0, redge, xcol, s) : launch_up2_edges_only(p0, s);
 }
 
 }  // namespace pgconv

@@ -47,7 +47,7 @@ PLUGIN_SOURCES = {
                       'conv2d16_inst_k1x2.hip', 'conv2d16_inst_k3s2.hip', 'conv2d16_inst_up2f.hip', 'conv1x1_head16.hip', 'optim.hip'],
 }
 
-ABI_VERSION = 12     # == PG_ABI_VERSION of include/pasta_gan_ops.h; bumped with every struct / signature change
+ABI_VERSION = 13     # == PG_ABI_VERSION of include/pasta_gan_ops.h; bumped with every struct / signature change
 
 _cached_plugins = dict()
 

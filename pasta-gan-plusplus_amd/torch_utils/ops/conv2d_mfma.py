@@ -159,7 +159,7 @@ def _init(plugin_name='conv2d_plugin'):
         lib.pg_conv2d_up2x3_pack_weight.restype = i
         lib.pg_conv2d_up2x3_pack_weight.argtypes = [vp, vp, i, i, vp]
         lib.pg_conv2d_up2x3_forward.restype = i
-        lib.pg_conv2d_up2x3_forward.argtypes = [vp, vp, vp, vp, i, i, i, i, i, ctypes.POINTER(ctypes.c_int64), vp, vp, vp]
+        lib.pg_conv2d_up2x3_forward.argtypes = [vp, vp, vp, vp, i, i, i, i, i, ctypes.POINTER(ctypes.c_int64), vp, vp, vp, vp]
         lib.pg_conv2d_up2_forward_splitk.restype = i
         lib.pg_conv2d_up2_forward_splitk.argtypes = [vp, vp, vp, i, i, i, i, i, ctypes.POINTER(ctypes.c_int64), vp, vp, vp, i, vp]
         lib.pg_conv3x3_cin1.restype = i
@@ -582,10 +582,11 @@ def pack_up2(weight, flip=False, x3=True):
 UP2_X3 = os.environ.get('PG_UP2_X3', '1') != '0'
 
 
-def conv_up2_forward(x, packs, cout, in_scale=None, out_scale=None, x3=None):
+def conv_up2_forward(x, packs, cout, in_scale=None, out_scale=None, x3=None, edge_column=True):
     """conv_transpose2d(x * in_scale, w, stride=2, padding=0) * out_scale for a 3x3 kernel: all four output parities and the last
     output column in one launch (csrc/conv2d_up2.h).  `packs` = pack_up2(w).  Returns a [N, Cout, 2H+1, 2W+1] view whose rows are
-    padded to a multiple of 4 floats (aligned pair stores here, aligned rows for the FIR pass that follows)."""
+    padded to a multiple of 4 floats (aligned pair stores here, aligned rows for the FIR pass that follows).
+    `edge_column` = False (tests): the bf16-pipe form's edge kernel gathers input column W - 1 from x instead of reading the dense copy the main kernel leaves."""
     lib = _init().lib
     x = _f32c(x, 'x')
     n, cin, h, w = x.shape
@@ -604,8 +605,9 @@ def conv_up2_forward(x, packs, cout, in_scale=None, out_scale=None, x3=None):
         # `x3` = False: the fp32-MFMA kernel whatever the pack holds (the training route: see training/networks.py _ModConvUp2Train)
         x3 = packs.get('x3') if (x3 is not False and UP2_X3 and ksplit == 1 and w > 16 and w % 4 == 0 and cin % 16 == 0 and cin >= 32 and x.data_ptr() % 16 == 0) else None
         if x3 is not None:
+            xcol = torch.empty([n * cin * h], dtype=torch.float32, device=x.device) if edge_column else None      # scratch: input column W - 1, dense, for the edge kernel
             st = lib.pg_conv2d_up2x3_forward(nat.ptr(x), nat.ptr(packs['main']), nat.ptr(x3), nat.ptr(y), n, cin, h, w, cout, nat.i64arr(y.stride()), nat.ptr(s_in), nat.ptr(s_out),
-                                             nat.stream_of(x))
+                                             nat.ptr(xcol), nat.stream_of(x))
         elif ksplit > 1:
             ws = torch.empty([ksplit * buf.numel()], dtype=torch.float32, device=x.device)
             st = lib.pg_conv2d_up2_forward_splitk(nat.ptr(x), nat.ptr(packs['main']), nat.ptr(y), n, cin, h, w, cout, nat.i64arr(y.stride()), nat.ptr(s_in), nat.ptr(s_out),

@@ -2330,6 +2330,37 @@ def test_up2_transposed_conv_on_the_bf16_pipe_is_float32_class(n, cin, cout, h, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('n,cin,cout,h,w', [(2, 64, 48, 40, 64), (1, 32, 32, 24, 48), (2, 96, 64, 33, 36), (1, 64, 40, 64, 20)])
+def test_up2_bf16x3_edge_kernel(n, cin, cout, h, w):
+    """The last output column / row of the bf16-pipe form (csrc/conv2d_up2_edges.h: 32 positions x 32 couts per workgroup, K split over its four waves, fp32
+    MFMA) against float64 at the fp32 kernel's bar, on ragged shapes (H + 1 and W not multiples of 32, H not a multiple of 8: the main tiles then cover row 2H;
+    Cin = 32: two of the four waves have no chunk), with the dense input column the main kernel leaves behind and without it: the two must agree bit for bit."""
+    from torch_utils.ops import conv2d_mfma
+    gen = torch.Generator().manual_seed(59)
+    x = torch.randn([n, cin, h, w], generator=gen).to(DEV)
+    wt = (torch.randn([cout, cin, 3, 3], generator=gen) / (3 * math.sqrt(cin))).to(DEV)
+    s_in, s_out = (torch.rand([n, cin], generator=gen) + 0.5).to(DEV), (torch.rand([n, cout], generator=gen) + 0.5).to(DEV)
+    packs = conv2d_mfma.pack_up2(wt)
+    assert 'x3' in packs and conv2d_mfma._init().lib.pg_conv2d_up2_splitk_plan(n, cin, h, w, cout) == 1
+    for mod in (True, False):
+        kw = dict(in_scale=s_in, out_scale=s_out) if mod else {}
+        y = conv2d_mfma.conv_up2_forward(x, packs, cout, **kw)
+        y_gather = conv2d_mfma.conv_up2_forward(x, packs, cout, edge_column=False, **kw)
+        y32 = conv2d_mfma.conv_up2_forward(x, packs, cout, x3=False, **kw)
+        xd = (x * s_in[:, :, None, None]).double() if mod else x.double()
+        ref = torch.nn.functional.conv_transpose2d(xd, wt.double().transpose(0, 1), stride=2)
+        if mod:
+            ref = ref * s_out[:, :, None, None].double()
+        assert y.shape == ref.shape == (n, cout, 2 * h + 1, 2 * w + 1)
+        assert torch.equal(y, y_gather)
+        edge = lambda t: torch.cat([t[:, :, :, -1].reshape(-1), t[:, :, -1, :].reshape(-1)])
+        sc = scale_of(ref)
+        e_new, e_32 = float((edge(y).double() - edge(ref)).abs().max()), float((edge(y32).double() - edge(ref)).abs().max())
+        assert e_new <= max(2.0 * e_32, 2e-6 * sc), f'edge error {e_new:.3e} against {e_32:.3e} of the fp32 kernel (scale {sc:.3g})'
+        assert float((y.double() - ref).abs().max()) <= 4e-6 * sc
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('n,cin,cout,h', [(8, 128, 64, 256), (8, 512, 256, 64), (4, 512, 512, 32)])
 def test_up2_bf16x3_repeated_launches_are_identical(n, cin, cout, h):
     """Full-size launches of conv2d_up2x3 (producer / consumer waves behind one barrier per chunk, counted vector-memory waits, planes and weight slabs double

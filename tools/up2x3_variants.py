@@ -5,10 +5,21 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'pasta-gan-plusplus_amd'))
 from torch_utils import custom_ops
 custom_ops.verbosity = 'none'
-VARIANTS = [int(v) for v in os.environ.get('UX_VARIANTS', '0').split(',')]
+VARIANTS = os.environ.get('UX_VARIANTS', '0').split(',')       # "mask" or "mask:NAME=VALUE[:NAME=VALUE]" (extra -D defines, e.g. 0:UE_DEPTH_DEF=3)
+
+
+def flags_of(v):
+    parts = v.split(':')
+    return [f'-DUX_EXP={int(parts[0])}'] + [f'-D{d}' for d in parts[1:]]
+
+
+def name_of(v):
+    return 'ux_exp' + ''.join(ch if ch.isalnum() else '_' for ch in v)
+
+
 SRC = custom_ops.PLUGIN_SOURCES['conv2d_plugin']
 for v in VARIANTS:
-    custom_ops.get_plugin(f'ux_exp{v}', sources=SRC, extra_hipcc_flags=[f'-DUX_EXP={v}'], build_only=True)
+    custom_ops.get_plugin(name_of(v), sources=SRC, extra_hipcc_flags=flags_of(v), build_only=True)
 if sys.argv[1] == 'build':
     sys.exit(0)
 import torch
@@ -16,12 +27,12 @@ from torch_utils.ops import conv2d_mfma
 libs = {}
 for v in VARIANTS:
     conv2d_mfma._plugin = None
-    custom_ops.PLUGIN_SOURCES[f'ux_exp{v}'] = SRC
+    custom_ops.PLUGIN_SOURCES[name_of(v)] = SRC
     _orig = custom_ops.get_plugin
-    custom_ops.get_plugin = lambda name, _v=v, **kw: _orig(name, extra_hipcc_flags=[f'-DUX_EXP={_v}'], abi_name='conv2d_plugin', **kw)
-    libs[v] = conv2d_mfma._init(f'ux_exp{v}')
+    custom_ops.get_plugin = lambda name, _v=v, **kw: _orig(name, extra_hipcc_flags=flags_of(_v), abi_name='conv2d_plugin', **kw)
+    libs[v] = conv2d_mfma._init(name_of(v))
     custom_ops.get_plugin = _orig
-for (N, cin, cout, H) in [(8, 128, 64, 256), (8, 256, 128, 128), (8, 512, 256, 64)]:
+for (N, cin, cout, H) in [(8, 128, 64, 256), (8, 256, 128, 128), (8, 512, 256, 64), (8, 512, 512, 32)]:
     x = torch.randn(N, cin, H, H, device='cuda')
     w = torch.randn(cout, cin, 3, 3, device='cuda') / (3 * cin ** 0.5)
     ins, outs = torch.rand(N, cin, device='cuda') + 0.5, torch.rand(N, cout, device='cuda') + 0.5
@@ -40,4 +51,4 @@ for (N, cin, cout, H) in [(8, 128, 64, 256), (8, 256, 128, 128), (8, 512, 256, 6
             e1.record(); torch.cuda.synchronize()
             if r > 0:
                 times[v].append(e0.elapsed_time(e1) / 4 * 1e3)
-    print(f'N{N} {cin}->{cout} {H}^2: ' + '  '.join(f'[{v}] {statistics.median(times[v]):7.1f}us' for v in VARIANTS), flush=True)
+    print(f'N{N} {cin}->{cout} {H}^2: ' + '  '.join(f'[{v}] {statistics.median(times[v]):6.1f}us' for v in VARIANTS), flush=True)

@@ -325,6 +325,16 @@ int pg_conv2d_up2x3_pack_weight(const float* packed, void* packed_x3, int Cout, 
 int pg_conv2d_up2x3_forward(const float* x, const float* packed, const void* packed_x3, float* y, int N, int Cin, int H, int W, int Cout,
                             const int64_t ystride[4], const float* in_scale, const float* out_scale, float* edge_column, void* stream);
 
+/* Round 6 -- the 7x7 three-channel stem of the garment encoder (networks.py:2233-2238: Conv2dLayer(3, 64, kernel_size=7) = conv2d_resample.py:145-147 ->
+ * conv2d_gradfix.conv2d, bias_act in the epilogue) on the bf16 matrix pipe with the three-term operand split (csrc/conv2d_stem7x3.h): float32-class results.
+ * x [N, 3, H, W] contiguous, stride 1, padding 3; `packed` = pg_conv2d_stem7x3_pack_weight of the OIHW kernel w [Cout, 3, 7, 7] * scale (flip_hw as
+ * pg_conv2d_pack_weight), pg_conv2d_stem7x3_packed_size(Cout) BYTES, once per weight version.  Fusion: bias, act in {linear, relu, lrelu}, gain, clamp;
+ * any other stage set -> PG_ERR_UNSUPPORTED (callers then use pg_conv2d_forward). */
+int64_t pg_conv2d_stem7x3_packed_size(int Cout);
+int pg_conv2d_stem7x3_pack_weight(const float* w, void* packed, int Cout, float scale, int flip_hw, void* stream);
+int pg_conv2d_stem7x3_forward(const float* x, const void* packed, float* y, int N, int H, int W, int Cout, const int64_t ystride[4],
+                              const pg_conv2d_fusion* fusion, void* stream);
+
 /* Streaming 1x1 convolution with few output channels (Cout <= 8; the ToRGB / parsing heads, networks.py:287-316,
  * modulated_conv2d with demodulate=False at networks.py:37-94): float32 NCHW, HW % 4 == 0, 16-byte aligned tensors:
  *   y[n,o,p] = clamp(sum_c x[n,c,p] * w[o,c] * scale * styles[n,c] + bias[o]) + skip[n,o,p]

@@ -42,7 +42,7 @@ PLUGIN_SOURCES = {
     'upfirdn2d_plugin': ['upfirdn2d.hip'],
     'patch_routing_plugin': ['patch_routing.hip'],
     'conv2d_plugin': ['conv2d.hip', 'conv2d_inst_k3s1.hip', 'conv2d_inst_k1s1.hip', 'conv2d_inst_k2x2.hip', 'conv2d_inst_k2x1.hip',
-                      'conv2d_inst_k1x2.hip', 'conv2d_inst_k7s1.hip', 'conv2d_inst_k3s2.hip', 'conv2d_inst_k1s2.hip', 'conv2d_inst_wino.hip', 'conv2d_inst_wino4.hip', 'conv2d_inst_wino4s.hip', 'conv2d_inst_wino4t.hip', 'conv2d_inst_wino4x.hip', 'conv2d_inst_wino4xs.hip', 'conv2d_inst_wino4xt.hip', 'conv2d_inst_wino4b.hip', 'conv2d_inst_wino4bs.hip', 'conv2d_inst_up2.hip', 'conv2d_inst_s1x1.hip',
+                      'conv2d_inst_k1x2.hip', 'conv2d_inst_k7s1.hip', 'conv2d_inst_k3s2.hip', 'conv2d_inst_k1s2.hip', 'conv2d_inst_wino.hip', 'conv2d_inst_wino4.hip', 'conv2d_inst_wino4s.hip', 'conv2d_inst_wino4t.hip', 'conv2d_inst_wino4x.hip', 'conv2d_inst_wino4xs.hip', 'conv2d_inst_wino4xt.hip', 'conv2d_inst_wino4b.hip', 'conv2d_inst_wino4bs.hip', 'conv2d_inst_up2.hip', 'conv2d_inst_stem7.hip', 'conv2d_inst_s1x1.hip',
                       'conv2d_wgrad.hip', 'conv2d16.hip', 'conv2d16_inst_k3s1.hip', 'conv2d16_inst_k3s1b.hip', 'conv2d16_inst_k1s1.hip', 'conv2d16_inst_k2x2.hip', 'conv2d16_inst_k2x1.hip',
                       'conv2d16_inst_k1x2.hip', 'conv2d16_inst_k3s2.hip', 'conv2d16_inst_up2f.hip', 'conv1x1_head16.hip', 'optim.hip'],
 }

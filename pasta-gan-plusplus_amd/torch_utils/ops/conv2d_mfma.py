@@ -162,6 +162,12 @@ def _init(plugin_name='conv2d_plugin'):
         lib.pg_conv2d_up2x3_forward.argtypes = [vp, vp, vp, vp, i, i, i, i, i, ctypes.POINTER(ctypes.c_int64), vp, vp, vp, vp]
         lib.pg_conv2d_up2_forward_splitk.restype = i
         lib.pg_conv2d_up2_forward_splitk.argtypes = [vp, vp, vp, i, i, i, i, i, ctypes.POINTER(ctypes.c_int64), vp, vp, vp, i, vp]
+        lib.pg_conv2d_stem7x3_packed_size.restype = i64
+        lib.pg_conv2d_stem7x3_packed_size.argtypes = [i]
+        lib.pg_conv2d_stem7x3_pack_weight.restype = i
+        lib.pg_conv2d_stem7x3_pack_weight.argtypes = [vp, vp, i, ctypes.c_float, i, vp]
+        lib.pg_conv2d_stem7x3_forward.restype = i
+        lib.pg_conv2d_stem7x3_forward.argtypes = [vp, vp, vp, i, i, i, i, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(Fusion), vp]
         lib.pg_conv3x3_cin1.restype = i
         lib.pg_conv3x3_cin1.argtypes = [vp, vp, vp, i, i, i, i, f, i, vp]
         lib.pg_conv1x1_small.restype = i
@@ -620,6 +626,53 @@ def conv_up2_forward(x, packs, cout, in_scale=None, out_scale=None, x3=None, edg
             tl.append(((3, 3, 2, 'direct', f'N{n} {cin}->{cout} {h}x{w} up2' + (' x3' if x3 is not None else '') + (' mod' if in_scale is not None else '')), 2.0 * n * cout * cin * 9 * h * w, ev0, ev1,
                        4 * (x.numel() + n * cout * oh * ow)))
     nat.check(st, 'pg_conv2d_up2_forward')
+    return y
+
+
+STEM7_X3 = os.environ.get('PG_STEM7_X3', '1') != '0'
+
+
+def pack_stem7(weight, scale=1.0, flip=False):
+    """Packed weights of `conv_stem7_forward` for the OIHW [Cout, 3, 7, 7] float32 kernel `weight` * `scale` (flipped spatially iff `flip`): three bf16 planes
+    per weight, in the MFMA A-fragment order of csrc/conv2d_stem7x3.h."""
+    lib = _init().lib
+    w = _f32c(weight.detach(), 'weight')
+    cout, cin, kh, kw = w.shape
+    if (cin, kh, kw) != (3, 7, 7):
+        raise nat.NativeOpError('conv2d_mfma.pack_stem7: a [Cout, 3, 7, 7] kernel')
+    packed = torch.empty([lib.pg_conv2d_stem7x3_packed_size(cout)], dtype=torch.uint8, device=w.device)
+    with torch.cuda.device(w.device):
+        nat.check(lib.pg_conv2d_stem7x3_pack_weight(nat.ptr(w), nat.ptr(packed), cout, float(scale), int(bool(flip)), nat.stream_of(w)), 'pg_conv2d_stem7x3_pack_weight')
+    return packed
+
+
+def conv_stem7_forward(x, packed, cout, bias=None, act='linear', alpha=0.0, gain=1.0, clamp=None):
+    """clamp(act(conv2d(x [N, 3, H, W], w, padding=3) + bias) * gain) for a 7x7 kernel on the bf16 matrix pipe (round 6, csrc/conv2d_stem7x3.h: float32
+    operands as exact sums of three bf16 values, six plane products per float32 product, float32 accumulation -- float32-class).  `packed` = pack_stem7(w)."""
+    lib = _init().lib
+    x = _f32c(x, 'x')
+    n, cin, h, w = x.shape
+    if cin != 3 or act not in FUSED_ACTS:
+        raise nat.NativeNotCovered('conv2d_mfma.conv_stem7_forward: three input channels, linear / relu / lrelu')
+    y = torch.empty([n, cout, h, w], dtype=torch.float32, device=x.device)
+    fz = Fusion()
+    b = _f32c(bias, 'bias') if bias is not None else None
+    fz.bias = b.data_ptr() if b is not None else None
+    fz.act, fz.alpha, fz.gain = ACT_INDEX[act], float(alpha), float(gain)
+    fz.clamp = -1.0 if clamp is None else float(clamp)
+    fz.in_clamp, fz.in_gain = -1.0, 1.0
+    tl = _timeline
+    with torch.cuda.device(x.device):
+        if tl is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+        st = lib.pg_conv2d_stem7x3_forward(nat.ptr(x), nat.ptr(packed), nat.ptr(y), n, h, w, cout, nat.i64arr(y.stride()), ctypes.byref(fz), nat.stream_of(x))
+        if tl is not None:
+            ev1.record()
+            tl.append(((7, 7, 1, 'direct', f'N{n} 3->{cout} {h}x{w} x3'), 2.0 * n * cout * h * w * 3 * 49, ev0, ev1, 4 * (x.numel() + y.numel())))
+    if st == -2:
+        raise nat.NativeNotCovered('pg_conv2d_stem7x3_forward declined the launch')
+    nat.check(st, 'pg_conv2d_stem7x3_forward')
     return y
 
 

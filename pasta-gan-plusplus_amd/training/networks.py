@@ -834,6 +834,10 @@ class Conv2dLayer(_ConvBase):
         if self.down == 1:
             if x2 is not None and x.shape[1] % 16 != 0:
                 x, x2 = torch.cat([x, x2], dim=1), None
+            if k == 7 and x.shape[1] == 3 and x2 is None and residual is None and conv2d_mfma.STEM7_X3:
+                # round 6: the garment encoder's stem on the bf16 matrix pipe (three-term operand split, float32-class: csrc/conv2d_stem7x3.h)
+                packed = self._cache.get(('stem7x3',), [self.weight], lambda: conv2d_mfma.pack_stem7(self.weight, scale=self.weight_gain))
+                return conv2d_mfma.conv_stem7_forward(x, packed, cout, bias=self.bias, act=ep['act'], alpha=ep['alpha'], gain=ep['gain'], clamp=ep['clamp'])
             wg = conv2d_mfma.use_winograd(k, k, 1, cout, x.shape[1], x2, pad=(self.padding, self.padding), hw=x.shape[2:], ep=ep)
             return conv2d_mfma.conv2d_forward(x, self._packed(False, wg), cout, k, k, pad=(self.padding, self.padding), x2=x2, winograd=wg, **ep)
         if x2 is not None:

@@ -2330,6 +2330,38 @@ def test_up2_transposed_conv_on_the_bf16_pipe_is_float32_class(n, cin, cout, h, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('n,cout,h,w,act,clamp', [(2, 64, 64, 64, 'relu', None), (1, 64, 37, 100, 'lrelu', 0.4), (1, 48, 33, 300, 'linear', None), (2, 128, 70, 260, 'relu', None),
+                                                  (1, 64, 5, 7, 'relu', None)])
+def test_stem7_conv_on_the_bf16_pipe_is_float32_class(n, cout, h, w, act, clamp):
+    """csrc/conv2d_stem7x3.h (round 6): the garment encoder's 7x7 three-channel stem (networks.py:2233-2238 -> conv2d_resample.py:145-147, bias_act in the epilogue)
+    with every float32 operand as the exact sum of three bf16 values, six plane products per float32 product on v_mfma_f32_32x32x16_bf16, float32 accumulation;
+    column records sliding down a 256-column strip, weights resident in registers.  Admissible as float32 only if it IS float32-class: referee float64, error <= 2x
+    the fp32-MFMA kernel's on the same launch and <= 2e-6 of the output scale; ragged strips (W % 256 != 0, two strips), ragged row segments (H % 32 != 0), images
+    smaller than the kernel, Cout % 64 != 0 and two m-pairs, bias / activation / gain / clamp in the epilogue; bit-identical repeats."""
+    from torch_utils.ops import conv2d_mfma
+    gen = torch.Generator().manual_seed(11 * cout + h + w)
+    x = (torch.rand([n, 3, h, w], generator=gen) * 2 - 1).to(DEV)
+    wt = torch.randn([cout, 3, 7, 7], generator=gen).to(DEV)
+    bias = torch.randn([cout], generator=gen).to(DEV)
+    scale, gain = 1 / math.sqrt(3 * 49), math.sqrt(2)
+    alpha = 0.2 if act == 'lrelu' else 0.0
+    pre = torch.nn.functional.conv2d(x.double(), wt.double() * scale, padding=3) + bias.double()[None, :, None, None]
+    ref = {'linear': pre, 'relu': pre.clamp(min=0), 'lrelu': torch.where(pre > 0, pre, pre * alpha)}[act] * gain
+    if clamp is not None:
+        ref = ref.clamp(-clamp, clamp)
+    packed = conv2d_mfma.pack_stem7(wt, scale=scale)
+    assert packed.numel() == conv2d_mfma._init().lib.pg_conv2d_stem7x3_packed_size(cout)
+    y = conv2d_mfma.conv_stem7_forward(x, packed, cout, bias=bias, act=act, alpha=alpha, gain=gain, clamp=clamp)
+    y32 = conv2d_mfma.conv2d_forward(x, conv2d_mfma.pack_weight(wt, scale=scale), cout, 7, 7, pad=(3, 3), bias=bias, act=act, alpha=alpha, gain=gain, clamp=clamp)
+    assert y.shape == ref.shape
+    sc = float(pre.abs().max())
+    e32, e = float((y32.double() - ref).abs().max()), float((y.double() - ref).abs().max())
+    assert e <= 2 * e32 and e <= 2e-6 * sc, (e / sc, e32 / sc)
+    for _ in range(2):
+        assert torch.equal(conv2d_mfma.conv_stem7_forward(x, packed, cout, bias=bias, act=act, alpha=alpha, gain=gain, clamp=clamp), y)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('n,cin,cout,h,w', [(2, 64, 48, 40, 64), (1, 32, 32, 24, 48), (2, 96, 64, 33, 36), (1, 64, 40, 64, 20)])
 def test_up2_bf16x3_edge_kernel(n, cin, cout, h, w):
     """The last output column / row of the bf16-pipe form (csrc/conv2d_up2_edges.h: 32 positions x 32 couts per workgroup, K split over its four waves, fp32

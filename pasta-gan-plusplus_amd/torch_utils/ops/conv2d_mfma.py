@@ -452,6 +452,17 @@ def _tap_index(taps, device):
     return _tap_indices[key]
 
 
+def _desc_taps_slice(taps):
+    """The ascending slice whose reversal is the tap list `taps` (equal descending steps, or one tap); None otherwise."""
+    taps = [int(t) for t in taps]
+    if len(taps) == 1:
+        return slice(taps[0], taps[0] + 1)
+    step = taps[0] - taps[1]
+    if step > 0 and all(taps[i] - taps[i + 1] == step for i in range(len(taps) - 1)):
+        return slice(taps[-1], taps[0] + 1, step)
+    return None
+
+
 def pack_transposed(w_iohw, stride, pad, in_hw, out_hw, scale=1.0):
     """Packed per-phase weights of conv_transpose2d(x, w_iohw, stride, padding=pad) -> list of (phase, packed)."""
     kh, kw = int(w_iohw.shape[2]), int(w_iohw.shape[3])
@@ -462,6 +473,12 @@ def pack_transposed(w_iohw, stride, pad, in_hw, out_hw, scale=1.0):
     for ph in phases:
         if not supported(len(ph['ky']), len(ph['kx']), 1):
             return None
+        sy, sx = _desc_taps_slice(ph['ky']), _desc_taps_slice(ph['kx'])
+        if sy is not None and sx is not None:
+            # the tap lists of a phase descend in equal steps ([2, 0], [1]: transposed_phases): a strided view read back to front -- one copy + the pack's
+            # own flip instead of two index_select launches (440 of them per training iteration, 2.2 ms)
+            out.append((ph, pack_weight(w_iohw.detach()[:, :, sy, sx], scale=scale, transpose_oi=True, flip=True)))
+            continue
         sel = w_iohw.detach().index_select(2, _tap_index(ph['ky'], w_iohw.device)).index_select(3, _tap_index(ph['kx'], w_iohw.device))
         out.append((ph, pack_weight(sel, scale=scale, transpose_oi=True)))
     return out

@@ -2362,6 +2362,32 @@ def test_stem7_conv_on_the_bf16_pipe_is_float32_class(n, cout, h, w, act, clamp)
 
 
 @pytest.mark.gpu
+def test_stem7_bf16x3_repeated_full_size_launches_are_identical():
+    """conv2d_stem7x3 at the size the headline runs it (N = 8, 3 -> 64 at 512^2: 256 workgroups, one per CU, double-buffered column records behind one barrier per
+    row, samples by LDS-DMA with a hand-placed wait), 30 launches with other kernels in between: every result equals the first bit for bit and matches the fp32
+    kernel to rounding (the kind of test that caught the F(4x4) kernel's missing barrier in round 3)."""
+    from torch_utils.ops import conv2d_mfma
+    gen = torch.Generator().manual_seed(61)
+    x = (torch.rand([8, 3, 512, 512], generator=gen) * 2 - 1).to(DEV)
+    other = (torch.rand([8, 3, 512, 512], generator=gen) * 2 - 1).to(DEV)
+    wt = torch.randn([64, 3, 7, 7], generator=gen).to(DEV)
+    bias = torch.randn([64], generator=gen).to(DEV)
+    scale = 1 / math.sqrt(147)
+    packed, packed32 = conv2d_mfma.pack_stem7(wt, scale=scale), conv2d_mfma.pack_weight(wt, scale=scale)
+    kw = dict(bias=bias, act='relu', gain=math.sqrt(2))
+    ref = conv2d_mfma.conv2d_forward(x, packed32, 64, 7, 7, pad=(3, 3), **kw)
+    first = conv2d_mfma.conv_stem7_forward(x, packed, 64, **kw)
+    assert float((first - ref).abs().max()) <= 4e-6 * float(ref.abs().max())
+    for it in range(30):
+        if it % 3 == 1:
+            conv2d_mfma.conv2d_forward(other, packed32, 64, 7, 7, pad=(3, 3), **kw)
+        if it % 4 == 2:
+            conv2d_mfma.conv_stem7_forward(other, packed, 64, **kw)
+        y = conv2d_mfma.conv_stem7_forward(x, packed, 64, **kw)
+        assert torch.equal(y, first), f'launch {it} differs from the first one: max |d| {float((y - first).abs().max()):.3e}'
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('n,cin,cout,h,w', [(2, 64, 48, 40, 64), (1, 32, 32, 24, 48), (2, 96, 64, 33, 36), (1, 64, 40, 64, 20)])
 def test_up2_bf16x3_edge_kernel(n, cin, cout, h, w):
     """The last output column / row of the bf16-pipe form (csrc/conv2d_up2_edges.h: 32 positions x 32 couts per workgroup, K split over its four waves, fp32

@@ -237,6 +237,7 @@ class _BiasActGrad(torch.autograd.Function):
             db = channel_sum(dx.detach(), dim) if with_db else None
         ctx.save_for_backward(dy if spec.has_2nd_grad else None, x, b, y)
         ctx.cfg = (dim, act, alpha, gain, clamp)
+        ctx.dx_shape = tuple(dx.shape)              # (backward may see d_db alone while neither x nor y was saved)
         #  no zero-filled gradient for an output nobody consumed: with the default materialisation every R1 double backward handed `backward`
         # a zero d_db and paid a full-size `d_dx + d_db.reshape(...)` pass per layer for it
         ctx.set_materialize_grads(False)
@@ -250,10 +251,9 @@ class _BiasActGrad(torch.autograd.Function):
         if d_dx is None and d_db is None:
             return (None,) * 10
         if d_db is not None:                                 # db = sum(dx): its gradient is spread back over dx
-            ref = y if y is not None else x if x is not None else d_dx
-            shape = [1] * ref.ndim
+            shape = [1] * len(ctx.dx_shape)
             shape[dim] = -1
-            d_dx = d_db.reshape(shape).expand(ref.shape) if d_dx is None else d_dx + d_db.reshape(shape)
+            d_dx = d_db.reshape(shape).expand(ctx.dx_shape) if d_dx is None else d_dx + d_db.reshape(shape)
         d_dy = d_x = d_b = None
         if ctx.needs_input_grad[0]:
             d_dy = _BiasActGrad.apply(d_dx, x, b, y, dim, act, alpha, gain, clamp)

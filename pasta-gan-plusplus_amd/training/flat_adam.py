@@ -48,10 +48,12 @@ class FlatAdam:
         self.chunks = torch.tensor(table, dtype=torch.int32).to(dev)
         self.steps = [torch.zeros([len(bucket.params)], dtype=torch.float32, device=dev) for _ in range(2)]
         bucket.device_flags = True
-        self.param_groups = [dict(params=list(bucket.params), lr=self.lr, betas=self.betas, eps=self.eps)]      # (read-only mirror of torch.optim's attribute)
+        self.param_groups = [dict(params=list(bucket.params), lr=self.lr, betas=self.betas, eps=self.eps)]      # torch.optim's attribute: `step` reads lr / betas / eps from it, so schedulers that edit it act
 
     def step(self):
         b = self.bucket
+        g0 = self.param_groups[0]                      # (inside a replayed hipGraph the values of the capture are frozen, like every other scalar kernel argument)
+        self.lr, self.betas, self.eps = float(g0['lr']), (float(g0['betas'][0]), float(g0['betas'][1])), float(g0['eps'])
         src, dst = self.steps[0], self.steps[1]       # (fixed roles + a device-side copy back, not a host-side swap: inside a replayed hipGraph the pointers are frozen)
         with torch.cuda.device(b.flat.device):
             st = self._lib.pg_adam_flat_step(nat.ptr(self.flat_p), nat.ptr(b.flat), nat.ptr(self.exp_avg), nat.ptr(self.exp_avg_sq), nat.ptr(self.chunks),

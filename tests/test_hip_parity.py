@@ -2560,6 +2560,8 @@ def test_flat_adam_matches_torch_adam_and_skips_untouched_parameters():
     dead = 3
     for it in range(4):
         use2 = it == 2
+        if it == 3:                                   # a schedule editing param_groups (`step` reads lr / betas / eps from there, like torch.optim)
+            opt.param_groups[0]['lr'] = ref_opt.param_groups[0]['lr'] = lr * 0.25
         bucket.begin()
         for i, (p, r) in enumerate(zip(ps, ref)):
             r.grad = None

@@ -893,7 +893,7 @@ class Spade_Conv2dLayer(_ConvBase):
             pro = {} if no_act else dict(in_act=self.activation, in_gain=act_gain, in_clamp=act_clamp,
                                          in_alpha=bias_act.activation_funcs[self.activation].def_alpha)
             wg = conv2d_mfma.use_winograd(k, k, 1, cout, x.shape[1], pad=(self.padding, self.padding), hw=x.shape[2:], xf=not no_act)
-            if stats_eps is not None and wg == 2 and no_act and residual is None and post_act == 'linear' and os.environ.get('PG_FUSED_STATS', '1') != '0':
+            if stats_eps is not None and wg in (2, 4) and no_act and residual is None and post_act == 'linear' and os.environ.get('PG_FUSED_STATS', '1') != '0':
                 try:
                     return conv2d_mfma.conv2d_forward(x, self._packed(False, wg), cout, k, k, pad=(self.padding, self.padding), winograd=wg, stats_eps=stats_eps)
                 except nat.NativeNotCovered:

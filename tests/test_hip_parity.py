@@ -2362,6 +2362,31 @@ def test_stem7_conv_on_the_bf16_pipe_is_float32_class(n, cout, h, w, act, clamp)
 
 
 @pytest.mark.gpu
+def test_spade_res_block_gathers_its_statistics_in_the_convolution_tails(monkeypatch):
+    """A SPADE res-block at the widths of the generator (128 channels, 64^2: the F(4x4) kernel's wide form, whichever `conv2d_mfma.F4_WIDE` names) makes NO
+    separate instance-norm statistics pass: the three norm blocks' statistics come out of the tails of the convolutions that produce their inputs (round 4).
+    Round 6 had lost that silently when the bf16x3 form became the default (`wg == 2` in Spade_Conv2dLayer.forward: six extra passes, 0.42 ms of the config-2 step)."""
+    from training import networks as PN
+    from training.synthetic import fill_module_
+    from torch_utils.ops import conv2d_mfma
+    blk = fill_module_(PN.Spade_ResBlockV4_512(128, 128, spade_channels=128), 'st.spade.').to(DEV).eval()
+    gen = torch.Generator().manual_seed(67)
+    x = torch.randn([2, 128, 64, 64], generator=gen).to(DEV)
+    feat = torch.randn([2, 128, 64, 64], generator=gen).to(DEV)
+    calls = []
+    real = conv2d_mfma.instance_norm_stats
+    monkeypatch.setattr(conv2d_mfma, 'instance_norm_stats', lambda t, eps: (calls.append(tuple(t.shape)), real(t, eps=eps))[1])
+    with torch.no_grad():
+        y = blk(x, feat)
+    assert not calls, f'separate statistics passes over {calls}'
+    monkeypatch.setenv('PG_FUSED_STATS', '0')
+    with torch.no_grad():
+        y0 = blk(x, feat)
+    assert len(calls) == 2                             # (the A/B switch: x and dx each take a pass)
+    assert float((y - y0).abs().max()) <= 2e-5 * float(y0.abs().max())
+
+
+@pytest.mark.gpu
 def test_stem7_bf16x3_repeated_full_size_launches_are_identical():
     """conv2d_stem7x3 at the size the headline runs it (N = 8, 3 -> 64 at 512^2: 256 workgroups, one per CU, double-buffered column records behind one barrier per
     row, samples by LDS-DMA with a hand-placed wait), 30 launches with other kernels in between: every result equals the first bit for bit and matches the fp32

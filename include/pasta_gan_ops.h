@@ -4,7 +4,7 @@
  *
  * Four shared libraries export these symbols (one per reference "plugin", plus the loader's patch routing):
  *   bias_act_plugin.so      pg_bias_act
- *   upfirdn2d_plugin.so     pg_upfirdn2d, pg_upfirdn2d_bias_act
+ *   upfirdn2d_plugin.so     pg_upfirdn2d, pg_upfirdn2d_bias_act, pg_upfirdn2d_with_odd_samples
  *   conv2d_plugin.so        fp32: pg_conv2d_{packed_size,pack_weight,forward,splitk_plan,forward_splitk}, pg_conv2d_winograd_*,
  *                           pg_conv2d_up2_{forward,splitk_plan,forward_splitk}, pg_conv1x1_small, pg_conv3x3_cin1, pg_conv2d_wgrad{_plan,}, pg_split3_bf16_cl;
  *                           16-bit: pg_conv2d16_{packed_size,pack_weight,pack_weight_grouped,forward,splitk_plan,forward_splitk,up2_fused,wgrad,wgrad_plan,wgrad_x3}, pg_adam_flat_{chunk,step},
@@ -92,6 +92,15 @@ int pg_upfirdn2d(const void* x, const float* f, void* y, int dtype,
                  int outH, int outW, const int64_t ystride[4],
                  int upx, int upy, int downx, int downy, int padx0, int pady0,
                  int flip, float gain, void* stream);
+/* Round 6 -- pg_upfirdn2d (no resampling) that also writes the odd rows and columns of its output as a dense tensor: y_odd[n, c, j, i] = y[n, c, 2 j + 1, 2 i + 1],
+ * [N, C, (outH - 1) / 2, (outW - 1) / 2].  A ResBlock with down = 2 filters its input twice (conv2d_resample.py:119-122 with padding 2 in front of the strided 3x3
+ * convolution, :107-110 with padding 1 and every second sample in front of the 1x1 skip convolution): the second result is exactly these samples of the first.
+ * float32, dense NCHW, the tiled kernel's filter sizes; anything else PG_ERR_UNSUPPORTED (callers then make the two pg_upfirdn2d calls). */
+int pg_upfirdn2d_with_odd_samples(const void* x, const float* f, void* y, float* y_odd, int dtype,
+                                  int N, int C, int inH, int inW, const int64_t xstride[4],
+                                  int fh, int fw, const int64_t fstride[2],
+                                  int outH, int outW, const int64_t ystride[4],
+                                  int padx0, int pady0, int flip, float gain, void* stream);
 /* upfirdn2d followed, in the same pass, by the tail of a SynthesisLayer: v = fir(x) * gain + noise * noise_gain + bias[c];
  * y = clamp(act(v) * act_gain) with act in {linear, relu, lrelu}.  float32, dense NCHW, the filter sizes / factors of the
  * tiled kernel only (PG_ERR_UNSUPPORTED otherwise -- callers then run pg_upfirdn2d and pg_bias_act separately). */

@@ -41,6 +41,9 @@ struct Params {
     int has_ep;
     const float* noise; int64_t noise_bs; float noise_gain;
     const float* bias; float slope, act_gain, clamp;
+    // optional second output (tiled float32 path, no resampling): the odd rows and columns of y, dense -- y_odd[n, c, j, i] = y[n, c, 2 j + 1, 2 i + 1]
+    // (pg_upfirdn2d_with_odd_samples: what the down = 2 FIR of a ResBlock's skip path computes from the same input)
+    float* y2; int y2H, y2W;
 };
 
 __device__ __forceinline__ int floor_div(int a, int b) {   // b > 0
@@ -211,6 +214,9 @@ __global__ __launch_bounds__(256) void upfirdn2d_tiled(Params p, int tilesX, int
                 v = fminf(fmaxf(v, -p.clamp), p.clamp);
             }
             yp[(int64_t)oy * p.outW + ox] = (T)v;
+            if constexpr (sizeof(T) == 4 && UPX == 1 && UPY == 1 && DNX == 1 && DNY == 1) {
+                if (p.y2 && (oy & 1) && (ox & 1)) p.y2[(plane * p.y2H + (oy >> 1)) * p.y2W + (ox >> 1)] = (float)v;
+            }
         }
     }
 }
@@ -644,6 +650,12 @@ int run(const Params& p, hipStream_t s, bool allow_tiled) {
                             p.xs[0] == (int64_t)p.C * p.xs[1] && p.ys[3] == 1 && p.ys[2] == p.outW &&
                             p.ys[1] == (int64_t)p.outH * p.outW && p.ys[0] == (int64_t)p.C * p.outH * p.outW;
     int st = PG_OK;
+    if (p.y2) {                                          // the second output exists on the tiled float32 kernel without resampling only
+        if constexpr (sizeof(T) == 4) {
+            if (allow_tiled && dense_nchw && !p.has_ep && p.upx == 1 && p.upy == 1 && p.dnx == 1 && p.dny == 1 && try_tiled<T>(p, s, &st)) return st;
+        }
+        return PG_ERR_UNSUPPORTED;
+    }
     if constexpr (sizeof(T) == 4) { if (allow_tiled && dense_nchw && try_blur4(p, s, &st)) return st; }
     if (allow_tiled && dense_nchw && (!p.has_ep || sizeof(T) == 4) && try_tiled<T>(p, s, &st)) return st;
     if constexpr (sizeof(T) <= 4) { if (allow_tiled && try_channels_last<T>(p, s, &st)) return st; }
@@ -664,7 +676,7 @@ static int upfirdn2d_impl(const void* x, const float* f, void* y, int dtype,
                           int fh, int fw, const int64_t fstride[2],
                           int outH, int outW, const int64_t ystride[4],
                           int upx, int upy, int downx, int downy, int padx0, int pady0,
-                          int flip, float gain, const pg_fir_epilogue* ep, void* stream) {
+                          int flip, float gain, const pg_fir_epilogue* ep, void* stream, float* y_odd = nullptr) {
     if (!x || !f || !y || !xstride || !fstride || !ystride) return PG_ERR_INVALID_ARG;
     if (N <= 0 || C <= 0 || inH <= 0 || inW <= 0 || outH <= 0 || outW <= 0 || fh <= 0 || fw <= 0) return PG_ERR_INVALID_ARG;
     if (upx < 1 || upy < 1 || downx < 1 || downy < 1) return PG_ERR_INVALID_ARG;
@@ -679,6 +691,8 @@ static int upfirdn2d_impl(const void* x, const float* f, void* y, int dtype,
     p.fs[0] = fstride[0]; p.fs[1] = fstride[1];
     p.upx = upx; p.upy = upy; p.dnx = downx; p.dny = downy; p.padx0 = padx0; p.pady0 = pady0;
     p.flip = flip ? 1 : 0; p.gain = gain;
+    p.y2 = y_odd; p.y2H = (outH - 1) / 2; p.y2W = (outW - 1) / 2;
+    if (y_odd && (dtype != PG_F32 || p.y2H <= 0 || p.y2W <= 0)) return PG_ERR_UNSUPPORTED;
     p.has_ep = 0; p.noise = nullptr; p.bias = nullptr; p.noise_bs = 0; p.noise_gain = 0.f; p.slope = 1.f; p.act_gain = 1.f; p.clamp = __builtin_inff();
     if (ep) {
         if (dtype == PG_F64) return PG_ERR_UNSUPPORTED;
@@ -717,4 +731,18 @@ PG_EXPORT int pg_upfirdn2d_bias_act(const void* x, const float* f, void* y, int 
     if (!epilogue) return PG_ERR_INVALID_ARG;
     return upfirdn2d_impl(x, f, y, dtype, N, C, inH, inW, xstride, fh, fw, fstride, outH, outW, ystride,
                           upx, upy, downx, downy, padx0, pady0, flip, gain, epilogue, stream);
+}
+
+/* Round 6 -- pg_upfirdn2d that also writes the odd rows and columns of its output as a dense tensor: y_odd[n, c, j, i] = y[n, c, 2 j + 1, 2 i + 1],
+ * [N, C, (outH - 1) / 2, (outW - 1) / 2].  A ResBlock with down = 2 (networks.py:1586-1621) filters its input twice -- padding 2 in front of the strided 3x3
+ * convolution (conv2d_resample.py:119-122), padding 1 and every second sample in front of the 1x1 skip convolution (conv2d_resample.py:107-110) -- and the second
+ * result is exactly these samples of the first.  float32, no resampling, the tiled kernel's filter sizes, dense NCHW: anything else PG_ERR_UNSUPPORTED. */
+PG_EXPORT int pg_upfirdn2d_with_odd_samples(const void* x, const float* f, void* y, float* y_odd, int dtype,
+                                            int N, int C, int inH, int inW, const int64_t xstride[4],
+                                            int fh, int fw, const int64_t fstride[2],
+                                            int outH, int outW, const int64_t ystride[4],
+                                            int padx0, int pady0, int flip, float gain, void* stream) {
+    if (!y_odd) return PG_ERR_INVALID_ARG;
+    return upfirdn2d_impl(x, f, y, dtype, N, C, inH, inW, xstride, fh, fw, fstride, outH, outW, ystride,
+                          1, 1, 1, 1, padx0, pady0, flip, gain, nullptr, stream, y_odd);
 }

@@ -35,6 +35,9 @@ def _init():
         fn2 = plugin.lib.pg_upfirdn2d_bias_act
         fn2.restype = ctypes.c_int
         fn2.argtypes = fn.argtypes[:-1] + [ctypes.POINTER(_FirEpilogue), ctypes.c_void_p]
+        fn3 = plugin.lib.pg_upfirdn2d_with_odd_samples
+        fn3.restype = ctypes.c_int
+        fn3.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, i, i, i, i, i, p64, i, i, p64, i, i, p64, i, i, i, ctypes.c_float, ctypes.c_void_p]
         _plugin = plugin
     return True
 
@@ -154,6 +157,32 @@ def setup_filter(f, device=torch.device('cpu'), normalize=True, flip_filter=Fals
 
 
 # ---------------------------------------------------------------------------- native call
+
+def filter_with_odd_samples(x, f, padding, flip_filter=False, gain=1):
+    """(y, y_odd): y = upfirdn2d(x, f, padding=padding) and y_odd = y[:, :, 1::2, 1::2] as a dense tensor, from ONE pass over x (round 6,
+    pg_upfirdn2d_with_odd_samples).  The two FIR calls of a `down = 2` ResBlock: `upfirdn2d(x, f, padding=p + 1)` in front of the strided 3x3 convolution
+    (conv2d_resample.py:119-122) and `upfirdn2d(x, f, down=2, padding=p)` in front of the 1x1 skip convolution (:107-110) -- the second is the odd samples of the
+    first.  Inference only (no autograd); float32 GPU tensors; raises NativeNotCovered when the kernel declines."""
+    _init()
+    px0, px1, py0, py1 = _parse_padding(padding)
+    if x.dtype != torch.float32 or not x.is_cuda or f is None or f.ndim != 2 or f.device != x.device or not x.is_contiguous():
+        raise nat.NativeNotCovered('upfirdn2d.filter_with_odd_samples: a contiguous float32 GPU tensor and a 2-D filter')
+    n, c, ih, iw = x.shape
+    fh, fw = f.shape
+    ow, oh = iw + px0 + px1 - fw + 1, ih + py0 + py1 - fh + 1
+    if ow < 3 or oh < 3 or n == 0 or c == 0:
+        raise nat.NativeNotCovered('upfirdn2d.filter_with_odd_samples: empty output')
+    y = torch.empty([n, c, oh, ow], dtype=x.dtype, device=x.device)
+    y_odd = torch.empty([n, c, (oh - 1) // 2, (ow - 1) // 2], dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        st = _plugin.lib.pg_upfirdn2d_with_odd_samples(nat.ptr(x), nat.ptr(f), nat.ptr(y), nat.ptr(y_odd), nat.PG_DTYPE[x.dtype], n, c, ih, iw, nat.i64arr(x.stride()),
+                                                       fh, fw, nat.i64arr(f.stride()), oh, ow, nat.i64arr(y.stride()), px0, py0, int(bool(flip_filter)), float(gain),
+                                                       nat.stream_of(x))
+    if st == -2:
+        raise nat.NativeNotCovered('pg_upfirdn2d_with_odd_samples declined the call')
+    nat.check(st, 'pg_upfirdn2d_with_odd_samples')
+    return y, y_odd
+
 
 def _native_upfirdn2d(x, f, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, gain):
     """Tensor-level twin of the reference plugin entry ``upfirdn2d(...)`` (upfirdn2d.cpp:16-94)."""

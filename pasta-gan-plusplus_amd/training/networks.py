@@ -801,13 +801,15 @@ class _ConvBase(nn.Module):
 class Conv2dLayer(_ConvBase):
     """conv2d_resample -> bias_act (networks.py:170-179); `residual` (private) is added to the result."""
 
-    def forward(self, x, gain=1, residual=None, x2=None):
-        """`x2` (private): a second input whose channels follow x's -- `layer(torch.cat([x, x2], 1))` without the copy."""
+    def forward(self, x, gain=1, residual=None, x2=None, _filtered=None):
+        """`x2` (private): a second input whose channels follow x's -- `layer(torch.cat([x, x2], 1))` without the copy.
+        `_filtered` (private, inference route of a down = 2 layer): the FIR pass over x the caller has already made (ResBlock: one pass for both of its
+        down = 2 layers) -- the full-resolution result for a 3x3 layer, its odd samples for a 1x1 layer."""
         act_gain = self.act_gain * gain
         act_clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
         cout, _, k, _ = self.weight.shape
         try:
-            y = self._forward_fused(x, act_gain, act_clamp, residual, x2)
+            y = self._forward_fused(x, act_gain, act_clamp, residual, x2, _filtered)
             if y is not None:
                 return y
         except nat.NativeNotCovered:           # a valid request the kernels decline (size / geometry): compose it from the ops
@@ -823,7 +825,7 @@ class Conv2dLayer(_ConvBase):
                                             flip_weight=(self.up == 1), _epilogue=dict(bias=b, act=self.activation, gain=act_gain, clamp=act_clamp))
         return x if residual is None else residual.add_(x) if not _needs_graph(residual, x) else residual + x
 
-    def _forward_fused(self, x, act_gain, act_clamp, residual, x2):
+    def _forward_fused(self, x, act_gain, act_clamp, residual, x2, filtered=None):
         """Inference route: one launch of the MFMA convolution with bias / activation / gain / clamp / residual in its epilogue
         (after the FIR pass for down=2); None when this layer or these tensors do not qualify."""
         cout, _, k, _ = self.weight.shape
@@ -847,9 +849,9 @@ class Conv2dLayer(_ConvBase):
         p = self.padding
         pads = [p + (fw - self.down + 1) // 2, p + (fw - self.down) // 2, p + (fh - self.down + 1) // 2, p + (fh - self.down) // 2]
         if k == 1:
-            x = upfirdn2d.upfirdn2d(x, self.resample_filter, down=self.down, padding=pads)
+            x = filtered if filtered is not None else upfirdn2d.upfirdn2d(x, self.resample_filter, down=self.down, padding=pads)
             return conv2d_mfma.conv2d_forward(x, self._packed(False), cout, 1, 1, **ep)
-        x = upfirdn2d.upfirdn2d(x, self.resample_filter, padding=pads)
+        x = filtered if filtered is not None else upfirdn2d.upfirdn2d(x, self.resample_filter, padding=pads)
         return conv2d_mfma.conv2d_forward(x, self._packed(False), cout, k, k, stride=self.down, **ep)
 
 
@@ -864,8 +866,22 @@ class ResBlock(nn.Module):
         self.skip = Conv2dLayer(in_channels, out_channels, kernel_size=1, bias=False, up=up, down=down, **kw)
 
     def forward(self, x):
-        y = self.skip(x, gain=SQRT_HALF)
-        x = self.conv0(x)
+        full = odd = None
+        c0, sk = self.conv0, self.skip
+        if (c0.down == 2 and sk.down == 2 and c0.up == 1 and sk.up == 1 and int(c0.weight.shape[2]) == 3 and int(sk.weight.shape[2]) == 1 and _fast_ok(x, c0.weight, sk.weight)
+                and c0._fast_geometry() and sk._fast_geometry() and x.is_contiguous() and os.environ.get('PG_FIR_SHARED', '1') != '0'):
+            # inference route, down = 2: both layers start with a FIR pass over x -- padding 2 in front of the strided 3x3 convolution, padding 1 and every second
+            # sample in front of the 1x1 skip convolution (conv2d_resample.py:119-122, 107-110) -- and the second is the odd rows / columns of the first: one pass
+            # writes both (round 6, pg_upfirdn2d_with_odd_samples; bit-identical)
+            fw, fh = upfirdn2d._get_filter_size(self.resample_filter)
+            p = c0.padding
+            if fw == fh and fw % 2 == 0 and sk.padding == 0:
+                try:
+                    full, odd = upfirdn2d.filter_with_odd_samples(x, self.resample_filter, padding=[p + (fw - 1) // 2, p + (fw - 2) // 2, p + (fh - 1) // 2, p + (fh - 2) // 2])
+                except nat.NativeNotCovered:
+                    full = odd = None
+        y = self.skip(x, gain=SQRT_HALF, _filtered=odd)
+        x = self.conv0(x, _filtered=full)
         return self.conv1(x, gain=SQRT_HALF, residual=y)      # y + conv1(x), the add folded into conv1's epilogue
 
 

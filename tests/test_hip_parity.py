@@ -2362,6 +2362,35 @@ def test_stem7_conv_on_the_bf16_pipe_is_float32_class(n, cout, h, w, act, clamp)
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('n,c,h,w', [(2, 5, 64, 64), (1, 3, 37, 50), (1, 64, 512, 512), (2, 2, 4, 6)])
+def test_fir_pass_shared_by_the_two_down2_layers_of_a_res_block(n, c, h, w, monkeypatch):
+    """pg_upfirdn2d_with_odd_samples (round 6): the FIR pass in front of a strided 3x3 convolution (padding p + 1, conv2d_resample.py:119-122) also writes its odd
+    rows / columns densely -- bit for bit what the FIR pass in front of the 1x1 skip convolution computes (down = 2, padding p: conv2d_resample.py:107-110).  Then a
+    whole ResBlock(down = 2) with and without the shared pass: identical outputs."""
+    from torch_utils.ops import upfirdn2d
+    from training import networks as PN
+    from training.synthetic import fill_module_ as fill
+    gen = torch.Generator().manual_seed(71)
+    x = torch.randn([n, c, h, w], generator=gen).to(DEV)
+    f = upfirdn2d.setup_filter([1, 3, 3, 1]).to(DEV)
+    y, y_odd = upfirdn2d.filter_with_odd_samples(x, f, padding=[2, 2, 2, 2])
+    assert torch.equal(y, upfirdn2d.upfirdn2d(x, f, padding=[2, 2, 2, 2]))
+    assert torch.equal(y_odd, upfirdn2d.upfirdn2d(x, f, down=2, padding=[1, 1, 1, 1]))
+    if c >= 3 and h >= 8:
+        blk = fill(PN.ResBlock(c, 2 * c, kernel_size=4, activation='relu', down=2), 'fs.res.').to(DEV).eval()
+        calls = []
+        real = upfirdn2d.filter_with_odd_samples
+        monkeypatch.setattr(upfirdn2d, 'filter_with_odd_samples', lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+        with torch.no_grad():
+            a = blk(x)
+            assert calls == [1]
+            monkeypatch.setenv('PG_FIR_SHARED', '0')
+            b = blk(x)
+            assert calls == [1]
+        assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
 def test_spade_res_block_gathers_its_statistics_in_the_convolution_tails(monkeypatch):
     """A SPADE res-block at the widths of the generator (128 channels, 64^2: the F(4x4) kernel's wide form, whichever `conv2d_mfma.F4_WIDE` names) makes NO
     separate instance-norm statistics pass: the three norm blocks' statistics come out of the tails of the convolutions that produce their inputs (round 4).

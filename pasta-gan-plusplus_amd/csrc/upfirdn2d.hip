@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void upfirdn2d_tiled(Params p, int tilesX, int
             }
             yp[(int64_t)oy * p.outW + ox] = (T)v;
             if constexpr (sizeof(T) == 4 && UPX == 1 && UPY == 1 && DNX == 1 && DNY == 1) {
-                if (p.y2 && (oy & 1) && (ox & 1)) p.y2[(plane * p.y2H + (oy >> 1)) * p.y2W + (ox >> 1)] = (float)v;
+                if (p.y2 && (oy & 1) && (ox & 1) && (oy >> 1) < p.y2H && (ox >> 1) < p.y2W) p.y2[(plane * p.y2H + (oy >> 1)) * p.y2W + (ox >> 1)] = (float)v;      // (an even extent has one odd sample more than the decimated pass keeps)
             }
         }
     }

@@ -2362,7 +2362,7 @@ def test_stem7_conv_on_the_bf16_pipe_is_float32_class(n, cout, h, w, act, clamp)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('n,c,h,w', [(2, 5, 64, 64), (1, 3, 37, 50), (1, 64, 512, 512), (2, 2, 4, 6)])
+@pytest.mark.parametrize('n,c,h,w', [(2, 5, 64, 64), (1, 3, 37, 50), (3, 4, 37, 51), (1, 64, 512, 512), (2, 2, 4, 6)])
 def test_fir_pass_shared_by_the_two_down2_layers_of_a_res_block(n, c, h, w, monkeypatch):
     """pg_upfirdn2d_with_odd_samples (round 6): the FIR pass in front of a strided 3x3 convolution (padding p + 1, conv2d_resample.py:119-122) also writes its odd
     rows / columns densely -- bit for bit what the FIR pass in front of the 1x1 skip convolution computes (down = 2, padding p: conv2d_resample.py:107-110).  Then a
@@ -2376,6 +2376,9 @@ def test_fir_pass_shared_by_the_two_down2_layers_of_a_res_block(n, c, h, w, monk
     y, y_odd = upfirdn2d.filter_with_odd_samples(x, f, padding=[2, 2, 2, 2])
     assert torch.equal(y, upfirdn2d.upfirdn2d(x, f, padding=[2, 2, 2, 2]))
     assert torch.equal(y_odd, upfirdn2d.upfirdn2d(x, f, down=2, padding=[1, 1, 1, 1]))
+    for _ in range(3):                                 # (odd input extents: the full pass then has one odd row / column more than the decimated pass keeps -- it must
+        y2, y2_odd = upfirdn2d.filter_with_odd_samples(x, f, padding=[2, 2, 2, 2])      #  not be written past the end of a plane: round 6's first build raced there)
+        assert torch.equal(y2, y) and torch.equal(y2_odd, y_odd)
     if c >= 3 and h >= 8:
         blk = fill(PN.ResBlock(c, 2 * c, kernel_size=4, activation='relu', down=2), 'fs.res.').to(DEV).eval()
         calls = []

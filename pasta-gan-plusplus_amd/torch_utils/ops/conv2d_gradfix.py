@@ -157,6 +157,8 @@ def conv_transpose2d(input, weight, bias=None, stride=1, padding=0, output_paddi
                                                 output_padding=output_padding, groups=groups, dilation=dilation)
 
 
+UP2_TRANSPOSED = os.environ.get('PG_UP2_TRANSPOSED', '1') != '0'      # A/B: 0 = the transposed 3x3 stride-2 convolution as four phase launches
+
 _pack_cache = {}      # (storage ptr, version, shape, strides, winograd, flip, transpose) -> (weakref to the source, packed weights)
 _PACK_CACHE_MAX_BYTES = 1 << 30
 
@@ -211,8 +213,15 @@ class _Conv2dMfma(torch.autograd.Function):
             assert ep is None
             cout = int(weight.shape[1])
             out_hw = ((h - 1) * stride - 2 * padding[0] + kh + output_padding[0], (w - 1) * stride - 2 * padding[1] + kw + output_padding[1])
-            phases = conv2d_mfma.pack_transposed(weight, stride, padding, (h, w), out_hw)
-            y = conv2d_mfma.conv_transpose2d_forward(x, phases, cout, out_hw, stride=stride, bias=bias)
+            if ((kh, kw, stride) == (3, 3, 2) and tuple(padding) == (0, 0) and tuple(output_padding) == (0, 0) and bias is None and UP2_TRANSPOSED
+                    and (n * cout * out_hw[0] * ((out_hw[1] + 3) // 4 * 4)) * 4 < 2 ** 31):
+                # the stride-2 transposed 3x3 convolution without padding -- the input gradient of every `down = 2` 3x3 layer (FIR, then a strided convolution with
+                # padding 0) -- as ONE launch of the four-parity kernel of the up = 2 layers (csrc/conv2d_up2.h, fp32 MFMA) instead of four gather-form phase
+                # launches with a weight pack each (late round 6).  The IOHW weight packs as the kernel's OIHW operand without a copy (transpose_oi).
+                y = conv2d_mfma.conv_up2_forward(x, dict(main=_packed(weight, 0, flip=False, transpose_oi=True)), cout, x3=False)
+            else:
+                phases = conv2d_mfma.pack_transposed(weight, stride, padding, (h, w), out_hw)
+                y = conv2d_mfma.conv_transpose2d_forward(x, phases, cout, out_hw, stride=stride, bias=bias)
         ctx.save_for_backward(x, weight, y if ep is not None else None)
         ctx.cfg = (stride, padding, transposed, output_padding, bias is not None, ep)
         return y

@@ -159,6 +159,9 @@ def conv_transpose2d(input, weight, bias=None, stride=1, padding=0, output_paddi
 
 UP2_TRANSPOSED = os.environ.get('PG_UP2_TRANSPOSED', '1') != '0'      # A/B: 0 = the transposed 3x3 stride-2 convolution as four phase launches
 
+UP2_TRANSPOSED_X3 = os.environ.get('PG_UP2_TRANSPOSED_X3', '1') != '0'
+_x3_of_pack = {}      # id(float32 pack) -> (weakref to it, its bf16 plane slabs)
+
 _pack_cache = {}      # (storage ptr, version, shape, strides, winograd, flip, transpose) -> (weakref to the source, packed weights)
 _PACK_CACHE_MAX_BYTES = 1 << 30
 
@@ -218,7 +221,16 @@ class _Conv2dMfma(torch.autograd.Function):
                 # the stride-2 transposed 3x3 convolution without padding -- the input gradient of every `down = 2` 3x3 layer (FIR, then a strided convolution with
                 # padding 0) -- as ONE launch of the four-parity kernel of the up = 2 layers (csrc/conv2d_up2.h, fp32 MFMA) instead of four gather-form phase
                 # launches with a weight pack each (late round 6).  The IOHW weight packs as the kernel's OIHW operand without a copy (transpose_oi).
-                y = conv2d_mfma.conv_up2_forward(x, dict(main=_packed(weight, 0, flip=False, transpose_oi=True)), cout, x3=False)
+                main = _packed(weight, 0, flip=False, transpose_oi=True)
+                packs = dict(main=main)
+                if UP2_TRANSPOSED_X3 and cin % 16 == 0 and cin >= 32:
+                    # ... with its main tiles on the bf16 pipe (csrc/conv2d_up2x3.h, float32-class): the split planes of the same pack, kept while the pack lives
+                    hit = _x3_of_pack.get(id(main))
+                    if hit is None or hit[0]() is not main:
+                        x3 = conv2d_mfma.pack_s2x3_planes(main, cout, cin)
+                        _x3_of_pack[id(main)] = hit = (weakref.ref(main, lambda r, k=id(main): _x3_of_pack.pop(k, None)), x3)
+                    packs['x3'] = hit[1]
+                y = conv2d_mfma.conv_up2_forward(x, packs, cout, x3=None if 'x3' in packs else False)
             else:
                 phases = conv2d_mfma.pack_transposed(weight, stride, padding, (h, w), out_hw)
                 y = conv2d_mfma.conv_transpose2d_forward(x, phases, cout, out_hw, stride=stride, bias=bias)

@@ -601,6 +601,15 @@ def pack_up2(weight, flip=False, x3=True):
     return packs
 
 
+def pack_s2x3_planes(packed32, cout, cin):
+    """The bf16 plane slabs of `conv_up2_forward`'s bf16-pipe form from the float32 pack of a 3x3 kernel (`pack_weight`): what `pack_up2` stores under 'x3'."""
+    lib = _init().lib
+    x3 = torch.empty([lib.pg_conv2d_up2x3_packed_size(cout, cin)], dtype=torch.uint8, device=packed32.device)
+    with torch.cuda.device(packed32.device):
+        nat.check(lib.pg_conv2d_up2x3_pack_weight(nat.ptr(packed32), nat.ptr(x3), cout, cin, nat.stream_of(packed32)), 'pg_conv2d_up2x3_pack_weight')
+    return x3
+
+
 # PG_UP2_X3=0: the fp32-MFMA kernel everywhere (A/B runs).  Default: layers whose input is wider than 16 pixels (a multiple of 4) with Cin % 16 == 0 multiply on the bf16 pipe.
 UP2_X3 = os.environ.get('PG_UP2_X3', '1') != '0'
 
